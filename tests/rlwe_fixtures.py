@@ -1,0 +1,96 @@
+"""Host-side RLWE key material for the semantic (decrypt-and-check) tests.
+
+Restates, with OUR OWN seeded PRNG (the reference's blake2b-keyed sampler lives
+in an un-vendored dependency), the key shapes of:
+  * secret key: ternary, NTT + Montgomery         core/rlwe/keygenerator.go:58-70
+  * zero-encryption in QP                         core/rlwe/encryptor.go:406-435
+  * evaluation key skIn -> skOut                  core/rlwe/keygenerator.go:287-330
+  * gadget P * skIn on the digit's Q-limbs        core/rlwe/gadgetciphertext.go:172-241
+All arithmetic goes through the CPU oracle (test infrastructure).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import oracle as O
+from tests.helpers import prod
+
+
+def small_to_rns(vals, moduli):
+    """signed small integers -> [limbs, N] residues."""
+    out = np.empty((len(moduli), len(vals)), dtype=np.uint64)
+    v = np.asarray(vals, dtype=np.int64)
+    for i, q in enumerate(moduli):
+        out[i] = np.where(v < 0, np.uint64(int(q)) - (-v).astype(np.uint64), v.astype(np.uint64))
+    return out
+
+
+class SecretKey:
+    def __init__(self, rng, ringQ: O.Ring, ringP: O.Ring, vals=None):
+        N = ringQ.N
+        self.vals = rng.integers(-1, 2, size=N) if vals is None else np.asarray(vals)
+        self.Q = ringQ.unop("MForm", ringQ.NTT(small_to_rns(self.vals, ringQ.moduli)))
+        self.P = ringP.unop("MForm", ringP.NTT(small_to_rns(self.vals, ringP.moduli)))
+
+
+def automorphism_secret(rng, ringQ, ringP, sk: SecretKey, galel: int) -> SecretKey:
+    """pi_galel(sk) in the coefficient domain (ring/automorphism.go:113)."""
+    N = ringQ.N
+    out = np.zeros(N, dtype=np.int64)
+    for i in range(N):
+        raw = i * galel
+        idx = raw & (N - 1)
+        sign = -1 if (raw >> (N.bit_length() - 1)) & 1 else 1
+        out[idx] = sign * sk.vals[i]
+    return SecretKey(rng, ringQ, ringP, vals=out)
+
+
+def gen_evaluation_key(rng, ringQ: O.Ring, ringP: O.Ring, sk_in_Q: np.ndarray, sk_out: SecretKey,
+                       sigma: float = 3.2) -> O.EvaluationKey:
+    """evk[d][k] (k=0: b, k=1: a), NTT + Montgomery, at max levels."""
+    N = ringQ.N
+    LQ, LP = len(ringQ.moduli), len(ringP.moduli)
+    levelQ, levelP = LQ - 1, LP - 1
+    beta = O.BaseRNSDecompositionVectorSize(levelQ, levelP)
+    P = prod(ringP.moduli)
+    kq = np.zeros((beta, 2, LQ, N), dtype=np.uint64)
+    kp = np.zeros((beta, 2, LP, N), dtype=np.uint64)
+    p_times_skin = ringQ.MulScalarBigint(sk_in_Q, P)
+    for d in range(beta):
+        e = np.clip(np.rint(rng.normal(0.0, sigma, size=N)), -19, 19).astype(np.int64)
+        aQ = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringQ.moduli])
+        aP = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringP.moduli])
+        bQ = ringQ.unop("MForm", ringQ.NTT(small_to_rns(e, ringQ.moduli)))
+        bP = ringP.unop("MForm", ringP.NTT(small_to_rns(e, ringP.moduli)))
+        bQ = ringQ.binop("MulCoeffsMontgomeryThenSub", aQ, sk_out.Q, bQ)
+        bP = ringP.binop("MulCoeffsMontgomeryThenSub", aP, sk_out.P, bP)
+        lo, hi = d * LP, min((d + 1) * LP, LQ)
+        tmp = ringQ.binop("Add", bQ, p_times_skin)
+        bQ[lo:hi] = tmp[lo:hi]
+        kq[d, 0], kq[d, 1], kp[d, 0], kp[d, 1] = bQ, aQ, bP, aP
+    return O.EvaluationKey(kq, kp)
+
+
+def centered(ring: O.Ring, poly_coeff: np.ndarray, limb: int = 0) -> np.ndarray:
+    q = int(ring.moduli[limb])
+    v = poly_coeff[limb].astype(object)
+    return np.array([int(x) - q if int(x) > q // 2 else int(x) for x in v], dtype=object)
+
+
+def phase(ringQ: O.Ring, ct: np.ndarray, skQ: np.ndarray) -> np.ndarray:
+    """Decrypt degree-d NTT-domain ct by Horner (core/rlwe/decryptor.go:49-93); returns NTT-domain phase."""
+    level = ct.shape[1] - 1
+    s = skQ[: level + 1]
+    acc = ct[-1].copy()
+    sub = O.Ring(ringQ.N, ringQ.moduli[: level + 1])
+    for i in range(ct.shape[0] - 2, -1, -1):
+        acc = sub.binop("Add", sub.binop("MulCoeffsMontgomery", acc, s), ct[i])
+    return acc
+
+
+def noise_log2(ringQ: O.Ring, ntt_poly: np.ndarray) -> float:
+    level = ntt_poly.shape[0] - 1
+    sub = O.Ring(ringQ.N, ringQ.moduli[: level + 1])
+    c = centered(sub, sub.INTT(ntt_poly), 0)
+    m = max(abs(int(x)) for x in c)
+    return float(np.log2(m)) if m > 0 else 0.0
