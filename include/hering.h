@@ -1,0 +1,248 @@
+/*
+ * hering.h -- C ABI of libhering.so: MI355X (gfx950) ring-arithmetic backend for
+ * Lattigo-style RNS homomorphic encryption.
+ *
+ * This is the drop-in boundary.  The reference (tuneinsight/lattigo v6.2.0) is
+ * pure Go and has no FFI; these entry points are what a cgo binding of its
+ * `ring` / `core/rlwe` operator layer binds (INTEGRATION.md shows the stub).
+ * Every entry cites the reference method it replaces (paths relative to the
+ * reference tree).
+ *
+ * Conventions
+ *  - plain C: opaque uint64 handles, raw pointers + sizes, no C++/torch types;
+ *  - every function returns 0 on success, <0 on error (HE_E*); he_last_error()
+ *    returns a thread-local message (the Go shim wraps it into an `error`);
+ *    the library never aborts the process;
+ *  - host buffers are borrowed for the duration of the call only (cgo's
+ *    no-retained-pointer rule);
+ *  - polynomials live in device HBM: a poly handle is [batch][limbs][N] uint64,
+ *    limb-major like ring.Poly.Coeffs (ring/poly.go:13-15); `level` = "limbs
+ *    0..level in use" as in Ring.AtLevel (ring/ring.go:186);
+ *  - all work of a context is enqueued on its HIP stream; results become
+ *    visible to the host after he_ctx_sync / he_poly_download;
+ *  - thread-safe: handles may be used from any OS thread (per-call
+ *    hipSetDevice); concurrent calls on ONE context serialize on its stream.
+ *  - outputs are caller-allocated and come last; in-place aliasing is allowed
+ *    exactly where the reference allows it (coefficient-wise ops, NTT), not for
+ *    automorphisms (ring/automorphism.go:37).
+ */
+#ifndef HERING_H
+#define HERING_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t he_handle;
+
+enum {
+    HE_OK = 0,
+    HE_EINVAL = -1,   /* bad argument / shape mismatch                         */
+    HE_EHANDLE = -2,  /* unknown or wrong-type handle                          */
+    HE_EDEVICE = -3,  /* HIP runtime error                                     */
+    HE_EPARAM = -4,   /* invalid ring parameters (not prime, not 1 mod 2N ...) */
+    HE_ENOMEM = -5
+};
+
+const char *he_last_error(void);
+const char *he_version(void);
+
+/* ---- context ---------------------------------------------------------------- */
+int he_ctx_create(int device_id, he_handle *ctx);
+int he_ctx_destroy(he_handle ctx);
+int he_ctx_sync(he_handle ctx);
+/* HIP-event timing on the context's stream (bench.py's timed region). */
+int he_timer_start(he_handle ctx);
+int he_timer_stop(he_handle ctx, float *elapsed_ms);
+/* device facts for reports: out[0]=CU count, out[1]=LDS bytes/CU, out[2]=clock kHz, out[3]=total HBM bytes */
+int he_device_info(he_handle ctx, uint64_t out[4]);
+
+/* ---- ring: ring.NewRing (ring/ring.go:207), SubRing tables (ring/subring.go:99-159),
+ *      RescaleConstants (ring/ring.go:329).  Standard (negacyclic) type, NthRoot = 2N. */
+int he_ring_create(he_handle ctx, int logN, const uint64_t *moduli, int n_moduli, he_handle *ring);
+int he_ring_destroy(he_handle ring);
+/* which = 0: Modulus, 1: MRedConstant, 2: BRedConstant[0], 3: BRedConstant[1], 4: NInv, 5: PrimitiveRoot */
+int he_ring_constant(he_handle ring, int limb, int which, uint64_t *out);
+/* download RootsForward (dir=0) / RootsBackward (dir=1) of one limb: N words */
+int he_ring_roots(he_handle ring, int limb, int dir, uint64_t *out);
+
+/* ---- polynomials: ring.Poly (ring/poly.go:13) as device-resident batches -------- */
+int he_poly_alloc(he_handle ring, int n_limbs, int batch, he_handle *poly);
+int he_poly_free(he_handle poly);
+int he_poly_shape(he_handle poly, int *n_limbs, int *batch, int *N);
+/* whole-batch transfers of the contiguous [batch][limbs][N] image */
+int he_poly_upload(he_handle poly, const uint64_t *src, size_t n_words);
+int he_poly_download(he_handle poly, uint64_t *dst, size_t n_words);
+/* one limb of one batch entry (what a [][]uint64 row maps to) */
+int he_poly_upload_limb(he_handle poly, int b, int limb, const uint64_t *src);
+int he_poly_download_limb(he_handle poly, int b, int limb, uint64_t *dst);
+int he_poly_copy(he_handle dst, he_handle src, int level);      /* Poly.CopyLvl */
+int he_poly_zero(he_handle poly);
+
+/* ---- NTT: Ring.NTT / NTTLazy / INTT / INTTLazy (ring/ntt.go:127-152) ------------- */
+int he_ntt(he_handle ring, int level, he_handle p1, he_handle p2);
+int he_ntt_lazy(he_handle ring, int level, he_handle p1, he_handle p2);   /* returns values in [0, 2q) */
+int he_intt(he_handle ring, int level, he_handle p1, he_handle p2);
+int he_intt_lazy(he_handle ring, int level, he_handle p1, he_handle p2);
+
+/* ---- coefficient-wise ops (ring/operations.go:11-377 over ring/vec_ops.go) --------
+ * The numeric codes are the op tables of the reference: one entry per method.    */
+enum he_binop {
+    HE_ADD = 0,                               /* Ring.Add                          operations.go:11  */
+    HE_ADD_LAZY,                              /* Ring.AddLazy                      :18  */
+    HE_SUB,                                   /* Ring.Sub                          :25  */
+    HE_SUB_LAZY,                              /* Ring.SubLazy                      :32  */
+    HE_MUL_COEFFS_BARRETT,                    /* Ring.MulCoeffsBarrett             :60  */
+    HE_MUL_COEFFS_BARRETT_LAZY,               /* Ring.MulCoeffsBarrettLazy         :67  */
+    HE_MUL_COEFFS_BARRETT_THEN_ADD,           /* Ring.MulCoeffsBarrettThenAdd      :74  */
+    HE_MUL_COEFFS_BARRETT_THEN_ADD_LAZY,      /* Ring.MulCoeffsBarrettThenAddLazy  :81  */
+    HE_MUL_COEFFS_MONTGOMERY,                 /* Ring.MulCoeffsMontgomery          :88  */
+    HE_MUL_COEFFS_MONTGOMERY_LAZY,            /* Ring.MulCoeffsMontgomeryLazy      :95  */
+    HE_MUL_COEFFS_MONTGOMERY_LAZY_THEN_NEG,   /* Ring.MulCoeffsMontgomeryLazyThenNeg :102 */
+    HE_MUL_COEFFS_MONTGOMERY_THEN_ADD,        /* Ring.MulCoeffsMontgomeryThenAdd   :109 */
+    HE_MUL_COEFFS_MONTGOMERY_THEN_ADD_LAZY,   /* Ring.MulCoeffsMontgomeryThenAddLazy :116 */
+    HE_MUL_COEFFS_MONTGOMERY_LAZY_THEN_ADD_LAZY, /* Ring.MulCoeffsMontgomeryLazyThenAddLazy :123 */
+    HE_MUL_COEFFS_MONTGOMERY_THEN_SUB,        /* Ring.MulCoeffsMontgomeryThenSub   :130 */
+    HE_MUL_COEFFS_MONTGOMERY_THEN_SUB_LAZY,   /* Ring.MulCoeffsMontgomeryThenSubLazy :137 */
+    HE_MUL_COEFFS_MONTGOMERY_LAZY_THEN_SUB_LAZY, /* Ring.MulCoeffsMontgomeryLazyThenSubLazy :144 */
+    HE_BINOP_COUNT
+};
+enum he_unop {
+    HE_NEG = 0,       /* Ring.Neg        operations.go:39  */
+    HE_REDUCE,        /* Ring.Reduce     :46  */
+    HE_REDUCE_LAZY,   /* Ring.ReduceLazy :53  */
+    HE_MFORM,         /* Ring.MForm      :285 */
+    HE_MFORM_LAZY,    /* Ring.MFormLazy  :292 */
+    HE_IMFORM,        /* Ring.IMForm     :299 */
+    HE_UNOP_COUNT
+};
+enum he_scalarop {
+    HE_ADD_SCALAR = 0,        /* Ring.AddScalar        operations.go:151 */
+    HE_SUB_SCALAR,            /* Ring.SubScalar        :186 */
+    HE_MUL_SCALAR,            /* Ring.MulScalar        :201 */
+    HE_MUL_SCALAR_THEN_ADD,   /* Ring.MulScalarThenAdd :208 */
+    HE_MUL_SCALAR_THEN_SUB,   /* Ring.MulScalarThenSub :223 */
+    HE_SCALAROP_COUNT
+};
+/* p3 = op(p1, p2 [, p3]) on limbs 0..level of every batch entry */
+int he_binop(he_handle ring, int level, int op, he_handle p1, he_handle p2, he_handle p3);
+int he_unop(he_handle ring, int level, int op, he_handle p1, he_handle p2);
+int he_scalarop(he_handle ring, int level, int op, he_handle p1, uint64_t scalar, he_handle p2);
+/* Ring.MulRNSScalarMontgomery (operations.go:216): scalar[i] per limb, Montgomery form */
+int he_mul_rns_scalar_montgomery(he_handle ring, int level, he_handle p1, const uint64_t *scalar, he_handle p2);
+/* Ring.{Add,Sub,Mul}ScalarBigint (operations.go:158,193,231): little-endian 64-bit words */
+int he_add_scalar_bigint(he_handle ring, int level, he_handle p1, const uint64_t *words, int n_words, he_handle p2);
+int he_sub_scalar_bigint(he_handle ring, int level, he_handle p1, const uint64_t *words, int n_words, he_handle p2);
+int he_mul_scalar_bigint(he_handle ring, int level, he_handle p1, const uint64_t *words, int n_words, he_handle p2);
+
+/* named wrappers, one per reference method that the key-switch path calls */
+int he_add(he_handle ring, int level, he_handle p1, he_handle p2, he_handle p3);
+int he_sub(he_handle ring, int level, he_handle p1, he_handle p2, he_handle p3);
+int he_neg(he_handle ring, int level, he_handle p1, he_handle p2);
+int he_reduce(he_handle ring, int level, he_handle p1, he_handle p2);
+int he_mform(he_handle ring, int level, he_handle p1, he_handle p2);
+int he_imform(he_handle ring, int level, he_handle p1, he_handle p2);
+int he_mul_coeffs_montgomery(he_handle ring, int level, he_handle p1, he_handle p2, he_handle p3);
+int he_mul_coeffs_montgomery_then_add(he_handle ring, int level, he_handle p1, he_handle p2, he_handle p3);
+int he_mul_coeffs_montgomery_lazy(he_handle ring, int level, he_handle p1, he_handle p2, he_handle p3);
+int he_mul_coeffs_montgomery_lazy_then_add_lazy(he_handle ring, int level, he_handle p1, he_handle p2, he_handle p3);
+
+/* ---- rescale: ring/scaling.go --------------------------------------------------- */
+/* p1 receives limbs 0..level-nb.  In-place (p0 == p1) is allowed as in the reference. */
+int he_div_round_by_last_modulus_ntt(he_handle ring, int level, he_handle p0, he_handle p1);              /* :101 */
+int he_div_round_by_last_modulus(he_handle ring, int level, he_handle p0, he_handle p1);                  /* :126 */
+int he_div_floor_by_last_modulus_ntt(he_handle ring, int level, he_handle p0, he_handle p1);              /* :6   */
+int he_div_floor_by_last_modulus(he_handle ring, int level, he_handle p0, he_handle p1);                  /* :26  */
+int he_div_round_by_last_modulus_many_ntt(he_handle ring, int level, int nb, he_handle p0, he_handle p1); /* :148 */
+int he_div_round_by_last_modulus_many(he_handle ring, int level, int nb, he_handle p0, he_handle p1);     /* :177 */
+int he_div_floor_by_last_modulus_many_ntt(he_handle ring, int level, int nb, he_handle p0, he_handle p1); /* :37  */
+int he_div_floor_by_last_modulus_many(he_handle ring, int level, int nb, he_handle p0, he_handle p1);     /* :65  */
+
+/* ---- automorphism: ring/automorphism.go ------------------------------------------ */
+/* AutomorphismNTTIndex (:12): builds and keeps the index table on the device */
+int he_automorphism_index_create(he_handle ring, uint64_t gal_el, he_handle *index);
+int he_automorphism_index_destroy(he_handle index);
+int he_automorphism_index_download(he_handle index, uint64_t *dst);
+int he_automorphism_ntt_with_index(he_handle ring, int level, he_handle pin, he_handle index, he_handle pout);               /* :50 */
+int he_automorphism_ntt_with_index_then_add_lazy(he_handle ring, int level, he_handle pin, he_handle index, he_handle pout); /* :82 */
+int he_automorphism(he_handle ring, int level, he_handle pin, uint64_t gal_el, he_handle pout);                             /* :113 */
+
+/* ---- basis extension: ring.BasisExtender (ring/basis_extension.go:14) -------------- */
+int he_basis_extender_create(he_handle ringQ, he_handle ringP, he_handle *be);
+int he_basis_extender_destroy(he_handle be);
+int he_modup_q_to_p(he_handle be, int levelQ, int levelP, he_handle polQ, he_handle polP);                          /* :177 */
+int he_modup_p_to_q(he_handle be, int levelP, int levelQ, he_handle polP, he_handle polQ);                          /* :195 */
+int he_moddown_qp_to_q(he_handle be, int levelQ, int levelP, he_handle p1Q, he_handle p1P, he_handle p2Q);          /* :215 */
+int he_moddown_qp_to_q_ntt(he_handle be, int levelQ, int levelP, he_handle p1Q, he_handle p1P, he_handle p2Q);      /* :235 */
+int he_moddown_qp_to_p(he_handle be, int levelQ, int levelP, he_handle p1Q, he_handle p1P, he_handle p2P);          /* :262 */
+
+/* ---- rlwe.Evaluator hot path (core/rlwe/evaluator*.go), the EvaluatorProvider
+ *      operator interface of core/rlwe/rlwe.go:10-18.  Ciphertext components are
+ *      separate poly handles, as rlwe.Ciphertext.Value []ring.Poly; a QP element
+ *      is a (Q handle, P handle) pair, as ringqp.Poly{Q,P} (ring/ringqp/poly.go:17). */
+int he_evaluator_create(he_handle ringQ, he_handle ringP, he_handle *eval);
+int he_evaluator_destroy(he_handle eval);
+
+/* GadgetCiphertext (core/rlwe/gadgetciphertext.go:19-42), BaseTwoDecomposition = 0.
+ * Host image: q[beta][2][nQk][N], p[beta][2][nPk][N], NTT + Montgomery form.     */
+int he_evk_create(he_handle eval, int beta, int nQk, int nPk, const uint64_t *q, const uint64_t *p, he_handle *evk);
+int he_evk_destroy(he_handle evk);
+
+/* Decomposer.DecomposeAndSplit (ring/basis_extension.go:381): coefficient-domain
+ * p0Q -> digit `digit` extended to p1Q (limbs 0..levelQ except, for multi-limb
+ * digits, the digit's own) and p1P (limbs 0..levelP). */
+int he_decompose_and_split(he_handle eval, int levelQ, int levelP, int nbPi, int digit,
+                           he_handle p0Q, he_handle p1Q, he_handle p1P);
+
+/* BuffDecompQP []ringqp.Poly of DecomposeNTT: an opaque device buffer holding, per
+ * batch entry, beta digits of (Q limbs, P limbs). */
+int he_decomp_create(he_handle eval, int batch, he_handle *decomp);
+int he_decomp_destroy(he_handle decomp);
+int he_decomp_download_limb(he_handle decomp, int b, int digit, int is_p, int limb, uint64_t *dst);
+/* Evaluator.DecomposeNTT (core/rlwe/evaluator_gadget_product.go:459) */
+int he_decompose_ntt(he_handle eval, int levelQ, int levelP, int nbPi, he_handle c2, int c2_is_ntt, he_handle decomp);
+
+/* GadgetProductLazy (:108) -> (c0Q,c0P), (c1Q,c1P): NTT domain, canonical */
+int he_gadget_product_lazy(he_handle eval, int levelQ, he_handle cx, he_handle evk,
+                           he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P);
+/* GadgetProductHoistedLazy (:379) */
+int he_gadget_product_hoisted_lazy(he_handle eval, int levelQ, he_handle decomp, he_handle evk,
+                                   he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P);
+/* Evaluator.ModDown (:39), NTT in / NTT out */
+int he_moddown(he_handle eval, int levelQ, int levelP, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P,
+               he_handle out0, he_handle out1);
+/* GadgetProduct (:16) and GadgetProductHoisted (:348) */
+int he_gadget_product(he_handle eval, int levelQ, he_handle cx, he_handle evk, he_handle out0, he_handle out1);
+int he_gadget_product_hoisted(he_handle eval, int levelQ, he_handle decomp, he_handle evk, he_handle out0, he_handle out1);
+/* Evaluator.Relinearize (core/rlwe/evaluator_evaluationkey.go:117) */
+int he_relinearize(he_handle eval, int level, he_handle in0, he_handle in1, he_handle in2, he_handle rlk,
+                   he_handle out0, he_handle out1);
+/* Evaluator.Automorphism (core/rlwe/evaluator_automorphism.go:13), NTT domain */
+int he_automorphism_ct(he_handle eval, int level, he_handle in0, he_handle in1, uint64_t gal_el, he_handle gk,
+                       he_handle out0, he_handle out1);
+/* Evaluator.AutomorphismHoisted (:60): decomp = DecomposeNTT(in1) */
+int he_automorphism_hoisted(he_handle eval, int level, he_handle in0, he_handle decomp, uint64_t gal_el, he_handle gk,
+                            he_handle out0, he_handle out1);
+
+/* ---- scheme call sites ------------------------------------------------------------ */
+/* CKKS Evaluator.mulRelin (schemes/ckks/evaluator.go:764), degree 1 x degree 1.
+ * rlk = 0 -> no relinearisation: (out0,out1,out2); else (out0,out1), out2 ignored.  */
+int he_ckks_mul_relin(he_handle eval, int level, he_handle a0, he_handle a1, he_handle b0, he_handle b1,
+                      he_handle rlk, he_handle out0, he_handle out1, he_handle out2);
+/* BGV Evaluator.tensorStandard (schemes/bgv/evaluator.go:592), plaintext modulus t */
+int he_bgv_mul_relin(he_handle eval, int level, uint64_t t, he_handle a0, he_handle a1, he_handle b0, he_handle b1,
+                     he_handle rlk, he_handle out0, he_handle out1, he_handle out2);
+/* CKKS / BGV Evaluator.Rescale (ckks :477, bgv :1363) is, per ciphertext component,
+ * he_div_round_by_last_modulus_many_ntt above. */
+
+/* ---- diagnostics (not part of the reference surface) --------------------------------- */
+/* dependent-MRedLazy throughput probe: returns modular multiplies per second */
+int he_probe_modmul(he_handle ctx, int iters, double *mults_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HERING_H */

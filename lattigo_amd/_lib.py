@@ -1,0 +1,111 @@
+"""ctypes binding of libhering.so (include/hering.h).  Fails loudly when the HIP
+extension is missing: there is no Python or CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libhering.so")
+_HDR = os.path.join(os.path.dirname(_HERE), "include", "hering.h")
+
+H = C.c_uint64
+u64p = C.POINTER(C.c_uint64)
+
+
+class HeringError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libhering error {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return _SO
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/hering.h declares (used by the CPU-side export test)."""
+    src = open(_HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(he_[a-z0-9_]+)\s*\(", src)))
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise HeringError(-3, f"{_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _lib = C.CDLL(_SO)
+        _declare(_lib)
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise HeringError(rc, load().he_last_error().decode())
+
+
+def _declare(L):
+    i, sz = C.c_int, C.c_size_t
+    HP = C.POINTER(H)
+    L.he_last_error.restype = C.c_char_p
+    L.he_version.restype = C.c_char_p
+    sig = {
+        "he_ctx_create": [i, HP], "he_ctx_destroy": [H], "he_ctx_sync": [H], "he_timer_start": [H],
+        "he_timer_stop": [H, C.POINTER(C.c_float)], "he_device_info": [H, u64p],
+        "he_ring_create": [H, i, u64p, i, HP], "he_ring_destroy": [H], "he_ring_constant": [H, i, i, u64p],
+        "he_ring_roots": [H, i, i, u64p],
+        "he_poly_alloc": [H, i, i, HP], "he_poly_free": [H],
+        "he_poly_shape": [H, C.POINTER(i), C.POINTER(i), C.POINTER(i)],
+        "he_poly_upload": [H, u64p, sz], "he_poly_download": [H, u64p, sz],
+        "he_poly_upload_limb": [H, i, i, u64p], "he_poly_download_limb": [H, i, i, u64p],
+        "he_poly_copy": [H, H, i], "he_poly_zero": [H],
+        "he_ntt": [H, i, H, H], "he_ntt_lazy": [H, i, H, H], "he_intt": [H, i, H, H], "he_intt_lazy": [H, i, H, H],
+        "he_binop": [H, i, i, H, H, H], "he_unop": [H, i, i, H, H], "he_scalarop": [H, i, i, H, C.c_uint64, H],
+        "he_mul_rns_scalar_montgomery": [H, i, H, u64p, H],
+        "he_add_scalar_bigint": [H, i, H, u64p, i, H], "he_sub_scalar_bigint": [H, i, H, u64p, i, H],
+        "he_mul_scalar_bigint": [H, i, H, u64p, i, H],
+        "he_add": [H, i, H, H, H], "he_sub": [H, i, H, H, H], "he_neg": [H, i, H, H], "he_reduce": [H, i, H, H],
+        "he_mform": [H, i, H, H], "he_imform": [H, i, H, H],
+        "he_mul_coeffs_montgomery": [H, i, H, H, H], "he_mul_coeffs_montgomery_then_add": [H, i, H, H, H],
+        "he_mul_coeffs_montgomery_lazy": [H, i, H, H, H],
+        "he_mul_coeffs_montgomery_lazy_then_add_lazy": [H, i, H, H, H],
+        "he_div_round_by_last_modulus_ntt": [H, i, H, H], "he_div_round_by_last_modulus": [H, i, H, H],
+        "he_div_floor_by_last_modulus_ntt": [H, i, H, H], "he_div_floor_by_last_modulus": [H, i, H, H],
+        "he_div_round_by_last_modulus_many_ntt": [H, i, i, H, H], "he_div_round_by_last_modulus_many": [H, i, i, H, H],
+        "he_div_floor_by_last_modulus_many_ntt": [H, i, i, H, H], "he_div_floor_by_last_modulus_many": [H, i, i, H, H],
+        "he_automorphism_index_create": [H, C.c_uint64, HP], "he_automorphism_index_destroy": [H],
+        "he_automorphism_index_download": [H, u64p],
+        "he_automorphism_ntt_with_index": [H, i, H, H, H],
+        "he_automorphism_ntt_with_index_then_add_lazy": [H, i, H, H, H],
+        "he_automorphism": [H, i, H, C.c_uint64, H],
+        "he_basis_extender_create": [H, H, HP], "he_basis_extender_destroy": [H],
+        "he_modup_q_to_p": [H, i, i, H, H], "he_modup_p_to_q": [H, i, i, H, H],
+        "he_moddown_qp_to_q": [H, i, i, H, H, H], "he_moddown_qp_to_q_ntt": [H, i, i, H, H, H],
+        "he_moddown_qp_to_p": [H, i, i, H, H, H],
+        "he_evaluator_create": [H, H, HP], "he_evaluator_destroy": [H],
+        "he_evk_create": [H, i, i, i, u64p, u64p, HP], "he_evk_destroy": [H],
+        "he_decompose_and_split": [H, i, i, i, i, H, H, H],
+        "he_decomp_create": [H, i, HP], "he_decomp_destroy": [H],
+        "he_decomp_download_limb": [H, i, i, i, i, u64p],
+        "he_decompose_ntt": [H, i, i, i, H, i, H],
+        "he_gadget_product_lazy": [H, i, H, H, H, H, H, H],
+        "he_gadget_product_hoisted_lazy": [H, i, H, H, H, H, H, H],
+        "he_moddown": [H, i, i, H, H, H, H, H, H],
+        "he_gadget_product": [H, i, H, H, H, H], "he_gadget_product_hoisted": [H, i, H, H, H, H],
+        "he_relinearize": [H, i, H, H, H, H, H, H],
+        "he_automorphism_ct": [H, i, H, H, C.c_uint64, H, H, H],
+        "he_automorphism_hoisted": [H, i, H, H, C.c_uint64, H, H, H],
+        "he_ckks_mul_relin": [H, i, H, H, H, H, H, H, H, H],
+        "he_bgv_mul_relin": [H, i, C.c_uint64, H, H, H, H, H, H, H, H],
+        "he_probe_modmul": [H, i, C.POINTER(C.c_double)],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int

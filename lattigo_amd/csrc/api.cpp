@@ -1,0 +1,1519 @@
+// api.cpp -- the C ABI of libhering (include/hering.h): handle registry, device-resident
+// ring / poly / key objects and the host-side orchestration of the kernels in
+// kernels.hip.  Mirrors the reference's ring.Ring / ring.BasisExtender / ring.Decomposer /
+// rlwe.Evaluator call structure (file:line cited per function) with every loop over
+// coefficients replaced by a launch covering all (limb x batch entry) pairs.
+//
+// There is NO CPU fallback: every arithmetic entry point enqueues gfx950 kernels; if the
+// HIP runtime or device is missing the call fails with HE_EDEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/hering.h"
+#include "host_math.h"
+#include "kernels.h"
+
+using namespace he;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail(HE_EDEVICE, "%s: %s", #expr, hipGetErrorString(_e));    \
+    } while (0)
+#define TRY(expr)              \
+    do {                       \
+        int _r = (expr);       \
+        if (_r != HE_OK) return _r; \
+    } while (0)
+
+enum ObjType { T_CTX = 1, T_RING, T_POLY, T_INDEX, T_BE, T_EVAL, T_EVK, T_DECOMP };
+
+struct Obj {
+    ObjType type;
+    explicit Obj(ObjType t) : type(t) {}
+    virtual ~Obj() {}
+};
+
+struct Ctx : Obj {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // stream-ordered scratch arena (temporaries of one API call)
+    uint64_t *arena = nullptr;
+    size_t arena_words = 0, arena_used = 0;
+    std::mutex mu;
+    Ctx() : Obj(T_CTX) {}
+    ~Ctx() override {
+        hipSetDevice(dev);
+        if (stream) hipStreamSynchronize(stream);
+        if (arena) hipFree(arena);
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+        if (stream) hipStreamDestroy(stream);
+    }
+    void arena_reset() { arena_used = 0; }
+    // reserve the total a call needs up front (growing invalidates earlier pointers)
+    int arena_reserve(size_t words) {
+        if (words <= arena_words) return HE_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (arena) HIP_TRY(hipFree(arena));
+        arena = nullptr;
+        arena_words = 0;
+        size_t want = words + words / 4;
+        HIP_TRY(hipMalloc((void **)&arena, want * sizeof(uint64_t)));
+        arena_words = want;
+        return HE_OK;
+    }
+    uint64_t *arena_take(size_t words) {
+        uint64_t *p = arena + arena_used;
+        arena_used += (words + 1) & ~(size_t)1;  // keep 16-byte alignment
+        return p;
+    }
+};
+
+struct Ring : Obj {
+    std::shared_ptr<Ctx> ctx;
+    int logN = 0, N = 0;
+    std::vector<uint64_t> moduli;
+    std::vector<SubRingHost> sub;
+    std::vector<std::vector<uint64_t>> rescale;  // [j-1][i]
+    ModConst *d_mc = nullptr;
+    uint64_t *d_twf = nullptr, *d_twi = nullptr;
+    RingDev dev{};
+    Ring() : Obj(T_RING) {}
+    ~Ring() override {
+        hipSetDevice(ctx->dev);
+        hipStreamSynchronize(ctx->stream);
+        if (d_mc) hipFree(d_mc);
+        if (d_twf) hipFree(d_twf);
+        if (d_twi) hipFree(d_twi);
+    }
+    int nmod() const { return (int)moduli.size(); }
+};
+
+struct Poly : Obj {
+    std::shared_ptr<Ctx> ctx;
+    int N = 0, nlimbs = 0, batch = 0;
+    uint64_t *d = nullptr;
+    Poly() : Obj(T_POLY) {}
+    ~Poly() override {
+        hipSetDevice(ctx->dev);
+        hipStreamSynchronize(ctx->stream);
+        if (d) hipFree(d);
+    }
+    View view() const { return View{d, (size_t)nlimbs * N}; }
+    View view_at(int limb) const { return View{d + (size_t)limb * N, (size_t)nlimbs * N}; }
+};
+
+struct AutoIndex : Obj {
+    std::shared_ptr<Ctx> ctx;
+    int N = 0;
+    uint64_t gal = 0;
+    uint32_t *d = nullptr;
+    AutoIndex() : Obj(T_INDEX) {}
+    ~AutoIndex() override {
+        hipSetDevice(ctx->dev);
+        hipStreamSynchronize(ctx->stream);
+        if (d) hipFree(d);
+    }
+};
+
+// constant pool: host vectors concatenated into one device buffer
+struct ConstPool {
+    std::vector<uint64_t> host;
+    uint64_t *dev = nullptr;
+    size_t add(const std::vector<uint64_t> &v) {
+        size_t off = host.size();
+        host.insert(host.end(), v.begin(), v.end());
+        return off;
+    }
+    int upload() {
+        if (host.empty()) return HE_OK;
+        HIP_TRY(hipMalloc((void **)&dev, host.size() * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(dev, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        return HE_OK;
+    }
+    void release() {
+        if (dev) hipFree(dev);
+        dev = nullptr;
+    }
+};
+struct ModUpRef {
+    int nsrc = 0, ndst = 0;
+    size_t a = 0, T = 0, vt = 0;
+    ModUpDev on(const ConstPool &p) const { return ModUpDev{nsrc, ndst, p.dev + a, p.dev + T, p.dev + vt}; }
+};
+static ModUpRef pool_modup(ConstPool &pool, const std::vector<uint64_t> &S, const std::vector<uint64_t> &D) {
+    ModUpHost h = build_modup_constants(S, D);
+    ModUpRef r;
+    r.nsrc = h.nsrc; r.ndst = h.ndst;
+    r.a = pool.add(h.a); r.T = pool.add(h.T); r.vt = pool.add(h.vt);
+    return r;
+}
+
+// ring.BasisExtender (ring/basis_extension.go:14-89) over a combined QP modulus table:
+// modulus index i < LQ -> Q[i], LQ + j -> P[j].
+struct BasisExtender : Obj {
+    std::shared_ptr<Ctx> ctx;
+    std::shared_ptr<Ring> Q, P;
+    int LQ = 0, LP = 0;
+    ModConst *d_mc = nullptr;
+    uint64_t *d_twf = nullptr, *d_twi = nullptr;
+    RingDev qp{};
+    ConstPool pool;
+    std::vector<ModUpRef> qtop, ptoq;                      // per source level
+    std::vector<std::vector<uint64_t>> md_ptoq, md_qtop;   // modDownConstants [levelP][i], [levelQ][j]
+    BasisExtender() : Obj(T_BE) {}
+    ~BasisExtender() override {
+        hipSetDevice(ctx->dev);
+        hipStreamSynchronize(ctx->stream);
+        if (d_mc) hipFree(d_mc);
+        if (d_twf) hipFree(d_twf);
+        if (d_twi) hipFree(d_twi);
+        pool.release();
+    }
+    uint64_t modulus(int idx) const { return idx < LQ ? Q->moduli[idx] : P->moduli[idx - LQ]; }
+};
+
+// rlwe.Evaluator hot path: BasisExtender + ring.Decomposer constants (ring/basis_extension.go:320-377)
+struct Evaluator : Obj {
+    std::shared_ptr<BasisExtender> be;
+    ConstPool pool;
+    // dec[nbPi-2][digit][j]: source = first j+2 limbs of the digit, target = all Q then P[:nbPi]
+    std::vector<std::vector<std::vector<ModUpRef>>> dec;
+    Evaluator() : Obj(T_EVAL) {}
+    ~Evaluator() override {
+        hipSetDevice(be->ctx->dev);
+        hipStreamSynchronize(be->ctx->stream);
+        pool.release();
+    }
+};
+
+// GadgetCiphertext on the device: [beta][2][nQk + nPk][N], Q limbs then P limbs per (d,k)
+struct Evk : Obj {
+    std::shared_ptr<Evaluator> ev;
+    int beta = 0, nQk = 0, nPk = 0;
+    uint64_t *d = nullptr;
+    Evk() : Obj(T_EVK) {}
+    ~Evk() override {
+        hipSetDevice(ev->be->ctx->dev);
+        hipStreamSynchronize(ev->be->ctx->stream);
+        if (d) hipFree(d);
+    }
+};
+
+// BuffDecompQP: [batch][beta_max][LQ + LP][N]
+struct Decomp : Obj {
+    std::shared_ptr<Evaluator> ev;
+    int batch = 0, beta_max = 0, width = 0;  // width = LQ + LP limbs per digit
+    uint64_t *d = nullptr;
+    Decomp() : Obj(T_DECOMP) {}
+    ~Decomp() override {
+        hipSetDevice(ev->be->ctx->dev);
+        hipStreamSynchronize(ev->be->ctx->stream);
+        if (d) hipFree(d);
+    }
+    size_t bstride() const { return (size_t)beta_max * width * ev->be->Q->N; }
+    size_t dstride() const { return (size_t)width * ev->be->Q->N; }
+};
+
+std::mutex g_mu;
+std::unordered_map<uint64_t, std::shared_ptr<Obj>> g_objs;
+uint64_t g_next = 0x1000;
+
+uint64_t reg(std::shared_ptr<Obj> o) {
+    std::lock_guard<std::mutex> l(g_mu);
+    uint64_t h = g_next++;
+    g_objs[h] = std::move(o);
+    return h;
+}
+template <class T>
+std::shared_ptr<T> get(uint64_t h, ObjType t) {
+    std::lock_guard<std::mutex> l(g_mu);
+    auto it = g_objs.find(h);
+    if (it == g_objs.end() || it->second->type != t) return nullptr;
+    return std::static_pointer_cast<T>(it->second);
+}
+int unreg(uint64_t h, ObjType t) {
+    std::shared_ptr<Obj> keep;
+    {
+        std::lock_guard<std::mutex> l(g_mu);
+        auto it = g_objs.find(h);
+        if (it == g_objs.end() || it->second->type != t) return fail(HE_EHANDLE, "unknown handle %llu", (unsigned long long)h);
+        keep = it->second;
+        g_objs.erase(it);
+    }
+    keep.reset();
+    return HE_OK;
+}
+#define GET(var, T, h, tag)                                                                          \
+    auto var = get<T>(h, tag);                                                                       \
+    if (!var) return fail(HE_EHANDLE, "%s: bad %s handle %llu", __func__, #T, (unsigned long long)(h))
+
+struct Scope {  // per-call: select device, lock the context, reset the scratch arena
+    Ctx *c;
+    explicit Scope(Ctx *ctx) : c(ctx) {
+        c->mu.lock();
+        hipSetDevice(c->dev);
+        c->arena_reset();
+    }
+    ~Scope() { c->mu.unlock(); }
+};
+
+LimbTab ident_tab(int n, int in0 = 0, int out0 = 0, int mod0 = 0) {
+    LimbTab t;
+    t.n = n;
+    for (int i = 0; i < n; i++) {
+        t.in_limb[i] = (uint8_t)(in0 + i);
+        t.out_limb[i] = (uint8_t)(out0 + i);
+        t.mod[i] = (uint8_t)(mod0 + i);
+    }
+    return t;
+}
+
+int check_poly(const Poly &p, const Ring &r, int level, const char *who) {
+    if (p.N != r.N) return fail(HE_EINVAL, "%s: poly degree %d != ring degree %d", who, p.N, r.N);
+    if (level < 0 || level >= r.nmod()) return fail(HE_EINVAL, "%s: level %d out of range [0,%d]", who, level, r.nmod() - 1);
+    if (p.nlimbs < level + 1) return fail(HE_EINVAL, "%s: poly has %d limbs, level %d needs %d", who, p.nlimbs, level, level + 1);
+    return HE_OK;
+}
+
+int upload_tables(const std::vector<const SubRingHost *> &subs, int N, ModConst **d_mc, uint64_t **d_twf, uint64_t **d_twi) {
+    const size_t n = subs.size();
+    std::vector<ModConst> mc(n);
+    std::vector<uint64_t> twf(n * (size_t)N), twi(n * (size_t)N);
+    for (size_t i = 0; i < n; i++) {
+        mc[i] = subs[i]->mc;
+        std::copy(subs[i]->roots_fwd.begin(), subs[i]->roots_fwd.end(), twf.begin() + i * (size_t)N);
+        std::copy(subs[i]->roots_bwd.begin(), subs[i]->roots_bwd.end(), twi.begin() + i * (size_t)N);
+    }
+    HIP_TRY(hipMalloc((void **)d_mc, n * sizeof(ModConst)));
+    HIP_TRY(hipMalloc((void **)d_twf, twf.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)d_twi, twi.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(*d_mc, mc.data(), n * sizeof(ModConst), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(*d_twf, twf.data(), twf.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(*d_twi, twi.data(), twi.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return HE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *he_last_error(void) { return g_err.c_str(); }
+const char *he_version(void) { return "libhering 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+int he_ctx_create(int device_id, he_handle *out) {
+    if (!out) return fail(HE_EINVAL, "he_ctx_create: null output");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(HE_EDEVICE, "he_ctx_create: no HIP device available (%s); libhering has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(HE_EINVAL, "he_ctx_create: device %d out of range [0,%d)", device_id, ndev);
+    auto c = std::make_shared<Ctx>();
+    c->dev = device_id;
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    *out = reg(c);
+    return HE_OK;
+}
+int he_ctx_destroy(he_handle h) { return unreg(h, T_CTX); }
+int he_ctx_sync(he_handle h) {
+    GET(c, Ctx, h, T_CTX);
+    HIP_TRY(hipSetDevice(c->dev));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HE_OK;
+}
+int he_timer_start(he_handle h) {
+    GET(c, Ctx, h, T_CTX);
+    HIP_TRY(hipSetDevice(c->dev));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return HE_OK;
+}
+int he_timer_stop(he_handle h, float *ms) {
+    GET(c, Ctx, h, T_CTX);
+    HIP_TRY(hipSetDevice(c->dev));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return HE_OK;
+}
+int he_device_info(he_handle h, uint64_t out[4]) {
+    GET(c, Ctx, h, T_CTX);
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, c->dev));
+    out[0] = (uint64_t)p.multiProcessorCount;
+    out[1] = (uint64_t)p.maxSharedMemoryPerMultiProcessor;
+    out[2] = (uint64_t)p.clockRate;
+    out[3] = (uint64_t)p.totalGlobalMem;
+    return HE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// ring
+// ---------------------------------------------------------------------------------------
+int he_ring_create(he_handle hctx, int logN, const uint64_t *moduli, int n, he_handle *out) {
+    GET(c, Ctx, hctx, T_CTX);
+    if (!moduli || !out || n <= 0) return fail(HE_EINVAL, "he_ring_create: invalid ModuliChain (must be a non-empty []uint64)");
+    if (n > 48) return fail(HE_EINVAL, "he_ring_create: at most 48 moduli per ring");
+    if (logN < 4 || logN > 17) return fail(HE_EPARAM, "he_ring_create: logN=%d outside [4,17]", logN);
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            if (moduli[i] == moduli[j]) return fail(HE_EPARAM, "he_ring_create: invalid ModuliChain (moduli are not distinct)");
+    auto r = std::make_shared<Ring>();
+    r->ctx = c;
+    r->logN = logN;
+    r->N = 1 << logN;
+    r->moduli.assign(moduli, moduli + n);
+    r->sub.resize(n);
+    std::string err;
+    for (int i = 0; i < n; i++)
+        if (!build_subring(logN, moduli[i], r->sub[i], err)) return fail(HE_EPARAM, "he_ring_create: %s", err.c_str());
+    r->rescale = build_rescale_constants(r->moduli);
+    Scope sc(c.get());
+    std::vector<const SubRingHost *> subs;
+    for (auto &s : r->sub) subs.push_back(&s);
+    TRY(upload_tables(subs, r->N, &r->d_mc, &r->d_twf, &r->d_twi));
+    r->dev = RingDev{logN, r->N, r->d_mc, r->d_twf, r->d_twi};
+    *out = reg(r);
+    return HE_OK;
+}
+int he_ring_destroy(he_handle h) { return unreg(h, T_RING); }
+int he_ring_constant(he_handle h, int limb, int which, uint64_t *out) {
+    GET(r, Ring, h, T_RING);
+    if (limb < 0 || limb >= r->nmod() || !out) return fail(HE_EINVAL, "he_ring_constant: bad limb");
+    const SubRingHost &s = r->sub[limb];
+    switch (which) {
+        case 0: *out = s.mc.q; break;
+        case 1: *out = s.mc.qinv; break;
+        case 2: *out = s.mc.brc0; break;
+        case 3: *out = s.mc.brc1; break;
+        case 4: *out = s.mc.ninv; break;
+        case 5: *out = s.primroot; break;
+        default: return fail(HE_EINVAL, "he_ring_constant: bad selector %d", which);
+    }
+    return HE_OK;
+}
+int he_ring_roots(he_handle h, int limb, int dir, uint64_t *out) {
+    GET(r, Ring, h, T_RING);
+    if (limb < 0 || limb >= r->nmod() || !out) return fail(HE_EINVAL, "he_ring_roots: bad limb");
+    Scope sc(r->ctx.get());
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    HIP_TRY(hipMemcpy(out, (dir ? r->d_twi : r->d_twf) + (size_t)limb * r->N, (size_t)r->N * 8, hipMemcpyDeviceToHost));
+    return HE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// polynomials
+// ---------------------------------------------------------------------------------------
+int he_poly_alloc(he_handle hring, int n_limbs, int batch, he_handle *out) {
+    GET(r, Ring, hring, T_RING);
+    if (n_limbs <= 0 || n_limbs > 255 || batch <= 0 || !out) return fail(HE_EINVAL, "he_poly_alloc: bad shape (%d limbs, batch %d)", n_limbs, batch);
+    auto p = std::make_shared<Poly>();
+    p->ctx = r->ctx;
+    p->N = r->N;
+    p->nlimbs = n_limbs;
+    p->batch = batch;
+    Scope sc(r->ctx.get());
+    const size_t bytes = (size_t)batch * n_limbs * r->N * 8;
+    hipError_t e = hipMalloc((void **)&p->d, bytes);
+    if (e != hipSuccess) return fail(HE_ENOMEM, "he_poly_alloc: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    HIP_TRY(hipMemsetAsync(p->d, 0, bytes, r->ctx->stream));
+    *out = reg(p);
+    return HE_OK;
+}
+int he_poly_free(he_handle h) { return unreg(h, T_POLY); }
+int he_poly_shape(he_handle h, int *n_limbs, int *batch, int *N) {
+    GET(p, Poly, h, T_POLY);
+    if (n_limbs) *n_limbs = p->nlimbs;
+    if (batch) *batch = p->batch;
+    if (N) *N = p->N;
+    return HE_OK;
+}
+int he_poly_upload(he_handle h, const uint64_t *src, size_t n_words) {
+    GET(p, Poly, h, T_POLY);
+    const size_t total = (size_t)p->batch * p->nlimbs * p->N;
+    if (!src || n_words != total) return fail(HE_EINVAL, "he_poly_upload: expected %zu words, got %zu", total, n_words);
+    Scope sc(p->ctx.get());
+    HIP_TRY(hipMemcpyAsync(p->d, src, total * 8, hipMemcpyHostToDevice, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    return HE_OK;
+}
+int he_poly_download(he_handle h, uint64_t *dst, size_t n_words) {
+    GET(p, Poly, h, T_POLY);
+    const size_t total = (size_t)p->batch * p->nlimbs * p->N;
+    if (!dst || n_words != total) return fail(HE_EINVAL, "he_poly_download: expected %zu words, got %zu", total, n_words);
+    Scope sc(p->ctx.get());
+    HIP_TRY(hipMemcpyAsync(dst, p->d, total * 8, hipMemcpyDeviceToHost, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    return HE_OK;
+}
+int he_poly_upload_limb(he_handle h, int b, int limb, const uint64_t *src) {
+    GET(p, Poly, h, T_POLY);
+    if (!src || b < 0 || b >= p->batch || limb < 0 || limb >= p->nlimbs) return fail(HE_EINVAL, "he_poly_upload_limb: bad index");
+    Scope sc(p->ctx.get());
+    HIP_TRY(hipMemcpyAsync(p->d + ((size_t)b * p->nlimbs + limb) * p->N, src, (size_t)p->N * 8, hipMemcpyHostToDevice, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    return HE_OK;
+}
+int he_poly_download_limb(he_handle h, int b, int limb, uint64_t *dst) {
+    GET(p, Poly, h, T_POLY);
+    if (!dst || b < 0 || b >= p->batch || limb < 0 || limb >= p->nlimbs) return fail(HE_EINVAL, "he_poly_download_limb: bad index");
+    Scope sc(p->ctx.get());
+    HIP_TRY(hipMemcpyAsync(dst, p->d + ((size_t)b * p->nlimbs + limb) * p->N, (size_t)p->N * 8, hipMemcpyDeviceToHost, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    return HE_OK;
+}
+int he_poly_copy(he_handle hdst, he_handle hsrc, int level) {
+    GET(d, Poly, hdst, T_POLY);
+    GET(s, Poly, hsrc, T_POLY);
+    if (d->N != s->N || d->batch != s->batch || level < 0 || d->nlimbs < level + 1 || s->nlimbs < level + 1)
+        return fail(HE_EINVAL, "he_poly_copy: shape mismatch");
+    Scope sc(d->ctx.get());
+    HIP_TRY(hipMemcpy2DAsync(d->d, (size_t)d->nlimbs * d->N * 8, s->d, (size_t)s->nlimbs * s->N * 8, (size_t)(level + 1) * d->N * 8,
+                             d->batch, hipMemcpyDeviceToDevice, d->ctx->stream));
+    return HE_OK;
+}
+int he_poly_zero(he_handle h) {
+    GET(p, Poly, h, T_POLY);
+    Scope sc(p->ctx.get());
+    HIP_TRY(hipMemsetAsync(p->d, 0, (size_t)p->batch * p->nlimbs * p->N * 8, p->ctx->stream));
+    return HE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// NTT (ring/ntt.go:127-152)
+// ---------------------------------------------------------------------------------------
+static int ntt_api(he_handle hring, int level, he_handle h1, he_handle h2, bool inverse, int flags, const char *who) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    TRY(check_poly(*p1, *r, level, who));
+    TRY(check_poly(*p2, *r, level, who));
+    if (p1->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    Scope sc(r->ctx.get());
+    HIP_TRY(launch_ntt(r->dev, ident_tab(level + 1), p1->view(), p2->view(), p1->batch, inverse, flags | NTT_REDUCE_INPUT, r->ctx->stream));
+    return HE_OK;
+}
+int he_ntt(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, false, 0, "he_ntt"); }
+int he_ntt_lazy(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, false, NTT_LAZY_OUT, "he_ntt_lazy"); }
+int he_intt(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, true, 0, "he_intt"); }
+int he_intt_lazy(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, true, 0, "he_intt_lazy"); }
+
+// ---------------------------------------------------------------------------------------
+// coefficient-wise ops (ring/operations.go)
+// ---------------------------------------------------------------------------------------
+int he_binop(he_handle hring, int level, int op, he_handle h1, he_handle h2, he_handle h3) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    GET(p3, Poly, h3, T_POLY);
+    if (op < 0 || op >= HE_BINOP_COUNT) return fail(HE_EINVAL, "he_binop: unknown op %d", op);
+    TRY(check_poly(*p1, *r, level, "he_binop"));
+    TRY(check_poly(*p2, *r, level, "he_binop"));
+    TRY(check_poly(*p3, *r, level, "he_binop"));
+    if (p1->batch != p3->batch || p2->batch != p3->batch) return fail(HE_EINVAL, "he_binop: batch mismatch");
+    Scope sc(r->ctx.get());
+    HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), op, p1->view(), p2->view(), p3->view(), p3->batch, nullptr, nullptr, r->ctx->stream));
+    return HE_OK;
+}
+int he_unop(he_handle hring, int level, int op, he_handle h1, he_handle h2) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    if (op < 0 || op >= HE_UNOP_COUNT) return fail(HE_EINVAL, "he_unop: unknown op %d", op);
+    TRY(check_poly(*p1, *r, level, "he_unop"));
+    TRY(check_poly(*p2, *r, level, "he_unop"));
+    if (p1->batch != p2->batch) return fail(HE_EINVAL, "he_unop: batch mismatch");
+    Scope sc(r->ctx.get());
+    HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), EW_NEG + op, p1->view(), p1->view(), p2->view(), p2->batch, nullptr, nullptr, r->ctx->stream));
+    return HE_OK;
+}
+// scalar given per limb (already what the kernel consumes)
+static int scalar_launch(Ring &r, int level, int ewop, Poly &p1, Poly &p2, const ScalarTab &st) {
+    HIP_TRY(launch_ew(r.dev, ident_tab(level + 1), ewop, p1.view(), p1.view(), p2.view(), p2.batch, &st, nullptr, r.ctx->stream));
+    return HE_OK;
+}
+int he_scalarop(he_handle hring, int level, int op, he_handle h1, uint64_t scalar, he_handle h2) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    TRY(check_poly(*p1, *r, level, "he_scalarop"));
+    TRY(check_poly(*p2, *r, level, "he_scalarop"));
+    if (p1->batch != p2->batch) return fail(HE_EINVAL, "he_scalarop: batch mismatch");
+    ScalarTab st{};
+    int ewop;
+    for (int i = 0; i <= level; i++) {
+        const ModConst &m = r->sub[i].mc;
+        switch (op) {
+            case HE_ADD_SCALAR: st.s[i] = scalar; break;                                   // operations.go:151 (no reduction of the scalar)
+            case HE_SUB_SCALAR: st.s[i] = scalar; break;                                   // :186
+            case HE_MUL_SCALAR:                                                            // :201  MForm(scalar)
+            case HE_MUL_SCALAR_THEN_ADD: st.s[i] = mform(scalar, m.q, m.brc0, m.brc1); break;  // :208
+            case HE_MUL_SCALAR_THEN_SUB:                                                   // :223  MForm(q - BRedAdd(scalar))
+                st.s[i] = mform(m.q - bred_add(scalar, m.q, m.brc0), m.q, m.brc0, m.brc1);
+                break;
+            default: return fail(HE_EINVAL, "he_scalarop: unknown op %d", op);
+        }
+    }
+    switch (op) {
+        case HE_ADD_SCALAR: ewop = EW_ADD_SCALAR; break;
+        case HE_SUB_SCALAR: ewop = EW_SUB_SCALAR; break;
+        case HE_MUL_SCALAR: ewop = EW_MUL_SCALAR_MONT; break;
+        default: ewop = EW_MUL_SCALAR_MONT_THEN_ADD; break;
+    }
+    Scope sc(r->ctx.get());
+    return scalar_launch(*r, level, ewop, *p1, *p2, st);
+}
+int he_mul_rns_scalar_montgomery(he_handle hring, int level, he_handle h1, const uint64_t *scalar, he_handle h2) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    TRY(check_poly(*p1, *r, level, "he_mul_rns_scalar_montgomery"));
+    TRY(check_poly(*p2, *r, level, "he_mul_rns_scalar_montgomery"));
+    if (!scalar || p1->batch != p2->batch) return fail(HE_EINVAL, "he_mul_rns_scalar_montgomery: bad arguments");
+    ScalarTab st{};
+    for (int i = 0; i <= level; i++) st.s[i] = scalar[i];
+    Scope sc(r->ctx.get());
+    return scalar_launch(*r, level, EW_MUL_SCALAR_MONT, *p1, *p2, st);
+}
+static int bigint_api(he_handle hring, int level, he_handle h1, const uint64_t *words, int nw, he_handle h2, int kind) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    TRY(check_poly(*p1, *r, level, "he_*_scalar_bigint"));
+    TRY(check_poly(*p2, *r, level, "he_*_scalar_bigint"));
+    if (!words || nw <= 0 || p1->batch != p2->batch) return fail(HE_EINVAL, "he_*_scalar_bigint: bad arguments");
+    ScalarTab st{};
+    for (int i = 0; i <= level; i++) {
+        const ModConst &m = r->sub[i].mc;
+        const uint64_t v = words_mod(words, nw, m.q);
+        st.s[i] = kind == 2 ? mform(v, m.q, m.brc0, m.brc1) : v;
+    }
+    Scope sc(r->ctx.get());
+    return scalar_launch(*r, level, kind == 0 ? EW_ADD_SCALAR : (kind == 1 ? EW_SUB_SCALAR : EW_MUL_SCALAR_MONT), *p1, *p2, st);
+}
+int he_add_scalar_bigint(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 0); }
+int he_sub_scalar_bigint(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 1); }
+int he_mul_scalar_bigint(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 2); }
+
+int he_add(he_handle r, int l, he_handle a, he_handle b, he_handle c) { return he_binop(r, l, HE_ADD, a, b, c); }
+int he_sub(he_handle r, int l, he_handle a, he_handle b, he_handle c) { return he_binop(r, l, HE_SUB, a, b, c); }
+int he_neg(he_handle r, int l, he_handle a, he_handle b) { return he_unop(r, l, HE_NEG, a, b); }
+int he_reduce(he_handle r, int l, he_handle a, he_handle b) { return he_unop(r, l, HE_REDUCE, a, b); }
+int he_mform(he_handle r, int l, he_handle a, he_handle b) { return he_unop(r, l, HE_MFORM, a, b); }
+int he_imform(he_handle r, int l, he_handle a, he_handle b) { return he_unop(r, l, HE_IMFORM, a, b); }
+int he_mul_coeffs_montgomery(he_handle r, int l, he_handle a, he_handle b, he_handle c) { return he_binop(r, l, HE_MUL_COEFFS_MONTGOMERY, a, b, c); }
+int he_mul_coeffs_montgomery_then_add(he_handle r, int l, he_handle a, he_handle b, he_handle c) { return he_binop(r, l, HE_MUL_COEFFS_MONTGOMERY_THEN_ADD, a, b, c); }
+int he_mul_coeffs_montgomery_lazy(he_handle r, int l, he_handle a, he_handle b, he_handle c) { return he_binop(r, l, HE_MUL_COEFFS_MONTGOMERY_LAZY, a, b, c); }
+int he_mul_coeffs_montgomery_lazy_then_add_lazy(he_handle r, int l, he_handle a, he_handle b, he_handle c) { return he_binop(r, l, HE_MUL_COEFFS_MONTGOMERY_LAZY_THEN_ADD_LAZY, a, b, c); }
+
+// ---------------------------------------------------------------------------------------
+// rescale (ring/scaling.go).  `mod0` lets the same routine run on a sub-chain.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct RescaleScratch {
+    View s0;  // [batch][1][N]
+    View s1;  // [batch][level][N]
+};
+// one DivRound/DivFloor step in the NTT domain: p0 (level+1 limbs) -> p1 (level limbs)
+int div_by_last_modulus_ntt(Ring &r, int level, View p0, View p1, int batch, bool round, RescaleScratch sc) {
+    hipStream_t st = r.ctx->stream;
+    const int N = r.N;
+    (void)N;
+    // b0 = INTTLazy(p0[level])                                                  scaling.go:15 / :110
+    LimbTab t_top;
+    t_top.n = 1; t_top.in_limb[0] = (uint8_t)level; t_top.out_limb[0] = 0; t_top.mod[0] = (uint8_t)level;
+    HIP_TRY(launch_ntt(r.dev, t_top, p0, sc.s0, batch, true, NTT_REDUCE_INPUT, st));
+    ScalarTab s{};
+    const uint64_t qL = r.moduli[level], phalf = (qL - 1) >> 1;
+    if (round) {  // b0 += pHalf mod q_L                                          scaling.go:114
+        LimbTab t0; t0.n = 1; t0.in_limb[0] = 0; t0.out_limb[0] = 0; t0.mod[0] = (uint8_t)level;
+        s.s[0] = phalf;
+        HIP_TRY(launch_ew(r.dev, t0, EW_ADD_SCALAR, sc.s0, sc.s0, sc.s0, batch, &s, nullptr, st));
+    }
+    if (level == 0) return HE_OK;
+    // b1_i = b0 + (q_i - pHalf mod q_i)  (lazy), NTTLazy_i                       scaling.go:117-119
+    LimbTab tl = ident_tab(level);
+    uint8_t xl[kMaxLimbs] = {0};
+    LimbTab tin = tl;
+    for (int i = 0; i < level; i++) tin.in_limb[i] = 0;
+    if (round) {
+        for (int i = 0; i < level; i++) {
+            const ModConst &m = r.sub[i].mc;
+            s.s[i] = m.q - bred_add(phalf, m.q, m.brc0);
+        }
+        HIP_TRY(launch_ew(r.dev, tin, EW_ADD_SCALAR_LAZY, sc.s0, sc.s0, sc.s1, batch, &s, xl, st));
+        HIP_TRY(launch_ntt(r.dev, tl, sc.s1, sc.s1, batch, false, NTT_REDUCE_INPUT | NTT_LAZY_OUT, st));
+    } else {
+        HIP_TRY(launch_ntt(r.dev, tin, sc.s0, sc.s1, batch, false, NTT_REDUCE_INPUT | NTT_LAZY_OUT, st));
+    }
+    // p1_i = MRed(b1_i + 2q_i - p0_i, RescaleConstants[level-1][i])             scaling.go:120
+    for (int i = 0; i < level; i++) s.s[i] = r.rescale[level - 1][i];
+    // x = s1 (limb i), y = p0 (limb i), z = p1 (limb i)
+    HIP_TRY(launch_ew(r.dev, tl, EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sc.s1, p0, p1, batch, &s, nullptr, st));
+    return HE_OK;
+}
+// coefficient-domain step                                                         scaling.go:26-34, :126-144
+int div_by_last_modulus_coeff(Ring &r, int level, View p0, View p1, int batch, bool round, RescaleScratch sc) {
+    hipStream_t st = r.ctx->stream;
+    if (level == 0) return HE_OK;
+    ScalarTab s{};
+    LimbTab tl = ident_tab(level);
+    uint8_t xl[kMaxLimbs];
+    if (round) {
+        const uint64_t qL = r.moduli[level], phalf = (qL - 1) >> 1;
+        LimbTab t0; t0.n = 1; t0.in_limb[0] = (uint8_t)level; t0.out_limb[0] = 0; t0.mod[0] = (uint8_t)level;
+        s.s[0] = phalf;
+        HIP_TRY(launch_ew(r.dev, t0, EW_ADD_SCALAR, p0, p0, sc.s0, batch, &s, nullptr, st));
+        for (int i = 0; i < level; i++) {
+            const ModConst &m = r.sub[i].mc;
+            s.s[i] = r.rescale[level - 1][i];
+            s.s2[i] = m.q - bred_add(phalf, m.q, m.brc0);
+            xl[i] = 0;
+        }
+        HIP_TRY(launch_ew(r.dev, tl, EW_DIVROUND_COEFF, sc.s0, p0, p1, batch, &s, xl, st));
+    } else {
+        for (int i = 0; i < level; i++) { s.s[i] = r.rescale[level - 1][i]; xl[i] = (uint8_t)level; }
+        HIP_TRY(launch_ew(r.dev, tl, EW_SUB_THEN_MUL_SCALAR_MONT_2Q, p0, p0, p1, batch, &s, xl, st));
+    }
+    return HE_OK;
+}
+int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, bool round, bool ntt, const char *who) {
+    GET(r, Ring, hring, T_RING);
+    GET(p0, Poly, h0, T_POLY);
+    GET(p1, Poly, h1, T_POLY);
+    TRY(check_poly(*p0, *r, level, who));
+    if (nb < 0 || nb > level) return fail(HE_EINVAL, "%s: cannot divide %d times at level %d", who, nb, level);
+    if (p1->N != r->N || p1->nlimbs < level + 1 - nb || p0->batch != p1->batch) return fail(HE_EINVAL, "%s: output shape mismatch", who);
+    Scope sc(r->ctx.get());
+    hipStream_t st = r->ctx->stream;
+    const int B = p0->batch, N = r->N;
+    if (nb == 0) {
+        if (p0->d != p1->d)
+            HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), EW_COPY, p0->view(), p0->view(), p1->view(), B, nullptr, nullptr, st));
+        return HE_OK;
+    }
+    const size_t w0 = (size_t)B * N, w1 = (size_t)B * (level + 1) * N;
+    TRY(r->ctx->arena_reserve(w0 + 2 * w1));
+    RescaleScratch rs;
+    rs.s0 = View{r->ctx->arena_take(w0), (size_t)N};
+    rs.s1 = View{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
+    if (ntt && nb == 1) return div_by_last_modulus_ntt(*r, level, p0->view(), p1->view(), B, round, rs);
+    View buf{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
+    View cur = p0->view();
+    int lv = level;
+    if (ntt) {  // INTT, nb coefficient-domain steps, NTT          scaling.go:37-62, :148-174
+        HIP_TRY(launch_ntt(r->dev, ident_tab(level + 1), p0->view(), buf, B, true, NTT_REDUCE_INPUT, st));
+        cur = buf;
+    }
+    for (int i = 0; i < nb; i++) {
+        const bool last = (i == nb - 1);
+        View dst = (last && !ntt) ? p1->view() : buf;
+        TRY(div_by_last_modulus_coeff(*r, lv, cur, dst, B, round, rs));
+        cur = dst;
+        lv--;
+    }
+    if (ntt) HIP_TRY(launch_ntt(r->dev, ident_tab(lv + 1), buf, p1->view(), B, false, NTT_REDUCE_INPUT, st));
+    return HE_OK;
+}
+}  // namespace
+
+int he_div_round_by_last_modulus_ntt(he_handle r, int l, he_handle a, he_handle b) { return div_many(r, l, 1, a, b, true, true, "he_div_round_by_last_modulus_ntt"); }
+int he_div_round_by_last_modulus(he_handle r, int l, he_handle a, he_handle b) { return div_many(r, l, 1, a, b, true, false, "he_div_round_by_last_modulus"); }
+int he_div_floor_by_last_modulus_ntt(he_handle r, int l, he_handle a, he_handle b) { return div_many(r, l, 1, a, b, false, true, "he_div_floor_by_last_modulus_ntt"); }
+int he_div_floor_by_last_modulus(he_handle r, int l, he_handle a, he_handle b) { return div_many(r, l, 1, a, b, false, false, "he_div_floor_by_last_modulus"); }
+int he_div_round_by_last_modulus_many_ntt(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, true, true, "he_div_round_by_last_modulus_many_ntt"); }
+int he_div_round_by_last_modulus_many(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, true, false, "he_div_round_by_last_modulus_many"); }
+int he_div_floor_by_last_modulus_many_ntt(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, false, true, "he_div_floor_by_last_modulus_many_ntt"); }
+int he_div_floor_by_last_modulus_many(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, false, false, "he_div_floor_by_last_modulus_many"); }
+
+// ---------------------------------------------------------------------------------------
+// automorphism (ring/automorphism.go)
+// ---------------------------------------------------------------------------------------
+int he_automorphism_index_create(he_handle hring, uint64_t gal, he_handle *out) {
+    GET(r, Ring, hring, T_RING);
+    if (!out || !(gal & 1)) return fail(HE_EINVAL, "he_automorphism_index_create: Galois element must be odd");
+    auto ix = std::make_shared<AutoIndex>();
+    ix->ctx = r->ctx;
+    ix->N = r->N;
+    ix->gal = gal;
+    Scope sc(r->ctx.get());
+    HIP_TRY(hipMalloc((void **)&ix->d, (size_t)r->N * sizeof(uint32_t)));
+    HIP_TRY(launch_build_automorphism_index(r->logN, gal, ix->d, r->ctx->stream));
+    *out = reg(ix);
+    return HE_OK;
+}
+int he_automorphism_index_destroy(he_handle h) { return unreg(h, T_INDEX); }
+int he_automorphism_index_download(he_handle h, uint64_t *dst) {
+    GET(ix, AutoIndex, h, T_INDEX);
+    if (!dst) return fail(HE_EINVAL, "he_automorphism_index_download: null destination");
+    std::vector<uint32_t> tmp(ix->N);
+    Scope sc(ix->ctx.get());
+    HIP_TRY(hipMemcpyAsync(tmp.data(), ix->d, (size_t)ix->N * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
+    for (int i = 0; i < ix->N; i++) dst[i] = tmp[i];
+    return HE_OK;
+}
+static int gather_api(he_handle hring, int level, he_handle hin, he_handle hidx, he_handle hout, bool add, const char *who) {
+    GET(r, Ring, hring, T_RING);
+    GET(pin, Poly, hin, T_POLY);
+    GET(pout, Poly, hout, T_POLY);
+    GET(ix, AutoIndex, hidx, T_INDEX);
+    TRY(check_poly(*pin, *r, level, who));
+    TRY(check_poly(*pout, *r, level, who));
+    if (ix->N != r->N || pin->batch != pout->batch) return fail(HE_EINVAL, "%s: shape mismatch", who);
+    if (pin->d == pout->d) return fail(HE_EINVAL, "%s: the automorphism cannot be evaluated in place", who);
+    Scope sc(r->ctx.get());
+    HIP_TRY(launch_gather(r->dev, ident_tab(level + 1), pin->view(), ix->d, pout->view(), pin->batch, add, r->ctx->stream));
+    return HE_OK;
+}
+int he_automorphism_ntt_with_index(he_handle r, int l, he_handle in, he_handle idx, he_handle out) { return gather_api(r, l, in, idx, out, false, "he_automorphism_ntt_with_index"); }
+int he_automorphism_ntt_with_index_then_add_lazy(he_handle r, int l, he_handle in, he_handle idx, he_handle out) { return gather_api(r, l, in, idx, out, true, "he_automorphism_ntt_with_index_then_add_lazy"); }
+int he_automorphism(he_handle hring, int level, he_handle hin, uint64_t gal, he_handle hout) {
+    GET(r, Ring, hring, T_RING);
+    GET(pin, Poly, hin, T_POLY);
+    GET(pout, Poly, hout, T_POLY);
+    TRY(check_poly(*pin, *r, level, "he_automorphism"));
+    TRY(check_poly(*pout, *r, level, "he_automorphism"));
+    if (pin->batch != pout->batch) return fail(HE_EINVAL, "he_automorphism: batch mismatch");
+    if (pin->d == pout->d) return fail(HE_EINVAL, "he_automorphism: the automorphism cannot be evaluated in place");
+    Scope sc(r->ctx.get());
+    HIP_TRY(launch_automorphism_coeff(r->dev, ident_tab(level + 1), pin->view(), gal, pout->view(), pin->batch, r->ctx->stream));
+    return HE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// basis extension (ring/basis_extension.go)
+// ---------------------------------------------------------------------------------------
+int he_basis_extender_create(he_handle hq, he_handle hp, he_handle *out) {
+    GET(Q, Ring, hq, T_RING);
+    GET(P, Ring, hp, T_RING);
+    if (!out) return fail(HE_EINVAL, "he_basis_extender_create: null output");
+    if (Q->ctx != P->ctx || Q->N != P->N) return fail(HE_EINVAL, "he_basis_extender_create: rings must share context and degree");
+    if (Q->nmod() + P->nmod() > kMaxLimbs) return fail(HE_EINVAL, "he_basis_extender_create: more than %d moduli in QP", kMaxLimbs);
+    if (Q->nmod() > 32 || P->nmod() > 32) return fail(HE_EINVAL, "he_basis_extender_create: at most 32 source limbs (ring/basis_extension.go:285)");
+    for (uint64_t q : Q->moduli)
+        for (uint64_t p : P->moduli)
+            if (q == p) return fail(HE_EPARAM, "he_basis_extender_create: Q and P share a modulus");
+    auto be = std::make_shared<BasisExtender>();
+    be->ctx = Q->ctx; be->Q = Q; be->P = P; be->LQ = Q->nmod(); be->LP = P->nmod();
+    Scope sc(Q->ctx.get());
+    std::vector<const SubRingHost *> subs;
+    for (auto &s : Q->sub) subs.push_back(&s);
+    for (auto &s : P->sub) subs.push_back(&s);
+    TRY(upload_tables(subs, Q->N, &be->d_mc, &be->d_twf, &be->d_twi));
+    be->qp = RingDev{Q->logN, Q->N, be->d_mc, be->d_twf, be->d_twi};
+    for (int i = 0; i < be->LQ; i++)  // constantsQtoP[i] = GenModUpConstants(Q[:i+1], P)     basis_extension.go:62-65
+        be->qtop.push_back(pool_modup(be->pool, std::vector<uint64_t>(Q->moduli.begin(), Q->moduli.begin() + i + 1), P->moduli));
+    for (int i = 0; i < be->LP; i++)  // constantsPtoQ[i] = GenModUpConstants(P[:i+1], Q)     :67-70
+        be->ptoq.push_back(pool_modup(be->pool, std::vector<uint64_t>(P->moduli.begin(), P->moduli.begin() + i + 1), Q->moduli));
+    TRY(be->pool.upload());
+    be->md_ptoq.resize(be->LP);
+    for (int j = 0; j < be->LP; j++) {
+        std::vector<uint64_t> S(P->moduli.begin(), P->moduli.begin() + j + 1);
+        for (int i = 0; i < be->LQ; i++) be->md_ptoq[j].push_back(inv_product_mont(S, Q->moduli[i]));
+    }
+    be->md_qtop.resize(be->LQ);
+    for (int j = 0; j < be->LQ; j++) {
+        std::vector<uint64_t> S(Q->moduli.begin(), Q->moduli.begin() + j + 1);
+        for (int i = 0; i < be->LP; i++) be->md_qtop[j].push_back(inv_product_mont(S, P->moduli[i]));
+    }
+    *out = reg(be);
+    return HE_OK;
+}
+int he_basis_extender_destroy(he_handle h) { return unreg(h, T_BE); }
+
+namespace {
+// multSum's result stays below 4*p only while nsrc * max(source modulus) < 2^64; beyond that the
+// following forward NTT must first bring its input back to [0,2q).
+bool modup_out_needs_reduce(const std::vector<uint64_t> &basis) {
+    uint64_t mx = 0;
+    for (uint64_t m : basis) mx = std::max(mx, m);
+    return ((u128)mx * basis.size()) >> 63 != 0;
+}
+// ModUpQtoP / ModUpPtoQ (basis_extension.go:177-210): src limbs [0..levelS] of the source
+// ring -> dst limbs [0..levelD] of the other ring, centred by floor(S/2).
+// src_is_q selects direction.  dst_limb0 / dst view allow writing into QP-contiguous scratch.
+int modup_between(BasisExtender &be, bool src_is_q, int levelS, int levelD, View src, View dst, int dst_limb0, int batch) {
+    const Ring &S = src_is_q ? *be.Q : *be.P;
+    const Ring &D = src_is_q ? *be.P : *be.Q;
+    const int smod0 = src_is_q ? 0 : be.LQ, dmod0 = src_is_q ? be.LQ : 0;
+    const ModUpRef &ref = src_is_q ? be.qtop[levelS] : be.ptoq[levelS];
+    std::vector<uint64_t> basis(S.moduli.begin(), S.moduli.begin() + levelS + 1);
+    ModUpArgs a{};
+    a.nsrc = levelS + 1;
+    a.ndst = levelD + 1;
+    for (int i = 0; i <= levelS; i++) {
+        a.src_limb[i] = (uint8_t)i;
+        a.src_mod[i] = (uint8_t)(smod0 + i);
+        a.src_half[i] = half_product_mod(basis, S.moduli[i]);
+    }
+    for (int j = 0; j <= levelD; j++) {
+        a.dst_limb[j] = (uint8_t)(dst_limb0 + j);
+        a.dst_mod[j] = (uint8_t)(dmod0 + j);
+        a.dst_row[j] = (uint8_t)j;
+        a.dst_half[j] = half_product_mod(basis, D.moduli[j]);
+        a.dst_view[j] = 0;
+    }
+    HIP_TRY(launch_modup(be.qp, ref.on(be.pool), a, src, dst, dst, batch, be.ctx->stream));
+    return HE_OK;
+}
+int check_be_poly(const Poly &p, const BasisExtender &be, int nl, const char *who) {
+    if (p.N != be.Q->N || p.nlimbs < nl) return fail(HE_EINVAL, "%s: poly shape mismatch (needs %d limbs of degree %d)", who, nl, be.Q->N);
+    return HE_OK;
+}
+// ModDownQPtoQNTT for `batch` entries (basis_extension.go:235-256); pQ/pP NTT domain in, outQ NTT out.
+// scratch: sP [batch][levelP+1][N], sQ [batch][levelQ+1][N]
+int moddown_q_ntt(BasisExtender &be, int levelQ, int levelP, View pQ, View pP, View outQ, int batch, View sP, View sQ) {
+    hipStream_t st = be.ctx->stream;
+    // ringP.INTTLazy(p1P, buffP)
+    HIP_TRY(launch_ntt(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), pP, sP, batch, true, NTT_REDUCE_INPUT, st));
+    // ModUpPtoQ(buffP) -> buffQ
+    TRY(modup_between(be, false, levelP, levelQ, sP, sQ, 0, batch));
+    // ringQ.NTTLazy(buffQ, buffQ)
+    const bool red = modup_out_needs_reduce(std::vector<uint64_t>(be.P->moduli.begin(), be.P->moduli.begin() + levelP + 1));
+    HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), sQ, sQ, batch, false, NTT_LAZY_OUT | (red ? NTT_REDUCE_INPUT : 0), st));
+    // p2Q_i = MRed(buffQ_i + 2q_i - p1Q_i, q_i - modDownConstants[i])
+    ScalarTab s{};
+    for (int i = 0; i <= levelQ; i++) s.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
+    HIP_TRY(launch_ew(be.qp, ident_tab(levelQ + 1), EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sQ, pQ, outQ, batch, &s, nullptr, st));
+    return HE_OK;
+}
+}  // namespace
+
+int he_modup_q_to_p(he_handle hbe, int levelQ, int levelP, he_handle hq, he_handle hp) {
+    GET(be, BasisExtender, hbe, T_BE);
+    GET(pq, Poly, hq, T_POLY);
+    GET(pp, Poly, hp, T_POLY);
+    if (levelQ < 0 || levelQ >= be->LQ || levelP < 0 || levelP >= be->LP) return fail(HE_EINVAL, "he_modup_q_to_p: level out of range");
+    TRY(check_be_poly(*pq, *be, levelQ + 1, "he_modup_q_to_p"));
+    TRY(check_be_poly(*pp, *be, levelP + 1, "he_modup_q_to_p"));
+    if (pq->batch != pp->batch) return fail(HE_EINVAL, "he_modup_q_to_p: batch mismatch");
+    Scope sc(be->ctx.get());
+    return modup_between(*be, true, levelQ, levelP, pq->view(), pp->view(), 0, pq->batch);
+}
+int he_modup_p_to_q(he_handle hbe, int levelP, int levelQ, he_handle hp, he_handle hq) {
+    GET(be, BasisExtender, hbe, T_BE);
+    GET(pq, Poly, hq, T_POLY);
+    GET(pp, Poly, hp, T_POLY);
+    if (levelQ < 0 || levelQ >= be->LQ || levelP < 0 || levelP >= be->LP) return fail(HE_EINVAL, "he_modup_p_to_q: level out of range");
+    TRY(check_be_poly(*pq, *be, levelQ + 1, "he_modup_p_to_q"));
+    TRY(check_be_poly(*pp, *be, levelP + 1, "he_modup_p_to_q"));
+    if (pq->batch != pp->batch) return fail(HE_EINVAL, "he_modup_p_to_q: batch mismatch");
+    Scope sc(be->ctx.get());
+    return modup_between(*be, false, levelP, levelQ, pp->view(), pq->view(), 0, pq->batch);
+}
+static int moddown_api(he_handle hbe, int levelQ, int levelP, he_handle h1q, he_handle h1p, he_handle h2, int kind, const char *who) {
+    GET(be, BasisExtender, hbe, T_BE);
+    GET(p1q, Poly, h1q, T_POLY);
+    GET(p1p, Poly, h1p, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    if (levelQ < 0 || levelQ >= be->LQ || levelP < 0 || levelP >= be->LP) return fail(HE_EINVAL, "%s: level out of range", who);
+    TRY(check_be_poly(*p1q, *be, levelQ + 1, who));
+    TRY(check_be_poly(*p1p, *be, levelP + 1, who));
+    TRY(check_be_poly(*p2, *be, (kind == 2 ? levelP : levelQ) + 1, who));
+    if (p1q->batch != p1p->batch || p1q->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    Scope sc(be->ctx.get());
+    const int B = p1q->batch, N = be->Q->N;
+    const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
+    TRY(be->ctx->arena_reserve(wP + wQ));
+    View sP{be->ctx->arena_take(wP), (size_t)(levelP + 1) * N};
+    View sQ{be->ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
+    hipStream_t st = be->ctx->stream;
+    ScalarTab s{};
+    if (kind == 1) return moddown_q_ntt(*be, levelQ, levelP, p1q->view(), p1p->view(), p2->view(), B, sP, sQ);
+    if (kind == 0) {  // ModDownQPtoQ, basis_extension.go:215-230
+        TRY(modup_between(*be, false, levelP, levelQ, p1p->view(), sQ, 0, B));
+        for (int i = 0; i <= levelQ; i++) s.s[i] = be->Q->moduli[i] - be->md_ptoq[levelP][i];
+        HIP_TRY(launch_ew(be->qp, ident_tab(levelQ + 1), EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sQ, p1q->view(), p2->view(), B, &s, nullptr, st));
+        return HE_OK;
+    }
+    // ModDownQPtoP, basis_extension.go:262-277
+    TRY(modup_between(*be, true, levelQ, levelP, p1q->view(), sP, 0, B));
+    for (int i = 0; i <= levelP; i++) s.s[i] = be->P->moduli[i] - be->md_qtop[levelQ][i];
+    HIP_TRY(launch_ew(be->qp, ident_tab(levelP + 1, 0, 0, be->LQ), EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sP, p1p->view(), p2->view(), B, &s, nullptr, st));
+    return HE_OK;
+}
+int he_moddown_qp_to_q(he_handle be, int lq, int lp, he_handle a, he_handle b, he_handle c) { return moddown_api(be, lq, lp, a, b, c, 0, "he_moddown_qp_to_q"); }
+int he_moddown_qp_to_q_ntt(he_handle be, int lq, int lp, he_handle a, he_handle b, he_handle c) { return moddown_api(be, lq, lp, a, b, c, 1, "he_moddown_qp_to_q_ntt"); }
+int he_moddown_qp_to_p(he_handle be, int lq, int lp, he_handle a, he_handle b, he_handle c) { return moddown_api(be, lq, lp, a, b, c, 2, "he_moddown_qp_to_p"); }
+
+// ---------------------------------------------------------------------------------------
+// rlwe.Evaluator
+// ---------------------------------------------------------------------------------------
+int he_evaluator_create(he_handle hq, he_handle hp, he_handle *out) {
+    if (!out) return fail(HE_EINVAL, "he_evaluator_create: null output");
+    he_handle hbe = 0;
+    TRY(he_basis_extender_create(hq, hp, &hbe));
+    auto be = get<BasisExtender>(hbe, T_BE);
+    {  // the evaluator owns its extender; drop the public handle
+        std::lock_guard<std::mutex> l(g_mu);
+        g_objs.erase(hbe);
+    }
+    auto ev = std::make_shared<Evaluator>();
+    ev->be = be;
+    const int LQ = be->LQ, LP = be->LP;
+    const std::vector<uint64_t> &Q = be->Q->moduli, &P = be->P->moduli;
+    // NewDecomposer (ring/basis_extension.go:320-377): for nbPi = 2..LP
+    ev->dec.resize(LP > 1 ? LP - 1 : 0);
+    for (int lvlP = 0; lvlP < LP - 1; lvlP++) {
+        const int nbPi = lvlP + 2;
+        const int nd = (LQ + nbPi - 1) / nbPi;
+        ev->dec[lvlP].resize(nd);
+        std::vector<uint64_t> D(Q);
+        D.insert(D.end(), P.begin(), P.begin() + nbPi);
+        for (int i = 0; i < nd; i++) {
+            int xnb = nbPi;
+            if (i == nd - 1 && LQ % nbPi != 0) xnb = LQ % nbPi;
+            for (int j = 0; j < xnb - 1; j++) {
+                std::vector<uint64_t> S(Q.begin() + i * nbPi, Q.begin() + i * nbPi + j + 2);
+                ev->dec[lvlP][i].push_back(pool_modup(ev->pool, S, D));
+            }
+        }
+    }
+    Scope sc(be->ctx.get());
+    TRY(ev->pool.upload());
+    *out = reg(ev);
+    return HE_OK;
+}
+int he_evaluator_destroy(he_handle h) { return unreg(h, T_EVAL); }
+
+int he_evk_create(he_handle hev, int beta, int nQk, int nPk, const uint64_t *q, const uint64_t *p, he_handle *out) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    BasisExtender &be = *ev->be;
+    if (!q || !p || !out || beta <= 0 || nQk <= 0 || nQk > be.LQ || nPk <= 0 || nPk > be.LP)
+        return fail(HE_EINVAL, "he_evk_create: bad key shape (beta=%d, nQk=%d, nPk=%d)", beta, nQk, nPk);
+    auto k = std::make_shared<Evk>();
+    k->ev = ev; k->beta = beta; k->nQk = nQk; k->nPk = nPk;
+    Scope sc(be.ctx.get());
+    const size_t N = be.Q->N, blk = (size_t)(nQk + nPk) * N;
+    HIP_TRY(hipMalloc((void **)&k->d, (size_t)beta * 2 * blk * 8));
+    for (int d = 0; d < beta; d++)
+        for (int kk = 0; kk < 2; kk++) {
+            uint64_t *dst = k->d + ((size_t)d * 2 + kk) * blk;
+            HIP_TRY(hipMemcpyAsync(dst, q + ((size_t)d * 2 + kk) * nQk * N, (size_t)nQk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)nQk * N, p + ((size_t)d * 2 + kk) * nPk * N, (size_t)nPk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
+        }
+    HIP_TRY(hipStreamSynchronize(be.ctx->stream));
+    *out = reg(k);
+    return HE_OK;
+}
+int he_evk_destroy(he_handle h) { return unreg(h, T_EVK); }
+
+namespace {
+// BaseRNSDecompositionVectorSize, core/rlwe/params.go:543-550
+int base_rns_size(int levelQ, int levelP) { return (levelQ + levelP + 1) / (levelP + 1); }
+
+// DecomposeAndSplit for one digit (ring/basis_extension.go:381-502): coefficient-domain src
+// (limbs of ringQ) -> dstQ limbs (dstQ_limb0 + j) and dstP limbs (dstP_limb0 + j).
+// own_too: for single-limb digits the reference also rewrites the digit's own limb.
+int decompose_digit(Evaluator &ev, int levelQ, int levelP, int nbPi, int digit, View src, View dstQ, int dstQ_limb0, View dstP,
+                    int dstP_limb0, int batch) {
+    BasisExtender &be = *ev.be;
+    const int LQ = be.LQ;
+    const int st = digit * nbPi;
+    int ed = st + nbPi;
+    if (ed > levelQ + 1) ed = levelQ + 1;
+    if (st > levelQ) return fail(HE_EINVAL, "DecomposeAndSplit: digit %d out of range at levelQ %d", digit, levelQ);
+    int decompLvl;
+    if (levelQ > nbPi * (digit + 1) - 1) decompLvl = nbPi - 2;
+    else decompLvl = (levelQ % nbPi) - 1;
+    ModUpArgs a{};
+    int n = 0;
+    const bool single = decompLvl < 0;
+    std::vector<uint64_t> basis(be.Q->moduli.begin() + st, be.Q->moduli.begin() + ed);
+    for (int j = 0; j <= levelQ; j++) {
+        if (!single && j >= st && j < ed) continue;
+        a.dst_limb[n] = (uint8_t)(dstQ_limb0 + j); a.dst_mod[n] = (uint8_t)j; a.dst_row[n] = (uint8_t)j; a.dst_view[n] = 0;
+        a.dst_half[n] = single ? 0 : half_product_mod(basis, be.Q->moduli[j]);
+        n++;
+    }
+    for (int j = 0; j <= levelP; j++) {
+        a.dst_limb[n] = (uint8_t)(dstP_limb0 + j); a.dst_mod[n] = (uint8_t)(LQ + j); a.dst_row[n] = (uint8_t)(LQ + j); a.dst_view[n] = 1;
+        a.dst_half[n] = single ? 0 : half_product_mod(basis, be.P->moduli[j]);
+        n++;
+    }
+    a.ndst = n;
+    if (single) {
+        a.nsrc = 1; a.src_limb[0] = (uint8_t)st; a.src_mod[0] = (uint8_t)st;
+        HIP_TRY(launch_center_copy(be.qp, a, src, dstQ, dstP, batch, be.ctx->stream));
+        return HE_OK;
+    }
+    if (nbPi < 2 || nbPi - 2 >= (int)ev.dec.size() || digit >= (int)ev.dec[nbPi - 2].size() || decompLvl >= (int)ev.dec[nbPi - 2][digit].size())
+        return fail(HE_EINVAL, "DecomposeAndSplit: no constants for nbPi=%d digit=%d", nbPi, digit);
+    const ModUpRef &ref = ev.dec[nbPi - 2][digit][decompLvl];
+    a.nsrc = ed - st;
+    for (int i = 0; i < a.nsrc; i++) {
+        a.src_limb[i] = (uint8_t)(st + i); a.src_mod[i] = (uint8_t)(st + i);
+        a.src_half[i] = half_product_mod(basis, be.Q->moduli[st + i]);
+    }
+    HIP_TRY(launch_modup(be.qp, ref.on(ev.pool), a, src, dstQ, dstP, batch, be.ctx->stream));
+    return HE_OK;
+}
+
+// DecomposeNTT (core/rlwe/evaluator_gadget_product.go:459-510) into a Decomp buffer.
+// c2ntt / c2inv: NTT-domain and coefficient-domain views of the input (levelQ+1 limbs).
+int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2ntt, View c2inv, uint64_t *dec, size_t dec_bs,
+                       size_t dec_ds, int batch) {
+    BasisExtender &be = *ev.be;
+    const int LQ = be.LQ;
+    const int beta = base_rns_size(levelQ, levelP);
+    hipStream_t st = be.ctx->stream;
+    for (int d = 0; d < beta; d++) {
+        View blk{dec + (size_t)d * dec_ds, dec_bs};
+        TRY(decompose_digit(ev, levelQ, levelP, nbPi, d, c2inv, blk, 0, blk, LQ, batch));
+        const int s0 = d * nbPi, e0 = std::min(s0 + nbPi, levelQ + 1);
+        LimbTab t;  // NTT of every limb except the digit's own
+        t.n = 0;
+        for (int j = 0; j <= levelQ; j++) {
+            if (j >= s0 && j < e0) continue;
+            t.in_limb[t.n] = t.out_limb[t.n] = t.mod[t.n] = (uint8_t)j;
+            t.n++;
+        }
+        for (int j = 0; j <= levelP; j++) {
+            t.in_limb[t.n] = t.out_limb[t.n] = t.mod[t.n] = (uint8_t)(LQ + j);
+            t.n++;
+        }
+        const bool red = modup_out_needs_reduce(std::vector<uint64_t>(be.Q->moduli.begin() + s0, be.Q->moduli.begin() + e0));
+        HIP_TRY(launch_ntt(be.qp, t, blk, blk, batch, false, red ? NTT_REDUCE_INPUT : 0, st));
+        // own limbs: copy of the NTT-domain input                         evaluator_gadget_product.go:498-503
+        HIP_TRY(launch_ew(be.qp, ident_tab(e0 - s0, s0, s0, s0), EW_COPY, c2ntt, c2ntt, blk, batch, nullptr, nullptr, st));
+    }
+    return HE_OK;
+}
+
+// inner product of a decomposition with a key (gadgetProductMultiplePLazyHoisted :401-453)
+int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View o0Q,
+             View o0P, View o1Q, View o1P, int batch) {
+    BasisExtender &be = *ev.be;
+    const int LQ = be.LQ, N = be.Q->N;
+    KsArgs a{};
+    a.beta = base_rns_size(levelQ, levelP);
+    if (a.beta > k.beta) return fail(HE_EINVAL, "gadget product: key has %d digits, %d needed", k.beta, a.beta);
+    int n = 0;
+    for (int j = 0; j <= levelQ; j++) {
+        a.dec_limb[n] = (uint8_t)j; a.key_limb[n] = (uint8_t)j; a.out_limb[n] = (uint8_t)j; a.out_view[n] = 0; a.mod[n] = (uint8_t)j; n++;
+    }
+    for (int j = 0; j <= levelP; j++) {
+        a.dec_limb[n] = (uint8_t)(LQ + j); a.key_limb[n] = (uint8_t)(k.nQk + j); a.out_limb[n] = (uint8_t)j; a.out_view[n] = 1;
+        a.mod[n] = (uint8_t)(LQ + j); n++;
+    }
+    a.nlimbs = n;
+    a.dec_dstride = dec_ds;
+    a.key_kstride = (size_t)(k.nQk + k.nPk) * N;
+    a.key_dstride = 2 * a.key_kstride;
+    HIP_TRY(launch_ks_inner(be.qp, a, View{const_cast<uint64_t *>(dec), dec_bs}, k.d, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
+    return HE_OK;
+}
+
+struct KsScratch {  // per gadget product, for `batch` entries
+    uint64_t *cxinv;       // [batch][levelQ+1][N]
+    uint64_t *dec;         // [batch][beta][LQ+LP][N]
+    uint64_t *accP;        // [2][batch][levelP+1][N]
+    uint64_t *accQ;        // [2][batch][levelQ+1][N]
+    uint64_t *sP, *sQ;     // moddown scratch, [2*batch] entries
+};
+size_t ks_scratch_words(const BasisExtender &be, int levelQ, int levelP, int batch, bool need_dec) {
+    const size_t N = be.Q->N, B = batch;
+    const size_t beta = base_rns_size(levelQ, levelP);
+    size_t w = 0;
+    if (need_dec) w += B * (levelQ + 1) * N + B * beta * (be.LQ + be.LP) * N;
+    w += 2 * B * (levelP + 1) * N * 2 + 2 * B * (levelQ + 1) * N * 2;
+    return w + 64;
+}
+}  // namespace
+
+int he_decompose_and_split(he_handle hev, int levelQ, int levelP, int nbPi, int digit, he_handle h0, he_handle h1q, he_handle h1p) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(p0, Poly, h0, T_POLY);
+    GET(p1q, Poly, h1q, T_POLY);
+    GET(p1p, Poly, h1p, T_POLY);
+    BasisExtender &be = *ev->be;
+    if (levelQ < 0 || levelQ >= be.LQ || levelP < 0 || levelP >= be.LP || nbPi < 1 || digit < 0)
+        return fail(HE_EINVAL, "he_decompose_and_split: bad level/digit");
+    TRY(check_be_poly(*p0, be, levelQ + 1, "he_decompose_and_split"));
+    TRY(check_be_poly(*p1q, be, levelQ + 1, "he_decompose_and_split"));
+    TRY(check_be_poly(*p1p, be, levelP + 1, "he_decompose_and_split"));
+    if (p0->batch != p1q->batch || p0->batch != p1p->batch) return fail(HE_EINVAL, "he_decompose_and_split: batch mismatch");
+    Scope sc(be.ctx.get());
+    return decompose_digit(*ev, levelQ, levelP, nbPi, digit, p0->view(), p1q->view(), 0, p1p->view(), 0, p0->batch);
+}
+
+int he_decomp_create(he_handle hev, int batch, he_handle *out) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    if (batch <= 0 || !out) return fail(HE_EINVAL, "he_decomp_create: bad batch");
+    BasisExtender &be = *ev->be;
+    auto d = std::make_shared<Decomp>();
+    d->ev = ev;
+    d->batch = batch;
+    d->beta_max = base_rns_size(be.LQ - 1, be.LP - 1);  // digits at (max levelQ, max levelP)
+    d->width = be.LQ + be.LP;
+    Scope sc(be.ctx.get());
+    const size_t bytes = (size_t)batch * d->bstride() * 8;
+    hipError_t e = hipMalloc((void **)&d->d, bytes);
+    if (e != hipSuccess) return fail(HE_ENOMEM, "he_decomp_create: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    *out = reg(d);
+    return HE_OK;
+}
+int he_decomp_destroy(he_handle h) { return unreg(h, T_DECOMP); }
+int he_decomp_download_limb(he_handle h, int b, int digit, int is_p, int limb, uint64_t *dst) {
+    GET(d, Decomp, h, T_DECOMP);
+    BasisExtender &be = *d->ev->be;
+    if (!dst || b < 0 || b >= d->batch || digit < 0 || digit >= d->beta_max || limb < 0 || limb >= (is_p ? be.LP : be.LQ))
+        return fail(HE_EINVAL, "he_decomp_download_limb: bad index");
+    Scope sc(be.ctx.get());
+    const uint64_t *src = d->d + (size_t)b * d->bstride() + (size_t)digit * d->dstride() + (size_t)((is_p ? be.LQ : 0) + limb) * be.Q->N;
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)be.Q->N * 8, hipMemcpyDeviceToHost, be.ctx->stream));
+    HIP_TRY(hipStreamSynchronize(be.ctx->stream));
+    return HE_OK;
+}
+
+int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle hc2, int c2_is_ntt, he_handle hdec) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(c2, Poly, hc2, T_POLY);
+    GET(dec, Decomp, hdec, T_DECOMP);
+    BasisExtender &be = *ev->be;
+    if (dec->ev != ev) return fail(HE_EINVAL, "he_decompose_ntt: decomposition buffer belongs to another evaluator");
+    if (levelQ < 0 || levelQ >= be.LQ || levelP < 0 || levelP >= be.LP) return fail(HE_EINVAL, "he_decompose_ntt: level out of range");
+    TRY(check_be_poly(*c2, be, levelQ + 1, "he_decompose_ntt"));
+    if (c2->batch != dec->batch) return fail(HE_EINVAL, "he_decompose_ntt: batch mismatch");
+    if (base_rns_size(levelQ, levelP) > dec->beta_max) return fail(HE_EINVAL, "he_decompose_ntt: too many digits");
+    Scope sc(be.ctx.get());
+    const int B = c2->batch, N = be.Q->N;
+    const size_t w = (size_t)B * (levelQ + 1) * N;
+    TRY(be.ctx->arena_reserve(w));
+    View other{be.ctx->arena_take(w), (size_t)(levelQ + 1) * N};
+    View ntt = c2->view(), inv = other;
+    if (c2_is_ntt) {
+        HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), c2->view(), other, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+    } else {
+        HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), c2->view(), other, B, false, NTT_REDUCE_INPUT, be.ctx->stream));
+        ntt = other; inv = c2->view();
+    }
+    return decompose_ntt_into(*ev, levelQ, levelP, nbPi, ntt, inv, dec->d, dec->bstride(), dec->dstride(), B);
+}
+
+namespace {
+struct QPOut {
+    std::shared_ptr<Poly> q0, p0, q1, p1;
+};
+int get_qp_out(he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, const BasisExtender &be, int levelQ, int levelP, int batch,
+               QPOut &o, const char *who) {
+    o.q0 = get<Poly>(c0Q, T_POLY); o.p0 = get<Poly>(c0P, T_POLY); o.q1 = get<Poly>(c1Q, T_POLY); o.p1 = get<Poly>(c1P, T_POLY);
+    if (!o.q0 || !o.p0 || !o.q1 || !o.p1) return fail(HE_EHANDLE, "%s: bad output poly handle", who);
+    TRY(check_be_poly(*o.q0, be, levelQ + 1, who));
+    TRY(check_be_poly(*o.q1, be, levelQ + 1, who));
+    TRY(check_be_poly(*o.p0, be, levelP + 1, who));
+    TRY(check_be_poly(*o.p1, be, levelP + 1, who));
+    if (o.q0->batch != batch || o.q1->batch != batch || o.p0->batch != batch || o.p1->batch != batch)
+        return fail(HE_EINVAL, "%s: batch mismatch", who);
+    return HE_OK;
+}
+
+// GadgetProductLazy core: cx (NTT) -> accumulators (views).  Scratch from the arena.
+int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P) {
+    BasisExtender &be = *ev.be;
+    const int levelP = k.nPk - 1, N = be.Q->N;
+    const int beta = base_rns_size(levelQ, levelP);
+    const size_t wq = (size_t)B * (levelQ + 1) * N, ds = (size_t)(be.LQ + be.LP) * N, bs = (size_t)beta * ds;
+    uint64_t *cxinv = be.ctx->arena_take(wq);
+    uint64_t *dec = be.ctx->arena_take((size_t)B * bs);
+    View inv{cxinv, (size_t)(levelQ + 1) * N};
+    HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+    TRY(decompose_ntt_into(ev, levelQ, levelP, levelP + 1, cx, inv, dec, bs, ds, B));
+    return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
+}
+// Evaluator.ModDown (NTT/NTT branch): both components
+int moddown_pair(Evaluator &ev, int levelQ, int levelP, View c0Q, View c0P, View c1Q, View c1P, View out0, View out1, int B) {
+    BasisExtender &be = *ev.be;
+    const int N = be.Q->N;
+    const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
+    View sP{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
+    View sQ{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
+    TRY(moddown_q_ntt(be, levelQ, levelP, c0Q, c0P, out0, B, sP, sQ));
+    TRY(moddown_q_ntt(be, levelQ, levelP, c1Q, c1P, out1, B, sP, sQ));
+    return HE_OK;
+}
+// full GadgetProduct into (out0, out1) views (levelQ+1 limbs each)
+int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp *hoisted, const Evk &k, View out0, View out1, int B) {
+    BasisExtender &be = *ev.be;
+    const int levelP = k.nPk - 1, N = be.Q->N;
+    const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
+    View a0Q{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N}, a1Q{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
+    View a0P{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N}, a1P{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
+    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P));
+    else TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
+    return moddown_pair(ev, levelQ, levelP, a0Q, a0P, a1Q, a1P, out0, out1, B);
+}
+int check_key(const Evaluator &ev, const Evk &k, int &levelQ, const char *who) {
+    if (k.ev.get() != &ev) return fail(HE_EINVAL, "%s: key belongs to another evaluator", who);
+    if (levelQ < 0) return fail(HE_EINVAL, "%s: negative level", who);
+    levelQ = std::min(levelQ, k.nQk - 1);  // utils.Min(levelQ, gadgetCt.LevelQ())
+    return HE_OK;
+}
+}  // namespace
+
+int he_gadget_product_lazy(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(cx, Poly, hcx, T_POLY);
+    GET(k, Evk, hk, T_EVK);
+    BasisExtender &be = *ev->be;
+    TRY(check_key(*ev, *k, levelQ, "he_gadget_product_lazy"));
+    TRY(check_be_poly(*cx, be, levelQ + 1, "he_gadget_product_lazy"));
+    QPOut o;
+    TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, cx->batch, o, "he_gadget_product_lazy"));
+    Scope sc(be.ctx.get());
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true)));
+    return gadget_product_lazy_core(*ev, levelQ, cx->view(), cx->batch, *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view());
+}
+int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he_handle hk, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(dec, Decomp, hdec, T_DECOMP);
+    GET(k, Evk, hk, T_EVK);
+    BasisExtender &be = *ev->be;
+    TRY(check_key(*ev, *k, levelQ, "he_gadget_product_hoisted_lazy"));
+    QPOut o;
+    TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, dec->batch, o, "he_gadget_product_hoisted_lazy"));
+    Scope sc(be.ctx.get());
+    return ks_inner(*ev, levelQ, k->nPk - 1, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), dec->batch);
+}
+int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, he_handle hout0, he_handle hout1) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(out0, Poly, hout0, T_POLY);
+    GET(out1, Poly, hout1, T_POLY);
+    BasisExtender &be = *ev->be;
+    if (levelQ < 0 || levelQ >= be.LQ || levelP < 0 || levelP >= be.LP) return fail(HE_EINVAL, "he_moddown: level out of range");
+    QPOut o;
+    TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, levelP, out0->batch, o, "he_moddown"));
+    TRY(check_be_poly(*out0, be, levelQ + 1, "he_moddown"));
+    TRY(check_be_poly(*out1, be, levelQ + 1, "he_moddown"));
+    if (out1->batch != out0->batch) return fail(HE_EINVAL, "he_moddown: batch mismatch");
+    Scope sc(be.ctx.get());
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, levelP, out0->batch, false)));
+    return moddown_pair(*ev, levelQ, levelP, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), out0->view(), out1->view(), out0->batch);
+}
+int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he_handle hout0, he_handle hout1) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(cx, Poly, hcx, T_POLY);
+    GET(k, Evk, hk, T_EVK);
+    GET(out0, Poly, hout0, T_POLY);
+    GET(out1, Poly, hout1, T_POLY);
+    BasisExtender &be = *ev->be;
+    TRY(check_key(*ev, *k, levelQ, "he_gadget_product"));
+    TRY(check_be_poly(*cx, be, levelQ + 1, "he_gadget_product"));
+    TRY(check_be_poly(*out0, be, levelQ + 1, "he_gadget_product"));
+    TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product"));
+    if (out0->batch != cx->batch || out1->batch != cx->batch) return fail(HE_EINVAL, "he_gadget_product: batch mismatch");
+    Scope sc(be.ctx.get());
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true)));
+    const View cxv = cx->view();
+    return gadget_product_core(*ev, levelQ, &cxv, nullptr, *k, out0->view(), out1->view(), cx->batch);
+}
+int he_gadget_product_hoisted(he_handle hev, int levelQ, he_handle hdec, he_handle hk, he_handle hout0, he_handle hout1) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(dec, Decomp, hdec, T_DECOMP);
+    GET(k, Evk, hk, T_EVK);
+    GET(out0, Poly, hout0, T_POLY);
+    GET(out1, Poly, hout1, T_POLY);
+    BasisExtender &be = *ev->be;
+    TRY(check_key(*ev, *k, levelQ, "he_gadget_product_hoisted"));
+    TRY(check_be_poly(*out0, be, levelQ + 1, "he_gadget_product_hoisted"));
+    TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product_hoisted"));
+    if (out0->batch != dec->batch || out1->batch != dec->batch) return fail(HE_EINVAL, "he_gadget_product_hoisted: batch mismatch");
+    Scope sc(be.ctx.get());
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, dec->batch, false)));
+    return gadget_product_core(*ev, levelQ, nullptr, dec.get(), *k, out0->view(), out1->view(), dec->batch);
+}
+
+// Relinearize (core/rlwe/evaluator_evaluationkey.go:117-148)
+int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_handle hin2, he_handle hk, he_handle hout0, he_handle hout1) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(in0, Poly, hin0, T_POLY);
+    GET(in1, Poly, hin1, T_POLY);
+    GET(in2, Poly, hin2, T_POLY);
+    GET(k, Evk, hk, T_EVK);
+    GET(out0, Poly, hout0, T_POLY);
+    GET(out1, Poly, hout1, T_POLY);
+    BasisExtender &be = *ev->be;
+    TRY(check_key(*ev, *k, level, "he_relinearize"));
+    for (Poly *p : {in0.get(), in1.get(), in2.get(), out0.get(), out1.get()}) {
+        TRY(check_be_poly(*p, be, level + 1, "he_relinearize"));
+        if (p->batch != in0->batch) return fail(HE_EINVAL, "he_relinearize: batch mismatch");
+    }
+    Scope sc(be.ctx.get());
+    const int B = in0->batch, N = be.Q->N;
+    const size_t wQ = (size_t)B * (level + 1) * N;
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true) + 2 * wQ));
+    View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
+    const View in2v = in2->view();
+    TRY(gadget_product_core(*ev, level, &in2v, nullptr, *k, t0, t1, B));
+    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, in0->view(), t0, out0->view(), B, nullptr, nullptr, be.ctx->stream));
+    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, in1->view(), t1, out1->view(), B, nullptr, nullptr, be.ctx->stream));
+    return HE_OK;
+}
+
+// Automorphism / AutomorphismHoisted (core/rlwe/evaluator_automorphism.go:13-100), NTT domain
+static int automorphism_common(he_handle hev, int level, he_handle hin0, he_handle hin1, he_handle hdec, uint64_t gal, he_handle hk,
+                               he_handle hout0, he_handle hout1, const char *who) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(in0, Poly, hin0, T_POLY);
+    GET(k, Evk, hk, T_EVK);
+    GET(out0, Poly, hout0, T_POLY);
+    GET(out1, Poly, hout1, T_POLY);
+    std::shared_ptr<Poly> in1;
+    std::shared_ptr<Decomp> dec;
+    if (hdec) { dec = get<Decomp>(hdec, T_DECOMP); if (!dec) return fail(HE_EHANDLE, "%s: bad decomposition handle", who); }
+    else { in1 = get<Poly>(hin1, T_POLY); if (!in1) return fail(HE_EHANDLE, "%s: bad poly handle", who); }
+    BasisExtender &be = *ev->be;
+    TRY(check_key(*ev, *k, level, who));
+    TRY(check_be_poly(*in0, be, level + 1, who));
+    TRY(check_be_poly(*out0, be, level + 1, who));
+    TRY(check_be_poly(*out1, be, level + 1, who));
+    if (in1) TRY(check_be_poly(*in1, be, level + 1, who));
+    const int B = in0->batch;
+    if (out0->batch != B || out1->batch != B || (in1 && in1->batch != B) || (dec && dec->batch != B)) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    if (!(gal & 1)) return fail(HE_EINVAL, "%s: Galois element must be odd", who);
+    Scope sc(be.ctx.get());
+    const int N = be.Q->N;
+    const size_t wQ = (size_t)B * (level + 1) * N;
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, !dec) + 2 * wQ + (size_t)N));
+    View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
+    uint32_t *index = reinterpret_cast<uint32_t *>(be.ctx->arena_take((size_t)N / 2 + 2));
+    hipStream_t st = be.ctx->stream;
+    HIP_TRY(launch_build_automorphism_index(be.Q->logN, gal, index, st));
+    View in1v{nullptr, 0};
+    if (in1) in1v = in1->view();
+    TRY(gadget_product_core(*ev, level, in1 ? &in1v : nullptr, dec ? dec.get() : nullptr, *k, t0, t1, B));
+    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, t0, in0->view(), t0, B, nullptr, nullptr, st));
+    HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t0, index, out0->view(), B, false, st));
+    HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t1, index, out1->view(), B, false, st));
+    return HE_OK;
+}
+int he_automorphism_ct(he_handle ev, int level, he_handle in0, he_handle in1, uint64_t gal, he_handle gk, he_handle out0, he_handle out1) {
+    return automorphism_common(ev, level, in0, in1, 0, gal, gk, out0, out1, "he_automorphism_ct");
+}
+int he_automorphism_hoisted(he_handle ev, int level, he_handle in0, he_handle dec, uint64_t gal, he_handle gk, he_handle out0, he_handle out1) {
+    if (!dec) return fail(HE_EHANDLE, "he_automorphism_hoisted: null decomposition handle");
+    return automorphism_common(ev, level, in0, 0, dec, gal, gk, out0, out1, "he_automorphism_hoisted");
+}
+
+// CKKS mulRelin / BGV tensorStandard (schemes/ckks/evaluator.go:764-872, schemes/bgv/evaluator.go:592-685)
+static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_handle ha0, he_handle ha1, he_handle hb0, he_handle hb1,
+                            he_handle hk, he_handle hout0, he_handle hout1, he_handle hout2, const char *who) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(a0, Poly, ha0, T_POLY);
+    GET(a1, Poly, ha1, T_POLY);
+    GET(b0, Poly, hb0, T_POLY);
+    GET(b1, Poly, hb1, T_POLY);
+    GET(out0, Poly, hout0, T_POLY);
+    GET(out1, Poly, hout1, T_POLY);
+    std::shared_ptr<Evk> k;
+    std::shared_ptr<Poly> out2;
+    BasisExtender &be = *ev->be;
+    if (level < 0 || level >= be.LQ) return fail(HE_EINVAL, "%s: level out of range", who);
+    if (hk) {
+        k = get<Evk>(hk, T_EVK);
+        if (!k) return fail(HE_EHANDLE, "%s: bad relinearization key handle", who);
+        int lv = level;
+        TRY(check_key(*ev, *k, lv, who));
+        if (lv != level) return fail(HE_EINVAL, "%s: relinearization key level %d below ciphertext level %d", who, k->nQk - 1, level);
+    } else {
+        out2 = get<Poly>(hout2, T_POLY);
+        if (!out2) return fail(HE_EHANDLE, "%s: out2 required when no relinearization key is given", who);
+    }
+    const int B = a0->batch;
+    for (Poly *p : {a0.get(), a1.get(), b0.get(), b1.get(), out0.get(), out1.get(), out2.get()}) {
+        if (!p) continue;
+        TRY(check_be_poly(*p, be, level + 1, who));
+        if (p->batch != B) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    }
+    std::vector<uint64_t> sc_(level + 1);
+    for (int i = 0; i <= level; i++) {
+        const ModConst &m = be.Q->sub[i].mc;
+        if (bgv) {  // tMontgomery = MForm(t * 2^64 mod q)                     schemes/bgv/evaluator.go:59-62
+            const uint64_t w[2] = {0, t};
+            sc_[i] = mform(words_mod(w, 2, m.q), m.q, m.brc0, m.brc1);
+        } else {    // MForm(x) = MRed(x, 2^128 mod q)
+            sc_[i] = m.r2;
+        }
+    }
+    Scope sc(be.ctx.get());
+    const int N = be.Q->N;
+    const size_t wQ = (size_t)B * (level + 1) * N;
+    hipStream_t st = be.ctx->stream;
+    if (!k) {
+        HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),
+                              out1->view(), out2->view(), B, st));
+        return HE_OK;
+    }
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true) + 3 * wQ));
+    View c2{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
+    View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
+    HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),
+                          out1->view(), c2, B, st));
+    TRY(gadget_product_core(*ev, level, &c2, nullptr, *k, t0, t1, B));
+    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, out0->view(), t0, out0->view(), B, nullptr, nullptr, st));
+    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, out1->view(), t1, out1->view(), B, nullptr, nullptr, st));
+    return HE_OK;
+}
+int he_ckks_mul_relin(he_handle ev, int level, he_handle a0, he_handle a1, he_handle b0, he_handle b1, he_handle rlk, he_handle o0, he_handle o1, he_handle o2) {
+    return mul_relin_common(ev, level, false, 0, a0, a1, b0, b1, rlk, o0, o1, o2, "he_ckks_mul_relin");
+}
+int he_bgv_mul_relin(he_handle ev, int level, uint64_t t, he_handle a0, he_handle a1, he_handle b0, he_handle b1, he_handle rlk, he_handle o0, he_handle o1, he_handle o2) {
+    return mul_relin_common(ev, level, true, t, a0, a1, b0, b1, rlk, o0, o1, o2, "he_bgv_mul_relin");
+}
+
+// ---------------------------------------------------------------------------------------
+// diagnostics
+// ---------------------------------------------------------------------------------------
+int he_probe_modmul(he_handle hctx, int iters, double *out) {
+    GET(c, Ctx, hctx, T_CTX);
+    if (!out || iters <= 0) return fail(HE_EINVAL, "he_probe_modmul: bad arguments");
+    Scope sc(c.get());
+    const size_t n = (size_t)1 << 24;
+    TRY(c->arena_reserve(n));
+    uint64_t *buf = c->arena_take(n);
+    HIP_TRY(hipMemsetAsync(buf, 0x5a, n * 8, c->stream));
+    const uint64_t q = 0x1fffffffffe00001ull;
+    uint64_t inv = q;
+    for (int i = 0; i < 6; i++) inv *= 2 - q * inv;
+    HIP_TRY(launch_modmul_probe(buf, n, 8, q, inv, c->stream));  // warm-up
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_modmul_probe(buf, n, iters, q, inv, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *out = (double)n * iters / (ms * 1e-3);
+    return HE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (implemented in kernels.hip).
+// All launchers enqueue on the given stream and return the hipError_t of the launch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "modarith.h"
+
+namespace he {
+
+constexpr int kMaxLimbs = 64;  // limbs addressed by one launch
+
+// Which limbs a launch touches: entry y of the grid's y-dimension reads limb in_limb[y]
+// of the input view(s), writes limb out_limb[y] and uses modulus record mod[y].
+struct LimbTab {
+    int n;
+    uint8_t in_limb[kMaxLimbs];
+    uint8_t out_limb[kMaxLimbs];
+    uint8_t mod[kMaxLimbs];
+};
+
+// A device-resident polynomial batch: limb stride N words, batch stride bstride words.
+struct View {
+    uint64_t *p;
+    size_t bstride;
+};
+
+struct RingDev {
+    int logN;
+    int N;
+    const ModConst *mc;      // [n_mod]
+    const uint64_t *tw_fwd;  // [n_mod][N] RootsForward  (Montgomery form, bit-reversed order)
+    const uint64_t *tw_inv;  // [n_mod][N] RootsBackward
+};
+
+// ---- NTT ---------------------------------------------------------------------------
+enum NttFlags {
+    NTT_REDUCE_INPUT = 1,  // inputs are arbitrary 64-bit words: bring them to [0,2q) first
+    NTT_LAZY_OUT = 2,      // forward: leave the output in [0,2q) instead of [0,q)
+};
+hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
+                      hipStream_t s);
+
+// ---- coefficient-wise -----------------------------------------------------------------
+// op codes: 0..16 = he_binop, 100.. = he_unop, 200.. = scalar forms (scalar per limb in sc[])
+enum EwOp {
+    EW_ADD = 0, EW_ADD_LAZY, EW_SUB, EW_SUB_LAZY,
+    EW_MUL_BARRETT, EW_MUL_BARRETT_LAZY, EW_MUL_BARRETT_THEN_ADD, EW_MUL_BARRETT_THEN_ADD_LAZY,
+    EW_MUL_MONT, EW_MUL_MONT_LAZY, EW_MUL_MONT_LAZY_THEN_NEG,
+    EW_MUL_MONT_THEN_ADD, EW_MUL_MONT_THEN_ADD_LAZY, EW_MUL_MONT_LAZY_THEN_ADD_LAZY,
+    EW_MUL_MONT_THEN_SUB, EW_MUL_MONT_THEN_SUB_LAZY, EW_MUL_MONT_LAZY_THEN_SUB_LAZY,
+    EW_NEG = 100, EW_REDUCE, EW_REDUCE_LAZY, EW_MFORM, EW_MFORM_LAZY, EW_IMFORM, EW_COPY,
+    EW_ADD_SCALAR = 200,           // CRed(x + s)
+    EW_SUB_SCALAR,                 // CRed(x + q - s)
+    EW_MUL_SCALAR_MONT,            // MRed(x, s)
+    EW_MUL_SCALAR_MONT_THEN_ADD,   // CRed(z + MRed(x, s))
+    EW_ADD_SCALAR_LAZY,            // x + s
+    // rescale / moddown fused forms (two-limb inputs)
+    EW_SUB_THEN_MUL_SCALAR_MONT_2Q = 300,  // z = MRed(2q - y + x, s)          vec_ops.go:766
+    EW_DIVROUND_COEFF,                     // z = MRed(x + (s0 + 2q - y), s)    scaling.go:138-142 (x = top limb + pHalf)
+};
+struct ScalarTab {
+    uint64_t s[kMaxLimbs];   // per launch-limb scalar
+    uint64_t s2[kMaxLimbs];  // second scalar where needed
+};
+// z[out_limb] = op(x[in_limb], y[in_limb or y_limb], z)   (y uses tab.in_limb unless y_tab given)
+hipError_t launch_ew(const RingDev &r, const LimbTab &tab, int op, View x, View y, View z, int batch,
+                     const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s);
+
+// ---- automorphism ------------------------------------------------------------------------
+hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const uint32_t *index, View out, int batch,
+                         bool then_add, hipStream_t s);
+// coefficient-domain automorphism X^i -> X^(i*gal) (ring/automorphism.go:153-174)
+hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View in, uint64_t gal, View out, int batch,
+                                     hipStream_t s);
+hipError_t launch_build_automorphism_index(int logN, uint64_t gal, uint32_t *index, hipStream_t s);
+
+// ---- basis extension -----------------------------------------------------------------------
+// One constant set of GenModUpConstants (ring/basis_extension.go:101) resident on the device.
+struct ModUpDev {
+    int nsrc, ndst;
+    const uint64_t *a;         // [nsrc]           qoverqiinvqi
+    const uint64_t *T;         // [ndst][nsrc]     qoverqimodp
+    const uint64_t *vt;        // [ndst][nsrc+1]   vtimesqmodp
+};
+struct ModUpArgs {
+    int nsrc, ndst;
+    uint8_t src_limb[32], src_mod[32];
+    uint64_t src_half[32];               // added (CRed) before reconstruction; 0 = none
+    uint8_t dst_limb[kMaxLimbs], dst_mod[kMaxLimbs], dst_row[kMaxLimbs];
+    uint64_t dst_half[kMaxLimbs];        // subtracted (CRed(x + p - half)) after
+    uint8_t dst_view[kMaxLimbs];         // 0 -> dstA, 1 -> dstB
+};
+hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a, View src, View dstA, View dstB,
+                        int batch, hipStream_t s);
+// single-limb digit: centred copy into every listed limb (ring/basis_extension.go:402-436)
+hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, View dstA, View dstB, int batch,
+                              hipStream_t s);
+
+// ---- key-switch inner product ---------------------------------------------------------------
+// acc[k][l] = sum_d evk[d][k][l] * dec[d][l] * 2^-64 mod q_l, canonical
+// (core/rlwe/evaluator_gadget_product.go:160-200 after its final Reduce).
+struct KsArgs {
+    int beta;
+    int nlimbs;                       // launch limbs
+    uint8_t dec_limb[kMaxLimbs];      // limb inside one digit block of dec
+    uint8_t key_limb[kMaxLimbs];      // limb inside one (d,k) block of the key
+    uint8_t out_limb[kMaxLimbs];
+    uint8_t out_view[kMaxLimbs];      // 0 -> Q outputs, 1 -> P outputs
+    uint8_t mod[kMaxLimbs];
+    size_t dec_dstride;               // words between digits in dec
+    size_t key_kstride;               // words between k=0 and k=1 blocks
+    size_t key_dstride;               // words between digits in the key
+};
+hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, const uint64_t *key, View out0Q, View out0P,
+                           View out1Q, View out1P, int batch, hipStream_t s);
+
+// ---- ciphertext tensor product (schemes/ckks/evaluator.go:807-820, schemes/bgv/evaluator.go:634-647)
+// c0 = MRed(MRed(a0,s),b0), c2 = MRed(MRed(a1,s),b1), c1 = CRed(MRed(MRed(a0,s),b1) + MRed(MRed(a1,s),b0))
+// with the per-limb scalar s = 2^128 mod q (CKKS: MForm) or t*2^128 mod q (BGV: tMontgomery).
+hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *scalar, View a0, View a1, View b0, View b1,
+                         View c0, View c1, View c2, int batch, hipStream_t s);
+
+// throughput probe used by bench.py --microbench (not on the product path)
+hipError_t launch_modmul_probe(uint64_t *buf, size_t n, int iters, uint64_t q, uint64_t qinv, hipStream_t s);
+
+}  // namespace he

@@ -1,0 +1,802 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of libhering.
+//
+// Everything here is 64-bit integer modular arithmetic over RNS limbs: no MFMA
+// (there is no dense low-precision contraction on this path).  The design rules
+// are the HBM/LDS ones: limb-major coalesced loads, twiddles and butterfly stages
+// staged through LDS / registers, one launch covering every (limb x batch entry).
+//
+// NTT decomposition (N = 2^n, n <= 17):  a = max(0, n-12) "column" stages are done
+// in registers on elements strided by N/2^a (ntt_cols), the remaining b = n-a <= 12
+// stages on contiguous rows of 2^b coefficients held in LDS, in rounds of up to four
+// stages with 16 coefficients per thread in registers (ntt_rows).  The transform is
+// the reference's (ring/ntt.go:223-257, :570-606): Cooley-Tukey natural->bit-reversed
+// forward with twiddle RootsForward[m+i], Gentleman-Sande inverse, same tables; the
+// butterflies use the Harvey lazy form on [0,4q) / [0,2q) and only canonical
+// outputs are promised (SURVEY.md section 8a note on lazy ranges).
+#include "kernels.h"
+
+namespace he {
+
+// ------------------------------------------------------------------------------------
+// butterflies
+// ------------------------------------------------------------------------------------
+// forward: U,V in [0,4q) -> X,Y in [0,4q)
+__device__ __forceinline__ void bfly_fwd(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t twoq, uint64_t qinv) {
+    uint64_t U = a >= twoq ? a - twoq : a;
+    uint64_t V = mred_lazy(b, w, q, qinv);
+    a = U + V;
+    b = U + twoq - V;
+}
+// inverse: U,V in [0,2q) -> X,Y in [0,2q)
+__device__ __forceinline__ void bfly_inv(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t twoq, uint64_t qinv) {
+    uint64_t U = a, V = b;
+    uint64_t X = U + V;
+    a = X >= twoq ? X - twoq : X;
+    b = mred_lazy(U + twoq - V, w, q, qinv);
+}
+// last inverse stage with N^-1 folded in: outputs canonical
+__device__ __forceinline__ void bfly_inv_scaled(uint64_t &a, uint64_t &b, uint64_t wn, uint64_t ninv, uint64_t q,
+                                                uint64_t twoq, uint64_t qinv) {
+    uint64_t U = a, V = b;
+    a = mred(U + V, ninv, q, qinv);
+    b = mred(U + twoq - V, wn, q, qinv);
+}
+
+struct NttArgs {
+    const uint64_t *in;
+    uint64_t *out;
+    size_t in_bs, out_bs;
+    const ModConst *mc;
+    const uint64_t *tw;
+    int N;
+    int a;       // column stages already done (forward) / still to do (inverse)
+    int flags;
+    int scale;   // inverse: fold N^-1 into the last stage of THIS kernel
+    LimbTab tab;
+};
+
+__device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
+
+// ------------------------------------------------------------------------------------
+// ntt_rows: b = LOGB stages on one contiguous row of 2^LOGB coefficients per workgroup.
+// grid = (rows per limb = 2^a, limbs, batch), block = 2^LOGB / 16 threads.
+// ------------------------------------------------------------------------------------
+template <int LOGB, bool INV>
+__global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) ntt_rows_kernel(NttArgs A) {
+    constexpr int N2 = 1 << LOGB;
+    constexpr int T = N2 / 16;
+    constexpr int NR = (LOGB + 3) / 4;
+    __shared__ uint64_t lds[N2 + N2 / 16];
+
+    const int tau = threadIdx.x;
+    const int row = blockIdx.x;
+    const int y = blockIdx.y;
+    const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
+    const ModConst mc = A.mc[mi];
+    const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
+    const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
+    const uint64_t *__restrict__ src = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
+    uint64_t *__restrict__ dst = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
+    const int rowtw = (1 << A.a) + row;  // 2^a + r
+
+    uint64_t x[16];
+
+    if constexpr (!INV) {
+        constexpr int sh0 = LOGB - 4;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = src[(k << sh0) + tau];
+        if (A.flags & NTT_REDUCE_INPUT) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = bred_add_lazy(x[k], q, mc.brc0);
+        }
+#pragma unroll
+        for (int rho = 0; rho < NR; rho++) {
+            const int s0 = 4 * rho;
+            const int g = (LOGB - s0) < 4 ? (LOGB - s0) : 4;
+            const int G = 1 << g, W = 16 / G, sh = LOGB - s0 - g;
+            if (rho > 0) {
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
+#pragma unroll
+                    for (int k = 0; k < G; k++) x[w * G + k] = lds[lds_phys((hi << (LOGB - s0)) + (k << sh) + lo)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < g; u++) {
+                const int d = 1 << (g - 1 - u);
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    const int gamma = tau * W + w, hi = gamma >> sh;
+                    const int base = (rowtw << (s0 + u)) + (hi << u);
+#pragma unroll
+                    for (int k = 0; k < G; k++) {
+                        if (k & d) continue;
+                        const uint64_t wv = tw[base + (k >> (g - u))];
+                        bfly_fwd(x[w * G + k], x[w * G + k + d], wv, q, twoq, qinv);
+                    }
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
+#pragma unroll
+                for (int k = 0; k < G; k++) lds[lds_phys((hi << (LOGB - s0)) + (k << sh) + lo)] = x[w * G + k];
+            }
+            __syncthreads();
+        }
+        const bool lazy = (A.flags & NTT_LAZY_OUT) != 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int e = k * T + tau;
+            uint64_t v = lds[lds_phys(e)];
+            v = v >= twoq ? v - twoq : v;
+            if (!lazy) v = v >= q ? v - q : v;
+            dst[e] = v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int e = k * T + tau;
+            uint64_t v = src[e];
+            if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, q, mc.brc0);
+            lds[lds_phys(e)] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rho = NR - 1; rho >= 0; rho--) {
+            const int s0 = 4 * rho;
+            const int g = (LOGB - s0) < 4 ? (LOGB - s0) : 4;
+            const int G = 1 << g, W = 16 / G, sh = LOGB - s0 - g;
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
+#pragma unroll
+                for (int k = 0; k < G; k++) x[w * G + k] = lds[lds_phys((hi << (LOGB - s0)) + (k << sh) + lo)];
+            }
+#pragma unroll
+            for (int u = g - 1; u >= 0; u--) {
+                const int d = 1 << (g - 1 - u);
+                const bool last = A.scale && rho == 0 && u == 0;
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    const int gamma = tau * W + w, hi = gamma >> sh;
+                    const int base = (rowtw << (s0 + u)) + (hi << u);
+#pragma unroll
+                    for (int k = 0; k < G; k++) {
+                        if (k & d) continue;
+                        const uint64_t wv = tw[base + (k >> (g - u))];
+                        if (last) {
+                            const uint64_t wn = mred(wv, mc.ninv, q, qinv);
+                            bfly_inv_scaled(x[w * G + k], x[w * G + k + d], wn, mc.ninv, q, twoq, qinv);
+                        } else {
+                            bfly_inv(x[w * G + k], x[w * G + k + d], wv, q, twoq, qinv);
+                        }
+                    }
+                }
+            }
+            if (rho > 0) {
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
+#pragma unroll
+                    for (int k = 0; k < G; k++) lds[lds_phys((hi << (LOGB - s0)) + (k << sh) + lo)] = x[w * G + k];
+                }
+                __syncthreads();
+            }
+        }
+        constexpr int sh0 = LOGB - 4;
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = x[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// ntt_cols: the a = LOGA outermost stages, in registers, on elements strided by N/2^a.
+// grid = (N2/256, limbs, batch), block = 256.
+// ------------------------------------------------------------------------------------
+template <int LOGA, bool INV>
+__global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
+    constexpr int R = 1 << LOGA;
+    const int N2 = A.N >> LOGA;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N2) return;
+    const int y = blockIdx.y;
+    const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
+    const ModConst mc = A.mc[mi];
+    const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
+    const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
+    const uint64_t *__restrict__ src = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)il * A.N + c;
+    uint64_t *__restrict__ dst = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)ol * A.N + c;
+
+    uint64_t x[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) x[r] = src[(size_t)r * N2];
+    if (A.flags & NTT_REDUCE_INPUT) {
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = bred_add_lazy(x[r], q, mc.brc0);
+    }
+    if constexpr (!INV) {
+#pragma unroll
+        for (int s = 0; s < LOGA; s++) {
+            const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (r & d) continue;
+                bfly_fwd(x[r], x[r + d], tw[(1 << s) + (r >> (LOGA - s))], q, twoq, qinv);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = LOGA - 1; s >= 0; s--) {
+            const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (r & d) continue;
+                const uint64_t wv = tw[(1 << s) + (r >> (LOGA - s))];
+                if (s == 0 && A.scale) {
+                    const uint64_t wn = mred(wv, mc.ninv, q, qinv);
+                    bfly_inv_scaled(x[r], x[r + d], wn, mc.ninv, q, twoq, qinv);
+                } else {
+                    bfly_inv(x[r], x[r + d], wv, q, twoq, qinv);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) dst[(size_t)r * N2] = x[r];
+}
+
+template <bool INV>
+static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
+#define HE_ROWS_CASE(B)                                                                           \
+    case B:                                                                                       \
+        hipLaunchKernelGGL((ntt_rows_kernel<B, INV>), grid, dim3((1 << B) / 16), 0, s, A);         \
+        break;
+    switch (logb) {
+        HE_ROWS_CASE(4) HE_ROWS_CASE(5) HE_ROWS_CASE(6) HE_ROWS_CASE(7) HE_ROWS_CASE(8) HE_ROWS_CASE(9)
+        HE_ROWS_CASE(10) HE_ROWS_CASE(11) HE_ROWS_CASE(12)
+        default: return hipErrorInvalidValue;
+    }
+#undef HE_ROWS_CASE
+    return hipGetLastError();
+}
+template <bool INV>
+static hipError_t launch_cols(int loga, dim3 grid, const NttArgs &A, hipStream_t s) {
+#define HE_COLS_CASE(Av)                                                                 \
+    case Av:                                                                             \
+        hipLaunchKernelGGL((ntt_cols_kernel<Av, INV>), grid, dim3(256), 0, s, A);         \
+        break;
+    switch (loga) {
+        HE_COLS_CASE(1) HE_COLS_CASE(2) HE_COLS_CASE(3) HE_COLS_CASE(4) HE_COLS_CASE(5)
+        default: return hipErrorInvalidValue;
+    }
+#undef HE_COLS_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
+                      hipStream_t s) {
+    if (tab.n <= 0 || batch <= 0) return hipSuccess;
+    const int n = r.logN;
+    if (n < 4 || n > 17) return hipErrorInvalidValue;
+    const int a = n > 12 ? n - 12 : 0, b = n - a;
+    NttArgs A;
+    A.mc = r.mc;
+    A.N = r.N;
+    A.a = a;
+    A.tab = tab;
+    dim3 grows(1u << a, tab.n, batch);
+    dim3 gcols((unsigned)(((r.N >> a) + 255) / 256), tab.n, batch);
+    hipError_t e;
+    if (!inverse) {
+        A.tw = r.tw_fwd;
+        A.scale = 0;
+        if (a > 0) {
+            A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
+            A.flags = flags & NTT_REDUCE_INPUT;
+            if ((e = launch_cols<false>(a, gcols, A, s)) != hipSuccess) return e;
+            // second pass in place on `out`: limbs are now addressed by out_limb
+            NttArgs B = A;
+            for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
+            B.in = out.p; B.in_bs = out.bstride;
+            B.flags = flags & NTT_LAZY_OUT;
+            return launch_rows<false>(b, grows, B, s);
+        }
+        A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
+        A.flags = flags;
+        return launch_rows<false>(b, grows, A, s);
+    }
+    A.tw = r.tw_inv;
+    A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
+    A.flags = flags & NTT_REDUCE_INPUT;
+    A.scale = (a == 0);
+    if ((e = launch_rows<true>(b, grows, A, s)) != hipSuccess) return e;
+    if (a > 0) {
+        NttArgs B = A;
+        for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
+        B.in = out.p; B.in_bs = out.bstride;
+        B.flags = 0;
+        B.scale = 1;
+        return launch_cols<true>(a, gcols, B, s);
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------
+// coefficient-wise kernels (ring/vec_ops.go): one launch for all limbs x batch.
+// Each thread handles two adjacent coefficients (16-byte accesses).
+// ------------------------------------------------------------------------------------
+struct EwArgs {
+    const uint64_t *x, *y;
+    uint64_t *z;
+    size_t x_bs, y_bs, z_bs;
+    const ModConst *mc;
+    int N;
+    int n;
+    uint8_t x_limb[kMaxLimbs], y_limb[kMaxLimbs], z_limb[kMaxLimbs], mod[kMaxLimbs];
+    uint64_t s[kMaxLimbs], s2[kMaxLimbs];
+};
+
+template <int OP>
+__device__ __forceinline__ uint64_t ew_apply(uint64_t x, uint64_t y, uint64_t z, const ModConst &m, uint64_t s, uint64_t s2) {
+    const uint64_t q = m.q, qinv = m.qinv;
+    if constexpr (OP == EW_ADD) return cred(x + y, q);
+    else if constexpr (OP == EW_ADD_LAZY) return x + y;
+    else if constexpr (OP == EW_SUB) return cred((x + q) - y, q);
+    else if constexpr (OP == EW_SUB_LAZY) return x + q - y;
+    else if constexpr (OP == EW_MUL_BARRETT) return bred(x, y, q, m.brc0, m.brc1);
+    else if constexpr (OP == EW_MUL_BARRETT_LAZY) return bred_lazy(x, y, q, m.brc0, m.brc1);
+    else if constexpr (OP == EW_MUL_BARRETT_THEN_ADD) return cred(z + bred(x, y, q, m.brc0, m.brc1), q);
+    else if constexpr (OP == EW_MUL_BARRETT_THEN_ADD_LAZY) return z + bred(x, y, q, m.brc0, m.brc1);
+    else if constexpr (OP == EW_MUL_MONT) return mred(x, y, q, qinv);
+    else if constexpr (OP == EW_MUL_MONT_LAZY) return mred_lazy(x, y, q, qinv);
+    else if constexpr (OP == EW_MUL_MONT_LAZY_THEN_NEG) return (q << 1) - mred_lazy(x, y, q, qinv);
+    else if constexpr (OP == EW_MUL_MONT_THEN_ADD) return cred(z + mred(x, y, q, qinv), q);
+    else if constexpr (OP == EW_MUL_MONT_THEN_ADD_LAZY) return z + mred(x, y, q, qinv);
+    else if constexpr (OP == EW_MUL_MONT_LAZY_THEN_ADD_LAZY) return z + mred_lazy(x, y, q, qinv);
+    else if constexpr (OP == EW_MUL_MONT_THEN_SUB) return cred(z + (q - mred(x, y, q, qinv)), q);
+    else if constexpr (OP == EW_MUL_MONT_THEN_SUB_LAZY) return z + (q - mred(x, y, q, qinv));
+    else if constexpr (OP == EW_MUL_MONT_LAZY_THEN_SUB_LAZY) return z + ((q << 1) - mred_lazy(x, y, q, qinv));
+    else if constexpr (OP == EW_NEG) return q - x;
+    else if constexpr (OP == EW_REDUCE) return bred_add(x, q, m.brc0);
+    else if constexpr (OP == EW_REDUCE_LAZY) return bred_add_lazy(x, q, m.brc0);
+    else if constexpr (OP == EW_MFORM) return mform(x, q, m.brc0, m.brc1);
+    else if constexpr (OP == EW_MFORM_LAZY) return mform_lazy(x, q, m.brc0, m.brc1);
+    else if constexpr (OP == EW_IMFORM) return imform(x, q, qinv);
+    else if constexpr (OP == EW_COPY) return x;
+    else if constexpr (OP == EW_ADD_SCALAR) return cred(x + s, q);
+    else if constexpr (OP == EW_SUB_SCALAR) return cred(x + q - s, q);
+    else if constexpr (OP == EW_MUL_SCALAR_MONT) return mred(x, s, q, qinv);
+    else if constexpr (OP == EW_MUL_SCALAR_MONT_THEN_ADD) return cred(z + mred(x, s, q, qinv), q);
+    else if constexpr (OP == EW_ADD_SCALAR_LAZY) return x + s;
+    else if constexpr (OP == EW_SUB_THEN_MUL_SCALAR_MONT_2Q) return mred((q << 1) - y + x, s, q, qinv);
+    else if constexpr (OP == EW_DIVROUND_COEFF) return mred(x + (s2 + (q << 1) - y), s, q, qinv);
+    else return 0;
+}
+template <int OP>
+constexpr bool ew_reads_y() {
+    return (OP >= 0 && OP < 100) || OP == EW_SUB_THEN_MUL_SCALAR_MONT_2Q || OP == EW_DIVROUND_COEFF;
+}
+template <int OP>
+constexpr bool ew_reads_z() {
+    return OP == EW_MUL_BARRETT_THEN_ADD || OP == EW_MUL_BARRETT_THEN_ADD_LAZY || OP == EW_MUL_MONT_THEN_ADD ||
+           OP == EW_MUL_MONT_THEN_ADD_LAZY || OP == EW_MUL_MONT_LAZY_THEN_ADD_LAZY || OP == EW_MUL_MONT_THEN_SUB ||
+           OP == EW_MUL_MONT_THEN_SUB_LAZY || OP == EW_MUL_MONT_LAZY_THEN_SUB_LAZY || OP == EW_MUL_SCALAR_MONT_THEN_ADD;
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (j >= A.N) return;
+    const int yy = blockIdx.y;
+    const ModConst m = A.mc[A.mod[yy]];
+    const uint64_t s = A.s[yy], s2 = A.s2[yy];
+    const size_t bz = blockIdx.z;
+    const ulonglong2 xv = *reinterpret_cast<const ulonglong2 *>(A.x + bz * A.x_bs + (size_t)A.x_limb[yy] * A.N + j);
+    ulonglong2 yv = make_ulonglong2(0, 0), zv = make_ulonglong2(0, 0);
+    if constexpr (ew_reads_y<OP>())
+        yv = *reinterpret_cast<const ulonglong2 *>(A.y + bz * A.y_bs + (size_t)A.y_limb[yy] * A.N + j);
+    uint64_t *zp = A.z + bz * A.z_bs + (size_t)A.z_limb[yy] * A.N + j;
+    if constexpr (ew_reads_z<OP>()) zv = *reinterpret_cast<const ulonglong2 *>(zp);
+    ulonglong2 o;
+    o.x = ew_apply<OP>(xv.x, yv.x, zv.x, m, s, s2);
+    o.y = ew_apply<OP>(xv.y, yv.y, zv.y, m, s, s2);
+    *reinterpret_cast<ulonglong2 *>(zp) = o;
+}
+
+hipError_t launch_ew(const RingDev &r, const LimbTab &tab, int op, View x, View y, View z, int batch,
+                     const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s) {
+    if (tab.n <= 0 || batch <= 0) return hipSuccess;
+    EwArgs A;
+    A.x = x.p; A.y = y.p; A.z = z.p;
+    A.x_bs = x.bstride; A.y_bs = y.bstride; A.z_bs = z.bstride;
+    A.mc = r.mc; A.N = r.N; A.n = tab.n;
+    for (int i = 0; i < tab.n; i++) {
+        A.x_limb[i] = x_limb_override ? x_limb_override[i] : tab.in_limb[i];
+        A.y_limb[i] = tab.in_limb[i];
+        A.z_limb[i] = tab.out_limb[i];
+        A.mod[i] = tab.mod[i];
+        A.s[i] = sc ? sc->s[i] : 0;
+        A.s2[i] = sc ? sc->s2[i] : 0;
+    }
+    dim3 grid((unsigned)((r.N / 2 + 255) / 256), tab.n, batch), block(256);
+#define HE_EW_CASE(O) \
+    case O: hipLaunchKernelGGL((ew_kernel<O>), grid, block, 0, s, A); break;
+    switch (op) {
+        HE_EW_CASE(EW_ADD) HE_EW_CASE(EW_ADD_LAZY) HE_EW_CASE(EW_SUB) HE_EW_CASE(EW_SUB_LAZY)
+        HE_EW_CASE(EW_MUL_BARRETT) HE_EW_CASE(EW_MUL_BARRETT_LAZY) HE_EW_CASE(EW_MUL_BARRETT_THEN_ADD)
+        HE_EW_CASE(EW_MUL_BARRETT_THEN_ADD_LAZY) HE_EW_CASE(EW_MUL_MONT) HE_EW_CASE(EW_MUL_MONT_LAZY)
+        HE_EW_CASE(EW_MUL_MONT_LAZY_THEN_NEG) HE_EW_CASE(EW_MUL_MONT_THEN_ADD) HE_EW_CASE(EW_MUL_MONT_THEN_ADD_LAZY)
+        HE_EW_CASE(EW_MUL_MONT_LAZY_THEN_ADD_LAZY) HE_EW_CASE(EW_MUL_MONT_THEN_SUB)
+        HE_EW_CASE(EW_MUL_MONT_THEN_SUB_LAZY) HE_EW_CASE(EW_MUL_MONT_LAZY_THEN_SUB_LAZY)
+        HE_EW_CASE(EW_NEG) HE_EW_CASE(EW_REDUCE) HE_EW_CASE(EW_REDUCE_LAZY) HE_EW_CASE(EW_MFORM)
+        HE_EW_CASE(EW_MFORM_LAZY) HE_EW_CASE(EW_IMFORM) HE_EW_CASE(EW_COPY)
+        HE_EW_CASE(EW_ADD_SCALAR) HE_EW_CASE(EW_SUB_SCALAR) HE_EW_CASE(EW_MUL_SCALAR_MONT)
+        HE_EW_CASE(EW_MUL_SCALAR_MONT_THEN_ADD) HE_EW_CASE(EW_ADD_SCALAR_LAZY)
+        HE_EW_CASE(EW_SUB_THEN_MUL_SCALAR_MONT_2Q) HE_EW_CASE(EW_DIVROUND_COEFF)
+        default: return hipErrorInvalidValue;
+    }
+#undef HE_EW_CASE
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// automorphism
+// ------------------------------------------------------------------------------------
+struct GatherArgs {
+    const uint64_t *in;
+    uint64_t *out;
+    size_t in_bs, out_bs;
+    const uint32_t *index;
+    int N;
+    uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs];
+};
+// out[l][j] (+)= in[l][index[j]]   (ring/automorphism.go:50-109); index shared by all limbs
+template <bool ADD>
+__global__ void __launch_bounds__(256) gather_kernel(GatherArgs A) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= A.N) return;
+    const uint32_t src = A.index[j];
+    const uint64_t *in = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N;
+    uint64_t *out = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N;
+    const uint64_t v = in[src];
+    if (ADD) out[j] += v; else out[j] = v;
+}
+hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const uint32_t *index, View out, int batch,
+                         bool then_add, hipStream_t s) {
+    if (tab.n <= 0 || batch <= 0) return hipSuccess;
+    GatherArgs A;
+    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.index = index; A.N = r.N;
+    for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; }
+    dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
+    if (then_add) hipLaunchKernelGGL((gather_kernel<true>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((gather_kernel<false>), grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+// index[i] = bitrev(((gal*(2*bitrev(i)+1) & (2N-1)) - 1) >> 1)   (ring/automorphism.go:12-34)
+__global__ void build_index_kernel(int logN, uint64_t gal, uint32_t *index) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t N = 1u << logN;
+    if (i >= N) return;
+    const uint64_t mask = 2ull * N - 1;
+    const uint64_t t1 = 2 * (__brevll((uint64_t)i) >> (64 - logN)) + 1;
+    const uint64_t t2 = (((gal * t1) & mask) - 1) >> 1;
+    index[i] = (uint32_t)(__brevll(t2) >> (64 - logN));
+}
+hipError_t launch_build_automorphism_index(int logN, uint64_t gal, uint32_t *index, hipStream_t s) {
+    const unsigned N = 1u << logN;
+    hipLaunchKernelGGL(build_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, logN, gal, index);
+    return hipGetLastError();
+}
+
+struct AutoCoeffArgs {
+    const uint64_t *in;
+    uint64_t *out;
+    size_t in_bs, out_bs;
+    const ModConst *mc;
+    int N, logN;
+    uint64_t gal;
+    uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs], mod[kMaxLimbs];
+};
+// out[i*gal mod N] = +-in[i]; a negated zero is stored as q, exactly as the reference's
+// `(q - c) * tmp` does (ring/automorphism.go:170)
+__global__ void __launch_bounds__(256) automorphism_coeff_kernel(AutoCoeffArgs A) {
+    const uint64_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)A.N) return;
+    const uint64_t raw = i * A.gal, idx = raw & (uint64_t)(A.N - 1), neg = (raw >> A.logN) & 1;
+    const uint64_t q = A.mc[A.mod[blockIdx.y]].q;
+    const uint64_t c = (A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N)[i];
+    (A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N)[idx] = neg ? q - c : c;
+}
+hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View in, uint64_t gal, View out, int batch,
+                                     hipStream_t s) {
+    if (tab.n <= 0 || batch <= 0) return hipSuccess;
+    AutoCoeffArgs A;
+    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.logN = r.logN;
+    A.gal = gal;
+    for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
+    dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
+    hipLaunchKernelGGL(automorphism_coeff_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// basis extension: ModUpExact = reconstructRNS + multSum per coefficient
+// (ring/basis_extension.go:282-308, :550-673).  One thread per coefficient; the y_i stay
+// in registers, the destination limbs are split over blockIdx.y chunks.
+// The float64 term v = trunc(sum_i fl(fl(y_i)/fl(q_i))) is accumulated sequentially in
+// source-limb order with IEEE round-to-nearest division and addition (no contraction),
+// which is what the Go code does.
+// ------------------------------------------------------------------------------------
+struct ModUpKArgs {
+    const uint64_t *src;
+    uint64_t *dstA, *dstB;
+    size_t src_bs, dstA_bs, dstB_bs;
+    const ModConst *mc;
+    const uint64_t *a, *T, *vt;
+    int N, nchunk;
+    ModUpArgs m;
+};
+
+template <int NSRC>
+__global__ void __launch_bounds__(64) modup_kernel(ModUpKArgs A) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= A.N) return;
+    const size_t bz = blockIdx.z;
+    const int nsrc = NSRC > 0 ? NSRC : A.m.nsrc;
+    uint64_t yv[NSRC > 0 ? NSRC : 32];
+    double vi = 0.0;
+    const uint64_t *src = A.src + bz * A.src_bs + x;
+#pragma unroll
+    for (int i = 0; i < (NSRC > 0 ? NSRC : 32); i++) {
+        if (i < nsrc) {
+            const ModConst mq = A.mc[A.m.src_mod[i]];
+            uint64_t v = src[(size_t)A.m.src_limb[i] * A.N];
+            const uint64_t h = A.m.src_half[i];
+            if (h) v = cred(v + h, mq.q);
+            const uint64_t yi = mred(v, A.a[i], mq.q, mq.qinv);
+            yv[i] = yi;
+            vi = __dadd_rn(vi, __ddiv_rn(__ull2double_rn(yi), __ull2double_rn(mq.q)));
+        }
+    }
+    const uint64_t v = (uint64_t)vi;
+    const int per = (A.m.ndst + A.nchunk - 1) / A.nchunk;
+    const int j0 = blockIdx.y * per, j1 = min(A.m.ndst, j0 + per);
+    for (int j = j0; j < j1; j++) {
+        const ModConst mp = A.mc[A.m.dst_mod[j]];
+        const int row = A.m.dst_row[j];
+        const uint64_t *Tr = A.T + (size_t)row * nsrc;
+        u128 acc = (u128)yv[0] * Tr[0];
+#pragma unroll
+        for (int i = 1; i < (NSRC > 0 ? NSRC : 32); i++)
+            if (i < nsrc) acc += (u128)yv[i] * Tr[i];
+        const uint64_t rlo = (uint64_t)acc, rhi = (uint64_t)(acc >> 64);
+        uint64_t res = rhi - mulhi64(rlo * mp.qinv, mp.q) + mp.q + A.vt[(size_t)row * (nsrc + 1) + v];
+        res = cred(res + mp.q - A.m.dst_half[j], mp.q);   // SubScalar, vec_ops.go:653
+        uint64_t *dst = A.m.dst_view[j] ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs);
+        dst[(size_t)A.m.dst_limb[j] * A.N + x] = res;
+    }
+}
+
+hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a, View src, View dstA, View dstB,
+                        int batch, hipStream_t s) {
+    if (a.ndst <= 0 || batch <= 0) return hipSuccess;
+    ModUpKArgs A;
+    A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
+    A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
+    A.mc = r.mc; A.a = c.a; A.T = c.T; A.vt = c.vt; A.N = r.N; A.m = a;
+    const int bx = (r.N + 63) / 64;
+    int nchunk = 2048 / (bx * batch);
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > a.ndst) nchunk = a.ndst;
+    if (nchunk > 4) nchunk = 4;
+    A.nchunk = nchunk;
+    dim3 grid(bx, nchunk, batch), block(64);
+    switch (a.nsrc) {
+        case 1: hipLaunchKernelGGL((modup_kernel<1>), grid, block, 0, s, A); break;
+        case 2: hipLaunchKernelGGL((modup_kernel<2>), grid, block, 0, s, A); break;
+        case 3: hipLaunchKernelGGL((modup_kernel<3>), grid, block, 0, s, A); break;
+        case 4: hipLaunchKernelGGL((modup_kernel<4>), grid, block, 0, s, A); break;
+        case 5: hipLaunchKernelGGL((modup_kernel<5>), grid, block, 0, s, A); break;
+        case 6: hipLaunchKernelGGL((modup_kernel<6>), grid, block, 0, s, A); break;
+        case 7: hipLaunchKernelGGL((modup_kernel<7>), grid, block, 0, s, A); break;
+        case 8: hipLaunchKernelGGL((modup_kernel<8>), grid, block, 0, s, A); break;
+        default: hipLaunchKernelGGL((modup_kernel<0>), grid, block, 0, s, A); break;
+    }
+    return hipGetLastError();
+}
+
+// single-limb digit (ring/basis_extension.go:402-436): centred value reduced into every
+// destination limb:  c >= q/2 ? q_dst - BRedAdd(q - c) : BRedAdd(c)
+struct CenterArgs {
+    const uint64_t *src;
+    uint64_t *dstA, *dstB;
+    size_t src_bs, dstA_bs, dstB_bs;
+    const ModConst *mc;
+    int N;
+    ModUpArgs m;
+};
+__global__ void __launch_bounds__(256) center_copy_kernel(CenterArgs A) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= A.N) return;
+    const size_t bz = blockIdx.z;
+    const uint64_t qs = A.mc[A.m.src_mod[0]].q;
+    uint64_t c = (A.src + bz * A.src_bs)[(size_t)A.m.src_limb[0] * A.N + x];
+    const bool neg = c >= (qs >> 1);
+    if (neg) c = qs - c;
+    const int j = blockIdx.y;
+    const ModConst mp = A.mc[A.m.dst_mod[j]];
+    const uint64_t t = bred_add(c, mp.q, mp.brc0);
+    uint64_t *dst = A.m.dst_view[j] ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs);
+    dst[(size_t)A.m.dst_limb[j] * A.N + x] = neg ? mp.q - t : t;
+}
+hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, View dstA, View dstB, int batch,
+                              hipStream_t s) {
+    if (a.ndst <= 0 || batch <= 0) return hipSuccess;
+    CenterArgs A;
+    A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
+    A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
+    A.mc = r.mc; A.N = r.N; A.m = a;
+    dim3 grid((unsigned)((r.N + 255) / 256), a.ndst, batch), block(256);
+    hipLaunchKernelGGL(center_copy_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// key-switch inner product.  Per (limb, coefficient): acc_k = sum_d key[d][k] * dec[d]
+// accumulated exactly in 128 bits (high word kept below q), ONE Montgomery reduction at
+// the end.  The canonical result equals the reference's lazy MRedLazy accumulation after
+// its final Reduce (core/rlwe/evaluator_gadget_product.go:160-200).  Key words are loaded
+// once per thread and reused across BB batch entries.
+// ------------------------------------------------------------------------------------
+struct KsKArgs {
+    const uint64_t *dec;
+    const uint64_t *key;
+    uint64_t *o0Q, *o0P, *o1Q, *o1P;
+    size_t dec_bs, oQ0_bs, oP0_bs, oQ1_bs, oP1_bs;
+    const ModConst *mc;
+    int N, batch;
+    KsArgs k;
+};
+
+template <int BB>
+__global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= A.N) return;
+    const int l = blockIdx.y;
+    const int b0 = blockIdx.z * BB;
+    const ModConst m = A.mc[A.k.mod[l]];
+    const uint64_t q = m.q;
+    uint64_t hi0[BB], lo0[BB], hi1[BB], lo1[BB];
+#pragma unroll
+    for (int b = 0; b < BB; b++) { hi0[b] = lo0[b] = hi1[b] = lo1[b] = 0; }
+    const uint64_t *kp = A.key + (size_t)A.k.key_limb[l] * A.N + x;
+    const uint64_t *dp = A.dec + (size_t)A.k.dec_limb[l] * A.N + x;
+    for (int d = 0; d < A.k.beta; d++) {
+        const uint64_t k0 = kp[(size_t)d * A.k.key_dstride];
+        const uint64_t k1 = kp[(size_t)d * A.k.key_dstride + A.k.key_kstride];
+#pragma unroll
+        for (int b = 0; b < BB; b++) {
+            if (b0 + b < A.batch) {
+                const uint64_t c = dp[(size_t)(b0 + b) * A.dec_bs + (size_t)d * A.k.dec_dstride];
+                uint64_t ph, pl;
+                mul64wide(c, k0, ph, pl);
+                lo0[b] += pl; hi0[b] += ph + (lo0[b] < pl);
+                hi0[b] = hi0[b] >= q ? hi0[b] - q : hi0[b];
+                mul64wide(c, k1, ph, pl);
+                lo1[b] += pl; hi1[b] += ph + (lo1[b] < pl);
+                hi1[b] = hi1[b] >= q ? hi1[b] - q : hi1[b];
+            }
+        }
+    }
+    const int ol = A.k.out_limb[l];
+    const bool isP = A.k.out_view[l] != 0;
+#pragma unroll
+    for (int b = 0; b < BB; b++) {
+        if (b0 + b < A.batch) {
+            const uint64_t r0 = cred(mred128_lazy(hi0[b], lo0[b], q, m.qinv), q);
+            const uint64_t r1 = cred(mred128_lazy(hi1[b], lo1[b], q, m.qinv), q);
+            uint64_t *o0 = isP ? A.o0P + (size_t)(b0 + b) * A.oP0_bs : A.o0Q + (size_t)(b0 + b) * A.oQ0_bs;
+            uint64_t *o1 = isP ? A.o1P + (size_t)(b0 + b) * A.oP1_bs : A.o1Q + (size_t)(b0 + b) * A.oQ1_bs;
+            o0[(size_t)ol * A.N + x] = r0;
+            o1[(size_t)ol * A.N + x] = r1;
+        }
+    }
+}
+
+hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, const uint64_t *key, View out0Q, View out0P,
+                           View out1Q, View out1P, int batch, hipStream_t s) {
+    if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
+    KsKArgs A;
+    A.dec = dec.p; A.dec_bs = dec.bstride; A.key = key;
+    A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
+    A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
+    A.mc = r.mc; A.N = r.N; A.batch = batch; A.k = a;
+    const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
+    dim3 grid((unsigned)((r.N + 255) / 256), a.nlimbs, (batch + bb - 1) / bb), block(256);
+    if (bb == 4) hipLaunchKernelGGL((ks_inner_kernel<4>), grid, block, 0, s, A);
+    else if (bb == 2) hipLaunchKernelGGL((ks_inner_kernel<2>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((ks_inner_kernel<1>), grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// degree-1 x degree-1 tensor product, fused: 4 inputs -> 3 outputs in one pass.
+// ------------------------------------------------------------------------------------
+struct TensorArgs {
+    const uint64_t *a0, *a1, *b0, *b1;
+    uint64_t *c0, *c1, *c2;
+    size_t a0_bs, a1_bs, b0_bs, b1_bs, c0_bs, c1_bs, c2_bs;
+    const ModConst *mc;
+    int N;
+    uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs], mod[kMaxLimbs];
+    uint64_t s[kMaxLimbs];
+};
+__global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (j >= A.N) return;
+    const int yy = blockIdx.y;
+    const ModConst m = A.mc[A.mod[yy]];
+    const uint64_t q = m.q, qinv = m.qinv, sc = A.s[yy];
+    const size_t bz = blockIdx.z, io = (size_t)A.in_limb[yy] * A.N + j, oo = (size_t)A.out_limb[yy] * A.N + j;
+    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(A.a0 + bz * A.a0_bs + io);
+    const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(A.a1 + bz * A.a1_bs + io);
+    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(A.b0 + bz * A.b0_bs + io);
+    const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(A.b1 + bz * A.b1_bs + io);
+    ulonglong2 c0, c1, c2;
+    {
+        const uint64_t t0 = mred(a0.x, sc, q, qinv), t1 = mred(a1.x, sc, q, qinv);
+        c0.x = mred(t0, b0.x, q, qinv);
+        c2.x = mred(t1, b1.x, q, qinv);
+        c1.x = cred(mred(t0, b1.x, q, qinv) + mred(t1, b0.x, q, qinv), q);
+    }
+    {
+        const uint64_t t0 = mred(a0.y, sc, q, qinv), t1 = mred(a1.y, sc, q, qinv);
+        c0.y = mred(t0, b0.y, q, qinv);
+        c2.y = mred(t1, b1.y, q, qinv);
+        c1.y = cred(mred(t0, b1.y, q, qinv) + mred(t1, b0.y, q, qinv), q);
+    }
+    *reinterpret_cast<ulonglong2 *>(A.c0 + bz * A.c0_bs + oo) = c0;
+    *reinterpret_cast<ulonglong2 *>(A.c1 + bz * A.c1_bs + oo) = c1;
+    *reinterpret_cast<ulonglong2 *>(A.c2 + bz * A.c2_bs + oo) = c2;
+}
+hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *scalar, View a0, View a1, View b0, View b1,
+                         View c0, View c1, View c2, int batch, hipStream_t s) {
+    if (tab.n <= 0 || batch <= 0) return hipSuccess;
+    TensorArgs A;
+    A.a0 = a0.p; A.a1 = a1.p; A.b0 = b0.p; A.b1 = b1.p; A.c0 = c0.p; A.c1 = c1.p; A.c2 = c2.p;
+    A.a0_bs = a0.bstride; A.a1_bs = a1.bstride; A.b0_bs = b0.bstride; A.b1_bs = b1.bstride;
+    A.c0_bs = c0.bstride; A.c1_bs = c1.bstride; A.c2_bs = c2.bstride;
+    A.mc = r.mc; A.N = r.N;
+    for (int i = 0; i < tab.n; i++) {
+        A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; A.s[i] = scalar[i];
+    }
+    dim3 grid((unsigned)((r.N / 2 + 255) / 256), tab.n, batch), block(256);
+    hipLaunchKernelGGL(tensor_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// modular-multiply throughput probe (bench.py --microbench): `iters` dependent MRedLazy
+// per element, 4 independent chains per thread.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) modmul_probe_kernel(uint64_t *buf, size_t n, int iters, uint64_t q, uint64_t qinv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i * 4 + 3 >= n) return;
+    uint64_t a0 = buf[i * 4], a1 = buf[i * 4 + 1], a2 = buf[i * 4 + 2], a3 = buf[i * 4 + 3];
+    const uint64_t w = a0 | 1;
+    for (int k = 0; k < iters; k++) {
+        a0 = mred_lazy(a0, w, q, qinv); a1 = mred_lazy(a1, w, q, qinv);
+        a2 = mred_lazy(a2, w, q, qinv); a3 = mred_lazy(a3, w, q, qinv);
+    }
+    buf[i * 4] = a0; buf[i * 4 + 1] = a1; buf[i * 4 + 2] = a2; buf[i * 4 + 3] = a3;
+}
+hipError_t launch_modmul_probe(uint64_t *buf, size_t n, int iters, uint64_t q, uint64_t qinv, hipStream_t s) {
+    const size_t threads = n / 4;
+    hipLaunchKernelGGL(modmul_probe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, buf, n, iters, q, qinv);
+    return hipGetLastError();
+}
+
+}  // namespace he

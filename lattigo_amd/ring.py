@@ -1,0 +1,366 @@
+"""Host-side mirror of the reference's ``ring`` package surface for the hot path
+(ring.Ring, ring.Poly, ring.BasisExtender), backed by libhering's HIP kernels.
+
+Method names and argument order follow the reference (outputs last, ``level``
+implicit in ``Ring.AtLevel``); every method cites the Go method it mirrors.
+Polynomials are device-resident batches ``[batch][limbs][N]`` (``Poly``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import H, check, load, u64p
+
+BINOPS = {
+    "Add": 0, "AddLazy": 1, "Sub": 2, "SubLazy": 3,
+    "MulCoeffsBarrett": 4, "MulCoeffsBarrettLazy": 5, "MulCoeffsBarrettThenAdd": 6,
+    "MulCoeffsBarrettThenAddLazy": 7,
+    "MulCoeffsMontgomery": 8, "MulCoeffsMontgomeryLazy": 9, "MulCoeffsMontgomeryLazyThenNeg": 10,
+    "MulCoeffsMontgomeryThenAdd": 11, "MulCoeffsMontgomeryThenAddLazy": 12,
+    "MulCoeffsMontgomeryLazyThenAddLazy": 13,
+    "MulCoeffsMontgomeryThenSub": 14, "MulCoeffsMontgomeryThenSubLazy": 15,
+    "MulCoeffsMontgomeryLazyThenSubLazy": 16,
+}
+UNOPS = {"Neg": 0, "Reduce": 1, "ReduceLazy": 2, "MForm": 3, "MFormLazy": 4, "IMForm": 5}
+SCALAROPS = {"AddScalar": 0, "SubScalar": 1, "MulScalar": 2, "MulScalarThenAdd": 3, "MulScalarThenSub": 4}
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _words(x: int) -> np.ndarray:
+    w = []
+    while True:
+        w.append(x & 0xFFFFFFFFFFFFFFFF)
+        x >>= 64
+        if x == 0:
+            break
+    return np.array(w, dtype=np.uint64)
+
+
+class Context:
+    """One HIP device + stream (one per process/GPU)."""
+
+    def __init__(self, device_id: int = 0):
+        h = H()
+        check(load().he_ctx_create(device_id, C.byref(h)))
+        self.h = h.value
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().he_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(load().he_ctx_sync(self.h))
+
+    def timer_start(self):
+        check(load().he_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(load().he_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def device_info(self):
+        out = (C.c_uint64 * 4)()
+        check(load().he_device_info(self.h, out))
+        return dict(cus=int(out[0]), lds_per_cu=int(out[1]), clock_khz=int(out[2]), hbm_bytes=int(out[3]))
+
+    def probe_modmul(self, iters=256) -> float:
+        out = C.c_double()
+        check(load().he_probe_modmul(self.h, iters, C.byref(out)))
+        return float(out.value)
+
+
+class Poly:
+    """Device-resident ring.Poly batch (ring/poly.go:13): [batch][limbs][N] uint64."""
+
+    def __init__(self, ring: "Ring", n_limbs: int | None = None, batch: int = 1):
+        self.ring = ring
+        self.n_limbs = ring.MaxLevel() + 1 if n_limbs is None else n_limbs
+        self.batch = batch
+        self.N = ring.N
+        h = H()
+        check(load().he_poly_alloc(ring.h, self.n_limbs, batch, C.byref(h)))
+        self.h = h.value
+
+    def free(self):
+        if getattr(self, "h", None):
+            load().he_poly_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def Level(self):
+        return self.n_limbs - 1
+
+    def upload(self, arr) -> "Poly":
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(self.batch, self.n_limbs, self.N)
+        check(load().he_poly_upload(self.h, _p(a), a.size))
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.batch, self.n_limbs, self.N), dtype=np.uint64)
+        check(load().he_poly_download(self.h, _p(out), out.size))
+        return out
+
+    def get(self, level=None) -> np.ndarray:
+        """[limbs, N] of batch entry 0 (or [batch, limbs, N] when batch > 1), limbs 0..level."""
+        a = self.download()
+        if level is not None:
+            a = a[:, : level + 1]
+        return a[0] if self.batch == 1 else a
+
+    def upload_limb(self, b, limb, row):
+        r = np.ascontiguousarray(row, dtype=np.uint64)
+        assert r.size == self.N
+        check(load().he_poly_upload_limb(self.h, b, limb, _p(r)))
+
+    def download_limb(self, b, limb) -> np.ndarray:
+        out = np.empty(self.N, dtype=np.uint64)
+        check(load().he_poly_download_limb(self.h, b, limb, _p(out)))
+        return out
+
+    def CopyLvl(self, level, src: "Poly"):
+        check(load().he_poly_copy(self.h, src.h, level))
+
+    def Zero(self):
+        check(load().he_poly_zero(self.h))
+
+
+class Ring:
+    """ring.Ring (ring/ring.go:71), standard type.  ``AtLevel`` returns a view sharing tables."""
+
+    def __init__(self, ctx: Context, N: int, moduli, _parent: "Ring | None" = None, _level: int | None = None):
+        self.ctx = ctx
+        self.N = N
+        self.moduli = [int(m) for m in moduli]
+        if _parent is not None:
+            self.h, self._owner, self.level = _parent.h, _parent._owner, _level
+            return
+        logN = N.bit_length() - 1
+        if N <= 0 or (1 << logN) != N:
+            raise _lib.HeringError(-4, "invalid ring degree: must be a power of 2")
+        arr = (C.c_uint64 * len(self.moduli))(*self.moduli)
+        h = H()
+        check(load().he_ring_create(ctx.h, logN, arr, len(self.moduli), C.byref(h)))
+        self.h = h.value
+        self._owner = self
+        self.level = len(self.moduli) - 1
+
+    def close(self):
+        if self._owner is self and getattr(self, "h", None):
+            load().he_ring_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- structure (ring/ring.go:175-213)
+    def AtLevel(self, level: int) -> "Ring":
+        if level < 0:
+            raise ValueError("level cannot be negative")
+        if level > self.MaxLevel():
+            raise ValueError("level cannot be larger than max level")
+        return Ring(self.ctx, self.N, self.moduli, _parent=self, _level=level)
+
+    def Level(self):
+        return self.level
+
+    def MaxLevel(self):
+        return len(self.moduli) - 1
+
+    def ModuliChain(self):
+        return list(self.moduli)
+
+    def NthRoot(self):
+        return 2 * self.N
+
+    def NewPoly(self, batch: int = 1) -> Poly:
+        return Poly(self, self.level + 1, batch)
+
+    def constant(self, limb, which) -> int:
+        out = C.c_uint64()
+        check(load().he_ring_constant(self.h, limb, which, C.byref(out)))
+        return int(out.value)
+
+    def roots(self, limb, backward=False) -> np.ndarray:
+        out = np.empty(self.N, dtype=np.uint64)
+        check(load().he_ring_roots(self.h, limb, int(backward), _p(out)))
+        return out
+
+    # -- NTT (ring/ntt.go:127-152)
+    def NTT(self, p1: Poly, p2: Poly):
+        check(load().he_ntt(self.h, self.level, p1.h, p2.h))
+
+    def NTTLazy(self, p1: Poly, p2: Poly):
+        check(load().he_ntt_lazy(self.h, self.level, p1.h, p2.h))
+
+    def INTT(self, p1: Poly, p2: Poly):
+        check(load().he_intt(self.h, self.level, p1.h, p2.h))
+
+    def INTTLazy(self, p1: Poly, p2: Poly):
+        check(load().he_intt_lazy(self.h, self.level, p1.h, p2.h))
+
+    # -- coefficient-wise (ring/operations.go:11-377)
+    def binop(self, name: str, p1: Poly, p2: Poly, p3: Poly):
+        check(load().he_binop(self.h, self.level, BINOPS[name], p1.h, p2.h, p3.h))
+
+    def unop(self, name: str, p1: Poly, p2: Poly):
+        check(load().he_unop(self.h, self.level, UNOPS[name], p1.h, p2.h))
+
+    def scalarop(self, name: str, p1: Poly, scalar: int, p2: Poly):
+        check(load().he_scalarop(self.h, self.level, SCALAROPS[name], p1.h, scalar, p2.h))
+
+    def MulRNSScalarMontgomery(self, p1: Poly, scalar, p2: Poly):
+        sc = np.ascontiguousarray(scalar, dtype=np.uint64)
+        check(load().he_mul_rns_scalar_montgomery(self.h, self.level, p1.h, _p(sc), p2.h))
+
+    def AddScalarBigint(self, p1: Poly, scalar: int, p2: Poly):
+        w = _words(int(scalar))
+        check(load().he_add_scalar_bigint(self.h, self.level, p1.h, _p(w), len(w), p2.h))
+
+    def SubScalarBigint(self, p1: Poly, scalar: int, p2: Poly):
+        w = _words(int(scalar))
+        check(load().he_sub_scalar_bigint(self.h, self.level, p1.h, _p(w), len(w), p2.h))
+
+    def MulScalarBigint(self, p1: Poly, scalar: int, p2: Poly):
+        w = _words(int(scalar))
+        check(load().he_mul_scalar_bigint(self.h, self.level, p1.h, _p(w), len(w), p2.h))
+
+    # -- rescale (ring/scaling.go)
+    def DivRoundByLastModulusNTT(self, p0: Poly, p1: Poly):
+        check(load().he_div_round_by_last_modulus_ntt(self.h, self.level, p0.h, p1.h))
+
+    def DivRoundByLastModulus(self, p0: Poly, p1: Poly):
+        check(load().he_div_round_by_last_modulus(self.h, self.level, p0.h, p1.h))
+
+    def DivFloorByLastModulusNTT(self, p0: Poly, p1: Poly):
+        check(load().he_div_floor_by_last_modulus_ntt(self.h, self.level, p0.h, p1.h))
+
+    def DivFloorByLastModulus(self, p0: Poly, p1: Poly):
+        check(load().he_div_floor_by_last_modulus(self.h, self.level, p0.h, p1.h))
+
+    def DivRoundByLastModulusManyNTT(self, nb: int, p0: Poly, p1: Poly):
+        check(load().he_div_round_by_last_modulus_many_ntt(self.h, self.level, nb, p0.h, p1.h))
+
+    def DivRoundByLastModulusMany(self, nb: int, p0: Poly, p1: Poly):
+        check(load().he_div_round_by_last_modulus_many(self.h, self.level, nb, p0.h, p1.h))
+
+    def DivFloorByLastModulusManyNTT(self, nb: int, p0: Poly, p1: Poly):
+        check(load().he_div_floor_by_last_modulus_many_ntt(self.h, self.level, nb, p0.h, p1.h))
+
+    def DivFloorByLastModulusMany(self, nb: int, p0: Poly, p1: Poly):
+        check(load().he_div_floor_by_last_modulus_many(self.h, self.level, nb, p0.h, p1.h))
+
+    # -- automorphism (ring/automorphism.go)
+    def AutomorphismNTTIndex(self, galel: int) -> "AutomorphismIndex":
+        return AutomorphismIndex(self, galel)
+
+    def AutomorphismNTTWithIndex(self, pin: Poly, index: "AutomorphismIndex", pout: Poly):
+        check(load().he_automorphism_ntt_with_index(self.h, self.level, pin.h, index.h, pout.h))
+
+    def AutomorphismNTTWithIndexThenAddLazy(self, pin: Poly, index: "AutomorphismIndex", pout: Poly):
+        check(load().he_automorphism_ntt_with_index_then_add_lazy(self.h, self.level, pin.h, index.h, pout.h))
+
+    def Automorphism(self, pin: Poly, galel: int, pout: Poly):
+        check(load().he_automorphism(self.h, self.level, pin.h, galel, pout.h))
+
+
+def _named(name, table, kind):
+    if kind == "bin":
+        def f(self, p1, p2, p3):
+            self.binop(name, p1, p2, p3)
+    elif kind == "un":
+        def f(self, p1, p2):
+            self.unop(name, p1, p2)
+    else:
+        def f(self, p1, scalar, p2):
+            self.scalarop(name, p1, scalar, p2)
+    f.__name__ = name
+    f.__doc__ = f"Ring.{name} (ring/operations.go)"
+    return f
+
+
+for _n in BINOPS:
+    setattr(Ring, _n, _named(_n, BINOPS, "bin"))
+for _n in UNOPS:
+    setattr(Ring, _n, _named(_n, UNOPS, "un"))
+for _n in SCALAROPS:
+    setattr(Ring, _n, _named(_n, SCALAROPS, "sc"))
+
+
+class AutomorphismIndex:
+    """Device copy of ring.AutomorphismNTTIndex (ring/automorphism.go:12)."""
+
+    def __init__(self, ring: Ring, galel: int):
+        h = H()
+        check(load().he_automorphism_index_create(ring.h, galel, C.byref(h)))
+        self.h = h.value
+        self.N = ring.N
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                load().he_automorphism_index_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.N, dtype=np.uint64)
+        check(load().he_automorphism_index_download(self.h, _p(out)))
+        return out
+
+
+class BasisExtender:
+    """ring.BasisExtender (ring/basis_extension.go:14)."""
+
+    def __init__(self, ringQ: Ring, ringP: Ring):
+        self.ringQ, self.ringP = ringQ, ringP
+        h = H()
+        check(load().he_basis_extender_create(ringQ.h, ringP.h, C.byref(h)))
+        self.h = h.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                load().he_basis_extender_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def ModUpQtoP(self, levelQ, levelP, polQ: Poly, polP: Poly):
+        check(load().he_modup_q_to_p(self.h, levelQ, levelP, polQ.h, polP.h))
+
+    def ModUpPtoQ(self, levelP, levelQ, polP: Poly, polQ: Poly):
+        check(load().he_modup_p_to_q(self.h, levelP, levelQ, polP.h, polQ.h))
+
+    def ModDownQPtoQ(self, levelQ, levelP, p1Q: Poly, p1P: Poly, p2Q: Poly):
+        check(load().he_moddown_qp_to_q(self.h, levelQ, levelP, p1Q.h, p1P.h, p2Q.h))
+
+    def ModDownQPtoQNTT(self, levelQ, levelP, p1Q: Poly, p1P: Poly, p2Q: Poly):
+        check(load().he_moddown_qp_to_q_ntt(self.h, levelQ, levelP, p1Q.h, p1P.h, p2Q.h))
+
+    def ModDownQPtoP(self, levelQ, levelP, p1Q: Poly, p1P: Poly, p2P: Poly):
+        check(load().he_moddown_qp_to_p(self.h, levelQ, levelP, p1Q.h, p1P.h, p2P.h))

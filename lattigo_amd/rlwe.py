@@ -1,0 +1,153 @@
+"""Host-side mirror of the rlwe.Evaluator hot path (core/rlwe/evaluator*.go,
+operator interface core/rlwe/rlwe.go:10-18) and of the CKKS/BGV call sites that
+sit on it, backed by libhering's HIP kernels.  NTT-domain ciphertexts; a
+ciphertext is a list of ``Poly`` (rlwe.Ciphertext.Value), a QP element a
+``(Q, P)`` pair of ``Poly`` (ringqp.Poly)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import H, check, load, u64p
+from .ring import Poly, Ring, _p
+
+
+def BaseRNSDecompositionVectorSize(levelQ: int, levelP: int) -> int:
+    """core/rlwe/params.go:543-550"""
+    if levelP == -1:
+        return levelQ + 1
+    return (levelQ + levelP + 1) // (levelP + 1)
+
+
+class EvaluationKey:
+    """rlwe.GadgetCiphertext / EvaluationKey with BaseTwoDecomposition = 0
+    (core/rlwe/gadgetciphertext.go:19): q [beta,2,nQk,N], p [beta,2,nPk,N], NTT + Montgomery."""
+
+    def __init__(self, evaluator: "Evaluator", q: np.ndarray, p: np.ndarray):
+        q = np.ascontiguousarray(q, dtype=np.uint64)
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        assert q.ndim == 4 and p.ndim == 4 and q.shape[:2] == p.shape[:2] and q.shape[1] == 2
+        self.beta, self.nQk, self.nPk = q.shape[0], q.shape[2], p.shape[2]
+        h = H()
+        check(load().he_evk_create(evaluator.h, self.beta, self.nQk, self.nPk, _p(q), _p(p), C.byref(h)))
+        self.h = h.value
+
+    def LevelQ(self):
+        return self.nQk - 1
+
+    def LevelP(self):
+        return self.nPk - 1
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                load().he_evk_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Decomposition:
+    """BuffDecompQP []ringqp.Poly of Evaluator.DecomposeNTT, device resident."""
+
+    def __init__(self, evaluator: "Evaluator", batch: int = 1):
+        self.ev = evaluator
+        self.batch = batch
+        h = H()
+        check(load().he_decomp_create(evaluator.h, batch, C.byref(h)))
+        self.h = h.value
+
+    def limb(self, b, digit, is_p, limb) -> np.ndarray:
+        out = np.empty(self.ev.ringQ.N, dtype=np.uint64)
+        check(load().he_decomp_download_limb(self.h, b, digit, int(is_p), limb, _p(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                load().he_decomp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Evaluator:
+    """rlwe.Evaluator (core/rlwe/evaluator.go:12) restricted to the key-switch path."""
+
+    def __init__(self, ringQ: Ring, ringP: Ring):
+        self.ringQ, self.ringP = ringQ, ringP
+        h = H()
+        check(load().he_evaluator_create(ringQ.h, ringP.h, C.byref(h)))
+        self.h = h.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                load().he_evaluator_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def NewEvaluationKey(self, q, p) -> EvaluationKey:
+        return EvaluationKey(self, q, p)
+
+    # ring.Decomposer.DecomposeAndSplit (ring/basis_extension.go:381)
+    def DecomposeAndSplit(self, levelQ, levelP, nbPi, digit, p0Q: Poly, p1Q: Poly, p1P: Poly):
+        check(load().he_decompose_and_split(self.h, levelQ, levelP, nbPi, digit, p0Q.h, p1Q.h, p1P.h))
+
+    # EvaluatorProvider.DecomposeNTT (core/rlwe/evaluator_gadget_product.go:459)
+    def DecomposeNTT(self, levelQ, levelP, nbPi, c2: Poly, c2IsNTT: bool, decomp: Decomposition):
+        check(load().he_decompose_ntt(self.h, levelQ, levelP, nbPi, c2.h, int(c2IsNTT), decomp.h))
+
+    # EvaluatorProvider.GadgetProductLazy (:108); ctQP = [(Q0,P0),(Q1,P1)]
+    def GadgetProductLazy(self, levelQ, cx: Poly, evk: EvaluationKey, ctQP):
+        (q0, p0), (q1, p1) = ctQP
+        check(load().he_gadget_product_lazy(self.h, levelQ, cx.h, evk.h, q0.h, p0.h, q1.h, p1.h))
+
+    # EvaluatorProvider.GadgetProductHoistedLazy (:379)
+    def GadgetProductHoistedLazy(self, levelQ, decomp: Decomposition, evk: EvaluationKey, ctQP):
+        (q0, p0), (q1, p1) = ctQP
+        check(load().he_gadget_product_hoisted_lazy(self.h, levelQ, decomp.h, evk.h, q0.h, p0.h, q1.h, p1.h))
+
+    # Evaluator.ModDown (:39)
+    def ModDown(self, levelQ, levelP, ctQP, ct):
+        (q0, p0), (q1, p1) = ctQP
+        check(load().he_moddown(self.h, levelQ, levelP, q0.h, p0.h, q1.h, p1.h, ct[0].h, ct[1].h))
+
+    # Evaluator.GadgetProduct (:16) / GadgetProductHoisted (:348)
+    def GadgetProduct(self, levelQ, cx: Poly, evk: EvaluationKey, ct):
+        check(load().he_gadget_product(self.h, levelQ, cx.h, evk.h, ct[0].h, ct[1].h))
+
+    def GadgetProductHoisted(self, levelQ, decomp: Decomposition, evk: EvaluationKey, ct):
+        check(load().he_gadget_product_hoisted(self.h, levelQ, decomp.h, evk.h, ct[0].h, ct[1].h))
+
+    # Evaluator.Relinearize (core/rlwe/evaluator_evaluationkey.go:117)
+    def Relinearize(self, level, ctIn, rlk: EvaluationKey, opOut):
+        check(load().he_relinearize(self.h, level, ctIn[0].h, ctIn[1].h, ctIn[2].h, rlk.h, opOut[0].h, opOut[1].h))
+
+    # Evaluator.Automorphism (core/rlwe/evaluator_automorphism.go:13)
+    def Automorphism(self, level, ctIn, galEl: int, gk: EvaluationKey, opOut):
+        check(load().he_automorphism_ct(self.h, level, ctIn[0].h, ctIn[1].h, galEl, gk.h, opOut[0].h, opOut[1].h))
+
+    # Evaluator.AutomorphismHoisted (:60)
+    def AutomorphismHoisted(self, level, ctIn, c1DecompQP: Decomposition, galEl: int, gk: EvaluationKey, opOut):
+        check(load().he_automorphism_hoisted(self.h, level, ctIn[0].h, c1DecompQP.h, galEl, gk.h, opOut[0].h, opOut[1].h))
+
+    # schemes/ckks Evaluator.Mul / MulRelin (schemes/ckks/evaluator.go:613,742 -> mulRelin :764)
+    def CKKSMulRelin(self, level, op0, op1, rlk: EvaluationKey | None, opOut):
+        o2 = opOut[2].h if rlk is None else 0
+        check(load().he_ckks_mul_relin(self.h, level, op0[0].h, op0[1].h, op1[0].h, op1[1].h, rlk.h if rlk else 0,
+                                       opOut[0].h, opOut[1].h, o2))
+
+    # schemes/bgv Evaluator.Mul / MulRelin (schemes/bgv/evaluator.go:529 -> tensorStandard :592)
+    def BGVMulRelin(self, level, t: int, op0, op1, rlk: EvaluationKey | None, opOut):
+        o2 = opOut[2].h if rlk is None else 0
+        check(load().he_bgv_mul_relin(self.h, level, t, op0[0].h, op0[1].h, op1[0].h, op1[1].h, rlk.h if rlk else 0,
+                                      opOut[0].h, opOut[1].h, o2))
+
+    # schemes/{ckks,bgv} Evaluator.Rescale (ckks :477, bgv :1363)
+    def Rescale(self, level, nbRescales, op0, opOut):
+        r = self.ringQ.AtLevel(level)
+        for a, b in zip(op0, opOut):
+            r.DivRoundByLastModulusManyNTT(nbRescales, a, b)

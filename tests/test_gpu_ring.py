@@ -1,0 +1,223 @@
+"""GPU parity, ring layer: libhering's HIP kernels vs the CPU
+oracle on the same seeded inputs, bit-exact, plus the reference's own NTT known-answer vectors
+(ring/ntt_test.go) and size-independent properties at logN = 15/16."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lattigo_amd as la
+from oracle import oracle as O
+from tests.conftest import Pi60, Qi60
+from tests.gpu_common import Pair, ctx  # noqa: F401
+from tests.helpers import rng_for, uniform_poly
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ntt_kat.json")
+
+
+def test_ntt_known_answer_vectors(ctx):
+    kat = json.load(open(GOLDEN))
+    for c in kat["cases"]:
+        r = la.Ring(ctx, c["N"], c["Qis"])
+        x = np.array(c["poly"], dtype=np.uint64)
+        y = np.array(c["polyNTT"], dtype=np.uint64)
+        px, pz = r.NewPoly().upload(x), r.NewPoly()
+        r.NTT(px, pz)
+        assert np.array_equal(pz.get(), y), f"N={c['N']}"
+        r.INTT(pz, pz)  # in place, as ring/ntt_test.go:113
+        assert np.array_equal(pz.get(), x), f"N={c['N']}"
+
+
+def test_tables_match_oracle(ctx):
+    pr = Pair(ctx, 11, 3)
+    for i in range(3):
+        oc = pr.oQ.constants(i)
+        assert pr.gQ.constant(i, 0) == oc["q"] and pr.gQ.constant(i, 1) == oc["qinv"]
+        assert (pr.gQ.constant(i, 2), pr.gQ.constant(i, 3)) == oc["brc"]
+        assert pr.gQ.constant(i, 4) == oc["ninv"] and pr.gQ.constant(i, 5) == oc["primroot"]
+        assert np.array_equal(pr.gQ.roots(i), pr.oQ.roots_forward(i))
+        assert np.array_equal(pr.gQ.roots(i, True), pr.oQ.roots_backward(i))
+
+
+@pytest.mark.parametrize("logN", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+def test_ntt_matches_oracle(ctx, logN):
+    pr = Pair(ctx, logN, 3)
+    rng = rng_for(1000 + logN)
+    x = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(2)])  # batch of 2
+    px, py = pr.up(pr.gQ, x, 2), la.Poly(pr.gQ, 3, 2)
+    pr.gQ.NTT(px, py)
+    want = np.stack([pr.oQ.NTT(x[b]) for b in range(2)])
+    assert np.array_equal(py.get(), want)
+    pr.gQ.NTTLazy(px, py)
+    lz = py.get()
+    assert np.all(lz < 2 * np.array(pr.q, dtype=np.uint64)[None, :, None])
+    assert np.array_equal(np.stack([pr.oQ.unop("Reduce", lz[b]) for b in range(2)]), want)
+    pz = la.Poly(pr.gQ, 3, 2)
+    pr.gQ.INTT(py, pz)
+    assert np.array_equal(pz.get(), x)
+    pr.gQ.INTTLazy(py, pz)
+    assert np.array_equal(pz.get(), x)
+    # at a lower level only the first limbs are touched
+    pw = la.Poly(pr.gQ, 3, 2)
+    pr.gQ.AtLevel(1).NTT(px, pw)
+    got = pw.get()
+    assert np.array_equal(got[:, :2], want[:, :2]) and not got[:, 2].any()
+
+
+@pytest.mark.parametrize("logN", [15, 16])
+def test_ntt_large_roundtrip_and_linearity(ctx, logN):
+    """Full-size property checks (the oracle is only sampled on one limb)."""
+    pr = Pair(ctx, logN, 4)
+    rng = rng_for(1100 + logN)
+    x, y = uniform_poly(rng, pr.q, pr.N), uniform_poly(rng, pr.q, pr.N)
+    px, py, ps = pr.up(pr.gQ, x), pr.up(pr.gQ, y), pr.gQ.NewPoly()
+    fx, fy, fs = pr.gQ.NewPoly(), pr.gQ.NewPoly(), pr.gQ.NewPoly()
+    pr.gQ.NTT(px, fx)
+    pr.gQ.NTT(py, fy)
+    pr.gQ.Add(px, py, ps)
+    pr.gQ.NTT(ps, fs)
+    pr.gQ.Add(fx, fy, fy)
+    assert np.array_equal(fs.get(), fy.get())  # linearity
+    assert np.array_equal(fx.get()[0], pr.oQ.NTT(x)[0])  # oracle on limb 0
+    pr.gQ.INTT(fx, fx)
+    assert np.array_equal(fx.get(), x)  # round trip
+    # negacyclic convolution theorem: NTT(x * X) = NTT(x) .* NTT(X)
+    mono = np.zeros_like(x)
+    mono[:, 1] = 1
+    pm, fm = pr.up(pr.gQ, mono), pr.gQ.NewPoly()
+    pr.gQ.NTT(pm, fm)
+    pr.gQ.NTT(px, fx)
+    pr.gQ.MulCoeffsBarrett(fx, fm, fm)
+    pr.gQ.INTT(fm, fm)
+    shifted = np.roll(x, 1, axis=1)
+    shifted[:, 0] = (np.array(pr.q, dtype=np.uint64) - x[:, -1]) % np.array(pr.q, dtype=np.uint64)
+    assert np.array_equal(fm.get(), shifted)
+
+
+def test_ntt_edge_inputs(ctx):
+    """zeros, q-1 everywhere, and non-canonical inputs (the reference NTT accepts any word below overflow)."""
+    pr = Pair(ctx, 10, 2)
+    q = np.array(pr.q, dtype=np.uint64)[:, None]
+    for x in (np.zeros((2, pr.N), dtype=np.uint64), np.broadcast_to(q - 1, (2, pr.N)).copy(),
+              np.broadcast_to(3 * q + 5, (2, pr.N)).copy()):
+        px, py = pr.up(pr.gQ, x), pr.gQ.NewPoly()
+        pr.gQ.NTT(px, py)
+        assert np.array_equal(py.get(), pr.oQ.NTT(x))
+
+
+BIN = ["Add", "AddLazy", "Sub", "SubLazy", "MulCoeffsBarrett", "MulCoeffsBarrettLazy", "MulCoeffsBarrettThenAdd",
+       "MulCoeffsBarrettThenAddLazy", "MulCoeffsMontgomery", "MulCoeffsMontgomeryLazy",
+       "MulCoeffsMontgomeryLazyThenNeg", "MulCoeffsMontgomeryThenAdd", "MulCoeffsMontgomeryThenAddLazy",
+       "MulCoeffsMontgomeryLazyThenAddLazy", "MulCoeffsMontgomeryThenSub", "MulCoeffsMontgomeryThenSubLazy",
+       "MulCoeffsMontgomeryLazyThenSubLazy"]
+
+
+def test_all_coefficient_wise_ops_word_exact(ctx):
+    """Every ring/vec_ops.go formula, including the *Lazy representatives, word for word."""
+    pr = Pair(ctx, 10, 4)
+    rng = rng_for(1200)
+    a, b, c = (uniform_poly(rng, pr.q, pr.N) for _ in range(3))
+    # edge operands in the first columns
+    q = np.array(pr.q, dtype=np.uint64)
+    a[:, 0], b[:, 0] = 0, 0
+    a[:, 1], b[:, 1] = q - 1, q - 1
+    a[:, 2], b[:, 2] = 1, q - 1
+    pa, pb = pr.up(pr.gQ, a), pr.up(pr.gQ, b)
+    for name in BIN:
+        pc = pr.up(pr.gQ, c)
+        pr.gQ.binop(name, pa, pb, pc)
+        assert np.array_equal(pc.get(), pr.oQ.binop(name, a, b, c)), name
+    wide = a.copy()
+    wide[:, 3] = 0xFFFFFFFFFFFFFFFF
+    pw = pr.up(pr.gQ, wide)
+    for name in ["Neg", "Reduce", "ReduceLazy", "MForm", "MFormLazy", "IMForm"]:
+        src, psrc = (wide, pw) if "Reduce" in name else (a, pa)
+        pc = pr.gQ.NewPoly()
+        pr.gQ.unop(name, psrc, pc)
+        assert np.array_equal(pc.get(), pr.oQ.unop(name, src)), name
+    for name in ["AddScalar", "SubScalar", "MulScalar", "MulScalarThenAdd", "MulScalarThenSub"]:
+        for scalar in (0, 1, 12345678901234567, int(q[0]) - 1):
+            pc = pr.up(pr.gQ, c)
+            pr.gQ.scalarop(name, pa, scalar, pc)
+            assert np.array_equal(pc.get(), pr.oQ.scalarop(name, a, scalar, c)), (name, scalar)
+    big = (1 << 300) + 987654321
+    for name in ["AddScalarBigint", "SubScalarBigint", "MulScalarBigint"]:
+        pc = pr.gQ.NewPoly()
+        getattr(pr.gQ, name)(pa, big, pc)
+        assert np.array_equal(pc.get(), getattr(pr.oQ, name)(a, big)), name
+    sc = np.array([O.MForm(7 + i, m) for i, m in enumerate(pr.q)], dtype=np.uint64)
+    pc = pr.gQ.NewPoly()
+    pr.gQ.MulRNSScalarMontgomery(pa, sc, pc)
+    assert np.array_equal(pc.get(), pr.oQ.MulRNSScalarMontgomery(a, sc))
+    # in place + lower level
+    pr.gQ.AtLevel(2).Add(pa, pb, pa)
+    got = pa.get()
+    assert np.array_equal(got[:3], pr.oQ.binop("Add", a, b)[:3]) and np.array_equal(got[3], a[3])
+
+
+@pytest.mark.parametrize("mods", ["same", "mixed"])
+def test_rescale_all_variants(ctx, mods):
+    """ring/scaling.go: every DivRound/DivFloor variant, NTT and coefficient domain, nb = 1..3."""
+    qm = Qi60[:5] if mods == "same" else None
+    if mods == "mixed":  # CKKS-like chain: a large q0 and small rescaling primes (q_L << q_i and q_L >> q_i)
+        qs, _ = O.GenModuli(12, [55, 36, 36, 60, 36], [])
+        qm = qs
+    pr = Pair(ctx, 11, 5, qmods=qm)
+    rng = rng_for(1300)
+    x = uniform_poly(rng, pr.q, pr.N)
+    px = pr.up(pr.gQ, x)
+    for name in ["DivRoundByLastModulusNTT", "DivRoundByLastModulus", "DivFloorByLastModulusNTT", "DivFloorByLastModulus"]:
+        po = pr.gQ.NewPoly()
+        getattr(pr.gQ, name)(px, po)
+        assert np.array_equal(po.get()[:4], getattr(pr.oQ, name)(x)), name
+    for name in ["DivRoundByLastModulusManyNTT", "DivRoundByLastModulusMany", "DivFloorByLastModulusManyNTT",
+                 "DivFloorByLastModulusMany"]:
+        for nb in (0, 1, 2, 3):
+            po = pr.gQ.NewPoly()
+            getattr(pr.gQ, name)(nb, px, po)
+            assert np.array_equal(po.get()[: 5 - nb], getattr(pr.oQ, name)(nb, x)), (name, nb)
+    # in place and at a lower level
+    pin = pr.up(pr.gQ, x)
+    pr.gQ.AtLevel(3).DivRoundByLastModulusNTT(pin, pin)
+    sub = O.Ring(pr.N, pr.q[:4])
+    assert np.array_equal(pin.get()[:3], sub.DivRoundByLastModulusNTT(x[:4]))
+
+
+def test_automorphism(ctx):
+    pr = Pair(ctx, 11, 3)
+    rng = rng_for(1400)
+    x, acc = uniform_poly(rng, pr.q, pr.N), uniform_poly(rng, pr.q, pr.N)
+    px = pr.up(pr.gQ, x)
+    for galel in (5, pow(5, 77, 2 * pr.N), 2 * pr.N - 1, 1):
+        idx = pr.gQ.AutomorphismNTTIndex(galel)
+        assert np.array_equal(idx.download(), pr.oQ.AutomorphismNTTIndex(galel))
+        po = pr.gQ.NewPoly()
+        pr.gQ.AutomorphismNTTWithIndex(px, idx, po)
+        assert np.array_equal(po.get(), pr.oQ.AutomorphismNTTWithIndex(x, idx.download()))
+        pa = pr.up(pr.gQ, acc)
+        pr.gQ.AutomorphismNTTWithIndexThenAddLazy(px, idx, pa)
+        assert np.array_equal(pa.get(), pr.oQ.AutomorphismNTTWithIndexThenAddLazy(x, idx.download(), acc))
+        xz = x.copy()
+        xz[:, :4] = 0  # negated zeros come out as q in the reference
+        pz, po2 = pr.up(pr.gQ, xz), pr.gQ.NewPoly()
+        pr.gQ.Automorphism(pz, galel, po2)
+        assert np.array_equal(po2.get(), pr.oQ.Automorphism(xz, galel))
+    with pytest.raises(la.HeringError):
+        pr.gQ.AutomorphismNTTWithIndex(px, pr.gQ.AutomorphismNTTIndex(5), px)  # not in place (automorphism.go:37)
+
+
+def test_error_behaviour(ctx):
+    with pytest.raises(la.HeringError):
+        la.Ring(ctx, 1 << 10, [Qi60[0], Qi60[0]])  # not distinct
+    with pytest.raises(la.HeringError):
+        la.Ring(ctx, 1 << 10, [0x1fffffffffe00001 + 2])  # not prime / not 1 mod 2N
+    with pytest.raises(la.HeringError):
+        la.Ring(ctx, 1 << 10, [])
+    r = la.Ring(ctx, 1 << 10, Qi60[:2])
+    small = la.Poly(r, 1, 1)
+    with pytest.raises(la.HeringError):
+        r.NTT(small, small)  # needs 2 limbs at level 1
+    with pytest.raises(ValueError):
+        r.AtLevel(5)

@@ -1,0 +1,250 @@
+"""GPU parity, basis extension and key-switch: libhering vs the
+CPU oracle, bit-exact on every output limb, plus decrypt-and-check semantics
+(core/rlwe/rlwe_test.go:666-779 style) on the GPU outputs."""
+import numpy as np
+import pytest
+
+import lattigo_amd as la
+from oracle import oracle as O
+from tests.conftest import Pi60, Qi60
+from tests.gpu_common import Pair, ctx  # noqa: F401
+from tests.helpers import prod, rand_bigints, rng_for, set_coefficients_bigint, uniform_poly
+from tests.rlwe_fixtures import SecretKey, automorphism_secret, gen_evaluation_key, noise_log2, phase
+
+pytestmark = pytest.mark.gpu
+
+
+def _uploadQ(pr, arr, batch=1):
+    return la.Poly(pr.gQ, arr.shape[-2], batch).upload(arr)
+
+
+def _uploadP(pr, arr, batch=1):
+    return la.Poly(pr.gP, arr.shape[-2], batch).upload(arr)
+
+
+@pytest.mark.parametrize("nq,np_", [(6, 3), (14, 14), (4, 1)])
+def test_modup_moddown_word_exact(ctx, nq, np_):
+    """ring/basis_extension.go ModUp/ModDown: exact words (incl. the lazy ModUp representative)."""
+    logN = 10
+    pr = Pair(ctx, logN, nq, np_, qmods=Qi60[-nq:], pmods=Pi60[-np_:])
+    be, obe = la.BasisExtender(pr.gQ, pr.gP), O.BasisExtender(pr.oQ, pr.oP)
+    rng = rng_for(2000 + nq)
+    for levelQ, levelP in {(nq - 1, np_ - 1), (max(0, nq - 2), max(0, np_ - 2)), (0, 0)}:
+        Qm, Pm = pr.q[: levelQ + 1], pr.p[: levelP + 1]
+        xq, xp = uniform_poly(rng, Qm, pr.N), uniform_poly(rng, Pm, pr.N)
+        pq, pp = _uploadQ(pr, xq), _uploadP(pr, xp)
+        out = la.Poly(pr.gP, levelP + 1)
+        be.ModUpQtoP(levelQ, levelP, pq, out)
+        assert np.array_equal(out.get(), obe.ModUpQtoP(levelQ, levelP, xq)), ("QtoP", levelQ, levelP)
+        out = la.Poly(pr.gQ, levelQ + 1)
+        be.ModUpPtoQ(levelP, levelQ, pp, out)
+        assert np.array_equal(out.get(), obe.ModUpPtoQ(levelP, levelQ, xp)), ("PtoQ", levelQ, levelP)
+        for name, ring_, nl in (("ModDownQPtoQ", pr.gQ, levelQ + 1), ("ModDownQPtoQNTT", pr.gQ, levelQ + 1),
+                                ("ModDownQPtoP", pr.gP, levelP + 1)):
+            out = la.Poly(ring_, nl)
+            getattr(be, name)(levelQ, levelP, pq, pp, out)
+            assert np.array_equal(out.get(), getattr(obe, name)(levelQ, levelP, xq, xp)), (name, levelQ, levelP)
+
+
+def test_modup_against_bigint_and_adversarial_float(ctx):
+    """ModUp of centred big integers (ring/ring_test.go:714) plus inputs engineered so that the
+    float64 sum v sits next to an integer boundary (coefficients 0, +-1, Q/2 and neighbours)."""
+    pr = Pair(ctx, 10, 6, 4, qmods=Qi60[-6:], pmods=Pi60[-4:])
+    be, obe = la.BasisExtender(pr.gQ, pr.gP), O.BasisExtender(pr.oQ, pr.oP)
+    Q = prod(pr.q)
+    half = Q >> 1
+    coeffs = [c - half for c in rand_bigints(rng_for(2100), Q, pr.N)]
+    special = [0, 1, -1, half, -half, half - 1, -half + 1, 2, -2, Q // 3, -(Q // 3)]
+    for k in range(6):  # exact multiples of Q/q_k +- 1: the y_i/q_i sum is within 1 ulp of an integer
+        special += [(Q // pr.q[k]) * j + d for j in (1, 2, pr.q[k] // 2) for d in (-1, 0, 1)]
+    for i, s in enumerate(special):
+        s = ((s + half) % Q) - half
+        coeffs[i] = s
+    xq = set_coefficients_bigint(coeffs, pr.q)
+    out = la.Poly(pr.gP, 4)
+    be.ModUpQtoP(5, 3, _uploadQ(pr, xq), out)
+    got = out.get()
+    assert np.array_equal(got, obe.ModUpQtoP(5, 3, xq))
+    assert np.array_equal(pr.oP.unop("Reduce", got), set_coefficients_bigint(coeffs, pr.p))
+
+
+def _setup(ctx, logN, nq, np_, seed):
+    pr = Pair(ctx, logN, nq, np_)
+    rng = rng_for(seed)
+    oev, gev = O.Evaluator(pr.oQ, pr.oP), la.Evaluator(pr.gQ, pr.gP)
+    sk = SecretKey(rng, pr.oQ, pr.oP)
+    return pr, rng, oev, gev, sk
+
+
+@pytest.mark.parametrize("nq,np_", [(7, 3), (6, 2), (5, 1), (8, 4)])
+def test_decompose_and_gadget_product(ctx, nq, np_):
+    pr, rng, oev, gev, sk = _setup(ctx, 10, nq, np_, 2200 + nq)
+    sk2 = SecretKey(rng, pr.oQ, pr.oP)
+    oevk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, sk2)
+    gevk = gev.NewEvaluationKey(oevk.q, oevk.p)
+    odec = O.Decomposer(pr.oQ, pr.oP)
+    levelP = np_ - 1
+    for levelQ in (nq - 1, nq - 2, max(0, nq - 4), 0):
+        Qm = pr.q[: levelQ + 1]
+        cx = uniform_poly(rng, Qm, pr.N)
+        pcx = _uploadQ(pr, cx)
+        beta = O.BaseRNSDecompositionVectorSize(levelQ, levelP)
+        # DecomposeAndSplit on the coefficient-domain input, every digit
+        for d in range(beta):
+            p1Q, p1P = la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gP, levelP + 1)
+            gev.DecomposeAndSplit(levelQ, levelP, levelP + 1, d, pcx, p1Q, p1P)
+            wQ, wP = odec.DecomposeAndSplit(levelQ, levelP, levelP + 1, d, cx)
+            lo, hi = d * np_, min(d * np_ + np_, levelQ + 1)
+            own = set(range(lo, hi)) if hi - lo > 1 else set()
+            gQ = p1Q.get()
+            for l in range(levelQ + 1):
+                if l not in own:
+                    assert np.array_equal(gQ[l], wQ[l]), (levelQ, d, l)
+            assert np.array_equal(p1P.get(), wP), (levelQ, d)
+        # DecomposeNTT (hoisting buffer)
+        dq, dp = oev.DecomposeNTT(levelQ, levelP, levelP + 1, cx, True)
+        gdec = la.Decomposition(gev)
+        if beta <= O.BaseRNSDecompositionVectorSize(nq - 1, levelP):
+            gev.DecomposeNTT(levelQ, levelP, levelP + 1, pcx, True, gdec)
+            for d in range(beta):
+                for l in range(levelQ + 1):
+                    assert np.array_equal(gdec.limb(0, d, False, l), dq[d, l]), (levelQ, d, l)
+                for l in range(levelP + 1):
+                    assert np.array_equal(gdec.limb(0, d, True, l), dp[d, l]), (levelQ, d, l)
+        # GadgetProductLazy / Hoisted / ModDown / GadgetProduct
+        wQ, wP = oev.GadgetProductLazy(levelQ, cx, oevk)
+        qp = [(la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gP, levelP + 1)) for _ in range(2)]
+        gev.GadgetProductLazy(levelQ, pcx, gevk, qp)
+        for k in range(2):
+            assert np.array_equal(qp[k][0].get(), wQ[k]) and np.array_equal(qp[k][1].get(), wP[k]), (levelQ, k)
+        if beta <= O.BaseRNSDecompositionVectorSize(nq - 1, levelP):
+            qp2 = [(la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gP, levelP + 1)) for _ in range(2)]
+            gev.GadgetProductHoistedLazy(levelQ, gdec, gevk, qp2)
+            for k in range(2):
+                assert np.array_equal(qp2[k][0].get(), wQ[k]) and np.array_equal(qp2[k][1].get(), wP[k])
+        want = oev.GadgetProduct(levelQ, cx, oevk)
+        ct = [la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gQ, levelQ + 1)]
+        gev.ModDown(levelQ, levelP, qp, ct)
+        assert np.array_equal(np.stack([c.get() for c in ct]), want)
+        ct2 = [la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gQ, levelQ + 1)]
+        gev.GadgetProduct(levelQ, pcx, gevk, ct2)
+        got = np.stack([c.get() for c in ct2])
+        assert np.array_equal(got, want)
+        # semantic: <ct,(1,sk2)> = cx*sk + small
+        sub = O.Ring(pr.N, Qm)
+        noise = noise_log2(pr.oQ, sub.binop("Sub", phase(pr.oQ, got, sk2.Q),
+                                            sub.binop("MulCoeffsMontgomery", cx, sk.Q[: levelQ + 1])))
+        assert noise <= 16, noise
+
+
+def test_batched_gadget_product_matches_single(ctx):
+    pr, rng, oev, gev, sk = _setup(ctx, 11, 6, 3, 2300)
+    oevk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, sk)
+    gevk = gev.NewEvaluationKey(oevk.q, oevk.p)
+    for B in (2, 3, 5):
+        cx = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(B)])
+        pcx = la.Poly(pr.gQ, 6, B).upload(cx)
+        ct = [la.Poly(pr.gQ, 6, B), la.Poly(pr.gQ, 6, B)]
+        gev.GadgetProduct(5, pcx, gevk, ct)
+        g0, g1 = ct[0].get(), ct[1].get()
+        for b in range(B):
+            want = oev.GadgetProduct(5, cx[b], oevk)
+            assert np.array_equal(g0[b], want[0]) and np.array_equal(g1[b], want[1]), (B, b)
+
+
+@pytest.mark.parametrize("scheme", ["ckks", "bgv"])
+@pytest.mark.parametrize("nq,np_", [(5, 2), (4, 1)])
+def test_mul_relin_rescale(ctx, scheme, nq, np_):
+    pr, rng, oev, gev, sk = _setup(ctx, 11, nq, np_, 2400 + nq)
+    sk_sq = pr.oQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q)
+    orlk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk_sq, sk)
+    grlk = gev.NewEvaluationKey(orlk.q, orlk.p)
+    level, t = nq - 1, 65537
+    ct0 = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(2)])
+    ct1 = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(2)])
+    a, b = [_uploadQ(pr, c) for c in ct0], [_uploadQ(pr, c) for c in ct1]
+    omul = (lambda r, k: oev.CKKSMulRelin(ct0, ct1, k, r)) if scheme == "ckks" else (lambda r, k: oev.BGVMulRelin(t, ct0, ct1, k, r))
+    gmul = (lambda k, o: gev.CKKSMulRelin(level, a, b, k, o)) if scheme == "ckks" else (lambda k, o: gev.BGVMulRelin(level, t, a, b, k, o))
+    out3 = [pr.gQ.NewPoly() for _ in range(3)]
+    gmul(None, out3)
+    deg2 = np.stack([o.get() for o in out3])
+    assert np.array_equal(deg2, omul(False, None))
+    out2 = [pr.gQ.NewPoly() for _ in range(2)]
+    gmul(grlk, out2)
+    rel = np.stack([o.get() for o in out2])
+    assert np.array_equal(rel, omul(True, orlk))
+    # Relinearize of the degree-2 result gives the same ciphertext
+    out2b = [pr.gQ.NewPoly() for _ in range(2)]
+    gev.Relinearize(level, out3, grlk, out2b)
+    assert np.array_equal(np.stack([o.get() for o in out2b]), rel)
+    # Rescale (1 and 2 levels), also in place
+    for nb in (1, 2):
+        res = [la.Poly(pr.gQ, nq - nb) for _ in range(2)]
+        gev.Rescale(level, nb, out2, res)
+        assert np.array_equal(np.stack([r.get() for r in res]), oev.Rescale(rel, nb))
+    # semantic check: decrypts to the product of the phases (times t for BGV)
+    p0, p1 = phase(pr.oQ, ct0, sk.Q), phase(pr.oQ, ct1, sk.Q)
+    want = pr.oQ.binop("MulCoeffsBarrett", p0, p1)
+    if scheme == "bgv":
+        want = pr.oQ.scalarop("MulScalar", want, t)
+    assert np.array_equal(phase(pr.oQ, deg2, sk.Q), want)
+    assert noise_log2(pr.oQ, pr.oQ.binop("Sub", phase(pr.oQ, rel, sk.Q), want)) <= 18
+
+
+@pytest.mark.parametrize("nq,np_", [(5, 2), (4, 1)])
+def test_rotate(ctx, nq, np_):
+    pr, rng, oev, gev, sk = _setup(ctx, 11, nq, np_, 2500 + nq)
+    N = pr.N
+    level = nq - 1
+    ct = np.stack([uniform_poly(rng, pr.q, N) for _ in range(2)])
+    pct = [_uploadQ(pr, c) for c in ct]
+    gdec = la.Decomposition(gev)
+    gev.DecomposeNTT(level, np_ - 1, np_, pct[1], True, gdec)
+    for galel in (5, 2 * N - 1, pow(5, 9, 2 * N)):
+        sk_out = automorphism_secret(rng, pr.oQ, pr.oP, sk, pow(galel, 2 * N - 1, 2 * N))
+        ogk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, sk_out)
+        ggk = gev.NewEvaluationKey(ogk.q, ogk.p)
+        want = oev.Automorphism(ct, galel, ogk)
+        out = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
+        gev.Automorphism(level, pct, galel, ggk, out)
+        got = np.stack([o.get() for o in out])
+        assert np.array_equal(got, want), galel
+        out2 = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
+        gev.AutomorphismHoisted(level, pct, gdec, galel, ggk, out2)
+        assert np.array_equal(np.stack([o.get() for o in out2]), want), galel
+        idx = pr.oQ.AutomorphismNTTIndex(galel)
+        wantp = pr.oQ.AutomorphismNTTWithIndex(phase(pr.oQ, ct, sk.Q), idx)
+        assert noise_log2(pr.oQ, pr.oQ.binop("Sub", phase(pr.oQ, got, sk.Q), wantp)) <= 18
+
+
+def test_full_size_properties_logN15(ctx):
+    """BASELINE config 3 shape (logN=15, 12 Q-limbs, 3 P-limbs): hoisted == plain, batch == single,
+    linearity of the gadget product in cx, and one limb of every output checked against the oracle."""
+    logN, nq, np_ = 15, 12, 3
+    q, p = O.GenModuli(logN + 1, [55] + [45] * 11, [55] * 3)
+    pr = Pair(ctx, logN, nq, np_, qmods=q, pmods=p)
+    rng = rng_for(3)
+    gev = la.Evaluator(pr.gQ, pr.gP)
+    kq = np.stack([np.stack([uniform_poly(rng, q, pr.N) for _ in range(2)]) for _ in range(4)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, pr.N) for _ in range(2)]) for _ in range(4)])
+    gevk = gev.NewEvaluationKey(kq, kp)
+    cx = np.stack([uniform_poly(rng, q, pr.N) for _ in range(2)])
+    pcx = la.Poly(pr.gQ, nq, 2).upload(cx)
+    ct = [la.Poly(pr.gQ, nq, 2), la.Poly(pr.gQ, nq, 2)]
+    gev.GadgetProduct(nq - 1, pcx, gevk, ct)
+    g0 = ct[0].get()
+    # single == batched
+    p1 = la.Poly(pr.gQ, nq).upload(cx[1])
+    ct1 = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
+    gev.GadgetProduct(nq - 1, p1, gevk, ct1)
+    assert np.array_equal(ct1[0].get(), g0[1])
+    # hoisted == plain
+    dec = la.Decomposition(gev)
+    gev.DecomposeNTT(nq - 1, np_ - 1, np_, p1, True, dec)
+    ct2 = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
+    gev.GadgetProductHoisted(nq - 1, dec, gevk, ct2)
+    assert np.array_equal(ct2[0].get(), g0[1]) and np.array_equal(ct2[1].get(), ct1[1].get())
+    # oracle on the whole op (seconds at this size)
+    oev = O.Evaluator(pr.oQ, pr.oP)
+    want = oev.GadgetProduct(nq - 1, cx[1], O.EvaluationKey(kq, kp))
+    assert np.array_equal(g0[1], want[0]) and np.array_equal(ct1[1].get(), want[1])
