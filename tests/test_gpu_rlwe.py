@@ -64,8 +64,11 @@ def test_modup_against_bigint_and_adversarial_float(ctx):
     out = la.Poly(pr.gP, 4)
     be.ModUpQtoP(5, 3, _uploadQ(pr, xq), out)
     got = out.get()
-    assert np.array_equal(got, obe.ModUpQtoP(5, 3, xq))
-    assert np.array_equal(pr.oP.unop("Reduce", got), set_coefficients_bigint(coeffs, pr.p))
+    assert np.array_equal(got, obe.ModUpQtoP(5, 3, xq))  # word-exact, adversarial columns included
+    # big-integer ground truth on the random columns only: next to +-Q/2 the reference's own
+    # float64 method (HPS) is allowed to be off by Q, and the GPU must reproduce exactly that.
+    ns = len(special)
+    assert np.array_equal(pr.oP.unop("Reduce", got)[:, ns:], set_coefficients_bigint(coeffs, pr.p)[:, ns:])
 
 
 def _setup(ctx, logN, nq, np_, seed):
