@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X ring-arithmetic backend.
+
+Workload (BASELINE.json configs[2], the one its metric "ciphertext-mul+relin ops/s at logN=15"
+is quoted on): BGV, logN=15, 12 Q-limbs (LogQ=[55,45x11]), 3 P-limbs (LogP=[55x3]), T=65537,
+ct x ct Mul + Relinearize (schemes/bgv/evaluator.go:592 tensorStandard + GadgetProduct).
+A "step" is one MulRelin over a batch of B independent ciphertext pairs already resident in HBM.
+Synthetic inputs: coefficients uniform in [0, q_i), PCG64 seed 0x1A77160 + 2.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; independent ciphertexts are sharded
+across ranks (weak scaling, no data-path collective -- SURVEY.md section 8e); ranks synchronise only
+for the barrier around the timed region and the MAX over ranks of the elapsed time.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOGN = 15
+LOGQ = [55] + [45] * 11
+LOGP = [55] * 3
+T = 65537
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def gen_moduli():
+    """NTT-friendly primes for the workload.  The product path needs only the primes; they come
+    from the oracle's restated GenModuli (core/rlwe/params.go:811) when it is available and are
+    pinned here so the bench does not depend on it."""
+    # = GenModuli(LogNthRoot=16, LogQ=[55,45x11], LogP=[55x3])
+    q = [36028797019488257, 35184372744193, 35184373006337, 35184373989377, 35184368877569, 35184368025601,
+         35184367828993, 35184376545281, 35184377331713, 35184366911489, 35184378511361, 35184378707969]
+    p = [36028797020209153, 36028797017456641, 36028797020602369]
+    return q, p
+
+
+def uniform(rng, moduli, N, lead=()):
+    out = np.empty(tuple(lead) + (len(moduli), N), dtype=np.uint64)
+    for i, m in enumerate(moduli):
+        out[..., i, :] = rng.integers(0, int(m), size=tuple(lead) + (N,), dtype=np.uint64)
+    return out
+
+
+def cpu_baseline(q, p, kq, kp, seconds=12.0):
+    """The restated reference (oracle/, a scalar C port) timed on the host cores: one MulRelin per
+    call, independent ciphertexts on one thread per core (the reference's own parallel mode is
+    b.RunParallel over independent outputs, schemes/ckks/ckks_benchmarks_test.go:116)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+    N = 1 << LOGN
+    cores = os.cpu_count() or 1
+    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
+    ev = O.Evaluator(ringQ, ringP)
+    rlk = O.EvaluationKey(kq, kp)
+    rng = np.random.Generator(np.random.PCG64(0x1A77160 + 2))
+    ct0, ct1 = uniform(rng, q, N, (2,)), uniform(rng, q, N, (2,))
+    t0 = time.perf_counter()
+    ev.BGVMulRelin(T, ct0, ct1, rlk, True)
+    one = time.perf_counter() - t0
+    # bounded sample: every thread repeats the op until a shared deadline (~`seconds` of wall time)
+    deadline = time.perf_counter() + seconds
+    counts = [0] * cores
+
+    def work(i):
+        while True:
+            ev.BGVMulRelin(T, ct0, ct1, rlk, True)  # ctypes releases the GIL
+            counts[i] += 1
+            if time.perf_counter() >= deadline:
+                return
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    n = sum(counts)
+    return {"value": n / dt, "unit": "ctxt-mul+relin ops/s", "cores": cores, "kind": "port",
+            "single_thread_ops_s": 1.0 / one,
+            "sample": f"{n} BGV MulRelin (logN=15, 12+3 limbs) over {cores} threads in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="independent ciphertext pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--microbench", action="store_true", help="also print NTT/s and the modmul probe to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        # control plane only (barrier + MAX of the elapsed time); the data path has no collective
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import lattigo_amd as la
+    ctx = la.Context(local_rank if world > 1 else 0)
+    N, B = 1 << LOGN, args.batch
+    q, p = gen_moduli()
+    L, alpha = len(q), len(p)
+    beta = (L + alpha - 1) // alpha
+    ringQ, ringP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+    ev = la.Evaluator(ringQ, ringP)
+    rng = np.random.Generator(np.random.PCG64(0x1A77160 + 2 + 1000 * rank))
+    kq, kp = uniform(rng, q, N, (beta, 2)), uniform(rng, p, N, (beta, 2))
+    rlk = ev.NewEvaluationKey(kq, kp)
+    a = [la.Poly(ringQ, L, B).upload(uniform(rng, q, N, (B,))) for _ in range(2)]
+    b = [la.Poly(ringQ, L, B).upload(uniform(rng, q, N, (B,))) for _ in range(2)]
+    out = [la.Poly(ringQ, L, B), la.Poly(ringQ, L, B)]
+
+    def step():
+        ev.BGVMulRelin(L - 1, T, a, b, rlk, out)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ops = world * B * args.steps
+    value = ops / elapsed
+    limb = N * 8
+    alg_bytes_op = (6 * L + 2 * beta * (L + alpha)) * limb  # 48 MiB
+
+    # ---- roofline leg: per-kernel HIP-event timing over an identical region --------------------
+    ctx.prof_begin()
+    for _ in range(args.steps):
+        step()
+    prof = ctx.prof_end()
+    total_ms = sum(v[1] for v in prof.values())
+    dom = max(prof.items(), key=lambda kv: kv[1][1])
+    dom_name, (dom_launches, dom_ms) = dom
+    # algorithmic bytes per launch of each kernel family in ONE MulRelin of B ciphertexts:
+    # what the kernel must read + write once (twiddles / constants excluded, resident)
+    nonown = beta * (L + alpha) - L                # limbs that get a forward NTT in DecomposeNTT
+    per_step_bytes = {
+        "ntt_rows_fwd": 2 * (nonown + 2 * L) * limb * B,        # decomposition NTTs + 2 ModDown NTTs
+        "ntt_cols_fwd": 2 * (nonown + 2 * L) * limb * B,
+        "ntt_rows_inv": 2 * (L + 2 * alpha) * limb * B,         # INTT(c2) + 2 ModDown INTT(P)
+        "ntt_cols_inv": 2 * (L + 2 * alpha) * limb * B,
+        "ks_inner": (beta * (L + alpha) * B + 2 * beta * (L + alpha) + 2 * (L + alpha) * B) * limb,
+        "tensor": 7 * L * limb * B,
+        "modup": (beta * ((L + alpha)) + 2 * (alpha + L)) * limb * B,
+        "ew": (L * B + 2 * 3 * L * B + 2 * 3 * L * B) * limb,  # own-limb copies, ModDown sub-mul, final adds
+    }
+    dom_bytes_launch = per_step_bytes.get(dom_name, 0) * args.steps / max(dom_launches, 1)
+    dom_avg_ms = dom_ms / max(dom_launches, 1)
+    achieved = dom_bytes_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": dom_avg_ms, "launches": dom_launches,
+                "alg_bytes_per_launch": dom_bytes_launch,
+                "whole_op": {"alg_bytes_per_op": alg_bytes_op, "achieved_GBs": alg_bytes_op * value / world / 1e9,
+                             "frac": alg_bytes_op * value / world / 1e9 / HBM_PEAK_GBS},
+                "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+                "kernel_time_sum_ms_per_step": total_ms / args.steps}
+
+    line = {
+        "metric": "ciphertext-mul+relin ops/s", "value": value, "unit": "ctxt-mul+relin ops/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "BGV logN=15, 12 Q-limbs [55,45x11] + 3 P-limbs [55x3], T=65537: ct x ct MulRelin "
+                               "(tensor + gadget product + ModDown), inputs resident in HBM",
+                   "batch_per_gpu": B, "logN": LOGN, "L": L, "alpha": alpha, "beta": beta,
+                   "parallelism": f"{world} independent replicas, ciphertext-sharded"},
+        "hip_event_ms_per_step": ev_ms / args.steps,
+        "roofline": roofline,
+    }
+    if args.microbench:
+        x = la.Poly(ringQ, L, B).upload(uniform(rng, q, N, (B,)))
+        for _ in range(3):
+            ringQ.NTT(x, x)
+        ctx.timer_start()
+        for _ in range(20):
+            ringQ.NTT(x, x)
+        ms = ctx.timer_stop()
+        line["ntt_limb_per_s"] = 20 * L * B / (ms * 1e-3)
+        line["modmul_per_s"] = ctx.probe_modmul(256)
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            line["cpu_baseline"] = cpu_baseline(q, p, kq, kp)
+        except Exception as e:  # the oracle is optional test infrastructure
+            line["cpu_baseline"] = {"error": str(e)}
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

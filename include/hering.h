@@ -239,6 +239,11 @@ int he_bgv_mul_relin(he_handle eval, int level, uint64_t t, he_handle a0, he_han
  * he_div_round_by_last_modulus_many_ntt above. */
 
 /* ---- diagnostics (not part of the reference surface) --------------------------------- */
+/* per-kernel HIP-event timing on the context's stream: begin, run work, end -> per kernel id
+ * launch counts and summed durations (bench.py's roofline leg; adds two events per launch) */
+int he_prof_begin(he_handle ctx);
+int he_prof_end(he_handle ctx, int max_kernels, int *counts, float *total_ms, int *n_kernels);
+const char *he_prof_kernel_name(int id);
 /* dependent-MRedLazy throughput probe: returns modular multiplies per second */
 int he_probe_modmul(he_handle ctx, int iters, double *mults_per_s);
 

@@ -55,6 +55,8 @@ def _declare(L):
     HP = C.POINTER(H)
     L.he_last_error.restype = C.c_char_p
     L.he_version.restype = C.c_char_p
+    L.he_prof_kernel_name.restype = C.c_char_p
+    L.he_prof_kernel_name.argtypes = [C.c_int]
     sig = {
         "he_ctx_create": [i, HP], "he_ctx_destroy": [H], "he_ctx_sync": [H], "he_timer_start": [H],
         "he_timer_stop": [H, C.POINTER(C.c_float)], "he_device_info": [H, u64p],
@@ -104,6 +106,7 @@ def _declare(L):
         "he_ckks_mul_relin": [H, i, H, H, H, H, H, H, H, H],
         "he_bgv_mul_relin": [H, i, C.c_uint64, H, H, H, H, H, H, H, H],
         "he_probe_modmul": [H, i, C.POINTER(C.c_double)],
+        "he_prof_begin": [H], "he_prof_end": [H, i, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(i)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

@@ -1494,6 +1494,24 @@ int he_bgv_mul_relin(he_handle ev, int level, uint64_t t, he_handle a0, he_handl
 // ---------------------------------------------------------------------------------------
 // diagnostics
 // ---------------------------------------------------------------------------------------
+int he_prof_begin(he_handle hctx) {
+    GET(c, Ctx, hctx, T_CTX);
+    Scope sc(c.get());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prof_begin();
+    return HE_OK;
+}
+int he_prof_end(he_handle hctx, int max_kernels, int *counts, float *total_ms, int *n_kernels) {
+    GET(c, Ctx, hctx, T_CTX);
+    if (!counts || !total_ms || max_kernels < K_COUNT) return fail(HE_EINVAL, "he_prof_end: need room for %d kernels", (int)K_COUNT);
+    Scope sc(c.get());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prof_end(counts, total_ms);
+    if (n_kernels) *n_kernels = K_COUNT;
+    return HE_OK;
+}
+const char *he_prof_kernel_name(int id) { return kernel_name(id); }
+
 int he_probe_modmul(he_handle hctx, int iters, double *out) {
     GET(c, Ctx, hctx, T_CTX);
     if (!out || iters <= 0) return fail(HE_EINVAL, "he_probe_modmul: bad arguments");

@@ -122,6 +122,15 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, const ui
 hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *scalar, View a0, View a1, View b0, View b1,
                          View c0, View c1, View c2, int batch, hipStream_t s);
 
+// ---- per-kernel HIP-event profiling (diagnostics: bench.py's roofline leg) --------------------
+enum KernelId {
+    K_NTT_COLS_FWD = 0, K_NTT_ROWS_FWD, K_NTT_ROWS_INV, K_NTT_COLS_INV, K_EW, K_GATHER, K_AUTO_COEFF, K_INDEX,
+    K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_COUNT
+};
+const char *kernel_name(int id);
+void prof_begin();                                   // start recording (one stream at a time)
+int prof_end(int *counts, float *total_ms);          // stop, sync events, fill [K_COUNT] arrays
+
 // throughput probe used by bench.py --microbench (not on the product path)
 hipError_t launch_modmul_probe(uint64_t *buf, size_t n, int iters, uint64_t q, uint64_t qinv, hipStream_t s);
 

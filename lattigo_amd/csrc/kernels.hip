@@ -15,7 +15,55 @@
 // outputs are promised (SURVEY.md section 8a note on lazy ranges).
 #include "kernels.h"
 
+#include <vector>
+
 namespace he {
+
+// ------------------------------------------------------------------------------------
+// optional per-launch HIP-event timing (off by default; bench.py's roofline leg turns it on)
+// ------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { int id; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    bool on; int id; hipStream_t s; hipEvent_t e0;
+    ProfScope(int id_, hipStream_t s_) : on(g_prof_on), id(id_), s(s_), e0(nullptr) {
+        if (on) { e0 = prof_event(); (void)hipEventRecord(e0, s); }
+    }
+    ~ProfScope() {
+        if (on) { hipEvent_t e1 = prof_event(); (void)hipEventRecord(e1, s); g_prof_recs.push_back(ProfRec{id, e0, e1}); }
+    }
+};
+}  // namespace
+const char *kernel_name(int id) {
+    static const char *names[K_COUNT] = {"ntt_cols_fwd", "ntt_rows_fwd", "ntt_rows_inv", "ntt_cols_inv", "ew", "gather",
+                                         "automorphism_coeff", "build_index", "modup", "center_copy", "ks_inner",
+                                         "tensor", "modmul_probe"};
+    return (id >= 0 && id < K_COUNT) ? names[id] : "?";
+}
+void prof_begin() { g_prof_recs.clear(); g_prof_on = true; }
+int prof_end(int *counts, float *total_ms) {
+    g_prof_on = false;
+    for (int i = 0; i < K_COUNT; i++) { counts[i] = 0; total_ms[i] = 0.f; }
+    for (auto &r : g_prof_recs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        counts[r.id]++; total_ms[r.id] += ms;
+        g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1);
+    }
+    int n = (int)g_prof_recs.size();
+    g_prof_recs.clear();
+    return n;
+}
 
 // ------------------------------------------------------------------------------------
 // butterflies
@@ -251,7 +299,8 @@ template <bool INV>
 static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
 #define HE_ROWS_CASE(B)                                                                           \
     case B:                                                                                       \
-        hipLaunchKernelGGL((ntt_rows_kernel<B, INV>), grid, dim3((1 << B) / 16), 0, s, A);         \
+        { ProfScope ps(INV ? K_NTT_ROWS_INV : K_NTT_ROWS_FWD, s);                                   \
+        hipLaunchKernelGGL((ntt_rows_kernel<B, INV>), grid, dim3((1 << B) / 16), 0, s, A); }       \
         break;
     switch (logb) {
         HE_ROWS_CASE(4) HE_ROWS_CASE(5) HE_ROWS_CASE(6) HE_ROWS_CASE(7) HE_ROWS_CASE(8) HE_ROWS_CASE(9)
@@ -265,7 +314,8 @@ template <bool INV>
 static hipError_t launch_cols(int loga, dim3 grid, const NttArgs &A, hipStream_t s) {
 #define HE_COLS_CASE(Av)                                                                 \
     case Av:                                                                             \
-        hipLaunchKernelGGL((ntt_cols_kernel<Av, INV>), grid, dim3(256), 0, s, A);         \
+        { ProfScope ps(INV ? K_NTT_COLS_INV : K_NTT_COLS_FWD, s);                          \
+        hipLaunchKernelGGL((ntt_cols_kernel<Av, INV>), grid, dim3(256), 0, s, A); }       \
         break;
     switch (loga) {
         HE_COLS_CASE(1) HE_COLS_CASE(2) HE_COLS_CASE(3) HE_COLS_CASE(4) HE_COLS_CASE(5)
@@ -421,6 +471,7 @@ hipError_t launch_ew(const RingDev &r, const LimbTab &tab, int op, View x, View 
         A.s2[i] = sc ? sc->s2[i] : 0;
     }
     dim3 grid((unsigned)((r.N / 2 + 255) / 256), tab.n, batch), block(256);
+    ProfScope ps(K_EW, s);
 #define HE_EW_CASE(O) \
     case O: hipLaunchKernelGGL((ew_kernel<O>), grid, block, 0, s, A); break;
     switch (op) {
@@ -470,6 +521,7 @@ hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const ui
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.index = index; A.N = r.N;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
+    ProfScope ps(K_GATHER, s);
     if (then_add) hipLaunchKernelGGL((gather_kernel<true>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((gather_kernel<false>), grid, block, 0, s, A);
     return hipGetLastError();
@@ -487,6 +539,7 @@ __global__ void build_index_kernel(int logN, uint64_t gal, uint32_t *index) {
 }
 hipError_t launch_build_automorphism_index(int logN, uint64_t gal, uint32_t *index, hipStream_t s) {
     const unsigned N = 1u << logN;
+    ProfScope ps(K_INDEX, s);
     hipLaunchKernelGGL(build_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, logN, gal, index);
     return hipGetLastError();
 }
@@ -518,6 +571,7 @@ hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View 
     A.gal = gal;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
+    ProfScope ps(K_AUTO_COEFF, s);
     hipLaunchKernelGGL(automorphism_coeff_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
@@ -594,6 +648,7 @@ hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a,
     if (nchunk > 4) nchunk = 4;
     A.nchunk = nchunk;
     dim3 grid(bx, nchunk, batch), block(64);
+    ProfScope ps(K_MODUP, s);
     switch (a.nsrc) {
         case 1: hipLaunchKernelGGL((modup_kernel<1>), grid, block, 0, s, A); break;
         case 2: hipLaunchKernelGGL((modup_kernel<2>), grid, block, 0, s, A); break;
@@ -640,6 +695,7 @@ hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, Vi
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
     A.mc = r.mc; A.N = r.N; A.m = a;
     dim3 grid((unsigned)((r.N + 255) / 256), a.ndst, batch), block(256);
+    ProfScope ps(K_CENTER, s);
     hipLaunchKernelGGL(center_copy_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
@@ -716,6 +772,7 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, const ui
     A.mc = r.mc; A.N = r.N; A.batch = batch; A.k = a;
     const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
     dim3 grid((unsigned)((r.N + 255) / 256), a.nlimbs, (batch + bb - 1) / bb), block(256);
+    ProfScope ps(K_KS_INNER, s);
     if (bb == 4) hipLaunchKernelGGL((ks_inner_kernel<4>), grid, block, 0, s, A);
     else if (bb == 2) hipLaunchKernelGGL((ks_inner_kernel<2>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((ks_inner_kernel<1>), grid, block, 0, s, A);
@@ -774,6 +831,7 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
         A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; A.s[i] = scalar[i];
     }
     dim3 grid((unsigned)((r.N / 2 + 255) / 256), tab.n, batch), block(256);
+    ProfScope ps(K_TENSOR, s);
     hipLaunchKernelGGL(tensor_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }

@@ -79,6 +79,16 @@ class Context:
         check(load().he_device_info(self.h, out))
         return dict(cus=int(out[0]), lds_per_cu=int(out[1]), clock_khz=int(out[2]), hbm_bytes=int(out[3]))
 
+    def prof_begin(self):
+        check(load().he_prof_begin(self.h))
+
+    def prof_end(self) -> dict:
+        """{kernel name: (launches, total ms)} since prof_begin()."""
+        n = 32
+        counts, ms, nk = (C.c_int * n)(), (C.c_float * n)(), C.c_int()
+        check(load().he_prof_end(self.h, n, counts, ms, C.byref(nk)))
+        return {load().he_prof_kernel_name(i).decode(): (int(counts[i]), float(ms[i])) for i in range(nk.value) if counts[i]}
+
     def probe_modmul(self, iters=256) -> float:
         out = C.c_double()
         check(load().he_probe_modmul(self.h, iters, C.byref(out)))
