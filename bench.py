@@ -100,18 +100,12 @@ def main():
     ap.add_argument("--microbench", action="store_true", help="also print NTT/s and the modmul probe to stderr")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    from lattigo_amd.dist import ControlPlane
+    cp = ControlPlane()  # gloo control plane only (barrier + MAX of the elapsed time); no data-path collective
+    rank, local_rank, world = cp.rank, cp.local_rank, cp.world
     if world > 1:
         import torch
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        # control plane only (barrier + MAX of the elapsed time); the data path has no collective
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     import lattigo_amd as la
     ctx = la.Context(local_rank if world > 1 else 0)
@@ -133,10 +127,10 @@ def main():
 
     def barrier():
         ctx.sync()
-        if dist is not None:
+        if world > 1:
             import torch
             torch.cuda.synchronize()
-            dist.barrier()
+        cp.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -148,16 +142,10 @@ def main():
     ev_ms = ctx.timer_stop()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = cp.max_over_ranks(elapsed)
 
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        cp.close()
         return
 
     ops = world * B * args.steps
@@ -225,9 +213,7 @@ def main():
         except Exception as e:  # the oracle is optional test infrastructure
             line["cpu_baseline"] = {"error": str(e)}
     print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    cp.close()
 
 
 if __name__ == "__main__":
