@@ -12,7 +12,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -197,15 +199,28 @@ struct BasisExtender : Obj {
 };
 
 // rlwe.Evaluator hot path: BasisExtender + ring.Decomposer constants (ring/basis_extension.go:320-377)
+// descriptors of the fused basis-extension kernel, grouped by source-limb count
+struct FusedGroup {
+    ModUpDesc *dev;
+    int n, nsrc;
+};
+struct FusedPlan {
+    bool ok = false;
+    std::vector<FusedGroup> groups;
+};
 struct Evaluator : Obj {
     std::shared_ptr<BasisExtender> be;
     ConstPool pool;
     // dec[nbPi-2][digit][j]: source = first j+2 limbs of the digit, target = all Q then P[:nbPi]
     std::vector<std::vector<std::vector<ModUpRef>>> dec;
+    std::map<std::tuple<int, int, int>, FusedPlan> dec_plans;  // (levelQ, levelP, nbPi)
+    std::map<std::pair<int, int>, FusedPlan> md_plans;         // (levelQ, levelP)
+    std::vector<ModUpDesc *> plan_mem;
     Evaluator() : Obj(T_EVAL) {}
     ~Evaluator() override {
         hipSetDevice(be->ctx->dev);
         hipStreamSynchronize(be->ctx->stream);
+        for (ModUpDesc *p : plan_mem) hipFree(p);
         pool.release();
     }
 };
@@ -1087,6 +1102,7 @@ int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2n
     const int LQ = be.LQ;
     const int beta = base_rns_size(levelQ, levelP);
     hipStream_t st = be.ctx->stream;
+    if (dec_ds != (size_t)(be.LQ + be.LP) * be.Q->N) return fail(HE_EINVAL, "decompose: unexpected digit stride");
     for (int d = 0; d < beta; d++) {
         View blk{dec + (size_t)d * dec_ds, dec_bs};
         TRY(decompose_digit(ev, levelQ, levelP, nbPi, d, c2inv, blk, 0, blk, LQ, batch));
@@ -1112,7 +1128,7 @@ int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2n
 
 // inner product of a decomposition with a key (gadgetProductMultiplePLazyHoisted :401-453)
 int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View o0Q,
-             View o0P, View o1Q, View o1P, int batch) {
+             View o0P, View o1Q, View o1P, int batch, const View *own = nullptr, int own_alpha = 0) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     KsArgs a{};
@@ -1130,8 +1146,140 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
     a.dec_dstride = dec_ds;
     a.key_kstride = (size_t)(k.nQk + k.nPk) * N;
     a.key_dstride = 2 * a.key_kstride;
-    HIP_TRY(launch_ks_inner(be.qp, a, View{const_cast<uint64_t *>(dec), dec_bs}, k.d, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
+    a.own_alpha = own ? own_alpha : 0;
+    a.own_nq = levelQ + 1;
+    const View decv{const_cast<uint64_t *>(dec), dec_bs};
+    HIP_TRY(launch_ks_inner(be.qp, a, decv, own ? *own : decv, k.d, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
     return HE_OK;
+}
+
+// ---- fused pipeline plans ------------------------------------------------------------------
+int upload_plan(Evaluator &ev, const std::vector<ModUpDesc> &descs, FusedPlan &plan) {
+    plan.ok = !descs.empty();
+    for (const ModUpDesc &d : descs)
+        if (!modup_fused_supported(ev.be->Q->logN, d.nsrc)) plan.ok = false;
+    if (!plan.ok) return HE_OK;
+    ModUpDesc *dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, descs.size() * sizeof(ModUpDesc)));
+    HIP_TRY(hipMemcpy(dev, descs.data(), descs.size() * sizeof(ModUpDesc), hipMemcpyHostToDevice));
+    ev.plan_mem.push_back(dev);
+    size_t i = 0;
+    while (i < descs.size()) {
+        size_t j = i;
+        while (j < descs.size() && descs[j].nsrc == descs[i].nsrc) j++;
+        plan.groups.push_back(FusedGroup{dev + i, (int)(j - i), descs[i].nsrc});
+        i = j;
+    }
+    return HE_OK;
+}
+// all digits of DecomposeNTT at (levelQ, levelP, nbPi) into a [beta][LQ+LP][N] block per batch entry
+int get_dec_plan(Evaluator &ev, int levelQ, int levelP, int nbPi, const FusedPlan **out) {
+    auto key = std::make_tuple(levelQ, levelP, nbPi);
+    auto it = ev.dec_plans.find(key);
+    if (it != ev.dec_plans.end()) { *out = &it->second; return HE_OK; }
+    BasisExtender &be = *ev.be;
+    const int LQ = be.LQ, width = be.LQ + be.LP, N = be.Q->N;
+    const int beta = base_rns_size(levelQ, levelP);
+    std::vector<ModUpDesc> descs;
+    bool ok = true;
+    for (int d = 0; d < beta && ok; d++) {
+        const int st = d * nbPi, ed = std::min(st + nbPi, levelQ + 1);
+        if (st > levelQ) { ok = false; break; }
+        int decompLvl = (levelQ > nbPi * (d + 1) - 1) ? nbPi - 2 : (levelQ % nbPi) - 1;
+        ModUpDesc D;
+        memset(&D, 0, sizeof D);
+        D.single = decompLvl < 0;
+        D.nsrc = ed - st;
+        if (D.nsrc > 8) { ok = false; break; }
+        std::vector<uint64_t> basis(be.Q->moduli.begin() + st, be.Q->moduli.begin() + ed);
+        if (!D.single) {
+            if (nbPi < 2 || nbPi - 2 >= (int)ev.dec.size() || d >= (int)ev.dec[nbPi - 2].size() ||
+                decompLvl >= (int)ev.dec[nbPi - 2][d].size()) { ok = false; break; }
+            const ModUpDev c = ev.dec[nbPi - 2][d][decompLvl].on(ev.pool);
+            D.a = c.a; D.T = c.T; D.vt = c.vt;
+            D.reduce_out = modup_out_needs_reduce(basis) ? 1 : 0;
+        }
+        for (int i = 0; i < D.nsrc; i++) {
+            D.src_limb[i] = (uint8_t)(st + i); D.src_mod[i] = (uint8_t)(st + i);
+            D.src_half[i] = D.single ? 0 : half_product_mod(basis, be.Q->moduli[st + i]);
+        }
+        D.dst_off = (size_t)d * width * N;
+        int n = 0;
+        for (int j = 0; j <= levelQ; j++) {
+            if (j >= st && j < ed) continue;  // own limbs come from the NTT-domain input
+            D.dst_limb[n] = (uint8_t)j; D.dst_mod[n] = (uint8_t)j; D.dst_row[n] = (uint8_t)j; D.dst_view[n] = 0;
+            D.dst_half[n] = D.single ? 0 : half_product_mod(basis, be.Q->moduli[j]);
+            n++;
+        }
+        for (int j = 0; j <= levelP; j++) {
+            D.dst_limb[n] = (uint8_t)(LQ + j); D.dst_mod[n] = (uint8_t)(LQ + j); D.dst_row[n] = (uint8_t)(LQ + j); D.dst_view[n] = 0;
+            D.dst_half[n] = D.single ? 0 : half_product_mod(basis, be.P->moduli[j]);
+            n++;
+        }
+        D.ndst = n;
+        descs.push_back(D);
+    }
+    FusedPlan plan;
+    if (ok && beta * width <= 256) TRY(upload_plan(ev, descs, plan));
+    auto ins = ev.dec_plans.emplace(key, plan);
+    *out = &ins.first->second;
+    return HE_OK;
+}
+// ModUpPtoQ inside ModDownQPtoQNTT at (levelQ, levelP)
+int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
+    auto key = std::make_pair(levelQ, levelP);
+    auto it = ev.md_plans.find(key);
+    if (it != ev.md_plans.end()) { *out = &it->second; return HE_OK; }
+    BasisExtender &be = *ev.be;
+    std::vector<uint64_t> basis(be.P->moduli.begin(), be.P->moduli.begin() + levelP + 1);
+    ModUpDesc D;
+    memset(&D, 0, sizeof D);
+    D.nsrc = levelP + 1;
+    FusedPlan plan;
+    if (D.nsrc <= 8) {
+        const ModUpDev c = be.ptoq[levelP].on(be.pool);
+        D.a = c.a; D.T = c.T; D.vt = c.vt;
+        D.reduce_out = modup_out_needs_reduce(basis) ? 1 : 0;
+        for (int i = 0; i <= levelP; i++) {
+            D.src_limb[i] = (uint8_t)i; D.src_mod[i] = (uint8_t)(be.LQ + i);
+            D.src_half[i] = half_product_mod(basis, be.P->moduli[i]);
+        }
+        for (int j = 0; j <= levelQ; j++) {
+            D.dst_limb[j] = (uint8_t)j; D.dst_mod[j] = (uint8_t)j; D.dst_row[j] = (uint8_t)j; D.dst_view[j] = 0;
+            D.dst_half[j] = half_product_mod(basis, be.Q->moduli[j]);
+        }
+        D.ndst = levelQ + 1;
+        TRY(upload_plan(ev, std::vector<ModUpDesc>{D}, plan));
+    }
+    auto ins = ev.md_plans.emplace(key, plan);
+    *out = &ins.first->second;
+    return HE_OK;
+}
+// forward ROWS pass over every non-own limb of every digit block of a decomposition
+int dec_rows_ntt(Evaluator &ev, int levelQ, int levelP, int nbPi, uint64_t *dec, size_t dec_bs, int batch) {
+    BasisExtender &be = *ev.be;
+    const int LQ = be.LQ, width = be.LQ + be.LP;
+    const int beta = base_rns_size(levelQ, levelP);
+    LimbTab t;
+    t.n = 0;
+    auto flush = [&]() -> int {
+        if (t.n == 0) return HE_OK;
+        HIP_TRY(launch_ntt_rows(be.qp, t, View{dec, dec_bs}, View{dec, dec_bs}, batch, false, 0, be.ctx->stream));
+        t.n = 0;
+        return HE_OK;
+    };
+    for (int d = 0; d < beta; d++) {
+        const int st = d * nbPi, ed = std::min(st + nbPi, levelQ + 1);
+        for (int j = 0; j <= levelQ + levelP + 1; j++) {
+            const bool isP = j > levelQ;
+            const int limb = isP ? LQ + (j - levelQ - 1) : j;
+            if (!isP && j >= st && j < ed) continue;
+            t.in_limb[t.n] = t.out_limb[t.n] = (uint8_t)(d * width + limb);
+            t.mod[t.n] = (uint8_t)limb;
+            if (++t.n == kMaxLimbs) TRY(flush());
+        }
+    }
+    return flush();
 }
 
 struct KsScratch {  // per gadget product, for `batch` entries
@@ -1151,6 +1299,10 @@ size_t ks_scratch_words(const BasisExtender &be, int levelQ, int levelP, int bat
 }
 }  // namespace
 
+namespace {
+int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, uint64_t *dec,
+                    size_t dec_bs, int batch);
+}
 int he_decompose_and_split(he_handle hev, int levelQ, int levelP, int nbPi, int digit, he_handle h0, he_handle h1q, he_handle h1p) {
     GET(ev, Evaluator, hev, T_EVAL);
     GET(p0, Poly, h0, T_POLY);
@@ -1213,6 +1365,19 @@ int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle 
     View other{be.ctx->arena_take(w), (size_t)(levelQ + 1) * N};
     View ntt = c2->view(), inv = other;
     if (c2_is_ntt) {
+        const FusedPlan *plan = nullptr;
+        TRY(get_dec_plan(*ev, levelQ, levelP, nbPi, &plan));
+        if (plan->ok) {
+            HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), c2->view(), other, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+            TRY(decompose_fused(*ev, *plan, levelQ, levelP, nbPi, other, dec->d, dec->bstride(), B));
+            const int beta = base_rns_size(levelQ, levelP);
+            for (int d = 0; d < beta; d++) {  // own limbs: copy of the NTT-domain input (evaluator_gadget_product.go:498-503)
+                const int s0 = d * nbPi, e0 = std::min(s0 + nbPi, levelQ + 1);
+                View blk{dec->d + (size_t)d * dec->dstride(), dec->bstride()};
+                HIP_TRY(launch_ew(be.qp, ident_tab(e0 - s0, s0, s0, s0), EW_COPY, c2->view(), c2->view(), blk, B, nullptr, nullptr, be.ctx->stream));
+            }
+            return HE_OK;
+        }
         HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), c2->view(), other, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
     } else {
         HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), c2->view(), other, B, false, NTT_REDUCE_INPUT, be.ctx->stream));
@@ -1238,6 +1403,17 @@ int get_qp_out(he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, const
     return HE_OK;
 }
 
+// DecomposeNTT through the fused kernels: `rows_inv` = inverse ROWS pass of the NTT-domain input.
+// Own limbs are NOT written (ks_inner reads them from the input; he_decompose_ntt copies them).
+int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, uint64_t *dec,
+                    size_t dec_bs, int batch) {
+    BasisExtender &be = *ev.be;
+    const View dv{dec, dec_bs};
+    for (const FusedGroup &g : plan.groups)
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, rows_inv, dv, dv, batch, be.ctx->stream));
+    return dec_rows_ntt(ev, levelQ, levelP, nbPi, dec, dec_bs, batch);
+}
+
 // GadgetProductLazy core: cx (NTT) -> accumulators (views).  Scratch from the arena.
 int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P) {
     BasisExtender &be = *ev.be;
@@ -1247,31 +1423,75 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
     uint64_t *cxinv = be.ctx->arena_take(wq);
     uint64_t *dec = be.ctx->arena_take((size_t)B * bs);
     View inv{cxinv, (size_t)(levelQ + 1) * N};
+    const FusedPlan *plan = nullptr;
+    TRY(get_dec_plan(ev, levelQ, levelP, levelP + 1, &plan));
+    if (plan->ok) {
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+        TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B));
+        return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
+    }
     HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
     TRY(decompose_ntt_into(ev, levelQ, levelP, levelP + 1, cx, inv, dec, bs, ds, B));
     return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
 }
-// Evaluator.ModDown (NTT/NTT branch): both components
+// ModDownQPtoQNTT up to (not including) its last fused op: sQ = NTTLazy(ModUpPtoQ(INTTLazy(accP))) for nb entries
+int moddown_front(Evaluator &ev, int levelQ, int levelP, View accP, View sP, View sQ, int nb) {
+    BasisExtender &be = *ev.be;
+    hipStream_t st = be.ctx->stream;
+    const FusedPlan *plan = nullptr;
+    TRY(get_md_plan(ev, levelQ, levelP, &plan));
+    if (plan->ok) {
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, NTT_REDUCE_INPUT, st));
+        const FusedGroup &g = plan->groups[0];
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, sP, sQ, sQ, nb, st));
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT, st));
+        return HE_OK;
+    }
+    HIP_TRY(launch_ntt(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, NTT_REDUCE_INPUT, st));
+    TRY(modup_between(be, false, levelP, levelQ, sP, sQ, 0, nb));
+    const bool red = modup_out_needs_reduce(std::vector<uint64_t>(be.P->moduli.begin(), be.P->moduli.begin() + levelP + 1));
+    HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT | (red ? NTT_REDUCE_INPUT : 0), st));
+    return HE_OK;
+}
+// last op of ModDown, optionally fused with the Ring.Add that every caller applies next:
+// out = [add +] MRed(sQ + 2q - accQ, q - P^-1)
+int moddown_back(Evaluator &ev, int levelQ, int levelP, View sQ, View accQ, View out, const View *add, int B) {
+    BasisExtender &be = *ev.be;
+    ScalarTab s{};
+    for (int i = 0; i <= levelQ; i++) s.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
+    if (add) HIP_TRY(launch_ew_w(be.qp, ident_tab(levelQ + 1), EW_SUBMUL2Q_THEN_ADD, sQ, accQ, *add, out, B, &s, be.ctx->stream));
+    else HIP_TRY(launch_ew(be.qp, ident_tab(levelQ + 1), EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sQ, accQ, out, B, &s, nullptr, be.ctx->stream));
+    return HE_OK;
+}
+// Evaluator.ModDown (NTT/NTT branch) on caller-provided accumulators
 int moddown_pair(Evaluator &ev, int levelQ, int levelP, View c0Q, View c0P, View c1Q, View c1P, View out0, View out1, int B) {
     BasisExtender &be = *ev.be;
     const int N = be.Q->N;
     const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
     View sP{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
     View sQ{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
-    TRY(moddown_q_ntt(be, levelQ, levelP, c0Q, c0P, out0, B, sP, sQ));
-    TRY(moddown_q_ntt(be, levelQ, levelP, c1Q, c1P, out1, B, sP, sQ));
+    TRY(moddown_front(ev, levelQ, levelP, c0P, sP, sQ, B));
+    TRY(moddown_back(ev, levelQ, levelP, sQ, c0Q, out0, nullptr, B));
+    TRY(moddown_front(ev, levelQ, levelP, c1P, sP, sQ, B));
+    TRY(moddown_back(ev, levelQ, levelP, sQ, c1Q, out1, nullptr, B));
     return HE_OK;
 }
-// full GadgetProduct into (out0, out1) views (levelQ+1 limbs each)
-int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp *hoisted, const Evk &k, View out0, View out1, int B) {
+// full GadgetProduct: out_k = [add_k +] GadgetProduct(cx)_k.  Both components share every launch
+// (accumulators are laid out [2][B] so ModDown runs once over 2B entries).
+int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp *hoisted, const Evk &k, View out0, View out1, int B,
+                        const View *add0 = nullptr, const View *add1 = nullptr) {
     BasisExtender &be = *ev.be;
     const int levelP = k.nPk - 1, N = be.Q->N;
-    const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
-    View a0Q{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N}, a1Q{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
-    View a0P{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N}, a1P{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
+    const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
+    uint64_t *aQ = be.ctx->arena_take(2 * B * sQw), *aP = be.ctx->arena_take(2 * B * sPw);
+    View a0Q{aQ, sQw}, a1Q{aQ + (size_t)B * sQw, sQw}, a0P{aP, sPw}, a1P{aP + (size_t)B * sPw, sPw};
     if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P));
     else TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
-    return moddown_pair(ev, levelQ, levelP, a0Q, a0P, a1Q, a1P, out0, out1, B);
+    View sP{be.ctx->arena_take(2 * B * sPw), sPw}, sQ{be.ctx->arena_take(2 * B * sQw), sQw};
+    TRY(moddown_front(ev, levelQ, levelP, View{aP, sPw}, sP, sQ, 2 * B));
+    TRY(moddown_back(ev, levelQ, levelP, sQ, a0Q, out0, add0, B));
+    TRY(moddown_back(ev, levelQ, levelP, View{sQ.p + (size_t)B * sQw, sQw}, a1Q, out1, add1, B));
+    return HE_OK;
 }
 int check_key(const Evaluator &ev, const Evk &k, int &levelQ, const char *who) {
     if (k.ev.get() != &ev) return fail(HE_EINVAL, "%s: key belongs to another evaluator", who);
@@ -1370,14 +1590,10 @@ int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_
     }
     Scope sc(be.ctx.get());
     const int B = in0->batch, N = be.Q->N;
-    const size_t wQ = (size_t)B * (level + 1) * N;
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true) + 2 * wQ));
-    View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
-    const View in2v = in2->view();
-    TRY(gadget_product_core(*ev, level, &in2v, nullptr, *k, t0, t1, B));
-    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, in0->view(), t0, out0->view(), B, nullptr, nullptr, be.ctx->stream));
-    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, in1->view(), t1, out1->view(), B, nullptr, nullptr, be.ctx->stream));
-    return HE_OK;
+    (void)N;
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true)));
+    const View in2v = in2->view(), in0v = in0->view(), in1v = in1->view();
+    return gadget_product_core(*ev, level, &in2v, nullptr, *k, out0->view(), out1->view(), B, &in0v, &in1v);
 }
 
 // Automorphism / AutomorphismHoisted (core/rlwe/evaluator_automorphism.go:13-100), NTT domain
@@ -1411,8 +1627,8 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     HIP_TRY(launch_build_automorphism_index(be.Q->logN, gal, index, st));
     View in1v{nullptr, 0};
     if (in1) in1v = in1->view();
-    TRY(gadget_product_core(*ev, level, in1 ? &in1v : nullptr, dec ? dec.get() : nullptr, *k, t0, t1, B));
-    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, t0, in0->view(), t0, B, nullptr, nullptr, st));
+    const View in0v = in0->view();
+    TRY(gadget_product_core(*ev, level, in1 ? &in1v : nullptr, dec ? dec.get() : nullptr, *k, t0, t1, B, &in0v, nullptr));
     HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t0, index, out0->view(), B, false, st));
     HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t1, index, out1->view(), B, false, st));
     return HE_OK;
@@ -1474,15 +1690,12 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
                               out1->view(), out2->view(), B, st));
         return HE_OK;
     }
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true) + 3 * wQ));
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true) + wQ));
     View c2{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
-    View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
     HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),
                           out1->view(), c2, B, st));
-    TRY(gadget_product_core(*ev, level, &c2, nullptr, *k, t0, t1, B));
-    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, out0->view(), t0, out0->view(), B, nullptr, nullptr, st));
-    HIP_TRY(launch_ew(be.qp, ident_tab(level + 1), EW_ADD, out1->view(), t1, out1->view(), B, nullptr, nullptr, st));
-    return HE_OK;
+    const View o0v = out0->view(), o1v = out1->view();
+    return gadget_product_core(*ev, level, &c2, nullptr, *k, o0v, o1v, B, &o0v, &o1v);
 }
 int he_ckks_mul_relin(he_handle ev, int level, he_handle a0, he_handle a1, he_handle b0, he_handle b1, he_handle rlk, he_handle o0, he_handle o1, he_handle o2) {
     return mul_relin_common(ev, level, false, 0, a0, a1, b0, b1, rlk, o0, o1, o2, "he_ckks_mul_relin");

@@ -41,6 +41,11 @@ enum NttFlags {
 };
 hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
                       hipStream_t s);
+// only the contiguous-row pass (the last min(logN,12) forward stages / the first ones of the inverse);
+// the strided column stages are then done by the producer / consumer kernel (launch_modup_fused).
+// For logN <= 12 this is the whole transform (inverse: N^-1 included).
+hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
+                           hipStream_t s);
 
 // ---- coefficient-wise -----------------------------------------------------------------
 // op codes: 0..16 = he_binop, 100.. = he_unop, 200.. = scalar forms (scalar per limb in sc[])
@@ -59,6 +64,7 @@ enum EwOp {
     // rescale / moddown fused forms (two-limb inputs)
     EW_SUB_THEN_MUL_SCALAR_MONT_2Q = 300,  // z = MRed(2q - y + x, s)          vec_ops.go:766
     EW_DIVROUND_COEFF,                     // z = MRed(x + (s0 + 2q - y), s)    scaling.go:138-142 (x = top limb + pHalf)
+    EW_SUBMUL2Q_THEN_ADD,                  // z = CRed(z + MRed(2q - y + x, s)): ModDown epilogue fused with Ring.Add
 };
 struct ScalarTab {
     uint64_t s[kMaxLimbs];   // per launch-limb scalar
@@ -67,6 +73,9 @@ struct ScalarTab {
 // z[out_limb] = op(x[in_limb], y[in_limb or y_limb], z)   (y uses tab.in_limb unless y_tab given)
 hipError_t launch_ew(const RingDev &r, const LimbTab &tab, int op, View x, View y, View z, int batch,
                      const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s);
+// same with a separate addend view w for the *_THEN_ADD forms (z = f(x, y) + w)
+hipError_t launch_ew_w(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
+                       const ScalarTab *sc, hipStream_t s);
 
 // ---- automorphism ------------------------------------------------------------------------
 hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const uint32_t *index, View out, int batch,
@@ -98,6 +107,25 @@ hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a,
 hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, View dstA, View dstB, int batch,
                               hipStream_t s);
 
+// Fused basis extension for the key-switch pipelines: [last `a` inverse-NTT stages + N^-1 on the
+// sources] -> ModUpExact (or the centred copy of a one-limb digit) -> [first `a` forward-NTT stages on
+// every destination limb], a = logN - 12.  Sources are the output of the inverse ROWS pass, destinations
+// feed the forward ROWS pass, so the strided "column" passes never touch HBM on their own.
+// One descriptor per digit, resident in device memory (built once per (levelQ, levelP) plan).
+struct ModUpDesc {
+    int nsrc, ndst, single, reduce_out;
+    const uint64_t *a, *T, *vt;
+    uint64_t src_half[8];
+    uint8_t src_limb[8], src_mod[8];
+    size_t dst_off;  // words added to the destination bases (digit block)
+    uint8_t dst_limb[kMaxLimbs], dst_mod[kMaxLimbs], dst_row[kMaxLimbs], dst_view[kMaxLimbs];
+    uint64_t dst_half[kMaxLimbs];
+};
+// all descriptors must share nsrc; returns hipErrorInvalidValue when (nsrc, logN) has no fused kernel
+bool modup_fused_supported(int logN, int nsrc);
+hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, View src, View dstA,
+                              View dstB, int batch, hipStream_t s);
+
 // ---- key-switch inner product ---------------------------------------------------------------
 // acc[k][l] = sum_d evk[d][k][l] * dec[d][l] * 2^-64 mod q_l, canonical
 // (core/rlwe/evaluator_gadget_product.go:160-200 after its final Reduce).
@@ -112,9 +140,13 @@ struct KsArgs {
     size_t dec_dstride;               // words between digits in dec
     size_t key_kstride;               // words between k=0 and k=1 blocks
     size_t key_dstride;               // words between digits in the key
+    // optional: the digit's own limbs are read straight from the NTT-domain input instead of dec
+    // (core/rlwe/evaluator_gadget_product.go:498-503 copies them); alpha = 0 disables
+    int own_alpha;                    // digit d owns Q limbs [d*alpha, (d+1)*alpha)
+    int own_nq;                       // launch limbs < own_nq are Q limbs with limb index == launch index
 };
-hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, const uint64_t *key, View out0Q, View out0P,
-                           View out1Q, View out1P, int batch, hipStream_t s);
+hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
+                           View out0P, View out1Q, View out1P, int batch, hipStream_t s);
 
 // ---- ciphertext tensor product (schemes/ckks/evaluator.go:807-820, schemes/bgv/evaluator.go:634-647)
 // c0 = MRed(MRed(a0,s),b0), c2 = MRed(MRed(a1,s),b1), c1 = CRed(MRed(MRed(a0,s),b1) + MRed(MRed(a1,s),b0))

@@ -373,14 +373,30 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     return hipSuccess;
 }
 
+hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
+                           hipStream_t s) {
+    if (tab.n <= 0 || batch <= 0) return hipSuccess;
+    const int n = r.logN;
+    if (n < 4 || n > 17) return hipErrorInvalidValue;
+    const int a = n > 12 ? n - 12 : 0, b = n - a;
+    NttArgs A;
+    A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
+    A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
+    A.flags = flags;
+    dim3 grows(1u << a, tab.n, batch);
+    if (!inverse) { A.tw = r.tw_fwd; A.scale = 0; return launch_rows<false>(b, grows, A, s); }
+    A.tw = r.tw_inv; A.scale = (a == 0);
+    return launch_rows<true>(b, grows, A, s);
+}
+
 // ------------------------------------------------------------------------------------
 // coefficient-wise kernels (ring/vec_ops.go): one launch for all limbs x batch.
 // Each thread handles two adjacent coefficients (16-byte accesses).
 // ------------------------------------------------------------------------------------
 struct EwArgs {
-    const uint64_t *x, *y;
+    const uint64_t *x, *y, *w;
     uint64_t *z;
-    size_t x_bs, y_bs, z_bs;
+    size_t x_bs, y_bs, z_bs, w_bs;
     const ModConst *mc;
     int N;
     int n;
@@ -422,17 +438,19 @@ __device__ __forceinline__ uint64_t ew_apply(uint64_t x, uint64_t y, uint64_t z,
     else if constexpr (OP == EW_ADD_SCALAR_LAZY) return x + s;
     else if constexpr (OP == EW_SUB_THEN_MUL_SCALAR_MONT_2Q) return mred((q << 1) - y + x, s, q, qinv);
     else if constexpr (OP == EW_DIVROUND_COEFF) return mred(x + (s2 + (q << 1) - y), s, q, qinv);
+    else if constexpr (OP == EW_SUBMUL2Q_THEN_ADD) return cred(z + mred((q << 1) - y + x, s, q, qinv), q);
     else return 0;
 }
 template <int OP>
 constexpr bool ew_reads_y() {
-    return (OP >= 0 && OP < 100) || OP == EW_SUB_THEN_MUL_SCALAR_MONT_2Q || OP == EW_DIVROUND_COEFF;
+    return (OP >= 0 && OP < 100) || OP == EW_SUB_THEN_MUL_SCALAR_MONT_2Q || OP == EW_DIVROUND_COEFF || OP == EW_SUBMUL2Q_THEN_ADD;
 }
 template <int OP>
 constexpr bool ew_reads_z() {
     return OP == EW_MUL_BARRETT_THEN_ADD || OP == EW_MUL_BARRETT_THEN_ADD_LAZY || OP == EW_MUL_MONT_THEN_ADD ||
            OP == EW_MUL_MONT_THEN_ADD_LAZY || OP == EW_MUL_MONT_LAZY_THEN_ADD_LAZY || OP == EW_MUL_MONT_THEN_SUB ||
-           OP == EW_MUL_MONT_THEN_SUB_LAZY || OP == EW_MUL_MONT_LAZY_THEN_SUB_LAZY || OP == EW_MUL_SCALAR_MONT_THEN_ADD;
+           OP == EW_MUL_MONT_THEN_SUB_LAZY || OP == EW_MUL_MONT_LAZY_THEN_SUB_LAZY || OP == EW_MUL_SCALAR_MONT_THEN_ADD ||
+           OP == EW_SUBMUL2Q_THEN_ADD;
 }
 
 template <int OP>
@@ -448,19 +466,30 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
     if constexpr (ew_reads_y<OP>())
         yv = *reinterpret_cast<const ulonglong2 *>(A.y + bz * A.y_bs + (size_t)A.y_limb[yy] * A.N + j);
     uint64_t *zp = A.z + bz * A.z_bs + (size_t)A.z_limb[yy] * A.N + j;
-    if constexpr (ew_reads_z<OP>()) zv = *reinterpret_cast<const ulonglong2 *>(zp);
+    if constexpr (ew_reads_z<OP>())
+        zv = *reinterpret_cast<const ulonglong2 *>(A.w + bz * A.w_bs + (size_t)A.z_limb[yy] * A.N + j);
     ulonglong2 o;
     o.x = ew_apply<OP>(xv.x, yv.x, zv.x, m, s, s2);
     o.y = ew_apply<OP>(xv.y, yv.y, zv.y, m, s, s2);
     *reinterpret_cast<ulonglong2 *>(zp) = o;
 }
 
+static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
+                                 const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s);
 hipError_t launch_ew(const RingDev &r, const LimbTab &tab, int op, View x, View y, View z, int batch,
                      const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s) {
+    return launch_ew_impl(r, tab, op, x, y, z, z, batch, sc, x_limb_override, s);
+}
+hipError_t launch_ew_w(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
+                       const ScalarTab *sc, hipStream_t s) {
+    return launch_ew_impl(r, tab, op, x, y, w, z, batch, sc, nullptr, s);
+}
+static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
+                                 const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s) {
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     EwArgs A;
-    A.x = x.p; A.y = y.p; A.z = z.p;
-    A.x_bs = x.bstride; A.y_bs = y.bstride; A.z_bs = z.bstride;
+    A.x = x.p; A.y = y.p; A.z = z.p; A.w = w.p;
+    A.x_bs = x.bstride; A.y_bs = y.bstride; A.z_bs = z.bstride; A.w_bs = w.bstride;
     A.mc = r.mc; A.N = r.N; A.n = tab.n;
     for (int i = 0; i < tab.n; i++) {
         A.x_limb[i] = x_limb_override ? x_limb_override[i] : tab.in_limb[i];
@@ -485,7 +514,7 @@ hipError_t launch_ew(const RingDev &r, const LimbTab &tab, int op, View x, View 
         HE_EW_CASE(EW_MFORM_LAZY) HE_EW_CASE(EW_IMFORM) HE_EW_CASE(EW_COPY)
         HE_EW_CASE(EW_ADD_SCALAR) HE_EW_CASE(EW_SUB_SCALAR) HE_EW_CASE(EW_MUL_SCALAR_MONT)
         HE_EW_CASE(EW_MUL_SCALAR_MONT_THEN_ADD) HE_EW_CASE(EW_ADD_SCALAR_LAZY)
-        HE_EW_CASE(EW_SUB_THEN_MUL_SCALAR_MONT_2Q) HE_EW_CASE(EW_DIVROUND_COEFF)
+        HE_EW_CASE(EW_SUB_THEN_MUL_SCALAR_MONT_2Q) HE_EW_CASE(EW_DIVROUND_COEFF) HE_EW_CASE(EW_SUBMUL2Q_THEN_ADD)
         default: return hipErrorInvalidValue;
     }
 #undef HE_EW_CASE
@@ -663,6 +692,165 @@ hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a,
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// fused basis extension (see kernels.h): one thread owns the 2^LOGA coefficients
+// {c + r*N/2^LOGA} of every source / destination limb.
+// ------------------------------------------------------------------------------------
+struct ModUpFusedArgs {
+    const ModUpDesc *desc;
+    const uint64_t *src;
+    uint64_t *dstA, *dstB;
+    size_t src_bs, dstA_bs, dstB_bs;
+    const ModConst *mc;
+    const uint64_t *tw_fwd, *tw_inv;
+    int N;
+};
+
+template <int NSRC, int LOGA>
+__global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
+    constexpr int R = 1 << LOGA;
+    const int N2 = A.N >> LOGA;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N2) return;
+    const ModUpDesc &D = A.desc[blockIdx.y];
+    const size_t bz = blockIdx.z;
+    const uint64_t *src = A.src + bz * A.src_bs + c;
+
+    uint64_t y[R][NSRC];
+    double vi[R];
+    uint64_t neg[R];  // centred-copy path only
+#pragma unroll
+    for (int r = 0; r < R; r++) { vi[r] = 0.0; neg[r] = 0; }
+#pragma unroll
+    for (int i = 0; i < NSRC; i++) {
+        const int mi = D.src_mod[i];
+        const ModConst mq = A.mc[mi];
+        const uint64_t q = mq.q, qinv = mq.qinv, twoq = mq.q << 1;
+        uint64_t x[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = src[(size_t)D.src_limb[i] * A.N + (size_t)r * N2];
+        if constexpr (LOGA > 0) {  // finish the inverse NTT: the LOGA strided stages, N^-1 folded into the last
+            const uint64_t *tw = A.tw_inv + (size_t)mi * A.N;
+#pragma unroll
+            for (int s = LOGA - 1; s >= 0; s--) {
+                const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (r & d) continue;
+                    const uint64_t wv = tw[(1 << s) + (r >> (LOGA - s))];
+                    if (s == 0) bfly_inv_scaled(x[r], x[r + d], mred(wv, mq.ninv, q, qinv), mq.ninv, q, twoq, qinv);
+                    else bfly_inv(x[r], x[r + d], wv, q, twoq, qinv);
+                }
+            }
+        }
+        if (D.single) {  // one-limb digit: centred value (ring/basis_extension.go:402-436)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint64_t cv = x[r];
+                neg[r] = cv >= (q >> 1);
+                y[r][i] = neg[r] ? q - cv : cv;
+            }
+        } else {
+            const uint64_t h = D.src_half[i], ai = D.a[i];
+            const double qf = __ull2double_rn(q);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint64_t yi = mred(cred(x[r] + h, q), ai, q, qinv);
+                y[r][i] = yi;
+                vi[r] = __dadd_rn(vi[r], __ddiv_rn(__ull2double_rn(yi), qf));
+            }
+        }
+    }
+    uint32_t v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = (uint32_t)(uint64_t)vi[r];
+
+    for (int j = 0; j < D.ndst; j++) {
+        const int mi = D.dst_mod[j];
+        const ModConst mp = A.mc[mi];
+        const uint64_t p = mp.q, pinv = mp.qinv, twop = mp.q << 1;
+        uint64_t o[R];
+        if (D.single) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint64_t t = bred_add(y[r][0], p, mp.brc0);
+                o[r] = neg[r] ? p - t : t;
+            }
+        } else {
+            const int row = D.dst_row[j];
+            const uint64_t *Tr = D.T + (size_t)row * NSRC;
+            const uint64_t *vtr = D.vt + (size_t)row * (NSRC + 1);
+            const uint64_t hd = D.dst_half[j];
+            uint64_t Tv[NSRC];
+#pragma unroll
+            for (int i = 0; i < NSRC; i++) Tv[i] = Tr[i];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                u128 acc = (u128)y[r][0] * Tv[0];
+#pragma unroll
+                for (int i = 1; i < NSRC; i++) acc += (u128)y[r][i] * Tv[i];
+                uint64_t res = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p + vtr[v[r]];
+                res = cred(res + p - hd, p);
+                if (D.reduce_out) res = bred_add_lazy(res, p, mp.brc0);
+                o[r] = res;
+            }
+        }
+        if constexpr (LOGA > 0) {  // start the forward NTT: the LOGA strided stages
+            const uint64_t *tw = A.tw_fwd + (size_t)mi * A.N;
+#pragma unroll
+            for (int s = 0; s < LOGA; s++) {
+                const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (r & d) continue;
+                    bfly_fwd(o[r], o[r + d], tw[(1 << s) + (r >> (LOGA - s))], p, twop, pinv);
+                }
+            }
+        }
+        uint64_t *dst = (D.dst_view[j] ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs)) + D.dst_off +
+                        (size_t)D.dst_limb[j] * A.N + c;
+#pragma unroll
+        for (int r = 0; r < R; r++) dst[(size_t)r * N2] = o[r];
+    }
+}
+
+bool modup_fused_supported(int logN, int nsrc) {
+    const int a = logN > 12 ? logN - 12 : 0;
+    return nsrc >= 1 && nsrc <= 5 && (a == 0 || a == 2 || a == 3 || a == 4);
+}
+
+hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, View src, View dstA,
+                              View dstB, int batch, hipStream_t s) {
+    if (ndesc <= 0 || batch <= 0) return hipSuccess;
+    if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
+    const int a = r.logN > 12 ? r.logN - 12 : 0;
+    ModUpFusedArgs A;
+    A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
+    A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
+    A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.N = r.N;
+    const int n2 = r.N >> a;
+    dim3 grid((unsigned)((n2 + 127) / 128), ndesc, batch), block(128);
+    ProfScope ps(K_MODUP, s);
+#define HE_MF(NS, LA) hipLaunchKernelGGL((modup_fused_kernel<NS, LA>), grid, block, 0, s, A)
+#define HE_MF_A(NS)                                  \
+    switch (a) {                                     \
+        case 0: HE_MF(NS, 0); break;                 \
+        case 2: HE_MF(NS, 2); break;                 \
+        case 3: HE_MF(NS, 3); break;                 \
+        default: HE_MF(NS, 4); break;                \
+    }
+    switch (nsrc) {
+        case 1: HE_MF_A(1); break;
+        case 2: HE_MF_A(2); break;
+        case 3: HE_MF_A(3); break;
+        case 4: HE_MF_A(4); break;
+        default: HE_MF_A(5); break;
+    }
+#undef HE_MF_A
+#undef HE_MF
+    return hipGetLastError();
+}
+
 // single-limb digit (ring/basis_extension.go:402-436): centred value reduced into every
 // destination limb:  c >= q/2 ? q_dst - BRedAdd(q - c) : BRedAdd(c)
 struct CenterArgs {
@@ -708,6 +896,8 @@ hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, Vi
 // once per thread and reused across BB batch entries.
 // ------------------------------------------------------------------------------------
 struct KsKArgs {
+    const uint64_t *own;
+    size_t own_bs;
     const uint64_t *dec;
     const uint64_t *key;
     uint64_t *o0Q, *o0P, *o1Q, *o1P;
@@ -730,13 +920,17 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
     for (int b = 0; b < BB; b++) { hi0[b] = lo0[b] = hi1[b] = lo1[b] = 0; }
     const uint64_t *kp = A.key + (size_t)A.k.key_limb[l] * A.N + x;
     const uint64_t *dp = A.dec + (size_t)A.k.dec_limb[l] * A.N + x;
+    const uint64_t *op = A.own + (size_t)l * A.N + x;
     for (int d = 0; d < A.k.beta; d++) {
         const uint64_t k0 = kp[(size_t)d * A.k.key_dstride];
         const uint64_t k1 = kp[(size_t)d * A.k.key_dstride + A.k.key_kstride];
+        // the digit's own Q limbs come from the NTT-domain input itself (block-uniform branch)
+        const bool is_own = A.k.own_alpha > 0 && l < A.k.own_nq && l >= d * A.k.own_alpha && l < (d + 1) * A.k.own_alpha;
 #pragma unroll
         for (int b = 0; b < BB; b++) {
             if (b0 + b < A.batch) {
-                const uint64_t c = dp[(size_t)(b0 + b) * A.dec_bs + (size_t)d * A.k.dec_dstride];
+                const uint64_t c = is_own ? op[(size_t)(b0 + b) * A.own_bs]
+                                          : dp[(size_t)(b0 + b) * A.dec_bs + (size_t)d * A.k.dec_dstride];
                 uint64_t ph, pl;
                 mul64wide(c, k0, ph, pl);
                 lo0[b] += pl; hi0[b] += ph + (lo0[b] < pl);
@@ -762,10 +956,11 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
     }
 }
 
-hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, const uint64_t *key, View out0Q, View out0P,
-                           View out1Q, View out1P, int batch, hipStream_t s) {
+hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
+                           View out0P, View out1Q, View out1P, int batch, hipStream_t s) {
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     KsKArgs A;
+    A.own = own.p; A.own_bs = own.bstride;
     A.dec = dec.p; A.dec_bs = dec.bstride; A.key = key;
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
