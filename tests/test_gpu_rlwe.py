@@ -251,3 +251,63 @@ def test_full_size_properties_logN15(ctx):
     oev = O.Evaluator(pr.oQ, pr.oP)
     want = oev.GadgetProduct(nq - 1, cx[1], O.EvaluationKey(kq, kp))
     assert np.array_equal(g0[1], want[0]) and np.array_equal(ct1[1].get(), want[1])
+
+
+def _full_size_check(ctx, logN, logq, logp, seed, do_rotate):
+    """Full-size config check: one limb-complete oracle comparison of GadgetProduct (+ Rotate) on a
+    random key, batch of 2, plus hoisted == plain."""
+    q, p = O.GenModuli(logN + 1, logq, logp)
+    nq, np_ = len(q), len(p)
+    pr = Pair(ctx, logN, nq, np_, qmods=q, pmods=p)
+    rng = rng_for(seed)
+    gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+    beta = O.BaseRNSDecompositionVectorSize(nq - 1, np_ - 1)
+    kq = np.stack([np.stack([uniform_poly(rng, q, pr.N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, pr.N) for _ in range(2)]) for _ in range(beta)])
+    gevk, oevk = gev.NewEvaluationKey(kq, kp), O.EvaluationKey(kq, kp)
+    for level in (nq - 1, nq - 2):
+        Qm = q[: level + 1]
+        ct = np.stack([np.stack([uniform_poly(rng, Qm, pr.N) for _ in range(2)]) for _ in range(2)])  # [b][k]
+        pc = [la.Poly(pr.gQ, level + 1, 2).upload(ct[:, k]) for k in range(2)]
+        out = [la.Poly(pr.gQ, level + 1, 2), la.Poly(pr.gQ, level + 1, 2)]
+        gev.GadgetProduct(level, pc[1], gevk, out)
+        g = [o.get() for o in out]
+        want = oev.GadgetProduct(level, ct[1, 1], oevk)
+        assert np.array_equal(g[0][1], want[0]) and np.array_equal(g[1][1], want[1]), ("GadgetProduct", level)
+        if do_rotate:
+            galel = pow(5, 3, 2 * pr.N)
+            out2 = [la.Poly(pr.gQ, level + 1, 2), la.Poly(pr.gQ, level + 1, 2)]
+            gev.Automorphism(level, pc, galel, gevk, out2)
+            wantr = oev.Automorphism(ct[0], galel, oevk)
+            assert np.array_equal(out2[0].get()[0], wantr[0]) and np.array_equal(out2[1].get()[0], wantr[1]), ("Rotate", level)
+            dec = la.Decomposition(gev, 2)
+            gev.DecomposeNTT(level, np_ - 1, np_, pc[1], True, dec)
+            out3 = [la.Poly(pr.gQ, level + 1, 2), la.Poly(pr.gQ, level + 1, 2)]
+            gev.AutomorphismHoisted(level, pc, dec, galel, gevk, out3)
+            assert np.array_equal(out3[0].get(), out2[0].get()) and np.array_equal(out3[1].get(), out2[1].get())
+        # MulRelin (CKKS tensor) + Rescale at this level
+        ct2 = np.stack([uniform_poly(rng, Qm, pr.N) for _ in range(2)])
+        a = [la.Poly(pr.gQ, level + 1).upload(c) for c in ct[0]]
+        b = [la.Poly(pr.gQ, level + 1).upload(c) for c in ct2]
+        o2 = [la.Poly(pr.gQ, level + 1), la.Poly(pr.gQ, level + 1)]
+        gev.CKKSMulRelin(level, a, b, gevk, o2)
+        wantm = oev.CKKSMulRelin(ct[0], ct2, oevk, True)
+        assert np.array_equal(np.stack([o.get() for o in o2]), wantm), ("MulRelin", level)
+        res = [la.Poly(pr.gQ, level), la.Poly(pr.gQ, level)]
+        gev.Rescale(level, 1, o2, res)
+        assert np.array_equal(np.stack([r.get() for r in res]), oev.Rescale(wantm, 1)), ("Rescale", level)
+
+
+def test_full_size_config2_ckks_logN14(ctx):
+    """BASELINE config 2: CKKS LogN=14, LogQ=[50,40x7], LogP=[60] (alpha = 1 path)."""
+    _full_size_check(ctx, 14, [50] + [40] * 7, [60], 2, True)
+
+
+def test_full_size_config4_ckks_logN16(ctx):
+    """BASELINE config 4: CKKS LogN=16, LogQ=[60,45x19], LogP=[61x4] (alpha = 4, beta = 5): Rotate."""
+    _full_size_check(ctx, 16, [60] + [45] * 19, [61] * 4, 4, True)
+
+
+def test_full_size_config5_shape_logN16(ctx):
+    """Bootstrapping-sized chain (logN=16, 25 Q-limbs, 5 P-limbs of 61 bits, alpha = 5)."""
+    _full_size_check(ctx, 16, [60] + [45] * 10 + [60] * 6 + [40] * 8, [61] * 5, 5, False)
