@@ -102,6 +102,7 @@ struct Ring : Obj {
     std::vector<std::vector<uint64_t>> rescale;  // [j-1][i]
     ModConst *d_mc = nullptr;
     uint64_t *d_twf = nullptr, *d_twi = nullptr;
+    std::vector<uint8_t> small;
     RingDev dev{};
     Ring() : Obj(T_RING) {}
     ~Ring() override {
@@ -182,6 +183,7 @@ struct BasisExtender : Obj {
     int LQ = 0, LP = 0;
     ModConst *d_mc = nullptr;
     uint64_t *d_twf = nullptr, *d_twi = nullptr;
+    std::vector<uint8_t> small;
     RingDev qp{};
     ConstPool pool;
     std::vector<ModUpRef> qtop, ptoq;                      // per source level
@@ -416,7 +418,8 @@ int he_ring_create(he_handle hctx, int logN, const uint64_t *moduli, int n, he_h
     std::vector<const SubRingHost *> subs;
     for (auto &s : r->sub) subs.push_back(&s);
     TRY(upload_tables(subs, r->N, &r->d_mc, &r->d_twf, &r->d_twi));
-    r->dev = RingDev{logN, r->N, r->d_mc, r->d_twf, r->d_twi};
+    for (uint64_t m : r->moduli) r->small.push_back((m >> 58) == 0);
+    r->dev = RingDev{logN, r->N, r->d_mc, r->d_twf, r->d_twi, r->small.data()};
     *out = reg(r);
     return HE_OK;
 }
@@ -845,7 +848,9 @@ int he_basis_extender_create(he_handle hq, he_handle hp, he_handle *out) {
     for (auto &s : Q->sub) subs.push_back(&s);
     for (auto &s : P->sub) subs.push_back(&s);
     TRY(upload_tables(subs, Q->N, &be->d_mc, &be->d_twf, &be->d_twi));
-    be->qp = RingDev{Q->logN, Q->N, be->d_mc, be->d_twf, be->d_twi};
+    for (uint64_t m : Q->moduli) be->small.push_back((m >> 58) == 0);
+    for (uint64_t m : P->moduli) be->small.push_back((m >> 58) == 0);
+    be->qp = RingDev{Q->logN, Q->N, be->d_mc, be->d_twf, be->d_twi, be->small.data()};
     for (int i = 0; i < be->LQ; i++)  // constantsQtoP[i] = GenModUpConstants(Q[:i+1], P)     basis_extension.go:62-65
         be->qtop.push_back(pool_modup(be->pool, std::vector<uint64_t>(Q->moduli.begin(), Q->moduli.begin() + i + 1), P->moduli));
     for (int i = 0; i < be->LP; i++)  // constantsPtoQ[i] = GenModUpConstants(P[:i+1], Q)     :67-70

@@ -32,6 +32,7 @@ struct RingDev {
     const ModConst *mc;      // [n_mod]
     const uint64_t *tw_fwd;  // [n_mod][N] RootsForward  (Montgomery form, bit-reversed order)
     const uint64_t *tw_inv;  // [n_mod][N] RootsBackward
+    const uint8_t *host_small;  // HOST array [n_mod]: 1 when the modulus is below 2^58 (correction-free butterflies)
 };
 
 // ---- NTT ---------------------------------------------------------------------------

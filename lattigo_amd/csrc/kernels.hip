@@ -75,6 +75,18 @@ __device__ __forceinline__ void bfly_fwd(uint64_t &a, uint64_t &b, uint64_t w, u
     a = U + V;
     b = U + twoq - V;
 }
+// forward without range correction, for q < 2^58: every output is below (input bound + 2q), so the
+// 15 stages of a logN=16 transform stay below 34q < 2^64; one Barrett reduction at the very end.
+//   d = V*w*2^-64 - q (signed, |d| < q);  X = U + q + d,  Y = U + q - d
+__device__ __forceinline__ void bfly_fwd_nc(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t qinv) {
+    uint64_t ahi, alo;
+    mul64wide(b, w, ahi, alo);
+    const uint64_t d = ahi - mulhi64(alo * qinv, q);
+    const uint64_t uq = a + q;
+    a = uq + d;
+    b = uq - d;
+}
+constexpr int kNoCorrBits = 58;
 // inverse: U,V in [0,2q) -> X,Y in [0,2q)
 __device__ __forceinline__ void bfly_inv(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t twoq, uint64_t qinv) {
     uint64_t U = a, V = b;
@@ -108,12 +120,78 @@ __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
 // ------------------------------------------------------------------------------------
 // ntt_rows: b = LOGB stages on one contiguous row of 2^LOGB coefficients per workgroup.
 // grid = (rows per limb = 2^a, limbs, batch), block = 2^LOGB / 16 threads.
+// Rounds of g <= 4 stages; in a round a thread owns W = 16/2^g groups of 2^g coefficients
+//   e = hi*2^(LOGB-s0) + k*2^sh + lo,  sh = LOGB-s0-g,  group id = tau*W + w = hi*2^sh + lo
+// and stage s0+u uses twiddle index 2^(s0+u)*(2^a+row) + hi*2^u + (k >> (g-u)).
+// The round loop is NOT unrolled (the three radix-16 rounds of a 4096-row share one copy of
+// the 32-butterfly network; the fully unrolled kernel overflowed the instruction cache).
+// NC: butterflies without range correction (all moduli of the launch below 2^58).
 // ------------------------------------------------------------------------------------
-template <int LOGB, bool INV>
+template <int G4, bool INV, bool NC>
+__device__ __forceinline__ void rows_round(uint64_t (&x)[16], const uint64_t *__restrict__ tw, int rowtw, int s0, int hi0,
+                                           int tau, int sh, uint64_t q, uint64_t twoq, uint64_t qinv, const ModConst &mc,
+                                           bool scale_last) {
+    // G4 = log2 of the group size (g), W = 16 >> g groups per thread
+    constexpr int g = G4, G = 1 << g, W = 16 / G;
+    if constexpr (!INV) {
+#pragma unroll
+        for (int u = 0; u < g; u++) {
+            const int d = 1 << (g - 1 - u);
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const int hi = (W == 1) ? hi0 : ((tau * W + w) >> sh);
+                const int base = (rowtw << (s0 + u)) + (hi << u);
+#pragma unroll
+                for (int k = 0; k < G; k++) {
+                    if (k & d) continue;
+                    const uint64_t wv = tw[base + (k >> (g - u))];
+                    if constexpr (NC) bfly_fwd_nc(x[w * G + k], x[w * G + k + d], wv, q, qinv);
+                    else bfly_fwd(x[w * G + k], x[w * G + k + d], wv, q, twoq, qinv);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = g - 1; u >= 0; u--) {
+            const int d = 1 << (g - 1 - u);
+            const bool last = scale_last && u == 0;
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const int hi = (W == 1) ? hi0 : ((tau * W + w) >> sh);
+                const int base = (rowtw << (s0 + u)) + (hi << u);
+#pragma unroll
+                for (int k = 0; k < G; k++) {
+                    if (k & d) continue;
+                    const uint64_t wv = tw[base + (k >> (g - u))];
+                    if (last) bfly_inv_scaled(x[w * G + k], x[w * G + k + d], mred(wv, mc.ninv, q, qinv), mc.ninv, q, twoq, qinv);
+                    else bfly_inv(x[w * G + k], x[w * G + k + d], wv, q, twoq, qinv);
+                }
+            }
+        }
+    }
+}
+
+template <int LOGB, int G4>
+__device__ __forceinline__ void rows_lds_xfer(uint64_t (&x)[16], uint64_t *lds, int tau, int s0, int sh, bool store) {
+    constexpr int g = G4, G = 1 << g, W = 16 / G;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const int e = (hi << (LOGB - s0)) + (k << sh) + lo;
+            if (store) lds[lds_phys(e)] = x[w * G + k];
+            else x[w * G + k] = lds[lds_phys(e)];
+        }
+    }
+}
+
+template <int LOGB, bool INV, bool NC>
 __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) ntt_rows_kernel(NttArgs A) {
     constexpr int N2 = 1 << LOGB;
     constexpr int T = N2 / 16;
-    constexpr int NR = (LOGB + 3) / 4;
+    constexpr int NR4 = LOGB / 4;       // full radix-16 rounds
+    constexpr int GREM = LOGB % 4;      // stages of the trailing partial round (test sizes only)
     __shared__ uint64_t lds[N2 + N2 / 16];
 
     const int tau = threadIdx.x;
@@ -137,40 +215,19 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = bred_add_lazy(x[k], q, mc.brc0);
         }
-#pragma unroll
-        for (int rho = 0; rho < NR; rho++) {
-            const int s0 = 4 * rho;
-            const int g = (LOGB - s0) < 4 ? (LOGB - s0) : 4;
-            const int G = 1 << g, W = 16 / G, sh = LOGB - s0 - g;
-            if (rho > 0) {
-#pragma unroll
-                for (int w = 0; w < W; w++) {
-                    const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
-#pragma unroll
-                    for (int k = 0; k < G; k++) x[w * G + k] = lds[lds_phys((hi << (LOGB - s0)) + (k << sh) + lo)];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < g; u++) {
-                const int d = 1 << (g - 1 - u);
-#pragma unroll
-                for (int w = 0; w < W; w++) {
-                    const int gamma = tau * W + w, hi = gamma >> sh;
-                    const int base = (rowtw << (s0 + u)) + (hi << u);
-#pragma unroll
-                    for (int k = 0; k < G; k++) {
-                        if (k & d) continue;
-                        const uint64_t wv = tw[base + (k >> (g - u))];
-                        bfly_fwd(x[w * G + k], x[w * G + k + d], wv, q, twoq, qinv);
-                    }
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < W; w++) {
-                const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
-#pragma unroll
-                for (int k = 0; k < G; k++) lds[lds_phys((hi << (LOGB - s0)) + (k << sh) + lo)] = x[w * G + k];
-            }
+#pragma unroll 1
+        for (int rho = 0; rho < NR4; rho++) {
+            const int s0 = 4 * rho, sh = LOGB - s0 - 4;
+            if (rho > 0) rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, false);
+            rows_round<4, false, NC>(x, tw, rowtw, s0, tau >> sh, tau, sh, q, twoq, qinv, mc, false);
+            rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, true);
+            __syncthreads();
+        }
+        if constexpr (GREM > 0) {
+            constexpr int s0 = 4 * NR4;
+            rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, false);
+            rows_round<GREM, false, NC>(x, tw, rowtw, s0, 0, tau, 0, q, twoq, qinv, mc, false);
+            rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, true);
             __syncthreads();
         }
         const bool lazy = (A.flags & NTT_LAZY_OUT) != 0;
@@ -178,7 +235,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
         for (int k = 0; k < 16; k++) {
             const int e = k * T + tau;
             uint64_t v = lds[lds_phys(e)];
-            v = v >= twoq ? v - twoq : v;
+            if constexpr (NC) v = bred_add_lazy(v, q, mc.brc0);  // [0, 36q) -> [0, 2q)
+            else v = v >= twoq ? v - twoq : v;
             if (!lazy) v = v >= q ? v - q : v;
             dst[e] = v;
         }
@@ -191,45 +249,20 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             lds[lds_phys(e)] = v;
         }
         __syncthreads();
-#pragma unroll
-        for (int rho = NR - 1; rho >= 0; rho--) {
-            const int s0 = 4 * rho;
-            const int g = (LOGB - s0) < 4 ? (LOGB - s0) : 4;
-            const int G = 1 << g, W = 16 / G, sh = LOGB - s0 - g;
-#pragma unroll
-            for (int w = 0; w < W; w++) {
-                const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
-#pragma unroll
-                for (int k = 0; k < G; k++) x[w * G + k] = lds[lds_phys((hi << (LOGB - s0)) + (k << sh) + lo)];
-            }
-#pragma unroll
-            for (int u = g - 1; u >= 0; u--) {
-                const int d = 1 << (g - 1 - u);
-                const bool last = A.scale && rho == 0 && u == 0;
-#pragma unroll
-                for (int w = 0; w < W; w++) {
-                    const int gamma = tau * W + w, hi = gamma >> sh;
-                    const int base = (rowtw << (s0 + u)) + (hi << u);
-#pragma unroll
-                    for (int k = 0; k < G; k++) {
-                        if (k & d) continue;
-                        const uint64_t wv = tw[base + (k >> (g - u))];
-                        if (last) {
-                            const uint64_t wn = mred(wv, mc.ninv, q, qinv);
-                            bfly_inv_scaled(x[w * G + k], x[w * G + k + d], wn, mc.ninv, q, twoq, qinv);
-                        } else {
-                            bfly_inv(x[w * G + k], x[w * G + k + d], wv, q, twoq, qinv);
-                        }
-                    }
-                }
-            }
+        if constexpr (GREM > 0) {
+            constexpr int s0 = 4 * NR4;
+            rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, false);
+            rows_round<GREM, true, false>(x, tw, rowtw, s0, 0, tau, 0, q, twoq, qinv, mc, false);
+            rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, true);
+            __syncthreads();
+        }
+#pragma unroll 1
+        for (int rho = NR4 - 1; rho >= 0; rho--) {
+            const int s0 = 4 * rho, sh = LOGB - s0 - 4;
+            rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, false);
+            rows_round<4, true, false>(x, tw, rowtw, s0, tau >> sh, tau, sh, q, twoq, qinv, mc, A.scale && rho == 0);
             if (rho > 0) {
-#pragma unroll
-                for (int w = 0; w < W; w++) {
-                    const int gamma = tau * W + w, hi = gamma >> sh, lo = gamma & ((1 << sh) - 1);
-#pragma unroll
-                    for (int k = 0; k < G; k++) lds[lds_phys((hi << (LOGB - s0)) + (k << sh) + lo)] = x[w * G + k];
-                }
+                rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, true);
                 __syncthreads();
             }
         }
@@ -265,13 +298,15 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
         for (int r = 0; r < R; r++) x[r] = bred_add_lazy(x[r], q, mc.brc0);
     }
     if constexpr (!INV) {
+        const bool nc = (q >> kNoCorrBits) == 0;
 #pragma unroll
         for (int s = 0; s < LOGA; s++) {
             const int d = 1 << (LOGA - 1 - s);
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if (r & d) continue;
-                bfly_fwd(x[r], x[r + d], tw[(1 << s) + (r >> (LOGA - s))], q, twoq, qinv);
+                if (nc) bfly_fwd_nc(x[r], x[r + d], tw[(1 << s) + (r >> (LOGA - s))], q, qinv);
+                else bfly_fwd(x[r], x[r + d], tw[(1 << s) + (r >> (LOGA - s))], q, twoq, qinv);
             }
         }
     } else {
@@ -295,12 +330,12 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
     for (int r = 0; r < R; r++) dst[(size_t)r * N2] = x[r];
 }
 
-template <bool INV>
-static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
+template <bool INV, bool NC>
+static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
 #define HE_ROWS_CASE(B)                                                                           \
     case B:                                                                                       \
         { ProfScope ps(INV ? K_NTT_ROWS_INV : K_NTT_ROWS_FWD, s);                                   \
-        hipLaunchKernelGGL((ntt_rows_kernel<B, INV>), grid, dim3((1 << B) / 16), 0, s, A); }       \
+        hipLaunchKernelGGL((ntt_rows_kernel<B, INV, NC>), grid, dim3((1 << B) / 16), 0, s, A); }   \
         break;
     switch (logb) {
         HE_ROWS_CASE(4) HE_ROWS_CASE(5) HE_ROWS_CASE(6) HE_ROWS_CASE(7) HE_ROWS_CASE(8) HE_ROWS_CASE(9)
@@ -309,6 +344,25 @@ static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, hipStream_t
     }
 #undef HE_ROWS_CASE
     return hipGetLastError();
+}
+// Forward launches are split by modulus size: limbs whose modulus is below 2^58 take the
+// correction-free butterflies, the others the Harvey [0,4q) form.
+template <bool INV>
+static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, const uint8_t *g_small_mod, hipStream_t s) {
+    if (INV || !g_small_mod) return launch_rows_nc<INV, false>(logb, grid, A, s);
+    NttArgs S = A, L = A;
+    S.tab.n = L.tab.n = 0;
+    for (int i = 0; i < A.tab.n; i++) {
+        NttArgs &D = g_small_mod[A.tab.mod[i]] ? S : L;
+        D.tab.in_limb[D.tab.n] = A.tab.in_limb[i];
+        D.tab.out_limb[D.tab.n] = A.tab.out_limb[i];
+        D.tab.mod[D.tab.n] = A.tab.mod[i];
+        D.tab.n++;
+    }
+    hipError_t e = hipSuccess;
+    if (S.tab.n) { dim3 g2(grid.x, S.tab.n, grid.z); e = launch_rows_nc<INV, true>(logb, g2, S, s); }
+    if (e == hipSuccess && L.tab.n) { dim3 g2(grid.x, L.tab.n, grid.z); e = launch_rows_nc<INV, false>(logb, g2, L, s); }
+    return e;
 }
 template <bool INV>
 static hipError_t launch_cols(int loga, dim3 grid, const NttArgs &A, hipStream_t s) {
@@ -351,17 +405,17 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
             for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
             B.in = out.p; B.in_bs = out.bstride;
             B.flags = flags & NTT_LAZY_OUT;
-            return launch_rows<false>(b, grows, B, s);
+            return launch_rows<false>(b, grows, B, r.host_small, s);
         }
         A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
         A.flags = flags;
-        return launch_rows<false>(b, grows, A, s);
+        return launch_rows<false>(b, grows, A, r.host_small, s);
     }
     A.tw = r.tw_inv;
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = flags & NTT_REDUCE_INPUT;
     A.scale = (a == 0);
-    if ((e = launch_rows<true>(b, grows, A, s)) != hipSuccess) return e;
+    if ((e = launch_rows<true>(b, grows, A, r.host_small, s)) != hipSuccess) return e;
     if (a > 0) {
         NttArgs B = A;
         for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
@@ -384,9 +438,9 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = flags;
     dim3 grows(1u << a, tab.n, batch);
-    if (!inverse) { A.tw = r.tw_fwd; A.scale = 0; return launch_rows<false>(b, grows, A, s); }
+    if (!inverse) { A.tw = r.tw_fwd; A.scale = 0; return launch_rows<false>(b, grows, A, r.host_small, s); }
     A.tw = r.tw_inv; A.scale = (a == 0);
-    return launch_rows<true>(b, grows, A, s);
+    return launch_rows<true>(b, grows, A, r.host_small, s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -797,13 +851,15 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
         }
         if constexpr (LOGA > 0) {  // start the forward NTT: the LOGA strided stages
             const uint64_t *tw = A.tw_fwd + (size_t)mi * A.N;
+            const bool nc = (p >> kNoCorrBits) == 0;
 #pragma unroll
             for (int s = 0; s < LOGA; s++) {
                 const int d = 1 << (LOGA - 1 - s);
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     if (r & d) continue;
-                    bfly_fwd(o[r], o[r + d], tw[(1 << s) + (r >> (LOGA - s))], p, twop, pinv);
+                    if (nc) bfly_fwd_nc(o[r], o[r + d], tw[(1 << s) + (r >> (LOGA - s))], p, pinv);
+                    else bfly_fwd(o[r], o[r + d], tw[(1 << s) + (r >> (LOGA - s))], p, twop, pinv);
                 }
             }
         }
