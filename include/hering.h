@@ -227,6 +227,11 @@ int he_automorphism_ct(he_handle eval, int level, he_handle in0, he_handle in1, 
 int he_automorphism_hoisted(he_handle eval, int level, he_handle in0, he_handle decomp, uint64_t gal_el, he_handle gk,
                             he_handle out0, he_handle out1);
 
+/* EvaluatorProvider.AutomorphismHoistedLazy (core/rlwe/evaluator_automorphism.go:104): in0 = ctIn.Value[0],
+ * decomp = DecomposeNTT(ctIn.Value[1]); output in QP, NTT domain, not divided by P */
+int he_automorphism_hoisted_lazy(he_handle eval, int levelQ, he_handle in0, he_handle decomp, uint64_t gal_el, he_handle gk,
+                                 he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P);
+
 /* ---- scheme call sites ------------------------------------------------------------ */
 /* CKKS Evaluator.mulRelin (schemes/ckks/evaluator.go:764), degree 1 x degree 1.
  * rlk = 0 -> no relinearisation: (out0,out1,out2); else (out0,out1), out2 ignored.  */

@@ -1646,6 +1646,48 @@ int he_automorphism_hoisted(he_handle ev, int level, he_handle in0, he_handle de
     return automorphism_common(ev, level, in0, 0, dec, gal, gk, out0, out1, "he_automorphism_hoisted");
 }
 
+// AutomorphismHoistedLazy (core/rlwe/evaluator_automorphism.go:104-165), NTT domain
+int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_handle hdec, uint64_t gal, he_handle hk, he_handle c0Q,
+                                 he_handle c0P, he_handle c1Q, he_handle c1P) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(in0, Poly, hin0, T_POLY);
+    GET(dec, Decomp, hdec, T_DECOMP);
+    GET(k, Evk, hk, T_EVK);
+    BasisExtender &be = *ev->be;
+    if (levelQ < 0 || levelQ > k->nQk - 1) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: levelQ out of range");
+    const int levelP = k->nPk - 1, B = dec->batch, N = be.Q->N;
+    if (k->ev.get() != ev.get()) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: key belongs to another evaluator");
+    if (!(gal & 1)) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: Galois element must be odd");
+    TRY(check_be_poly(*in0, be, levelQ + 1, "he_automorphism_hoisted_lazy"));
+    if (in0->batch != B) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: batch mismatch");
+    QPOut o;
+    TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, levelP, B, o, "he_automorphism_hoisted_lazy"));
+    Scope sc(be.ctx.get());
+    const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
+    TRY(be.ctx->arena_reserve(2 * B * (sQw + sPw) + N + 64));
+    View t0Q{be.ctx->arena_take(B * sQw), sQw}, t1Q{be.ctx->arena_take(B * sQw), sQw};
+    View t0P{be.ctx->arena_take(B * sPw), sPw}, t1P{be.ctx->arena_take(B * sPw), sPw};
+    uint32_t *index = reinterpret_cast<uint32_t *>(be.ctx->arena_take((size_t)N / 2 + 2));
+    hipStream_t st = be.ctx->stream;
+    HIP_TRY(launch_build_automorphism_index(be.Q->logN, gal, index, st));
+    TRY(ks_inner(*ev, levelQ, levelP, dec->d, dec->bstride(), dec->dstride(), *k, t0Q, t0P, t1Q, t1P, B));
+    const LimbTab tq = ident_tab(levelQ + 1), tp = ident_tab(levelP + 1, 0, 0, be.LQ);
+    HIP_TRY(launch_gather(be.qp, tq, t1Q, index, o.q1->view(), B, false, st));
+    HIP_TRY(launch_gather(be.qp, tp, t1P, index, o.p1->view(), B, false, st));
+    ScalarTab s{};  // ctTmp[1].Q = ctIn[0] * P   (MulScalarBigint with P = prod p_j at levelP)
+    for (int i = 0; i <= levelQ; i++) {
+        const ModConst &m = be.Q->sub[i].mc;
+        uint64_t pm = 1;
+        for (int j = 0; j <= levelP; j++) pm = mulmod(pm, be.P->moduli[j] % m.q, m.q);
+        s.s[i] = mform(pm, m.q, m.brc0, m.brc1);
+    }
+    HIP_TRY(launch_ew(be.qp, tq, EW_MUL_SCALAR_MONT, in0->view(), in0->view(), t1Q, B, &s, nullptr, st));
+    HIP_TRY(launch_ew(be.qp, tq, EW_ADD, t0Q, t1Q, t0Q, B, nullptr, nullptr, st));
+    HIP_TRY(launch_gather(be.qp, tq, t0Q, index, o.q0->view(), B, false, st));
+    HIP_TRY(launch_gather(be.qp, tp, t0P, index, o.p0->view(), B, false, st));
+    return HE_OK;
+}
+
 // CKKS mulRelin / BGV tensorStandard (schemes/ckks/evaluator.go:764-872, schemes/bgv/evaluator.go:592-685)
 static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_handle ha0, he_handle ha1, he_handle hb0, he_handle hb1,
                             he_handle hk, he_handle hout0, he_handle hout1, he_handle hout2, const char *who) {

@@ -134,6 +134,12 @@ class Evaluator:
     def AutomorphismHoisted(self, level, ctIn, c1DecompQP: Decomposition, galEl: int, gk: EvaluationKey, opOut):
         check(load().he_automorphism_hoisted(self.h, level, ctIn[0].h, c1DecompQP.h, galEl, gk.h, opOut[0].h, opOut[1].h))
 
+    # EvaluatorProvider.AutomorphismHoistedLazy (:104)
+    def AutomorphismHoistedLazy(self, levelQ, ctIn, c1DecompQP: Decomposition, galEl: int, gk: EvaluationKey, ctQP):
+        (q0, p0), (q1, p1) = ctQP
+        check(load().he_automorphism_hoisted_lazy(self.h, levelQ, ctIn[0].h, c1DecompQP.h, galEl, gk.h,
+                                                  q0.h, p0.h, q1.h, p1.h))
+
     # schemes/ckks Evaluator.Mul / MulRelin (schemes/ckks/evaluator.go:613,742 -> mulRelin :764)
     def CKKSMulRelin(self, level, op0, op1, rlk: EvaluationKey | None, opOut):
         o2 = opOut[2].h if rlk is None else 0

@@ -1299,6 +1299,35 @@ void lo_automorphism_hoisted(const lo_evaluator *e, int level, const uint64_t *c
     free(tmp); free(index);
 }
 
+/* AutomorphismHoistedLazy, core/rlwe/evaluator_automorphism.go:104-165 (ctQP.IsNTT).
+ * ct_in0: [level+1][N] (ctIn.Value[0]); outQ: [2][levelQ+1][N], outP: [2][levelP+1][N]. */
+void lo_automorphism_hoisted_lazy(const lo_evaluator *e, int levelQ, const uint64_t *ct_in0, const uint64_t *decompQ,
+                                  const uint64_t *decompP, uint64_t galel, const lo_evk *gk, uint64_t *outQ, uint64_t *outP) {
+    int N = e->ringQ->N, levelP = gk->nPk - 1;
+    size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
+    uint64_t *tQ = (uint64_t *)malloc(2 * szQ * 8), *tP = (uint64_t *)malloc(2 * szP * 8);
+    uint64_t *index = (uint64_t *)malloc((size_t)N * 8);
+    lo_automorphism_ntt_index(N, 2 * (uint64_t)N, galel, index);
+    lo_gadget_product_hoisted_lazy(e, levelQ, decompQ, decompP, gk, tQ, tP);
+    lo_automorphism_ntt_with_index(e->ringQ, levelQ, tQ + szQ, index, outQ + szQ);
+    lo_automorphism_ntt_with_index(e->ringP, levelP, tP + szP, index, outP + szP);
+    {   /* ringQ.MulScalarBigint(ctIn.Value[0], ringP.ModulusAtLevel[levelP], ctTmp.Value[1].Q) */
+        uint64_t mods[64], words[64];
+        ring_moduli(e->ringP, mods);
+        int nw = 1; words[0] = 1;
+        for (int i = 0; i <= levelP; i++) {
+            uint64_t carry = 0;
+            for (int k = 0; k < nw; k++) { u128 t = (u128)words[k] * mods[i] + carry; words[k] = (uint64_t)t; carry = (uint64_t)(t >> 64); }
+            if (carry) words[nw++] = carry;
+        }
+        lo_mul_scalar_bigint(e->ringQ, levelQ, ct_in0, words, nw, tQ + szQ);
+    }
+    lo_binop(e->ringQ, levelQ, LO_ADD, tQ, tQ + szQ, tQ);
+    lo_automorphism_ntt_with_index(e->ringQ, levelQ, tQ, index, outQ);
+    lo_automorphism_ntt_with_index(e->ringP, levelP, tP, index, outP);
+    free(tQ); free(tP); free(index);
+}
+
 /* ========================================================================== */
 /* Scheme glue                                                                  */
 /* ========================================================================== */

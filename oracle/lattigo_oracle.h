@@ -208,6 +208,9 @@ void lo_automorphism_ct(const lo_evaluator *e, int level, const uint64_t *ct_in,
 void lo_automorphism_hoisted(const lo_evaluator *e, int level, const uint64_t *ct_in, const uint64_t *decompQ,
                              const uint64_t *decompP, uint64_t galel, const lo_evk *gk, uint64_t *ct_out);
 
+void lo_automorphism_hoisted_lazy(const lo_evaluator *e, int levelQ, const uint64_t *ct_in0, const uint64_t *decompQ,
+                                  const uint64_t *decompP, uint64_t galel, const lo_evk *gk, uint64_t *outQ, uint64_t *outP);
+
 /* ---- scheme glue: schemes/ckks/evaluator.go, schemes/bgv/evaluator.go ------- */
 /* op0, op1: [2][level+1][N]; out: [3] (relin=0) or [2] (relin=1) */
 void lo_ckks_mul_relin(const lo_evaluator *e, int level, const uint64_t *op0, const uint64_t *op1,

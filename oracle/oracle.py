@@ -132,6 +132,7 @@ def _declare(L):
     L.lo_relinearize.argtypes = [vp, i, u64p, ep, u64p]
     L.lo_automorphism_ct.argtypes = [vp, i, u64p, u64, ep, u64p]
     L.lo_automorphism_hoisted.argtypes = [vp, i, u64p, u64p, u64p, u64, ep, u64p]
+    L.lo_automorphism_hoisted_lazy.argtypes = [vp, i, u64p, u64p, u64p, u64, ep, u64p, u64p]
     L.lo_ckks_mul_relin.argtypes = [vp, i, u64p, u64p, ep, i, u64p]
     L.lo_bgv_mul_relin.argtypes = [vp, i, u64, u64p, u64p, ep, i, u64p]
     L.lo_rescale.argtypes = [vp, i, i, i, u64p, u64p]
@@ -572,6 +573,14 @@ class Evaluator:
         out = np.zeros_like(ct_in)
         lib().lo_automorphism_hoisted(self._h, level, _p(ct_in), _p(_c(dq)), _p(_c(dp)), galel, gk.ref(), _p(out))
         return out
+
+    def AutomorphismHoistedLazy(self, levelQ, ct_in0, dq, dp, galel, gk: EvaluationKey):
+        N = self.ringQ.N
+        outQ = np.zeros((2, levelQ + 1, N), dtype=np.uint64)
+        outP = np.zeros((2, gk.LevelP() + 1, N), dtype=np.uint64)
+        lib().lo_automorphism_hoisted_lazy(self._h, levelQ, _p(_c(ct_in0)), _p(_c(dq)), _p(_c(dp)), galel, gk.ref(),
+                                           _p(outQ), _p(outP))
+        return outQ, outP
 
     # scheme glue
     def CKKSMulRelin(self, op0, op1, rlk: EvaluationKey | None, relin: bool):

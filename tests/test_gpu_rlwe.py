@@ -215,6 +215,13 @@ def test_rotate(ctx, nq, np_):
         out2 = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
         gev.AutomorphismHoisted(level, pct, gdec, galel, ggk, out2)
         assert np.array_equal(np.stack([o.get() for o in out2]), want), galel
+        # EvaluatorProvider.AutomorphismHoistedLazy: QP output, not divided by P
+        dq, dp = oev.DecomposeNTT(level, np_ - 1, np_, ct[1], True)
+        wQ, wP = oev.AutomorphismHoistedLazy(level, ct[0], dq, dp, galel, ogk)
+        qp = [(pr.gQ.NewPoly(), pr.gP.NewPoly()) for _ in range(2)]
+        gev.AutomorphismHoistedLazy(level, pct, gdec, galel, ggk, qp)
+        for k in range(2):
+            assert np.array_equal(qp[k][0].get(), wQ[k]) and np.array_equal(qp[k][1].get(), wP[k]), (galel, k)
         idx = pr.oQ.AutomorphismNTTIndex(galel)
         wantp = pr.oQ.AutomorphismNTTWithIndex(phase(pr.oQ, ct, sk.Q), idx)
         assert noise_log2(pr.oQ, pr.oQ.binop("Sub", phase(pr.oQ, got, sk.Q), wantp)) <= 18
