@@ -63,6 +63,10 @@ int he_device_info(he_handle ctx, uint64_t out[4]);
 /* ---- ring: ring.NewRing (ring/ring.go:207), SubRing tables (ring/subring.go:99-159),
  *      RescaleConstants (ring/ring.go:329).  Standard (negacyclic) type, NthRoot = 2N. */
 int he_ring_create(he_handle ctx, int logN, const uint64_t *moduli, int n_moduli, he_handle *ring);
+/* ring.NewRingFromType (ring/ring.go:267): ring_type 0 = Standard, 1 = ConjugateInvariant
+ * (Z[X+X^-1]/(X^2N+1), NthRoot = 4N; NTT of ring/ntt.go:716-1311).  Conjugate-invariant rings support the
+ * ring-level ops (NTT, coefficient-wise, rescale); basis extension / key-switch take standard rings. */
+int he_ring_create_type(he_handle ctx, int logN, int ring_type, const uint64_t *moduli, int n_moduli, he_handle *ring);
 int he_ring_destroy(he_handle ring);
 /* which = 0: Modulus, 1: MRedConstant, 2: BRedConstant[0], 3: BRedConstant[1], 4: NInv, 5: PrimitiveRoot */
 int he_ring_constant(he_handle ring, int limb, int which, uint64_t *out);

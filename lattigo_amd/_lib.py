@@ -60,7 +60,7 @@ def _declare(L):
     sig = {
         "he_ctx_create": [i, HP], "he_ctx_destroy": [H], "he_ctx_sync": [H], "he_timer_start": [H],
         "he_timer_stop": [H, C.POINTER(C.c_float)], "he_device_info": [H, u64p],
-        "he_ring_create": [H, i, u64p, i, HP], "he_ring_destroy": [H], "he_ring_constant": [H, i, i, u64p],
+        "he_ring_create": [H, i, u64p, i, HP], "he_ring_create_type": [H, i, i, u64p, i, HP], "he_ring_destroy": [H], "he_ring_constant": [H, i, i, u64p],
         "he_ring_roots": [H, i, i, u64p],
         "he_poly_alloc": [H, i, i, HP], "he_poly_free": [H],
         "he_poly_shape": [H, C.POINTER(i), C.POINTER(i), C.POINTER(i)],

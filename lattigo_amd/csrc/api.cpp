@@ -97,6 +97,7 @@ struct Ctx : Obj {
 struct Ring : Obj {
     std::shared_ptr<Ctx> ctx;
     int logN = 0, N = 0;
+    int type = 0;  // 0 Standard, 1 ConjugateInvariant
     std::vector<uint64_t> moduli;
     std::vector<SubRingHost> sub;
     std::vector<std::vector<uint64_t>> rescale;  // [j-1][i]
@@ -397,7 +398,11 @@ int he_device_info(he_handle h, uint64_t out[4]) {
 // ring
 // ---------------------------------------------------------------------------------------
 int he_ring_create(he_handle hctx, int logN, const uint64_t *moduli, int n, he_handle *out) {
+    return he_ring_create_type(hctx, logN, 0, moduli, n, out);
+}
+int he_ring_create_type(he_handle hctx, int logN, int ring_type, const uint64_t *moduli, int n, he_handle *out) {
     GET(c, Ctx, hctx, T_CTX);
+    if (ring_type != 0 && ring_type != 1) return fail(HE_EINVAL, "he_ring_create: invalid ring type %d", ring_type);
     if (!moduli || !out || n <= 0) return fail(HE_EINVAL, "he_ring_create: invalid ModuliChain (must be a non-empty []uint64)");
     if (n > 48) return fail(HE_EINVAL, "he_ring_create: at most 48 moduli per ring");
     if (logN < 4 || logN > 17) return fail(HE_EPARAM, "he_ring_create: logN=%d outside [4,17]", logN);
@@ -410,9 +415,11 @@ int he_ring_create(he_handle hctx, int logN, const uint64_t *moduli, int n, he_h
     r->N = 1 << logN;
     r->moduli.assign(moduli, moduli + n);
     r->sub.resize(n);
+    r->type = ring_type;
     std::string err;
     for (int i = 0; i < n; i++)
-        if (!build_subring(logN, moduli[i], r->sub[i], err)) return fail(HE_EPARAM, "he_ring_create: %s", err.c_str());
+        if (!(ring_type ? build_subring_ci(logN, moduli[i], r->sub[i], err) : build_subring(logN, moduli[i], r->sub[i], err)))
+            return fail(HE_EPARAM, "he_ring_create: %s", err.c_str());
     r->rescale = build_rescale_constants(r->moduli);
     Scope sc(c.get());
     std::vector<const SubRingHost *> subs;
@@ -529,6 +536,22 @@ int he_poly_zero(he_handle h) {
 // ---------------------------------------------------------------------------------------
 // NTT (ring/ntt.go:127-152)
 // ---------------------------------------------------------------------------------------
+// NTT of a Ring of either type: the conjugate-invariant transform is a fold around the standard
+// network (ring/ntt.go:716-1311)
+static hipError_t ring_ntt(const Ring &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags) {
+    hipStream_t st = r.ctx->stream;
+    if (r.type == 0) return launch_ntt(r.dev, tab, in, out, batch, inverse, flags, st);
+    LimbTab oo = tab;  // second step works in place on `out`
+    for (int i = 0; i < tab.n; i++) oo.in_limb[i] = tab.out_limb[i];
+    hipError_t e;
+    if (!inverse) {
+        if ((e = launch_ci_fold(r.dev, tab, in, out, batch, false, (flags & NTT_REDUCE_INPUT) != 0, st)) != hipSuccess) return e;
+        return launch_ntt(r.dev, oo, out, out, batch, false, flags & ~NTT_REDUCE_INPUT, st);
+    }
+    if ((e = launch_ntt(r.dev, tab, in, out, batch, true, flags, st)) != hipSuccess) return e;
+    return launch_ci_fold(r.dev, oo, out, out, batch, true, false, st);
+}
+
 static int ntt_api(he_handle hring, int level, he_handle h1, he_handle h2, bool inverse, int flags, const char *who) {
     GET(r, Ring, hring, T_RING);
     GET(p1, Poly, h1, T_POLY);
@@ -537,7 +560,7 @@ static int ntt_api(he_handle hring, int level, he_handle h1, he_handle h2, bool 
     TRY(check_poly(*p2, *r, level, who));
     if (p1->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
     Scope sc(r->ctx.get());
-    HIP_TRY(launch_ntt(r->dev, ident_tab(level + 1), p1->view(), p2->view(), p1->batch, inverse, flags | NTT_REDUCE_INPUT, r->ctx->stream));
+    HIP_TRY(ring_ntt(*r, ident_tab(level + 1), p1->view(), p2->view(), p1->batch, inverse, flags | NTT_REDUCE_INPUT));
     return HE_OK;
 }
 int he_ntt(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, false, 0, "he_ntt"); }
@@ -669,7 +692,7 @@ int div_by_last_modulus_ntt(Ring &r, int level, View p0, View p1, int batch, boo
     // b0 = INTTLazy(p0[level])                                                  scaling.go:15 / :110
     LimbTab t_top;
     t_top.n = 1; t_top.in_limb[0] = (uint8_t)level; t_top.out_limb[0] = 0; t_top.mod[0] = (uint8_t)level;
-    HIP_TRY(launch_ntt(r.dev, t_top, p0, sc.s0, batch, true, NTT_REDUCE_INPUT, st));
+    HIP_TRY(ring_ntt(r, t_top, p0, sc.s0, batch, true, NTT_REDUCE_INPUT));
     ScalarTab s{};
     const uint64_t qL = r.moduli[level], phalf = (qL - 1) >> 1;
     if (round) {  // b0 += pHalf mod q_L                                          scaling.go:114
@@ -689,9 +712,9 @@ int div_by_last_modulus_ntt(Ring &r, int level, View p0, View p1, int batch, boo
             s.s[i] = m.q - bred_add(phalf, m.q, m.brc0);
         }
         HIP_TRY(launch_ew(r.dev, tin, EW_ADD_SCALAR_LAZY, sc.s0, sc.s0, sc.s1, batch, &s, xl, st));
-        HIP_TRY(launch_ntt(r.dev, tl, sc.s1, sc.s1, batch, false, NTT_REDUCE_INPUT | NTT_LAZY_OUT, st));
+        HIP_TRY(ring_ntt(r, tl, sc.s1, sc.s1, batch, false, NTT_REDUCE_INPUT | NTT_LAZY_OUT));
     } else {
-        HIP_TRY(launch_ntt(r.dev, tin, sc.s0, sc.s1, batch, false, NTT_REDUCE_INPUT | NTT_LAZY_OUT, st));
+        HIP_TRY(ring_ntt(r, tin, sc.s0, sc.s1, batch, false, NTT_REDUCE_INPUT | NTT_LAZY_OUT));
     }
     // p1_i = MRed(b1_i + 2q_i - p0_i, RescaleConstants[level-1][i])             scaling.go:120
     for (int i = 0; i < level; i++) s.s[i] = r.rescale[level - 1][i];
@@ -744,12 +767,16 @@ int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, boo
     RescaleScratch rs;
     rs.s0 = View{r->ctx->arena_take(w0), (size_t)N};
     rs.s1 = View{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
+    if (ntt && nb == 1 && !round && r->type == 1)
+        // the reference feeds the *lazy* representative of INTTConjugateInvariantLazy (which depends on its
+        // unrolled reduction schedule, ring/ntt.go:1160-1311) into a different modulus here; not reproduced
+        return fail(HE_EINVAL, "%s: DivFloorByLastModulusNTT is not supported on conjugate-invariant rings", who);
     if (ntt && nb == 1) return div_by_last_modulus_ntt(*r, level, p0->view(), p1->view(), B, round, rs);
     View buf{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
     View cur = p0->view();
     int lv = level;
     if (ntt) {  // INTT, nb coefficient-domain steps, NTT          scaling.go:37-62, :148-174
-        HIP_TRY(launch_ntt(r->dev, ident_tab(level + 1), p0->view(), buf, B, true, NTT_REDUCE_INPUT, st));
+        HIP_TRY(ring_ntt(*r, ident_tab(level + 1), p0->view(), buf, B, true, NTT_REDUCE_INPUT));
         cur = buf;
     }
     for (int i = 0; i < nb; i++) {
@@ -759,7 +786,7 @@ int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, boo
         cur = dst;
         lv--;
     }
-    if (ntt) HIP_TRY(launch_ntt(r->dev, ident_tab(lv + 1), buf, p1->view(), B, false, NTT_REDUCE_INPUT, st));
+    if (ntt) HIP_TRY(ring_ntt(*r, ident_tab(lv + 1), buf, p1->view(), B, false, NTT_REDUCE_INPUT));
     return HE_OK;
 }
 }  // namespace
@@ -836,6 +863,7 @@ int he_basis_extender_create(he_handle hq, he_handle hp, he_handle *out) {
     GET(P, Ring, hp, T_RING);
     if (!out) return fail(HE_EINVAL, "he_basis_extender_create: null output");
     if (Q->ctx != P->ctx || Q->N != P->N) return fail(HE_EINVAL, "he_basis_extender_create: rings must share context and degree");
+    if (Q->type != 0 || P->type != 0) return fail(HE_EINVAL, "he_basis_extender_create: conjugate-invariant rings are not supported here");
     if (Q->nmod() + P->nmod() > kMaxLimbs) return fail(HE_EINVAL, "he_basis_extender_create: more than %d moduli in QP", kMaxLimbs);
     if (Q->nmod() > 32 || P->nmod() > 32) return fail(HE_EINVAL, "he_basis_extender_create: at most 32 source limbs (ring/basis_extension.go:285)");
     for (uint64_t q : Q->moduli)

@@ -85,8 +85,29 @@ static uint64_t bitrev(uint64_t x, int bits) {
     return r;
 }
 
+static bool build_subring_nth(int logN, uint64_t q, uint64_t nth, SubRingHost &out, std::string &err);
 bool build_subring(int logN, uint64_t q, SubRingHost &out, std::string &err) {
-    const uint64_t N = 1ull << logN, nth = 2 * N;
+    return build_subring_nth(logN, q, 2ull << logN, out, err);
+}
+bool build_subring_ci(int logN, uint64_t q, SubRingHost &out, std::string &err) {
+    SubRingHost big;
+    if (!build_subring_nth(logN, q, 4ull << logN, big, err)) return false;
+    const uint64_t N = 1ull << logN;
+    out.mc = big.mc;
+    out.primroot = big.primroot;
+    out.mc.pad0 = big.roots_fwd[1];
+    out.mc.pad1 = big.roots_bwd[1];
+    out.roots_fwd.assign(N, 0);
+    out.roots_bwd.assign(N, 0);
+    for (uint64_t h = 1; h < N; h <<= 1)
+        for (uint64_t i = 0; i < h; i++) {
+            out.roots_fwd[h + i] = big.roots_fwd[2 * h + i];
+            out.roots_bwd[h + i] = big.roots_bwd[2 * h + i];
+        }
+    return true;
+}
+static bool build_subring_nth(int logN, uint64_t q, uint64_t nth, SubRingHost &out, std::string &err) {
+    const uint64_t N = 1ull << logN;
     if (q >> 62) { err = "modulus must be below 2^62 (lazy butterflies keep values in [0,4q))"; return false; }
     if (!is_prime_u64(q)) { err = "invalid modulus: " + std::to_string(q) + " is not prime"; return false; }
     if ((q & (nth - 1)) != 1) { err = "invalid modulus: " + std::to_string(q) + " != 1 mod NthRoot"; return false; }
@@ -100,7 +121,10 @@ bool build_subring(int logN, uint64_t q, SubRingHost &out, std::string &err) {
     u128 rem = ((u128)1 << 64) % q;
     mc.brc0 = (uint64_t)(((u128)1 << 64) / q);
     mc.brc1 = (uint64_t)((rem << 64) / q);
-    mc.ninv = to_mont(invmod(N % q, q), q);
+    const uint64_t half = nth >> 1;  // table length: N (standard) or 2N (conjugate invariant)
+    int loghalf = 0;
+    while ((1ull << loghalf) < half) loghalf++;
+    mc.ninv = to_mont(invmod(half % q, q), q);
     mc.r2 = to_mont(to_mont(1, q), q);
     mc.pad0 = mc.pad1 = 0;
     // smallest generator g >= 3 of Z_q^* (ring/subring.go:181-193)
@@ -114,12 +138,13 @@ bool build_subring(int logN, uint64_t q, SubRingHost &out, std::string &err) {
     }
     out.primroot = g;
     const uint64_t psi = powmod(g, (q - 1) / nth, q), psiinv = invmod(psi, q);
-    out.roots_fwd.assign(N, 0);
-    out.roots_bwd.assign(N, 0);
+    (void)N;
+    out.roots_fwd.assign(half, 0);
+    out.roots_bwd.assign(half, 0);
     uint64_t pf = to_mont(1, q), pb = pf;
     const uint64_t psim = to_mont(psi, q), psiinvm = to_mont(psiinv, q);
-    for (uint64_t j = 0; j < N; j++) {
-        const uint64_t idx = bitrev(j, logN);
+    for (uint64_t j = 0; j < half; j++) {
+        const uint64_t idx = bitrev(j, loghalf);
         out.roots_fwd[idx] = pf;
         out.roots_bwd[idx] = pb;
         pf = mred(pf, psim, q, mc.qinv);

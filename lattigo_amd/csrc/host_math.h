@@ -29,6 +29,12 @@ struct SubRingHost {
 };
 // returns false and fills err if (N, q) does not define an NTT-enabled SubRing
 bool build_subring(int logN, uint64_t q, SubRingHost &out, std::string &err);
+// Conjugate-invariant SubRing Z[X+X^-1]/(X^2N+1) (ring/ring.go:260, NthRoot = 4N).  The transform of
+// ring/ntt.go:757-786 / :1104-1152 is a fold with roots[1] around a standard butterfly network whose stage
+// with h blocks uses roots4N[2h+i]; roots_fwd/bwd are returned already remapped to that network
+// (tw[h+i] = roots4N[2h+i], N entries), the fold twiddles in mc.pad0 (forward) / mc.pad1 (backward),
+// and mc.ninv = MForm((2N)^-1).
+bool build_subring_ci(int logN, uint64_t q, SubRingHost &out, std::string &err);
 
 // RescaleConstants[j-1][i] = MForm(q_i - q_j^-1 mod q_i), i < j   (ring/ring.go:329-346)
 std::vector<std::vector<uint64_t>> build_rescale_constants(const std::vector<uint64_t> &moduli);

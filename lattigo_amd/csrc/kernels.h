@@ -48,6 +48,12 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
 hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
                            hipStream_t s);
 
+// conjugate-invariant fold (ring/ntt.go:764-769 forward, :1146-1151 backward), pairs (j, N-j) per thread:
+//   forward : out[j] = in[j] + 2q - MRedLazy(in[N-j], F), out[0] = in[0]          (F = ModConst.pad0)
+//   backward: out[j] = CRed(in[j] + q - MRed(in[N-j], F)), out[0] = 2*in[0] mod q  (F = ModConst.pad1, in canonical)
+hipError_t launch_ci_fold(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, bool reduce_input,
+                          hipStream_t s);
+
 // ---- coefficient-wise -----------------------------------------------------------------
 // op codes: 0..16 = he_binop, 100.. = he_unop, 200.. = scalar forms (scalar per limb in sc[])
 enum EwOp {
@@ -158,7 +164,7 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
 // ---- per-kernel HIP-event profiling (diagnostics: bench.py's roofline leg) --------------------
 enum KernelId {
     K_NTT_COLS_FWD = 0, K_NTT_ROWS_FWD, K_NTT_ROWS_INV, K_NTT_COLS_INV, K_EW, K_GATHER, K_AUTO_COEFF, K_INDEX,
-    K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_COUNT
+    K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_CI_FOLD, K_COUNT
 };
 const char *kernel_name(int id);
 void prof_begin();                                   // start recording (one stream at a time)

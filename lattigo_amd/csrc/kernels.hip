@@ -46,7 +46,7 @@ struct ProfScope {
 const char *kernel_name(int id) {
     static const char *names[K_COUNT] = {"ntt_cols_fwd", "ntt_rows_fwd", "ntt_rows_inv", "ntt_cols_inv", "ew", "gather",
                                          "automorphism_coeff", "build_index", "modup", "center_copy", "ks_inner",
-                                         "tensor", "modmul_probe"};
+                                         "tensor", "modmul_probe", "ci_fold"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 void prof_begin() { g_prof_recs.clear(); g_prof_on = true; }
@@ -441,6 +441,54 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     if (!inverse) { A.tw = r.tw_fwd; A.scale = 0; return launch_rows<false>(b, grows, A, r.host_small, s); }
     A.tw = r.tw_inv; A.scale = (a == 0);
     return launch_rows<true>(b, grows, A, r.host_small, s);
+}
+
+// ------------------------------------------------------------------------------------
+// conjugate-invariant fold around the standard butterfly network (see kernels.h)
+// ------------------------------------------------------------------------------------
+struct CiFoldArgs {
+    const uint64_t *in;
+    uint64_t *out;
+    size_t in_bs, out_bs;
+    const ModConst *mc;
+    int N, inverse, reduce_input;
+    uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs], mod[kMaxLimbs];
+};
+__global__ void __launch_bounds__(256) ci_fold_kernel(CiFoldArgs A) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. N/2
+    if (j > A.N / 2) return;
+    const ModConst m = A.mc[A.mod[blockIdx.y]];
+    const uint64_t q = m.q, qinv = m.qinv, twoq = m.q << 1;
+    const uint64_t *in = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N;
+    uint64_t *out = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N;
+    const int jy = (A.N - j) & (A.N - 1);  // partner; j = 0 and j = N/2 pair with themselves
+    uint64_t a = in[j], b = in[jy];
+    if (A.reduce_input) { a = bred_add_lazy(a, q, m.brc0); b = bred_add_lazy(b, q, m.brc0); }
+    if (!A.inverse) {
+        const uint64_t F = m.pad0;
+        if (j == 0) { out[0] = a; return; }
+        const uint64_t oa = a + twoq - mred_lazy(b, F, q, qinv), ob = b + twoq - mred_lazy(a, F, q, qinv);
+        out[j] = oa;
+        if (jy != j) out[jy] = ob;
+    } else {
+        const uint64_t F = m.pad1;
+        if (j == 0) { out[0] = cred(a << 1, q); return; }
+        const uint64_t oa = cred(a + q - mred(b, F, q, qinv), q), ob = cred(b + q - mred(a, F, q, qinv), q);
+        out[j] = oa;
+        if (jy != j) out[jy] = ob;
+    }
+}
+hipError_t launch_ci_fold(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, bool reduce_input,
+                          hipStream_t s) {
+    if (tab.n <= 0 || batch <= 0) return hipSuccess;
+    CiFoldArgs A;
+    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N;
+    A.inverse = inverse; A.reduce_input = reduce_input;
+    for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
+    dim3 grid((unsigned)((r.N / 2 + 1 + 255) / 256), tab.n, batch), block(256);
+    ProfScope ps(K_CI_FOLD, s);
+    hipLaunchKernelGGL(ci_fold_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------

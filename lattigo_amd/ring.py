@@ -158,10 +158,13 @@ class Poly:
 class Ring:
     """ring.Ring (ring/ring.go:71), standard type.  ``AtLevel`` returns a view sharing tables."""
 
-    def __init__(self, ctx: Context, N: int, moduli, _parent: "Ring | None" = None, _level: int | None = None):
+    def __init__(self, ctx: Context, N: int, moduli, _parent: "Ring | None" = None, _level: int | None = None,
+                 conjugate_invariant: bool = False):
+        """ring.NewRing / ring.NewRingFromType (ring/ring.go:207,267)."""
         self.ctx = ctx
         self.N = N
         self.moduli = [int(m) for m in moduli]
+        self.conjugate_invariant = conjugate_invariant if _parent is None else _parent.conjugate_invariant
         if _parent is not None:
             self.h, self._owner, self.level = _parent.h, _parent._owner, _level
             return
@@ -170,7 +173,7 @@ class Ring:
             raise _lib.HeringError(-4, "invalid ring degree: must be a power of 2")
         arr = (C.c_uint64 * len(self.moduli))(*self.moduli)
         h = H()
-        check(load().he_ring_create(ctx.h, logN, arr, len(self.moduli), C.byref(h)))
+        check(load().he_ring_create_type(ctx.h, logN, int(conjugate_invariant), arr, len(self.moduli), C.byref(h)))
         self.h = h.value
         self._owner = self
         self.level = len(self.moduli) - 1
@@ -204,7 +207,7 @@ class Ring:
         return list(self.moduli)
 
     def NthRoot(self):
-        return 2 * self.N
+        return (4 if self.conjugate_invariant else 2) * self.N
 
     def NewPoly(self, batch: int = 1) -> Poly:
         return Poly(self, self.level + 1, batch)

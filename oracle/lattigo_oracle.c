@@ -217,9 +217,10 @@ static uint64_t bitrev64(uint64_t x, int bits) {
 
 /* NewSubRingWithCustomNTT (ring/subring.go:46-80) + generateNTTConstants
  * (:99-159) + PrimitiveRoot (:163-196), standard ring (NthRoot = 2N). */
-lo_subring *lo_subring_new(int N, uint64_t q) {
+lo_subring *lo_subring_new(int N, uint64_t q) { return lo_subring_new_nthroot(N, q, 2 * (uint64_t)N); }
+/* NthRoot = 2N: standard ring; NthRoot = 4N: conjugate-invariant ring (ring/ring.go:260-261) */
+lo_subring *lo_subring_new_nthroot(int N, uint64_t q, uint64_t nthroot) {
     if (N < 8 || (N & (N - 1)) != 0) { LO_FAIL("invalid ring degree: must be a power of 2 greater than 8"); return NULL; }
-    uint64_t nthroot = 2 * (uint64_t)N;
     if (!lo_is_prime(q)) { LO_FAIL("invalid modulus: %llu is not prime)", (unsigned long long)q); return NULL; }
     if ((q & (nthroot - 1)) != 1) { LO_FAIL("invalid modulus: %llu != 1 mod NthRoot)", (unsigned long long)q); return NULL; }
     lo_subring *s = (lo_subring *)calloc(1, sizeof *s);
@@ -260,7 +261,9 @@ void lo_subring_free(lo_subring *s) {
 }
 
 /* NewRing (ring/ring.go:207-320) + rewRescaleConstants (:329-346) */
-lo_ring *lo_ring_new(int N, const uint64_t *moduli, int nmod) {
+lo_ring *lo_ring_new(int N, const uint64_t *moduli, int nmod) { return lo_ring_new_type(N, moduli, nmod, 0); }
+/* NewRingFromType, ring/ring.go:267-279: type 0 = Standard, 1 = ConjugateInvariant */
+lo_ring *lo_ring_new_type(int N, const uint64_t *moduli, int nmod, int type) {
     if (nmod <= 0) { LO_FAIL("invalid ModuliChain (must be a non-empty []uint64)"); return NULL; }
     for (int i = 0; i < nmod; i++)
         for (int j = i + 1; j < nmod; j++)
@@ -269,7 +272,7 @@ lo_ring *lo_ring_new(int N, const uint64_t *moduli, int nmod) {
     r->N = N; r->nmod = nmod;
     r->s = (lo_subring **)calloc(nmod, sizeof(lo_subring *));
     for (int i = 0; i < nmod; i++) {
-        r->s[i] = lo_subring_new(N, moduli[i]);
+        r->s[i] = lo_subring_new_nthroot(N, moduli[i], (type == 1 ? 4 : 2) * (uint64_t)N);
         if (!r->s[i]) { lo_ring_free(r); return NULL; }
     }
     r->rescale = (uint64_t **)calloc(nmod > 1 ? nmod - 1 : 1, sizeof(uint64_t *));
@@ -438,13 +441,90 @@ static void intt_core_lazy(const uint64_t *p1, uint64_t *p2, int N, uint64_t Q, 
         t <<= 1;
     }
 }
-/* NTTStandard / NTTStandardLazy, ring/ntt.go:174-183 */
+/* nttConjugateInvariantLazy, ring/ntt.go:757-786 (the unrolled form :788-1090 is the same arithmetic
+ * with a sparser 4q-correction schedule, i.e. other lazy representatives of the same residues) */
+static void ntt_ci_core_lazy(const uint64_t *p1, uint64_t *p2, int N, uint64_t Q, uint64_t qinv, const uint64_t *roots) {
+    uint64_t fourQ = 4 * Q, twoQ = 2 * Q;
+    int t = N;
+    uint64_t F = roots[1];
+    for (int jx = 1, jy = N - 1; jx < (N >> 1); jx++, jy--) {
+        uint64_t a = p1[jx], b = p1[jy];
+        p2[jx] = a + twoQ - lo_mred_lazy(b, F, Q, qinv);
+        p2[jy] = b + twoQ - lo_mred_lazy(a, F, Q, qinv);
+    }
+    p2[N >> 1] = p1[N >> 1] + twoQ - lo_mred_lazy(p1[N >> 1], F, Q, qinv);
+    p2[0] = p1[0];
+    for (int m = 2; m < 2 * N; m <<= 1) {
+        t >>= 1;
+        int h = m >> 1;
+        for (int i = 0, j1 = 0; i < h; i++, j1 += 2 * t) {
+            F = roots[m + i];
+            for (int jx = j1, jy = j1 + t; jx < j1 + t; jx++, jy++) {
+                uint64_t U = p2[jx];
+                if (U >= fourQ) U -= fourQ;
+                uint64_t V = lo_mred_lazy(p2[jy], F, Q, qinv);
+                p2[jx] = U + V; p2[jy] = U + twoQ - V;
+            }
+        }
+    }
+}
+/* inttConjugateInvariantLazy, ring/ntt.go:1104-1152 */
+static void intt_ci_core_lazy(const uint64_t *p1, uint64_t *p2, int N, uint64_t Q, uint64_t qinv, const uint64_t *roots) {
+    uint64_t twoQ = Q << 1, fourQ = Q << 2;
+    int t = 1, h = N >> 1;
+    for (int i = 0, j1 = 0; i < h; i++, j1 += 2 * t) {
+        uint64_t F = roots[N + i];
+        for (int jx = j1, jy = j1 + t; jx < j1 + t; jx++, jy++) {
+            uint64_t U = p1[jx], V = p1[jy];
+            uint64_t X = U + V; if (X >= twoQ) X -= twoQ;
+            p2[jx] = X; p2[jy] = lo_mred_lazy(U + fourQ - V, F, Q, qinv);
+        }
+    }
+    t <<= 1;
+    for (int m = N >> 1; m > 1; m >>= 1) {
+        h = m >> 1;
+        for (int i = 0, j1 = 0; i < h; i++, j1 += 2 * t) {
+            uint64_t F = roots[m + i];
+            for (int jx = j1, jy = j1 + t; jx < j1 + t; jx++, jy++) {
+                uint64_t U = p2[jx], V = p2[jy];
+                uint64_t X = U + V; if (X >= twoQ) X -= twoQ;
+                p2[jx] = X; p2[jy] = lo_mred_lazy(U + fourQ - V, F, Q, qinv);
+            }
+        }
+        t <<= 1;
+    }
+    uint64_t F = roots[1];
+    for (int jx = 1, jy = N - 1; jx < (N >> 1); jx++, jy--) {
+        uint64_t a = p2[jx], b = p2[jy];
+        p2[jx] = a + twoQ - lo_mred_lazy(b, F, Q, qinv);
+        p2[jy] = b + twoQ - lo_mred_lazy(a, F, Q, qinv);
+    }
+    p2[N >> 1] = p2[N >> 1] + twoQ - lo_mred_lazy(p2[N >> 1], F, Q, qinv);
+    p2[0] = lo_cred(p2[0] << 1, Q);
+}
+/* NTTStandard / NTTStandardLazy, ring/ntt.go:174-183; NTTConjugateInvariant[Lazy] :717-725 */
 void lo_subring_ntt(const lo_subring *s, const uint64_t *p1, uint64_t *p2, int lazy) {
+    if (s->nthroot == 4 * (uint64_t)s->N) {
+        if (p1 == p2) {  /* the fold reads p1[N-j] after p2[j] is written: go through a copy like a caller would */
+            uint64_t *tmp = (uint64_t *)malloc((size_t)s->N * 8);
+            memcpy(tmp, p1, (size_t)s->N * 8);
+            ntt_ci_core_lazy(tmp, p2, s->N, s->q, s->qinv, s->roots_fwd);
+            free(tmp);
+        } else ntt_ci_core_lazy(p1, p2, s->N, s->q, s->qinv, s->roots_fwd);
+        if (!lazy) for (int i = 0; i < s->N; i++) p2[i] = lo_bred_add(p2[i], s->q, s->brc);
+        return;
+    }
     ntt_core_lazy(p1, p2, s->N, s->q, s->qinv, s->roots_fwd);
     if (!lazy) for (int i = 0; i < s->N; i++) p2[i] = lo_bred_add(p2[i], s->q, s->brc);
 }
 /* INTTStandard / INTTStandardLazy, ring/ntt.go:185-207 */
 void lo_subring_intt(const lo_subring *s, const uint64_t *p1, uint64_t *p2, int lazy) {
+    if (s->nthroot == 4 * (uint64_t)s->N) {  /* INTTConjugateInvariant[Lazy], ring/ntt.go:728-737 */
+        intt_ci_core_lazy(p1, p2, s->N, s->q, s->qinv, s->roots_bwd);
+        for (int i = 0; i < s->N; i++)
+            p2[i] = lazy ? lo_mred_lazy(p2[i], s->ninv, s->q, s->qinv) : lo_mred(p2[i], s->ninv, s->q, s->qinv);
+        return;
+    }
     intt_core_lazy(p1, p2, s->N, s->q, s->qinv, s->roots_bwd);
     if (s->N < 16 && lazy) { for (int i = 0; i < s->N; i++) p2[i] = lo_mred_lazy(p2[i], s->ninv, s->q, s->qinv); }
     else { for (int i = 0; i < s->N; i++) p2[i] = lo_mred(p2[i], s->ninv, s->q, s->qinv); }

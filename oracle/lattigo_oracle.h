@@ -68,6 +68,8 @@ typedef struct lo_ring {
 } lo_ring;
 
 lo_subring *lo_subring_new(int N, uint64_t q);             /* NULL on error */
+lo_subring *lo_subring_new_nthroot(int N, uint64_t q, uint64_t nthroot);
+lo_ring    *lo_ring_new_type(int N, const uint64_t *moduli, int nmod, int type); /* 1 = ConjugateInvariant */
 void        lo_subring_free(lo_subring *s);
 lo_ring    *lo_ring_new(int N, const uint64_t *moduli, int nmod);
 void        lo_ring_free(lo_ring *r);

@@ -78,6 +78,8 @@ def _declare(L):
     L.lo_is_prime.argtypes = [u64]
     L.lo_ring_new.restype = vp
     L.lo_ring_new.argtypes = [i, u64p, i]
+    L.lo_ring_new_type.restype = vp
+    L.lo_ring_new_type.argtypes = [i, u64p, i, i]
     L.lo_ring_free.argtypes = [vp]
     L.lo_ring_roots_fwd.restype = u64p
     L.lo_ring_roots_fwd.argtypes = [vp, i]
@@ -252,11 +254,12 @@ def _words(x: int):
 class Ring:
     """Restated ring.Ring (ring/ring.go:71) -- standard (negacyclic) type only."""
 
-    def __init__(self, N: int, moduli):
+    def __init__(self, N: int, moduli, conjugate_invariant: bool = False):
         self.N = N
         self.moduli = [int(m) for m in moduli]
+        self.conjugate_invariant = conjugate_invariant
         arr = (C.c_uint64 * len(self.moduli))(*self.moduli)
-        self._h = lib().lo_ring_new(N, arr, len(self.moduli))
+        self._h = lib().lo_ring_new_type(N, arr, len(self.moduli), int(conjugate_invariant))
         if not self._h:
             raise ValueError(lib().lo_last_error().decode())
 
@@ -282,10 +285,12 @@ class Ring:
                     primroot=int(out[5]), mask=int(out[6]))
 
     def roots_forward(self, i):
-        return np.ctypeslib.as_array(lib().lo_ring_roots_fwd(self._h, i), shape=(self.N,)).copy()
+        n = 2 * self.N if self.conjugate_invariant else self.N
+        return np.ctypeslib.as_array(lib().lo_ring_roots_fwd(self._h, i), shape=(n,)).copy()
 
     def roots_backward(self, i):
-        return np.ctypeslib.as_array(lib().lo_ring_roots_bwd(self._h, i), shape=(self.N,)).copy()
+        n = 2 * self.N if self.conjugate_invariant else self.N
+        return np.ctypeslib.as_array(lib().lo_ring_roots_bwd(self._h, i), shape=(n,)).copy()
 
     def rescale_constant(self, j, i):
         return int(lib().lo_ring_rescale_constant(self._h, j, i))

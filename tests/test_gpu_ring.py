@@ -221,3 +221,56 @@ def test_error_behaviour(ctx):
         r.NTT(small, small)  # needs 2 limbs at level 1
     with pytest.raises(ValueError):
         r.AtLevel(5)
+
+
+@pytest.mark.parametrize("logN", [4, 7, 10, 12, 13])
+def test_conjugate_invariant_ntt(ctx, logN):
+    """ring/ntt.go:716-1311: conjugate-invariant NTT vs the oracle, bit-exact on strict
+    outputs, plus the reference's own property (ring/ring_test.go:85-126) against a standard 2N ring."""
+    N, Q = 1 << logN, Qi60[:3]
+    g, o = la.Ring(ctx, N, Q, conjugate_invariant=True), O.Ring(N, Q, conjugate_invariant=True)
+    rng = rng_for(1500 + logN)
+    x = np.stack([uniform_poly(rng, Q, N) for _ in range(2)])
+    px, py = la.Poly(g, 3, 2).upload(x), la.Poly(g, 3, 2)
+    g.NTT(px, py)
+    want = np.stack([o.NTT(x[b]) for b in range(2)])
+    assert np.array_equal(py.get(), want)
+    g.NTTLazy(px, py)
+    assert np.array_equal(np.stack([o.unop("Reduce", v) for v in py.get()]), want)
+    pz = la.Poly(g, 3, 2)
+    g.INTT(py, pz)
+    assert np.array_equal(pz.get(), x)
+    g.NTT(px, px)  # in place
+    assert np.array_equal(px.get(), want)
+    # squaring agrees with the unfolded polynomial in the standard ring of degree 2N
+    g2 = la.Ring(ctx, 2 * N, Q)
+    p2 = np.zeros((3, 2 * N), dtype=np.uint64)
+    p2[:, :N] = x[0]
+    for i, qi in enumerate(Q):
+        p2[i, N + 1:] = (np.uint64(qi) - x[0][i, 1:][::-1]) % np.uint64(qi)
+    q2 = la.Poly(g2, 3).upload(p2)
+    g2.NTT(q2, q2)
+    g2.MulCoeffsBarrett(q2, q2, q2)
+    g2.INTT(q2, q2)
+    t = la.Poly(g, 3).upload(x[0])
+    g.NTT(t, t)
+    g.MulCoeffsBarrett(t, t, t)
+    g.INTT(t, t)
+    assert np.array_equal(t.get(), q2.get()[:, :N])
+
+
+def test_conjugate_invariant_rescale(ctx):
+    """ring/scaling.go on a conjugate-invariant ring (the NTT variants go through the folded transform)."""
+    N, Q = 1 << 10, Qi60[:4]
+    g, o = la.Ring(ctx, N, Q, conjugate_invariant=True), O.Ring(N, Q, conjugate_invariant=True)
+    x = uniform_poly(rng_for(1600), Q, N)
+    px = la.Poly(g, 4).upload(x)
+    for name in ["DivRoundByLastModulusNTT", "DivRoundByLastModulus", "DivFloorByLastModulus"]:
+        po = g.NewPoly()
+        getattr(g, name)(px, po)
+        assert np.array_equal(po.get()[:3], getattr(o, name)(x)), name
+    with pytest.raises(la.HeringError):  # depends on the reference's lazy INTT representative: rejected, not approximated
+        g.DivFloorByLastModulusNTT(px, g.NewPoly())
+    po = g.NewPoly()
+    g.DivRoundByLastModulusManyNTT(2, px, po)
+    assert np.array_equal(po.get()[:2], o.DivRoundByLastModulusManyNTT(2, x))

@@ -216,3 +216,26 @@ def test_gen_moduli_shapes():
     # 61-bit primes walk downstream from 2^61
     q, p = O.GenModuli(17, [45, 45], [61, 61])
     assert p[0] > p[1] and p[0] < (1 << 61)
+
+
+def test_conjugate_invariant_ntt_vs_standard_2n(ring_test_params):
+    """ring/ring_test.go:85-126: squaring through the conjugate-invariant NTT of degree N equals
+    squaring the unfolded polynomial through the standard NTT of degree 2N."""
+    N = 1 << ring_test_params["logN"]
+    Q = ring_test_params["qi"][:4]
+    ring2n, ringci = O.Ring(2 * N, Q), O.Ring(N, Q, conjugate_invariant=True)
+    p1 = uniform_poly(rng_for(107), Q, N)
+    p2 = np.zeros((len(Q), 2 * N), dtype=np.uint64)
+    p2[:, :N] = p1
+    for i, qi in enumerate(Q):
+        for j in range(1, N):
+            p2[i, 2 * N - j] = qi - int(p1[i, j])
+    p2 = ring2n.NTT(p2)
+    p2 = ring2n.INTT(ring2n.binop("MulCoeffsBarrett", p2, p2))
+    t = ringci.NTT(p1)
+    got = ringci.INTT(ringci.binop("MulCoeffsBarrett", t, t))
+    assert np.array_equal(got, p2[:, :N])
+    # lazy forms are other representatives of the same residues; round trip is the identity
+    assert np.array_equal(ringci.unop("Reduce", ringci.NTTLazy(p1)), t)
+    assert np.array_equal(ringci.INTT(t), p1)
+    assert np.array_equal(ringci.unop("Reduce", ringci.INTTLazy(t)), p1)
