@@ -92,6 +92,11 @@ int he_ntt_lazy(he_handle ring, int level, he_handle p1, he_handle p2);   /* ret
 int he_intt(he_handle ring, int level, he_handle p1, he_handle p2);
 int he_intt_lazy(he_handle ring, int level, he_handle p1, he_handle p2);
 
+/* ring.NumberTheoreticTransformer (ring/ntt.go:17-22: Forward/ForwardLazy/Backward/BackwardLazy(p1, p2 []uint64)),
+ * the per-limb host-slice plug point of ring.NewRingWithCustomNTT (ring/ring.go:284): N words in, N words out,
+ * one H2D + D2H round trip per call (BASELINE config 1 plumbing; the device-resident entries above are the fast path). */
+int he_subring_ntt_host(he_handle ring, int limb, int backward, int lazy, const uint64_t *p1, uint64_t *p2);
+
 /* ---- coefficient-wise ops (ring/operations.go:11-377 over ring/vec_ops.go) --------
  * The numeric codes are the op tables of the reference: one entry per method.    */
 enum he_binop {
@@ -193,6 +198,14 @@ int he_evaluator_destroy(he_handle eval);
 /* GadgetCiphertext (core/rlwe/gadgetciphertext.go:19-42), BaseTwoDecomposition = 0.
  * Host image: q[beta][2][nQk][N], p[beta][2][nPk][N], NTT + Montgomery form.     */
 int he_evk_create(he_handle eval, int beta, int nQk, int nPk, const uint64_t *q, const uint64_t *p, he_handle *evk);
+/* Base-2 gadget (GadgetCiphertext.BaseTwoDecomposition = pw2 != 0, at most one special prime): one RNS digit per
+ * Q-limb i with nj[i] = ceil(bits(q_i)/pw2) bit windows (core/rlwe/params.go:523-540); block (i, j) is stored at
+ * index sum_{i'<i} nj[i'] + j.  Host image q[sum nj][2][nQk][N], p[sum nj][2][nPk][N].  Such keys are accepted by
+ * he_gadget_product[_lazy], he_relinearize, he_automorphism_ct and the mul_relin entries
+ * (gadgetProductSinglePAndBitDecompLazy, core/rlwe/evaluator_gadget_product.go:203); the hoisted entries reject
+ * them, as the reference does (:381-383). */
+int he_evk_create_base2(he_handle eval, int pw2, const int *nj, int n_rns_digits, int nQk, int nPk, const uint64_t *q,
+                        const uint64_t *p, he_handle *evk);
 int he_evk_destroy(he_handle evk);
 
 /* Decomposer.DecomposeAndSplit (ring/basis_extension.go:381): coefficient-domain

@@ -68,6 +68,7 @@ def _declare(L):
         "he_poly_upload_limb": [H, i, i, u64p], "he_poly_download_limb": [H, i, i, u64p],
         "he_poly_copy": [H, H, i], "he_poly_zero": [H],
         "he_ntt": [H, i, H, H], "he_ntt_lazy": [H, i, H, H], "he_intt": [H, i, H, H], "he_intt_lazy": [H, i, H, H],
+        "he_subring_ntt_host": [H, i, i, i, u64p, u64p],
         "he_binop": [H, i, i, H, H, H], "he_unop": [H, i, i, H, H], "he_scalarop": [H, i, i, H, C.c_uint64, H],
         "he_mul_rns_scalar_montgomery": [H, i, H, u64p, H],
         "he_add_scalar_bigint": [H, i, H, u64p, i, H], "he_sub_scalar_bigint": [H, i, H, u64p, i, H],
@@ -92,6 +93,7 @@ def _declare(L):
         "he_moddown_qp_to_p": [H, i, i, H, H, H],
         "he_evaluator_create": [H, H, HP], "he_evaluator_destroy": [H],
         "he_evk_create": [H, i, i, i, u64p, u64p, HP], "he_evk_destroy": [H],
+        "he_evk_create_base2": [H, i, C.POINTER(i), i, i, i, u64p, u64p, HP],
         "he_decompose_and_split": [H, i, i, i, i, H, H, H],
         "he_decomp_create": [H, i, HP], "he_decomp_destroy": [H],
         "he_decomp_download_limb": [H, i, i, i, i, u64p],

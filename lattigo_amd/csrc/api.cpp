@@ -232,6 +232,8 @@ struct Evaluator : Obj {
 struct Evk : Obj {
     std::shared_ptr<Evaluator> ev;
     int beta = 0, nQk = 0, nPk = 0;
+    int pw2 = 0;                 // BaseTwoDecomposition
+    std::vector<int> nj, prefix; // bit windows per RNS digit and their prefix sums (pw2 != 0)
     uint64_t *d = nullptr;
     Evk() : Obj(T_EVK) {}
     ~Evk() override {
@@ -567,6 +569,23 @@ int he_ntt(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(
 int he_ntt_lazy(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, false, NTT_LAZY_OUT, "he_ntt_lazy"); }
 int he_intt(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, true, 0, "he_intt"); }
 int he_intt_lazy(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, true, 0, "he_intt_lazy"); }
+
+int he_subring_ntt_host(he_handle hring, int limb, int backward, int lazy, const uint64_t *p1, uint64_t *p2) {
+    GET(r, Ring, hring, T_RING);
+    if (!p1 || !p2 || limb < 0 || limb >= r->nmod()) return fail(HE_EINVAL, "he_subring_ntt_host: bad arguments");
+    Scope sc(r->ctx.get());
+    const size_t N = r->N;
+    TRY(r->ctx->arena_reserve(N));
+    uint64_t *buf = r->ctx->arena_take(N);
+    hipStream_t st = r->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(buf, p1, N * 8, hipMemcpyHostToDevice, st));
+    LimbTab t; t.n = 1; t.in_limb[0] = 0; t.out_limb[0] = 0; t.mod[0] = (uint8_t)limb;
+    View v{buf, N};
+    HIP_TRY(ring_ntt(*r, t, v, v, 1, backward != 0, NTT_REDUCE_INPUT | ((lazy && !backward) ? NTT_LAZY_OUT : 0)));
+    HIP_TRY(hipMemcpyAsync(p2, buf, N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HE_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // coefficient-wise ops (ring/operations.go)
@@ -1054,13 +1073,18 @@ int he_evaluator_create(he_handle hq, he_handle hp, he_handle *out) {
 }
 int he_evaluator_destroy(he_handle h) { return unreg(h, T_EVAL); }
 
-int he_evk_create(he_handle hev, int beta, int nQk, int nPk, const uint64_t *q, const uint64_t *p, he_handle *out) {
+static int evk_create_common(he_handle hev, int beta, int nQk, int nPk, const uint64_t *q, const uint64_t *p, int pw2,
+                             const int *nj, int n_rns, he_handle *out) {
     GET(ev, Evaluator, hev, T_EVAL);
     BasisExtender &be = *ev->be;
     if (!q || !p || !out || beta <= 0 || nQk <= 0 || nQk > be.LQ || nPk <= 0 || nPk > be.LP)
         return fail(HE_EINVAL, "he_evk_create: bad key shape (beta=%d, nQk=%d, nPk=%d)", beta, nQk, nPk);
     auto k = std::make_shared<Evk>();
-    k->ev = ev; k->beta = beta; k->nQk = nQk; k->nPk = nPk;
+    k->ev = ev; k->beta = beta; k->nQk = nQk; k->nPk = nPk; k->pw2 = pw2;
+    if (pw2) {
+        k->prefix.push_back(0);
+        for (int i = 0; i < n_rns; i++) { k->nj.push_back(nj[i]); k->prefix.push_back(k->prefix.back() + nj[i]); }
+    }
     Scope sc(be.ctx.get());
     const size_t N = be.Q->N, blk = (size_t)(nQk + nPk) * N;
     HIP_TRY(hipMalloc((void **)&k->d, (size_t)beta * 2 * blk * 8));
@@ -1073,6 +1097,21 @@ int he_evk_create(he_handle hev, int beta, int nQk, int nPk, const uint64_t *q, 
     HIP_TRY(hipStreamSynchronize(be.ctx->stream));
     *out = reg(k);
     return HE_OK;
+}
+int he_evk_create(he_handle hev, int beta, int nQk, int nPk, const uint64_t *q, const uint64_t *p, he_handle *out) {
+    return evk_create_common(hev, beta, nQk, nPk, q, p, 0, nullptr, 0, out);
+}
+int he_evk_create_base2(he_handle hev, int pw2, const int *nj, int n_rns, int nQk, int nPk, const uint64_t *q, const uint64_t *p,
+                        he_handle *out) {
+    if (pw2 <= 0 || pw2 > 62 || !nj || n_rns != nQk) return fail(HE_EINVAL, "he_evk_create_base2: one RNS digit per key Q-limb is required");
+    if (nPk != 1) return fail(HE_EINVAL, "he_evk_create_base2: a base-2 gadget takes exactly one special prime");
+    int beta = 0;
+    for (int i = 0; i < n_rns; i++) {
+        if (nj[i] <= 0 || nj[i] * pw2 > 64 + pw2) return fail(HE_EINVAL, "he_evk_create_base2: bad window count");
+        beta += nj[i];
+    }
+    if (beta > 255) return fail(HE_EINVAL, "he_evk_create_base2: more than 255 gadget blocks");
+    return evk_create_common(hev, beta, nQk, nPk, q, p, pw2, nj, n_rns, out);
 }
 int he_evk_destroy(he_handle h) { return unreg(h, T_EVK); }
 
@@ -1165,7 +1204,7 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     KsArgs a{};
-    a.beta = base_rns_size(levelQ, levelP);
+    a.beta = k.pw2 ? k.prefix[levelQ + 1] : base_rns_size(levelQ, levelP);
     if (a.beta > k.beta) return fail(HE_EINVAL, "gadget product: key has %d digits, %d needed", k.beta, a.beta);
     int n = 0;
     for (int j = 0; j <= levelQ; j++) {
@@ -1322,9 +1361,9 @@ struct KsScratch {  // per gadget product, for `batch` entries
     uint64_t *accQ;        // [2][batch][levelQ+1][N]
     uint64_t *sP, *sQ;     // moddown scratch, [2*batch] entries
 };
-size_t ks_scratch_words(const BasisExtender &be, int levelQ, int levelP, int batch, bool need_dec) {
+size_t ks_scratch_words(const BasisExtender &be, int levelQ, int levelP, int batch, bool need_dec, const Evk *key = nullptr) {
     const size_t N = be.Q->N, B = batch;
-    const size_t beta = base_rns_size(levelQ, levelP);
+    const size_t beta = (key && key->pw2) ? (size_t)key->prefix[levelQ + 1] : (size_t)base_rns_size(levelQ, levelP);
     size_t w = 0;
     if (need_dec) w += B * (levelQ + 1) * N + B * beta * (be.LQ + be.LP) * N;
     w += 2 * B * (levelP + 1) * N * 2 + 2 * B * (levelQ + 1) * N * 2;
@@ -1451,11 +1490,34 @@ int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP
 int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P) {
     BasisExtender &be = *ev.be;
     const int levelP = k.nPk - 1, N = be.Q->N;
-    const int beta = base_rns_size(levelQ, levelP);
+    const int beta = k.pw2 ? k.prefix[levelQ + 1] : base_rns_size(levelQ, levelP);
     const size_t wq = (size_t)B * (levelQ + 1) * N, ds = (size_t)(be.LQ + be.LP) * N, bs = (size_t)beta * ds;
     uint64_t *cxinv = be.ctx->arena_take(wq);
     uint64_t *dec = be.ctx->arena_take((size_t)B * bs);
     View inv{cxinv, (size_t)(levelQ + 1) * N};
+    if (k.pw2) {  // base-2 gadget: bit windows of every Q-limb, NTT'd into every limb (evaluator_gadget_product.go:203-338)
+        hipStream_t st = be.ctx->stream;
+        HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT, st));
+        MaskSpreadArgs m{};
+        m.mask = ((uint64_t)1 << k.pw2) - 1;
+        LimbTab t;
+        t.n = 0;
+        for (int j = 0; j <= levelQ; j++) { t.in_limb[t.n] = t.out_limb[t.n] = t.mod[t.n] = (uint8_t)j; m.dst_limb[t.n] = (uint8_t)j; t.n++; }
+        for (int j = 0; j <= levelP; j++) { t.in_limb[t.n] = t.out_limb[t.n] = t.mod[t.n] = (uint8_t)(be.LQ + j); m.dst_limb[t.n] = (uint8_t)(be.LQ + j); t.n++; }
+        m.ndst = t.n;
+        for (int i = 0; i <= levelQ; i++)
+            for (int j = 0; j < k.nj[i]; j++) {
+                m.blk_limb[m.nblk] = (uint8_t)i;
+                m.blk_shift[m.nblk] = (uint8_t)(j * k.pw2);  // < bits(q_i) <= 62
+                m.nblk++;
+            }
+        HIP_TRY(launch_mask_spread(be.qp, m, inv, dec, bs, ds, B, st));
+        for (int d = 0; d < beta; d++) {
+            View blk{dec + (size_t)d * ds, bs};
+            HIP_TRY(launch_ntt(be.qp, t, blk, blk, B, false, 0, st));
+        }
+        return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
+    }
     const FusedPlan *plan = nullptr;
     TRY(get_dec_plan(ev, levelQ, levelP, levelP + 1, &plan));
     if (plan->ok) {
@@ -1544,7 +1606,7 @@ int he_gadget_product_lazy(he_handle hev, int levelQ, he_handle hcx, he_handle h
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, cx->batch, o, "he_gadget_product_lazy"));
     Scope sc(be.ctx.get());
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true)));
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true, k.get())));
     return gadget_product_lazy_core(*ev, levelQ, cx->view(), cx->batch, *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view());
 }
 int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he_handle hk, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
@@ -1553,6 +1615,7 @@ int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he
     GET(k, Evk, hk, T_EVK);
     BasisExtender &be = *ev->be;
     TRY(check_key(*ev, *k, levelQ, "he_gadget_product_hoisted_lazy"));
+    if (k->pw2) return fail(HE_EINVAL, "he_gadget_product_hoisted_lazy: method is unsupported for BaseTwoDecomposition != 0");
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, dec->batch, o, "he_gadget_product_hoisted_lazy"));
     Scope sc(be.ctx.get());
@@ -1586,7 +1649,7 @@ int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product"));
     if (out0->batch != cx->batch || out1->batch != cx->batch) return fail(HE_EINVAL, "he_gadget_product: batch mismatch");
     Scope sc(be.ctx.get());
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true)));
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true, k.get())));
     const View cxv = cx->view();
     return gadget_product_core(*ev, levelQ, &cxv, nullptr, *k, out0->view(), out1->view(), cx->batch);
 }
@@ -1598,6 +1661,7 @@ int he_gadget_product_hoisted(he_handle hev, int levelQ, he_handle hdec, he_hand
     GET(out1, Poly, hout1, T_POLY);
     BasisExtender &be = *ev->be;
     TRY(check_key(*ev, *k, levelQ, "he_gadget_product_hoisted"));
+    if (k->pw2) return fail(HE_EINVAL, "he_gadget_product_hoisted: method is unsupported for BaseTwoDecomposition != 0");
     TRY(check_be_poly(*out0, be, levelQ + 1, "he_gadget_product_hoisted"));
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product_hoisted"));
     if (out0->batch != dec->batch || out1->batch != dec->batch) return fail(HE_EINVAL, "he_gadget_product_hoisted: batch mismatch");
@@ -1624,7 +1688,7 @@ int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_
     Scope sc(be.ctx.get());
     const int B = in0->batch, N = be.Q->N;
     (void)N;
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true)));
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k.get())));
     const View in2v = in2->view(), in0v = in0->view(), in1v = in1->view();
     return gadget_product_core(*ev, level, &in2v, nullptr, *k, out0->view(), out1->view(), B, &in0v, &in1v);
 }
@@ -1650,10 +1714,11 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     const int B = in0->batch;
     if (out0->batch != B || out1->batch != B || (in1 && in1->batch != B) || (dec && dec->batch != B)) return fail(HE_EINVAL, "%s: batch mismatch", who);
     if (!(gal & 1)) return fail(HE_EINVAL, "%s: Galois element must be odd", who);
+    if (dec && k->pw2) return fail(HE_EINVAL, "%s: method is unsupported for BaseTwoDecomposition != 0", who);
     Scope sc(be.ctx.get());
     const int N = be.Q->N;
     const size_t wQ = (size_t)B * (level + 1) * N;
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, !dec) + 2 * wQ + (size_t)N));
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, !dec, k.get()) + 2 * wQ + (size_t)N));
     View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
     uint32_t *index = reinterpret_cast<uint32_t *>(be.ctx->arena_take((size_t)N / 2 + 2));
     hipStream_t st = be.ctx->stream;
@@ -1685,6 +1750,7 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     if (levelQ < 0 || levelQ > k->nQk - 1) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: levelQ out of range");
     const int levelP = k->nPk - 1, B = dec->batch, N = be.Q->N;
     if (k->ev.get() != ev.get()) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: key belongs to another evaluator");
+    if (k->pw2) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: method is unsupported for BaseTwoDecomposition != 0");
     if (!(gal & 1)) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: Galois element must be odd");
     TRY(check_be_poly(*in0, be, levelQ + 1, "he_automorphism_hoisted_lazy"));
     if (in0->batch != B) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: batch mismatch");
@@ -1765,7 +1831,7 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
                               out1->view(), out2->view(), B, st));
         return HE_OK;
     }
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true) + wQ));
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k.get()) + wQ));
     View c2{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
     HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),
                           out1->view(), c2, B, st));

@@ -133,6 +133,18 @@ bool modup_fused_supported(int logN, int nsrc);
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, View src, View dstA,
                               View dstB, int batch, hipStream_t s);
 
+// base-2 gadget decomposition (ring.MaskVec, ring/vec_ops.go:870, as used by
+// core/rlwe/evaluator_gadget_product.go:256-258): block b = (RNS digit i, window j) gets
+// (src[limb_i] >> shift_b) & mask replicated into every listed destination limb
+struct MaskSpreadArgs {
+    int nblk, ndst;
+    uint64_t mask;
+    uint8_t blk_limb[256], blk_shift[256];
+    uint8_t dst_limb[kMaxLimbs];
+};
+hipError_t launch_mask_spread(const RingDev &r, const MaskSpreadArgs &a, View src, uint64_t *dec, size_t dec_bs, size_t dec_ds,
+                              int batch, hipStream_t s);
+
 // ---- key-switch inner product ---------------------------------------------------------------
 // acc[k][l] = sum_d evk[d][k][l] * dec[d][l] * 2^-64 mod q_l, canonical
 // (core/rlwe/evaluator_gadget_product.go:160-200 after its final Reduce).
@@ -164,7 +176,7 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
 // ---- per-kernel HIP-event profiling (diagnostics: bench.py's roofline leg) --------------------
 enum KernelId {
     K_NTT_COLS_FWD = 0, K_NTT_ROWS_FWD, K_NTT_ROWS_INV, K_NTT_COLS_INV, K_EW, K_GATHER, K_AUTO_COEFF, K_INDEX,
-    K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_CI_FOLD, K_COUNT
+    K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_CI_FOLD, K_MASK_SPREAD, K_COUNT
 };
 const char *kernel_name(int id);
 void prof_begin();                                   // start recording (one stream at a time)

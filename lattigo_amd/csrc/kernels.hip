@@ -46,7 +46,7 @@ struct ProfScope {
 const char *kernel_name(int id) {
     static const char *names[K_COUNT] = {"ntt_cols_fwd", "ntt_rows_fwd", "ntt_rows_inv", "ntt_cols_inv", "ew", "gather",
                                          "automorphism_coeff", "build_index", "modup", "center_copy", "ks_inner",
-                                         "tensor", "modmul_probe", "ci_fold"};
+                                         "tensor", "modmul_probe", "ci_fold", "mask_spread"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 void prof_begin() { g_prof_recs.clear(); g_prof_on = true; }
@@ -989,6 +989,36 @@ hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, Vi
     dim3 grid((unsigned)((r.N + 255) / 256), a.ndst, batch), block(256);
     ProfScope ps(K_CENTER, s);
     hipLaunchKernelGGL(center_copy_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// base-2 gadget windows
+// ------------------------------------------------------------------------------------
+struct MaskSpreadKArgs {
+    const uint64_t *src;
+    uint64_t *dec;
+    size_t src_bs, dec_bs, dec_ds;
+    int N;
+    MaskSpreadArgs m;
+};
+__global__ void __launch_bounds__(256) mask_spread_kernel(MaskSpreadKArgs A) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= A.N) return;
+    const int b = blockIdx.y;
+    const size_t bz = blockIdx.z;
+    const uint64_t v = (A.src[bz * A.src_bs + (size_t)A.m.blk_limb[b] * A.N + x] >> A.m.blk_shift[b]) & A.m.mask;
+    uint64_t *dst = A.dec + bz * A.dec_bs + (size_t)b * A.dec_ds + x;
+    for (int l = 0; l < A.m.ndst; l++) dst[(size_t)A.m.dst_limb[l] * A.N] = v;
+}
+hipError_t launch_mask_spread(const RingDev &r, const MaskSpreadArgs &a, View src, uint64_t *dec, size_t dec_bs, size_t dec_ds,
+                              int batch, hipStream_t s) {
+    if (a.nblk <= 0 || batch <= 0) return hipSuccess;
+    MaskSpreadKArgs A;
+    A.src = src.p; A.src_bs = src.bstride; A.dec = dec; A.dec_bs = dec_bs; A.dec_ds = dec_ds; A.N = r.N; A.m = a;
+    dim3 grid((unsigned)((r.N + 255) / 256), a.nblk, batch), block(256);
+    ProfScope ps(K_MASK_SPREAD, s);
+    hipLaunchKernelGGL(mask_spread_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
 

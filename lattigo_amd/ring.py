@@ -148,6 +148,20 @@ class Poly:
         check(load().he_poly_download_limb(self.h, b, limb, _p(out)))
         return out
 
+    def MarshalBinary(self, b: int = 0) -> bytes:
+        """ring.Poly.MarshalBinary (ring/poly.go:167) of batch entry b."""
+        from . import wire
+        return wire.poly_marshal(self.download()[b])
+
+    def UnmarshalBinary(self, data: bytes, b: int = 0):
+        """ring.Poly.UnmarshalBinary (ring/poly.go:176) into batch entry b."""
+        from . import wire
+        a = wire.poly_unmarshal(data)
+        if a.shape != (self.n_limbs, self.N):
+            raise ValueError(f"polynomial shape {a.shape} does not match ({self.n_limbs}, {self.N})")
+        for i in range(self.n_limbs):
+            self.upload_limb(b, i, a[i])
+
     def CopyLvl(self, level, src: "Poly"):
         check(load().he_poly_copy(self.h, src.h, level))
 
@@ -234,6 +248,25 @@ class Ring:
 
     def INTTLazy(self, p1: Poly, p2: Poly):
         check(load().he_intt_lazy(self.h, self.level, p1.h, p2.h))
+
+    # -- ring.NumberTheoreticTransformer on host slices (ring/ntt.go:17-22), one limb
+    def _ntt_host(self, limb, backward, lazy, p1):
+        a = np.ascontiguousarray(p1, dtype=np.uint64)
+        out = np.empty(self.N, dtype=np.uint64)
+        check(load().he_subring_ntt_host(self.h, limb, int(backward), int(lazy), _p(a), _p(out)))
+        return out
+
+    def Forward(self, limb, p1):
+        return self._ntt_host(limb, False, False, p1)
+
+    def ForwardLazy(self, limb, p1):
+        return self._ntt_host(limb, False, True, p1)
+
+    def Backward(self, limb, p1):
+        return self._ntt_host(limb, True, False, p1)
+
+    def BackwardLazy(self, limb, p1):
+        return self._ntt_host(limb, True, True, p1)
 
     # -- coefficient-wise (ring/operations.go:11-377)
     def binop(self, name: str, p1: Poly, p2: Poly, p3: Poly):

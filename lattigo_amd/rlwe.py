@@ -24,13 +24,20 @@ class EvaluationKey:
     """rlwe.GadgetCiphertext / EvaluationKey with BaseTwoDecomposition = 0
     (core/rlwe/gadgetciphertext.go:19): q [beta,2,nQk,N], p [beta,2,nPk,N], NTT + Montgomery."""
 
-    def __init__(self, evaluator: "Evaluator", q: np.ndarray, p: np.ndarray):
+    def __init__(self, evaluator: "Evaluator", q: np.ndarray, p: np.ndarray, BaseTwoDecomposition: int = 0,
+                 BaseTwoDecompositionVectorSize=None):
         q = np.ascontiguousarray(q, dtype=np.uint64)
         p = np.ascontiguousarray(p, dtype=np.uint64)
         assert q.ndim == 4 and p.ndim == 4 and q.shape[:2] == p.shape[:2] and q.shape[1] == 2
         self.beta, self.nQk, self.nPk = q.shape[0], q.shape[2], p.shape[2]
+        self.BaseTwoDecomposition = BaseTwoDecomposition
         h = H()
-        check(load().he_evk_create(evaluator.h, self.beta, self.nQk, self.nPk, _p(q), _p(p), C.byref(h)))
+        if BaseTwoDecomposition:
+            nj = (C.c_int * len(BaseTwoDecompositionVectorSize))(*BaseTwoDecompositionVectorSize)
+            check(load().he_evk_create_base2(evaluator.h, BaseTwoDecomposition, nj, len(BaseTwoDecompositionVectorSize),
+                                             self.nQk, self.nPk, _p(q), _p(p), C.byref(h)))
+        else:
+            check(load().he_evk_create(evaluator.h, self.beta, self.nQk, self.nPk, _p(q), _p(p), C.byref(h)))
         self.h = h.value
 
     def LevelQ(self):
@@ -89,8 +96,8 @@ class Evaluator:
         except Exception:
             pass
 
-    def NewEvaluationKey(self, q, p) -> EvaluationKey:
-        return EvaluationKey(self, q, p)
+    def NewEvaluationKey(self, q, p, BaseTwoDecomposition=0, BaseTwoDecompositionVectorSize=None) -> EvaluationKey:
+        return EvaluationKey(self, q, p, BaseTwoDecomposition, BaseTwoDecompositionVectorSize)
 
     # ring.Decomposer.DecomposeAndSplit (ring/basis_extension.go:381)
     def DecomposeAndSplit(self, levelQ, levelP, nbPi, digit, p0Q: Poly, p1Q: Poly, p1P: Poly):

@@ -1252,46 +1252,53 @@ static void gadget_product_multiple_p_lazy(const lo_evaluator *e, int levelQ, co
     final_reduce(e, levelQ, levelP, reduce, QiOverF, PiOverF, ctQ, ctP);
     free(cxInv); free(c2Q); free(c2P);
 }
-/* gadgetProductSinglePAndBitDecompLazy, :203-338 with BaseTwoDecomposition = 0
- * (mask == 0), ctQP.IsNTT = true */
+/* gadgetProductSinglePAndBitDecompLazy, :203-338 (ctQP.IsNTT = true): one RNS digit per Q-limb, and for a
+ * base-2 gadget (BaseTwoDecomposition = pw2 != 0) one bit window (x >> j*pw2) & mask per stored block */
 static void gadget_product_single_p_lazy(const lo_evaluator *e, int levelQ, const uint64_t *cx, const lo_evk *evk,
                                          uint64_t *ctQ, uint64_t *ctP) {
     int N = e->ringQ->N, levelP = evk->nPk - 1;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
     uint64_t *cxInv = (uint64_t *)malloc(szQ * 8);
     uint64_t *c2Q = (uint64_t *)malloc(szQ * 8), *c2P = (uint64_t *)malloc(szP * 8);
-    uint64_t *cw = (uint64_t *)malloc((size_t)N * 8);
+    uint64_t *cw = (uint64_t *)malloc((size_t)N * 8), *cwNTT = (uint64_t *)malloc((size_t)N * 8);
     lo_intt(e->ringQ, levelQ, cx, cxInv);
-    int beta = levelQ + 1;
+    int pw2 = evk->pw2;
+    uint64_t mask = pw2 ? (((uint64_t)1 << pw2) - 1) : 0;
     int QiOverF = overflow_margin(e->ringQ, levelQ) >> 1, PiOverF = overflow_margin(e->ringP, levelP) >> 1;
-    int reduce = 0;
-    for (int i = 0; i < beta; i++) {
-        lo_decompose_and_split(e->dec, levelQ, levelP, levelP + 1, i, cxInv, c2Q, c2P);
-        for (int u = 0; u <= levelQ; u++) {
-            const lo_subring *s = e->ringQ->s[u];
-            lo_subring_ntt(s, c2Q + (size_t)u * N, cw, 1);
-            for (int k = 0; k < 2; k++) {
-                const uint64_t *kq = evk->q + (((size_t)(i * 2 + k) * evk->nQk) + u) * N;
-                uint64_t *z = ctQ + k * szQ + (size_t)u * N;
-                if (i == 0) for (int j = 0; j < N; j++) z[j] = lo_mred_lazy(kq[j], cw[j], s->q, s->qinv);
-                else for (int j = 0; j < N; j++) z[j] += lo_mred_lazy(kq[j], cw[j], s->q, s->qinv);
+    int reduce = 0, blk = 0;
+    for (int i = 0; i < levelQ + 1; i++) {
+        if (mask == 0) lo_decompose_and_split(e->dec, levelQ, levelP, levelP + 1, i, cxInv, c2Q, c2P);
+        int nj = pw2 ? evk->nj[i] : 1;
+        for (int j = 0; j < nj; j++, blk++) {
+            if (mask != 0)   /* ring.MaskVec, ring/vec_ops.go:870 */
+                for (int x = 0; x < N; x++) cw[x] = (cxInv[(size_t)i * N + x] >> (j * pw2)) & mask;
+            int first = (i == 0 && j == 0);
+            for (int u = 0; u <= levelQ; u++) {
+                const lo_subring *s = e->ringQ->s[u];
+                lo_subring_ntt(s, mask == 0 ? c2Q + (size_t)u * N : cw, cwNTT, 1);
+                for (int k = 0; k < 2; k++) {
+                    const uint64_t *kq = evk->q + (((size_t)(blk * 2 + k) * evk->nQk) + u) * N;
+                    uint64_t *z = ctQ + k * szQ + (size_t)u * N;
+                    if (first) for (int x = 0; x < N; x++) z[x] = lo_mred_lazy(kq[x], cwNTT[x], s->q, s->qinv);
+                    else for (int x = 0; x < N; x++) z[x] += lo_mred_lazy(kq[x], cwNTT[x], s->q, s->qinv);
+                }
             }
-        }
-        for (int u = 0; u <= levelP; u++) {
-            const lo_subring *s = e->ringP->s[u];
-            lo_subring_ntt(s, c2P + (size_t)u * N, cw, 1);
-            for (int k = 0; k < 2; k++) {
-                const uint64_t *kp = evk->p + (((size_t)(i * 2 + k) * evk->nPk) + u) * N;
-                uint64_t *z = ctP + k * szP + (size_t)u * N;
-                if (i == 0) for (int j = 0; j < N; j++) z[j] = lo_mred_lazy(kp[j], cw[j], s->q, s->qinv);
-                else for (int j = 0; j < N; j++) z[j] += lo_mred_lazy(kp[j], cw[j], s->q, s->qinv);
+            for (int u = 0; u <= levelP; u++) {
+                const lo_subring *s = e->ringP->s[u];
+                lo_subring_ntt(s, mask == 0 ? c2P + (size_t)u * N : cw, cwNTT, 1);
+                for (int k = 0; k < 2; k++) {
+                    const uint64_t *kp = evk->p + (((size_t)(blk * 2 + k) * evk->nPk) + u) * N;
+                    uint64_t *z = ctP + k * szP + (size_t)u * N;
+                    if (first) for (int x = 0; x < N; x++) z[x] = lo_mred_lazy(kp[x], cwNTT[x], s->q, s->qinv);
+                    else for (int x = 0; x < N; x++) z[x] += lo_mred_lazy(kp[x], cwNTT[x], s->q, s->qinv);
+                }
             }
+            periodic_reduce(e, levelQ, levelP, reduce, QiOverF, PiOverF, ctQ, ctP);
+            reduce++;
         }
-        periodic_reduce(e, levelQ, levelP, reduce, QiOverF, PiOverF, ctQ, ctP);
-        reduce++;
     }
     final_reduce(e, levelQ, levelP, reduce, QiOverF, PiOverF, ctQ, ctP);
-    free(cxInv); free(c2Q); free(c2P); free(cw);
+    free(cxInv); free(c2Q); free(c2P); free(cw); free(cwNTT);
 }
 /* GadgetProductLazy, :108-127 */
 void lo_gadget_product_lazy(const lo_evaluator *e, int levelQ, const uint64_t *cx, const lo_evk *evk,

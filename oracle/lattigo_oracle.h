@@ -178,9 +178,12 @@ void lo_decompose_and_split(const lo_decomposer *d, int levelQ, int levelP, int 
  * BaseTwoDecomposition = 0: value[d][k] = {Q:[nQk][N], P:[nPk][N]}, NTT+Montgomery.
  * Flat layout: q[((d*2+k)*nQk + limb)*N + j], p[((d*2+k)*nPk + limb)*N + j]. */
 typedef struct lo_evk {
-    int beta;      /* number of RNS digits stored   */
+    int beta;      /* number of stored (RNS digit, bit window) blocks: sum_i nj[i] */
     int nQk, nPk;  /* limbs of the key (levelQ+1, levelP+1) */
     const uint64_t *q, *p;
+    int pw2;       /* BaseTwoDecomposition (0 = none)                                       */
+    int nj[64];    /* BaseTwoDecompositionVectorSize()[i]: bit windows of RNS digit i;       */
+                   /* block (i, j) is stored at index sum_{i'<i} nj[i'] + j (all 1 if pw2=0) */
 } lo_evk;
 
 typedef struct lo_evaluator {

@@ -44,7 +44,8 @@ def lib():
 
 
 class _Evk(C.Structure):
-    _fields_ = [("beta", C.c_int), ("nQk", C.c_int), ("nPk", C.c_int), ("q", u64p), ("p", u64p)]
+    _fields_ = [("beta", C.c_int), ("nQk", C.c_int), ("nPk", C.c_int), ("q", u64p), ("p", u64p),
+                ("pw2", C.c_int), ("nj", C.c_int * 64)]
 
 
 def _declare(L):
@@ -486,10 +487,14 @@ class EvaluationKey:
 
     q: [beta, 2, nQk, N], p: [beta, 2, nPk, N] -- NTT + Montgomery form."""
 
-    def __init__(self, q: np.ndarray, p: np.ndarray):
+    def __init__(self, q: np.ndarray, p: np.ndarray, pw2: int = 0, nj=None):
         self.q, self.p = _c(q), _c(p)
         assert self.q.ndim == 4 and self.p.ndim == 4 and self.q.shape[:2] == self.p.shape[:2]
-        self._s = _Evk(self.q.shape[0], self.q.shape[2], self.p.shape[2], _p(self.q), _p(self.p))
+        self.pw2 = pw2
+        self.nj = list(nj) if nj is not None else [1] * 64
+        assert pw2 == 0 or sum(self.nj) == self.q.shape[0]
+        arr = (C.c_int * 64)(*(self.nj + [0] * (64 - len(self.nj))))
+        self._s = _Evk(self.q.shape[0], self.q.shape[2], self.p.shape[2], _p(self.q), _p(self.p), pw2, arr)
 
     def LevelQ(self):
         return self.q.shape[2] - 1

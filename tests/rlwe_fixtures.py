@@ -94,3 +94,33 @@ def noise_log2(ringQ: O.Ring, ntt_poly: np.ndarray) -> float:
     c = centered(sub, sub.INTT(ntt_poly), 0)
     m = max(abs(int(x)) for x in c)
     return float(np.log2(m)) if m > 0 else 0.0
+
+
+def gen_evaluation_key_base2(rng, ringQ: O.Ring, ringP: O.Ring, sk_in_Q: np.ndarray, sk_out: SecretKey, pw2: int,
+                             sigma: float = 3.2) -> O.EvaluationKey:
+    """Base-2 gadget key (core/rlwe/gadgetciphertext.go:172-241 with BaseTwoDecomposition = pw2, one P limb):
+    block (i, j) encrypts P * 2^(j*pw2) * skIn on Q-limb i only; nj[i] = ceil(bits(q_i) / pw2)
+    (core/rlwe/params.go:523-540)."""
+    N = ringQ.N
+    LQ, LP = len(ringQ.moduli), len(ringP.moduli)
+    assert LP == 1
+    nj = [(int(q).bit_length() + pw2 - 1) // pw2 for q in ringQ.moduli]
+    D = sum(nj)
+    P = prod(ringP.moduli)
+    kq = np.zeros((D, 2, LQ, N), dtype=np.uint64)
+    kp = np.zeros((D, 2, LP, N), dtype=np.uint64)
+    blk = 0
+    for i in range(LQ):
+        for j in range(nj[i]):
+            e = np.clip(np.rint(rng.normal(0.0, sigma, size=N)), -19, 19).astype(np.int64)
+            aQ = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringQ.moduli])
+            aP = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringP.moduli])
+            bQ = ringQ.unop("MForm", ringQ.NTT(small_to_rns(e, ringQ.moduli)))
+            bP = ringP.unop("MForm", ringP.NTT(small_to_rns(e, ringP.moduli)))
+            bQ = ringQ.binop("MulCoeffsMontgomeryThenSub", aQ, sk_out.Q, bQ)
+            bP = ringP.binop("MulCoeffsMontgomeryThenSub", aP, sk_out.P, bP)
+            g = ringQ.MulScalarBigint(sk_in_Q, P << (j * pw2))
+            bQ[i] = ringQ.binop("Add", bQ, g)[i]
+            kq[blk, 0], kq[blk, 1], kp[blk, 0], kp[blk, 1] = bQ, aQ, bP, aP
+            blk += 1
+    return O.EvaluationKey(kq, kp, pw2=pw2, nj=nj)

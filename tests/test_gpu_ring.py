@@ -30,6 +30,24 @@ def test_ntt_known_answer_vectors(ctx):
         assert np.array_equal(pz.get(), x), f"N={c['N']}"
 
 
+def test_config1_host_slice_transformer(ctx):
+    """BASELINE config 1: ring.NTT forward+inverse, N=2^12, one prime Qi60[0] (ring/ntt_benchmark_test.go:29),
+    through the ring.NumberTheoreticTransformer host-slice plug point (ring/ntt.go:17-22)."""
+    N, q = 1 << 12, [0x1fffffffffe00001]
+    g, o = la.Ring(ctx, N, q), O.Ring(N, q)
+    x = uniform_poly(rng_for(0), q, N)
+    y = g.Forward(0, x[0])
+    assert np.array_equal(y, o.NTT(x)[0])
+    assert np.array_equal(g.Backward(0, y), x[0])
+    assert np.array_equal(o.unop("Reduce", g.ForwardLazy(0, x[0])[None])[0], y)
+    assert np.array_equal(g.BackwardLazy(0, y), x[0])
+    # wire format round trip through a device poly
+    p = g.NewPoly().upload(x)
+    p2 = g.NewPoly()
+    p2.UnmarshalBinary(p.MarshalBinary())
+    assert np.array_equal(p2.get(), x)
+
+
 def test_tables_match_oracle(ctx):
     pr = Pair(ctx, 11, 3)
     for i in range(3):

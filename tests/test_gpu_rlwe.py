@@ -9,7 +9,8 @@ from oracle import oracle as O
 from tests.conftest import Pi60, Qi60
 from tests.gpu_common import Pair, ctx  # noqa: F401
 from tests.helpers import prod, rand_bigints, rng_for, set_coefficients_bigint, uniform_poly
-from tests.rlwe_fixtures import SecretKey, automorphism_secret, gen_evaluation_key, noise_log2, phase
+from tests.rlwe_fixtures import (SecretKey, automorphism_secret, gen_evaluation_key, gen_evaluation_key_base2,
+                                 noise_log2, phase)
 
 pytestmark = pytest.mark.gpu
 
@@ -318,3 +319,31 @@ def test_full_size_config4_ckks_logN16(ctx):
 def test_full_size_config5_shape_logN16(ctx):
     """Bootstrapping-sized chain (logN=16, 25 Q-limbs, 5 P-limbs of 61 bits, alpha = 5)."""
     _full_size_check(ctx, 16, [60] + [45] * 10 + [60] * 6 + [40] * 8, [61] * 5, 5, False)
+
+
+@pytest.mark.parametrize("pw2", [12, 20, 31])
+def test_base2_gadget_product(ctx, pw2):
+    """gadgetProductSinglePAndBitDecompLazy with BaseTwoDecomposition != 0 (core/rlwe/evaluator_gadget_product.go:203-338)."""
+    pr, rng, oev, gev, sk = _setup(ctx, 11, 4, 1, 2600 + pw2)
+    sk2 = SecretKey(rng, pr.oQ, pr.oP)
+    oevk = gen_evaluation_key_base2(rng, pr.oQ, pr.oP, sk.Q, sk2, pw2)
+    gevk = gev.NewEvaluationKey(oevk.q, oevk.p, pw2, oevk.nj[:4])
+    for levelQ in (3, 2, 0):
+        Qm = pr.q[: levelQ + 1]
+        cx = np.stack([uniform_poly(rng, Qm, pr.N) for _ in range(2)])
+        pcx = la.Poly(pr.gQ, levelQ + 1, 2).upload(cx)
+        qp = [(la.Poly(pr.gQ, levelQ + 1, 2), la.Poly(pr.gP, 1, 2)) for _ in range(2)]
+        gev.GadgetProductLazy(levelQ, pcx, gevk, qp)
+        wQ, wP = oev.GadgetProductLazy(levelQ, cx[1], oevk)
+        for k in range(2):
+            assert np.array_equal(qp[k][0].get()[1], wQ[k]) and np.array_equal(qp[k][1].get()[1], wP[k]), (levelQ, k)
+        ct = [la.Poly(pr.gQ, levelQ + 1, 2), la.Poly(pr.gQ, levelQ + 1, 2)]
+        gev.GadgetProduct(levelQ, pcx, gevk, ct)
+        want = oev.GadgetProduct(levelQ, cx[0], oevk)
+        got = np.stack([c.get()[0] for c in ct])
+        assert np.array_equal(got, want), levelQ
+        sub = O.Ring(pr.N, Qm)
+        noise = noise_log2(pr.oQ, sub.binop("Sub", phase(pr.oQ, got, sk2.Q), sub.binop("MulCoeffsMontgomery", cx[0], sk.Q[: levelQ + 1])))
+        assert noise <= 11 + pw2 + 6, noise
+    with pytest.raises(la.HeringError):  # hoisted forms reject base-2 keys, as the reference (:381-383)
+        gev.GadgetProductHoisted(3, la.Decomposition(gev, 2), gevk, ct)

@@ -8,7 +8,7 @@ from oracle import oracle as O
 from tests.conftest import Pi60, Qi60
 from tests.helpers import rng_for, uniform_poly
 from tests.rlwe_fixtures import (SecretKey, automorphism_secret, gen_evaluation_key,
-                                 noise_log2, phase)
+                                 gen_evaluation_key_base2, noise_log2, phase)
 
 N = 1 << 10
 
@@ -138,3 +138,18 @@ def test_rescale_matches_ring_op():
     out2 = ev.Rescale(ct, 2)
     for i in range(3):
         assert np.array_equal(out2[i], ringQ.DivRoundByLastModulusManyNTT(2, ct[i]))
+
+
+@pytest.mark.parametrize("pw2", [12, 20, 31])
+def test_base2_gadget_product_decrypts(pw2):
+    """gadgetProductSinglePAndBitDecompLazy with BaseTwoDecomposition != 0 (core/rlwe/evaluator_gadget_product.go:203)."""
+    rng, ringQ, ringP, ev, sk = setup(4, 1, 400 + pw2)
+    sk2 = SecretKey(rng, ringQ, ringP)
+    evk = gen_evaluation_key_base2(rng, ringQ, ringP, sk.Q, sk2, pw2)
+    for levelQ in (3, 1):
+        sub = O.Ring(N, ringQ.moduli[: levelQ + 1])
+        cx = uniform_poly(rng, sub.moduli, N)
+        ct = ev.GadgetProduct(levelQ, cx, evk)
+        got = phase(ringQ, ct, sk2.Q)
+        want = sub.binop("MulCoeffsMontgomery", cx, sk.Q[: levelQ + 1])
+        assert noise_log2(ringQ, sub.binop("Sub", got, want)) <= 10 + pw2 + 6
