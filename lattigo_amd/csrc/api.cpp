@@ -104,6 +104,7 @@ struct Ring : Obj {
     ModConst *d_mc = nullptr;
     uint64_t *d_twf = nullptr, *d_twi = nullptr;
     std::vector<uint8_t> small;
+    double *d_twdf = nullptr, *d_twdi = nullptr;
     RingDev dev{};
     Ring() : Obj(T_RING) {}
     ~Ring() override {
@@ -112,6 +113,8 @@ struct Ring : Obj {
         if (d_mc) hipFree(d_mc);
         if (d_twf) hipFree(d_twf);
         if (d_twi) hipFree(d_twi);
+        if (d_twdf) hipFree(d_twdf);
+        if (d_twdi) hipFree(d_twdi);
     }
     int nmod() const { return (int)moduli.size(); }
 };
@@ -185,6 +188,7 @@ struct BasisExtender : Obj {
     ModConst *d_mc = nullptr;
     uint64_t *d_twf = nullptr, *d_twi = nullptr;
     std::vector<uint8_t> small;
+    double *d_twdf = nullptr, *d_twdi = nullptr;
     RingDev qp{};
     ConstPool pool;
     std::vector<ModUpRef> qtop, ptoq;                      // per source level
@@ -196,6 +200,8 @@ struct BasisExtender : Obj {
         if (d_mc) hipFree(d_mc);
         if (d_twf) hipFree(d_twf);
         if (d_twi) hipFree(d_twi);
+        if (d_twdf) hipFree(d_twdf);
+        if (d_twdi) hipFree(d_twdi);
         pool.release();
     }
     uint64_t modulus(int idx) const { return idx < LQ ? Q->moduli[idx] : P->moduli[idx - LQ]; }
@@ -319,6 +325,29 @@ int check_poly(const Poly &p, const Ring &r, int level, const char *who) {
     return HE_OK;
 }
 
+uint8_t modulus_class(uint64_t q) { return (q >> 47) == 0 ? 2 : ((q >> 58) == 0 ? 1 : 0); }
+// plain (non-Montgomery) twiddles as doubles for the moduli the double-precision row kernel handles
+int upload_f64_tables(const std::vector<const SubRingHost *> &subs, int N, double **d_f, double **d_i) {
+    const size_t n = subs.size();
+    bool any = false;
+    for (auto *s : subs) any = any || modulus_class(s->mc.q) == 2;
+    *d_f = *d_i = nullptr;
+    if (!any) return HE_OK;
+    std::vector<double> tf(n * (size_t)N, 0.0), ti(n * (size_t)N, 0.0);
+    for (size_t i = 0; i < n; i++) {
+        const ModConst &m = subs[i]->mc;
+        if (modulus_class(m.q) != 2) continue;
+        for (int j = 0; j < N; j++) {
+            tf[i * (size_t)N + j] = (double)imform(subs[i]->roots_fwd[j], m.q, m.qinv);
+            ti[i * (size_t)N + j] = (double)imform(subs[i]->roots_bwd[j], m.q, m.qinv);
+        }
+    }
+    HIP_TRY(hipMalloc((void **)d_f, tf.size() * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)d_i, ti.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(*d_f, tf.data(), tf.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(*d_i, ti.data(), ti.size() * sizeof(double), hipMemcpyHostToDevice));
+    return HE_OK;
+}
 int upload_tables(const std::vector<const SubRingHost *> &subs, int N, ModConst **d_mc, uint64_t **d_twf, uint64_t **d_twi) {
     const size_t n = subs.size();
     std::vector<ModConst> mc(n);
@@ -427,8 +456,9 @@ int he_ring_create_type(he_handle hctx, int logN, int ring_type, const uint64_t 
     std::vector<const SubRingHost *> subs;
     for (auto &s : r->sub) subs.push_back(&s);
     TRY(upload_tables(subs, r->N, &r->d_mc, &r->d_twf, &r->d_twi));
-    for (uint64_t m : r->moduli) r->small.push_back((m >> 58) == 0);
-    r->dev = RingDev{logN, r->N, r->d_mc, r->d_twf, r->d_twi, r->small.data()};
+    for (uint64_t m : r->moduli) r->small.push_back(modulus_class(m));
+    TRY(upload_f64_tables(subs, r->N, &r->d_twdf, &r->d_twdi));
+    r->dev = RingDev{logN, r->N, r->d_mc, r->d_twf, r->d_twi, r->small.data(), r->d_twdf, r->d_twdi};
     *out = reg(r);
     return HE_OK;
 }
@@ -895,9 +925,10 @@ int he_basis_extender_create(he_handle hq, he_handle hp, he_handle *out) {
     for (auto &s : Q->sub) subs.push_back(&s);
     for (auto &s : P->sub) subs.push_back(&s);
     TRY(upload_tables(subs, Q->N, &be->d_mc, &be->d_twf, &be->d_twi));
-    for (uint64_t m : Q->moduli) be->small.push_back((m >> 58) == 0);
-    for (uint64_t m : P->moduli) be->small.push_back((m >> 58) == 0);
-    be->qp = RingDev{Q->logN, Q->N, be->d_mc, be->d_twf, be->d_twi, be->small.data()};
+    for (uint64_t m : Q->moduli) be->small.push_back(modulus_class(m));
+    for (uint64_t m : P->moduli) be->small.push_back(modulus_class(m));
+    TRY(upload_f64_tables(subs, Q->N, &be->d_twdf, &be->d_twdi));
+    be->qp = RingDev{Q->logN, Q->N, be->d_mc, be->d_twf, be->d_twi, be->small.data(), be->d_twdf, be->d_twdi};
     for (int i = 0; i < be->LQ; i++)  // constantsQtoP[i] = GenModUpConstants(Q[:i+1], P)     basis_extension.go:62-65
         be->qtop.push_back(pool_modup(be->pool, std::vector<uint64_t>(Q->moduli.begin(), Q->moduli.begin() + i + 1), P->moduli));
     for (int i = 0; i < be->LP; i++)  // constantsPtoQ[i] = GenModUpConstants(P[:i+1], Q)     :67-70

@@ -32,7 +32,11 @@ struct RingDev {
     const ModConst *mc;      // [n_mod]
     const uint64_t *tw_fwd;  // [n_mod][N] RootsForward  (Montgomery form, bit-reversed order)
     const uint64_t *tw_inv;  // [n_mod][N] RootsBackward
-    const uint8_t *host_small;  // HOST array [n_mod]: 1 when the modulus is below 2^58 (correction-free butterflies)
+    // HOST array [n_mod], kernel class per modulus: 2 = below 2^47 (double-precision row kernel),
+    // 1 = below 2^58 (correction-free integer butterflies), 0 = generic
+    const uint8_t *host_small;
+    const double *twd_fwd;      // [n_mod][N] plain twiddles as doubles (entries of class-2 moduli only), or null
+    const double *twd_inv;
 };
 
 // ---- NTT ---------------------------------------------------------------------------
