@@ -168,14 +168,31 @@ struct ConstPool {
 };
 struct ModUpRef {
     int nsrc = 0, ndst = 0;
-    size_t a = 0, T = 0, vt = 0;
+    size_t a = 0, T = 0, vt = 0, Td = 0, vtd = 0;
     ModUpDev on(const ConstPool &p) const { return ModUpDev{nsrc, ndst, p.dev + a, p.dev + T, p.dev + vt}; }
+    const double *Td_on(const ConstPool &p) const { return reinterpret_cast<const double *>(p.dev + Td); }
+    const double *vtd_on(const ConstPool &p) const { return reinterpret_cast<const double *>(p.dev + vtd); }
 };
+static uint64_t dbits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 static ModUpRef pool_modup(ConstPool &pool, const std::vector<uint64_t> &S, const std::vector<uint64_t> &D) {
     ModUpHost h = build_modup_constants(S, D);
     ModUpRef r;
     r.nsrc = h.nsrc; r.ndst = h.ndst;
     r.a = pool.add(h.a); r.T = pool.add(h.T); r.vt = pool.add(h.vt);
+    // double-precision copies for the destination moduli the f64 path handles (plain, non-Montgomery integers)
+    std::vector<uint64_t> Td((size_t)h.ndst * h.nsrc * 2, 0), vtd((size_t)h.ndst * (h.nsrc + 1), 0);
+    for (int j = 0; j < h.ndst; j++) {
+        const uint64_t p = D[j];
+        if (p >> 47) continue;
+        const uint64_t rinv = invmod(to_mont(1, p), p);  // 2^-64 mod p
+        for (int i = 0; i < h.nsrc; i++) {
+            const uint64_t t = mulmod(h.T[(size_t)j * h.nsrc + i], rinv, p);
+            Td[((size_t)j * h.nsrc + i) * 2] = dbits((double)t);
+            Td[((size_t)j * h.nsrc + i) * 2 + 1] = dbits((double)mulmod(t, (1ull << 26) % p, p));
+        }
+        for (int v = 0; v <= h.nsrc; v++) vtd[(size_t)j * (h.nsrc + 1) + v] = dbits((double)h.vt[(size_t)j * (h.nsrc + 1) + v]);
+    }
+    r.Td = pool.add(Td); r.vtd = pool.add(vtd);
     return r;
 }
 
@@ -212,6 +229,7 @@ struct BasisExtender : Obj {
 struct FusedGroup {
     ModUpDesc *dev;
     int n, nsrc;
+    int dst_classes;  // bit 0: some destination modulus >= 2^47, bit 1: some below
 };
 struct FusedPlan {
     bool ok = false;
@@ -1270,7 +1288,10 @@ int upload_plan(Evaluator &ev, const std::vector<ModUpDesc> &descs, FusedPlan &p
     while (i < descs.size()) {
         size_t j = i;
         while (j < descs.size() && descs[j].nsrc == descs[i].nsrc) j++;
-        plan.groups.push_back(FusedGroup{dev + i, (int)(j - i), descs[i].nsrc});
+        int cls = 0;
+        for (size_t k = i; k < j; k++)
+            for (int t = 0; t < descs[k].ndst; t++) cls |= (ev.be->modulus(descs[k].dst_mod[t]) >> 47) ? 1 : 2;
+        plan.groups.push_back(FusedGroup{dev + i, (int)(j - i), descs[i].nsrc, cls});
         i = j;
     }
     return HE_OK;
@@ -1298,13 +1319,16 @@ int get_dec_plan(Evaluator &ev, int levelQ, int levelP, int nbPi, const FusedPla
         if (!D.single) {
             if (nbPi < 2 || nbPi - 2 >= (int)ev.dec.size() || d >= (int)ev.dec[nbPi - 2].size() ||
                 decompLvl >= (int)ev.dec[nbPi - 2][d].size()) { ok = false; break; }
-            const ModUpDev c = ev.dec[nbPi - 2][d][decompLvl].on(ev.pool);
+            const ModUpRef &ref = ev.dec[nbPi - 2][d][decompLvl];
+            const ModUpDev c = ref.on(ev.pool);
             D.a = c.a; D.T = c.T; D.vt = c.vt;
+            D.Td = ref.Td_on(ev.pool); D.vtd = ref.vtd_on(ev.pool);
             D.reduce_out = modup_out_needs_reduce(basis) ? 1 : 0;
         }
         for (int i = 0; i < D.nsrc; i++) {
             D.src_limb[i] = (uint8_t)(st + i); D.src_mod[i] = (uint8_t)(st + i);
             D.src_half[i] = D.single ? 0 : half_product_mod(basis, be.Q->moduli[st + i]);
+            D.src_split[i] = (be.Q->moduli[st + i] >> 51) ? 1 : 0;
         }
         D.dst_off = (size_t)d * width * N;
         int n = 0;
@@ -1342,10 +1366,12 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
     if (D.nsrc <= 8) {
         const ModUpDev c = be.ptoq[levelP].on(be.pool);
         D.a = c.a; D.T = c.T; D.vt = c.vt;
+        D.Td = be.ptoq[levelP].Td_on(be.pool); D.vtd = be.ptoq[levelP].vtd_on(be.pool);
         D.reduce_out = modup_out_needs_reduce(basis) ? 1 : 0;
         for (int i = 0; i <= levelP; i++) {
             D.src_limb[i] = (uint8_t)i; D.src_mod[i] = (uint8_t)(be.LQ + i);
             D.src_half[i] = half_product_mod(basis, be.P->moduli[i]);
+            D.src_split[i] = (be.P->moduli[i] >> 51) ? 1 : 0;
         }
         for (int j = 0; j <= levelQ; j++) {
             D.dst_limb[j] = (uint8_t)j; D.dst_mod[j] = (uint8_t)j; D.dst_row[j] = (uint8_t)j; D.dst_view[j] = 0;
@@ -1513,7 +1539,7 @@ int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP
     BasisExtender &be = *ev.be;
     const View dv{dec, dec_bs};
     for (const FusedGroup &g : plan.groups)
-        HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, rows_inv, dv, dv, batch, be.ctx->stream));
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, g.dst_classes, rows_inv, dv, dv, batch, be.ctx->stream));
     return dec_rows_ntt(ev, levelQ, levelP, nbPi, dec, dec_bs, batch);
 }
 
@@ -1569,7 +1595,7 @@ int moddown_front(Evaluator &ev, int levelQ, int levelP, View accP, View sP, Vie
     if (plan->ok) {
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, NTT_REDUCE_INPUT, st));
         const FusedGroup &g = plan->groups[0];
-        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, sP, sQ, sQ, nb, st));
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, nb, st));
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT, st));
         return HE_OK;
     }
@@ -1614,6 +1640,22 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
     if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P));
     else TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
     View sP{be.ctx->arena_take(2 * B * sPw), sPw}, sQ{be.ctx->arena_take(2 * B * sQw), sQw};
+    const FusedPlan *plan = nullptr;
+    TRY(get_md_plan(ev, levelQ, levelP, &plan));
+    if (plan->ok) {
+        // ModDown with every pass fused: INTT rows (P, both components) -> [cols + ModUpPtoQ + cols] -> NTT rows whose
+        // epilogue applies (x - acc) * P^-1 and the caller's Add and writes the final output
+        hipStream_t st = be.ctx->stream;
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), View{aP, sPw}, sP, 2 * B, true, NTT_REDUCE_INPUT, st));
+        const FusedGroup &g = plan->groups[0];
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, 2 * B, st));
+        NttEpilogue epi;
+        for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
+        epi.y = a0Q; epi.has_w = add0 != nullptr; epi.w = add0 ? *add0 : a0Q;
+        epi.zsplit = B; epi.out2 = out1; epi.y2 = a1Q; epi.has_w2 = add1 != nullptr; epi.w2 = add1 ? *add1 : a1Q;
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, out0, 2 * B, false, 0, st, &epi));
+        return HE_OK;
+    }
     TRY(moddown_front(ev, levelQ, levelP, View{aP, sPw}, sP, sQ, 2 * B));
     TRY(moddown_back(ev, levelQ, levelP, sQ, a0Q, out0, add0, B));
     TRY(moddown_back(ev, levelQ, levelP, View{sQ.p + (size_t)B * sQw, sQw}, a1Q, out1, add1, B));

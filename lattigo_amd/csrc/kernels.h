@@ -49,8 +49,21 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
 // only the contiguous-row pass (the last min(logN,12) forward stages / the first ones of the inverse);
 // the strided column stages are then done by the producer / consumer kernel (launch_modup_fused).
 // For logN <= 12 this is the whole transform (inverse: N^-1 included).
+// Optional epilogue of the forward row pass = the last op of ModDownQPtoQNTT (ring/basis_extension.go:252-255),
+// optionally fused with the Ring.Add every key-switch caller applies next:
+//   out = [w +] MRed(NTT(in) + 2q - y, s[limb])      (y, w, out indexed by tab.out_limb)
+struct NttEpilogue {
+    View y, w;
+    bool has_w;
+    uint64_t s[kMaxLimbs];
+    // optional second output set: batch entries >= zsplit use (out2, y2, w2) with index z - zsplit
+    // (both components of a ciphertext in one launch)
+    int zsplit = 0;
+    View out2, y2, w2;
+    bool has_w2 = false;
+};
 hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
-                           hipStream_t s);
+                           hipStream_t s, const NttEpilogue *epi = nullptr);
 
 // conjugate-invariant fold (ring/ntt.go:764-769 forward, :1146-1151 backward), pairs (j, N-j) per thread:
 //   forward : out[j] = in[j] + 2q - MRedLazy(in[N-j], F), out[0] = in[0]          (F = ModConst.pad0)
@@ -126,6 +139,10 @@ hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, Vi
 struct ModUpDesc {
     int nsrc, ndst, single, reduce_out;
     const uint64_t *a, *T, *vt;
+    // double-precision copies for destination moduli below 2^47: Td[row][i] = {T, T*2^26 mod p} (plain integers),
+    // vtd[row][v] = vt; a source residue y >= 2^51 is split as y = yh*2^26 + yl (src_split[i])
+    const double *Td, *vtd;
+    uint8_t src_split[8];
     uint64_t src_half[8];
     uint8_t src_limb[8], src_mod[8];
     size_t dst_off;  // words added to the destination bases (digit block)
@@ -134,8 +151,9 @@ struct ModUpDesc {
 };
 // all descriptors must share nsrc; returns hipErrorInvalidValue when (nsrc, logN) has no fused kernel
 bool modup_fused_supported(int logN, int nsrc);
-hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, View src, View dstA,
-                              View dstB, int batch, hipStream_t s);
+// dst_classes: bit 0 = some destination modulus is >= 2^47 (integer path), bit 1 = some is below (double path)
+hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
+                              View dstA, View dstB, int batch, hipStream_t s);
 
 // base-2 gadget decomposition (ring.MaskVec, ring/vec_ops.go:870, as used by
 // core/rlwe/evaluator_gadget_product.go:256-258): block b = (RNS digit i, window j) gets

@@ -114,6 +114,17 @@ struct NttArgs {
     int flags;
     int scale;   // inverse: fold N^-1 into the last stage of THIS kernel
     LimbTab tab;
+    // forward epilogue (see NttEpilogue)
+    int epi;     // 0 none, 1 = MRed(v + 2q - y, s), 2 = w + that
+    const uint64_t *epi_y, *epi_w;
+    size_t epi_y_bs, epi_w_bs;
+    uint64_t epi_s[kMaxLimbs];
+    int zsplit;  // batch entries >= zsplit write the second output set
+    int epi2;
+    uint64_t *out2;
+    size_t out2_bs;
+    const uint64_t *epi_y2, *epi_w2;
+    size_t epi_y2_bs, epi_w2_bs;
 };
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
@@ -238,8 +249,18 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             uint64_t v = lds[lds_phys(e)];
             if constexpr (NC) v = bred_add_lazy(v, q, mc.brc0);  // [0, 36q) -> [0, 2q)
             else v = v >= twoq ? v - twoq : v;
-            if (!lazy) v = v >= q ? v - q : v;
-            dst[e] = v;
+            if (A.epi) {
+                const bool second = A.zsplit && (int)blockIdx.z >= A.zsplit;
+                const size_t zz = second ? blockIdx.z - A.zsplit : blockIdx.z;
+                const size_t off = (size_t)ol * A.N + (size_t)row * N2 + e;
+                const uint64_t yv = second ? A.epi_y2[zz * A.epi_y2_bs + off] : A.epi_y[zz * A.epi_y_bs + off];
+                v = mred(v + twoq - yv, A.epi_s[y], q, qinv);
+                if ((second ? A.epi2 : A.epi) == 2) v = cred((second ? A.epi_w2[zz * A.epi_w2_bs + off] : A.epi_w[zz * A.epi_w_bs + off]) + v, q);
+                (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs)[off] = v;
+            } else {
+                if (!lazy) v = v >= q ? v - q : v;
+                dst[e] = v;
+            }
         }
     } else {
 #pragma unroll
@@ -403,7 +424,18 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int e = k * T + tau;
-            dst[e] = canon_f64(lds[lds_phys(e)], q, qi);
+            uint64_t v = canon_f64(lds[lds_phys(e)], q, qi);
+            if (A.epi) {
+                const bool second = A.zsplit && (int)blockIdx.z >= A.zsplit;
+                const size_t zz = second ? blockIdx.z - A.zsplit : blockIdx.z;
+                const size_t off = (size_t)ol * A.N + (size_t)row * N2 + e;
+                const uint64_t yv = second ? A.epi_y2[zz * A.epi_y2_bs + off] : A.epi_y[zz * A.epi_y_bs + off];
+                v = mred(v + (mc.q << 1) - yv, A.epi_s[y], mc.q, mc.qinv);
+                if ((second ? A.epi2 : A.epi) == 2) v = cred((second ? A.epi_w2[zz * A.epi_w2_bs + off] : A.epi_w[zz * A.epi_w_bs + off]) + v, mc.q);
+                (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs)[off] = v;
+            } else {
+                dst[e] = v;
+            }
         }
     } else {
 #pragma unroll
@@ -548,6 +580,7 @@ static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, const uint8
         D.tab.in_limb[D.tab.n] = A.tab.in_limb[i];
         D.tab.out_limb[D.tab.n] = A.tab.out_limb[i];
         D.tab.mod[D.tab.n] = A.tab.mod[i];
+        D.epi_s[D.tab.n] = A.epi_s[i];
         D.tab.n++;
     }
     hipError_t e = hipSuccess;
@@ -582,6 +615,8 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     A.N = r.N;
     A.a = a;
     A.tab = tab;
+    A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
+    A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
     dim3 grows(1u << a, tab.n, batch);
     dim3 gcols((unsigned)(((r.N >> a) + 255) / 256), tab.n, batch);
     hipError_t e;
@@ -622,13 +657,28 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
 }
 
 hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
-                           hipStream_t s) {
+                           hipStream_t s, const NttEpilogue *epi) {
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     const int n = r.logN;
     if (n < 4 || n > 17) return hipErrorInvalidValue;
+    if (epi && inverse) return hipErrorInvalidValue;
     const int a = n > 12 ? n - 12 : 0, b = n - a;
     NttArgs A;
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
+    A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
+    A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
+    if (epi) {
+        A.epi = epi->has_w ? 2 : 1;
+        A.epi_y = epi->y.p; A.epi_y_bs = epi->y.bstride;
+        A.epi_w = epi->w.p; A.epi_w_bs = epi->w.bstride;
+        for (int i = 0; i < tab.n; i++) A.epi_s[i] = epi->s[i];
+        if (epi->zsplit > 0) {
+            A.zsplit = epi->zsplit; A.epi2 = epi->has_w2 ? 2 : 1;
+            A.out2 = epi->out2.p; A.out2_bs = epi->out2.bstride;
+            A.epi_y2 = epi->y2.p; A.epi_y2_bs = epi->y2.bstride;
+            A.epi_w2 = epi->w2.p; A.epi_w2_bs = epi->w2.bstride;
+        }
+    }
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = flags;
     dim3 grows(1u << a, tab.n, batch);
@@ -999,10 +1049,15 @@ struct ModUpFusedArgs {
     size_t src_bs, dstA_bs, dstB_bs;
     const ModConst *mc;
     const uint64_t *tw_fwd, *tw_inv;
+    const double *twd_fwd;
     int N;
+    int skip_f64_dst;  // integer variant: leave destination moduli below 2^47 to the double-precision variant
 };
 
-template <int NSRC, int LOGA>
+// DSTF64 = false: destinations in 64-bit integer arithmetic (any modulus).
+// DSTF64 = true : only destination moduli below 2^47, the mat-vec and the column stages in exact double-precision
+//                 integer arithmetic (see ntt_rows_f64_kernel); same canonical results.
+template <int NSRC, int LOGA, bool DSTF64>
 __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
     constexpr int R = 1 << LOGA;
     const int N2 = A.N >> LOGA;
@@ -1012,7 +1067,11 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
     const size_t bz = blockIdx.z;
     const uint64_t *src = A.src + bz * A.src_bs + c;
 
-    uint64_t y[R][NSRC];
+    // mixed variant: the integer residues live in LDS (read back only for the few large destination moduli)
+    __shared__ uint64_t ylds[DSTF64 ? NSRC * R : 1][128];
+    uint64_t y[DSTF64 ? 1 : R][DSTF64 ? 1 : NSRC];   // integer variant
+    double yl[DSTF64 ? R : 1][DSTF64 ? NSRC : 1];      // double variant: y (or its low 26 bits)
+    double yh[DSTF64 ? R : 1][DSTF64 ? NSRC : 1];      //                 y >> 26 when split
     double vi[R];
     uint64_t neg[R];  // centred-copy path only
 #pragma unroll
@@ -1044,16 +1103,25 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
             for (int r = 0; r < R; r++) {
                 uint64_t cv = x[r];
                 neg[r] = cv >= (q >> 1);
-                y[r][i] = neg[r] ? q - cv : cv;
+                cv = neg[r] ? q - cv : cv;
+                if constexpr (DSTF64) ylds[i * R + r][threadIdx.x] = cv;
+                else y[r][i] = cv;
             }
         } else {
             const uint64_t h = D.src_half[i], ai = D.a[i];
             const double qf = __ull2double_rn(q);
+            const bool split = D.src_split[i] != 0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const uint64_t yi = mred(cred(x[r] + h, q), ai, q, qinv);
-                y[r][i] = yi;
                 vi[r] = __dadd_rn(vi[r], __ddiv_rn(__ull2double_rn(yi), qf));
+                if constexpr (DSTF64) {
+                    ylds[i * R + r][threadIdx.x] = yi;
+                    yl[r][i] = (double)(split ? (yi & ((1ull << 26) - 1)) : yi);
+                    yh[r][i] = (double)(split ? (yi >> 26) : 0ull);
+                } else {
+                    y[r][i] = yi;
+                }
             }
         }
     }
@@ -1065,50 +1133,106 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
         const int mi = D.dst_mod[j];
         const ModConst mp = A.mc[mi];
         const uint64_t p = mp.q, pinv = mp.qinv, twop = mp.q << 1;
-        uint64_t o[R];
-        if (D.single) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint64_t t = bred_add(y[r][0], p, mp.brc0);
-                o[r] = neg[r] ? p - t : t;
-            }
-        } else {
-            const int row = D.dst_row[j];
-            const uint64_t *Tr = D.T + (size_t)row * NSRC;
-            const uint64_t *vtr = D.vt + (size_t)row * (NSRC + 1);
-            const uint64_t hd = D.dst_half[j];
-            uint64_t Tv[NSRC];
-#pragma unroll
-            for (int i = 0; i < NSRC; i++) Tv[i] = Tr[i];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                u128 acc = (u128)y[r][0] * Tv[0];
-#pragma unroll
-                for (int i = 1; i < NSRC; i++) acc += (u128)y[r][i] * Tv[i];
-                uint64_t res = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p + vtr[v[r]];
-                res = cred(res + p - hd, p);
-                if (D.reduce_out) res = bred_add_lazy(res, p, mp.brc0);
-                o[r] = res;
-            }
-        }
-        if constexpr (LOGA > 0) {  // start the forward NTT: the LOGA strided stages
-            const uint64_t *tw = A.tw_fwd + (size_t)mi * A.N;
-            const bool nc = (p >> kNoCorrBits) == 0;
-#pragma unroll
-            for (int s = 0; s < LOGA; s++) {
-                const int d = 1 << (LOGA - 1 - s);
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    if (r & d) continue;
-                    if (nc) bfly_fwd_nc(o[r], o[r + d], tw[(1 << s) + (r >> (LOGA - s))], p, pinv);
-                    else bfly_fwd(o[r], o[r + d], tw[(1 << s) + (r >> (LOGA - s))], p, twop, pinv);
-                }
-            }
-        }
+        const bool small = (p >> kF64Bits) == 0;  // block-uniform
         uint64_t *dst = (D.dst_view[j] ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs)) + D.dst_off +
                         (size_t)D.dst_limb[j] * A.N + c;
+        // residue y_i of coefficient r as an integer (the mixed variant keeps them as doubles)
+        auto Y = [&](int r, int i) -> uint64_t {
+            if constexpr (DSTF64) return ylds[i * R + r][threadIdx.x];
+            else return y[r][i];
+        };
+        bool done = false;
+        if constexpr (DSTF64) if (small) {
+            done = true;
+            const double pd = (double)p, pid = 1.0 / pd;
+            double o[R];
+            if (D.single) {
 #pragma unroll
-        for (int r = 0; r < R; r++) dst[(size_t)r * N2] = o[r];
+                for (int r = 0; r < R; r++) {
+                    const uint64_t t = bred_add(ylds[r][threadIdx.x], p, mp.brc0);
+                    o[r] = (double)(neg[r] ? p - t : t);
+                }
+            } else {
+                const int row = D.dst_row[j];
+                const double *Tr = D.Td + (size_t)row * NSRC * 2;
+                const double *vtr = D.vtd + (size_t)row * (NSRC + 1);
+                const double hd = (double)D.dst_half[j];
+                double Tl[NSRC], Th[NSRC];
+#pragma unroll
+                for (int i = 0; i < NSRC; i++) { Tl[i] = Tr[2 * i]; Th[i] = Tr[2 * i + 1]; }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    double sacc = vtr[v[r]] - hd;
+#pragma unroll
+                    for (int i = 0; i < NSRC; i++) {
+                        sacc += modmul_f64(yl[r][i], Tl[i], pd, pid);
+                        if (D.src_split[i]) sacc += modmul_f64(yh[r][i], Th[i], pd, pid);
+                    }
+                    o[r] = sacc;  // |o| < (2 + 4*NSRC) p
+                }
+            }
+            if constexpr (LOGA > 0) {
+                const double *tw = A.twd_fwd + (size_t)mi * A.N;
+#pragma unroll
+                for (int s = 0; s < LOGA; s++) {
+                    const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (r & d) continue;
+                        const double t = modmul_f64(o[r + d], tw[(1 << s) + (r >> (LOGA - s))], pd, pid);
+                        const double U = o[r];
+                        o[r] = U + t;
+                        o[r + d] = U - t;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) dst[(size_t)r * N2] = (uint64_t)(reduce_f64(o[r], pd, pid) + pd);  // (0, 2p)
+        }
+        if (!done) {
+            uint64_t o[R];
+            if (D.single) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint64_t t = bred_add(Y(r, 0), p, mp.brc0);
+                    o[r] = neg[r] ? p - t : t;
+                }
+            } else {
+                const int row = D.dst_row[j];
+                const uint64_t *Tr = D.T + (size_t)row * NSRC;
+                const uint64_t *vtr = D.vt + (size_t)row * (NSRC + 1);
+                const uint64_t hd = D.dst_half[j];
+                uint64_t Tv[NSRC];
+#pragma unroll
+                for (int i = 0; i < NSRC; i++) Tv[i] = Tr[i];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    u128 acc = (u128)Y(r, 0) * Tv[0];
+#pragma unroll
+                    for (int i = 1; i < NSRC; i++) acc += (u128)Y(r, i) * Tv[i];
+                    uint64_t res = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p + vtr[v[r]];
+                    res = cred(res + p - hd, p);
+                    if (D.reduce_out) res = bred_add_lazy(res, p, mp.brc0);
+                    o[r] = res;
+                }
+            }
+            if constexpr (LOGA > 0) {  // start the forward NTT: the LOGA strided stages
+                const uint64_t *tw = A.tw_fwd + (size_t)mi * A.N;
+                const bool nc = (p >> kNoCorrBits) == 0;
+#pragma unroll
+                for (int s = 0; s < LOGA; s++) {
+                    const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (r & d) continue;
+                        if (nc) bfly_fwd_nc(o[r], o[r + d], tw[(1 << s) + (r >> (LOGA - s))], p, pinv);
+                        else bfly_fwd(o[r], o[r + d], tw[(1 << s) + (r >> (LOGA - s))], p, twop, pinv);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) dst[(size_t)r * N2] = o[r];
+        }
     }
 }
 
@@ -1117,19 +1241,9 @@ bool modup_fused_supported(int logN, int nsrc) {
     return nsrc >= 1 && nsrc <= 5 && (a == 0 || a == 2 || a == 3 || a == 4);
 }
 
-hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, View src, View dstA,
-                              View dstB, int batch, hipStream_t s) {
-    if (ndesc <= 0 || batch <= 0) return hipSuccess;
-    if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
-    const int a = r.logN > 12 ? r.logN - 12 : 0;
-    ModUpFusedArgs A;
-    A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
-    A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
-    A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.N = r.N;
-    const int n2 = r.N >> a;
-    dim3 grid((unsigned)((n2 + 127) / 128), ndesc, batch), block(128);
-    ProfScope ps(K_MODUP, s);
-#define HE_MF(NS, LA) hipLaunchKernelGGL((modup_fused_kernel<NS, LA>), grid, block, 0, s, A)
+template <bool F64>
+static void launch_modup_fused_variant(int a, int nsrc, dim3 grid, dim3 block, const ModUpFusedArgs &A, hipStream_t s) {
+#define HE_MF(NS, LA) hipLaunchKernelGGL((modup_fused_kernel<NS, LA, F64>), grid, block, 0, s, A)
 #define HE_MF_A(NS)                                  \
     switch (a) {                                     \
         case 0: HE_MF(NS, 0); break;                 \
@@ -1146,6 +1260,24 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
     }
 #undef HE_MF_A
 #undef HE_MF
+}
+
+hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
+                              View dstA, View dstB, int batch, hipStream_t s) {
+    if (ndesc <= 0 || batch <= 0) return hipSuccess;
+    if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
+    const int a = r.logN > 12 ? r.logN - 12 : 0;
+    ModUpFusedArgs A;
+    A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
+    A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
+    A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.twd_fwd = r.twd_fwd; A.N = r.N;
+    const bool use_f64 = (dst_classes & 2) && r.twd_fwd != nullptr;
+    A.skip_f64_dst = 0;
+    const int n2 = r.N >> a;
+    dim3 grid((unsigned)((n2 + 127) / 128), ndesc, batch), block(128);
+    ProfScope ps(K_MODUP, s);
+    if (use_f64) launch_modup_fused_variant<true>(a, nsrc, grid, block, A, s);   // mixed: f64 for small destinations
+    else launch_modup_fused_variant<false>(a, nsrc, grid, block, A, s);
     return hipGetLastError();
 }
 
