@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="independent ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="independent ciphertext pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--microbench", action="store_true", help="also print NTT/s and the modmul probe to stderr")
     args = ap.parse_args()
@@ -161,24 +161,43 @@ def main():
     total_ms = sum(v[1] for v in prof.values())
     dom = max(prof.items(), key=lambda kv: kv[1][1])
     dom_name, (dom_launches, dom_ms) = dom
-    # algorithmic bytes per launch of each kernel family in ONE MulRelin of B ciphertexts:
-    # what the kernel must read + write once (twiddles / constants excluded, resident)
-    nonown = beta * (L + alpha) - L                # limbs that get a forward NTT in DecomposeNTT
+    # algorithmic bytes per step of each kernel family (what the kernel must read + write once for B
+    # ciphertexts; twiddles / constants excluded, resident).  Limbs below 2^47 run the double-precision row
+    # kernels ("*_f64"), the others the 64-bit integer ones.
+    nonown = beta * (L + alpha) - L                # limbs written by the decomposition
+    small_q = [m < (1 << 47) for m in q]
+    small_p = [m < (1 << 47) for m in p]
+    dec_small = dec_big = 0                        # forward row passes of DecomposeNTT (non-own limbs)
+    for d in range(beta):
+        for l in range(L):
+            if not (d * alpha <= l < (d + 1) * alpha):
+                dec_small, dec_big = dec_small + small_q[l], dec_big + (not small_q[l])
+        dec_small, dec_big = dec_small + sum(small_p), dec_big + (alpha - sum(small_p))
+    nsq, nsp = sum(small_q), sum(small_p)
     per_step_bytes = {
-        "ntt_rows_fwd": 2 * (nonown + 2 * L) * limb * B,        # decomposition NTTs + 2 ModDown NTTs
-        "ntt_cols_fwd": 2 * (nonown + 2 * L) * limb * B,
-        "ntt_rows_inv": 2 * (L + 2 * alpha) * limb * B,         # INTT(c2) + 2 ModDown INTT(P)
-        "ntt_cols_inv": 2 * (L + 2 * alpha) * limb * B,
+        # decomposition NTTs (in + out) + ModDown NTTs of both components with the fused epilogue (in, acc, add, out)
+        "ntt_rows_fwd_f64": (2 * dec_small + 4 * 2 * nsq) * limb * B,
+        "ntt_rows_fwd": (2 * dec_big + 4 * 2 * (L - nsq)) * limb * B,
+        # INTT(c2) + INTT of the P part of both accumulators
+        "ntt_rows_inv_f64": 2 * (nsq + 2 * nsp) * limb * B,
+        "ntt_rows_inv": 2 * ((L - nsq) + 2 * (alpha - nsp)) * limb * B,
         "ks_inner": (beta * (L + alpha) * B + 2 * beta * (L + alpha) + 2 * (L + alpha) * B) * limb,
         "tensor": 7 * L * limb * B,
-        "modup": (beta * ((L + alpha)) + 2 * (alpha + L)) * limb * B,
-        "ew": (L * B + 2 * 3 * L * B + 2 * 3 * L * B) * limb,  # own-limb copies, ModDown sub-mul, final adds
+        # fused basis extension: decomposition (L in, beta*(L+alpha)-L out) + ModDown (2*alpha in, 2*L out)
+        "modup": (L + nonown + 2 * alpha + 2 * L) * limb * B,
     }
     dom_bytes_launch = per_step_bytes.get(dom_name, 0) * args.steps / max(dom_launches, 1)
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     achieved = dom_bytes_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+    traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 + WRITE_SIZE)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pmc.get("batch") == B and dom_name in pmc.get("kernels", {}):
+            traffic = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": dom_avg_ms, "launches": dom_launches,
                 "alg_bytes_per_launch": dom_bytes_launch,
                 "whole_op": {"alg_bytes_per_op": alg_bytes_op, "achieved_GBs": alg_bytes_op * value / world / 1e9,

@@ -198,7 +198,8 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
 // ---- per-kernel HIP-event profiling (diagnostics: bench.py's roofline leg) --------------------
 enum KernelId {
     K_NTT_COLS_FWD = 0, K_NTT_ROWS_FWD, K_NTT_ROWS_INV, K_NTT_COLS_INV, K_EW, K_GATHER, K_AUTO_COEFF, K_INDEX,
-    K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_CI_FOLD, K_MASK_SPREAD, K_COUNT
+    K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_CI_FOLD, K_MASK_SPREAD, K_NTT_ROWS_FWD_F64, K_NTT_ROWS_INV_F64,
+    K_COUNT
 };
 const char *kernel_name(int id);
 void prof_begin();                                   // start recording (one stream at a time)

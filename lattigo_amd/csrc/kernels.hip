@@ -46,7 +46,8 @@ struct ProfScope {
 const char *kernel_name(int id) {
     static const char *names[K_COUNT] = {"ntt_cols_fwd", "ntt_rows_fwd", "ntt_rows_inv", "ntt_cols_inv", "ew", "gather",
                                          "automorphism_coeff", "build_index", "modup", "center_copy", "ks_inner",
-                                         "tensor", "modmul_probe", "ci_fold", "mask_spread"};
+                                         "tensor", "modmul_probe", "ci_fold", "mask_spread", "ntt_rows_fwd_f64",
+                                         "ntt_rows_inv_f64"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 void prof_begin() { g_prof_recs.clear(); g_prof_on = true; }
@@ -554,7 +555,7 @@ template <bool INV>
 static hipError_t launch_rows_f64(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
 #define HE_ROWSF_CASE(B)                                                                          \
     case B:                                                                                       \
-        { ProfScope ps(INV ? K_NTT_ROWS_INV : K_NTT_ROWS_FWD, s);                                   \
+        { ProfScope ps(INV ? K_NTT_ROWS_INV_F64 : K_NTT_ROWS_FWD_F64, s);                           \
         hipLaunchKernelGGL((ntt_rows_f64_kernel<B, INV>), grid, dim3((1 << B) / 16), 0, s, A); }   \
         break;
     switch (logb) {
