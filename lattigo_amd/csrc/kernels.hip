@@ -130,6 +130,11 @@ struct NttArgs {
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
 
+// N = 2^n is split into a strided "column" stages and b contiguous "row" stages: rows of 4096 coefficients
+// (b = 12) up to logN = 15, rows of 8192 (b = 13, two 512-thread workgroups per CU) from logN = 16 so that the
+// fused basis extension never holds more than 8 strided coefficients per thread.
+static inline int ntt_row_bits(int n) { return n <= 12 ? n : (n <= 15 ? 12 : 13); }
+
 // ------------------------------------------------------------------------------------
 // ntt_rows: b = LOGB stages on one contiguous row of 2^LOGB coefficients per workgroup.
 // grid = (rows per limb = 2^a, limbs, batch), block = 2^LOGB / 16 threads.
@@ -545,7 +550,7 @@ static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStrea
         break;
     switch (logb) {
         HE_ROWS_CASE(4) HE_ROWS_CASE(5) HE_ROWS_CASE(6) HE_ROWS_CASE(7) HE_ROWS_CASE(8) HE_ROWS_CASE(9)
-        HE_ROWS_CASE(10) HE_ROWS_CASE(11) HE_ROWS_CASE(12)
+        HE_ROWS_CASE(10) HE_ROWS_CASE(11) HE_ROWS_CASE(12) HE_ROWS_CASE(13)
         default: return hipErrorInvalidValue;
     }
 #undef HE_ROWS_CASE
@@ -560,7 +565,7 @@ static hipError_t launch_rows_f64(int logb, dim3 grid, const NttArgs &A, hipStre
         break;
     switch (logb) {
         HE_ROWSF_CASE(4) HE_ROWSF_CASE(5) HE_ROWSF_CASE(6) HE_ROWSF_CASE(7) HE_ROWSF_CASE(8) HE_ROWSF_CASE(9)
-        HE_ROWSF_CASE(10) HE_ROWSF_CASE(11) HE_ROWSF_CASE(12)
+        HE_ROWSF_CASE(10) HE_ROWSF_CASE(11) HE_ROWSF_CASE(12) HE_ROWSF_CASE(13)
         default: return hipErrorInvalidValue;
     }
 #undef HE_ROWSF_CASE
@@ -610,7 +615,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     const int n = r.logN;
     if (n < 4 || n > 17) return hipErrorInvalidValue;
-    const int a = n > 12 ? n - 12 : 0, b = n - a;
+    const int b = ntt_row_bits(n), a = n - b;
     NttArgs A;
     A.mc = r.mc;
     A.N = r.N;
@@ -663,7 +668,7 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     const int n = r.logN;
     if (n < 4 || n > 17) return hipErrorInvalidValue;
     if (epi && inverse) return hipErrorInvalidValue;
-    const int a = n > 12 ? n - 12 : 0, b = n - a;
+    const int b = ntt_row_bits(n), a = n - b;
     NttArgs A;
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
@@ -1238,7 +1243,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
 }
 
 bool modup_fused_supported(int logN, int nsrc) {
-    const int a = logN > 12 ? logN - 12 : 0;
+    const int a = logN - ntt_row_bits(logN);
     return nsrc >= 1 && nsrc <= 5 && (a == 0 || a == 2 || a == 3 || a == 4);
 }
 
@@ -1267,7 +1272,7 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
                               View dstA, View dstB, int batch, hipStream_t s) {
     if (ndesc <= 0 || batch <= 0) return hipSuccess;
     if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
-    const int a = r.logN > 12 ? r.logN - 12 : 0;
+    const int a = r.logN - ntt_row_bits(r.logN);
     ModUpFusedArgs A;
     A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
