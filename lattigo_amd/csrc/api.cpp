@@ -258,12 +258,14 @@ struct Evk : Obj {
     int beta = 0, nQk = 0, nPk = 0;
     int pw2 = 0;                 // BaseTwoDecomposition
     std::vector<int> nj, prefix; // bit windows per RNS digit and their prefix sums (pw2 != 0)
+    double *keyd = nullptr;      // plain key words as doubles for the limbs below 2^47 (fused NTT+MAC kernel), same layout
     uint64_t *d = nullptr;
     Evk() : Obj(T_EVK) {}
     ~Evk() override {
         hipSetDevice(ev->be->ctx->dev);
         hipStreamSynchronize(ev->be->ctx->stream);
         if (d) hipFree(d);
+        if (keyd) hipFree(keyd);
     }
 };
 
@@ -1143,6 +1145,16 @@ static int evk_create_common(he_handle hev, int beta, int nQk, int nPk, const ui
             HIP_TRY(hipMemcpyAsync(dst, q + ((size_t)d * 2 + kk) * nQk * N, (size_t)nQk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
             HIP_TRY(hipMemcpyAsync(dst + (size_t)nQk * N, p + ((size_t)d * 2 + kk) * nPk * N, (size_t)nPk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
         }
+    {   // double-precision copy for the fused NTT+MAC kernel, when some key limb is below 2^47
+        bool any = false;
+        uint8_t mods[kMaxLimbs];
+        for (int i = 0; i < nQk; i++) { mods[i] = (uint8_t)i; any = any || be.small[i] == 2; }
+        for (int i = 0; i < nPk; i++) { mods[nQk + i] = (uint8_t)(be.LQ + i); any = any || be.small[be.LQ + i] == 2; }
+        if (any && be.d_twdf && pw2 == 0) {
+            HIP_TRY(hipMalloc((void **)&k->keyd, (size_t)beta * 2 * blk * 8));
+            HIP_TRY(launch_key_to_f64(be.qp, k->d, k->keyd, beta * 2, mods, nQk + nPk, be.ctx->stream));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(be.ctx->stream));
     *out = reg(k);
     return HE_OK;
@@ -1248,8 +1260,9 @@ int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2n
 }
 
 // inner product of a decomposition with a key (gadgetProductMultiplePLazyHoisted :401-453)
+// limb_filter: 0 = every limb, 1 = only limbs NOT of class 2 (the fused f64 NTT+MAC kernel takes the others)
 int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View o0Q,
-             View o0P, View o1Q, View o1P, int batch, const View *own = nullptr, int own_alpha = 0) {
+             View o0P, View o1Q, View o1P, int batch, const View *own = nullptr, int own_alpha = 0, int limb_filter = 0) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     KsArgs a{};
@@ -1257,9 +1270,11 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
     if (a.beta > k.beta) return fail(HE_EINVAL, "gadget product: key has %d digits, %d needed", k.beta, a.beta);
     int n = 0;
     for (int j = 0; j <= levelQ; j++) {
+        if (limb_filter == 1 && be.small[j] == 2) continue;
         a.dec_limb[n] = (uint8_t)j; a.key_limb[n] = (uint8_t)j; a.out_limb[n] = (uint8_t)j; a.out_view[n] = 0; a.mod[n] = (uint8_t)j; n++;
     }
     for (int j = 0; j <= levelP; j++) {
+        if (limb_filter == 1 && be.small[LQ + j] == 2) continue;
         a.dec_limb[n] = (uint8_t)(LQ + j); a.key_limb[n] = (uint8_t)(k.nQk + j); a.out_limb[n] = (uint8_t)j; a.out_view[n] = 1;
         a.mod[n] = (uint8_t)(LQ + j); n++;
     }
@@ -1385,7 +1400,8 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
     return HE_OK;
 }
 // forward ROWS pass over every non-own limb of every digit block of a decomposition
-int dec_rows_ntt(Evaluator &ev, int levelQ, int levelP, int nbPi, uint64_t *dec, size_t dec_bs, int batch) {
+// limb_filter 1: skip the class-2 limbs (their transform is fused into launch_ntt_mac_f64)
+int dec_rows_ntt(Evaluator &ev, int levelQ, int levelP, int nbPi, uint64_t *dec, size_t dec_bs, int batch, int limb_filter = 0) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, width = be.LQ + be.LP;
     const int beta = base_rns_size(levelQ, levelP);
@@ -1403,6 +1419,7 @@ int dec_rows_ntt(Evaluator &ev, int levelQ, int levelP, int nbPi, uint64_t *dec,
             const bool isP = j > levelQ;
             const int limb = isP ? LQ + (j - levelQ - 1) : j;
             if (!isP && j >= st && j < ed) continue;
+            if (limb_filter == 1 && be.small[limb] == 2) continue;
             t.in_limb[t.n] = t.out_limb[t.n] = (uint8_t)(d * width + limb);
             t.mod[t.n] = (uint8_t)limb;
             if (++t.n == kMaxLimbs) TRY(flush());
@@ -1430,7 +1447,7 @@ size_t ks_scratch_words(const BasisExtender &be, int levelQ, int levelP, int bat
 
 namespace {
 int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, uint64_t *dec,
-                    size_t dec_bs, int batch);
+                    size_t dec_bs, int batch, int ntt_filter = 0);
 }
 int he_decompose_and_split(he_handle hev, int levelQ, int levelP, int nbPi, int digit, he_handle h0, he_handle h1q, he_handle h1p) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -1535,12 +1552,39 @@ int get_qp_out(he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, const
 // DecomposeNTT through the fused kernels: `rows_inv` = inverse ROWS pass of the NTT-domain input.
 // Own limbs are NOT written (ks_inner reads them from the input; he_decompose_ntt copies them).
 int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, uint64_t *dec,
-                    size_t dec_bs, int batch) {
+                    size_t dec_bs, int batch, int ntt_filter) {
     BasisExtender &be = *ev.be;
     const View dv{dec, dec_bs};
     for (const FusedGroup &g : plan.groups)
         HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, g.dst_classes, rows_inv, dv, dv, batch, be.ctx->stream));
-    return dec_rows_ntt(ev, levelQ, levelP, nbPi, dec, dec_bs, batch);
+    return dec_rows_ntt(ev, levelQ, levelP, nbPi, dec, dec_bs, batch, ntt_filter);
+}
+// class-2 limbs of the gadget product: forward row NTT + key MAC in one kernel (dec holds the post-column state)
+int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View cx,
+               int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch) {
+    BasisExtender &be = *ev.be;
+    const int LQ = be.LQ, N = be.Q->N;
+    NttMacArgs a{};
+    a.beta = base_rns_size(levelQ, levelP);
+    int n = 0;
+    for (int j = 0; j <= levelQ; j++) {
+        if (be.small[j] != 2) continue;
+        a.dec_limb[n] = (uint8_t)j; a.key_limb[n] = (uint8_t)j; a.out_limb[n] = (uint8_t)j; a.out_view[n] = 0; a.mod[n] = (uint8_t)j; n++;
+    }
+    for (int j = 0; j <= levelP; j++) {
+        if (be.small[LQ + j] != 2) continue;
+        a.dec_limb[n] = (uint8_t)(LQ + j); a.key_limb[n] = (uint8_t)(k.nQk + j); a.out_limb[n] = (uint8_t)j; a.out_view[n] = 1;
+        a.mod[n] = (uint8_t)(LQ + j); n++;
+    }
+    a.nlimbs = n;
+    a.dec_dstride = dec_ds;
+    a.key_kstride = (size_t)(k.nQk + k.nPk) * N;
+    a.key_dstride = 2 * a.key_kstride;
+    a.own_alpha = own_alpha;
+    a.own_nq = levelQ + 1;
+    HIP_TRY(launch_ntt_mac_f64(be.qp, a, View{const_cast<uint64_t *>(dec), dec_bs}, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch,
+                               be.ctx->stream));
+    return HE_OK;
 }
 
 // GadgetProductLazy core: cx (NTT) -> accumulators (views).  Scratch from the arena.
@@ -1579,6 +1623,11 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
     TRY(get_dec_plan(ev, levelQ, levelP, levelP + 1, &plan));
     if (plan->ok) {
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+        if (k.keyd) {  // limbs below 2^47: NTT + MAC fused; the rest: row NTT then ks_inner
+            TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B, 1));
+            TRY(ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
+            return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B);
+        }
         TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B));
         return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
     }

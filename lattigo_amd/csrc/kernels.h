@@ -189,6 +189,22 @@ struct KsArgs {
 hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
                            View out0P, View out1Q, View out1P, int batch, hipStream_t s);
 
+// Fused "forward row NTT + key multiply-accumulate" for limbs below 2^47 (double-precision path): one workgroup
+// owns (row, limb, batch entry) and loops over the beta digits; every non-own digit's row is transformed in LDS and
+// multiplied by the two key rows straight out of LDS, the own digit's row is read from the NTT-domain input, the two
+// accumulators stay in registers and are written once.  The transformed decomposition never goes to HBM.
+struct NttMacArgs {
+    int beta, nlimbs;
+    uint8_t dec_limb[kMaxLimbs], key_limb[kMaxLimbs], out_limb[kMaxLimbs], out_view[kMaxLimbs], mod[kMaxLimbs];
+    size_t dec_dstride, key_kstride, key_dstride;
+    int own_alpha, own_nq;
+};
+hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
+                              View out0P, View out1Q, View out1P, int batch, hipStream_t s);
+// keyd[i] = (double)IMForm(key[i]) for the limbs of class 2 (plain residues < 2^47), 0 elsewhere
+hipError_t launch_key_to_f64(const RingDev &r, const uint64_t *key, double *keyd, int nblocks, const uint8_t *limb_mod_host,
+                             int nlimbs, hipStream_t s);
+
 // ---- ciphertext tensor product (schemes/ckks/evaluator.go:807-820, schemes/bgv/evaluator.go:634-647)
 // c0 = MRed(MRed(a0,s),b0), c2 = MRed(MRed(a1,s),b1), c1 = CRed(MRed(MRed(a0,s),b1) + MRed(MRed(a1,s),b0))
 // with the per-limb scalar s = 2^128 mod q (CKKS: MForm) or t*2^128 mod q (BGV: tMontgomery).
@@ -199,7 +215,7 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
 enum KernelId {
     K_NTT_COLS_FWD = 0, K_NTT_ROWS_FWD, K_NTT_ROWS_INV, K_NTT_COLS_INV, K_EW, K_GATHER, K_AUTO_COEFF, K_INDEX,
     K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_CI_FOLD, K_MASK_SPREAD, K_NTT_ROWS_FWD_F64, K_NTT_ROWS_INV_F64,
-    K_COUNT
+    K_NTT_MAC_F64, K_COUNT
 };
 const char *kernel_name(int id);
 void prof_begin();                                   // start recording (one stream at a time)

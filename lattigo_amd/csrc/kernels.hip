@@ -47,7 +47,7 @@ const char *kernel_name(int id) {
     static const char *names[K_COUNT] = {"ntt_cols_fwd", "ntt_rows_fwd", "ntt_rows_inv", "ntt_cols_inv", "ew", "gather",
                                          "automorphism_coeff", "build_index", "modup", "center_copy", "ks_inner",
                                          "tensor", "modmul_probe", "ci_fold", "mask_spread", "ntt_rows_fwd_f64",
-                                         "ntt_rows_inv_f64"};
+                                         "ntt_rows_inv_f64", "ntt_mac_f64"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 void prof_begin() { g_prof_recs.clear(); g_prof_on = true; }
@@ -212,15 +212,18 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     constexpr int GREM = LOGB % 4;      // stages of the trailing partial round (test sizes only)
     __shared__ uint64_t lds[N2 + N2 / 16];
 
+    // grid = (batch, limbs, rows): the batch index varies fastest so that the workgroups sharing a twiddle row
+    // (same limb and row) are dispatched together and hit it in L2
     const int tau = threadIdx.x;
-    const int row = blockIdx.x;
+    const int row = blockIdx.z;
+    const unsigned bzi = blockIdx.x;
     const int y = blockIdx.y;
     const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
     const ModConst mc = A.mc[mi];
     const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
     const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
-    const uint64_t *__restrict__ src = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
-    uint64_t *__restrict__ dst = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
+    const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
+    uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
     const int rowtw = (1 << A.a) + row;  // 2^a + r
 
     uint64_t x[16];
@@ -256,8 +259,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             if constexpr (NC) v = bred_add_lazy(v, q, mc.brc0);  // [0, 36q) -> [0, 2q)
             else v = v >= twoq ? v - twoq : v;
             if (A.epi) {
-                const bool second = A.zsplit && (int)blockIdx.z >= A.zsplit;
-                const size_t zz = second ? blockIdx.z - A.zsplit : blockIdx.z;
+                const bool second = A.zsplit && (int)bzi >= A.zsplit;
+                const size_t zz = second ? bzi - A.zsplit : bzi;
                 const size_t off = (size_t)ol * A.N + (size_t)row * N2 + e;
                 const uint64_t yv = second ? A.epi_y2[zz * A.epi_y2_bs + off] : A.epi_y[zz * A.epi_y_bs + off];
                 v = mred(v + twoq - yv, A.epi_s[y], q, qinv);
@@ -393,14 +396,15 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     __shared__ double lds[N2 + N2 / 16];
 
     const int tau = threadIdx.x;
-    const int row = blockIdx.x;
+    const int row = blockIdx.z;
+    const unsigned bzi = blockIdx.x;
     const int y = blockIdx.y;
     const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
     const ModConst mc = A.mc[mi];
     const double q = (double)mc.q, qi = 1.0 / q;
     const double *__restrict__ tw = A.twd + (size_t)mi * A.N;
-    const uint64_t *__restrict__ src = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
-    uint64_t *__restrict__ dst = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
+    const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
+    uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
     const int rowtw = (1 << A.a) + row;
 
     double x[16];
@@ -432,8 +436,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             const int e = k * T + tau;
             uint64_t v = canon_f64(lds[lds_phys(e)], q, qi);
             if (A.epi) {
-                const bool second = A.zsplit && (int)blockIdx.z >= A.zsplit;
-                const size_t zz = second ? blockIdx.z - A.zsplit : blockIdx.z;
+                const bool second = A.zsplit && (int)bzi >= A.zsplit;
+                const size_t zz = second ? bzi - A.zsplit : bzi;
                 const size_t off = (size_t)ol * A.N + (size_t)row * N2 + e;
                 const uint64_t yv = second ? A.epi_y2[zz * A.epi_y2_bs + off] : A.epi_y[zz * A.epi_y_bs + off];
                 v = mred(v + (mc.q << 1) - yv, A.epi_s[y], mc.q, mc.qinv);
@@ -481,6 +485,143 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
         for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = canon_f64(x[k], q, qi);
     }
+}
+
+// ------------------------------------------------------------------------------------
+// ntt_mac_f64: forward row NTT of every non-own digit fused with the key-switch inner product (see kernels.h)
+// ------------------------------------------------------------------------------------
+struct NttMacKArgs {
+    const uint64_t *dec, *own;
+    size_t dec_bs, own_bs;
+    const double *keyd;
+    uint64_t *o0Q, *o0P, *o1Q, *o1P;
+    size_t oQ0_bs, oP0_bs, oQ1_bs, oP1_bs;
+    const ModConst *mc;
+    const double *twd;
+    int N, a;
+    NttMacArgs m;
+};
+template <int LOGB>
+__global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) ntt_mac_f64_kernel(NttMacKArgs A) {
+    constexpr int N2 = 1 << LOGB;
+    constexpr int T = N2 / 16;
+    constexpr int NR4 = LOGB / 4;
+    constexpr int GREM = LOGB % 4;
+    __shared__ double lds[N2 + N2 / 16];
+
+    const int tau = threadIdx.x;
+    const int row = blockIdx.z;
+    const int l = blockIdx.y;
+    const size_t bz = blockIdx.x;  // batch fastest: workgroups sharing the key / twiddle rows run together
+    const int mi = A.m.mod[l];
+    const ModConst mc = A.mc[mi];
+    const double q = (double)mc.q, qi = 1.0 / q;
+    const double *__restrict__ tw = A.twd + (size_t)mi * A.N;
+    const int rowtw = (1 << A.a) + row;
+    const size_t rowoff = (size_t)row * N2;
+    const double *kbase = A.keyd + (size_t)A.m.key_limb[l] * A.N + rowoff;
+    const int ql = A.m.dec_limb[l];  // Q-limb index when l < own_nq
+
+    double acc0[16], acc1[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { acc0[k] = 0.0; acc1[k] = 0.0; }
+
+    for (int d = 0; d < A.m.beta; d++) {
+        const bool is_own = A.m.own_alpha > 0 && A.m.out_view[l] == 0 && ql >= d * A.m.own_alpha && ql < (d + 1) * A.m.own_alpha;
+        double x[16];
+        if (is_own) {  // block-uniform: the digit's own limb is the NTT-domain input itself
+            const uint64_t *src = A.own + bz * A.own_bs + (size_t)ql * A.N + rowoff;
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = (double)src[k * T + tau];
+        } else {
+            const uint64_t *src = A.dec + bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)A.m.dec_limb[l] * A.N + rowoff;
+            constexpr int sh0 = LOGB - 4;
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = (double)src[(k << sh0) + tau];
+#pragma unroll 1
+            for (int rho = 0; rho < NR4; rho++) {
+                const int s0 = 4 * rho, sh = LOGB - s0 - 4;
+                if (rho > 0) rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, false);
+                rows_round_f64<4, false>(x, tw, rowtw, s0, tau >> sh, tau, sh, q, qi);
+                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, true);
+                __syncthreads();
+            }
+            if constexpr (GREM > 0) {
+                constexpr int s0 = 4 * NR4;
+                rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, s0, 0, false);
+                rows_round_f64<GREM, false>(x, tw, rowtw, s0, 0, tau, 0, q, qi);
+                rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, s0, 0, true);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = lds[lds_phys(k * T + tau)];
+        }
+        const double *k0 = kbase + (size_t)d * A.m.key_dstride, *k1 = k0 + A.m.key_kstride;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const double v = x[k];
+            acc0[k] += modmul_f64(v, k0[k * T + tau], q, qi);
+            acc1[k] += modmul_f64(v, k1[k * T + tau], q, qi);
+        }
+        __syncthreads();  // LDS is reused by the next digit
+    }
+    const int ol = A.m.out_limb[l];
+    const bool isP = A.m.out_view[l] != 0;
+    uint64_t *o0 = (isP ? A.o0P + bz * A.oP0_bs : A.o0Q + bz * A.oQ0_bs) + (size_t)ol * A.N + rowoff;
+    uint64_t *o1 = (isP ? A.o1P + bz * A.oP1_bs : A.o1Q + bz * A.oQ1_bs) + (size_t)ol * A.N + rowoff;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        o0[k * T + tau] = canon_f64(acc0[k], q, qi);
+        o1[k * T + tau] = canon_f64(acc1[k], q, qi);
+    }
+}
+
+hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
+                              View out0P, View out1Q, View out1P, int batch, hipStream_t s) {
+    if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
+    if (!r.twd_fwd || !keyd) return hipErrorInvalidValue;
+    const int b = ntt_row_bits(r.logN), aa = r.logN - b;
+    NttMacKArgs A;
+    A.dec = dec.p; A.dec_bs = dec.bstride; A.own = own.p; A.own_bs = own.bstride; A.keyd = keyd;
+    A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
+    A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
+    A.mc = r.mc; A.twd = r.twd_fwd; A.N = r.N; A.a = aa; A.m = a;
+    dim3 grid(batch, a.nlimbs, 1u << aa);
+    ProfScope ps(K_NTT_MAC_F64, s);
+#define HE_MAC_CASE(B) \
+    case B: hipLaunchKernelGGL((ntt_mac_f64_kernel<B>), grid, dim3((1 << B) / 16), 0, s, A); break;
+    switch (b) {
+        HE_MAC_CASE(4) HE_MAC_CASE(5) HE_MAC_CASE(6) HE_MAC_CASE(7) HE_MAC_CASE(8) HE_MAC_CASE(9) HE_MAC_CASE(10)
+        HE_MAC_CASE(11) HE_MAC_CASE(12) HE_MAC_CASE(13)
+        default: return hipErrorInvalidValue;
+    }
+#undef HE_MAC_CASE
+    return hipGetLastError();
+}
+
+struct KeyF64Args {
+    const uint64_t *key;
+    double *keyd;
+    const ModConst *mc;
+    int N, nlimbs;
+    uint8_t mod[kMaxLimbs];
+};
+__global__ void __launch_bounds__(256) key_to_f64_kernel(KeyF64Args A) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= A.N) return;
+    const int l = blockIdx.y;
+    const size_t off = ((size_t)blockIdx.z * A.nlimbs + l) * A.N + x;
+    const ModConst m = A.mc[A.mod[l]];
+    A.keyd[off] = (m.q >> kF64Bits) == 0 ? (double)imform(A.key[off], m.q, m.qinv) : 0.0;
+}
+hipError_t launch_key_to_f64(const RingDev &r, const uint64_t *key, double *keyd, int nblocks, const uint8_t *limb_mod_host,
+                             int nlimbs, hipStream_t s) {
+    KeyF64Args A;
+    A.key = key; A.keyd = keyd; A.mc = r.mc; A.N = r.N; A.nlimbs = nlimbs;
+    for (int i = 0; i < nlimbs; i++) A.mod[i] = limb_mod_host[i];
+    dim3 grid((unsigned)((r.N + 255) / 256), nlimbs, nblocks), block(256);
+    hipLaunchKernelGGL(key_to_f64_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------
@@ -623,7 +764,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     A.tab = tab;
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
-    dim3 grows(1u << a, tab.n, batch);
+    dim3 grows(batch, tab.n, 1u << a);
     dim3 gcols((unsigned)(((r.N >> a) + 255) / 256), tab.n, batch);
     hipError_t e;
     if (!inverse) {
@@ -687,7 +828,7 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     }
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = flags;
-    dim3 grows(1u << a, tab.n, batch);
+    dim3 grows(batch, tab.n, 1u << a);
     if (!inverse) { A.tw = r.tw_fwd; A.twd = r.twd_fwd; A.scale = 0; return launch_rows<false>(b, grows, A, r.host_small, s); }
     A.tw = r.tw_inv; A.twd = r.twd_inv; A.scale = (a == 0);
     return launch_rows<true>(b, grows, A, r.host_small, s);
@@ -1386,12 +1527,13 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
     for (int b = 0; b < BB; b++) { hi0[b] = lo0[b] = hi1[b] = lo1[b] = 0; }
     const uint64_t *kp = A.key + (size_t)A.k.key_limb[l] * A.N + x;
     const uint64_t *dp = A.dec + (size_t)A.k.dec_limb[l] * A.N + x;
-    const uint64_t *op = A.own + (size_t)l * A.N + x;
+    const uint64_t *op = A.own + (size_t)A.k.dec_limb[l] * A.N + x;
     for (int d = 0; d < A.k.beta; d++) {
         const uint64_t k0 = kp[(size_t)d * A.k.key_dstride];
         const uint64_t k1 = kp[(size_t)d * A.k.key_dstride + A.k.key_kstride];
         // the digit's own Q limbs come from the NTT-domain input itself (block-uniform branch)
-        const bool is_own = A.k.own_alpha > 0 && l < A.k.own_nq && l >= d * A.k.own_alpha && l < (d + 1) * A.k.own_alpha;
+        const int ql = A.k.dec_limb[l];  // Q-limb index for Q limbs
+        const bool is_own = A.k.own_alpha > 0 && A.k.out_view[l] == 0 && ql >= d * A.k.own_alpha && ql < (d + 1) * A.k.own_alpha;
 #pragma unroll
         for (int b = 0; b < BB; b++) {
             if (b0 + b < A.batch) {

@@ -347,3 +347,39 @@ def test_base2_gadget_product(ctx, pw2):
         assert noise <= 11 + pw2 + 6, noise
     with pytest.raises(la.HeringError):  # hoisted forms reject base-2 keys, as the reference (:381-383)
         gev.GadgetProductHoisted(3, la.Decomposition(gev, 2), gevk, ct)
+
+
+@pytest.mark.parametrize("logN", [9, 10, 12, 13])
+def test_mixed_modulus_sizes_all_kernel_classes(ctx, logN):
+    """Chains mixing moduli below 2^47 (double-precision kernels, fused NTT+MAC), below 2^58 (correction-free
+    integer butterflies) and 60/61-bit ones (Harvey form), in Q and in P: every class must give the oracle's bits."""
+    q, p = O.GenModuli(logN + 1, [55, 40, 61, 45, 40, 60, 36], [40, 60, 46])
+    pr = Pair(ctx, logN, len(q), len(p), qmods=q, pmods=p)
+    rng = rng_for(2700 + logN)
+    gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+    sk = SecretKey(rng, pr.oQ, pr.oP)
+    sk2 = SecretKey(rng, pr.oQ, pr.oP)
+    oevk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, sk2)
+    gevk = gev.NewEvaluationKey(oevk.q, oevk.p)
+    for levelQ in (6, 5, 3):
+        Qm = q[: levelQ + 1]
+        cx = np.stack([uniform_poly(rng, Qm, pr.N) for _ in range(3)])
+        pcx = la.Poly(pr.gQ, levelQ + 1, 3).upload(cx)
+        x = la.Poly(pr.gQ, levelQ + 1, 3)
+        pr.gQ.AtLevel(levelQ).NTT(pcx, x)
+        sub = O.Ring(pr.N, Qm)
+        assert np.array_equal(x.get()[2], sub.NTT(cx[2]))
+        pr.gQ.AtLevel(levelQ).INTT(x, x)
+        assert np.array_equal(x.get(), cx)
+        qp = [(la.Poly(pr.gQ, levelQ + 1, 3), la.Poly(pr.gP, 3, 3)) for _ in range(2)]
+        gev.GadgetProductLazy(levelQ, pcx, gevk, qp)
+        wQ, wP = oev.GadgetProductLazy(levelQ, cx[1], oevk)
+        for k in range(2):
+            assert np.array_equal(qp[k][0].get()[1], wQ[k]) and np.array_equal(qp[k][1].get()[1], wP[k]), (levelQ, k)
+        ct = [la.Poly(pr.gQ, levelQ + 1, 3), la.Poly(pr.gQ, levelQ + 1, 3)]
+        gev.GadgetProduct(levelQ, pcx, gevk, ct)
+        want = oev.GadgetProduct(levelQ, cx[0], oevk)
+        got = np.stack([c.get()[0] for c in ct])
+        assert np.array_equal(got, want), levelQ
+        noise = noise_log2(pr.oQ, sub.binop("Sub", phase(pr.oQ, got, sk2.Q), sub.binop("MulCoeffsMontgomery", cx[0], sk.Q[: levelQ + 1])))
+        assert noise <= logN + 8, noise
