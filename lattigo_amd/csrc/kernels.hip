@@ -1196,9 +1196,9 @@ struct ModUpFusedArgs {
     size_t src_bs, dstA_bs, dstB_bs;
     const ModConst *mc;
     const uint64_t *tw_fwd, *tw_inv;
-    const double *twd_fwd;
+    const double *twd_fwd, *twd_inv;
     int N;
-    int skip_f64_dst;  // integer variant: leave destination moduli below 2^47 to the double-precision variant
+    int skip_f64_dst;  // unused (kept for layout stability)
 };
 
 // DSTF64 = false: destinations in 64-bit integer arithmetic (any modulus).
@@ -1231,7 +1231,33 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
         uint64_t x[R];
 #pragma unroll
         for (int r = 0; r < R; r++) x[r] = src[(size_t)D.src_limb[i] * A.N + (size_t)r * N2];
-        if constexpr (LOGA > 0) {  // finish the inverse NTT: the LOGA strided stages, N^-1 folded into the last
+        const bool src_small = DSTF64 && (q >> kF64Bits) == 0 && A.twd_inv != nullptr;  // block-uniform
+        if (src_small) {
+            // source modulus below 2^47: the inverse column stages, N^-1 and y_i = x*c_i in exact double arithmetic
+            const double qd = (double)q, qid = 1.0 / qd;
+            double xd[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) xd[r] = (double)x[r];
+            if constexpr (LOGA > 0) {
+                const double *tw = A.twd_inv + (size_t)mi * A.N;
+#pragma unroll
+                for (int s = LOGA - 1; s >= 0; s--) {
+                    const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (r & d) continue;
+                        const double U = xd[r], V = xd[r + d];
+                        xd[r] = U + V;
+                        xd[r + d] = modmul_f64(U - V, tw[(1 << s) + (r >> (LOGA - s))], qd, qid);
+                    }
+                }
+                const double ninv = (double)imform(mq.ninv, q, qinv);
+#pragma unroll
+                for (int r = 0; r < R; r++) xd[r] = modmul_f64(xd[r], ninv, qd, qid);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) x[r] = canon_f64(xd[r], qd, qid);
+        } else if constexpr (LOGA > 0) {  // finish the inverse NTT: the LOGA strided stages, N^-1 folded into the last
             const uint64_t *tw = A.tw_inv + (size_t)mi * A.N;
 #pragma unroll
             for (int s = LOGA - 1; s >= 0; s--) {
@@ -1257,11 +1283,17 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
         } else {
             const uint64_t h = D.src_half[i], ai = D.a[i];
             const double qf = __ull2double_rn(q);
+            const double rq = 1.0 / qf;
             const bool split = D.src_split[i] != 0;
+            const double qd = (double)q, qid = 1.0 / qd, apl = src_small ? (double)imform(ai, q, qinv) : 0.0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint64_t yi = mred(cred(x[r] + h, q), ai, q, qinv);
-                vi[r] = __dadd_rn(vi[r], __ddiv_rn(__ull2double_rn(yi), qf));
+                uint64_t yi;
+                if (src_small) yi = canon_f64(modmul_f64((double)cred(x[r] + h, q), apl, qd, qid), qd, qid);
+                else yi = mred(cred(x[r] + h, q), ai, q, qinv);
+                // fast estimate of fl(y/q); the exact IEEE division is redone below only when the sum lands within
+                // 2^-40 of an integer (|estimate - exact sum| < 2^-42 for <= 32 terms)
+                vi[r] = __dadd_rn(vi[r], __ull2double_rn(yi) * rq);
                 if constexpr (DSTF64) {
                     ylds[i * R + r][threadIdx.x] = yi;
                     yl[r][i] = (double)(split ? (yi & ((1ull << 26) - 1)) : yi);
@@ -1269,6 +1301,23 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                 } else {
                     y[r][i] = yi;
                 }
+            }
+        }
+    }
+    if (!D.single) {  // exact v = trunc(sum_i fl(fl(y_i)/fl(q_i))) where the estimate is not conclusive (rare)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double fr = vi[r] - floor(vi[r]);
+            if (fr < 0x1p-40 || fr > 1.0 - 0x1p-40) {
+                double e = 0.0;
+#pragma unroll
+                for (int i = 0; i < NSRC; i++) {
+                    uint64_t yi;
+                    if constexpr (DSTF64) yi = ylds[i * R + r][threadIdx.x];
+                    else yi = y[r][i];
+                    e = __dadd_rn(e, __ddiv_rn(__ull2double_rn(yi), __ull2double_rn(A.mc[D.src_mod[i]].q)));
+                }
+                vi[r] = e;
             }
         }
     }
@@ -1417,7 +1466,7 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
     ModUpFusedArgs A;
     A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
-    A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.twd_fwd = r.twd_fwd; A.N = r.N;
+    A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.twd_fwd = r.twd_fwd; A.twd_inv = r.twd_inv; A.N = r.N;
     const bool use_f64 = (dst_classes & 2) && r.twd_fwd != nullptr;
     A.skip_f64_dst = 0;
     const int n2 = r.N >> a;

@@ -383,3 +383,47 @@ def test_mixed_modulus_sizes_all_kernel_classes(ctx, logN):
         assert np.array_equal(got, want), levelQ
         noise = noise_log2(pr.oQ, sub.binop("Sub", phase(pr.oQ, got, sk2.Q), sub.binop("MulCoeffsMontgomery", cx[0], sk.Q[: levelQ + 1])))
         assert noise <= logN + 8, noise
+
+
+@pytest.mark.parametrize("logN,logq,logp", [(14, [55, 45, 45, 45, 45, 45, 45], [55, 55, 55]), (12, [60, 45, 45, 61, 40, 45], [61, 46])])
+def test_fused_decomposition_adversarial_float(ctx, logN, logq, logp):
+    """The fused basis extension estimates v = trunc(sum fl(y_i/q_i)) with a reciprocal and redoes the exact IEEE
+    divisions only near integers: feed digits whose CRT value sits at 0, +-1, +-Q_d/2 and at multiples of Q_d/q_k +- 1
+    (the y_i/q_i sum is then within an ulp of an integer) and require the oracle's bits."""
+    q, p = O.GenModuli(logN + 1, logq, logp)
+    nq, np_ = len(q), len(p)
+    pr = Pair(ctx, logN, nq, np_, qmods=q, pmods=p)
+    rng = rng_for(2800 + logN)
+    gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+    beta = O.BaseRNSDecompositionVectorSize(nq - 1, np_ - 1)
+    kq = np.stack([np.stack([uniform_poly(rng, q, pr.N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, pr.N) for _ in range(2)]) for _ in range(beta)])
+    gevk, oevk = gev.NewEvaluationKey(kq, kp), O.EvaluationKey(kq, kp)
+    coeff = uniform_poly(rng, q, pr.N)  # coefficient domain
+    col = 0
+    for d in range(beta):
+        lo, hi = d * np_, min(d * np_ + np_, nq)
+        mods = q[lo:hi]
+        Qd = prod(mods)
+        half = Qd >> 1
+        special = [0, 1, Qd - 1, half, half + 1, half - 1, 2, Qd - 2]
+        for k, m in enumerate(mods):
+            for j in (1, 2, m // 2, m - 1):
+                for dd in (-1, 0, 1):
+                    special.append(((Qd // m) * j + dd) % Qd)
+        for v in special:  # the reference adds Qd/2 before reconstructing: place the special value AFTER that shift
+            x = (v - half) % Qd
+            for k, m in enumerate(mods):
+                coeff[lo + k, col] = x % m
+            col += 1
+    assert col < pr.N
+    cx = pr.oQ.NTT(coeff)
+    pcx = la.Poly(pr.gQ, nq).upload(cx)
+    qp = [(la.Poly(pr.gQ, nq), la.Poly(pr.gP, np_)) for _ in range(2)]
+    gev.GadgetProductLazy(nq - 1, pcx, gevk, qp)
+    wQ, wP = oev.GadgetProductLazy(nq - 1, cx, oevk)
+    for k in range(2):
+        assert np.array_equal(qp[k][0].get(), wQ[k]) and np.array_equal(qp[k][1].get(), wP[k]), k
+    ct = [la.Poly(pr.gQ, nq), la.Poly(pr.gQ, nq)]
+    gev.GadgetProduct(nq - 1, pcx, gevk, ct)
+    assert np.array_equal(np.stack([c.get() for c in ct]), oev.GadgetProduct(nq - 1, cx, oevk))

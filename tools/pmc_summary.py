@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-FAMILY = [("ntt_rows_f64_kernel<12, false>", "ntt_rows_fwd_f64"), ("ntt_rows_f64_kernel<12, true>", "ntt_rows_inv_f64"),
+FAMILY = [("ntt_mac_f64_kernel", "ntt_mac_f64"), ("ntt_rows_f64_kernel<12, false>", "ntt_rows_fwd_f64"), ("ntt_rows_f64_kernel<12, true>", "ntt_rows_inv_f64"),
           ("ntt_rows_kernel<12, false", "ntt_rows_fwd"), ("ntt_rows_kernel<12, true", "ntt_rows_inv"),
           ("modup_fused_kernel", "modup"), ("ks_inner_kernel", "ks_inner"), ("tensor_kernel", "tensor"), ("ew_kernel", "ew")]
 
