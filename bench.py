@@ -174,14 +174,21 @@ def main():
                 dec_small, dec_big = dec_small + small_q[l], dec_big + (not small_q[l])
         dec_small, dec_big = dec_small + sum(small_p), dec_big + (alpha - sum(small_p))
     nsq, nsp = sum(small_q), sum(small_p)
+    n_small = nsq + nsp                            # limbs of QP on the double-precision path
+    n_big = L + alpha - n_small
     per_step_bytes = {
-        # decomposition NTTs (in + out) + ModDown NTTs of both components with the fused epilogue (in, acc, add, out)
-        "ntt_rows_fwd_f64": (2 * dec_small + 4 * 2 * nsq) * limb * B,
+        # fused forward row NTT + key MAC on the small limbs: decomposed non-own limbs + own limbs of c2 in, the key
+        # once, both accumulators out
+        "ntt_mac_f64": ((dec_small + nsq) * B + 2 * beta * n_small + 2 * n_small * B) * limb,
+        # ModDown NTTs of both components with the fused epilogue (in, acc, add, out)
+        "ntt_rows_fwd_f64": 4 * 2 * nsq * limb * B,
+        # decomposition NTTs of the large limbs (in + out) + their share of the ModDown NTTs
         "ntt_rows_fwd": (2 * dec_big + 4 * 2 * (L - nsq)) * limb * B,
         # INTT(c2) + INTT of the P part of both accumulators
         "ntt_rows_inv_f64": 2 * (nsq + 2 * nsp) * limb * B,
         "ntt_rows_inv": 2 * ((L - nsq) + 2 * (alpha - nsp)) * limb * B,
-        "ks_inner": (beta * (L + alpha) * B + 2 * beta * (L + alpha) + 2 * (L + alpha) * B) * limb,
+        # key MAC on the large limbs: beta digits in, the key once, both accumulators out
+        "ks_inner": (beta * n_big * B + 2 * beta * n_big + 2 * n_big * B) * limb,
         "tensor": 7 * L * limb * B,
         # fused basis extension: decomposition (L in, beta*(L+alpha)-L out) + ModDown (2*alpha in, 2*L out)
         "modup": (L + nonown + 2 * alpha + 2 * L) * limb * B,

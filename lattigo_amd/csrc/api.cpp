@@ -649,9 +649,14 @@ int he_binop(he_handle hring, int level, int op, he_handle h1, he_handle h2, he_
     TRY(check_poly(*p1, *r, level, "he_binop"));
     TRY(check_poly(*p2, *r, level, "he_binop"));
     TRY(check_poly(*p3, *r, level, "he_binop"));
-    if (p1->batch != p3->batch || p2->batch != p3->batch) return fail(HE_EINVAL, "he_binop: batch mismatch");
+    // an input of batch 1 broadcasts over the batch of the output (one plaintext against a batch of ciphertexts)
+    if ((p1->batch != p3->batch && p1->batch != 1) || (p2->batch != p3->batch && p2->batch != 1))
+        return fail(HE_EINVAL, "he_binop: batch mismatch");
+    View v1 = p1->view(), v2 = p2->view();
+    if (p1->batch != p3->batch) v1.bstride = 0;
+    if (p2->batch != p3->batch) v2.bstride = 0;
     Scope sc(r->ctx.get());
-    HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), op, p1->view(), p2->view(), p3->view(), p3->batch, nullptr, nullptr, r->ctx->stream));
+    HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), op, v1, v2, p3->view(), p3->batch, nullptr, nullptr, r->ctx->stream));
     return HE_OK;
 }
 int he_unop(he_handle hring, int level, int op, he_handle h1, he_handle h2) {

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import H, check, load, u64p
-from .ring import Poly, Ring, _p
+from .ring import BasisExtender, Poly, Ring, _p
 
 
 def BaseRNSDecompositionVectorSize(levelQ: int, levelP: int) -> int:
@@ -164,3 +164,156 @@ class Evaluator:
         r = self.ringQ.AtLevel(level)
         for a, b in zip(op0, opOut):
             r.DivRoundByLastModulusManyNTT(nbRescales, a, b)
+
+
+# ----------------------------------------------------------------------------------------------------
+# core/rlwe/inner_sum.go: Trace / PartialTracesSum / InnerSum / Replicate.  Host-side drivers over the
+# device-resident operators above, exactly as the reference's own code sits on rlwe.EvaluatorProvider.
+# ----------------------------------------------------------------------------------------------------
+GaloisGen = 5  # core/rlwe/params.go:33
+
+
+def GaloisElement(nth_root: int, k: int) -> int:
+    """Parameters.GaloisElement (core/rlwe/params.go:580): GaloisGen^k mod NthRoot, k reduced as a uint64."""
+    return pow(GaloisGen, (k & 0xFFFFFFFFFFFFFFFF) & (nth_root - 1), nth_root)
+
+
+class GaloisKeySet:
+    """rlwe.MemEvaluationKeySet restricted to Galois keys (core/rlwe/evaluationkeyset.go): galEl -> EvaluationKey."""
+
+    def __init__(self, keys: dict | None = None):
+        self.keys = dict(keys or {})
+
+    def GetGaloisKey(self, galEl: int) -> EvaluationKey:
+        if galEl not in self.keys:
+            raise KeyError(f"GaloisKey[{galEl}] is nil")
+        return self.keys[galEl]
+
+
+class InnerSumEvaluator:
+    """The inner_sum.go methods of rlwe.Evaluator, bound to an Evaluator and a Galois key set."""
+
+    def __init__(self, evaluator: Evaluator, gks: GaloisKeySet):
+        self.eval, self.gks = evaluator, gks
+        self.ringQ, self.ringP = evaluator.ringQ, evaluator.ringP
+        self.be = BasisExtender(self.ringQ, self.ringP)
+        self.nth_root = self.ringQ.NthRoot()
+        self.logN = self.ringQ.N.bit_length() - 1
+
+    def GaloisElement(self, k: int) -> int:
+        return GaloisElement(self.nth_root, k)
+
+    # Evaluator.Trace (core/rlwe/inner_sum.go:36); ct = [c0, c1] at `level`
+    def Trace(self, level, ctIn, logN: int, opOut, isNTT: bool = True):
+        rQ = self.ringQ.AtLevel(level)
+        gap = 1 << (self.logN - logN - 1)
+        if logN == 0:
+            gap <<= 1
+        if gap <= 1:
+            if ctIn is not opOut:
+                for a, b in zip(opOut, ctIn):
+                    a.CopyLvl(level, b)
+            return
+        Q = 1
+        for m in self.ringQ.ModuliChain()[: level + 1]:
+            Q *= int(m)
+        ninv = pow(gap, -1, Q)
+        for a, b in zip(ctIn, opOut):
+            rQ.MulScalarBigint(a, ninv, b)  # pre-multiplication by (N/n)^-1 (:68-70)
+            if not isNTT:
+                rQ.NTT(b, b)
+        buff = [Poly(self.ringQ, level + 1, opOut[0].batch) for _ in range(2)]
+        steps = [self.GaloisElement(1 << i) for i in range(logN, self.logN - 1)]
+        if logN == 0:
+            steps.append(self.nth_root - 1)  # X -> X^-1 (:97-105)
+        for galEl in steps:
+            self.eval.Automorphism(level, opOut, galEl, self.gks.GetGaloisKey(galEl), buff)
+            for a, b in zip(opOut, buff):
+                rQ.Add(a, b, a)
+        if not isNTT:
+            for b in opOut:
+                rQ.INTT(b, b)
+
+    # Evaluator.PartialTracesSum (core/rlwe/inner_sum.go:147)
+    def PartialTracesSum(self, level, ctIn, offset: int, n: int, opOut, isNTT: bool = True):
+        if n == 0 or offset == 0:
+            raise ValueError("partialtrace: invalid parameter (n = 0 or batchSize = 0)")
+        levelQ, levelP = level, self.ringP.MaxLevel()
+        rQ, rP = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
+        B = ctIn[0].batch
+        ctInNTT = [Poly(self.ringQ, levelQ + 1, B) for _ in range(2)]
+        for a, b in zip(ctIn, ctInNTT):
+            if not isNTT:
+                rQ.NTT(a, b)
+            else:
+                b.CopyLvl(levelQ, a)
+        if n == 1:
+            if ctIn is not opOut:
+                for a, b in zip(ctIn, opOut):
+                    b.CopyLvl(levelQ, a)
+        else:
+            newQP = lambda: (Poly(self.ringQ, levelQ + 1, B), Poly(self.ringP, levelP + 1, B))
+            accQP, cQP = [newQP(), newQP()], [newQP(), newQP()]
+            cQ = [cQP[0][0], cQP[1][0]]
+            decomp = Decomposition(self.eval, B)
+            state, copy = False, True
+            i, j = 0, n
+            while j > 0:  # binary reading of n (:216)
+                self.eval.DecomposeNTT(levelQ, levelP, levelP + 1, ctInNTT[1], True, decomp)
+                if j & 1:
+                    k = (n - (n & ((2 << i) - 1))) * offset
+                    if k != 0:
+                        rot = self.GaloisElement(k)
+                        gk = self.gks.GetGaloisKey(rot)
+                        if copy:
+                            self.eval.AutomorphismHoistedLazy(levelQ, ctInNTT, decomp, rot, gk, accQP)
+                            copy = False
+                        else:
+                            self.eval.AutomorphismHoistedLazy(levelQ, ctInNTT, decomp, rot, gk, cQP)
+                            for a, c in zip(accQP, cQP):
+                                rQ.Add(a[0], c[0], a[0])
+                                rP.Add(a[1], c[1], a[1])
+                    else:
+                        state = True
+                        if n & (n - 1):
+                            for a, o, c in zip(accQP, opOut, ctInNTT):
+                                self.be.ModDownQPtoQNTT(levelQ, levelP, a[0], a[1], o)
+                                rQ.Add(o, c, o)
+                        else:
+                            for o, c in zip(opOut, ctInNTT):
+                                o.CopyLvl(levelQ, c)
+                if not state:
+                    rot = self.GaloisElement((1 << i) * offset)
+                    self.eval.AutomorphismHoisted(levelQ, ctInNTT, decomp, rot, self.gks.GetGaloisKey(rot), cQ)
+                    for c, t in zip(ctInNTT, cQ):
+                        rQ.Add(c, t, c)
+                i, j = i + 1, j >> 1
+        if not isNTT:
+            for o in opOut:
+                rQ.INTT(o, o)
+
+    # InnerSum / Replicate (core/rlwe/inner_sum.go:475 and the scheme-level InnerSum wrappers)
+    def InnerSum(self, level, ctIn, batchSize: int, n: int, opOut, isNTT: bool = True):
+        self.PartialTracesSum(level, ctIn, batchSize, n, opOut, isNTT)
+
+    def Replicate(self, level, ctIn, batchSize: int, n: int, opOut, isNTT: bool = True):
+        self.PartialTracesSum(level, ctIn, -batchSize, n, opOut, isNTT)
+
+
+def GaloisElementsForInnerSum(nth_root: int, batch: int, n: int):
+    """core/rlwe/inner_sum.go:442"""
+    rots = set()
+    i = 1
+    while i < n:
+        rots.add(i * batch)
+        rots.add((n - (n & ((i << 1) - 1))) * batch)
+        i <<= 1
+    return sorted({GaloisElement(nth_root, k) for k in rots})
+
+
+def GaloisElementsForTrace(nth_root: int, logN_ring: int, logN: int):
+    """core/rlwe/inner_sum.go:120 (standard ring)"""
+    g = [GaloisElement(nth_root, 1 << i) for i in range(logN, logN_ring - 1)]
+    if logN == 0:
+        g.append(nth_root - 1)
+    return g

@@ -1,0 +1,298 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's host-side drivers that sit on
+rlwe.EvaluatorProvider: core/rlwe/inner_sum.go (Trace, PartialTracesSum, InnerSum, Replicate) and
+circuits/common/lintrans/lintrans_evaluator.go (MultiplyByDiagMatrix, MultiplyByDiagMatrixBSGS, EvaluateMany).
+Built on the C oracle's primitives (oracle.py); functional style: arrays in, arrays out.  A ciphertext is an array
+[2][limbs][N], a QP element a pair (Q [limbs_q][N], P [limbs_p][N]).  Nothing under lattigo_amd/ imports this."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import oracle as O
+
+GaloisGen = 5  # core/rlwe/params.go:33
+
+
+def GaloisElement(nth_root: int, k: int) -> int:
+    """core/rlwe/params.go:580"""
+    return O.ModExp(GaloisGen, (k & 0xFFFFFFFFFFFFFFFF) & (nth_root - 1), nth_root)
+
+
+def _prod(ms):
+    r = 1
+    for m in ms:
+        r *= int(m)
+    return r
+
+
+class InnerSumEvaluator:
+    def __init__(self, evaluator: O.Evaluator, gks: dict):
+        self.eval, self.gks = evaluator, gks
+        self.ringQ, self.ringP = evaluator.ringQ, evaluator.ringP
+        self.be = O.BasisExtender(self.ringQ, self.ringP)
+        self.nth_root = 2 * self.ringQ.N
+        self.logN = self.ringQ.N.bit_length() - 1
+
+    def GaloisElement(self, k):
+        return GaloisElement(self.nth_root, k)
+
+    def Trace(self, ctIn, logN, isNTT=True):
+        """core/rlwe/inner_sum.go:36-117 (standard ring)"""
+        ctIn = np.asarray(ctIn, dtype=np.uint64)
+        level = ctIn.shape[1] - 1
+        rQ = self.ringQ
+        gap = 1 << (self.logN - logN - 1)
+        if logN == 0:
+            gap <<= 1
+        if gap <= 1:
+            return ctIn.copy()
+        ninv = pow(gap, -1, _prod(rQ.moduli[: level + 1]))
+        out = np.stack([rQ.MulScalarBigint(ctIn[k], ninv) for k in range(2)])  # :68-70
+        if not isNTT:
+            out = np.stack([rQ.NTT(out[k]) for k in range(2)])
+        steps = [self.GaloisElement(1 << i) for i in range(logN, self.logN - 1)]  # :82
+        if logN == 0:
+            steps.append(self.nth_root - 1)  # :97
+        for galEl in steps:
+            buff = self.eval.Automorphism(out, galEl, self.gks[galEl])
+            out = np.stack([rQ.binop("Add", out[k], buff[k]) for k in range(2)])
+        if not isNTT:
+            out = np.stack([rQ.INTT(out[k]) for k in range(2)])
+        return out
+
+    def PartialTracesSum(self, ctIn, offset, n, isNTT=True):
+        """core/rlwe/inner_sum.go:147-294"""
+        if n == 0 or offset == 0:
+            raise ValueError("partialtrace: invalid parameter (n = 0 or batchSize = 0)")
+        ctIn = np.asarray(ctIn, dtype=np.uint64)
+        levelQ, levelP = ctIn.shape[1] - 1, self.ringP.MaxLevel()
+        rQ, rP = self.ringQ, self.ringP
+        ctInNTT = ctIn.copy() if isNTT else np.stack([rQ.NTT(ctIn[k]) for k in range(2)])
+        opOut = None
+        if n == 1:
+            opOut = ctIn.copy()
+        else:
+            accQ = accP = None
+            state, copy = False, True
+            i, j = 0, n
+            while j > 0:  # :216
+                dq, dp = self.eval.DecomposeNTT(levelQ, levelP, levelP + 1, ctInNTT[1], True)
+                if j & 1:
+                    k = (n - (n & ((2 << i) - 1))) * offset
+                    if k != 0:
+                        rot = self.GaloisElement(k)
+                        cQ, cP = self.eval.AutomorphismHoistedLazy(levelQ, ctInNTT[0], dq, dp, rot, self.gks[rot])
+                        if copy:
+                            accQ, accP, copy = cQ, cP, False
+                        else:  # ringQP.Add (:243-244)
+                            accQ = np.stack([rQ.binop("Add", accQ[t], cQ[t]) for t in range(2)])
+                            accP = np.stack([rP.binop("Add", accP[t], cP[t]) for t in range(2)])
+                    else:
+                        state = True
+                        if n & (n - 1):  # :255-262
+                            opOut = np.stack([rQ.binop("Add", self.be.ModDownQPtoQNTT(levelQ, levelP, accQ[t], accP[t]),
+                                                       ctInNTT[t]) for t in range(2)])
+                        else:
+                            opOut = ctInNTT.copy()
+                if not state:  # :271-281
+                    rot = self.GaloisElement((1 << i) * offset)
+                    cQ = self.eval.AutomorphismHoisted(ctInNTT, dq, dp, rot, self.gks[rot])
+                    ctInNTT = np.stack([rQ.binop("Add", ctInNTT[t], cQ[t]) for t in range(2)])
+                i, j = i + 1, j >> 1
+        if not isNTT:
+            opOut = np.stack([rQ.INTT(opOut[k]) for k in range(2)])
+        return opOut
+
+    def InnerSum(self, ctIn, batchSize, n, isNTT=True):
+        return self.PartialTracesSum(ctIn, batchSize, n, isNTT)
+
+    def Replicate(self, ctIn, batchSize, n, isNTT=True):
+        """core/rlwe/inner_sum.go:475"""
+        return self.PartialTracesSum(ctIn, -batchSize, n, isNTT)
+
+
+def BSGSIndex(nonZeroDiags, slots, N1):
+    """circuits/common/lintrans/lintrans.go:344-366"""
+    index, r1, r2 = {}, set(), set()
+    for rot in nonZeroDiags:
+        rot &= slots - 1
+        a = ((rot // N1) * N1) & (slots - 1)
+        b = rot & (N1 - 1)
+        index.setdefault(a, []).append(b)
+        r1.add(a)
+        r2.add(b)
+    for k in index:
+        index[k].sort()
+    return index, sorted(r1), sorted(r2)
+
+
+class LinearTransformation:
+    """Vec[k] = (Q [LevelQ+1][N], P [LevelP+1][N]) encoded diagonals (NTT, Montgomery)"""
+
+    def __init__(self, Vec, LevelQ, LevelP, slots, N1=0):
+        self.Vec, self.LevelQ, self.LevelP, self.slots, self.N1 = Vec, LevelQ, LevelP, slots, N1
+
+
+def _margin(moduli, level):
+    """core/rlwe/params.go:554-568"""
+    return int(2.0 ** 64 / float(max(int(m) for m in moduli[: level + 1])))
+
+
+class LinTransEvaluator:
+    def __init__(self, evaluator: O.Evaluator, gks: dict):
+        self.eval, self.gks = evaluator, gks
+        self.ringQ, self.ringP = evaluator.ringQ, evaluator.ringP
+        self.be = O.BasisExtender(self.ringQ, self.ringP)
+        self.nth_root = 2 * self.ringQ.N
+
+    def GaloisElement(self, k):
+        return GaloisElement(self.nth_root, k)
+
+    def EvaluateMany(self, ctIn, lts):
+        """lintrans_evaluator.go:27-79"""
+        ctIn = np.asarray(ctIn, dtype=np.uint64)
+        levelP = lts[0].LevelP
+        levelQ = min(max(lt.LevelQ for lt in lts), ctIn.shape[1] - 1)
+        dq, dp = self.eval.DecomposeNTT(levelQ, levelP, levelP + 1, ctIn[1][: levelQ + 1], True)
+        pre, outs = {}, []
+        for lt in lts:
+            if lt.N1 == 0:
+                outs.append(self.MultiplyByDiagMatrix(ctIn, lt, dq, dp))
+            else:
+                _, _, rotN2 = BSGSIndex(list(lt.Vec.keys()), lt.slots, lt.N1)
+                self.PreRotated(levelQ, levelP, ctIn, dq, dp, rotN2, pre)
+                outs.append(self.MultiplyByDiagMatrixBSGS(ctIn, lt, pre))
+        return outs
+
+    def PreRotated(self, levelQ, levelP, ctIn, dq, dp, rots, pre):
+        """lintrans_evaluator.go:82-110"""
+        for i in list(pre):
+            if i not in rots:
+                del pre[i]
+        for i in rots:
+            if i != 0 and i not in pre:
+                g = self.GaloisElement(i)
+                pre[i] = self.eval.AutomorphismHoistedLazy(levelQ, ctIn[0][: levelQ + 1], dq, dp, g, self.gks[g])
+
+    def MultiplyByDiagMatrix(self, ctIn, matrix, dq, dp, out_level=None):
+        """lintrans_evaluator.go:142-274"""
+        ctIn = np.asarray(ctIn, dtype=np.uint64)
+        lv = ctIn.shape[1] - 1
+        levelQ = min(lv if out_level is None else out_level, lv, matrix.LevelQ)
+        levelP = matrix.LevelP
+        rQ, rP = self.ringQ, self.ringP
+        QiOverF, PiOverF = _margin(rQ.moduli, levelQ), _margin(rP.moduli, levelP)
+        c0, c1 = ctIn[0][: levelQ + 1].copy(), ctIn[1][: levelQ + 1].copy()
+        ct0TimesP = rQ.MulScalarBigint(c0, _prod(rP.moduli[: levelP + 1]))
+        keys = sorted(matrix.Vec.keys())
+        state = False
+        if keys[0] == 0:
+            state, keys = True, keys[1:]
+        outQ = [None, None]
+        outP = [None, None]
+        for i, k in enumerate(keys):
+            k &= matrix.slots - 1
+            g = self.GaloisElement(k)
+            evk = self.gks[g]
+            index = rQ.AutomorphismNTTIndex(g)
+            cQ, cP = self.eval.GadgetProductHoistedLazy(levelQ, dq, dp, evk)
+            cQ[0] = rQ.binop("Add", cQ[0], ct0TimesP)
+            ptQ, ptP = matrix.Vec[k]
+            for t in range(2):
+                tq = rQ.AutomorphismNTTWithIndex(cQ[t], index)
+                tp = rP.AutomorphismNTTWithIndex(cP[t], index)
+                if i == 0:
+                    outQ[t] = rQ.binop("MulCoeffsMontgomery", ptQ[: levelQ + 1], tq)
+                    outP[t] = rP.binop("MulCoeffsMontgomery", ptP[: levelP + 1], tp)
+                else:
+                    outQ[t] = rQ.binop("MulCoeffsMontgomeryThenAdd", ptQ[: levelQ + 1], tq, outQ[t])
+                    outP[t] = rP.binop("MulCoeffsMontgomeryThenAdd", ptP[: levelP + 1], tp, outP[t])
+            if i % QiOverF == QiOverF - 1:
+                outQ = [rQ.unop("Reduce", x) for x in outQ]
+            if i % PiOverF == PiOverF - 1:
+                outP = [rP.unop("Reduce", x) for x in outP]
+        if len(keys) % QiOverF == 0:
+            outQ = [rQ.unop("Reduce", x) for x in outQ]
+        if len(keys) % PiOverF == 0:
+            outP = [rP.unop("Reduce", x) for x in outP]
+        res = [self.be.ModDownQPtoQNTT(levelQ, levelP, outQ[t], outP[t]) for t in range(2)]
+        if state:
+            pt0 = matrix.Vec[0][0][: levelQ + 1]
+            res[0] = rQ.binop("MulCoeffsMontgomeryThenAdd", pt0, c0, res[0])
+            res[1] = rQ.binop("MulCoeffsMontgomeryThenAdd", pt0, c1, res[1])
+        return np.stack(res)
+
+    def MultiplyByDiagMatrixBSGS(self, ctIn, matrix, pre, out_level=None):
+        """lintrans_evaluator.go:280-469"""
+        ctIn = np.asarray(ctIn, dtype=np.uint64)
+        lv = ctIn.shape[1] - 1
+        levelQ = min(lv if out_level is None else out_level, lv, matrix.LevelQ)
+        levelP = matrix.LevelP
+        rQ, rP = self.ringQ, self.ringP
+        QiOverF, PiOverF = _margin(rQ.moduli, levelQ) >> 1, _margin(rP.moduli, levelP) >> 1
+        index, _, _ = BSGSIndex(list(matrix.Vec.keys()), matrix.slots, matrix.N1)
+        Pm = _prod(rP.moduli[: levelP + 1])
+        cin = [rQ.MulScalarBigint(ctIn[t][: levelQ + 1], Pm) for t in range(2)]  # P*c0, P*c1 (:332-333)
+        N = rQ.N
+        outQ, outP = [None, None], [None, None]
+        cnt0 = 0
+        for j in sorted(index.keys()):
+            cnt1 = 0
+            tQ, tP = [None, None], [None, None]
+            for i in index[j]:
+                ptQ, ptP = matrix.Vec[j + i]
+                ptQ, ptP = ptQ[: levelQ + 1], ptP[: levelP + 1]
+                for t in range(2):
+                    if i == 0:
+                        if cnt1 == 0:
+                            tQ[t] = rQ.binop("MulCoeffsMontgomeryLazy", ptQ, cin[t])
+                            tP[t] = np.zeros((levelP + 1, N), dtype=np.uint64)
+                        else:
+                            tQ[t] = rQ.binop("MulCoeffsMontgomeryLazyThenAddLazy", ptQ, cin[t], tQ[t])
+                    else:
+                        cQ, cP = pre[i]
+                        if cnt1 == 0:
+                            tQ[t] = rQ.binop("MulCoeffsMontgomeryLazy", ptQ, cQ[t])
+                            tP[t] = rP.binop("MulCoeffsMontgomeryLazy", ptP, cP[t])
+                        else:
+                            tQ[t] = rQ.binop("MulCoeffsMontgomeryLazyThenAddLazy", ptQ, cQ[t], tQ[t])
+                            tP[t] = rP.binop("MulCoeffsMontgomeryLazyThenAddLazy", ptP, cP[t], tP[t])
+                if cnt1 % QiOverF == QiOverF - 1:
+                    tQ = [rQ.unop("Reduce", x) for x in tQ]
+                if cnt1 % PiOverF == PiOverF - 1:
+                    tP = [rP.unop("Reduce", x) for x in tP]
+                cnt1 += 1
+            if cnt1 % QiOverF != 0:
+                tQ = [rQ.unop("Reduce", x) for x in tQ]
+            if cnt1 % PiOverF != 0:
+                tP = [rP.unop("Reduce", x) for x in tP]
+            if j != 0:
+                t1 = self.be.ModDownQPtoQNTT(levelQ, levelP, tQ[1], tP[1])  # :397
+                g = self.GaloisElement(j)
+                rot = rQ.AutomorphismNTTIndex(g)
+                cQ, cP = self.eval.GadgetProductLazy(levelQ, t1, self.gks[g])
+                cQ[0] = rQ.binop("Add", cQ[0], tQ[0])
+                cP[0] = rP.binop("Add", cP[0], tP[0])
+                for t in range(2):
+                    if cnt0 == 0:
+                        outQ[t] = rQ.AutomorphismNTTWithIndex(cQ[t], rot)
+                        outP[t] = rP.AutomorphismNTTWithIndex(cP[t], rot)
+                    else:
+                        outQ[t] = rQ.AutomorphismNTTWithIndexThenAddLazy(cQ[t], rot, outQ[t])
+                        outP[t] = rP.AutomorphismNTTWithIndexThenAddLazy(cP[t], rot, outP[t])
+            else:
+                for t in range(2):
+                    if cnt0 == 0:
+                        outQ[t], outP[t] = tQ[t].copy(), tP[t].copy()
+                    else:
+                        outQ[t] = rQ.binop("AddLazy", outQ[t], tQ[t])
+                        outP[t] = rP.binop("AddLazy", outP[t], tP[t])
+            if cnt0 % QiOverF == QiOverF - 1:
+                outQ = [rQ.unop("Reduce", x) for x in outQ]
+            if cnt0 % PiOverF == PiOverF - 1:
+                outP = [rP.unop("Reduce", x) for x in outP]
+            cnt0 += 1
+        if cnt0 % QiOverF != 0:
+            outQ = [rQ.unop("Reduce", x) for x in outQ]
+        if cnt0 % PiOverF != 0:
+            outP = [rP.unop("Reduce", x) for x in outP]
+        return np.stack([self.be.ModDownQPtoQNTT(levelQ, levelP, outQ[t], outP[t]) for t in range(2)])

@@ -892,7 +892,7 @@ static void ring_moduli(const lo_ring *r, uint64_t *out) { for (int i = 0; i < r
 /* NewBasisExtender, :52-89 */
 lo_basis_extender *lo_basis_extender_new(lo_ring *ringQ, lo_ring *ringP) {
     lo_basis_extender *be = (lo_basis_extender *)calloc(1, sizeof *be);
-    be->ringQ = ringQ; be->ringP = ringP;
+    be->ringQ = ringQ; be->ringP = ringP; be->nQ = ringQ->nmod; be->nP = ringP->nmod;
     uint64_t *Q = (uint64_t *)malloc(8 * ringQ->nmod), *P = (uint64_t *)malloc(8 * ringP->nmod);
     ring_moduli(ringQ, Q); ring_moduli(ringP, P);
     be->qtop = (lo_modup_constants **)calloc(ringQ->nmod, sizeof(void *));
@@ -906,8 +906,8 @@ lo_basis_extender *lo_basis_extender_new(lo_ring *ringQ, lo_ring *ringP) {
 }
 void lo_basis_extender_free(lo_basis_extender *be) {
     if (!be) return;
-    for (int i = 0; i < be->ringQ->nmod; i++) { lo_modup_constants_free(be->qtop[i]); free(be->moddown_qtop[i]); }
-    for (int i = 0; i < be->ringP->nmod; i++) { lo_modup_constants_free(be->ptoq[i]); free(be->moddown_ptoq[i]); }
+    for (int i = 0; i < be->nQ; i++) { lo_modup_constants_free(be->qtop[i]); free(be->moddown_qtop[i]); }
+    for (int i = 0; i < be->nP; i++) { lo_modup_constants_free(be->ptoq[i]); free(be->moddown_ptoq[i]); }
     free(be->qtop); free(be->ptoq); free(be->moddown_ptoq); free(be->moddown_qtop); free(be);
 }
 

@@ -149,6 +149,7 @@ typedef struct lo_basis_extender {
     lo_modup_constants **ptoq;   /* [nP] source = P[:i+1], target = Q */
     uint64_t **moddown_ptoq;     /* [nP][nQ] */
     uint64_t **moddown_qtop;     /* [nQ][nP] */
+    int nQ, nP;                  /* table sizes (so that free does not need the rings) */
 } lo_basis_extender;
 
 lo_modup_constants *lo_gen_modup_constants(const uint64_t *Q, int nq, const uint64_t *P, int np);

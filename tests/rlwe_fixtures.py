@@ -124,3 +124,24 @@ def gen_evaluation_key_base2(rng, ringQ: O.Ring, ringP: O.Ring, sk_in_Q: np.ndar
             kq[blk, 0], kq[blk, 1], kp[blk, 0], kp[blk, 1] = bQ, aQ, bP, aP
             blk += 1
     return O.EvaluationKey(kq, kp, pw2=pw2, nj=nj)
+
+
+def gen_galois_keys(rng, ringQ: O.Ring, ringP: O.Ring, sk: SecretKey, galels):
+    """rlwe.KeyGenerator.GenGaloisKeysNew (core/rlwe/keygenerator.go:188-259): key for galEl switches
+    pi_{galEl^-1}(sk)... -> sk, i.e. skIn = sk, skOut = pi_{galEl^-1}(sk)."""
+    nth = 2 * ringQ.N
+    out = {}
+    for g in galels:
+        if g in out:
+            continue
+        ginv = pow(int(g), nth - 1, nth)  # core/rlwe/params.go:587
+        sk_out = automorphism_secret(rng, ringQ, ringP, sk, ginv)
+        out[int(g)] = gen_evaluation_key(rng, ringQ, ringP, sk.Q, sk_out)
+    return out
+
+
+def small_plaintext_qp(rng, ringQ: O.Ring, ringP: O.Ring, bound: int = 8):
+    """An 'encoded diagonal': a small polynomial in NTT + Montgomery form over Q and P."""
+    vals = rng.integers(-bound, bound + 1, size=ringQ.N)
+    return (ringQ.unop("MForm", ringQ.NTT(small_to_rns(vals, ringQ.moduli))),
+            ringP.unop("MForm", ringP.NTT(small_to_rns(vals, ringP.moduli))))

@@ -1,0 +1,155 @@
+"""Semantic (decrypt-and-check) tests of the oracle's restatement of the drivers that sit on
+rlwe.EvaluatorProvider: core/rlwe/inner_sum.go and circuits/common/lintrans.  They pin the COMPOSITION logic of
+oracle/circuits.py against the mathematical definition (sums of automorphisms of the plaintext); the GPU parity tests
+then compare the device drivers with it bit for bit.  No GPU needed."""
+import numpy as np
+import pytest
+
+from oracle import circuits as OC
+from oracle import oracle as O
+from tests.conftest import Pi60, Qi60
+from tests.helpers import rng_for, uniform_poly
+from tests.rlwe_fixtures import SecretKey, gen_galois_keys, noise_log2, phase, small_plaintext_qp
+
+N = 1 << 9
+NTH = 2 * N
+
+
+def setup(nq, np_, seed):
+    rng = rng_for(seed)
+    ringQ, ringP = O.Ring(N, Qi60[:nq]), O.Ring(N, Pi60[:np_])
+    ev = O.Evaluator(ringQ, ringP)
+    sk = SecretKey(rng, ringQ, ringP)
+    return rng, ringQ, ringP, ev, sk
+
+
+def rot(ringQ, x, k):
+    """phi_{5^k} of an NTT-domain polynomial"""
+    return ringQ.AutomorphismNTTWithIndex(x, ringQ.AutomorphismNTTIndex(OC.GaloisElement(NTH, k)))
+
+
+def sub_ring(ringQ, level):
+    return O.Ring(N, ringQ.moduli[: level + 1])
+
+
+@pytest.mark.parametrize("logn", [0, 3, 7, 8])
+def test_trace_keeps_the_subring_coefficients(logn):
+    rng, ringQ, ringP, ev, sk = setup(4, 2, 3100 + logn)
+    logN = N.bit_length() - 1
+    gals = [OC.GaloisElement(NTH, 1 << i) for i in range(logn, logN - 1)] + ([NTH - 1] if logn == 0 else [])
+    gks = gen_galois_keys(rng, ringQ, ringP, sk, gals)
+    ise = OC.InnerSumEvaluator(ev, gks)
+    ct = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])
+    out = ise.Trace(ct, logn)
+    m = ringQ.INTT(phase(ringQ, ct, sk.Q))
+    gap = N if logn == 0 else N >> (logn + 1)
+    want = np.zeros_like(m)
+    want[:, ::gap] = m[:, ::gap]
+    if gap <= 1:
+        assert np.array_equal(out, ct)
+    got = phase(ringQ, out, sk.Q)
+    assert noise_log2(ringQ, ringQ.binop("Sub", got, ringQ.NTT(want))) <= 24
+    # coefficient-domain input gives the same ciphertext up to the transforms
+    ctc = np.stack([ringQ.INTT(ct[k]) for k in range(2)])
+    outc = ise.Trace(ctc, logn, isNTT=False)
+    assert np.array_equal(np.stack([ringQ.NTT(outc[k]) for k in range(2)]), out)
+
+
+@pytest.mark.parametrize("n,offset", [(1, 1), (2, 1), (3, 1), (4, 2), (5, 1), (7, 3), (8, 1), (12, 2), (6, -1), (4, -4)])
+def test_partial_traces_sum(n, offset):
+    rng, ringQ, ringP, ev, sk = setup(4, 2, 3200 + n)
+    rots = set()
+    i = 1
+    while i < n:  # core/rlwe/inner_sum.go:442
+        rots.add(i * offset)
+        rots.add((n - (n & ((i << 1) - 1))) * offset)
+        i <<= 1
+    gks = gen_galois_keys(rng, ringQ, ringP, sk, [OC.GaloisElement(NTH, k) for k in rots])
+    ise = OC.InnerSumEvaluator(ev, gks)
+    for level in (3, 2):
+        sub = sub_ring(ringQ, level)
+        ct = np.stack([uniform_poly(rng, sub.moduli, N) for _ in range(2)])
+        out = ise.PartialTracesSum(ct, offset, n)
+        m = phase(ringQ, ct, sk.Q)
+        want = np.zeros_like(m)
+        for i in range(n):
+            want = sub.binop("Add", want, rot(sub, m, i * offset))
+        assert noise_log2(ringQ, sub.binop("Sub", phase(ringQ, out, sk.Q), want)) <= 24
+    with pytest.raises(ValueError):
+        ise.PartialTracesSum(ct, 0, n)
+
+
+def lintrans_setup(seed, diags, slots, N1, nq=4, np_=2, levelQ=None):
+    rng, ringQ, ringP, ev, sk = setup(nq, np_, seed)
+    levelQ = nq - 1 if levelQ is None else levelQ
+    if N1 == 0:
+        rots = [d & (slots - 1) for d in diags]
+    else:
+        _, r1, r2 = OC.BSGSIndex(diags, slots, N1)
+        rots = r1 + r2
+    gks = gen_galois_keys(rng, ringQ, ringP, sk, [OC.GaloisElement(NTH, k) for k in rots if k != 0])
+    Vec = {d: small_plaintext_qp(rng, ringQ, ringP) for d in diags}
+    lt = OC.LinearTransformation(Vec, levelQ, np_ - 1, slots, N1)
+    return rng, ringQ, ringP, ev, sk, gks, lt
+
+
+@pytest.mark.parametrize("diags", [[0, 1, 2, 5], [1, 3], [0], [0, 7, 100, 255]])
+def test_multiply_by_diag_matrix(diags):
+    slots = N // 2
+    rng, ringQ, ringP, ev, sk, gks, lt = lintrans_setup(3300 + len(diags), diags, slots, 0)
+    lte = OC.LinTransEvaluator(ev, gks)
+    ct = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])
+    if diags == [0]:
+        pytest.skip("a matrix with only the zero diagonal leaves the QP accumulator unwritten in the reference")
+    (out,) = lte.EvaluateMany(ct, [lt])
+    m = phase(ringQ, ct, sk.Q)
+    want = np.zeros_like(m)
+    for d in diags:
+        want = ringQ.binop("MulCoeffsMontgomeryThenAdd", lt.Vec[d][0], rot(ringQ, m, d), want)
+    assert noise_log2(ringQ, ringQ.binop("Sub", phase(ringQ, out, sk.Q), want)) <= 30
+
+
+@pytest.mark.parametrize("diags,N1", [([0, 1, 2, 3, 4, 5, 6, 7], 4), ([1, 2, 9, 17, 18], 8), ([0, 4, 8, 12], 4),
+                                      ([3, 4, 5], 4)])
+def test_multiply_by_diag_matrix_bsgs(diags, N1):
+    slots = N // 2
+    rng, ringQ, ringP, ev, sk, gks, lt = lintrans_setup(3400 + N1 + len(diags), diags, slots, N1)
+    lte = OC.LinTransEvaluator(ev, gks)
+    ct = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])
+    (out,) = lte.EvaluateMany(ct, [lt])
+    m = phase(ringQ, ct, sk.Q)
+    index, _, _ = OC.BSGSIndex(diags, slots, N1)
+    want = np.zeros_like(m)
+    for j, inner in index.items():  # sum_j phi_j( sum_i pt_{j+i} * phi_i(m) )
+        acc = np.zeros_like(m)
+        for i in inner:
+            acc = ringQ.binop("MulCoeffsMontgomeryThenAdd", lt.Vec[j + i][0], rot(ringQ, m, i), acc)
+        want = ringQ.binop("Add", want, rot(ringQ, acc, j))
+    assert noise_log2(ringQ, ringQ.binop("Sub", phase(ringQ, out, sk.Q), want)) <= 30
+
+
+def test_evaluate_many_shares_the_decomposition_and_levels():
+    slots = N // 2
+    rng, ringQ, ringP, ev, sk, gks, lt = lintrans_setup(3500, [0, 1, 2, 3, 5, 6], slots, 2, levelQ=2)
+    lt2 = OC.LinearTransformation({d: lt.Vec[d] for d in (1, 2)}, 2, 1, slots, 0)
+    lte = OC.LinTransEvaluator(ev, gks)
+    ct = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])  # level 3 > matrix level 2
+    o1, o2 = lte.EvaluateMany(ct, [lt, lt2])
+    assert o1.shape == (2, 3, N) and o2.shape == (2, 3, N)
+    sub = sub_ring(ringQ, 2)
+    m = phase(ringQ, ct[:, :3], sk.Q)
+    want = np.zeros_like(m)
+    for d in (1, 2):
+        want = sub.binop("MulCoeffsMontgomeryThenAdd", lt.Vec[d][0][:3], rot(sub, m, d), want)
+    assert noise_log2(ringQ, sub.binop("Sub", phase(ringQ, o2, sk.Q), want)) <= 30
+
+
+def test_host_helpers_of_the_product_match_the_oracle():
+    from lattigo_amd import lintrans as LT
+    from lattigo_amd import rlwe as R
+
+    for diags, slots, N1 in (([0, 1, 2, 3, 9, 200, 511], 256, 8), ([5, 6, 7], 512, 4), (list(range(40)), 64, 16)):
+        assert LT.BSGSIndex(diags, slots, N1) == OC.BSGSIndex(diags, slots, N1)
+    assert LT.FindBestBSGSRatio(list(range(64)), 64, 1) in (4, 8, 16)
+    for k in (0, 1, -1, 5, 12345, -77):
+        assert R.GaloisElement(1 << 13, k) == OC.GaloisElement(1 << 13, k) == pow(5, k % (1 << 13), 1 << 13)
