@@ -65,10 +65,56 @@ struct Ctx : Obj {
     uint64_t *arena = nullptr;
     size_t arena_words = 0, arena_used = 0;
     std::mutex mu;
+    // size-keyed cache of polynomial buffers: the drivers above the ABI allocate and drop temporaries per call, and
+    // hipMalloc/hipFree synchronise the device.  Reuse is stream-ordered (one stream per context), so a buffer can be
+    // handed out again without waiting for the kernels that last touched it.
+    std::multimap<size_t, void *> pool;
+    std::mutex pool_mu;  // own lock: the pool is used while an API call already holds `mu`
+    size_t pool_bytes = 0;
+    static constexpr size_t kPoolCap = (size_t)48 << 30;
+    hipError_t pool_take(size_t bytes, void **out) {
+        {
+            std::lock_guard<std::mutex> lk(pool_mu);
+            auto it = pool.find(bytes);
+            if (it != pool.end()) {
+                *out = it->second;
+                pool.erase(it);
+                pool_bytes -= bytes;
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) {  // give the cache back to the driver and retry once
+            (void)hipGetLastError();
+            pool_release_all();
+            e = hipMalloc(out, bytes);
+        }
+        return e;
+    }
+    void pool_give(size_t bytes, void *p) {
+        {
+            std::lock_guard<std::mutex> lk(pool_mu);
+            if (pool_bytes + bytes <= kPoolCap) {
+                pool.emplace(bytes, p);
+                pool_bytes += bytes;
+                return;
+            }
+        }
+        hipStreamSynchronize(stream);
+        hipFree(p);
+    }
+    void pool_release_all() {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        if (stream) hipStreamSynchronize(stream);
+        for (auto &kv : pool) hipFree(kv.second);
+        pool.clear();
+        pool_bytes = 0;
+    }
     Ctx() : Obj(T_CTX) {}
     ~Ctx() override {
         hipSetDevice(dev);
         if (stream) hipStreamSynchronize(stream);
+        pool_release_all();
         if (arena) hipFree(arena);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
@@ -126,8 +172,7 @@ struct Poly : Obj {
     Poly() : Obj(T_POLY) {}
     ~Poly() override {
         hipSetDevice(ctx->dev);
-        hipStreamSynchronize(ctx->stream);
-        if (d) hipFree(d);
+        if (d) ctx->pool_give((size_t)batch * nlimbs * N * 8, d);
     }
     View view() const { return View{d, (size_t)nlimbs * N}; }
     View view_at(int limb) const { return View{d + (size_t)limb * N, (size_t)nlimbs * N}; }
@@ -277,8 +322,7 @@ struct Decomp : Obj {
     Decomp() : Obj(T_DECOMP) {}
     ~Decomp() override {
         hipSetDevice(ev->be->ctx->dev);
-        hipStreamSynchronize(ev->be->ctx->stream);
-        if (d) hipFree(d);
+        if (d) ev->be->ctx->pool_give((size_t)batch * bstride() * 8, d);
     }
     size_t bstride() const { return (size_t)beta_max * width * ev->be->Q->N; }
     size_t dstride() const { return (size_t)width * ev->be->Q->N; }
@@ -520,8 +564,11 @@ int he_poly_alloc(he_handle hring, int n_limbs, int batch, he_handle *out) {
     p->batch = batch;
     Scope sc(r->ctx.get());
     const size_t bytes = (size_t)batch * n_limbs * r->N * 8;
-    hipError_t e = hipMalloc((void **)&p->d, bytes);
-    if (e != hipSuccess) return fail(HE_ENOMEM, "he_poly_alloc: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    hipError_t e = r->ctx->pool_take(bytes, (void **)&p->d);
+    if (e != hipSuccess) {
+        p->d = nullptr;
+        return fail(HE_ENOMEM, "he_poly_alloc: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
     HIP_TRY(hipMemsetAsync(p->d, 0, bytes, r->ctx->stream));
     *out = reg(p);
     return HE_OK;
@@ -1481,8 +1528,11 @@ int he_decomp_create(he_handle hev, int batch, he_handle *out) {
     d->width = be.LQ + be.LP;
     Scope sc(be.ctx.get());
     const size_t bytes = (size_t)batch * d->bstride() * 8;
-    hipError_t e = hipMalloc((void **)&d->d, bytes);
-    if (e != hipSuccess) return fail(HE_ENOMEM, "he_decomp_create: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    hipError_t e = be.ctx->pool_take(bytes, (void **)&d->d);
+    if (e != hipSuccess) {
+        d->d = nullptr;
+        return fail(HE_ENOMEM, "he_decomp_create: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
     *out = reg(d);
     return HE_OK;
 }

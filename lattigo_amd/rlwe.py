@@ -99,6 +99,19 @@ class Evaluator:
     def NewEvaluationKey(self, q, p, BaseTwoDecomposition=0, BaseTwoDecompositionVectorSize=None) -> EvaluationKey:
         return EvaluationKey(self, q, p, BaseTwoDecomposition, BaseTwoDecompositionVectorSize)
 
+    def EvaluationKeyFromBinary(self, data: bytes) -> EvaluationKey:
+        """rlwe.EvaluationKey.UnmarshalBinary (core/rlwe/keys.go:443 -> gadgetciphertext.go:134): load a key the
+        reference serialised straight into a device handle."""
+        from . import wire
+        kq, kp, base_two, nj = wire.gadget_ciphertext_unmarshal(data)
+        return EvaluationKey(self, kq, kp, base_two, nj if base_two else None)
+
+    def GaloisKeyFromBinary(self, data: bytes):
+        """rlwe.GaloisKey.UnmarshalBinary (core/rlwe/keys.go:659) -> (GaloisElement, NthRoot, EvaluationKey)"""
+        from . import wire
+        g, nth, kq, kp, base_two, nj = wire.galois_key_unmarshal(data)
+        return g, nth, EvaluationKey(self, kq, kp, base_two, nj if base_two else None)
+
     # ring.Decomposer.DecomposeAndSplit (ring/basis_extension.go:381)
     def DecomposeAndSplit(self, levelQ, levelP, nbPi, digit, p0Q: Poly, p1Q: Poly, p1P: Poly):
         check(load().he_decompose_and_split(self.h, levelQ, levelP, nbPi, digit, p0Q.h, p1Q.h, p1P.h))

@@ -427,3 +427,24 @@ def test_fused_decomposition_adversarial_float(ctx, logN, logq, logp):
     ct = [la.Poly(pr.gQ, nq), la.Poly(pr.gQ, nq)]
     gev.GadgetProduct(nq - 1, pcx, gevk, ct)
     assert np.array_equal(np.stack([c.get() for c in ct]), oev.GadgetProduct(nq - 1, cx, oevk))
+
+
+def test_keys_loaded_from_the_wire_format(ctx):
+    """rlwe.EvaluationKey / GaloisKey bytes (core/rlwe/keys.go:443,628) -> device handle: same gadget product."""
+    from lattigo_amd import wire
+    pr, rng, oev, gev, sk = _setup(ctx, 10, 4, 1, 2900)
+    sk2 = SecretKey(rng, pr.oQ, pr.oP)
+    cx = uniform_poly(rng, pr.q, pr.N)
+    pcx = _uploadQ(pr, cx)
+    for oevk, pw2 in ((gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, sk2), 0),
+                      (gen_evaluation_key_base2(rng, pr.oQ, pr.oP, sk.Q, sk2, 20), 20)):
+        nj = list(oevk.nj[:4]) if pw2 else None
+        blob = wire.galois_key_marshal(5, 2 * pr.N, oevk.q, oevk.p, pw2, nj)
+        g, nth, gevk = gev.GaloisKeyFromBinary(blob)
+        assert (g, nth) == (5, 2 * pr.N) and gevk.BaseTwoDecomposition == pw2
+        gevk2 = gev.EvaluationKeyFromBinary(blob[16:])
+        want = oev.GadgetProduct(3, cx, oevk)
+        for k in (gevk, gevk2):
+            ct = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
+            gev.GadgetProduct(3, pcx, k, ct)
+            assert np.array_equal(np.stack([c.get() for c in ct]), want)

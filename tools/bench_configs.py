@@ -100,6 +100,43 @@ def main():
     ms = timed(ctx, lambda: ev.AutomorphismHoisted(L - 1, ct, dec, gal, gk, o2), 10)
     out.append({"config": "c4", "what": "CKKS logN=16: hoisted Rotate (decomposition shared)", "batch": B, "ms": ms,
                 "ops_per_s": B / (ms * 1e-3)})
+    # ---- lintrans / inner sum on the config-4 chain: host drivers over the device operators
+    from lattigo_amd import lintrans as LT
+    from lattigo_amd import rlwe as R
+    B = 4
+    nth, slots = 2 * N, N // 2
+    ct = [la.Poly(rq, L, B).upload(uniform(rng, C4_Q, N, (B,))) for _ in range(2)]
+    gks = R.GaloisKeySet()
+
+    def need(galels):
+        for g in galels:
+            if g not in gks.keys:
+                gks.keys[g] = ev.NewEvaluationKey(uniform(rng, C4_Q, N, (beta, 2)), uniform(rng, C4_P, N, (beta, 2)))
+
+    def diag():
+        return (la.Poly(rq, L).upload(uniform(rng, C4_Q, N)), la.Poly(rp, len(C4_P)).upload(uniform(rng, C4_P, N)))
+
+    lte = LT.LinTransEvaluator(ev, gks)
+    for name, diags, N1 in (("BSGS 32 diagonals (N1=8: 7 baby + 3 giant rotations)", list(range(32)), 8),
+                            ("naive 8 diagonals (single hoisting)", list(range(8)), 0)):
+        need(LT.GaloisElements(nth, diags, slots, -1) if N1 == 0 else
+             [R.GaloisElement(nth, r) for r in sum(LT.BSGSIndex(diags, slots, N1)[1:], []) if r])
+        lt = LT.LinearTransformation({d: diag() for d in diags}, L - 1, len(C4_P) - 1, slots, N1)
+        o2 = [la.Poly(rq, L, B) for _ in range(2)]
+        ms = timed(ctx, lambda: lte.EvaluateMany(L - 1, ct, [lt], [o2]), 3, warm=1)
+        ctx.prof_begin()
+        lte.EvaluateMany(L - 1, ct, [lt], [o2])
+        prof = ctx.prof_end()
+        out.append({"config": "lintrans", "what": f"CKKS logN=16 L=20 alpha=4: lintrans.EvaluateMany, {name}", "batch": B,
+                    "ms": ms, "ops_per_s": B / (ms * 1e-3),
+                    "kernel_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}})
+        del lt
+    ise = R.InnerSumEvaluator(ev, gks)
+    need(R.GaloisElementsForInnerSum(nth, 1, 64))
+    o2 = [la.Poly(rq, L, B) for _ in range(2)]
+    ms = timed(ctx, lambda: ise.InnerSum(L - 1, ct, 1, 64, o2), 3, warm=1)
+    out.append({"config": "innersum", "what": "CKKS logN=16 L=20 alpha=4: InnerSum(batch=1, n=64) (6 hoisted rotations)",
+                "batch": B, "ms": ms, "ops_per_s": B / (ms * 1e-3)})
     for line in out:
         print(json.dumps(line))
 
