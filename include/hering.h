@@ -260,6 +260,20 @@ int he_bgv_mul_relin(he_handle eval, int level, uint64_t t, he_handle a0, he_han
 /* CKKS / BGV Evaluator.Rescale (ckks :477, bgv :1363) is, per ciphertext component,
  * he_div_round_by_last_modulus_many_ntt above. */
 
+/* ---- fused driver step for circuits/common/lintrans --------------------------------------- */
+/* Inner accumulation of lintrans.Evaluator.MultiplyByDiagMatrixBSGS / MultiplyByDiagMatrix
+ * (circuits/common/lintrans/lintrans_evaluator.go:346-394 and :216-241): for k = 0,1
+ *   out_k = Reduce( [out_k +] sum_{i<n} MulCoeffsMontgomeryLazy(pt_i, phi_i(ct_i[k])) )   over Q limbs 0..levelQ and
+ * P limbs 0..levelP, i.e. the canonical value of the reference's ringqp MulCoeffsMontgomeryLazy[ThenAddLazy] / Reduce
+ * chain (resp. MulCoeffsMontgomery[ThenAdd]).  Arrays have n entries (n <= 64).  ptQ/ptP: encoded diagonals (batch 1
+ * broadcasts).  ctkP[i] == 0: term i has no P part (the P*ct term of the zero rotation, :349-352).  index[i] != 0: the
+ * ciphertext of term i is read through that automorphism index (fuses AutomorphismNTTWithIndex, :224-225);
+ * index == NULL: no automorphisms.  accumulate != 0 adds to the current (canonical) content of out. */
+int he_lintrans_mul_sum(he_handle eval, int levelQ, int levelP, int n, const he_handle *ptQ, const he_handle *ptP,
+                        const he_handle *ct0Q, const he_handle *ct0P, const he_handle *ct1Q, const he_handle *ct1P,
+                        const he_handle *index, int accumulate, he_handle out0Q, he_handle out0P, he_handle out1Q,
+                        he_handle out1P);
+
 /* ---- diagnostics (not part of the reference surface) --------------------------------- */
 /* per-kernel HIP-event timing on the context's stream: begin, run work, end -> per kernel id
  * launch counts and summed durations (bench.py's roofline leg; adds two events per launch) */

@@ -1959,6 +1959,72 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     return HE_OK;
 }
 
+// inner accumulation of the lintrans drivers (see hering.h)
+int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_handle *ptQ, const he_handle *ptP,
+                        const he_handle *ct0Q, const he_handle *ct0P, const he_handle *ct1Q, const he_handle *ct1P,
+                        const he_handle *index, int accumulate, he_handle o0Q, he_handle o0P, he_handle o1Q, he_handle o1P) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    BasisExtender &be = *ev->be;
+    const char *who = "he_lintrans_mul_sum";
+    if (n < 0 || n > kMaxDiag) return fail(HE_EINVAL, "%s: n must be in [0, %d]", who, kMaxDiag);
+    if (levelQ < 0 || levelQ >= be.LQ || levelP < 0 || levelP >= be.LP) return fail(HE_EINVAL, "%s: level out of range", who);
+    if (n > 0 && (!ptQ || !ptP || !ct0Q || !ct0P || !ct1Q || !ct1P)) return fail(HE_EINVAL, "%s: null array", who);
+    GET(q0, Poly, o0Q, T_POLY);
+    GET(p0, Poly, o0P, T_POLY);
+    GET(q1, Poly, o1Q, T_POLY);
+    GET(p1, Poly, o1P, T_POLY);
+    const int B = q0->batch;
+    QPOut o;
+    TRY(get_qp_out(o0Q, o0P, o1Q, o1P, be, levelQ, levelP, B, o, who));
+    DiagMacArgs aq{}, ap{};
+    aq.n = ap.n = n;
+    aq.nlimbs = levelQ + 1; ap.nlimbs = levelP + 1;
+    aq.accumulate = ap.accumulate = accumulate ? 1 : 0;
+    aq.mod0 = 0; ap.mod0 = be.LQ;
+    std::vector<std::shared_ptr<Obj>> keep;  // inputs stay alive until the launches are enqueued
+    for (int i = 0; i < n; i++) {
+        GET(tq, Poly, ptQ[i], T_POLY);
+        GET(c0q, Poly, ct0Q[i], T_POLY);
+        GET(c1q, Poly, ct1Q[i], T_POLY);
+        TRY(check_be_poly(*tq, be, levelQ + 1, who));
+        TRY(check_be_poly(*c0q, be, levelQ + 1, who));
+        TRY(check_be_poly(*c1q, be, levelQ + 1, who));
+        if ((tq->batch != 1 && tq->batch != B) || c0q->batch != B || c1q->batch != B) return fail(HE_EINVAL, "%s: batch mismatch (term %d)", who, i);
+        if (c0q->d == q0->d || c0q->d == q1->d || c1q->d == q0->d || c1q->d == q1->d) return fail(HE_EINVAL, "%s: an input aliases the output", who);
+        const uint32_t *ix = nullptr;
+        if (index && index[i]) {
+            GET(ixo, AutoIndex, index[i], T_INDEX);
+            if (ixo->N != be.Q->N) return fail(HE_EINVAL, "%s: automorphism index of another degree", who);
+            ix = ixo->d;
+            keep.push_back(ixo);
+        }
+        aq.pt[i] = tq->d; aq.pt_bs[i] = tq->batch == 1 ? 0 : tq->view().bstride;
+        aq.c0[i] = c0q->d; aq.c0_bs[i] = c0q->view().bstride;
+        aq.c1[i] = c1q->d; aq.c1_bs[i] = c1q->view().bstride;
+        aq.index[i] = ap.index[i] = ix;
+        keep.push_back(tq); keep.push_back(c0q); keep.push_back(c1q);
+        if ((ct0P[i] == 0) != (ct1P[i] == 0)) return fail(HE_EINVAL, "%s: term %d has only one P part", who, i);
+        if (ct0P[i] == 0) { ap.pt[i] = nullptr; ap.c0[i] = ap.c1[i] = nullptr; continue; }
+        GET(tp, Poly, ptP[i], T_POLY);
+        GET(c0p, Poly, ct0P[i], T_POLY);
+        GET(c1p, Poly, ct1P[i], T_POLY);
+        TRY(check_be_poly(*tp, be, levelP + 1, who));
+        TRY(check_be_poly(*c0p, be, levelP + 1, who));
+        TRY(check_be_poly(*c1p, be, levelP + 1, who));
+        if ((tp->batch != 1 && tp->batch != B) || c0p->batch != B || c1p->batch != B) return fail(HE_EINVAL, "%s: batch mismatch (term %d)", who, i);
+        if (c0p->d == p0->d || c0p->d == p1->d || c1p->d == p0->d || c1p->d == p1->d) return fail(HE_EINVAL, "%s: an input aliases the output", who);
+        ap.pt[i] = tp->d; ap.pt_bs[i] = tp->batch == 1 ? 0 : tp->view().bstride;
+        ap.c0[i] = c0p->d; ap.c0_bs[i] = c0p->view().bstride;
+        ap.c1[i] = c1p->d; ap.c1_bs[i] = c1p->view().bstride;
+        keep.push_back(tp); keep.push_back(c0p); keep.push_back(c1p);
+    }
+    Scope sc(be.ctx.get());
+    hipStream_t st = be.ctx->stream;
+    HIP_TRY(launch_diag_mac(be.qp, aq, o.q0->view(), o.q1->view(), B, st));
+    HIP_TRY(launch_diag_mac(be.qp, ap, o.p0->view(), o.p1->view(), B, st));
+    return HE_OK;
+}
+
 // CKKS mulRelin / BGV tensorStandard (schemes/ckks/evaluator.go:764-872, schemes/bgv/evaluator.go:592-685)
 static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_handle ha0, he_handle ha1, he_handle hb0, he_handle hb1,
                             he_handle hk, he_handle hout0, he_handle hout1, he_handle hout2, const char *who) {

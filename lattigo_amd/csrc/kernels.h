@@ -189,6 +189,21 @@ struct KsArgs {
 hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
                            View out0P, View out1Q, View out1P, int batch, hipStream_t s);
 
+// Plaintext-diagonal x ciphertext multiply-accumulate (inner loop of lintrans, circuits/common/lintrans/
+// lintrans_evaluator.go:346-394): out_k = Reduce(prev_k + sum_i MulCoeffsMontgomeryLazy(pt_i, ct_i[k])), k = 0,1, for the
+// limbs [0, nlimbs) of one ring; exact 128-bit accumulation and one Montgomery reduction, i.e. the canonical value of the
+// reference's lazy accumulation after its final Reduce.  pt_i is shared by the batch (bstride 0) or per entry; a term may
+// be read through an automorphism index (gather), which fuses AutomorphismNTTWithIndex into the product.
+constexpr int kMaxDiag = 64;
+struct DiagMacArgs {
+    int n, nlimbs, accumulate;
+    int mod0;                                                    // modulus record of limb 0 in the ring's table
+    const uint64_t *pt[kMaxDiag], *c0[kMaxDiag], *c1[kMaxDiag];  // c0/c1 null: the term is skipped on this ring
+    const uint32_t *index[kMaxDiag];                             // null: identity
+    size_t pt_bs[kMaxDiag], c0_bs[kMaxDiag], c1_bs[kMaxDiag];
+};
+hipError_t launch_diag_mac(const RingDev &r, const DiagMacArgs &a, View out0, View out1, int batch, hipStream_t s);
+
 // Fused "forward row NTT + key multiply-accumulate" for limbs below 2^47 (double-precision path): one workgroup
 // owns (row, limb, batch entry) and loops over the beta digits; every non-own digit's row is transformed in LDS and
 // multiplied by the two key rows straight out of LDS, the own digit's row is read from the NTT-domain input, the two
@@ -215,7 +230,7 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
 enum KernelId {
     K_NTT_COLS_FWD = 0, K_NTT_ROWS_FWD, K_NTT_ROWS_INV, K_NTT_COLS_INV, K_EW, K_GATHER, K_AUTO_COEFF, K_INDEX,
     K_MODUP, K_CENTER, K_KS_INNER, K_TENSOR, K_PROBE, K_CI_FOLD, K_MASK_SPREAD, K_NTT_ROWS_FWD_F64, K_NTT_ROWS_INV_F64,
-    K_NTT_MAC_F64, K_COUNT
+    K_NTT_MAC_F64, K_DIAG_MAC, K_COUNT
 };
 const char *kernel_name(int id);
 void prof_begin();                                   // start recording (one stream at a time)

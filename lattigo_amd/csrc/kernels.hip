@@ -47,7 +47,7 @@ const char *kernel_name(int id) {
     static const char *names[K_COUNT] = {"ntt_cols_fwd", "ntt_rows_fwd", "ntt_rows_inv", "ntt_cols_inv", "ew", "gather",
                                          "automorphism_coeff", "build_index", "modup", "center_copy", "ks_inner",
                                          "tensor", "modmul_probe", "ci_fold", "mask_spread", "ntt_rows_fwd_f64",
-                                         "ntt_rows_inv_f64", "ntt_mac_f64"};
+                                         "ntt_rows_inv_f64", "ntt_mac_f64", "diag_mac"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 void prof_begin() { g_prof_recs.clear(); g_prof_on = true; }
@@ -1628,6 +1628,81 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own
     if (bb == 4) hipLaunchKernelGGL((ks_inner_kernel<4>), grid, block, 0, s, A);
     else if (bb == 2) hipLaunchKernelGGL((ks_inner_kernel<2>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((ks_inner_kernel<1>), grid, block, 0, s, A);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// plaintext-diagonal x ciphertext multiply-accumulate (see kernels.h)
+// ------------------------------------------------------------------------------------
+struct DiagMacKArgs {
+    DiagMacArgs a;
+    uint64_t *o0, *o1;
+    size_t o0_bs, o1_bs;
+    const ModConst *mc;
+    int N, batch;
+};
+template <int BB>
+__global__ void __launch_bounds__(256) diag_mac_kernel(const DiagMacKArgs A) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= A.N) return;
+    const int l = blockIdx.y;
+    const int b0 = blockIdx.z * BB;
+    const ModConst m = A.mc[A.a.mod0 + l];
+    const uint64_t q = m.q;
+    uint64_t hi0[BB], lo0[BB], hi1[BB], lo1[BB];
+#pragma unroll
+    for (int b = 0; b < BB; b++) { hi0[b] = lo0[b] = hi1[b] = lo1[b] = 0; }
+    const size_t lo = (size_t)l * A.N;
+    for (int i = 0; i < A.a.n; i++) {
+        if (A.a.c0[i] == nullptr) continue;  // block-uniform
+        const int xi = A.a.index[i] ? (int)A.a.index[i][x] : x;
+        const uint64_t *pp = A.a.pt[i] + lo + x;
+        const uint64_t *p0 = A.a.c0[i] + lo + xi, *p1 = A.a.c1[i] + lo + xi;
+        const size_t pbs = A.a.pt_bs[i], bs0 = A.a.c0_bs[i], bs1 = A.a.c1_bs[i];
+        uint64_t w = pp[0];
+#pragma unroll
+        for (int b = 0; b < BB; b++) {
+            if (b0 + b < A.batch) {
+                if (pbs != 0) w = pp[(size_t)(b0 + b) * pbs];
+                uint64_t ph, pl;
+                mul64wide(p0[(size_t)(b0 + b) * bs0], w, ph, pl);
+                lo0[b] += pl; hi0[b] += ph + (lo0[b] < pl);
+                hi0[b] = hi0[b] >= q ? hi0[b] - q : hi0[b];
+                mul64wide(p1[(size_t)(b0 + b) * bs1], w, ph, pl);
+                lo1[b] += pl; hi1[b] += ph + (lo1[b] < pl);
+                hi1[b] = hi1[b] >= q ? hi1[b] - q : hi1[b];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < BB; b++) {
+        if (b0 + b < A.batch) {
+            uint64_t r0 = cred(mred128_lazy(hi0[b], lo0[b], q, m.qinv), q);
+            uint64_t r1 = cred(mred128_lazy(hi1[b], lo1[b], q, m.qinv), q);
+            uint64_t *o0 = A.o0 + (size_t)(b0 + b) * A.o0_bs + lo + x, *o1 = A.o1 + (size_t)(b0 + b) * A.o1_bs + lo + x;
+            if (A.a.accumulate) {
+                r0 = cred(r0 + bred_add(*o0, q, m.brc0), q);
+                r1 = cred(r1 + bred_add(*o1, q, m.brc0), q);
+            }
+            *o0 = r0;
+            *o1 = r1;
+        }
+    }
+}
+
+hipError_t launch_diag_mac(const RingDev &r, const DiagMacArgs &a, View out0, View out1, int batch, hipStream_t s) {
+    if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
+    if (a.n < 0 || a.n > kMaxDiag) return hipErrorInvalidValue;
+    DiagMacKArgs A;
+    A.a = a;
+    A.o0 = out0.p; A.o1 = out1.p; A.o0_bs = out0.bstride; A.o1_bs = out1.bstride;
+    A.mc = r.mc; A.N = r.N; A.batch = batch;
+    const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
+    dim3 grid((unsigned)((r.N + 255) / 256), a.nlimbs, (batch + bb - 1) / bb), block(256);
+    ProfScope ps(K_DIAG_MAC, s);
+    if (bb == 4) hipLaunchKernelGGL((diag_mac_kernel<4>), grid, block, 0, s, A);
+    else if (bb == 2) hipLaunchKernelGGL((diag_mac_kernel<2>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((diag_mac_kernel<1>), grid, block, 0, s, A);
     return hipGetLastError();
 }
 

@@ -6,9 +6,13 @@ job, circuits/common/lintrans/lintrans.go:205) stays on the host: a ``LinearTran
 diagonals as QP polynomials in the NTT + Montgomery domain."""
 from __future__ import annotations
 
-from .ring import Poly
+import ctypes as C
+
+from ._lib import H, check, load
+from .ring import BasisExtender, Poly
 from .rlwe import Decomposition, Evaluator, GaloisElement, GaloisKeySet
-from .ring import BasisExtender
+
+MAX_TERMS = 64  # terms per he_lintrans_mul_sum call
 
 
 def BSGSIndex(nonZeroDiags, slots: int, N1: int):
@@ -89,6 +93,21 @@ class LinTransEvaluator:
     def _qp(self, levelQ, levelP, B):
         return (Poly(self.ringQ, levelQ + 1, B), Poly(self.ringP, levelP + 1, B))
 
+    def _mul_sum(self, levelQ, levelP, terms, out0, out1, accumulate=False):
+        """out_k = Reduce([out_k +] sum_i MulCoeffsMontgomeryLazy(pt_i, phi_i(ct_i[k]))) on QP in one pass per ring
+        (he_lintrans_mul_sum): the canonical value of the reference's per-diagonal MulCoeffsMontgomeryLazy[ThenAddLazy] +
+        Reduce chain.  terms = [(ptQP, ct0QP, ct1QP, index or None)]; a ciphertext P part of None means "no P part"."""
+        for lo in range(0, max(len(terms), 1), MAX_TERMS):
+            chunk = terms[lo: lo + MAX_TERMS]
+            n = len(chunk)
+            arr = lambda f: (H * max(n, 1))(*[f(t) for t in chunk])
+            hp = lambda p: p.h if p is not None else 0
+            check(load().he_lintrans_mul_sum(
+                self.eval.h, levelQ, levelP, n, arr(lambda t: t[0][0].h), arr(lambda t: t[0][1].h),
+                arr(lambda t: t[1][0].h), arr(lambda t: hp(t[1][1])), arr(lambda t: t[2][0].h), arr(lambda t: hp(t[2][1])),
+                arr(lambda t: t[3].h if t[3] is not None else 0), int(accumulate or lo > 0),
+                out0[0].h, out0[1].h, out1[0].h, out1[1].h))
+
     # Evaluator.EvaluateMany (:27); ctIn = [c0, c1] NTT at level ctLevel; opOut = list of [c0, c1]
     def EvaluateMany(self, ctLevel, ctIn, linearTransformations, opOut):
         if len(opOut) < len(linearTransformations):
@@ -129,12 +148,9 @@ class LinTransEvaluator:
         levelQ, levelP = min(opOut[0].Level(), ctLevel, matrix.LevelQ), matrix.LevelP
         rQ, rP = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
         B = ctIn[0].batch
-        QiOverF = _overflow_margin(self.ringQ.ModuliChain(), levelQ)
-        PiOverF = _overflow_margin(self.ringP.ModuliChain(), levelP)
         c0P, c1P = Poly(self.ringP, levelP + 1, B), Poly(self.ringP, levelP + 1, B)
         c0OutQP, c1OutQP = (opOut[0], c0P), (opOut[1], c1P)
         ct0TimesP = Poly(self.ringQ, levelQ + 1, B)
-        tmp0QP, tmp1QP = self._qp(levelQ, levelP, B), self._qp(levelQ, levelP, B)
         cQP = [self._qp(levelQ, levelP, B), self._qp(levelQ, levelP, B)]
         ctInTmp0, ctInTmp1 = Poly(self.ringQ, levelQ + 1, B), Poly(self.ringQ, levelQ + 1, B)
         ctInTmp0.CopyLvl(levelQ, ctIn[0])
@@ -156,29 +172,9 @@ class LinTransEvaluator:
             index = self.AutomorphismIndex(galEl)
             self.eval.GadgetProductHoistedLazy(levelQ, decomp, evk, cQP)
             rQ.Add(cQP[0][0], ct0TimesP, cQP[0][0])
-            for src, dst in ((cQP[0], tmp0QP), (cQP[1], tmp1QP)):
-                rQ.AutomorphismNTTWithIndex(src[0], index, dst[0])
-                rP.AutomorphismNTTWithIndex(src[1], index, dst[1])
-            pt = matrix.Vec[k]
-            for tmp, out in ((tmp0QP, c0OutQP), (tmp1QP, c1OutQP)):
-                if i == 0:
-                    rQ.MulCoeffsMontgomery(pt[0], tmp[0], out[0])
-                    rP.MulCoeffsMontgomery(pt[1], tmp[1], out[1])
-                else:
-                    rQ.MulCoeffsMontgomeryThenAdd(pt[0], tmp[0], out[0])
-                    rP.MulCoeffsMontgomeryThenAdd(pt[1], tmp[1], out[1])
-            if i % QiOverF == QiOverF - 1:
-                rQ.Reduce(c0OutQP[0], c0OutQP[0])
-                rQ.Reduce(c1OutQP[0], c1OutQP[0])
-            if i % PiOverF == PiOverF - 1:
-                rP.Reduce(c0OutQP[1], c0OutQP[1])
-                rP.Reduce(c1OutQP[1], c1OutQP[1])
-        if len(keys) % QiOverF == 0:
-            rQ.Reduce(c0OutQP[0], c0OutQP[0])
-            rQ.Reduce(c1OutQP[0], c1OutQP[0])
-        if len(keys) % PiOverF == 0:
-            rP.Reduce(c0OutQP[1], c0OutQP[1])
-            rP.Reduce(c1OutQP[1], c1OutQP[1])
+            # AutomorphismNTTWithIndex + MulCoeffsMontgomery[ThenAdd] on QP (:224-241) in one fused pass per ring; the
+            # accumulator stays canonical, so the reference's periodic Reduce calls (:243-262) are no-ops here
+            self._mul_sum(levelQ, levelP, [(matrix.Vec[k], cQP[0], cQP[1], index)], c0OutQP, c1OutQP, accumulate=i > 0)
         self.be.ModDownQPtoQNTT(levelQ, levelP, c0OutQP[0], c0OutQP[1], c0OutQP[0])  # sum(phi(c0*P + d0_QP))/P
         self.be.ModDownQPtoQNTT(levelQ, levelP, c1OutQP[0], c1OutQP[1], c1OutQP[0])  # sum(phi(d1_QP))/P
         if state:  # rotation by zero
@@ -207,40 +203,17 @@ class LinTransEvaluator:
         rQ.MulScalarBigint(ctInTmp1, P, ctInTmp1)  # P*c1
         cnt0 = 0
         for j in sorted(index.keys()):  # outer loop
-            cnt1 = 0
-            for i in index[j]:  # inner loop
+            # inner loop (:342-394): tmp_k = Reduce(sum_i pt_{j+i} (.) ct_i[k]), one fused pass instead of one
+            # MulCoeffsMontgomeryLazy[ThenAddLazy] launch per diagonal plus the periodic Reduce calls
+            terms = []
+            for i in index[j]:
                 pt = matrix.Vec[j + i]
                 if i == 0:
-                    if cnt1 == 0:
-                        rQ.MulCoeffsMontgomeryLazy(pt[0], ctInTmp0, tmp0QP[0])
-                        rQ.MulCoeffsMontgomeryLazy(pt[0], ctInTmp1, tmp1QP[0])
-                        tmp0QP[1].Zero()
-                        tmp1QP[1].Zero()
-                    else:
-                        rQ.MulCoeffsMontgomeryLazyThenAddLazy(pt[0], ctInTmp0, tmp0QP[0])
-                        rQ.MulCoeffsMontgomeryLazyThenAddLazy(pt[0], ctInTmp1, tmp1QP[0])
+                    terms.append((pt, (ctInTmp0, None), (ctInTmp1, None), None))  # P*ct, no P part (:349-352)
                 else:
                     ct = ctInPreRot[i]
-                    for src, dst in ((ct[0], tmp0QP), (ct[1], tmp1QP)):
-                        if cnt1 == 0:
-                            rQ.MulCoeffsMontgomeryLazy(pt[0], src[0], dst[0])
-                            rP.MulCoeffsMontgomeryLazy(pt[1], src[1], dst[1])
-                        else:
-                            rQ.MulCoeffsMontgomeryLazyThenAddLazy(pt[0], src[0], dst[0])
-                            rP.MulCoeffsMontgomeryLazyThenAddLazy(pt[1], src[1], dst[1])
-                if cnt1 % QiOverF == QiOverF - 1:
-                    rQ.Reduce(tmp0QP[0], tmp0QP[0])
-                    rQ.Reduce(tmp1QP[0], tmp1QP[0])
-                if cnt1 % PiOverF == PiOverF - 1:
-                    rP.Reduce(tmp0QP[1], tmp0QP[1])
-                    rP.Reduce(tmp1QP[1], tmp1QP[1])
-                cnt1 += 1
-            if cnt1 % QiOverF != 0:
-                rQ.Reduce(tmp0QP[0], tmp0QP[0])
-                rQ.Reduce(tmp1QP[0], tmp1QP[0])
-            if cnt1 % PiOverF != 0:
-                rP.Reduce(tmp0QP[1], tmp0QP[1])
-                rP.Reduce(tmp1QP[1], tmp1QP[1])
+                    terms.append((pt, ct[0], ct[1], None))
+            self._mul_sum(levelQ, levelP, terms, tmp0QP, tmp1QP)
             if j != 0:
                 # hoisting of the ModDown of sum(sum(phi(d1) * plaintext)) (:397)
                 self.be.ModDownQPtoQNTT(levelQ, levelP, tmp1QP[0], tmp1QP[1], tmp1QP[0])

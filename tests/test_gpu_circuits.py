@@ -142,3 +142,57 @@ def test_evaluate_many_mixed_and_overflow_margins(ctx):
         assert np.array_equal(Rig.down(outs[k])[0], wants[k]), k
     with pytest.raises(ValueError):
         ge.EvaluateMany(2, rg.up(ct), [g1, g2], [outs[0]])
+
+
+def test_lintrans_mul_sum_kernel(ctx):
+    """he_lintrans_mul_sum against the reference's op chain (MulCoeffsMontgomeryLazy[ThenAddLazy] + Reduce, resp.
+    AutomorphismNTTWithIndex + MulCoeffsMontgomery[ThenAdd]): gather, accumulate, broadcast and per-entry plaintexts,
+    terms without a P part, more terms than one launch takes, lazy (non-canonical) ciphertext words."""
+    rg = Rig(ctx, 10, [61, 45, 58], [61, 46], 4500)
+    N, B, lq, lp = rg.N, 3, 2, 1
+    rng, oQ, oP = rg.rng, rg.pr.oQ, rg.pr.oP
+    lte = LT.LinTransEvaluator(rg.gev, rg.ggks)
+    for n, with_index, per_entry_pt in ((1, True, False), (5, False, True), (70, True, False)):
+        terms, oterms = [], []
+        for i in range(n):
+            ptq, ptp = uniform_poly(rng, rg.q, N), uniform_poly(rng, rg.p, N)
+            if per_entry_pt:
+                ptq, ptp = np.stack([ptq] * B), np.stack([ptp] * B)
+                ptq[1] = uniform_poly(rng, rg.q, N)
+                ptp[1] = uniform_poly(rng, rg.p, N)
+            cq = rng.integers(0, 1 << 64, size=(2, B, lq + 1, N), dtype=np.uint64)  # arbitrary 64-bit words
+            cp = rng.integers(0, 1 << 64, size=(2, B, lp + 1, N), dtype=np.uint64)
+            no_p = (i % 4 == 3)
+            gal = pow(5, i + 1, 2 * N) if with_index and i % 2 == 0 else None
+            gpt = (la.Poly(rg.pr.gQ, lq + 1, B if per_entry_pt else 1).upload(ptq),
+                   la.Poly(rg.pr.gP, lp + 1, B if per_entry_pt else 1).upload(ptp))
+            g0 = (la.Poly(rg.pr.gQ, lq + 1, B).upload(cq[0]), None if no_p else la.Poly(rg.pr.gP, lp + 1, B).upload(cp[0]))
+            g1 = (la.Poly(rg.pr.gQ, lq + 1, B).upload(cq[1]), None if no_p else la.Poly(rg.pr.gP, lp + 1, B).upload(cp[1]))
+            terms.append((gpt, g0, g1, lte.AutomorphismIndex(gal) if gal else None))
+            oterms.append((ptq, ptp, cq, cp, no_p, gal))
+        out0 = (la.Poly(rg.pr.gQ, lq + 1, B), la.Poly(rg.pr.gP, lp + 1, B))
+        out1 = (la.Poly(rg.pr.gQ, lq + 1, B), la.Poly(rg.pr.gP, lp + 1, B))
+        prevq = np.stack([np.stack([uniform_poly(rng, rg.q, N) for _ in range(B)]) for _ in range(2)])
+        prevp = np.stack([np.stack([uniform_poly(rng, rg.p, N) for _ in range(B)]) for _ in range(2)])
+        for acc in (False, True):
+            for k, o in enumerate((out0, out1)):
+                o[0].upload(prevq[k])
+                o[1].upload(prevp[k])
+            lte._mul_sum(lq, lp, terms, out0, out1, accumulate=acc)
+            got = [(out0[0].download(), out0[1].download()), (out1[0].download(), out1[1].download())]
+            for k in range(2):
+                for b in range(B):
+                    wq = prevq[k][b].copy() if acc else np.zeros((lq + 1, N), dtype=np.uint64)
+                    wp = prevp[k][b].copy() if acc else np.zeros((lp + 1, N), dtype=np.uint64)
+                    for ptq, ptp, cq, cp, no_p, gal in oterms:
+                        tq, tp = (ptq[b], ptp[b]) if per_entry_pt else (ptq, ptp)
+                        xq, xp = cq[k][b], cp[k][b]
+                        if gal:
+                            xq = oQ.AutomorphismNTTWithIndex(xq, oQ.AutomorphismNTTIndex(gal))
+                            xp = oP.AutomorphismNTTWithIndex(xp, oP.AutomorphismNTTIndex(gal))
+                        wq = oQ.binop("MulCoeffsMontgomeryThenAdd", tq, xq, wq)
+                        if not no_p:
+                            wp = oP.binop("MulCoeffsMontgomeryThenAdd", tp, xp, wp)
+                    assert np.array_equal(got[k][0][b], wq) and np.array_equal(got[k][1][b], wp), (n, acc, k, b)
+    with pytest.raises(la.HeringError):  # an input aliasing the output
+        lte._mul_sum(lq, lp, [(terms[0][0], out0, terms[0][2], None)], out0, out1)
