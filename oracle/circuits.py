@@ -296,3 +296,69 @@ class LinTransEvaluator:
         if cnt0 % PiOverF != 0:
             outP = [rP.unop("Reduce", x) for x in outP]
         return np.stack([self.be.ModDownQPtoQNTT(levelQ, levelP, outQ[t], outP[t]) for t in range(2)])
+
+
+class ScaleInvariantEvaluator:
+    """BFV-style multiplication of the bgv package: Evaluator.tensorScaleInvariant + modUpAndNTT + tensorLowDeg +
+    quantize (schemes/bgv/evaluator.go:898-1071), precomputation newEvaluatorPrecomp (:38-70)."""
+
+    def __init__(self, evaluator: O.Evaluator, ringQMul: O.Ring, t: int):
+        self.eval, self.t = evaluator, int(t)
+        self.ringQ, self.ringQMul = evaluator.ringQ, ringQMul
+        self.be = O.BasisExtender(self.ringQ, ringQMul)  # basisExtenderQ1toQ2 (:58)
+        logN = self.ringQ.N.bit_length() - 1
+        self.levelQMul = []
+        Q = 1
+        for m in self.ringQ.moduli:  # :43-48
+            Q *= int(m)
+            self.levelQMul.append(-(-(Q.bit_length() + logN) // 61) - 1)
+
+    def _mod_up_and_ntt(self, level, lm, ct):
+        """:991-1001"""
+        out = []
+        for c in ct:
+            buff = self.ringQ.INTT(c[: level + 1])
+            out.append(self.ringQMul.NTTLazy(self.be.ModUpQtoP(level, lm, buff)))
+        return out
+
+    def _quantize(self, level, lm, c2Q1, c2Q2):
+        """:1050-1071"""
+        c2Q1 = self.ringQ.INTTLazy(c2Q1)
+        c2Q2 = self.ringQMul.INTTLazy(c2Q2)
+        c2Q2 = self.be.ModDownQPtoP(level, lm, c2Q1, c2Q2)       # QP / Q -> P
+        c2Q1 = self.be.ModUpPtoQ(lm, level, c2Q2)                # centred, back to Q
+        c2Q1 = self.ringQ.scalarop("MulScalar", c2Q1, self.t)    # (ct/Q) * T
+        return self.ringQ.NTT(c2Q1)
+
+    def MulRelinScaleInvariant(self, ct0, ct1, rlk=None, square=False):
+        """tensorScaleInvariant (:898-972); ct0, ct1 degree-1 NTT ciphertexts at the same level; `square` is the
+        reference's ct0 == ct1 (same object) branch."""
+        ct0 = np.asarray(ct0, dtype=np.uint64)
+        ct1 = ct0 if square else np.asarray(ct1, dtype=np.uint64)
+        level = ct0.shape[1] - 1
+        lm = self.levelQMul[level]
+        rQ, rM = self.ringQ, self.ringQMul
+        t0M = self._mod_up_and_ntt(level, lm, ct0)
+        t1M = t0M if square else self._mod_up_and_ntt(level, lm, ct1)
+        # tensorLowDeg (:1003-1048)
+        c00, c01 = rQ.unop("MForm", ct0[0]), rQ.unop("MForm", ct0[1])
+        c00M, c01M = rM.unop("MForm", t0M[0]), rM.unop("MForm", t0M[1])
+        if square:
+            q = [rQ.binop("MulCoeffsMontgomery", c00, ct0[0]), rQ.binop("MulCoeffsMontgomery", c00, ct0[1]),
+                 rQ.binop("MulCoeffsMontgomery", c01, ct0[1])]
+            q[1] = rQ.binop("AddLazy", q[1], q[1])
+            m = [rM.binop("MulCoeffsMontgomery", c00M, t0M[0]), rM.binop("MulCoeffsMontgomery", c00M, t0M[1]),
+                 rM.binop("MulCoeffsMontgomery", c01M, t0M[1])]
+            m[1] = rM.binop("AddLazy", m[1], m[1])
+        else:
+            q = [rQ.binop("MulCoeffsMontgomery", c00, ct1[0]), rQ.binop("MulCoeffsMontgomery", c00, ct1[1]),
+                 rQ.binop("MulCoeffsMontgomery", c01, ct1[1])]
+            q[1] = rQ.binop("MulCoeffsMontgomeryThenAddLazy", c01, ct1[0], q[1])
+            m = [rM.binop("MulCoeffsMontgomery", c00M, t1M[0]), rM.binop("MulCoeffsMontgomery", c00M, t1M[1]),
+                 rM.binop("MulCoeffsMontgomery", c01M, t1M[1])]
+            m[1] = rM.binop("MulCoeffsMontgomeryThenAddLazy", c01M, t1M[0], m[1])
+        out = [self._quantize(level, lm, q[k], m[k]) for k in range(3)]
+        if rlk is None:
+            return np.stack(out)
+        tmp = self.eval.GadgetProduct(level, out[2], rlk)  # :966-969
+        return np.stack([rQ.binop("Add", out[0], tmp[0]), rQ.binop("Add", out[1], tmp[1])])

@@ -145,3 +145,47 @@ def small_plaintext_qp(rng, ringQ: O.Ring, ringP: O.Ring, bound: int = 8):
     vals = rng.integers(-bound, bound + 1, size=ringQ.N)
     return (ringQ.unop("MForm", ringQ.NTT(small_to_rns(vals, ringQ.moduli))),
             ringP.unop("MForm", ringP.NTT(small_to_rns(vals, ringP.moduli))))
+
+
+def downstream_primes(bits: int, nth_root: int, n: int, avoid=()):
+    """ring.NTTFriendlyPrimesGenerator.NextDownstreamPrimes (ring/primes.go): primes 2^bits + 1 - k*nth_root, k >= 1."""
+    out, x = [], (1 << bits) + 1
+    while len(out) < n:
+        x -= nth_root
+        if O.IsPrime(x) and x not in avoid:
+            out.append(x)
+    return out
+
+
+def bfv_encrypt(rng, ringQ: O.Ring, sk: SecretKey, m, t: int, sigma: float = 3.2) -> np.ndarray:
+    """(c0, c1) NTT with phase floor(Q/t) * m + e (BFV / the bgv package's MSB encoding at scale 1)."""
+    Q = prod(ringQ.moduli)
+    delta = Q // t
+    N = ringQ.N
+    e = np.clip(np.rint(rng.normal(0.0, sigma, size=N)), -19, 19).astype(np.int64)
+    pt = [(int(mi) * delta + int(ei)) % Q for mi, ei in zip(m, e)]
+    ptr = np.array([[x % int(qi) for x in pt] for qi in ringQ.moduli], dtype=np.uint64)
+    c1 = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringQ.moduli])
+    c0 = ringQ.binop("Sub", ringQ.NTT(ptr), ringQ.binop("MulCoeffsMontgomery", c1, sk.Q))
+    return np.stack([c0, c1])
+
+
+def bfv_decrypt(ringQ: O.Ring, ct: np.ndarray, sk: SecretKey, t: int):
+    """round(t/Q * centred phase) mod t, coefficient domain"""
+    Q = prod(ringQ.moduli)
+    ph = ringQ.INTT(phase(ringQ, ct, sk.Q))
+    w = [(Q // int(qi)) * pow(Q // int(qi), -1, int(qi)) for qi in ringQ.moduli]
+    out = []
+    for j in range(ringQ.N):
+        x = sum(int(ph[i, j]) * w[i] for i in range(len(w))) % Q
+        if x > Q // 2:
+            x -= Q
+        out.append(((2 * x * t + Q) // (2 * Q)) % t)
+    return np.array(out, dtype=np.int64)
+
+
+def negacyclic_mul_mod(a, b, t: int):
+    N = len(a)
+    full = np.convolve(np.asarray(a, dtype=object), np.asarray(b, dtype=object))
+    out = [int(full[k]) - (int(full[k + N]) if k + N < len(full) else 0) for k in range(N)]
+    return np.array([x % t for x in out], dtype=np.int64)

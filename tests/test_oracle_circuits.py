@@ -9,7 +9,8 @@ from oracle import circuits as OC
 from oracle import oracle as O
 from tests.conftest import Pi60, Qi60
 from tests.helpers import rng_for, uniform_poly
-from tests.rlwe_fixtures import SecretKey, gen_galois_keys, noise_log2, phase, small_plaintext_qp
+from tests.rlwe_fixtures import (SecretKey, bfv_decrypt, bfv_encrypt, downstream_primes, gen_evaluation_key, gen_galois_keys,
+                                 negacyclic_mul_mod, noise_log2, phase, small_plaintext_qp)
 
 N = 1 << 9
 NTH = 2 * N
@@ -153,3 +154,31 @@ def test_host_helpers_of_the_product_match_the_oracle():
     assert LT.FindBestBSGSRatio(list(range(64)), 64, 1) in (4, 8, 16)
     for k in (0, 1, -1, 5, 12345, -77):
         assert R.GaloisElement(1 << 13, k) == OC.GaloisElement(1 << 13, k) == pow(5, k % (1 << 13), 1 << 13)
+
+
+@pytest.mark.parametrize("drop", [0, 1])
+def test_scale_invariant_multiplication_decrypts(drop):
+    """BFV-style MulRelinScaleInvariant (schemes/bgv/evaluator.go:898): Dec(ct0 (x) ct1) = m0 * m1 in Z_t[X]/(X^N+1),
+    with and without relinearisation, and the squaring branch."""
+    t = 65537
+    q, p = O.GenModuli(10, [55, 45, 45], [55, 55])
+    rng = rng_for(3600 + drop)
+    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
+    nb = -(-(int(np.sum([int(x).bit_length() for x in q])) + 9) // 61)
+    ringM = O.Ring(N, downstream_primes(61, NTH, nb + 1, set(q) | set(p)))
+    ev = O.Evaluator(ringQ, ringP)
+    sk = SecretKey(rng, ringQ, ringP)
+    rlk = gen_evaluation_key(rng, ringQ, ringP, ringQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q), sk)
+    sie = OC.ScaleInvariantEvaluator(ev, ringM, t)
+    level = len(q) - 1 - drop
+    sub = sub_ring(ringQ, level)
+    m0, m1 = rng.integers(0, t, size=N), rng.integers(0, t, size=N)
+    sks = SecretKey(rng, sub, ringP, vals=sk.vals)
+    ct0, ct1 = bfv_encrypt(rng, sub, sks, m0, t), bfv_encrypt(rng, sub, sks, m1, t)
+    out = sie.MulRelinScaleInvariant(ct0, ct1, rlk)
+    assert np.array_equal(bfv_decrypt(sub, out, sks, t), negacyclic_mul_mod(m0, m1, t))
+    out3 = sie.MulRelinScaleInvariant(ct0, ct1, None)  # degree 2: decrypt with (1, s, s^2)
+    assert out3.shape[0] == 3 and np.array_equal(bfv_decrypt(sub, out3, sks, t), negacyclic_mul_mod(m0, m1, t))
+    sq = sie.MulRelinScaleInvariant(ct0, None, rlk, square=True)
+    assert np.array_equal(bfv_decrypt(sub, sq, sks, t), negacyclic_mul_mod(m0, m0, t))
+    assert np.array_equal(sq, sie.MulRelinScaleInvariant(ct0, ct0.copy(), rlk))  # both branches agree bit for bit
