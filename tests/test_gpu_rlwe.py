@@ -448,3 +448,42 @@ def test_keys_loaded_from_the_wire_format(ctx):
             ct = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
             gev.GadgetProduct(3, pcx, k, ct)
             assert np.array_equal(np.stack([c.get() for c in ct]), want)
+
+
+def test_concurrent_callers_share_an_evaluator(ctx):
+    """Since 6.2.0 every evaluator method of the reference is safe for concurrent callers (core/rlwe/evaluator.go:200-227);
+    here: 6 threads issue key-switches, NTTs and buffer churn on ONE context/evaluator/key, plus a second context
+    running alongside; every result must equal the oracle's."""
+    import threading
+    pr, rng, oev, gev, sk = _setup(ctx, 11, 5, 2, 3000)
+    oevk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, SecretKey(rng, pr.oQ, pr.oP))
+    gevk = gev.NewEvaluationKey(oevk.q, oevk.p)
+    inputs = [uniform_poly(rng, pr.q, pr.N) for _ in range(6)]
+    wants = [(oev.GadgetProduct(4, x, oevk), pr.oQ.NTT(x)) for x in inputs]
+    ctx2 = la.Context(0)
+    q2 = la.Ring(ctx2, pr.N, pr.q)
+    errs = []
+
+    def work(i):
+        try:
+            for rep in range(8):
+                if i == 5:  # a second context (own stream) running alongside
+                    p = la.Poly(q2, 5).upload(inputs[i])
+                    q2.NTT(p, p)
+                    assert np.array_equal(p.get(), wants[i][1])
+                    continue
+                pcx = _uploadQ(pr, inputs[i])
+                ct = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
+                gev.GadgetProduct(4, pcx, gevk, ct)
+                assert np.array_equal(np.stack([c.get() for c in ct]), wants[i][0]), (i, rep)
+                t = pr.gQ.NewPoly()
+                pr.gQ.NTT(pcx, t)
+                assert np.array_equal(t.get(), wants[i][1]), (i, rep)
+        except BaseException as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs, errs
+    assert not any(t.is_alive() for t in th)
