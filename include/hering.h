@@ -260,6 +260,17 @@ int he_bgv_mul_relin(he_handle eval, int level, uint64_t t, he_handle a0, he_han
 /* CKKS / BGV Evaluator.Rescale (ckks :477, bgv :1363) is, per ciphertext component,
  * he_div_round_by_last_modulus_many_ntt above. */
 
+/* ---- pieces of circuits/ckks/bootstrapping Evaluator.ModUp ------------------------------------ */
+/* The centred lifts of bootstrapping.Evaluator.ModUp (circuits/ckks/bootstrapping/evaluator.go:654-667, 677-696,
+ * 742-755): c = src[limb 0][j] (coefficient domain, modulus q = Q[0]); neg = strict ? c > q/2 : c >= q/2; c = neg ?
+ * q - c : c; every destination limb i gets t = BRedAdd(c, m_i), neg ? m_i - t : t -- Q limbs first_q..levelQ of dstQ
+ * and, when levelP >= 0, P limbs 0..levelP of dstP.  dstQ may be src itself (limbs >= 1 are written). */
+int he_centered_lift(he_handle eval, int strict, he_handle src, int first_q, int levelQ, he_handle dstQ, int levelP,
+                     he_handle dstP);
+/* Every digit of the hoisting buffer := (srcQ limbs 0..levelQ, srcP limbs 0..levelP), the way bootstrapping.ModUp fills
+ * BuffDecompQP for the sparse-to-dense key switch (evaluator.go:699-718). */
+int he_decomp_fill(he_handle decomp, int levelQ, int levelP, he_handle srcQ, he_handle srcP);
+
 /* ---- fused driver step for circuits/common/lintrans --------------------------------------- */
 /* Inner accumulation of lintrans.Evaluator.MultiplyByDiagMatrixBSGS / MultiplyByDiagMatrix
  * (circuits/common/lintrans/lintrans_evaluator.go:346-394 and :216-241): for k = 0,1

@@ -106,6 +106,8 @@ def _declare(L):
         "he_automorphism_ct": [H, i, H, H, C.c_uint64, H, H, H],
         "he_automorphism_hoisted": [H, i, H, H, C.c_uint64, H, H, H],
         "he_automorphism_hoisted_lazy": [H, i, H, H, C.c_uint64, H, H, H, H, H],
+        "he_centered_lift": [H, i, H, i, i, H, i, H],
+        "he_decomp_fill": [H, i, i, H, H],
         "he_lintrans_mul_sum": [H, i, i, i, HP, HP, HP, HP, HP, HP, HP, i, H, H, H, H],
         "he_ckks_mul_relin": [H, i, H, H, H, H, H, H, H, H],
         "he_bgv_mul_relin": [H, i, C.c_uint64, H, H, H, H, H, H, H, H],

@@ -1959,6 +1959,59 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     return HE_OK;
 }
 
+// centred lifts / hoisting-buffer fill of bootstrapping.Evaluator.ModUp (see hering.h)
+int he_centered_lift(he_handle hev, int strict, he_handle hsrc, int first_q, int levelQ, he_handle hdq, int levelP, he_handle hdp) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(src, Poly, hsrc, T_POLY);
+    GET(dq, Poly, hdq, T_POLY);
+    BasisExtender &be = *ev->be;
+    const char *who = "he_centered_lift";
+    if (first_q < 0 || levelQ >= be.LQ || first_q > levelQ + 1 || levelP >= be.LP) return fail(HE_EINVAL, "%s: level out of range", who);
+    TRY(check_be_poly(*src, be, 1, who));
+    TRY(check_be_poly(*dq, be, levelQ + 1, who));
+    if (src->batch != dq->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    std::shared_ptr<Poly> dp;
+    if (levelP >= 0) {
+        dp = get<Poly>(hdp, T_POLY);
+        if (!dp) return fail(HE_EHANDLE, "%s: bad P poly handle", who);
+        TRY(check_be_poly(*dp, be, levelP + 1, who));
+        if (dp->batch != src->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    }
+    ModUpArgs a{};
+    a.nsrc = 1;
+    a.src_limb[0] = 0;
+    a.src_mod[0] = 0;
+    int n = 0;
+    for (int i = first_q; i <= levelQ; i++, n++) { a.dst_limb[n] = (uint8_t)i; a.dst_mod[n] = (uint8_t)i; a.dst_view[n] = 0; }
+    for (int j = 0; j <= levelP; j++, n++) { a.dst_limb[n] = (uint8_t)j; a.dst_mod[n] = (uint8_t)(be.LQ + j); a.dst_view[n] = 1; }
+    a.ndst = n;
+    if (n > kMaxLimbs) return fail(HE_EINVAL, "%s: too many destination limbs", who);
+    Scope sc(be.ctx.get());
+    HIP_TRY(launch_center_copy(be.qp, a, src->view(), dq->view(), dp ? dp->view() : dq->view(), src->batch, be.ctx->stream, strict != 0));
+    return HE_OK;
+}
+int he_decomp_fill(he_handle hdec, int levelQ, int levelP, he_handle hq, he_handle hp) {
+    GET(d, Decomp, hdec, T_DECOMP);
+    GET(sq, Poly, hq, T_POLY);
+    GET(sp, Poly, hp, T_POLY);
+    BasisExtender &be = *d->ev->be;
+    const char *who = "he_decomp_fill";
+    if (levelQ < 0 || levelQ >= be.LQ || levelP < 0 || levelP >= be.LP) return fail(HE_EINVAL, "%s: level out of range", who);
+    TRY(check_be_poly(*sq, be, levelQ + 1, who));
+    TRY(check_be_poly(*sp, be, levelP + 1, who));
+    if (sq->batch != d->batch || sp->batch != d->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    Scope sc(be.ctx.get());
+    const size_t N = be.Q->N;
+    for (int dg = 0; dg < d->beta_max; dg++) {
+        uint64_t *base = d->d + (size_t)dg * d->dstride();
+        HIP_TRY(hipMemcpy2DAsync(base, d->bstride() * 8, sq->d, sq->view().bstride * 8, (size_t)(levelQ + 1) * N * 8, d->batch,
+                                 hipMemcpyDeviceToDevice, be.ctx->stream));
+        HIP_TRY(hipMemcpy2DAsync(base + (size_t)be.LQ * N, d->bstride() * 8, sp->d, sp->view().bstride * 8,
+                                 (size_t)(levelP + 1) * N * 8, d->batch, hipMemcpyDeviceToDevice, be.ctx->stream));
+    }
+    return HE_OK;
+}
+
 // inner accumulation of the lintrans drivers (see hering.h)
 int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_handle *ptQ, const he_handle *ptP,
                         const he_handle *ct0Q, const he_handle *ct0P, const he_handle *ct1Q, const he_handle *ct1P,

@@ -362,3 +362,55 @@ class ScaleInvariantEvaluator:
             return np.stack(out)
         tmp = self.eval.GadgetProduct(level, out[2], rlk)  # :966-969
         return np.stack([rQ.binop("Add", out[0], tmp[0]), rQ.binop("Add", out[1], tmp[1])])
+
+
+def ApplyEvaluationKey(ev: O.Evaluator, ct, evk):
+    """core/rlwe/evaluator_evaluationkey.go:36,98-106 (same ring degree)"""
+    ct = np.asarray(ct, dtype=np.uint64)
+    level = ct.shape[1] - 1
+    tmp = ev.GadgetProduct(level, ct[1], evk)
+    return np.stack([ev.ringQ.binop("Add", ct[0], tmp[0]), tmp[1]])
+
+
+def _centered_lift(c0, q, moduli, strict):
+    """circuits/ckks/bootstrapping/evaluator.go:654-667 / :677-696: rows for `moduli` from the limb-0 coefficients"""
+    c0 = np.asarray(c0, dtype=np.uint64)
+    half = np.uint64(q >> 1)
+    neg = (c0 > half) if strict else (c0 >= half)
+    coeff = np.where(neg, np.uint64(q) - c0, c0)
+    out = np.empty((len(moduli), c0.shape[0]), dtype=np.uint64)
+    for i, m in enumerate(moduli):
+        tmp = coeff % np.uint64(int(m))  # ring.BRedAdd: the canonical residue
+        out[i] = np.where(neg, np.uint64(int(m)) - tmp, tmp)
+    return out
+
+
+def BootstrappingModUp(ev: O.Evaluator, ise: InnerSumEvaluator, ct, scale, logSlots, EvkDenseToSparse=None,
+                       EvkSparseToDense=None):
+    """bootstrapping.Evaluator.ModUp (circuits/ckks/bootstrapping/evaluator.go:612-769); ct: [2][levelIn+1][N] NTT."""
+    ct = np.asarray(ct, dtype=np.uint64)
+    rQ, rP = ev.ringQ, ev.ringP
+    Q, P = rQ.moduli, rP.moduli
+    levelQ, levelP = len(Q) - 1, len(P) - 1
+    if EvkDenseToSparse is not None:
+        ct = ApplyEvaluationKey(ev, ct, EvkDenseToSparse)
+    c = [rQ.INTT(ct[k]) for k in range(2)]
+    q = int(Q[0])
+    c0 = np.concatenate([c[0][:1], _centered_lift(c[0][0], q, Q[1:], False)])  # :654-667
+    scalar = int(round(scale)) if scale > 1 else None
+    if EvkSparseToDense is not None:
+        dQ = rQ.NTT(_centered_lift(c[1][0], q, Q, True))  # :677-696, :699-705
+        dP = rP.NTT(_centered_lift(c[1][0], q, P, True))
+        c0 = rQ.NTT(c0)
+        if scalar is not None:  # :711-723
+            dQ, dP = rQ.scalarop("MulScalar", dQ, scalar), rP.scalarop("MulScalar", dP, scalar)
+            c0 = rQ.scalarop("MulScalar", c0, scalar)
+        beta = O.BaseRNSDecompositionVectorSize(levelQ, levelP)
+        tmp = ev.GadgetProductHoisted(levelQ, np.stack([dQ] * beta), np.stack([dP] * beta), EvkSparseToDense)  # :733
+        out = np.stack([rQ.binop("Add", c0, tmp[0]), tmp[1]])
+    else:
+        c1 = np.concatenate([c[1][:1], _centered_lift(c[1][0], q, Q[1:], False)])  # :742-755
+        out = np.stack([rQ.NTT(c0), rQ.NTT(c1)])
+        if scalar is not None:
+            out = np.stack([rQ.scalarop("MulScalar", out[k], scalar) for k in range(2)])
+    return ise.Trace(out, logSlots)  # :768

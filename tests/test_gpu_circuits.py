@@ -230,3 +230,35 @@ def test_scale_invariant_multiplication(ctx, logN, logq, logp):
             assert np.array_equal(got[b], os_.MulRelinScaleInvariant(ct0[b], ct1[b], orlk)), (level, b)
             assert np.array_equal(got3[b], os_.MulRelinScaleInvariant(ct0[b], ct1[b], None)), (level, b)
             assert np.array_equal(gots[b], os_.MulRelinScaleInvariant(ct0[b], None, orlk, square=True)), (level, b)
+
+
+@pytest.mark.parametrize("sparse,scale,logSlots,levelIn", [(False, 1000.3, 9, 0), (True, 37.6, 6, 0), (True, 0.5, 9, 1),
+                                                             (False, 1.0, 3, 2)])
+def test_bootstrapping_modup(ctx, sparse, scale, logSlots, levelIn):
+    """bootstrapping.Evaluator.ModUp (circuits/ckks/bootstrapping/evaluator.go:612-769): centred lifts with both sign
+    conventions, the hoisting buffer filled with the lifted polynomial, message rescaling, Trace; bit-exact, batch 2.
+    The first two coefficients are forced to q/2 and q/2 + 1 (where `>=` and `>` differ)."""
+    from lattigo_amd import bootstrapping as BS
+    rg = Rig(ctx, 10, [55, 45, 45, 50], [55, 46], 4700 + logSlots)
+    nth, top = 2 * rg.N, len(rg.q) - 1
+    rg.keys(R.GaloisElementsForTrace(nth, 10, logSlots) + [3, 7])
+    gi, oi = R.InnerSumEvaluator(rg.gev, rg.ggks), OC.InnerSumEvaluator(rg.oev, rg.ogks)
+    B = 2
+    coeff = rg.ct(levelIn, B)  # build in the coefficient domain so that the edge values can be planted
+    q0 = int(rg.q[0])
+    for b in range(B):
+        for k in range(2):
+            coeff[b, k, 0, :4] = [q0 >> 1, (q0 >> 1) + 1, (q0 >> 1) - 1, 0]
+    sub = O.Ring(rg.N, rg.q[: levelIn + 1])
+    ct = np.stack([np.stack([sub.NTT(coeff[b, k]) for k in range(2)]) for b in range(B)])
+    full = np.zeros((B, 2, top + 1, rg.N), dtype=np.uint64)
+    full[:, :, : levelIn + 1] = ct
+    g = [la.Poly(rg.pr.gQ, top + 1, B).upload(full[:, k]) for k in range(2)]
+    kw_g, kw_o = {}, {}
+    if sparse:
+        kw_g = dict(EvkDenseToSparse=rg.ggks.keys[3], EvkSparseToDense=rg.ggks.keys[7])
+        kw_o = dict(EvkDenseToSparse=rg.ogks[3], EvkSparseToDense=rg.ogks[7])
+    BS.ModUp(rg.gev, gi, levelIn, g, scale, logSlots, **kw_g)
+    got = Rig.down(g)
+    for b in range(B):
+        assert np.array_equal(got[b], OC.BootstrappingModUp(rg.oev, oi, ct[b], scale, logSlots, **kw_o)), b

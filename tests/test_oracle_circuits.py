@@ -182,3 +182,58 @@ def test_scale_invariant_multiplication_decrypts(drop):
     sq = sie.MulRelinScaleInvariant(ct0, None, rlk, square=True)
     assert np.array_equal(bfv_decrypt(sub, sq, sks, t), negacyclic_mul_mod(m0, m0, t))
     assert np.array_equal(sq, sie.MulRelinScaleInvariant(ct0, ct0.copy(), rlk))  # both branches agree bit for bit
+
+
+def _crt_centered(ring, coeffs):
+    Q = 1
+    for m in ring.moduli:
+        Q *= int(m)
+    w = [(Q // int(m)) * pow(Q // int(m), -1, int(m)) for m in ring.moduli]
+    out = []
+    for j in range(ring.N):
+        x = sum(int(coeffs[i, j]) * w[i] for i in range(len(w))) % Q
+        out.append(x - Q if x > Q // 2 else x)
+    return out
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_bootstrapping_modup_raises_the_modulus(sparse):
+    """bootstrapping.Evaluator.ModUp (circuits/ckks/bootstrapping/evaluator.go:612-769): a level-0 encryption of m comes
+    back at the top level as an encryption of scalar * (m + q0 * I) with I a small integer polynomial (|I| <= h/2 + 1 for a
+    secret of Hamming weight h), directly or through the sparse-secret encapsulation keys."""
+    q, p = O.GenModuli(10, [55, 45, 45, 45], [55, 55])
+    rng = rng_for(3700 + sparse)
+    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
+    ev = O.Evaluator(ringQ, ringP)
+
+    def ternary(h):
+        v = np.zeros(N, dtype=np.int64)
+        idx = rng.choice(N, size=h, replace=False)
+        v[idx] = rng.choice([-1, 1], size=h)
+        return v
+
+    sk = SecretKey(rng, ringQ, ringP, vals=ternary(64))       # the "dense" key
+    sks = SecretKey(rng, ringQ, ringP, vals=ternary(16))      # the sparse encapsulation key
+    ise = OC.InnerSumEvaluator(ev, {})
+    q0 = int(q[0])
+    m = rng.integers(-(1 << 30), 1 << 30, size=N)
+    r0 = O.Ring(N, q[:1])
+    c1 = uniform_poly(rng, q[:1], N)
+    e = np.clip(np.rint(rng.normal(0, 3.2, size=N)), -19, 19).astype(np.int64)
+    pt = np.array([[(int(a) + int(b)) % q0 for a, b in zip(m, e)]], dtype=np.uint64)
+    c0 = r0.binop("Sub", r0.NTT(pt), r0.binop("MulCoeffsMontgomery", c1, sk.Q[:1]))
+    ct = np.stack([c0, c1])
+    scale = 1000.3
+    kw = {}
+    if sparse:
+        kw = dict(EvkDenseToSparse=gen_evaluation_key(rng, ringQ, ringP, sk.Q, sks),
+                  EvkSparseToDense=gen_evaluation_key(rng, ringQ, ringP, sks.Q, sk))
+    out = OC.BootstrappingModUp(ev, ise, ct, scale, 8, **kw)  # logSlots = logN - 1: the Trace is the identity
+    assert out.shape == (2, len(q), N)
+    ph = _crt_centered(ringQ, ringQ.INTT(phase(ringQ, out, sk.Q)))
+    h = 16 if sparse else 64
+    for j in range(N):
+        r = ph[j] - 1000 * int(m[j])
+        I = (2 * r + 1000 * q0) // (2 * 1000 * q0)  # nearest multiple of scalar * q0
+        assert abs(I) <= h // 2 + 1, (j, I)
+        assert abs(r - I * 1000 * q0) < (1 << 40), j  # scalar * (fresh + key-switch noise) + key-switch noise
