@@ -146,6 +146,20 @@ int he_mul_rns_scalar_montgomery(he_handle ring, int level, he_handle p1, const 
 int he_add_scalar_bigint(he_handle ring, int level, he_handle p1, const uint64_t *words, int n_words, he_handle p2);
 int he_sub_scalar_bigint(he_handle ring, int level, he_handle p1, const uint64_t *words, int n_words, he_handle p2);
 int he_mul_scalar_bigint(he_handle ring, int level, he_handle p1, const uint64_t *words, int n_words, he_handle p2);
+/* Ring.MulScalarBigintThenAdd (operations.go:240) */
+int he_mul_scalar_bigint_then_add(he_handle ring, int level, he_handle p1, const uint64_t *words, int n_words, he_handle p2);
+/* Ring.AddDoubleRNSScalar / SubDoubleRNSScalar / MulDoubleRNSScalar / MulDoubleRNSScalarThenAdd (operations.go:166,176,
+ * 249,260): scalar0[i] applies to the coefficients [0, N/2) of limb i, scalar1[i] to [N/2, N); plain residues (the
+ * Montgomery form of the Mul forms is taken inside, as the reference).  op: 0 add, 1 sub, 2 mul, 3 mul-then-add. */
+int he_double_rns_scalarop(he_handle ring, int level, int op, he_handle p1, const uint64_t *scalar0, const uint64_t *scalar1,
+                           he_handle p2);
+/* Ring.Shift (operations.go:279): p2[i][j] = p1[i][(j + k) mod N]; p2 may be p1 */
+int he_shift(he_handle ring, int level, he_handle p1, int k, he_handle p2);
+/* Ring.MultByMonomial (operations.go:307): p2 = p1 * X^k, coefficient domain; p2 may be p1 */
+int he_mult_by_monomial(he_handle ring, int level, he_handle p1, int k, he_handle p2);
+/* Ring.MulByVectorMontgomery / MulByVectorMontgomeryThenAddLazy (operations.go:363,370): every limb of p1 times the
+ * same N-word vector (limb 0 of the batch-1 polynomial `vector`) */
+int he_mul_by_vector_montgomery(he_handle ring, int level, he_handle p1, he_handle vector, int then_add_lazy, he_handle p2);
 
 /* named wrappers, one per reference method that the key-switch path calls */
 int he_add(he_handle ring, int level, he_handle p1, he_handle p2, he_handle p3);

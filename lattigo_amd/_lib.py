@@ -72,7 +72,9 @@ def _declare(L):
         "he_binop": [H, i, i, H, H, H], "he_unop": [H, i, i, H, H], "he_scalarop": [H, i, i, H, C.c_uint64, H],
         "he_mul_rns_scalar_montgomery": [H, i, H, u64p, H],
         "he_add_scalar_bigint": [H, i, H, u64p, i, H], "he_sub_scalar_bigint": [H, i, H, u64p, i, H],
-        "he_mul_scalar_bigint": [H, i, H, u64p, i, H],
+        "he_mul_scalar_bigint": [H, i, H, u64p, i, H], "he_mul_scalar_bigint_then_add": [H, i, H, u64p, i, H],
+        "he_double_rns_scalarop": [H, i, i, H, u64p, u64p, H], "he_shift": [H, i, H, i, H],
+        "he_mult_by_monomial": [H, i, H, i, H], "he_mul_by_vector_montgomery": [H, i, H, H, i, H],
         "he_add": [H, i, H, H, H], "he_sub": [H, i, H, H, H], "he_neg": [H, i, H, H], "he_reduce": [H, i, H, H],
         "he_mform": [H, i, H, H], "he_imform": [H, i, H, H],
         "he_mul_coeffs_montgomery": [H, i, H, H, H], "he_mul_coeffs_montgomery_then_add": [H, i, H, H, H],

@@ -777,10 +777,74 @@ static int bigint_api(he_handle hring, int level, he_handle h1, const uint64_t *
     for (int i = 0; i <= level; i++) {
         const ModConst &m = r->sub[i].mc;
         const uint64_t v = words_mod(words, nw, m.q);
-        st.s[i] = kind == 2 ? mform(v, m.q, m.brc0, m.brc1) : v;
+        st.s[i] = kind >= 2 ? mform(v, m.q, m.brc0, m.brc1) : v;
     }
     Scope sc(r->ctx.get());
-    return scalar_launch(*r, level, kind == 0 ? EW_ADD_SCALAR : (kind == 1 ? EW_SUB_SCALAR : EW_MUL_SCALAR_MONT), *p1, *p2, st);
+    return scalar_launch(*r, level, kind == 0 ? EW_ADD_SCALAR : (kind == 1 ? EW_SUB_SCALAR : (kind == 2 ? EW_MUL_SCALAR_MONT : EW_MUL_SCALAR_MONT_THEN_ADD)), *p1, *p2, st);
+}
+int he_mul_scalar_bigint_then_add(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 3); }
+int he_double_rns_scalarop(he_handle hring, int level, int op, he_handle h1, const uint64_t *s0, const uint64_t *s1, he_handle h2) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    const char *who = "he_double_rns_scalarop";
+    TRY(check_poly(*p1, *r, level, who));
+    TRY(check_poly(*p2, *r, level, who));
+    if (!s0 || !s1 || op < 0 || op > 3 || p1->batch != p2->batch) return fail(HE_EINVAL, "%s: bad arguments", who);
+    ScalarTab st{};
+    for (int i = 0; i <= level; i++) {
+        const ModConst &m = r->sub[i].mc;
+        st.s[i] = op >= 2 ? mform(s0[i], m.q, m.brc0, m.brc1) : s0[i];
+        st.s2[i] = op >= 2 ? mform(s1[i], m.q, m.brc0, m.brc1) : s1[i];
+    }
+    static const int ops[4] = {EW_ADD_SCALAR, EW_SUB_SCALAR, EW_MUL_SCALAR_MONT, EW_MUL_SCALAR_MONT_THEN_ADD};
+    Scope sc(r->ctx.get());
+    HIP_TRY(launch_ew_double(r->dev, ident_tab(level + 1), ops[op], p1->view(), p2->view(), p2->batch, &st, r->ctx->stream));
+    return HE_OK;
+}
+static int shift_api(he_handle hring, int level, he_handle h1, int k, he_handle h2, bool monomial, const char *who) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    TRY(check_poly(*p1, *r, level, who));
+    TRY(check_poly(*p2, *r, level, who));
+    if (p1->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    const int N = r->N, B = p1->batch;
+    const int period = monomial ? 2 * N : N;
+    int kk = k % period;
+    if (kk < 0) kk += period;
+    Scope sc(r->ctx.get());
+    View in = p1->view();
+    const LimbTab tab = ident_tab(level + 1);
+    if (p1->d == p2->d) {  // in place: stage the input (the reference rotates in place / through a temporary)
+        const size_t w = (size_t)(level + 1) * N;
+        TRY(r->ctx->arena_reserve(B * w + 64));
+        View tmp{r->ctx->arena_take(B * w), w};
+        HIP_TRY(hipMemcpy2DAsync(tmp.p, w * 8, p1->d, p1->view().bstride * 8, w * 8, B, hipMemcpyDeviceToDevice, r->ctx->stream));
+        in = tmp;
+    }
+    if (monomial) HIP_TRY(launch_mult_by_monomial(r->dev, tab, in, kk, p2->view(), B, r->ctx->stream));
+    else HIP_TRY(launch_shift(r->dev, tab, in, kk, p2->view(), B, r->ctx->stream));
+    return HE_OK;
+}
+int he_shift(he_handle r, int l, he_handle p1, int k, he_handle p2) { return shift_api(r, l, p1, k, p2, false, "he_shift"); }
+int he_mult_by_monomial(he_handle r, int l, he_handle p1, int k, he_handle p2) { return shift_api(r, l, p1, k, p2, true, "he_mult_by_monomial"); }
+int he_mul_by_vector_montgomery(he_handle hring, int level, he_handle h1, he_handle hv, int then_add_lazy, he_handle h2) {
+    GET(r, Ring, hring, T_RING);
+    GET(p1, Poly, h1, T_POLY);
+    GET(v, Poly, hv, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    const char *who = "he_mul_by_vector_montgomery";
+    TRY(check_poly(*p1, *r, level, who));
+    TRY(check_poly(*p2, *r, level, who));
+    if (v->N != r->N || v->batch != 1 || p1->batch != p2->batch) return fail(HE_EINVAL, "%s: the vector is one batch-1 limb of degree N", who);
+    uint8_t zeros[kMaxLimbs] = {0};
+    View vv = v->view();
+    vv.bstride = 0;  // the same vector for every batch entry and (through the limb override) every limb
+    Scope sc(r->ctx.get());
+    HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), then_add_lazy ? EW_MUL_MONT_THEN_ADD_LAZY : EW_MUL_MONT, vv, p1->view(), p2->view(),
+                      p2->batch, nullptr, zeros, r->ctx->stream));
+    return HE_OK;
 }
 int he_add_scalar_bigint(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 0); }
 int he_sub_scalar_bigint(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 1); }

@@ -97,6 +97,14 @@ struct ScalarTab {
 // z[out_limb] = op(x[in_limb], y[in_limb or y_limb], z)   (y uses tab.in_limb unless y_tab given)
 hipError_t launch_ew(const RingDev &r, const LimbTab &tab, int op, View x, View y, View z, int batch,
                      const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s);
+// "double scalar" forms (Ring.{Add,Sub,Mul}DoubleRNSScalar, ring/operations.go:166-184,249-268): sc->s for the
+// coefficients [0, N/2), sc->s2 for [N/2, N); op is one of the scalar EW ops
+hipError_t launch_ew_double(const RingDev &r, const LimbTab &tab, int op, View x, View z, int batch, const ScalarTab *sc,
+                            hipStream_t s);
+// Ring.Shift (operations.go:279: out[j] = in[(j + k) mod N], k already reduced to [0, N)) and Ring.MultByMonomial
+// (:307: p2 = p1 * X^k in Z[X]/(X^N+1), word-exact incl. the q - 0 = q representative), shift in [0, 2N); not in place
+hipError_t launch_shift(const RingDev &r, const LimbTab &tab, View in, int k, View out, int batch, hipStream_t s);
+hipError_t launch_mult_by_monomial(const RingDev &r, const LimbTab &tab, View in, int shift, View out, int batch, hipStream_t s);
 // same with a separate addend view w for the *_THEN_ADD forms (z = f(x, y) + w)
 hipError_t launch_ew_w(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
                        const ScalarTab *sc, hipStream_t s);

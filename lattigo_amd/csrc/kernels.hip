@@ -895,6 +895,7 @@ struct EwArgs {
     int n;
     uint8_t x_limb[kMaxLimbs], y_limb[kMaxLimbs], z_limb[kMaxLimbs], mod[kMaxLimbs];
     uint64_t s[kMaxLimbs], s2[kMaxLimbs];
+    int dbl;  // double-scalar form: s for coefficients < N/2, s2 for the others
 };
 
 template <int OP>
@@ -952,7 +953,7 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
     if (j >= A.N) return;
     const int yy = blockIdx.y;
     const ModConst m = A.mc[A.mod[yy]];
-    const uint64_t s = A.s[yy], s2 = A.s2[yy];
+    const uint64_t s2 = A.s2[yy], s = (A.dbl && j >= (A.N >> 1)) ? s2 : A.s[yy];
     const size_t bz = blockIdx.z;
     const ulonglong2 xv = *reinterpret_cast<const ulonglong2 *>(A.x + bz * A.x_bs + (size_t)A.x_limb[yy] * A.N + j);
     ulonglong2 yv = make_ulonglong2(0, 0), zv = make_ulonglong2(0, 0);
@@ -968,7 +969,12 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
 }
 
 static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
-                                 const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s);
+                                 const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s, int dbl = 0);
+hipError_t launch_ew_double(const RingDev &r, const LimbTab &tab, int op, View x, View z, int batch, const ScalarTab *sc,
+                            hipStream_t s) {
+    if (r.N < 4) return hipErrorInvalidValue;  // two coefficients per thread must not straddle N/2
+    return launch_ew_impl(r, tab, op, x, x, z, z, batch, sc, nullptr, s, 1);
+}
 hipError_t launch_ew(const RingDev &r, const LimbTab &tab, int op, View x, View y, View z, int batch,
                      const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s) {
     return launch_ew_impl(r, tab, op, x, y, z, z, batch, sc, x_limb_override, s);
@@ -978,9 +984,10 @@ hipError_t launch_ew_w(const RingDev &r, const LimbTab &tab, int op, View x, Vie
     return launch_ew_impl(r, tab, op, x, y, w, z, batch, sc, nullptr, s);
 }
 static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
-                                 const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s) {
+                                 const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s, int dbl) {
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     EwArgs A;
+    A.dbl = dbl;
     A.x = x.p; A.y = y.p; A.z = z.p; A.w = w.p;
     A.x_bs = x.bstride; A.y_bs = y.bstride; A.z_bs = z.bstride; A.w_bs = w.bstride;
     A.mc = r.mc; A.N = r.N; A.n = tab.n;
@@ -1220,9 +1227,9 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
     double yl[DSTF64 ? R : 1][DSTF64 ? NSRC : 1];      // double variant: y (or its low 26 bits)
     double yh[DSTF64 ? R : 1][DSTF64 ? NSRC : 1];      //                 y >> 26 when split
     double vi[R];
-    uint64_t neg[R];  // centred-copy path only
+    uint32_t negmask = 0;  // centred-copy path only: bit r = coefficient r was negated
 #pragma unroll
-    for (int r = 0; r < R; r++) { vi[r] = 0.0; neg[r] = 0; }
+    for (int r = 0; r < R; r++) vi[r] = 0.0;
 #pragma unroll
     for (int i = 0; i < NSRC; i++) {
         const int mi = D.src_mod[i];
@@ -1275,8 +1282,9 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 uint64_t cv = x[r];
-                neg[r] = cv >= (q >> 1);
-                cv = neg[r] ? q - cv : cv;
+                const bool ng = cv >= (q >> 1);
+                negmask |= (uint32_t)ng << r;
+                cv = ng ? q - cv : cv;
                 if constexpr (DSTF64) ylds[i * R + r][threadIdx.x] = cv;
                 else y[r][i] = cv;
             }
@@ -1346,7 +1354,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const uint64_t t = bred_add(ylds[r][threadIdx.x], p, mp.brc0);
-                    o[r] = (double)(neg[r] ? p - t : t);
+                    o[r] = (double)(((negmask >> r) & 1) ? p - t : t);
                 }
             } else {
                 const int row = D.dst_row[j];
@@ -1391,7 +1399,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const uint64_t t = bred_add(Y(r, 0), p, mp.brc0);
-                    o[r] = neg[r] ? p - t : t;
+                    o[r] = ((negmask >> r) & 1) ? p - t : t;
                 }
             } else {
                 const int row = D.dst_row[j];
@@ -1629,6 +1637,64 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own
     else if (bb == 2) hipLaunchKernelGGL((ks_inner_kernel<2>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((ks_inner_kernel<1>), grid, block, 0, s, A);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Ring.Shift / Ring.MultByMonomial (coefficient permutations, see kernels.h)
+// ------------------------------------------------------------------------------------
+struct ShiftArgs {
+    const uint64_t *in;
+    uint64_t *out;
+    size_t in_bs, out_bs;
+    const ModConst *mc;
+    int N, k, monomial;
+    uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs], mod[kMaxLimbs];
+};
+__global__ void __launch_bounds__(256) shift_kernel(ShiftArgs A) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= A.N) return;
+    const int l = blockIdx.y;
+    const uint64_t *in = A.in + blockIdx.z * A.in_bs + (size_t)A.in_limb[l] * A.N;
+    uint64_t *out = A.out + blockIdx.z * A.out_bs + (size_t)A.out_limb[l] * A.N;
+    if (!A.monomial) {
+        int src = j + A.k;
+        if (src >= A.N) src -= A.N;
+        out[j] = in[src];
+        return;
+    }
+    // p1 * X^shift: first negate everything when shift >= N (tmp = q - p1), then rotate by shift mod N with the wrapped
+    // part negated again (ring/operations.go:326-358)
+    const uint64_t q = A.mc[A.mod[l]].q;
+    const bool flip = A.k >= A.N;
+    const int sh = flip ? A.k - A.N : A.k;
+    if (sh == 0) {  // k = N: only the negation (k = 0 is a copy)
+        out[j] = flip ? q - in[j] : in[j];
+        return;
+    }
+    if (j < sh) {
+        const uint64_t t = in[A.N - sh + j];
+        out[j] = q - (flip ? q - t : t);
+    } else {
+        const uint64_t t = in[j - sh];
+        out[j] = flip ? q - t : t;
+    }
+}
+static hipError_t launch_shift_impl(const RingDev &r, const LimbTab &tab, View in, int k, View out, int batch, int monomial,
+                                    hipStream_t s) {
+    if (tab.n <= 0 || batch <= 0) return hipSuccess;
+    ShiftArgs A;
+    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.k = k; A.monomial = monomial;
+    for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
+    dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
+    ProfScope ps(K_GATHER, s);
+    hipLaunchKernelGGL(shift_kernel, grid, block, 0, s, A);
+    return hipGetLastError();
+}
+hipError_t launch_shift(const RingDev &r, const LimbTab &tab, View in, int k, View out, int batch, hipStream_t s) {
+    return launch_shift_impl(r, tab, in, k, out, batch, 0, s);
+}
+hipError_t launch_mult_by_monomial(const RingDev &r, const LimbTab &tab, View in, int shift, View out, int batch, hipStream_t s) {
+    return launch_shift_impl(r, tab, in, shift, out, batch, 1, s);
 }
 
 // ------------------------------------------------------------------------------------

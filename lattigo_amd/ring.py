@@ -295,6 +295,56 @@ class Ring:
         check(load().he_mul_scalar_bigint(self.h, self.level, p1.h, _p(w), len(w), p2.h))
 
     # -- rescale (ring/scaling.go)
+    def MulScalarBigintThenAdd(self, p1: Poly, scalar: int, p2: Poly):
+        w = _words(int(scalar))
+        check(load().he_mul_scalar_bigint_then_add(self.h, self.level, p1.h, _p(w), len(w), p2.h))
+
+    # Ring.{Add,Sub,Mul}DoubleRNSScalar[ThenAdd] (ring/operations.go:166-184, 249-268)
+    def _double(self, op, p1: Poly, scalar0, scalar1, p2: Poly):
+        s0 = np.ascontiguousarray(scalar0, dtype=np.uint64)
+        s1 = np.ascontiguousarray(scalar1, dtype=np.uint64)
+        if s0.size < self.level + 1 or s1.size < self.level + 1:
+            raise ValueError("RNS scalars need one residue per limb")
+        check(load().he_double_rns_scalarop(self.h, self.level, op, p1.h, _p(s0), _p(s1), p2.h))
+
+    def AddDoubleRNSScalar(self, p1: Poly, scalar0, scalar1, p2: Poly):
+        self._double(0, p1, scalar0, scalar1, p2)
+
+    def SubDoubleRNSScalar(self, p1: Poly, scalar0, scalar1, p2: Poly):
+        self._double(1, p1, scalar0, scalar1, p2)
+
+    def MulDoubleRNSScalar(self, p1: Poly, scalar0, scalar1, p2: Poly):
+        self._double(2, p1, scalar0, scalar1, p2)
+
+    def MulDoubleRNSScalarThenAdd(self, p1: Poly, scalar0, scalar1, p2: Poly):
+        self._double(3, p1, scalar0, scalar1, p2)
+
+    def EvalPolyScalar(self, p1s, scalar: int, p2: Poly):
+        """Ring.EvalPolyScalar (ring/operations.go:271)"""
+        p2.CopyLvl(self.level, p1s[-1])
+        for i in range(len(p1s) - 1, 0, -1):
+            self.MulScalar(p2, scalar, p2)
+            self.Add(p2, p1s[i - 1], p2)
+
+    def Shift(self, p1: Poly, k: int, p2: Poly):
+        """Ring.Shift (ring/operations.go:279)"""
+        check(load().he_shift(self.h, self.level, p1.h, int(k), p2.h))
+
+    def MultByMonomial(self, p1: Poly, k: int, p2: Poly):
+        """Ring.MultByMonomial (ring/operations.go:307)"""
+        check(load().he_mult_by_monomial(self.h, self.level, p1.h, int(k), p2.h))
+
+    def MulByVectorMontgomery(self, p1: Poly, vector: Poly, p2: Poly):
+        """Ring.MulByVectorMontgomery (ring/operations.go:363); `vector`: a batch-1 polynomial whose limb 0 is the vector"""
+        check(load().he_mul_by_vector_montgomery(self.h, self.level, p1.h, vector.h, 0, p2.h))
+
+    def MulByVectorMontgomeryThenAddLazy(self, p1: Poly, vector: Poly, p2: Poly):
+        check(load().he_mul_by_vector_montgomery(self.h, self.level, p1.h, vector.h, 1, p2.h))
+
+    def AutomorphismNTT(self, pin: Poly, galel: int, pout: Poly):
+        """Ring.AutomorphismNTT (ring/automorphism.go:38)"""
+        self.AutomorphismNTTWithIndex(pin, self.AutomorphismNTTIndex(galel), pout)
+
     def DivRoundByLastModulusNTT(self, p0: Poly, p1: Poly):
         check(load().he_div_round_by_last_modulus_ntt(self.h, self.level, p0.h, p1.h))
 

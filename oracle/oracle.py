@@ -363,6 +363,89 @@ class Ring:
     def MulScalarBigint(self, p1, scalar, level=None):
         return self._bigint("lo_mul_scalar_bigint", p1, scalar, level)
 
+    # -- the remaining ring/operations.go methods, restated on top of the per-limb C primitives
+    def _limb_ring(self, i):
+        if not hasattr(self, "_limb_rings"):
+            self._limb_rings = {}
+        if i not in self._limb_rings:
+            self._limb_rings[i] = Ring(self.N, [self.moduli[i]])
+        return self._limb_rings[i]
+
+    def _double(self, name, p1, scalar0, scalar1, p2=None):
+        """Ring.{Add,Sub,Mul}DoubleRNSScalar[ThenAdd] (ring/operations.go:166-184, 249-268): scalar0[i] on the
+        coefficients [0, N/2) of limb i, scalar1[i] on [N/2, N) (Ring.MulScalar* take the Montgomery form inside)"""
+        p1 = _c(p1)
+        out = np.zeros_like(p1) if p2 is None else _c(p2).copy()
+        h = self.N >> 1
+        for i in range(p1.shape[0]):
+            r = self._limb_ring(i)
+            acc = None if p2 is None else out[i:i + 1]
+            a = r.scalarop(name, p1[i:i + 1], int(scalar0[i]), acc)
+            b = r.scalarop(name, p1[i:i + 1], int(scalar1[i]), acc)
+            out[i, :h], out[i, h:] = a[0, :h], b[0, h:]
+        return out
+
+    def AddDoubleRNSScalar(self, p1, scalar0, scalar1):
+        return self._double("AddScalar", p1, scalar0, scalar1)
+
+    def SubDoubleRNSScalar(self, p1, scalar0, scalar1):
+        return self._double("SubScalar", p1, scalar0, scalar1)
+
+    def MulDoubleRNSScalar(self, p1, scalar0, scalar1):
+        return self._double("MulScalar", p1, scalar0, scalar1)
+
+    def MulDoubleRNSScalarThenAdd(self, p1, scalar0, scalar1, p2):
+        return self._double("MulScalarThenAdd", p1, scalar0, scalar1, p2)
+
+    def MulScalarBigintThenAdd(self, p1, scalar, p2):
+        """ring/operations.go:240"""
+        p1 = _c(p1)
+        out = _c(p2).copy()
+        for i in range(p1.shape[0]):
+            out[i] = self._limb_ring(i).scalarop("MulScalarThenAdd", p1[i:i + 1], int(scalar) % self.moduli[i], out[i:i + 1])[0]
+        return out
+
+    def EvalPolyScalar(self, p1s, scalar):
+        """ring/operations.go:271: Horner in the ring"""
+        out = _c(p1s[-1]).copy()
+        for i in range(len(p1s) - 1, 0, -1):
+            out = self.binop("Add", self.scalarop("MulScalar", out, scalar), p1s[i - 1])
+        return out
+
+    def Shift(self, p1, k):
+        """ring/operations.go:279 -> utils.RotateSliceAllocFree (utils/slices.go:77): out[j] = in[(j + k) mod N]"""
+        p1 = _c(p1)
+        n = p1.shape[1]
+        k %= n
+        return np.concatenate([p1[:, k:], p1[:, :k]], axis=1)
+
+    def MultByMonomial(self, p1, k):
+        """ring/operations.go:307-359, loop for loop (incl. the q - 0 = q representative)"""
+        p1 = _c(p1)
+        N = self.N
+        shift = (k + (N << 1)) % (N << 1)
+        if shift == 0:
+            return p1.copy()
+        q = np.array(self.moduli[: p1.shape[0]], dtype=np.uint64)[:, None]
+        tmpx = p1.copy() if shift < N else q - p1
+        shift %= N
+        out = np.empty_like(p1)
+        out[:, :shift] = q - tmpx[:, N - shift:]
+        out[:, shift:] = tmpx[:, : N - shift]
+        return out
+
+    def MulByVectorMontgomery(self, p1, vector, p2=None):
+        """ring/operations.go:363 (p2 given: MulByVectorMontgomeryThenAddLazy :370)"""
+        p1 = _c(p1)
+        v = np.ascontiguousarray(np.broadcast_to(_c(vector), p1.shape))
+        if p2 is None:
+            return self.binop("MulCoeffsMontgomery", p1, v)
+        return self.binop("MulCoeffsMontgomeryThenAddLazy", p1, v, p2)
+
+    def AutomorphismNTT(self, pin, galel):
+        """ring/automorphism.go:38"""
+        return self.AutomorphismNTTWithIndex(pin, self.AutomorphismNTTIndex(galel))
+
     # -- rescale (ring/scaling.go); input has level+1 limbs, output level+1-nb limbs
     def _div(self, fn, p0, nb=None):
         p0 = _c(p0)

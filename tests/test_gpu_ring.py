@@ -292,3 +292,77 @@ def test_conjugate_invariant_rescale(ctx):
     po = g.NewPoly()
     g.DivRoundByLastModulusManyNTT(2, px, po)
     assert np.array_equal(po.get()[:2], o.DivRoundByLastModulusManyNTT(2, x))
+
+
+def test_remaining_ring_operations(ctx):
+    """The rest of ring/operations.go: {Add,Sub,Mul}DoubleRNSScalar[ThenAdd] (:166-184, 249-268), MulScalarBigintThenAdd
+    (:240), EvalPolyScalar (:271), Shift (:279, incl. the reference's known answer ring_test.go:917), MultByMonomial
+    (:307, every sign case, in place), MulByVectorMontgomery[ThenAddLazy] (:363-377), AutomorphismNTT; word-exact, batch 2."""
+    logN, nq, B = 9, 4, 2
+    pr = Pair(ctx, logN, nq, qmods=[Qi60[0], Qi60[1], Pi60[0], Qi60[5]])
+    N, q = pr.N, pr.q
+    rng = rng_for(1900)
+    x = np.stack([uniform_poly(rng, q, N) for _ in range(B)])
+    y = np.stack([uniform_poly(rng, q, N) for _ in range(B)])
+    x[:, :, :3] = 0
+    px = la.Poly(pr.gQ, nq, B).upload(x)
+    s0 = np.array([int(rng.integers(0, int(m))) for m in q], dtype=np.uint64)
+    s1 = np.array([int(rng.integers(0, int(m))) for m in q], dtype=np.uint64)
+    for level in (nq - 1, 1):
+        g, o = pr.gQ.AtLevel(level), O.Ring(N, q[: level + 1])
+        xs, ys = x[:, : level + 1], y[:, : level + 1]
+
+        def run(fn, *a, init=None):
+            out = la.Poly(pr.gQ, nq, B)
+            if init is not None:
+                out.upload(init)
+            fn(px, *a, out)
+            return out.download()[:, : level + 1]
+
+        for name in ("AddDoubleRNSScalar", "SubDoubleRNSScalar", "MulDoubleRNSScalar"):
+            got = run(getattr(g, name), s0, s1)
+            for b in range(B):
+                assert np.array_equal(got[b], getattr(o, name)(xs[b], s0, s1)), (name, level, b)
+        got = run(g.MulDoubleRNSScalarThenAdd, s0, s1, init=y)
+        big = (1 << 130) + 987654321
+        got2 = run(g.MulScalarBigintThenAdd, big, init=y)
+        for b in range(B):
+            assert np.array_equal(got[b], o.MulDoubleRNSScalarThenAdd(xs[b], s0, s1, ys[b])), (level, b)
+            assert np.array_equal(got2[b], o.MulScalarBigintThenAdd(xs[b], big, ys[b])), (level, b)
+        for k in (0, 3, N - 1, N, -5, 2 * N + 7):
+            got = run(g.Shift, k)
+            for b in range(B):
+                assert np.array_equal(got[b], o.Shift(xs[b], k)), ("shift", k)
+        for k in (0, 1, 9, N - 1, N, N + 3, 2 * N - 1, 2 * N, -1, -N - 2):
+            got = run(g.MultByMonomial, k)
+            for b in range(B):
+                assert np.array_equal(got[b], o.MultByMonomial(xs[b], k)), ("monomial", k)
+        tmp = la.Poly(pr.gQ, nq, B).upload(x)  # in place, as ring_test.go:897 (MultByMonomial(p3Test, 8, p3Test))
+        g.MultByMonomial(tmp, 1, tmp)
+        g.MultByMonomial(tmp, 8, tmp)
+        g.Shift(tmp, 5, tmp)
+        for b in range(B):
+            assert np.array_equal(tmp.download()[b, : level + 1], o.Shift(o.MultByMonomial(xs[b], 9), 5))
+        vec = rng.integers(0, 1 << 62, size=N, dtype=np.uint64)
+        pv = la.Poly(pr.gQ, 1).upload(vec[None, :])
+        got = run(g.MulByVectorMontgomery, pv)
+        got2 = run(g.MulByVectorMontgomeryThenAddLazy, pv, init=y)
+        for b in range(B):
+            assert np.array_equal(got[b], o.MulByVectorMontgomery(xs[b], vec))
+            assert np.array_equal(got2[b], o.MulByVectorMontgomery(xs[b], vec, ys[b]))
+        polys = [np.stack([uniform_poly(rng, q, N) for _ in range(B)]) for _ in range(4)]
+        gp = [la.Poly(pr.gQ, nq, B).upload(p) for p in polys]
+        out = la.Poly(pr.gQ, nq, B)
+        g.EvalPolyScalar(gp, 12345678901, out)
+        got = out.download()[:, : level + 1]
+        for b in range(B):
+            assert np.array_equal(got[b], o.EvalPolyScalar([p[b, : level + 1] for p in polys], 12345678901))
+        out = la.Poly(pr.gQ, nq, B)
+        g.AutomorphismNTT(px, 2 * N - 1, out)
+        assert np.array_equal(out.download()[0, : level + 1], o.AutomorphismNTT(xs[0], 2 * N - 1))
+    r16 = la.Ring(ctx, 16, [97])
+    p2 = r16.NewPoly()
+    r16.Shift(r16.NewPoly().upload(np.arange(16, dtype=np.uint64)[None, :]), 3, p2)
+    assert p2.get()[0].tolist() == [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2]  # ring_test.go:917
+    with pytest.raises(la.HeringError):
+        pr.gQ.MulByVectorMontgomery(px, px, la.Poly(pr.gQ, nq, B))  # the vector must be a batch-1 polynomial

@@ -239,3 +239,65 @@ def test_conjugate_invariant_ntt_vs_standard_2n(ring_test_params):
     assert np.array_equal(ringci.unop("Reduce", ringci.NTTLazy(p1)), t)
     assert np.array_equal(ringci.INTT(t), p1)
     assert np.array_equal(ringci.unop("Reduce", ringci.INTTLazy(t)), p1)
+
+
+def test_shift_known_answer():
+    """ring/ring_test.go:907-919 (testShift), the reference's literal answer"""
+    r = O.Ring(16, [97])
+    p1 = np.arange(16, dtype=np.uint64)[None, :]
+    assert r.Shift(p1, 3)[0].tolist() == [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2]
+    assert np.array_equal(r.Shift(p1, -13), r.Shift(p1, 3)) and np.array_equal(r.Shift(p1, 16), p1)
+
+
+def test_mult_by_monomial(rings):
+    """ring/ring_test.go:888-905 (X^1 then X^8 == X^9) + the definition in Z[X]/(X^N+1) for every sign case"""
+    ringQ = rings[0]
+    N, mods = ringQ.N, ringQ.moduli
+    rng = rng_for(77)
+    p1 = uniform_poly(rng, mods, N)
+    p1[:, :3] = 0  # zeros expose the q - 0 = q representative
+    assert np.array_equal(ringQ.MultByMonomial(ringQ.MultByMonomial(p1, 1), 8), ringQ.MultByMonomial(p1, 9))
+    for k in (0, 1, 5, N - 1, N, N + 3, 2 * N - 1, 2 * N, -1, -N - 2):
+        got = ringQ.unop("Reduce", ringQ.MultByMonomial(p1, k))
+        for i, q in enumerate(mods):
+            want = np.zeros(N, dtype=object)
+            for j in range(N):
+                e = (j + k) % (2 * N)
+                sign = 1 if e < N else -1
+                want[e % N] = (sign * int(p1[i, j])) % int(q)
+            assert got[i].tolist() == want.tolist(), (k, i)
+    if N >= 4:
+        assert (ringQ.MultByMonomial(p1, N)[:, :3] == np.array(mods, dtype=np.uint64)[:, None]).all()  # q - 0
+
+
+def test_double_rns_scalar_ops_and_friends(rings):
+    """ring/operations.go:166-184, 240-277, 363-377 against their definitions on Python integers"""
+    ringQ = rings[0]
+    N, mods = ringQ.N, ringQ.moduli
+    rng = rng_for(78)
+    p1, p2 = uniform_poly(rng, mods, N), uniform_poly(rng, mods, N)
+    s0 = np.array([int(rng.integers(0, int(q))) for q in mods], dtype=np.uint64)
+    s1 = np.array([int(rng.integers(0, int(q))) for q in mods], dtype=np.uint64)
+    h = N // 2
+    outs = {"add": ringQ.AddDoubleRNSScalar(p1, s0, s1), "sub": ringQ.SubDoubleRNSScalar(p1, s0, s1),
+            "mul": ringQ.MulDoubleRNSScalar(p1, s0, s1), "mad": ringQ.MulDoubleRNSScalarThenAdd(p1, s0, s1, p2)}
+    big = int(rng.integers(1, 1 << 62)) ** 3 + 12345
+    mba = ringQ.MulScalarBigintThenAdd(p1, big, p2)
+    vec = rng.integers(0, 1 << 62, size=N, dtype=np.uint64)
+    mv = ringQ.MulByVectorMontgomery(p1, vec)
+    mva = ringQ.unop("Reduce", ringQ.MulByVectorMontgomery(p1, vec, p2))
+    polys = [uniform_poly(rng, mods, N) for _ in range(4)]
+    ev = ringQ.EvalPolyScalar(polys, 12345678901)
+    for i, q in enumerate(mods):
+        q = int(q)
+        rinv = pow(1 << 64, -1, q)
+        for j in (0, 1, h - 1, h, h + 1, N - 1):
+            s = int(s0[i]) if j < h else int(s1[i])
+            x, y = int(p1[i, j]), int(p2[i, j])
+            assert int(outs["add"][i, j]) == (x + s) % q and int(outs["sub"][i, j]) == (x - s) % q
+            assert int(outs["mul"][i, j]) == x * s % q and int(outs["mad"][i, j]) == (y + x * s) % q
+            assert int(mba[i, j]) == (y + x * big) % q
+            assert int(mv[i, j]) == x * int(vec[j]) * rinv % q and int(mva[i, j]) == (y + x * int(vec[j]) * rinv) % q
+            assert int(ev[i, j]) == sum(int(polys[d][i, j]) * pow(12345678901, d, q) for d in range(4)) % q
+    g = 5
+    assert np.array_equal(ringQ.AutomorphismNTT(p1, g), ringQ.AutomorphismNTTWithIndex(p1, ringQ.AutomorphismNTTIndex(g)))
