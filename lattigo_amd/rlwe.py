@@ -330,3 +330,49 @@ def GaloisElementsForTrace(nth_root: int, logN_ring: int, logN: int):
     if logN == 0:
         g.append(nth_root - 1)
     return g
+
+
+class CKKSRotations:
+    """schemes/ckks Evaluator.Rotate / Conjugate / RotateHoisted / RotateHoistedLazyNew / InnerSum
+    (schemes/ckks/evaluator.go:1197-1262, 1283-1300), bound to an Evaluator and a Galois key set."""
+
+    def __init__(self, evaluator: Evaluator, gks: GaloisKeySet):
+        self.eval, self.gks = evaluator, gks
+        self.ise = InnerSumEvaluator(evaluator, gks)
+        self.nth_root = evaluator.ringQ.NthRoot()
+
+    def Rotate(self, level, op0, k: int, opOut):
+        g = GaloisElement(self.nth_root, k)
+        self.eval.Automorphism(level, op0, g, self.gks.GetGaloisKey(g), opOut)
+
+    def Conjugate(self, level, op0, opOut):
+        g = self.nth_root - 1  # GaloisElementOrderTwoOrthogonalSubgroup (core/rlwe/params.go:592)
+        self.eval.Automorphism(level, op0, g, self.gks.GetGaloisKey(g), opOut)
+
+    def RotateHoisted(self, level, ctIn, rotations, opOut: dict):
+        levelP = self.eval.ringP.MaxLevel()
+        decomp = Decomposition(self.eval, ctIn[0].batch)
+        self.eval.DecomposeNTT(level, levelP, levelP + 1, ctIn[1], True, decomp)
+        for i in rotations:
+            g = GaloisElement(self.nth_root, i)
+            self.eval.AutomorphismHoisted(level, ctIn, decomp, g, self.gks.GetGaloisKey(g), opOut[i])
+
+    def RotateHoistedLazyNew(self, level, rotations, ct, decomp: Decomposition) -> dict:
+        levelP, B, out = self.eval.ringP.MaxLevel(), ct[0].batch, {}
+        for i in rotations:
+            if i != 0:
+                out[i] = [(Poly(self.eval.ringQ, level + 1, B), Poly(self.eval.ringP, levelP + 1, B)) for _ in range(2)]
+                g = GaloisElement(self.nth_root, i)
+                self.eval.AutomorphismHoistedLazy(level, ct, decomp, g, self.gks.GetGaloisKey(g), out[i])
+        return out
+
+    def InnerSum(self, level, ctIn, batchSize: int, n: int, opOut, slots: int | None = None):
+        N = slots if slots is not None else self.eval.ringQ.N // 2
+        l = n * batchSize
+        if n <= 0 or batchSize <= 0:
+            raise ValueError("innersum: invalid parameter (n <= 0 or batchSize <= 0)")
+        if l > N:
+            raise ValueError(f"innersum: invalid parameters (n*batchSize={l} > #slots={N})")
+        if l & (l - 1):
+            raise ValueError(f"innersum: invalid parameters (n*batchSize={l} does not divide #slots={N})")
+        self.ise.PartialTracesSum(level, ctIn, batchSize, n, opOut)

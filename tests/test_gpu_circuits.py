@@ -262,3 +262,44 @@ def test_bootstrapping_modup(ctx, sparse, scale, logSlots, levelIn):
     got = Rig.down(g)
     for b in range(B):
         assert np.array_equal(got[b], OC.BootstrappingModUp(rg.oev, oi, ct[b], scale, logSlots, **kw_o)), b
+
+
+def test_ckks_rotation_call_sites(ctx):
+    """schemes/ckks Evaluator.Rotate / Conjugate / RotateHoisted / RotateHoistedLazyNew / InnerSum
+    (schemes/ckks/evaluator.go:1197-1300) against the oracle's Automorphism family."""
+    rg = Rig(ctx, 11, [55, 45, 45, 50], [55, 46], 4800)
+    nth, top = 2 * rg.N, 3
+    rots = [1, 5, -3, 0, 64]
+    rg.keys([R.GaloisElement(nth, k) for k in rots] + [nth - 1] + R.GaloisElementsForInnerSum(nth, 2, 8))
+    cr = R.CKKSRotations(rg.gev, rg.ggks)
+    B = 2
+    ct = rg.ct(top, B)
+    g = rg.up(ct)
+    outs = {k: rg.new_ct(top, B) for k in rots}
+    cr.RotateHoisted(top, g, rots, outs)
+    single, conj = rg.new_ct(top, B), rg.new_ct(top, B)
+    cr.Rotate(top, g, 5, single)
+    cr.Conjugate(top, g, conj)
+    dec = la.Decomposition(rg.gev, B)
+    rg.gev.DecomposeNTT(top, 1, 2, g[1], True, dec)
+    lazy = cr.RotateHoistedLazyNew(top, rots, g, dec)
+    assert sorted(lazy) == sorted(k for k in rots if k)
+    isum = rg.new_ct(top, B)
+    cr.InnerSum(top, g, 2, 8, isum)
+    oi = OC.InnerSumEvaluator(rg.oev, rg.ogks)
+    for b in range(B):
+        dq, dp = rg.oev.DecomposeNTT(top, 1, 2, ct[b][1], True)
+        for k in rots:
+            ge = R.GaloisElement(nth, k)
+            want = rg.oev.Automorphism(ct[b], ge, rg.ogks[ge])
+            assert np.array_equal(Rig.down(outs[k])[b], want), k
+            if k:
+                wQ, wP = rg.oev.AutomorphismHoistedLazy(top, ct[b][0], dq, dp, ge, rg.ogks[ge])
+                for c in range(2):
+                    assert np.array_equal(lazy[k][c][0].download()[b], wQ[c]) and np.array_equal(lazy[k][c][1].download()[b], wP[c])
+        assert np.array_equal(Rig.down(single)[b], rg.oev.Automorphism(ct[b], R.GaloisElement(nth, 5), rg.ogks[R.GaloisElement(nth, 5)]))
+        assert np.array_equal(Rig.down(conj)[b], rg.oev.Automorphism(ct[b], nth - 1, rg.ogks[nth - 1]))
+        assert np.array_equal(Rig.down(isum)[b], oi.PartialTracesSum(ct[b], 2, 8))
+    for bad in ((0, 4), (3, 8), (2, 3)):
+        with pytest.raises(ValueError):
+            cr.InnerSum(top, g, bad[0], bad[1], isum, slots=32 if bad == (3, 8) else None)
