@@ -1,0 +1,167 @@
+"""Host-side mirror of the ring-level call sites of ``schemes.Evaluator`` (schemes/schemes.go:14-28) for CKKS and BGV:
+``Add/Sub/Mul/MulRelin/MulThenAdd/MulRelinThenAdd/Relinearize/Rescale`` on ciphertext x ciphertext and ciphertext x
+plaintext operands, as drivers over the device-resident operators.  Everything that is floating-point scale management in
+the reference (CKKS scale ratios, plaintext encoding) stays with the caller: these methods are the polynomial arithmetic a
+call performs once levels and scales have been decided.  A ciphertext is a list of ``Poly`` (degree + 1 entries), a
+plaintext a single ``Poly``, all in the NTT domain."""
+from __future__ import annotations
+
+import numpy as np
+
+from .ring import Poly
+from .rlwe import EvaluationKey, Evaluator
+
+
+class _Base:
+    def __init__(self, evaluator: Evaluator):
+        self.eval, self.ringQ = evaluator, evaluator.ringQ
+
+    def _tmp(self, level, B):
+        return Poly(self.ringQ, level + 1, B)
+
+    # Evaluator.Add / Sub for operands of equal scale (schemes/ckks/evaluator.go:65,226; schemes/bgv/evaluator.go:168,350
+    # -> rlwe evaluateInPlace): component-wise, the operand of higher degree is copied (negated for Sub) beyond the other's
+    def Add(self, level, op0, op1, opOut):
+        self._addsub(level, op0, op1, opOut, False)
+
+    def Sub(self, level, op0, op1, opOut):
+        self._addsub(level, op0, op1, opOut, True)
+
+    def _addsub(self, level, op0, op1, opOut, sub):
+        r = self.ringQ.AtLevel(level)
+        d0, d1 = len(op0), len(op1)
+        for i in range(min(d0, d1)):
+            (r.Sub if sub else r.Add)(op0[i], op1[i], opOut[i])
+        for i in range(min(d0, d1), max(d0, d1)):
+            if d0 > d1:
+                if opOut[i] is not op0[i]:
+                    opOut[i].CopyLvl(level, op0[i])
+            elif sub:
+                r.Neg(op1[i], opOut[i])
+            elif opOut[i] is not op1[i]:
+                opOut[i].CopyLvl(level, op1[i])
+
+    def Relinearize(self, level, op0, rlk: EvaluationKey, opOut):
+        self.eval.Relinearize(level, op0, rlk, opOut)
+
+    def Rescale(self, level, op0, opOut, nbRescales: int = 1):
+        self.eval.Rescale(level, nbRescales, op0, opOut)
+
+    def _ct_ct_then_add(self, level, c00, c01, op1, rlk, opOut):
+        """the shared tail of mulRelinThenAdd (schemes/ckks/evaluator.go:1131-1155, schemes/bgv/evaluator.go:1288-1314)"""
+        r = self.ringQ.AtLevel(level)
+        B = op1[0].batch
+        r.MulCoeffsMontgomeryThenAdd(c00, op1[0], opOut[0])  # c0 += c[0]*c[0]
+        r.MulCoeffsMontgomeryThenAdd(c00, op1[1], opOut[1])  # c1 += c[0]*c[1]
+        r.MulCoeffsMontgomeryThenAdd(c01, op1[0], opOut[1])  # c1 += c[1]*c[0]
+        if rlk is not None:
+            c2 = self._tmp(level, B)
+            r.MulCoeffsMontgomery(c01, op1[1], c2)
+            tmp = [self._tmp(level, B), self._tmp(level, B)]
+            self.eval.GadgetProduct(level, c2, rlk, tmp)
+            r.Add(opOut[0], tmp[0], opOut[0])
+            r.Add(opOut[1], tmp[1], opOut[1])
+        else:
+            r.MulCoeffsMontgomeryThenAdd(c01, op1[1], opOut[2])  # c2 += c[1]*c[1]
+
+
+class CKKSEvaluator(_Base):
+    """schemes/ckks Evaluator, ring level."""
+
+    # Evaluator.Mul / MulRelin, ct x ct (schemes/ckks/evaluator.go:764-840)
+    def MulRelin(self, level, op0, op1, rlk: EvaluationKey | None, opOut):
+        self.eval.CKKSMulRelin(level, op0, op1, rlk, opOut)
+
+    # ... ct x pt (or pt x ct) branch (:842-870)
+    def MulPlaintext(self, level, op0, pt: Poly, opOut):
+        r = self.ringQ.AtLevel(level)
+        c0 = self._tmp(level, pt.batch)
+        r.MForm(pt, c0)
+        for a, o in zip(op0, opOut):
+            r.MulCoeffsMontgomery(c0, a, o)
+
+    # Evaluator.MulThenAdd / MulRelinThenAdd, ct x ct (:1081-1155; the scale-ratio rescaling of opOut, :1087-1096, is the
+    # caller's: it is a MulScalar by an integer decided from floating-point scales)
+    def MulRelinThenAdd(self, level, op0, op1, rlk: EvaluationKey | None, opOut):
+        r = self.ringQ.AtLevel(level)
+        B = op0[0].batch
+        c00, c01 = self._tmp(level, B), self._tmp(level, B)
+        r.MForm(op0[0], c00)
+        r.MForm(op0[1], c01)
+        self._ct_ct_then_add(level, c00, c01, op1, rlk, opOut)
+
+    # ... ct x pt branch (:1158-1170)
+    def MulPlaintextThenAdd(self, level, op0, pt: Poly, opOut):
+        r = self.ringQ.AtLevel(level)
+        c00 = self._tmp(level, pt.batch)
+        r.MForm(pt, c00)
+        for a, o in zip(op0, opOut):
+            r.MulCoeffsMontgomeryThenAdd(a, c00, o)
+
+
+def bgv_match_scales_binary(scale0: int, scale1: int, t: int):
+    """bgv.Evaluator.matchScalesBinary (schemes/bgv/evaluator.go:1569-1608): (r0, r1, e) with r0 * scale0 = r1 * scale1 mod t
+    and minimal |r0| + |r1|"""
+    from math import gcd
+    if gcd(scale0, t) != 1:
+        raise ValueError("cannot matchScalesBinary: invalid ciphertext scale: gcd(scale, t) != 1")
+    thalf = t >> 1
+    center = lambda x: t - x if x >= thalf else x
+    a, b = t, 0
+    A, Bv = pow(scale0, t - 2, t) * scale1 % t, 1
+    r0, r1 = A, Bv
+    e = center(A) + 1
+    while A != 0:
+        qq = a // A
+        a, A = A, a % A
+        b, Bv = Bv, (t + b - Bv * qq % t) % t
+        if A != 0 and gcd(A, t) == 1:
+            tmp = center(A) + center(Bv)
+            if tmp < e:
+                e = tmp
+                r0, r1 = A, Bv
+    return r0, r1, e
+
+
+class BGVEvaluator(_Base):
+    """schemes/bgv Evaluator (standard tensoring), ring level; t = plaintext modulus."""
+
+    def __init__(self, evaluator: Evaluator, t: int):
+        super().__init__(evaluator)
+        self.t = int(t)
+        # tMontgomery = MForm(T * 2^64 mod q_i) (schemes/bgv/evaluator.go:60-62)
+        self.tMontgomery = np.array([((self.t << 64) % int(q)) * (1 << 64) % int(q) for q in self.ringQ.ModuliChain()],
+                                    dtype=np.uint64)
+
+    # Evaluator.Mul / MulRelin, ct x ct (schemes/bgv/evaluator.go:592-667)
+    def MulRelin(self, level, op0, op1, rlk: EvaluationKey | None, opOut):
+        self.eval.BGVMulRelin(level, self.t, op0, op1, rlk, opOut)
+
+    # ... ct x pt branch (:669-683)
+    def MulPlaintext(self, level, op0, pt: Poly, opOut):
+        r = self.ringQ.AtLevel(level)
+        c00 = self._tmp(level, pt.batch)
+        r.MulRNSScalarMontgomery(pt, self.tMontgomery, c00)
+        for a, o in zip(op0, opOut):
+            r.MulCoeffsMontgomery(a, c00, o)
+
+    # Evaluator.MulThenAdd / MulRelinThenAdd, ct x ct (:1230-1314).  scales = (op0.Scale, op1.Scale, opOut.Scale) mod t;
+    # returns the new opOut scale
+    def MulRelinThenAdd(self, level, op0, op1, rlk: EvaluationKey | None, opOut, scales=(1, 1, 1)) -> int:
+        r = self.ringQ.AtLevel(level)
+        B = op0[0].batch
+        s0, s1, so = (int(x) % self.t for x in scales)
+        r0, target = 1, s0 * s1 % self.t
+        if so != target:  # :1267-1276
+            r0, r1, _ = bgv_match_scales_binary(target, so, self.t)
+            for o in opOut:
+                r.MulScalar(o, r1, o)
+            so = so * r1 % self.t
+        c00, c01 = self._tmp(level, B), self._tmp(level, B)
+        r.MulRNSScalarMontgomery(op0[0], self.tMontgomery, c00)
+        r.MulRNSScalarMontgomery(op0[1], self.tMontgomery, c01)
+        if r0 != 1:  # :1283-1286
+            r.MulScalar(c00, r0, c00)
+            r.MulScalar(c01, r0, c01)
+        self._ct_ct_then_add(level, c00, c01, op1, rlk, opOut)
+        return so

@@ -414,3 +414,90 @@ def BootstrappingModUp(ev: O.Evaluator, ise: InnerSumEvaluator, ct, scale, logSl
         if scalar is not None:
             out = np.stack([rQ.scalarop("MulScalar", out[k], scalar) for k in range(2)])
     return ise.Trace(out, logSlots)  # :768
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ring-level call sites of schemes.Evaluator for CKKS / BGV (ct x ct and ct x pt), restated op for op
+# ---------------------------------------------------------------------------------------------------------------
+def _ct_ct_then_add(ev: O.Evaluator, c00, c01, op1, rlk, opOut):
+    """schemes/ckks/evaluator.go:1131-1155 == schemes/bgv/evaluator.go:1288-1314"""
+    rQ = ev.ringQ
+    level = op1.shape[1] - 1
+    out = [np.asarray(x, dtype=np.uint64).copy() for x in opOut]
+    out[0] = rQ.binop("MulCoeffsMontgomeryThenAdd", c00, op1[0], out[0])
+    out[1] = rQ.binop("MulCoeffsMontgomeryThenAdd", c00, op1[1], out[1])
+    out[1] = rQ.binop("MulCoeffsMontgomeryThenAdd", c01, op1[0], out[1])
+    if rlk is not None:
+        c2 = rQ.binop("MulCoeffsMontgomery", c01, op1[1])
+        tmp = ev.GadgetProduct(level, c2, rlk)
+        out[0], out[1] = rQ.binop("Add", out[0], tmp[0]), rQ.binop("Add", out[1], tmp[1])
+    else:
+        out[2] = rQ.binop("MulCoeffsMontgomeryThenAdd", c01, op1[1], out[2])
+    return np.stack(out)
+
+
+def ckks_mul_relin_then_add(ev, op0, op1, rlk, opOut):
+    """schemes/ckks/evaluator.go:1081-1155 (ct x ct, scales already matched)"""
+    op0, op1 = np.asarray(op0, dtype=np.uint64), np.asarray(op1, dtype=np.uint64)
+    return _ct_ct_then_add(ev, ev.ringQ.unop("MForm", op0[0]), ev.ringQ.unop("MForm", op0[1]), op1, rlk, opOut)
+
+
+def ckks_mul_plaintext(ev, op0, pt, opOut=None):
+    """schemes/ckks/evaluator.go:842-870 (opOut None) and :1158-1170 (MulThenAdd)"""
+    rQ = ev.ringQ
+    c0 = rQ.unop("MForm", np.asarray(pt, dtype=np.uint64))
+    if opOut is None:
+        return np.stack([rQ.binop("MulCoeffsMontgomery", c0, a) for a in op0])
+    return np.stack([rQ.binop("MulCoeffsMontgomeryThenAdd", a, c0, o) for a, o in zip(op0, opOut)])
+
+
+def bgv_t_montgomery(ringQ, t):
+    """schemes/bgv/evaluator.go:60-62"""
+    return np.array([O.MForm((int(t) << 64) % int(q), int(q)) for q in ringQ.moduli], dtype=np.uint64)
+
+
+def bgv_match_scales_binary(scale0, scale1, t):
+    """schemes/bgv/evaluator.go:1569-1615"""
+    from math import gcd
+    assert gcd(scale0, t) == 1
+    thalf = t >> 1
+    center = lambda x: t - x if x >= thalf else x
+    a, b = t, 0
+    A, B = O.BRed(O.ModExp(scale0, t - 2, t), scale1, t), 1
+    r0, r1, e = A, B, center(A) + 1
+    while A != 0:
+        qq = a // A
+        a, A = A, a % A
+        b, B = B, (t + b - O.BRed(B, qq, t)) % t
+        if A != 0 and gcd(A, t) == 1:
+            tmp = center(A) + center(B)
+            if tmp < e:
+                e, r0, r1 = tmp, A, B
+    return r0, r1, e
+
+
+def bgv_mul_plaintext(ev, t, op0, pt):
+    """schemes/bgv/evaluator.go:669-683"""
+    rQ = ev.ringQ
+    level = np.asarray(pt).shape[0] - 1
+    c00 = rQ.MulRNSScalarMontgomery(np.asarray(pt, dtype=np.uint64), bgv_t_montgomery(rQ, t)[: level + 1])
+    return np.stack([rQ.binop("MulCoeffsMontgomery", a, c00) for a in op0])
+
+
+def bgv_mul_relin_then_add(ev, t, op0, op1, rlk, opOut, scales=(1, 1, 1)):
+    """schemes/bgv/evaluator.go:1230-1314 (ct x ct); returns (opOut, new opOut scale)"""
+    rQ = ev.ringQ
+    op0, op1 = np.asarray(op0, dtype=np.uint64), np.asarray(op1, dtype=np.uint64)
+    level = op0.shape[1] - 1
+    out = [np.asarray(x, dtype=np.uint64).copy() for x in opOut]
+    s0, s1, so = (int(x) % t for x in scales)
+    r0, target = 1, O.BRed(s0, s1, t)
+    if so != target:
+        r0, r1, _ = bgv_match_scales_binary(target, so, t)
+        out = [rQ.scalarop("MulScalar", o, r1) for o in out]
+        so = so * r1 % t
+    tm = bgv_t_montgomery(rQ, t)[: level + 1]
+    c00, c01 = rQ.MulRNSScalarMontgomery(op0[0], tm), rQ.MulRNSScalarMontgomery(op0[1], tm)
+    if r0 != 1:
+        c00, c01 = rQ.scalarop("MulScalar", c00, r0), rQ.scalarop("MulScalar", c01, r0)
+    return _ct_ct_then_add(ev, c00, c01, op1, rlk, out), so

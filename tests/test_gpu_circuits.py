@@ -303,3 +303,51 @@ def test_ckks_rotation_call_sites(ctx):
     for bad in ((0, 4), (3, 8), (2, 3)):
         with pytest.raises(ValueError):
             cr.InnerSum(top, g, bad[0], bad[1], isum, slots=32 if bad == (3, 8) else None)
+
+
+def test_scheme_evaluator_call_sites(ctx):
+    """schemes.Evaluator ring-level call sites for CKKS and BGV (MulRelinThenAdd with and without relinearisation, the
+    BGV scale-matching branch, ct x pt products, Add/Sub of unequal degrees) on the device vs the oracle, batch 2."""
+    from lattigo_amd import schemes as S
+    rg = Rig(ctx, 11, [55, 45, 45, 50], [55, 46], 4900)
+    rg.keys([1])
+    grlk, orlk = rg.ggks.keys[1], rg.ogks[1]
+    t, B, top = 65537, 2, 3
+    ck, bg = S.CKKSEvaluator(rg.gev), S.BGVEvaluator(rg.gev, t)
+    for level in (top, 1):
+        a, b = rg.ct(level, B), rg.ct(level, B)
+        acc = np.stack([np.stack([uniform_poly(rg.rng, rg.q[: level + 1], rg.N) for _ in range(3)]) for _ in range(B)])
+        pt = np.stack([uniform_poly(rg.rng, rg.q[: level + 1], rg.N) for _ in range(B)])
+        ga, gb = rg.up(a), rg.up(b)
+        gpt = la.Poly(rg.pr.gQ, level + 1, B).upload(pt)
+
+        def accs(n):
+            return [la.Poly(rg.pr.gQ, level + 1, B).upload(acc[:, k]) for k in range(n)]
+
+        sub = O.Evaluator(O.Ring(rg.N, rg.q[: level + 1]), rg.pr.oP) if level != top else rg.oev
+        cases = []
+        o = accs(2); ck.MulRelinThenAdd(level, ga, gb, grlk, o)
+        cases.append((o, lambda i: OC.ckks_mul_relin_then_add(rg.oev, a[i], b[i], orlk, acc[i][:2])))
+        o = accs(3); ck.MulRelinThenAdd(level, ga, gb, None, o)
+        cases.append((o, lambda i: OC.ckks_mul_relin_then_add(rg.oev, a[i], b[i], None, acc[i])))
+        o = accs(2); so = bg.MulRelinThenAdd(level, ga, gb, grlk, o, scales=(3, 5, 7))
+        assert so == OC.bgv_mul_relin_then_add(rg.oev, t, a[0], b[0], orlk, acc[0][:2], scales=(3, 5, 7))[1]
+        cases.append((o, lambda i: OC.bgv_mul_relin_then_add(rg.oev, t, a[i], b[i], orlk, acc[i][:2], scales=(3, 5, 7))[0]))
+        o = accs(3); bg.MulRelinThenAdd(level, ga, gb, None, o)
+        cases.append((o, lambda i: OC.bgv_mul_relin_then_add(rg.oev, t, a[i], b[i], None, acc[i])[0]))
+        o = rg.new_ct(level, B); ck.MulPlaintext(level, ga, gpt, o)
+        cases.append((o, lambda i: OC.ckks_mul_plaintext(sub, a[i], pt[i])))
+        o = accs(2); ck.MulPlaintextThenAdd(level, ga, gpt, o)
+        cases.append((o, lambda i: OC.ckks_mul_plaintext(sub, a[i], pt[i], acc[i][:2])))
+        o = rg.new_ct(level, B); bg.MulPlaintext(level, ga, gpt, o)
+        cases.append((o, lambda i: OC.bgv_mul_plaintext(sub, t, a[i], pt[i])))
+        o = accs(3); ck.Sub(level, ga, accs(3), o)  # degree 1 - degree 2
+        rs = O.Ring(rg.N, rg.q[: level + 1])
+        cases.append((o, lambda i: np.stack([rs.binop("Sub", a[i][0], acc[i][0]), rs.binop("Sub", a[i][1], acc[i][1]),
+                                            rs.unop("Neg", acc[i][2])])))
+        o = accs(3); ck.Add(level, accs(3), gb, o)  # degree 2 + degree 1
+        cases.append((o, lambda i: np.stack([rs.binop("Add", acc[i][0], b[i][0]), rs.binop("Add", acc[i][1], b[i][1]), acc[i][2]])))
+        for n, (o, want) in enumerate(cases):
+            got = Rig.down(o)
+            for i in range(B):
+                assert np.array_equal(got[i], want(i)), (level, n, i)

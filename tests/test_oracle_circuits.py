@@ -237,3 +237,36 @@ def test_bootstrapping_modup_raises_the_modulus(sparse):
         I = (2 * r + 1000 * q0) // (2 * 1000 * q0)  # nearest multiple of scalar * q0
         assert abs(I) <= h // 2 + 1, (j, I)
         assert abs(r - I * 1000 * q0) < (1 << 40), j  # scalar * (fresh + key-switch noise) + key-switch noise
+
+
+def test_scheme_call_sites_are_consistent_with_the_pinned_tensoring():
+    """MulRelinThenAdd on a zero accumulator must equal MulRelin (schemes/ckks/evaluator.go:1081 vs :764, schemes/bgv
+    :1230 vs :592); the BGV scale-matching branch is linear in (accumulator, product); ct x pt is the slot-wise product."""
+    rng, ringQ, ringP, ev, sk = setup(4, 2, 3800)
+    t = 65537
+    rlk = gen_evaluation_key(rng, ringQ, ringP, ringQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q), sk)
+    a = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])
+    b = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])
+    z2, z3 = np.zeros((2, 4, N), dtype=np.uint64), np.zeros((3, 4, N), dtype=np.uint64)
+    assert np.array_equal(OC.ckks_mul_relin_then_add(ev, a, b, rlk, z2), ev.CKKSMulRelin(a, b, rlk, True))
+    assert np.array_equal(OC.ckks_mul_relin_then_add(ev, a, b, None, z3), ev.CKKSMulRelin(a, b, None, False))
+    got, so = OC.bgv_mul_relin_then_add(ev, t, a, b, rlk, z2)
+    assert so == 1 and np.array_equal(got, ev.BGVMulRelin(t, a, b, rlk, True))
+    acc = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(3)])
+    got, so = OC.bgv_mul_relin_then_add(ev, t, a, b, None, acc, scales=(3, 5, 7))
+    r0, r1, _ = OC.bgv_match_scales_binary(15, 7, t)
+    assert so == 7 * r1 % t and r0 * 15 % t == r1 * 7 % t
+    prod3 = ev.BGVMulRelin(t, a, b, None, False)
+    want = np.stack([ringQ.binop("Add", ringQ.scalarop("MulScalar", acc[k], r1), ringQ.scalarop("MulScalar", prod3[k], r0))
+                     for k in range(3)])
+    assert np.array_equal(got, want)
+    pt = uniform_poly(rng, ringQ.moduli, N)
+    got = OC.ckks_mul_plaintext(ev, a, pt)
+    gotb = OC.bgv_mul_plaintext(ev, t, a, pt)
+    for i, q in enumerate(ringQ.moduli):
+        for j in (0, 1, N - 1):
+            assert int(got[0, i, j]) == int(pt[i, j]) * int(a[0, i, j]) % q
+            assert int(gotb[1, i, j]) == t * int(pt[i, j]) * int(a[1, i, j]) % q
+    acc2 = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])
+    got = OC.ckks_mul_plaintext(ev, a, pt, acc2)
+    assert np.array_equal(got, np.stack([ringQ.binop("Add", acc2[k], OC.ckks_mul_plaintext(ev, a, pt)[k]) for k in range(2)]))
