@@ -1205,7 +1205,6 @@ struct ModUpFusedArgs {
     const uint64_t *tw_fwd, *tw_inv;
     const double *twd_fwd, *twd_inv;
     int N;
-    int skip_f64_dst;  // unused (kept for layout stability)
 };
 
 // DSTF64 = false: destinations in 64-bit integer arithmetic (any modulus).
@@ -1476,7 +1475,6 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
     A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.twd_fwd = r.twd_fwd; A.twd_inv = r.twd_inv; A.N = r.N;
     const bool use_f64 = (dst_classes & 2) && r.twd_fwd != nullptr;
-    A.skip_f64_dst = 0;
     const int n2 = r.N >> a;
     dim3 grid((unsigned)((n2 + 127) / 128), ndesc, batch), block(128);
     ProfScope ps(K_MODUP, s);
