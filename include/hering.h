@@ -278,7 +278,9 @@ int he_bgv_mul_relin(he_handle eval, int level, uint64_t t, he_handle a0, he_han
 /* The centred lifts of bootstrapping.Evaluator.ModUp (circuits/ckks/bootstrapping/evaluator.go:654-667, 677-696,
  * 742-755): c = src[limb 0][j] (coefficient domain, modulus q = Q[0]); neg = strict ? c > q/2 : c >= q/2; c = neg ?
  * q - c : c; every destination limb i gets t = BRedAdd(c, m_i), neg ? m_i - t : t -- Q limbs first_q..levelQ of dstQ
- * and, when levelP >= 0, P limbs 0..levelP of dstP.  dstQ may be src itself (limbs >= 1 are written). */
+ * and, when levelP >= 0, P limbs 0..levelP of dstP.  dstQ may be src itself (limbs >= 1 are written).
+ * strict = 3: the small-norm form of ringqp.Ring.ExtendBasisSmallNormAndCenter (ring/ringqp/operations.go:325): sign test
+ * c > q/2 and |c| written without reduction (first_q > levelQ writes no Q limb). */
 int he_centered_lift(he_handle eval, int strict, he_handle src, int first_q, int levelQ, he_handle dstQ, int levelP,
                      he_handle dstP);
 /* Every digit of the hoisting buffer := (srcQ limbs 0..levelQ, srcP limbs 0..levelP), the way bootstrapping.ModUp fills

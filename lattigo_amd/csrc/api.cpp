@@ -2051,7 +2051,7 @@ int he_centered_lift(he_handle hev, int strict, he_handle hsrc, int first_q, int
     a.ndst = n;
     if (n > kMaxLimbs) return fail(HE_EINVAL, "%s: too many destination limbs", who);
     Scope sc(be.ctx.get());
-    HIP_TRY(launch_center_copy(be.qp, a, src->view(), dq->view(), dp ? dp->view() : dq->view(), src->batch, be.ctx->stream, strict != 0));
+    HIP_TRY(launch_center_copy(be.qp, a, src->view(), dq->view(), dp ? dp->view() : dq->view(), src->batch, be.ctx->stream, strict & 3));
     return HE_OK;
 }
 int he_decomp_fill(he_handle hdec, int levelQ, int levelP, he_handle hq, he_handle hp) {

@@ -136,9 +136,10 @@ struct ModUpArgs {
 hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a, View src, View dstA, View dstB,
                         int batch, hipStream_t s);
 // single-limb digit: centred copy into every listed limb (ring/basis_extension.go:402-436)
-// strict: the sign test is c > q/2 instead of c >= q/2 (circuits/ckks/bootstrapping/evaluator.go:681 vs :657)
+// strict bit 0: the sign test is c > q/2 instead of c >= q/2 (circuits/ckks/bootstrapping/evaluator.go:681 vs :657);
+// bit 1: |c| is written unreduced (ringqp.Ring.ExtendBasisSmallNormAndCenter, ring/ringqp/operations.go:325)
 hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, View dstA, View dstB, int batch,
-                              hipStream_t s, bool strict = false);
+                              hipStream_t s, int strict = 0);
 
 // Fused basis extension for the key-switch pipelines: [last `a` inverse-NTT stages + N^-1 on the
 // sources] -> ModUpExact (or the centred copy of a one-limb digit) -> [first `a` forward-NTT stages on

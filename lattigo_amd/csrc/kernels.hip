@@ -1499,21 +1499,22 @@ __global__ void __launch_bounds__(256) center_copy_kernel(CenterArgs A) {
     const size_t bz = blockIdx.z;
     const uint64_t qs = A.mc[A.m.src_mod[0]].q;
     uint64_t c = (A.src + bz * A.src_bs)[(size_t)A.m.src_limb[0] * A.N + x];
-    const bool neg = A.strict ? c > (qs >> 1) : c >= (qs >> 1);
+    const bool neg = (A.strict & 1) ? c > (qs >> 1) : c >= (qs >> 1);
     if (neg) c = qs - c;
     const int j = blockIdx.y;
     const ModConst mp = A.mc[A.m.dst_mod[j]];
-    const uint64_t t = bred_add(c, mp.q, mp.brc0);
+    // bit 1: small-norm form, no reduction of |c| (ring/ringqp/operations.go:325-349)
+    const uint64_t t = (A.strict & 2) ? c : bred_add(c, mp.q, mp.brc0);
     uint64_t *dst = A.m.dst_view[j] ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs);
     dst[(size_t)A.m.dst_limb[j] * A.N + x] = neg ? mp.q - t : t;
 }
 hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, View dstA, View dstB, int batch,
-                              hipStream_t s, bool strict) {
+                              hipStream_t s, int strict) {
     if (a.ndst <= 0 || batch <= 0) return hipSuccess;
     CenterArgs A;
     A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
-    A.mc = r.mc; A.N = r.N; A.m = a; A.strict = strict ? 1 : 0;
+    A.mc = r.mc; A.N = r.N; A.m = a; A.strict = strict;
     dim3 grid((unsigned)((r.N + 255) / 256), a.ndst, batch), block(256);
     ProfScope ps(K_CENTER, s);
     hipLaunchKernelGGL(center_copy_kernel, grid, block, 0, s, A);

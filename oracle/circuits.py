@@ -501,3 +501,15 @@ def bgv_mul_relin_then_add(ev, t, op0, op1, rlk, opOut, scales=(1, 1, 1)):
     if r0 != 1:
         c00, c01 = rQ.scalarop("MulScalar", c00, r0), rQ.scalarop("MulScalar", c01, r0)
     return _ct_ct_then_add(ev, c00, c01, op1, rlk, out), so
+
+
+def ExtendBasisSmallNormAndCenter(ringQ, ringP, polyInQ, levelP):
+    """ringqp.Ring.ExtendBasisSmallNormAndCenter (ring/ringqp/operations.go:325-349), 64-bit wrapping arithmetic"""
+    c = np.asarray(polyInQ, dtype=np.uint64)[0]
+    Q = np.uint64(ringQ.moduli[0])
+    neg = c > (Q >> np.uint64(1))
+    coeff = np.where(neg, Q - c, c)
+    out = np.empty((levelP + 1, c.shape[0]), dtype=np.uint64)
+    for i, pi in enumerate(ringP.moduli[: levelP + 1]):
+        out[i] = np.where(neg, np.uint64(pi) - coeff, coeff)
+    return out

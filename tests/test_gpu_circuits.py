@@ -351,3 +351,35 @@ def test_scheme_evaluator_call_sites(ctx):
             got = Rig.down(o)
             for i in range(B):
                 assert np.array_equal(got[i], want(i)), (level, n, i)
+
+
+def test_ringqp_mirror(ctx):
+    """ringqp.Ring (ring/ringqp/operations.go): Q-op then P-op, and ExtendBasisSmallNormAndCenter (:325) word for word,
+    also on coefficients that violate its small-norm precondition."""
+    from lattigo_amd.ringqp import RingQP
+    rg = Rig(ctx, 10, [55, 45, 45], [55, 46], 5000)
+    N, B = rg.N, 2
+    qp = RingQP(rg.pr.gQ, rg.pr.gP, rg.gev).AtLevel(2, 1)
+    q0 = int(rg.q[0])
+    small = rg.rng.integers(-5, 6, size=(B, N))
+    a = np.zeros((B, 3, N), dtype=np.uint64)
+    for i, m in enumerate(rg.q):
+        a[:, i] = np.where(small < 0, int(m) + small, small).astype(np.uint64)
+    a[0, 0, :4] = [q0 >> 1, (q0 >> 1) + 1, q0 - 1, 1 << 50]  # edge / large values
+    pin = la.Poly(rg.pr.gQ, 3, B).upload(a)
+    outQ, outP = la.Poly(rg.pr.gQ, 3, B), la.Poly(rg.pr.gP, 2, B)
+    qp.ExtendBasisSmallNormAndCenter(pin, 1, outQ, outP)
+    for b in range(B):
+        assert np.array_equal(outQ.download()[b], a[b])
+        assert np.array_equal(outP.download()[b], OC.ExtendBasisSmallNormAndCenter(rg.pr.oQ, rg.pr.oP, a[b], 1)), b
+    x = (la.Poly(rg.pr.gQ, 3, B).upload(rg.ct(2, B)[:, 0]), la.Poly(rg.pr.gP, 2, B).upload(
+        np.stack([uniform_poly(rg.rng, rg.p, N) for _ in range(B)])))
+    y, z = qp.NewPoly(B), qp.NewPoly(B)
+    qp.NTT(x, y)
+    qp.MulCoeffsMontgomery(x, y, z)
+    qp.AutomorphismNTT(z, 5, y)
+    xq, xp = x[0].download(), x[1].download()
+    for b in range(B):
+        wq = rg.pr.oQ.AutomorphismNTT(rg.pr.oQ.binop("MulCoeffsMontgomery", xq[b], rg.pr.oQ.NTT(xq[b])), 5)
+        wp = rg.pr.oP.AutomorphismNTT(rg.pr.oP.binop("MulCoeffsMontgomery", xp[b], rg.pr.oP.NTT(xp[b])), 5)
+        assert np.array_equal(y[0].download()[b], wq) and np.array_equal(y[1].download()[b], wp)
