@@ -203,7 +203,14 @@ def main():
             traffic = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
     except Exception:
         pass
+    valu = None  # VALU utilisation of the dominant kernel from the committed SQ-counter pass (profiles/r01_sq_counters.json)
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_counters.json")))
+        valu = sq["kernels"][dom_name]["valu_util"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "valu_util": valu,
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": dom_avg_ms, "launches": dom_launches,
                 "alg_bytes_per_launch": dom_bytes_launch,

@@ -120,24 +120,56 @@ class Evaluator:
     def DecomposeNTT(self, levelQ, levelP, nbPi, c2: Poly, c2IsNTT: bool, decomp: Decomposition):
         check(load().he_decompose_ntt(self.h, levelQ, levelP, nbPi, c2.h, int(c2IsNTT), decomp.h))
 
-    # EvaluatorProvider.GadgetProductLazy (:108); ctQP = [(Q0,P0),(Q1,P1)]
-    def GadgetProductLazy(self, levelQ, cx: Poly, evk: EvaluationKey, ctQP):
+    # EvaluatorProvider.GadgetProductLazy (:108); ctQP = [(Q0,P0),(Q1,P1)].  isNTT is the IsNTT flag of ctQP, i.e. the
+    # domain of cx and of the result (:121-125, :142-152)
+    def GadgetProductLazy(self, levelQ, cx: Poly, evk: EvaluationKey, ctQP, isNTT: bool = True):
         (q0, p0), (q1, p1) = ctQP
-        check(load().he_gadget_product_lazy(self.h, levelQ, cx.h, evk.h, q0.h, p0.h, q1.h, p1.h))
+        if isNTT:
+            check(load().he_gadget_product_lazy(self.h, levelQ, cx.h, evk.h, q0.h, p0.h, q1.h, p1.h))
+            return
+        rQ, rP = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(evk.LevelP())
+        cxNTT = Poly(self.ringQ, levelQ + 1, cx.batch)
+        rQ.NTT(cx, cxNTT)
+        check(load().he_gadget_product_lazy(self.h, levelQ, cxNTT.h, evk.h, q0.h, p0.h, q1.h, p1.h))
+        for q, p in ctQP:  # ringQP.INTT (:121-125)
+            rQ.INTT(q, q)
+            rP.INTT(p, p)
 
     # EvaluatorProvider.GadgetProductHoistedLazy (:379)
     def GadgetProductHoistedLazy(self, levelQ, decomp: Decomposition, evk: EvaluationKey, ctQP):
         (q0, p0), (q1, p1) = ctQP
         check(load().he_gadget_product_hoisted_lazy(self.h, levelQ, decomp.h, evk.h, q0.h, p0.h, q1.h, p1.h))
 
-    # Evaluator.ModDown (:39)
-    def ModDown(self, levelQ, levelP, ctQP, ct):
+    # Evaluator.ModDown (:39-97), the four domain combinations of (ctQP.IsNTT, ct.IsNTT); ctQP is modified in place in the
+    # NTT -> INTT case, as the reference
+    def ModDown(self, levelQ, levelP, ctQP, ct, ctQPIsNTT: bool = True, ctIsNTT: bool = True):
         (q0, p0), (q1, p1) = ctQP
-        check(load().he_moddown(self.h, levelQ, levelP, q0.h, p0.h, q1.h, p1.h, ct[0].h, ct[1].h))
+        if ctQPIsNTT and ctIsNTT:
+            check(load().he_moddown(self.h, levelQ, levelP, q0.h, p0.h, q1.h, p1.h, ct[0].h, ct[1].h))
+            return
+        from .ring import BasisExtender
+        if getattr(self, "_be", None) is None:
+            self._be = BasisExtender(self.ringQ, self.ringP)
+        rQ, rP = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
+        if ctQPIsNTT:  # NTT -> INTT (:51-58)
+            for q, p in ctQP:
+                rQ.INTTLazy(q, q)
+                rP.INTTLazy(p, p)
+        for (q, p), o in zip(ctQP, ct):
+            self._be.ModDownQPtoQ(levelQ, levelP, q, p, o)
+        if not ctQPIsNTT and ctIsNTT:  # INTT -> NTT (:62-67)
+            for o in ct:
+                rQ.NTT(o, o)
 
-    # Evaluator.GadgetProduct (:16) / GadgetProductHoisted (:348)
-    def GadgetProduct(self, levelQ, cx: Poly, evk: EvaluationKey, ct):
-        check(load().he_gadget_product(self.h, levelQ, cx.h, evk.h, ct[0].h, ct[1].h))
+    # Evaluator.GadgetProduct (:16) / GadgetProductHoisted (:348); isNTT = ct.IsNTT (domain of cx and of the result)
+    def GadgetProduct(self, levelQ, cx: Poly, evk: EvaluationKey, ct, isNTT: bool = True):
+        if isNTT:
+            check(load().he_gadget_product(self.h, levelQ, cx.h, evk.h, ct[0].h, ct[1].h))
+            return
+        B = cx.batch
+        ctQP = [(Poly(self.ringQ, levelQ + 1, B), Poly(self.ringP, evk.LevelP() + 1, B)) for _ in range(2)]
+        self.GadgetProductLazy(levelQ, cx, evk, ctQP, isNTT=False)
+        self.ModDown(levelQ, evk.LevelP(), ctQP, ct, ctQPIsNTT=False, ctIsNTT=False)
 
     def GadgetProductHoisted(self, levelQ, decomp: Decomposition, evk: EvaluationKey, ct):
         check(load().he_gadget_product_hoisted(self.h, levelQ, decomp.h, evk.h, ct[0].h, ct[1].h))

@@ -487,3 +487,33 @@ def test_concurrent_callers_share_an_evaluator(ctx):
     [t.join(120) for t in th]
     assert not errs, errs
     assert not any(t.is_alive() for t in th)
+
+
+def test_gadget_product_and_moddown_domain_flags(ctx):
+    """The IsNTT branches of GadgetProductLazy (core/rlwe/evaluator_gadget_product.go:121-125, 142-152) and the four
+    (ctQP.IsNTT, ct.IsNTT) cases of Evaluator.ModDown (:39-71): every result must equal the NTT-domain path up to the
+    strict transforms."""
+    pr, rng, oev, gev, sk = _setup(ctx, 10, 5, 2, 3100)
+    oevk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, SecretKey(rng, pr.oQ, pr.oP))
+    gevk = gev.NewEvaluationKey(oevk.q, oevk.p)
+    for levelQ in (4, 2):
+        sub = O.Ring(pr.N, pr.q[: levelQ + 1])
+        cx = uniform_poly(rng, pr.q[: levelQ + 1], pr.N)         # NTT domain
+        cxc = sub.INTT(cx)                                       # the same polynomial, coefficient domain
+        want = oev.GadgetProduct(levelQ, cx, oevk)               # NTT result
+        wantc = np.stack([sub.INTT(want[k]) for k in range(2)])  # coefficient-domain result
+        wQ, wP = oev.GadgetProductLazy(levelQ, cx, oevk)
+        # coefficient-domain input -> coefficient-domain QP output
+        qp = [(la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gP, 2)) for _ in range(2)]
+        gev.GadgetProductLazy(levelQ, _uploadQ(pr, cxc), gevk, qp, isNTT=False)
+        for k in range(2):
+            assert np.array_equal(qp[k][0].get(), sub.INTT(wQ[k])) and np.array_equal(qp[k][1].get(), pr.oP.INTT(wP[k]))
+        ct = [la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gQ, levelQ + 1)]
+        gev.GadgetProduct(levelQ, _uploadQ(pr, cxc), gevk, ct, isNTT=False)
+        assert np.array_equal(np.stack([c.get() for c in ct]), wantc)
+        for qp_ntt, ct_ntt in ((True, False), (False, True), (False, False), (True, True)):
+            qp = [(la.Poly(pr.gQ, levelQ + 1).upload(wQ[k] if qp_ntt else sub.INTT(wQ[k])),
+                   la.Poly(pr.gP, 2).upload(wP[k] if qp_ntt else pr.oP.INTT(wP[k]))) for k in range(2)]
+            out = [la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gQ, levelQ + 1)]
+            gev.ModDown(levelQ, 1, qp, out, ctQPIsNTT=qp_ntt, ctIsNTT=ct_ntt)
+            assert np.array_equal(np.stack([c.get() for c in out]), want if ct_ntt else wantc), (levelQ, qp_ntt, ct_ntt)
