@@ -1707,7 +1707,9 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
 }
 
 // GadgetProductLazy core: cx (NTT) -> accumulators (views).  Scratch from the arena.
-int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P) {
+// cx_canonical: cx was produced by this library and is known to be in [0, q) (skips the input reduction of the first pass)
+int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P,
+                             bool cx_canonical = false) {
     BasisExtender &be = *ev.be;
     const int levelP = k.nPk - 1, N = be.Q->N;
     const int beta = k.pw2 ? k.prefix[levelQ + 1] : base_rns_size(levelQ, levelP);
@@ -1741,7 +1743,7 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
     const FusedPlan *plan = nullptr;
     TRY(get_dec_plan(ev, levelQ, levelP, levelP + 1, &plan));
     if (plan->ok) {
-        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, cx_canonical ? 0 : NTT_REDUCE_INPUT, be.ctx->stream));
         if (k.keyd) {  // limbs below 2^47: NTT + MAC fused; the rest: row NTT then ks_inner
             TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B, 1));
             TRY(ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
@@ -1755,13 +1757,13 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
     return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
 }
 // ModDownQPtoQNTT up to (not including) its last fused op: sQ = NTTLazy(ModUpPtoQ(INTTLazy(accP))) for nb entries
-int moddown_front(Evaluator &ev, int levelQ, int levelP, View accP, View sP, View sQ, int nb) {
+int moddown_front(Evaluator &ev, int levelQ, int levelP, View accP, View sP, View sQ, int nb, bool canonical = false) {
     BasisExtender &be = *ev.be;
     hipStream_t st = be.ctx->stream;
     const FusedPlan *plan = nullptr;
     TRY(get_md_plan(ev, levelQ, levelP, &plan));
     if (plan->ok) {
-        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, NTT_REDUCE_INPUT, st));
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, canonical ? 0 : NTT_REDUCE_INPUT, st));
         const FusedGroup &g = plan->groups[0];
         HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, nb, st));
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT, st));
@@ -1799,13 +1801,13 @@ int moddown_pair(Evaluator &ev, int levelQ, int levelP, View c0Q, View c0P, View
 // full GadgetProduct: out_k = [add_k +] GadgetProduct(cx)_k.  Both components share every launch
 // (accumulators are laid out [2][B] so ModDown runs once over 2B entries).
 int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp *hoisted, const Evk &k, View out0, View out1, int B,
-                        const View *add0 = nullptr, const View *add1 = nullptr) {
+                        const View *add0 = nullptr, const View *add1 = nullptr, bool cx_canonical = false) {
     BasisExtender &be = *ev.be;
     const int levelP = k.nPk - 1, N = be.Q->N;
     const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
     uint64_t *aQ = be.ctx->arena_take(2 * B * sQw), *aP = be.ctx->arena_take(2 * B * sPw);
     View a0Q{aQ, sQw}, a1Q{aQ + (size_t)B * sQw, sQw}, a0P{aP, sPw}, a1P{aP + (size_t)B * sPw, sPw};
-    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P));
+    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical));
     else TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
     View sP{be.ctx->arena_take(2 * B * sPw), sPw}, sQ{be.ctx->arena_take(2 * B * sQw), sQw};
     const FusedPlan *plan = nullptr;
@@ -1814,7 +1816,7 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         // ModDown with every pass fused: INTT rows (P, both components) -> [cols + ModUpPtoQ + cols] -> NTT rows whose
         // epilogue applies (x - acc) * P^-1 and the caller's Add and writes the final output
         hipStream_t st = be.ctx->stream;
-        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), View{aP, sPw}, sP, 2 * B, true, NTT_REDUCE_INPUT, st));
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), View{aP, sPw}, sP, 2 * B, true, 0, st));  // canonical accumulators
         const FusedGroup &g = plan->groups[0];
         HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, 2 * B, st));
         NttEpilogue epi;
@@ -1824,7 +1826,7 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, out0, 2 * B, false, 0, st, &epi));
         return HE_OK;
     }
-    TRY(moddown_front(ev, levelQ, levelP, View{aP, sPw}, sP, sQ, 2 * B));
+    TRY(moddown_front(ev, levelQ, levelP, View{aP, sPw}, sP, sQ, 2 * B, true));  // accumulators of ks_inner / ntt_mac: canonical
     TRY(moddown_back(ev, levelQ, levelP, sQ, a0Q, out0, add0, B));
     TRY(moddown_back(ev, levelQ, levelP, View{sQ.p + (size_t)B * sQw, sQw}, a1Q, out1, add1, B));
     return HE_OK;
@@ -2196,7 +2198,7 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
     HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),
                           out1->view(), c2, B, st));
     const View o0v = out0->view(), o1v = out1->view();
-    return gadget_product_core(*ev, level, &c2, nullptr, *k, o0v, o1v, B, &o0v, &o1v);
+    return gadget_product_core(*ev, level, &c2, nullptr, *k, o0v, o1v, B, &o0v, &o1v, true);  // c2 from the tensor kernel: canonical
 }
 int he_ckks_mul_relin(he_handle ev, int level, he_handle a0, he_handle a1, he_handle b0, he_handle b1, he_handle rlk, he_handle o0, he_handle o1, he_handle o2) {
     return mul_relin_common(ev, level, false, 0, a0, a1, b0, b1, rlk, o0, o1, o2, "he_ckks_mul_relin");

@@ -431,20 +431,30 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, s0, 0, true);
             __syncthreads();
         }
+        if (A.epi) {
+            // out = [w +] MRed(x + 2q - y, s) with x the transform: the subtraction and the product by s run in double
+            // precision ((x - y) * s_plain mod q, s_plain = s * 2^-64 mod q), only the final CRed(w + .) is on integers so
+            // that a lazy addend w gives the reference's word.  y (a key-switch accumulator) is canonical and below 2^47.
+            const bool second = A.zsplit && (int)bzi >= A.zsplit;
+            const size_t zz = second ? bzi - A.zsplit : bzi;
+            const uint64_t *yp = (second ? A.epi_y2 + zz * A.epi_y2_bs : A.epi_y + zz * A.epi_y_bs) + (size_t)ol * A.N + (size_t)row * N2;
+            const uint64_t *wp = (second ? A.epi_w2 + zz * A.epi_w2_bs : A.epi_w + zz * A.epi_w_bs) + (size_t)ol * A.N + (size_t)row * N2;
+            uint64_t *op = (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs) + (size_t)ol * A.N + (size_t)row * N2;
+            const bool addw = (second ? A.epi2 : A.epi) == 2;
+            const double sp = (double)imform(A.epi_s[y], mc.q, mc.qinv);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int e = k * T + tau;
-            uint64_t v = canon_f64(lds[lds_phys(e)], q, qi);
-            if (A.epi) {
-                const bool second = A.zsplit && (int)bzi >= A.zsplit;
-                const size_t zz = second ? bzi - A.zsplit : bzi;
-                const size_t off = (size_t)ol * A.N + (size_t)row * N2 + e;
-                const uint64_t yv = second ? A.epi_y2[zz * A.epi_y2_bs + off] : A.epi_y[zz * A.epi_y_bs + off];
-                v = mred(v + (mc.q << 1) - yv, A.epi_s[y], mc.q, mc.qinv);
-                if ((second ? A.epi2 : A.epi) == 2) v = cred((second ? A.epi_w2[zz * A.epi_w2_bs + off] : A.epi_w[zz * A.epi_w_bs + off]) + v, mc.q);
-                (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs)[off] = v;
-            } else {
-                dst[e] = v;
+            for (int k = 0; k < 16; k++) {
+                const int e = k * T + tau;
+                const double d = lds[lds_phys(e)] - (double)yp[e];
+                uint64_t v = canon_f64(modmul_f64(d, sp, q, qi), q, qi);
+                if (addw) v = cred(wp[e] + v, mc.q);
+                op[e] = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int e = k * T + tau;
+                dst[e] = canon_f64(lds[lds_phys(e)], q, qi);
             }
         }
     } else {
