@@ -1680,7 +1680,7 @@ int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP
 }
 // class-2 limbs of the gadget product: forward row NTT + key MAC in one kernel (dec holds the post-column state)
 int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View cx,
-               int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch) {
+               int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch, bool q_out_f64 = false) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     NttMacArgs a{};
@@ -1701,15 +1701,35 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
     a.key_dstride = 2 * a.key_kstride;
     a.own_alpha = own_alpha;
     a.own_nq = levelQ + 1;
-    HIP_TRY(launch_ntt_mac_f64(be.qp, a, View{const_cast<uint64_t *>(dec), dec_bs}, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch,
-                               be.ctx->stream));
+    a.q_out_f64 = 0;
+    const View decv{const_cast<uint64_t *>(dec), dec_bs};
+    if (!q_out_f64) {
+        HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
+        return HE_OK;
+    }
+    // double-format Q accumulators: the Q limbs and the P limbs go to separate launches (different store code)
+    NttMacArgs aq = a, ap = a;
+    aq.nlimbs = ap.nlimbs = 0;
+    for (int i = 0; i < n; i++) {
+        NttMacArgs &d = a.out_view[i] ? ap : aq;
+        const int m = d.nlimbs++;
+        d.dec_limb[m] = a.dec_limb[i]; d.key_limb[m] = a.key_limb[i]; d.out_limb[m] = a.out_limb[i];
+        d.out_view[m] = a.out_view[i]; d.mod[m] = a.mod[i];
+    }
+    aq.q_out_f64 = 1;
+    HIP_TRY(launch_ntt_mac_f64(be.qp, aq, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
+    HIP_TRY(launch_ntt_mac_f64(be.qp, ap, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
     return HE_OK;
 }
 
 // GadgetProductLazy core: cx (NTT) -> accumulators (views).  Scratch from the arena.
 // cx_canonical: cx was produced by this library and is known to be in [0, q) (skips the input reduction of the first pass)
+// acc_q_f64 (in/out): on entry, whether the caller can take the Q-limb accumulators of the moduli below 2^47 as doubles; on
+// return, whether they were written that way (only the fused NTT+MAC path does)
 int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P,
-                             bool cx_canonical = false) {
+                             bool cx_canonical = false, bool *acc_q_f64 = nullptr) {
+    const bool want_f64 = acc_q_f64 && *acc_q_f64;
+    if (acc_q_f64) *acc_q_f64 = false;
     BasisExtender &be = *ev.be;
     const int levelP = k.nPk - 1, N = be.Q->N;
     const int beta = k.pw2 ? k.prefix[levelQ + 1] : base_rns_size(levelQ, levelP);
@@ -1747,7 +1767,8 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
         if (k.keyd) {  // limbs below 2^47: NTT + MAC fused; the rest: row NTT then ks_inner
             TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B, 1));
             TRY(ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
-            return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B);
+            if (acc_q_f64) *acc_q_f64 = want_f64;
+            return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64);
         }
         TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B));
         return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
@@ -1807,11 +1828,15 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
     const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
     uint64_t *aQ = be.ctx->arena_take(2 * B * sQw), *aP = be.ctx->arena_take(2 * B * sPw);
     View a0Q{aQ, sQw}, a1Q{aQ + (size_t)B * sQw, sQw}, a0P{aP, sPw}, a1P{aP + (size_t)B * sPw, sPw};
-    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical));
-    else TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
-    View sP{be.ctx->arena_take(2 * B * sPw), sPw}, sQ{be.ctx->arena_take(2 * B * sQw), sQw};
     const FusedPlan *plan = nullptr;
     TRY(get_md_plan(ev, levelQ, levelP, &plan));
+    bool acc_f64 = plan->ok;  // the fused ModDown epilogue can read double accumulators
+    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical, &acc_f64));
+    else {
+        acc_f64 = false;
+        TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
+    }
+    View sP{be.ctx->arena_take(2 * B * sPw), sPw}, sQ{be.ctx->arena_take(2 * B * sQw), sQw};
     if (plan->ok) {
         // ModDown with every pass fused: INTT rows (P, both components) -> [cols + ModUpPtoQ + cols] -> NTT rows whose
         // epilogue applies (x - acc) * P^-1 and the caller's Add and writes the final output
@@ -1822,6 +1847,7 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         NttEpilogue epi;
         for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
         epi.y = a0Q; epi.has_w = add0 != nullptr; epi.w = add0 ? *add0 : a0Q;
+        epi.y_small_f64 = acc_f64;
         epi.zsplit = B; epi.out2 = out1; epi.y2 = a1Q; epi.has_w2 = add1 != nullptr; epi.w2 = add1 ? *add1 : a1Q;
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, out0, 2 * B, false, 0, st, &epi));
         return HE_OK;

@@ -56,6 +56,9 @@ struct NttEpilogue {
     View y, w;
     bool has_w;
     uint64_t s[kMaxLimbs];
+    // the limbs handled by the double-precision kernel hold y as IEEE doubles (integers, |y| < q) -- the accumulators
+    // ntt_mac_f64 wrote with q_out_f64
+    bool y_small_f64 = false;
     // optional second output set: batch entries >= zsplit use (out2, y2, w2) with index z - zsplit
     // (both components of a ciphertext in one launch)
     int zsplit = 0;
@@ -223,6 +226,7 @@ struct NttMacArgs {
     uint8_t dec_limb[kMaxLimbs], key_limb[kMaxLimbs], out_limb[kMaxLimbs], out_view[kMaxLimbs], mod[kMaxLimbs];
     size_t dec_dstride, key_kstride, key_dstride;
     int own_alpha, own_nq;
+    int q_out_f64;   // Q-limb accumulators are written as IEEE doubles (exact integers, |x| < q) for the f64 ModDown epilogue
 };
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
                               View out0P, View out1Q, View out1P, int batch, hipStream_t s);

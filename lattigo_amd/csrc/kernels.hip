@@ -126,6 +126,7 @@ struct NttArgs {
     size_t out2_bs;
     const uint64_t *epi_y2, *epi_w2;
     size_t epi_y2_bs, epi_w2_bs;
+    int epi_y_f64;  // f64 kernel only: y holds doubles
 };
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
@@ -445,7 +446,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int e = k * T + tau;
-                const double d = lds[lds_phys(e)] - (double)yp[e];
+                const double d = lds[lds_phys(e)] - (A.epi_y_f64 ? reinterpret_cast<const double *>(yp)[e] : (double)yp[e]);
                 uint64_t v = canon_f64(modmul_f64(d, sp, q, qi), q, qi);
                 if (addw) v = cred(wp[e] + v, mc.q);
                 op[e] = v;
@@ -511,7 +512,8 @@ struct NttMacKArgs {
     int N, a;
     NttMacArgs m;
 };
-template <int LOGB>
+// QF64: every limb of the launch is a Q limb whose accumulators are written as doubles (NttMacArgs::q_out_f64)
+template <int LOGB, bool QF64>
 __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) ntt_mac_f64_kernel(NttMacKArgs A) {
     constexpr int N2 = 1 << LOGB;
     constexpr int T = N2 / 16;
@@ -579,10 +581,19 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     const bool isP = A.m.out_view[l] != 0;
     uint64_t *o0 = (isP ? A.o0P + bz * A.oP0_bs : A.o0Q + bz * A.oQ0_bs) + (size_t)ol * A.N + rowoff;
     uint64_t *o1 = (isP ? A.o1P + bz * A.oP1_bs : A.o1Q + bz * A.oQ1_bs) + (size_t)ol * A.N + rowoff;
+    if constexpr (QF64) {  // the f64 ModDown epilogue reads these as doubles
+        double *d0 = reinterpret_cast<double *>(o0), *d1 = reinterpret_cast<double *>(o1);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        o0[k * T + tau] = canon_f64(acc0[k], q, qi);
-        o1[k * T + tau] = canon_f64(acc1[k], q, qi);
+        for (int k = 0; k < 16; k++) {
+            d0[k * T + tau] = reduce_f64(acc0[k], q, qi);
+            d1[k * T + tau] = reduce_f64(acc1[k], q, qi);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            o0[k * T + tau] = canon_f64(acc0[k], q, qi);
+            o1[k * T + tau] = canon_f64(acc1[k], q, qi);
+        }
     }
 }
 
@@ -598,8 +609,11 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
     A.mc = r.mc; A.twd = r.twd_fwd; A.N = r.N; A.a = aa; A.m = a;
     dim3 grid(batch, a.nlimbs, 1u << aa);
     ProfScope ps(K_NTT_MAC_F64, s);
-#define HE_MAC_CASE(B) \
-    case B: hipLaunchKernelGGL((ntt_mac_f64_kernel<B>), grid, dim3((1 << B) / 16), 0, s, A); break;
+#define HE_MAC_CASE(B)                                                                                      \
+    case B:                                                                                                 \
+        if (a.q_out_f64) hipLaunchKernelGGL((ntt_mac_f64_kernel<B, true>), grid, dim3((1 << B) / 16), 0, s, A);  \
+        else hipLaunchKernelGGL((ntt_mac_f64_kernel<B, false>), grid, dim3((1 << B) / 16), 0, s, A);             \
+        break;
     switch (b) {
         HE_MAC_CASE(4) HE_MAC_CASE(5) HE_MAC_CASE(6) HE_MAC_CASE(7) HE_MAC_CASE(8) HE_MAC_CASE(9) HE_MAC_CASE(10)
         HE_MAC_CASE(11) HE_MAC_CASE(12) HE_MAC_CASE(13)
@@ -774,6 +788,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     A.tab = tab;
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
+    A.epi_y_f64 = 0;
     dim3 grows(batch, tab.n, 1u << a);
     dim3 gcols((unsigned)(((r.N >> a) + 255) / 256), tab.n, batch);
     hipError_t e;
@@ -824,7 +839,9 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
+    A.epi_y_f64 = 0;
     if (epi) {
+        A.epi_y_f64 = epi->y_small_f64 ? 1 : 0;
         A.epi = epi->has_w ? 2 : 1;
         A.epi_y = epi->y.p; A.epi_y_bs = epi->y.bstride;
         A.epi_w = epi->w.p; A.epi_w_bs = epi->w.bstride;
