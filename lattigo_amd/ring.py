@@ -34,6 +34,8 @@ def _p(a: np.ndarray):
 
 
 def _words(x: int) -> np.ndarray:
+    if x < 0:
+        raise ValueError("negative big integers must be reduced by the caller")
     w = []
     while True:
         w.append(x & 0xFFFFFFFFFFFFFFFF)
@@ -282,21 +284,31 @@ class Ring:
         sc = np.ascontiguousarray(scalar, dtype=np.uint64)
         check(load().he_mul_rns_scalar_montgomery(self.h, self.level, p1.h, _p(sc), p2.h))
 
+    def _nonneg(self, scalar: int) -> int:
+        """big.Int.Mod is Euclidean: a negative scalar acts as its non-negative residue in every limb"""
+        scalar = int(scalar)
+        if scalar < 0:
+            m = 1
+            for q in self.ModuliChain()[: self.level + 1]:
+                m *= int(q)
+            scalar %= m
+        return scalar
+
     def AddScalarBigint(self, p1: Poly, scalar: int, p2: Poly):
-        w = _words(int(scalar))
+        w = _words(self._nonneg(scalar))
         check(load().he_add_scalar_bigint(self.h, self.level, p1.h, _p(w), len(w), p2.h))
 
     def SubScalarBigint(self, p1: Poly, scalar: int, p2: Poly):
-        w = _words(int(scalar))
+        w = _words(self._nonneg(scalar))
         check(load().he_sub_scalar_bigint(self.h, self.level, p1.h, _p(w), len(w), p2.h))
 
     def MulScalarBigint(self, p1: Poly, scalar: int, p2: Poly):
-        w = _words(int(scalar))
+        w = _words(self._nonneg(scalar))
         check(load().he_mul_scalar_bigint(self.h, self.level, p1.h, _p(w), len(w), p2.h))
 
     # -- rescale (ring/scaling.go)
     def MulScalarBigintThenAdd(self, p1: Poly, scalar: int, p2: Poly):
-        w = _words(int(scalar))
+        w = _words(self._nonneg(scalar))
         check(load().he_mul_scalar_bigint_then_add(self.h, self.level, p1.h, _p(w), len(w), p2.h))
 
     # Ring.{Add,Sub,Mul}DoubleRNSScalar[ThenAdd] (ring/operations.go:166-184, 249-268)

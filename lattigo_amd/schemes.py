@@ -165,3 +165,177 @@ class BGVEvaluator(_Base):
             r.MulScalar(c01, r0, c01)
         self._ct_ct_then_add(level, c00, c01, op1, rlk, opOut)
         return so
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# bgv.Evaluator on rlwe.Ciphertext objects (level, degree and the scale in Z_t travel with the polynomials): the
+# schemes.Evaluator surface that circuits/common/polynomial is written against.
+# ----------------------------------------------------------------------------------------------------------------
+class Ciphertext:
+    """rlwe.Ciphertext: Value = degree+1 device polynomials (NTT), Level, Scale (an integer mod t for BGV)"""
+
+    def __init__(self, value, level: int, scale: int = 1):
+        self.Value, self.level, self.Scale = list(value), level, int(scale)
+
+    def Degree(self):
+        return len(self.Value) - 1
+
+    def Level(self):
+        return self.level
+
+
+class BGVCiphertextEvaluator:
+    """schemes/bgv Evaluator (standard tensoring) at the rlwe.Ciphertext level: Add (ciphertext or integer, with the
+    scale-matching branch), Mul / MulRelin (ciphertext or integer), MulThenAdd (integer), Relinearize, Rescale, with the
+    reference's level and scale bookkeeping (schemes/bgv/evaluator.go:122-260, 384-470, 500-560, 1056-1140, 1363-1393)."""
+
+    def __init__(self, evaluator: Evaluator, t: int, rlk: EvaluationKey | None = None):
+        self.eval, self.t, self.rlk = evaluator, int(t), rlk
+        self.ringQ = evaluator.ringQ
+        self.low = BGVEvaluator(evaluator, t)
+        self.Q = [int(q) for q in self.ringQ.ModuliChain()]
+        self.tInvModQ, Qi = [], 1  # schemes/bgv/encoder.go:67-71
+        for q in self.Q:
+            Qi *= q
+            self.tInvModQ.append(pow(self.t, -1, Qi))
+
+    # -- allocation helpers
+    def NewCiphertext(self, degree: int, level: int, batch: int = 1) -> Ciphertext:
+        return Ciphertext([Poly(self.ringQ, level + 1, batch) for _ in range(degree + 1)], level, 1)
+
+    def CopyNew(self, ct: Ciphertext) -> Ciphertext:
+        out = self.NewCiphertext(ct.Degree(), ct.level, ct.Value[0].batch)
+        for a, b in zip(ct.Value, out.Value):
+            b.CopyLvl(ct.level, a)
+        out.Scale = ct.Scale
+        return out
+
+    def _resize(self, ct: Ciphertext, degree: int, level: int):
+        """rlwe.Element.Resize: grow (zero polynomials) or shrink the degree, set the level"""
+        B = ct.Value[0].batch if ct.Value else 1
+        while len(ct.Value) < degree + 1:
+            ct.Value.append(Poly(self.ringQ, ct.Value[0].n_limbs if ct.Value else level + 1, B))
+        del ct.Value[degree + 1:]
+        ct.level = level
+
+    def _centered(self, x: int) -> int:
+        x %= self.t
+        return x - self.t if x > (self.t >> 1) else x
+
+    # -- Add (schemes/bgv/evaluator.go:122-205)
+    def Add(self, op0: Ciphertext, op1, opOut: Ciphertext):
+        if isinstance(op1, Ciphertext):
+            level = min(op0.level, op1.level, opOut.level)
+            self._resize(opOut, max(op0.Degree(), op1.Degree()), level)
+            r = self.ringQ.AtLevel(level)
+            if op0.Scale == op1.Scale:  # evaluateInPlace (:207-224)
+                small, large = (op0, op1) if op0.Degree() <= op1.Degree() else (op1, op0)
+                for i in range(small.Degree() + 1):
+                    r.Add(op0.Value[i], op1.Value[i], opOut.Value[i])
+                for i in range(small.Degree() + 1, large.Degree() + 1):
+                    if opOut.Value[i] is not large.Value[i]:
+                        opOut.Value[i].CopyLvl(level, large.Value[i])
+                opOut.Scale = max(op0.Scale, op1.Scale)
+            else:  # matchScaleThenEvaluateInPlace (:226-243)
+                r0, r1, _ = bgv_match_scales_binary(op0.Scale, op1.Scale, self.t)
+                for i in range(op0.Degree() + 1):
+                    r.MulScalar(op0.Value[i], r0, opOut.Value[i])
+                for i in range(op0.Degree() + 1, opOut.Degree() + 1):
+                    opOut.Value[i].Zero()
+                for i in range(op1.Degree() + 1):
+                    r.MulScalarThenAdd(op1.Value[i], r1, opOut.Value[i])
+                opOut.Scale = op0.Scale * r0 % self.t
+            return
+        # integer operand (:144-172): brought to the scale of op0, centred, times T^-1 mod Q, added to c0
+        level = min(op0.level, opOut.level)
+        self._resize(opOut, op0.Degree(), level)
+        v = self._centered(int(op1) * op0.Scale) * self.tInvModQ[level]
+        r = self.ringQ.AtLevel(level)
+        r.AddScalarBigint(op0.Value[0], v, opOut.Value[0])
+        if op0 is not opOut:
+            for i in range(1, op0.Degree() + 1):
+                opOut.Value[i].CopyLvl(level, op0.Value[i])
+            opOut.Scale = op0.Scale
+
+    # -- Mul / MulRelin (:384-470, 500-560, tensorStandard :592-685)
+    def _tensor(self, op0: Ciphertext, op1: Ciphertext, relin: bool, opOut: Ciphertext):
+        level = min(op0.level, op1.level, opOut.level)
+        if op0.Degree() != 1 or op1.Degree() != 1:
+            raise ValueError("cannot tensor: operands must be of degree 1")
+        self._resize(opOut, 1 if relin else 2, level)
+        if relin and self.rlk is None:
+            raise KeyError("cannot Tensor: cannot Relinearize: RelinearizationKey is nil")
+        self.eval.BGVMulRelin(level, self.t, op0.Value, op1.Value, self.rlk if relin else None, opOut.Value)
+        opOut.Scale = op0.Scale * op1.Scale % self.t
+
+    def Mul(self, op0: Ciphertext, op1, opOut: Ciphertext):
+        if isinstance(op1, Ciphertext):
+            self._tensor(op0, op1, False, opOut)
+            return
+        level = min(op0.level, opOut.level)  # integer operand (:414-437)
+        self._resize(opOut, op0.Degree(), level)
+        r = self.ringQ.AtLevel(level)
+        v = self._centered(int(op1))
+        for i in range(op0.Degree() + 1):
+            r.MulScalarBigint(op0.Value[i], v, opOut.Value[i])
+        opOut.Scale = op0.Scale
+
+    def MulRelin(self, op0: Ciphertext, op1, opOut: Ciphertext):
+        if isinstance(op1, Ciphertext):
+            self._tensor(op0, op1, True, opOut)
+        else:
+            self.Mul(op0, op1, opOut)
+
+    def MulNew(self, op0: Ciphertext, op1) -> Ciphertext:
+        B = op0.Value[0].batch
+        if isinstance(op1, Ciphertext):
+            out = self.NewCiphertext(op0.Degree() + op1.Degree(), min(op0.level, op1.level), B)
+        else:
+            out = self.NewCiphertext(op0.Degree(), op0.level, B)
+        self.Mul(op0, op1, out)
+        return out
+
+    def MulRelinNew(self, op0: Ciphertext, op1) -> Ciphertext:
+        B = op0.Value[0].batch
+        out = self.NewCiphertext(1, min(op0.level, op1.level) if isinstance(op1, Ciphertext) else op0.level, B)
+        self.MulRelin(op0, op1, out)
+        return out
+
+    # -- MulThenAdd with an integer operand (:1108-1140)
+    def MulThenAdd(self, op0: Ciphertext, op1: int, opOut: Ciphertext):
+        level = min(op0.level, opOut.level)
+        self._resize(opOut, op0.Degree(), opOut.level)  # (sic) the reference resizes to op0's degree
+        v = int(op1)
+        if op0.Scale != opOut.Scale:
+            v *= pow(op0.Scale, self.t - 2, self.t) * opOut.Scale % self.t
+        v = self._centered(v)
+        r = self.ringQ.AtLevel(level)
+        for i in range(op0.Degree() + 1):
+            r.MulScalarBigintThenAdd(op0.Value[i], v, opOut.Value[i])
+
+    # -- Relinearize (rlwe.Evaluator.Relinearize) / Rescale (:1363-1393)
+    def Relinearize(self, op0: Ciphertext, opOut: Ciphertext):
+        if self.rlk is None:
+            raise KeyError("cannot Relinearize: RelinearizationKey is nil")
+        level = min(op0.level, opOut.level)
+        B = op0.Value[0].batch
+        out = [Poly(self.ringQ, level + 1, B), Poly(self.ringQ, level + 1, B)] if opOut is op0 else None
+        tgt = out if out is not None else opOut.Value[:2]
+        if out is None:
+            self._resize(opOut, 1, level)
+            tgt = opOut.Value
+        self.eval.Relinearize(level, op0.Value, self.rlk, tgt)
+        if out is not None:
+            opOut.Value = out
+            opOut.level = level
+        opOut.Scale = op0.Scale
+
+    def Rescale(self, op0: Ciphertext, opOut: Ciphertext):
+        if op0.level == 0:
+            raise ValueError("cannot rescale: op0 already at level 0")
+        level = op0.level
+        r = self.ringQ.AtLevel(level)
+        for a, o in zip(op0.Value, opOut.Value):
+            r.DivRoundByLastModulusNTT(a, o)
+        self._resize(opOut, op0.Degree(), level - 1)
+        opOut.Scale = op0.Scale * pow(self.Q[level], -1, self.t) % self.t

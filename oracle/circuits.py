@@ -513,3 +513,141 @@ def ExtendBasisSmallNormAndCenter(ringQ, ringP, polyInQ, levelP):
     for i, pi in enumerate(ringP.moduli[: levelP + 1]):
         out[i] = np.where(neg, np.uint64(pi) - coeff, coeff)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bgv.Evaluator at the rlwe.Ciphertext level (numpy arrays), the backend the polynomial evaluator is checked against
+# ---------------------------------------------------------------------------------------------------------------
+class Ct:
+    """Value: list of [limbs][N] arrays (limbs = level + 1), Scale in Z_t"""
+
+    def __init__(self, value, scale=1):
+        self.Value, self.Scale = [np.asarray(v, dtype=np.uint64) for v in value], int(scale)
+
+    @property
+    def level(self):
+        return self.Value[0].shape[0] - 1
+
+    def Degree(self):
+        return len(self.Value) - 1
+
+    def Level(self):
+        return self.level
+
+
+class BGVCtEvaluator:
+    """schemes/bgv/evaluator.go:122-260, 384-470, 500-560, 592-685, 1056-1140, 1363-1393 on numpy ciphertexts"""
+
+    def __init__(self, ev: O.Evaluator, t: int, rlk=None):
+        self.ev, self.t, self.rlk, self.ringQ = ev, int(t), rlk, ev.ringQ
+        self.Q = [int(q) for q in ev.ringQ.moduli]
+        self.tInvModQ, Qi = [], 1
+        for q in self.Q:
+            Qi *= q
+            self.tInvModQ.append(pow(self.t, -1, Qi))
+
+    def NewCiphertext(self, degree, level, batch=1):
+        return Ct([np.zeros((level + 1, self.ringQ.N), dtype=np.uint64) for _ in range(degree + 1)], 1)
+
+    def CopyNew(self, ct):
+        return Ct([v.copy() for v in ct.Value], ct.Scale)
+
+    def _set(self, ct, values, level):
+        ct.Value = [np.asarray(v, dtype=np.uint64)[: level + 1].copy() for v in values]
+
+    def _centered(self, x):
+        x %= self.t
+        return x - self.t if x > (self.t >> 1) else x
+
+    def Add(self, op0, op1, opOut):
+        rQ = self.ringQ
+        if isinstance(op1, Ct):
+            level = min(op0.level, op1.level, opOut.level)
+            cut = lambda v: v[: level + 1]
+            if op0.Scale == op1.Scale:
+                small, large = (op0, op1) if op0.Degree() <= op1.Degree() else (op1, op0)
+                vals = [rQ.binop("Add", cut(op0.Value[i]), cut(op1.Value[i])) for i in range(small.Degree() + 1)]
+                vals += [cut(large.Value[i]) for i in range(small.Degree() + 1, large.Degree() + 1)]
+                scale = max(op0.Scale, op1.Scale)
+            else:
+                r0, r1, _ = bgv_match_scales_binary(op0.Scale, op1.Scale, self.t)
+                deg = max(op0.Degree(), op1.Degree())
+                vals = [rQ.scalarop("MulScalar", cut(op0.Value[i]), r0) if i <= op0.Degree()
+                        else np.zeros((level + 1, rQ.N), dtype=np.uint64) for i in range(deg + 1)]
+                for i in range(op1.Degree() + 1):
+                    vals[i] = rQ.scalarop("MulScalarThenAdd", cut(op1.Value[i]), r1, vals[i])
+                scale = op0.Scale * r0 % self.t
+            self._set(opOut, vals, level)
+            opOut.Scale = scale
+            return
+        level = min(op0.level, opOut.level)
+        v = self._centered(int(op1) * op0.Scale) * self.tInvModQ[level]
+        vals = [rQ.AddScalarBigint(op0.Value[0][: level + 1], v)] + [x[: level + 1] for x in op0.Value[1:]]
+        scale = op0.Scale
+        self._set(opOut, vals, level)
+        opOut.Scale = scale
+
+    def _tensor(self, op0, op1, relin, opOut):
+        level = min(op0.level, op1.level, opOut.level)
+        a = np.stack([v[: level + 1] for v in op0.Value])
+        b = np.stack([v[: level + 1] for v in op1.Value])
+        out = self.ev.BGVMulRelin(self.t, a, b, self.rlk if relin else None, relin)
+        self._set(opOut, list(out), level)
+        opOut.Scale = op0.Scale * op1.Scale % self.t
+
+    def Mul(self, op0, op1, opOut):
+        if isinstance(op1, Ct):
+            return self._tensor(op0, op1, False, opOut)
+        level = min(op0.level, opOut.level)
+        v = self._centered(int(op1))
+        vals = [self.ringQ.MulScalarBigint(x[: level + 1], v) for x in op0.Value]
+        scale = op0.Scale
+        self._set(opOut, vals, level)
+        opOut.Scale = scale
+
+    def MulRelin(self, op0, op1, opOut):
+        if isinstance(op1, Ct):
+            return self._tensor(op0, op1, True, opOut)
+        self.Mul(op0, op1, opOut)
+
+    def MulNew(self, op0, op1):
+        lv = min(op0.level, op1.level) if isinstance(op1, Ct) else op0.level
+        out = self.NewCiphertext(1, lv)
+        self.Mul(op0, op1, out)
+        return out
+
+    def MulRelinNew(self, op0, op1):
+        lv = min(op0.level, op1.level) if isinstance(op1, Ct) else op0.level
+        out = self.NewCiphertext(1, lv)
+        self.MulRelin(op0, op1, out)
+        return out
+
+    def MulThenAdd(self, op0, op1, opOut):
+        level = min(op0.level, opOut.level)
+        v = int(op1)
+        if op0.Scale != opOut.Scale:
+            v *= O.BRed(O.ModExp(op0.Scale, self.t - 2, self.t), opOut.Scale, self.t)
+        v = self._centered(v)
+        vals = list(opOut.Value[: op0.Degree() + 1])  # Resize(op0.Degree(), ...)
+        while len(vals) < op0.Degree() + 1:
+            vals.append(np.zeros((opOut.level + 1, self.ringQ.N), dtype=np.uint64))
+        for i in range(op0.Degree() + 1):
+            head = self.ringQ.MulScalarBigintThenAdd(op0.Value[i][: level + 1], v, vals[i][: level + 1])
+            vals[i] = np.concatenate([head, vals[i][level + 1:]])
+        opOut.Value = vals
+
+    def Relinearize(self, op0, opOut):
+        level = min(op0.level, opOut.level)
+        out = self.ev.Relinearize(np.stack([v[: level + 1] for v in op0.Value]), self.rlk)
+        scale = op0.Scale
+        self._set(opOut, list(out), level)
+        opOut.Scale = scale
+
+    def Rescale(self, op0, opOut):
+        if op0.level == 0:
+            raise ValueError("cannot rescale: op0 already at level 0")
+        level = op0.level
+        vals = [self.ringQ.DivRoundByLastModulusNTT(v) for v in op0.Value]
+        scale = op0.Scale * pow(self.Q[level], -1, self.t) % self.t
+        self._set(opOut, vals, level - 1)
+        opOut.Scale = scale

@@ -349,7 +349,13 @@ class Ring:
     def _bigint(self, fn, p1, scalar, level):
         p1 = _c(p1)
         level = p1.shape[0] - 1 if level is None else level
-        w = _words(int(scalar))
+        scalar = int(scalar)
+        if scalar < 0:  # big.Int.Mod is Euclidean: a negative scalar is its non-negative residue in every limb
+            m = 1
+            for q in self.moduli[: level + 1]:
+                m *= q
+            scalar %= m
+        w = _words(scalar)
         out = np.zeros_like(p1)
         getattr(lib(), fn)(self._h, level, _p(p1), _p(w), len(w), _p(out))
         return out

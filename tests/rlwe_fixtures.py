@@ -189,3 +189,37 @@ def negacyclic_mul_mod(a, b, t: int):
     full = np.convolve(np.asarray(a, dtype=object), np.asarray(b, dtype=object))
     out = [int(full[k]) - (int(full[k + N]) if k + N < len(full) else 0) for k in range(N)]
     return np.array([x % t for x in out], dtype=np.int64)
+
+
+def bgv_encrypt(rng, ringQ: O.Ring, sk: SecretKey, m, t: int, scale: int = 1, sigma: float = 3.2) -> np.ndarray:
+    """BGV ciphertext as the reference's bgv package holds it (schemes/bgv/encoder.go:395-406): phase =
+    centred(m * scale mod t) * (T^-1 mod Q) + e; m is a polynomial of R_t (coefficient domain)."""
+    Q = prod(ringQ.moduli)
+    tinv = pow(t, -1, Q)
+    N = ringQ.N
+    e = np.clip(np.rint(rng.normal(0.0, sigma, size=N)), -19, 19).astype(np.int64)
+    pt = []
+    for mi, ei in zip(m, e):
+        v = int(mi) * scale % t
+        v = v - t if v > t // 2 else v
+        pt.append((v * tinv + int(ei)) % Q)
+    ptr = np.array([[x % int(qi) for x in pt] for qi in ringQ.moduli], dtype=np.uint64)
+    c1 = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringQ.moduli])
+    c0 = ringQ.binop("Sub", ringQ.NTT(ptr), ringQ.binop("MulCoeffsMontgomery", c1, sk.Q[: len(ringQ.moduli)]))
+    return np.stack([c0, c1])
+
+
+def bgv_decrypt(ringQ: O.Ring, ct: np.ndarray, sk: SecretKey, t: int, scale: int = 1):
+    """(T * phase mod Q, centred) mod t, divided by the scale"""
+    Q = prod(ringQ.moduli)
+    ph = ringQ.INTT(phase(ringQ, ct, sk.Q))
+    w = [(Q // int(qi)) * pow(Q // int(qi), -1, int(qi)) for qi in ringQ.moduli]
+    sinv = pow(scale, -1, t)
+    out = []
+    for j in range(ringQ.N):
+        x = sum(int(ph[i, j]) * w[i] for i in range(len(w))) % Q
+        y = x * t % Q
+        if y > Q // 2:
+            y -= Q
+        out.append(y % t * sinv % t)
+    return np.array(out, dtype=np.int64)

@@ -383,3 +383,27 @@ def test_ringqp_mirror(ctx):
         wq = rg.pr.oQ.AutomorphismNTT(rg.pr.oQ.binop("MulCoeffsMontgomery", xq[b], rg.pr.oQ.NTT(xq[b])), 5)
         wp = rg.pr.oP.AutomorphismNTT(rg.pr.oP.binop("MulCoeffsMontgomery", xp[b], rg.pr.oP.NTT(xp[b])), 5)
         assert np.array_equal(y[0].download()[b], wq) and np.array_equal(y[1].download()[b], wp)
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3, 7, 8, 17, 33])
+def test_bgv_polynomial_evaluation(ctx, deg):
+    """circuits/bgv/polynomial Evaluator.Evaluate with the device-resident bgv.Evaluator mirror as the backend vs the oracle
+    backend (whose composition test_oracle_circuits.py pins by decryption): same polynomials, scale and level, batch 2."""
+    from lattigo_amd import polyeval as PE
+    from lattigo_amd import schemes as S
+    rg = Rig(ctx, 10, [55, 45, 45, 45, 45, 45, 45, 45], [55, 55], 5100 + deg)
+    rg.keys([1])
+    t, B, top = 65537, 2, 7
+    gbe = S.BGVCiphertextEvaluator(rg.gev, t, rg.ggks.keys[1])
+    obe = OC.BGVCtEvaluator(rg.oev, t, rg.ogks[1])
+    ct = rg.ct(top, B)
+    coeffs = [int(x) for x in rg.rng.integers(0, t, size=deg + 1)]
+    coeffs[-1] = coeffs[-1] or 1
+    gct = S.Ciphertext(rg.up(ct), top, 3)
+    res = PE.PolynomialEvaluator(gbe).Evaluate(gct, coeffs, 11)
+    got = np.stack([p.download() for p in res.Value], axis=1)  # [B][2][limbs][N]
+    for b in range(B):
+        want = PE.PolynomialEvaluator(obe).Evaluate(OC.Ct(list(ct[b]), 3), coeffs, 11)
+        assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (11, top - deg.bit_length(), 1)
+        assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (deg, b)
+    assert np.array_equal(gct.Value[0].download(), ct[:, 0])  # the input ciphertext is left untouched

@@ -270,3 +270,41 @@ def test_scheme_call_sites_are_consistent_with_the_pinned_tensoring():
     acc2 = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])
     got = OC.ckks_mul_plaintext(ev, a, pt, acc2)
     assert np.array_equal(got, np.stack([ringQ.binop("Add", acc2[k], OC.ckks_mul_plaintext(ev, a, pt)[k]) for k in range(2)]))
+
+
+def _ring_poly_eval(coeffs, m, t):
+    """p(m) in R_t = Z_t[X]/(X^N+1) by Horner"""
+    from tests.rlwe_fixtures import negacyclic_mul_mod
+    acc = np.zeros(len(m), dtype=np.int64)
+    for c in reversed(coeffs):
+        acc = negacyclic_mul_mod(acc, m, t)
+        acc[0] = (acc[0] + c) % t
+    return acc
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3, 5, 7, 8, 12, 17])
+def test_bgv_polynomial_evaluation_decrypts(deg):
+    """circuits/bgv/polynomial Evaluator.Evaluate (Paterson-Stockmeyer over the power basis, level / scale planning by the
+    simulated evaluator) with the oracle as the bgv.Evaluator backend: Dec(p(ct)) = p(m) in R_t, output scale = target."""
+    from lattigo_amd import polyeval as PE
+    from tests.rlwe_fixtures import bgv_decrypt, bgv_encrypt
+    t = 65537
+    q, p = O.GenModuli(10, [55, 45, 45, 45, 45, 45, 45], [55, 55])
+    rng = rng_for(3900 + deg)
+    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
+    ev = O.Evaluator(ringQ, ringP)
+    sk = SecretKey(rng, ringQ, ringP)
+    rlk = gen_evaluation_key(rng, ringQ, ringP, ringQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q), sk)
+    be = OC.BGVCtEvaluator(ev, t, rlk)
+    m = rng.integers(0, t, size=N)
+    in_scale = 3
+    ct = OC.Ct(list(bgv_encrypt(rng, ringQ, sk, m, t, in_scale)), in_scale)
+    coeffs = [int(x) for x in rng.integers(0, t, size=deg + 1)]
+    coeffs[-1] = coeffs[-1] or 1
+    target = 7
+    res = PE.PolynomialEvaluator(be).Evaluate(ct, coeffs, target)
+    assert res.Scale == target and res.Degree() == 1
+    assert res.level == len(q) - 1 - deg.bit_length()  # PolynomialDepth(deg) levels + the final Rescale
+    sub = O.Ring(N, q[: res.level + 1])
+    got = bgv_decrypt(sub, np.stack(res.Value), sk, t, res.Scale)
+    assert np.array_equal(got, _ring_poly_eval(coeffs, m, t))
