@@ -1,8 +1,9 @@
 """Host-side mirror of circuits/common/polynomial + circuits/bgv/polynomial: Paterson-Stockmeyer evaluation of a polynomial
 with integer coefficients on a BGV ciphertext (power basis, baby steps from the power basis, giant steps by monomials,
 level / scale planning by the simulated evaluator).  Pure control flow over a ``schemes.Evaluator``-shaped backend
-(``schemes.BGVCiphertextEvaluator`` on the device); every ring operation it triggers runs in the HIP kernels.
-Monomial basis, single polynomial (no slot mapping)."""
+(``schemes.BGVCiphertextEvaluator`` / ``schemes.CKKSCiphertextEvaluator`` on the device); every ring operation it triggers
+runs in the HIP kernels.  Monomial and Chebyshev bases, single polynomial (no slot mapping); the CKKS instantiation
+(circuits/ckks/polynomial) keeps scales as exact rationals."""
 from __future__ import annotations
 
 
@@ -28,8 +29,9 @@ class Polynomial:
     """polynomial.Polynomial over bignum.Polynomial in the monomial basis (circuits/common/polynomial/polynomial.go:12-30,
     utils/bignum/polynomial.go:44-151); NewPolynomial marks it both even and odd, i.e. no parity filtering."""
 
-    def __init__(self, coeffs, MaxDeg=None, Lead=True, Lazy=False):
+    def __init__(self, coeffs, MaxDeg=None, Lead=True, Lazy=False, Basis="Monomial"):
         self.Coeffs = list(coeffs)
+        self.Basis = Basis
         self.MaxDeg = len(self.Coeffs) - 1 if MaxDeg is None else MaxDeg
         self.Lead, self.Lazy = Lead, Lazy
         self.Level, self.Scale = 0, 1
@@ -42,16 +44,42 @@ class Polynomial:
         return (d - 1).bit_length() if d > 1 else 0  # ceil(log2(degree))
 
     def Factorize(self, n: int):
-        """p = q * X^n + r (polynomial.go:32-52 over utils/bignum/polynomial.go:258-314, monomial case)"""
+        """p = q * X^n + r, resp. q * T_n + r (polynomial.go:32-52 over utils/bignum/polynomial.go:258-314)"""
         if n < self.Degree() >> 1:
             raise ValueError("cannot Factorize: n < p.Degree()/2")
-        pr = Polynomial(self.Coeffs[:n], Lead=False)
-        pq = Polynomial(self.Coeffs[n:], Lead=False)
+        r = list(self.Coeffs[:n])
+        q = list(self.Coeffs[n:])
+        if self.Basis == "Chebyshev":  # T_i = 2 T_n T_{i-n} - T_{2n-i}
+            for i in range(n + 1, self.Degree() + 1):
+                j = i - n
+                q[i - n] = _cadd(self.Coeffs[i], self.Coeffs[i])
+                r[n - j] = _csub(r[n - j], self.Coeffs[i])
+        pr = Polynomial(r, Lead=False, Basis=self.Basis)
+        pq = Polynomial(q, Lead=False, Basis=self.Basis)
         pq.MaxDeg = self.MaxDeg
         pr.MaxDeg = n - 1 if self.MaxDeg == self.Degree() else self.MaxDeg - (self.Degree() - n + 1)
         pq.Lead = self.Lead
         pq.Lazy = pr.Lazy = False
         return pq, pr
+
+
+def _cpair(c):
+    from fractions import Fraction
+    if isinstance(c, tuple):
+        return Fraction(c[0]), Fraction(c[1])
+    if isinstance(c, complex):
+        return Fraction(c.real), Fraction(c.imag)
+    return Fraction(c), Fraction(0)
+
+
+def _cadd(a, b):
+    (ar, ai), (br, bi) = _cpair(a), _cpair(b)
+    return (ar + br, ai + bi)
+
+
+def _csub(a, b):
+    (ar, ai), (br, bi) = _cpair(a), _cpair(b)
+    return (ar - br, ai - bi)
 
 
 class SimOperand:
@@ -88,6 +116,33 @@ class BGVSimEvaluator:
         tScaleNew = self._div(tScaleOld, xPowScale)
         currentQi = self.Q[tLevelNew] if lead else self.Q[tLevelNew + 1]
         return tLevelNew + 1, tScaleNew * (currentQi % self.t) % self.t
+
+
+class CKKSSimEvaluator:
+    """circuits/ckks/polynomial/polynomial_evaluator_sim.go with LevelsConsumedPerRescaling = 1; exact rational scales"""
+
+    def __init__(self, Q):
+        from fractions import Fraction
+        self.Q = [Fraction(int(q)) for q in Q]
+
+    def PolynomialDepth(self, degree: int) -> int:
+        if degree <= 0:
+            raise ValueError(f"invalid degree: degree={degree} should be greater than zero")
+        return degree.bit_length() - 1
+
+    def Rescale(self, op0: SimOperand):
+        op0.Scale = op0.Scale / self.Q[op0.Level]
+        op0.Level -= 1
+
+    def MulNew(self, op0: SimOperand, op1: SimOperand) -> SimOperand:
+        return SimOperand(min(op0.Level, op1.Level), op0.Scale * op1.Scale)
+
+    def UpdateLevelAndScaleBabyStep(self, lead, tLevelOld, tScaleOld):
+        return tLevelOld, (tScaleOld * self.Q[tLevelOld] if lead else tScaleOld)
+
+    def UpdateLevelAndScaleGiantStep(self, lead, tLevelOld, tScaleOld, xPowScale):
+        qi = self.Q[tLevelOld] if lead else self.Q[tLevelOld + 1]
+        return tLevelOld + 1, tScaleOld * qi / xPowScale
 
 
 def _sim_gen_power(d: dict, n: int, sim):
@@ -139,8 +194,9 @@ def PatersonStockmeyerPolynomial(p: Polynomial, inputLevel, inputScale, outputSc
 class PowerBasis:
     """polynomial.PowerBasis (power_basis.go:17-160), monomial basis"""
 
-    def __init__(self, ct, evaluator):
+    def __init__(self, ct, evaluator, Basis="Monomial"):
         self.Value = {1: evaluator.CopyNew(ct)}
+        self.Basis = Basis
 
     def GenPower(self, n: int, lazy: bool, ev):
         if n not in self.Value:
@@ -163,6 +219,14 @@ class PowerBasis:
         if rescaleB:
             ev.Rescale(self.Value[b], self.Value[b])
         self.Value[n] = ev.MulNew(self.Value[a], self.Value[b]) if lazy else ev.MulRelinNew(self.Value[a], self.Value[b])
+        if self.Basis == "Chebyshev":  # T_n = 2 T_a T_b - T_|a-b| (power_basis.go:135-157)
+            c = abs(a - b)
+            ev.Add(self.Value[n], self.Value[n], self.Value[n])
+            if c == 0:
+                ev.Add(self.Value[n], -1, self.Value[n])
+            else:
+                self.GenPower(c, lazy, ev)
+                ev.Sub(self.Value[n], self.Value[c], self.Value[n])
         return True
 
 
@@ -178,13 +242,19 @@ class PolynomialEvaluator:
 
     def __init__(self, evaluator):
         self.eval = evaluator
-        self.sim = BGVSimEvaluator(evaluator.Q, evaluator.t)
+        self.bgv = getattr(evaluator, "t", None) is not None
+        self.sim = BGVSimEvaluator(evaluator.Q, evaluator.t) if self.bgv else CKKSSimEvaluator(evaluator.Q)
 
     def Evaluate(self, ct, coeffs, targetScale: int):
         """Evaluator.Evaluate (:33-92): ct -> p(ct), p = sum coeffs[i] X^i over Z_t"""
         ev = self.eval
-        p = coeffs if isinstance(coeffs, Polynomial) else Polynomial([int(c) % ev.t for c in coeffs])
-        pb = PowerBasis(ct, ev)
+        if isinstance(coeffs, Polynomial):
+            p = coeffs
+        elif self.bgv:
+            p = Polynomial([int(c) % ev.t for c in coeffs])
+        else:
+            p = Polynomial([_cpair(c) for c in coeffs])
+        pb = PowerBasis(ct, ev, p.Basis)
         level, depth = pb.Value[1].Level(), p.Depth()
         if level < depth:
             raise ValueError(f"{level} levels < {depth} log(d) -> cannot evaluate poly")
@@ -193,7 +263,12 @@ class PolynomialEvaluator:
         pb.GenPower(1 << (logDegree - 1), False, ev)
         for i in range((1 << logSplit) - 1, 2, -1):
             pb.GenPower(i, p.Lazy, ev)
-        PS = PatersonStockmeyerPolynomial(p, pb.Value[1].Level(), pb.Value[1].Scale, int(targetScale) % ev.t, self.sim)
+        if self.bgv:
+            targetScale = int(targetScale) % ev.t
+        else:
+            from fractions import Fraction
+            targetScale = Fraction(targetScale)
+        PS = PatersonStockmeyerPolynomial(p, pb.Value[1].Level(), pb.Value[1].Scale, targetScale, self.sim)
         return self.EvaluatePatersonStockmeyerPolynomial(PS, pb)
 
     def EvaluatePatersonStockmeyerPolynomial(self, polys, pb: PowerBasis):

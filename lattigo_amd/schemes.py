@@ -339,3 +339,175 @@ class BGVCiphertextEvaluator:
             r.DivRoundByLastModulusNTT(a, o)
         self._resize(opOut, op0.Degree(), level - 1)
         opOut.Scale = op0.Scale * pow(self.Q[level], -1, self.t) % self.t
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ckks.Evaluator on rlwe.Ciphertext objects.  Scales are exact rationals (fractions.Fraction) where the reference keeps
+# 128-bit floats, and a constant c is encoded as round-half-away(c * scale) computed exactly (the reference rounds a
+# big.Float product, schemes/ckks/scaling.go:10-43): the encoded integer can differ from the reference's by one unit in
+# its last place, far below the noise.  Everything after that point is the same integer arithmetic, bit for bit.
+# ----------------------------------------------------------------------------------------------------------------
+def _round_half_away(x):
+    from fractions import Fraction
+    x = Fraction(x)
+    if x > 0:
+        return (x + Fraction(1, 2)).__floor__()
+    if x < 0:
+        return -((-x + Fraction(1, 2)).__floor__())
+    return 0
+
+
+def _as_complex_fraction(c):
+    from fractions import Fraction
+    if isinstance(c, tuple):
+        return Fraction(c[0]), Fraction(c[1])
+    if isinstance(c, complex):
+        return Fraction(c.real), Fraction(c.imag)
+    return Fraction(c), Fraction(0)
+
+
+class CKKSCiphertextEvaluator:
+    """schemes/ckks Evaluator at the rlwe.Ciphertext level (one level per rescaling): Add / Sub (ciphertext or constant),
+    Mul / MulRelin (ciphertext or constant), MulThenAdd (constant), Relinearize, Rescale
+    (schemes/ckks/evaluator.go:42-135, 221-424, 477-515, 570-760, 875-940)."""
+
+    def __init__(self, evaluator: Evaluator, rlk: EvaluationKey | None = None):
+        self.eval, self.rlk, self.ringQ = evaluator, rlk, evaluator.ringQ
+        self.Q = [int(q) for q in self.ringQ.ModuliChain()]
+        self.t = None
+        # RootsForward[1] of every limb as a plain integer: the square root of -1 that evaluateWithScalar uses (:417)
+        self.imag_unit = [int(self.ringQ.roots(i)[1]) * pow(1 << 64, -1, q) % q for i, q in enumerate(self.Q)]
+
+    NewCiphertext = BGVCiphertextEvaluator.NewCiphertext
+    CopyNew = BGVCiphertextEvaluator.CopyNew
+    _resize = BGVCiphertextEvaluator._resize
+
+    def _rns(self, level, scale, c):
+        """bigComplexToRNSScalar + the (a + b i, a - b i) pair of evaluateWithScalar (schemes/ckks/scaling.go:10, evaluator.go:410)"""
+        re, im = _as_complex_fraction(c)
+        real, imag = _round_half_away(re * scale), _round_half_away(im * scale)
+        s0, s1 = [], []
+        for i, q in enumerate(self.Q[: level + 1]):
+            r, m = real % q, (imag % q) * self.imag_unit[i] % q
+            s0.append((r + m) % q)
+            s1.append((r - m) % q)
+        return np.array(s0, dtype=np.uint64), np.array(s1, dtype=np.uint64)
+
+    @staticmethod
+    def _is_int(c):
+        re, im = _as_complex_fraction(c)
+        return re.denominator == 1 and im.denominator == 1
+
+    def _addsub_ct(self, op0, op1, opOut, sub):
+        from fractions import Fraction
+        level = min(op0.level, op1.level, opOut.level)
+        r = self.ringQ.AtLevel(level)
+        a, b = op0, op1
+        scale = op0.Scale
+        if op0.Scale != op1.Scale:  # evaluateInPlace (:221-400): the smaller scale is brought up by the integer ratio
+            if op0.Scale > op1.Scale:
+                ratio = int(Fraction(op0.Scale) / Fraction(op1.Scale))
+                if ratio > 0:
+                    b = self.NewCiphertext(op1.Degree(), level, op1.Value[0].batch)
+                    self.Mul(op1, ratio, b)
+            else:
+                ratio = int(Fraction(op1.Scale) / Fraction(op0.Scale))
+                if ratio > 0:
+                    a = self.NewCiphertext(op0.Degree(), level, op0.Value[0].batch)
+                    self.Mul(op0, ratio, a)
+                    scale = op1.Scale
+        self._resize(opOut, max(op0.Degree(), op1.Degree()), level)
+        lo = min(a.Degree(), b.Degree())
+        for i in range(lo + 1):
+            (r.Sub if sub else r.Add)(a.Value[i], b.Value[i], opOut.Value[i])
+        for i in range(lo + 1, a.Degree() + 1):
+            if opOut.Value[i] is not a.Value[i]:
+                opOut.Value[i].CopyLvl(level, a.Value[i])
+        for i in range(lo + 1, b.Degree() + 1):
+            if sub:
+                r.Neg(b.Value[i], opOut.Value[i])
+            elif opOut.Value[i] is not b.Value[i]:
+                opOut.Value[i].CopyLvl(level, b.Value[i])
+        opOut.Scale = scale
+
+    def Add(self, op0, op1, opOut):
+        if isinstance(op1, Ciphertext):
+            return self._addsub_ct(op0, op1, opOut, False)
+        level = min(op0.level, opOut.level)  # constant (:68-86)
+        self._resize(opOut, op0.Degree(), level)
+        s0, s1 = self._rns(level, op0.Scale, op1)
+        self.ringQ.AtLevel(level).AddDoubleRNSScalar(op0.Value[0], s0, s1, opOut.Value[0])
+        if op0 is not opOut:
+            for i in range(1, op0.Degree() + 1):
+                opOut.Value[i].CopyLvl(level, op0.Value[i])
+            opOut.Scale = op0.Scale
+
+    def Sub(self, op0, op1, opOut):
+        if isinstance(op1, Ciphertext):
+            return self._addsub_ct(op0, op1, opOut, True)
+        re, im = _as_complex_fraction(op1)
+        self.Add(op0, (-re, -im), opOut)
+
+    def _tensor(self, op0, op1, relin, opOut):
+        level = min(op0.level, op1.level, opOut.level)
+        self._resize(opOut, 1 if relin else 2, level)
+        if relin and self.rlk is None:
+            raise KeyError("cannot relinearize: RelinearizationKey is nil")
+        self.eval.CKKSMulRelin(level, op0.Value, op1.Value, self.rlk if relin else None, opOut.Value)
+        opOut.Scale = op0.Scale * op1.Scale
+
+    def Mul(self, op0, op1, opOut):
+        if isinstance(op1, Ciphertext):
+            return self._tensor(op0, op1, False, opOut)
+        level = min(op0.level, opOut.level)  # constant (:625-660)
+        self._resize(opOut, op0.Degree(), level)
+        scale = 1 if self._is_int(op1) else self.Q[level]
+        s0, s1 = self._rns(level, scale, op1)
+        r = self.ringQ.AtLevel(level)
+        for i in range(op0.Degree() + 1):
+            r.MulDoubleRNSScalar(op0.Value[i], s0, s1, opOut.Value[i])
+        opOut.Scale = op0.Scale * scale
+
+    def MulRelin(self, op0, op1, opOut):
+        if isinstance(op1, Ciphertext):
+            return self._tensor(op0, op1, True, opOut)
+        self.Mul(op0, op1, opOut)
+
+    MulNew = BGVCiphertextEvaluator.MulNew
+    MulRelinNew = BGVCiphertextEvaluator.MulRelinNew
+
+    def MulThenAdd(self, op0, op1, opOut):
+        """constant operand (:893-935)"""
+        from fractions import Fraction
+        level = min(op0.level, opOut.level)
+        self._resize(opOut, op0.Degree(), opOut.level)
+        if op0.Scale == opOut.Scale:
+            if self._is_int(op1):
+                scale = 1
+            else:
+                scale = self.Q[level]
+                self.Mul(opOut, scale, opOut)  # an integer: the scale factor of Mul is 1, so set the new scale by hand
+                opOut.Scale = opOut.Scale * scale
+        elif op0.Scale < opOut.Scale:
+            scale = Fraction(opOut.Scale) / Fraction(op0.Scale)
+        else:
+            raise ValueError("cannot MulThenAdd: op0.Scale > opOut.Scale is not supported")
+        s0, s1 = self._rns(level, scale, op1)
+        r = self.ringQ.AtLevel(level)
+        for i in range(op0.Degree() + 1):
+            r.MulDoubleRNSScalarThenAdd(op0.Value[i], s0, s1, opOut.Value[i])
+
+    def Relinearize(self, op0, opOut):
+        BGVCiphertextEvaluator.Relinearize(self, op0, opOut)
+
+    def Rescale(self, op0, opOut):
+        """:477-515 with LevelsConsumedPerRescaling = 1"""
+        from fractions import Fraction
+        if op0.level <= 0:
+            raise ValueError("cannot Rescale: input Ciphertext level is too low")
+        level = op0.level
+        r = self.ringQ.AtLevel(level)
+        for a, o in zip(op0.Value, opOut.Value):
+            r.DivRoundByLastModulusManyNTT(1, a, o)
+        self._resize(opOut, op0.Degree(), level - 1)
+        opOut.Scale = Fraction(op0.Scale) / self.Q[level]

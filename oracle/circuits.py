@@ -651,3 +651,156 @@ class BGVCtEvaluator:
         scale = op0.Scale * pow(self.Q[level], -1, self.t) % self.t
         self._set(opOut, vals, level - 1)
         opOut.Scale = scale
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ckks.Evaluator at the rlwe.Ciphertext level (numpy arrays); scales are exact rationals, constants are encoded as
+# round-half-away(c * scale) (schemes/ckks/scaling.go:10-43 with exact instead of 128-bit float arithmetic)
+# ---------------------------------------------------------------------------------------------------------------
+def _rha(x):
+    from fractions import Fraction
+    x = Fraction(x)
+    if x > 0:
+        return (x + Fraction(1, 2)).__floor__()
+    if x < 0:
+        return -((-x + Fraction(1, 2)).__floor__())
+    return 0
+
+
+def _cfrac(c):
+    from fractions import Fraction
+    if isinstance(c, tuple):
+        return Fraction(c[0]), Fraction(c[1])
+    if isinstance(c, complex):
+        return Fraction(c.real), Fraction(c.imag)
+    return Fraction(c), Fraction(0)
+
+
+class CKKSCtEvaluator:
+    """schemes/ckks/evaluator.go:42-135, 221-424, 477-515, 570-760, 875-940 on numpy ciphertexts"""
+
+    def __init__(self, ev: O.Evaluator, rlk=None):
+        self.ev, self.rlk, self.ringQ, self.t = ev, rlk, ev.ringQ, None
+        self.Q = [int(q) for q in ev.ringQ.moduli]
+
+    NewCiphertext = BGVCtEvaluator.NewCiphertext
+    CopyNew = BGVCtEvaluator.CopyNew
+    _set = BGVCtEvaluator._set
+    MulNew = BGVCtEvaluator.MulNew
+    MulRelinNew = BGVCtEvaluator.MulRelinNew
+    Relinearize = BGVCtEvaluator.Relinearize
+
+    def _rns(self, level, scale, c):
+        re, im = _cfrac(c)
+        real, imag = _rha(re * scale), _rha(im * scale)
+        s0, s1 = [], []
+        for i, q in enumerate(self.Q[: level + 1]):
+            root = int(self.ringQ.roots_forward(i)[1])  # Montgomery form of sqrt(-1) mod q_i (evaluator.go:417)
+            r, m = real % q, O.MRed(imag % q, root, q)
+            s0.append((r + m) % q)
+            s1.append((r + q - m) % q)
+        return np.array(s0, dtype=np.uint64), np.array(s1, dtype=np.uint64)
+
+    @staticmethod
+    def _is_int(c):
+        re, im = _cfrac(c)
+        return re.denominator == 1 and im.denominator == 1
+
+    def _addsub_ct(self, op0, op1, opOut, sub):
+        from fractions import Fraction
+        rQ = self.ringQ
+        level = min(op0.level, op1.level, opOut.level)
+        a, b, scale = op0, op1, op0.Scale
+        if op0.Scale != op1.Scale:
+            if op0.Scale > op1.Scale:
+                ratio = int(Fraction(op0.Scale) / Fraction(op1.Scale))
+                if ratio > 0:
+                    b = self.NewCiphertext(op1.Degree(), level)
+                    self.Mul(op1, ratio, b)
+            else:
+                ratio = int(Fraction(op1.Scale) / Fraction(op0.Scale))
+                if ratio > 0:
+                    a = self.NewCiphertext(op0.Degree(), level)
+                    self.Mul(op0, ratio, a)
+                    scale = op1.Scale
+        cut = lambda v: v[: level + 1]
+        lo = min(a.Degree(), b.Degree())
+        vals = [rQ.binop("Sub" if sub else "Add", cut(a.Value[i]), cut(b.Value[i])) for i in range(lo + 1)]
+        vals += [cut(a.Value[i]) for i in range(lo + 1, a.Degree() + 1)]
+        vals += [rQ.unop("Neg", cut(b.Value[i])) if sub else cut(b.Value[i]) for i in range(lo + 1, b.Degree() + 1)]
+        self._set(opOut, vals, level)
+        opOut.Scale = scale
+
+    def Add(self, op0, op1, opOut):
+        if isinstance(op1, Ct):
+            return self._addsub_ct(op0, op1, opOut, False)
+        level = min(op0.level, opOut.level)
+        s0, s1 = self._rns(level, op0.Scale, op1)
+        vals = [self.ringQ.AddDoubleRNSScalar(op0.Value[0][: level + 1], s0, s1)] + [v[: level + 1] for v in op0.Value[1:]]
+        scale = op0.Scale
+        self._set(opOut, vals, level)
+        opOut.Scale = scale
+
+    def Sub(self, op0, op1, opOut):
+        if isinstance(op1, Ct):
+            return self._addsub_ct(op0, op1, opOut, True)
+        re, im = _cfrac(op1)
+        self.Add(op0, (-re, -im), opOut)
+
+    def _tensor(self, op0, op1, relin, opOut):
+        level = min(op0.level, op1.level, opOut.level)
+        a = np.stack([v[: level + 1] for v in op0.Value])
+        b = np.stack([v[: level + 1] for v in op1.Value])
+        out = self.ev.CKKSMulRelin(a, b, self.rlk if relin else None, relin)
+        scale = op0.Scale * op1.Scale
+        self._set(opOut, list(out), level)
+        opOut.Scale = scale
+
+    def Mul(self, op0, op1, opOut):
+        if isinstance(op1, Ct):
+            return self._tensor(op0, op1, False, opOut)
+        level = min(op0.level, opOut.level)
+        scale = 1 if self._is_int(op1) else self.Q[level]
+        s0, s1 = self._rns(level, scale, op1)
+        vals = [self.ringQ.MulDoubleRNSScalar(v[: level + 1], s0, s1) for v in op0.Value]
+        new_scale = op0.Scale * scale
+        self._set(opOut, vals, level)
+        opOut.Scale = new_scale
+
+    def MulRelin(self, op0, op1, opOut):
+        if isinstance(op1, Ct):
+            return self._tensor(op0, op1, True, opOut)
+        self.Mul(op0, op1, opOut)
+
+    def MulThenAdd(self, op0, op1, opOut):
+        from fractions import Fraction
+        level = min(op0.level, opOut.level)
+        vals = list(opOut.Value[: op0.Degree() + 1])
+        while len(vals) < op0.Degree() + 1:
+            vals.append(np.zeros((opOut.level + 1, self.ringQ.N), dtype=np.uint64))
+        opOut.Value = vals
+        if op0.Scale == opOut.Scale:
+            if self._is_int(op1):
+                scale = 1
+            else:
+                scale = self.Q[level]
+                self.Mul(opOut, scale, opOut)  # at opOut's own level (:912-916)
+                opOut.Scale = opOut.Scale * scale
+        elif op0.Scale < opOut.Scale:
+            scale = Fraction(opOut.Scale) / Fraction(op0.Scale)
+        else:
+            raise ValueError("cannot MulThenAdd: op0.Scale > opOut.Scale is not supported")
+        s0, s1 = self._rns(level, scale, op1)
+        for i in range(op0.Degree() + 1):
+            head = self.ringQ.MulDoubleRNSScalarThenAdd(op0.Value[i][: level + 1], s0, s1, opOut.Value[i][: level + 1])
+            opOut.Value[i] = np.concatenate([head, opOut.Value[i][level + 1:]])
+
+    def Rescale(self, op0, opOut):
+        from fractions import Fraction
+        if op0.level <= 0:
+            raise ValueError("cannot Rescale: input Ciphertext level is too low")
+        level = op0.level
+        vals = [self.ringQ.DivRoundByLastModulusManyNTT(1, v) for v in op0.Value]
+        scale = Fraction(op0.Scale) / self.Q[level]
+        self._set(opOut, vals, level - 1)
+        opOut.Scale = scale

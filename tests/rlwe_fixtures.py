@@ -223,3 +223,48 @@ def bgv_decrypt(ringQ: O.Ring, ct: np.ndarray, sk: SecretKey, t: int, scale: int
             y -= Q
         out.append(y % t * sinv % t)
     return np.array(out, dtype=np.int64)
+
+
+# ---- CKKS canonical embedding (test-side encoder: slots z_j = m(zeta_j), zeta_j = exp(i pi 5^j / N)) --------------------
+def ckks_slot_roots(N: int) -> np.ndarray:
+    g, out = 1, []
+    for _ in range(N // 2):
+        out.append(np.exp(1j * np.pi * g / N))
+        g = g * 5 % (2 * N)
+    return np.array(out)
+
+
+def ckks_encode(z, N: int, scale, moduli) -> np.ndarray:
+    """slots -> NTT-domain plaintext [limbs][N] at `scale` (real coefficients (2/N) Re(sum_j z_j conj(zeta_j)^k), rounded)"""
+    zeta = ckks_slot_roots(N)
+    k = np.arange(N)
+    V = zeta[:, None] ** k[None, :]  # [N/2][N]
+    coeffs = (2.0 / N) * np.real(np.conj(V).T @ np.asarray(z, dtype=complex))
+    ints = [int(round(float(c) * float(scale))) for c in coeffs]
+    res = np.array([[x % int(q) for x in ints] for q in moduli], dtype=np.uint64)
+    return O.Ring(N, moduli).NTT(res)
+
+
+def ckks_encrypt(rng, ringQ: O.Ring, sk: SecretKey, z, scale, sigma: float = 3.2) -> np.ndarray:
+    N = ringQ.N
+    pt = ckks_encode(z, N, scale, ringQ.moduli)
+    e = np.clip(np.rint(rng.normal(0.0, sigma, size=N)), -19, 19).astype(np.int64)
+    c1 = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringQ.moduli])
+    c0 = ringQ.binop("Add", ringQ.binop("Sub", pt, ringQ.binop("MulCoeffsMontgomery", c1, sk.Q[: len(ringQ.moduli)])),
+                     ringQ.NTT(small_to_rns(e, ringQ.moduli)))
+    return np.stack([c0, c1])
+
+
+def ckks_decrypt(ringQ: O.Ring, ct: np.ndarray, sk: SecretKey, scale) -> np.ndarray:
+    Q = prod(ringQ.moduli)
+    N = ringQ.N
+    ph = ringQ.INTT(phase(ringQ, ct, sk.Q))
+    w = [(Q // int(qi)) * pow(Q // int(qi), -1, int(qi)) for qi in ringQ.moduli]
+    coeffs = np.empty(N)
+    for j in range(N):
+        x = sum(int(ph[i, j]) * w[i] for i in range(len(w))) % Q
+        if x > Q // 2:
+            x -= Q
+        coeffs[j] = float(x / scale) if not isinstance(scale, float) else x / scale
+    zeta = ckks_slot_roots(N)
+    return (zeta[:, None] ** np.arange(N)[None, :]) @ coeffs

@@ -407,3 +407,28 @@ def test_bgv_polynomial_evaluation(ctx, deg):
         assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (11, top - deg.bit_length(), 1)
         assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (deg, b)
     assert np.array_equal(gct.Value[0].download(), ct[:, 0])  # the input ciphertext is left untouched
+
+
+@pytest.mark.parametrize("deg,basis", [(1, "Monomial"), (7, "Monomial"), (12, "Monomial"), (5, "Chebyshev"), (31, "Chebyshev")])
+def test_ckks_polynomial_evaluation(ctx, deg, basis):
+    """circuits/ckks/polynomial Evaluator.Evaluate (complex coefficients, monomial / Chebyshev power bases, exact rational
+    scale planning) with the device-resident ckks.Evaluator mirror vs the oracle backend: bit-exact, batch 2."""
+    from fractions import Fraction
+    from lattigo_amd import polyeval as PE
+    from lattigo_amd import schemes as S
+    rg = Rig(ctx, 10, [55] + [45] * 7, [55, 55], 5200 + deg)
+    rg.keys([1])
+    B, top = 2, 7
+    gce = S.CKKSCiphertextEvaluator(rg.gev, rg.ggks.keys[1])
+    oce = OC.CKKSCtEvaluator(rg.oev, rg.ogks[1])
+    ct = rg.ct(top, B)
+    rr = rg.rng
+    coeffs = [complex(a, b if basis == "Monomial" else 0.0) for a, b in zip(rr.uniform(-1, 1, size=deg + 1), rr.uniform(-1, 1, size=deg + 1))]
+    scale = Fraction(1 << 45)
+    pol = lambda: PE.Polynomial([PE._cpair(c) for c in coeffs], Basis=basis)
+    res = PE.PolynomialEvaluator(gce).Evaluate(S.Ciphertext(rg.up(ct), top, scale), pol(), scale)
+    got = np.stack([p.download() for p in res.Value], axis=1)
+    for b in range(B):
+        want = PE.PolynomialEvaluator(oce).Evaluate(OC.Ct(list(ct[b]), scale), pol(), scale)
+        assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (scale, top - deg.bit_length(), 1)
+        assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (deg, basis, b)

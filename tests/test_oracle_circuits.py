@@ -308,3 +308,36 @@ def test_bgv_polynomial_evaluation_decrypts(deg):
     sub = O.Ring(N, q[: res.level + 1])
     got = bgv_decrypt(sub, np.stack(res.Value), sk, t, res.Scale)
     assert np.array_equal(got, _ring_poly_eval(coeffs, m, t))
+
+
+@pytest.mark.parametrize("deg,basis", [(1, "Monomial"), (3, "Monomial"), (7, "Monomial"), (12, "Monomial"), (5, "Chebyshev"),
+                                       (16, "Chebyshev"), (31, "Chebyshev")])
+def test_ckks_polynomial_evaluation_decrypts(deg, basis):
+    """circuits/ckks/polynomial Evaluator.Evaluate (monomial and Chebyshev bases, complex coefficients) with the oracle as
+    the ckks.Evaluator backend: the slots of Dec(p(ct)) equal p(slots of ct) to ~1e-7, output scale = target exactly."""
+    from fractions import Fraction
+    from lattigo_amd import polyeval as PE
+    from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
+    q, p = O.GenModuli(10, [55] + [45] * 7, [55, 55])
+    rng = rng_for(4000 + deg)
+    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
+    ev = O.Evaluator(ringQ, ringP)
+    sk = SecretKey(rng, ringQ, ringP)
+    rlk = gen_evaluation_key(rng, ringQ, ringP, ringQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q), sk)
+    ce = OC.CKKSCtEvaluator(ev, rlk)
+    scale = Fraction(1 << 45)
+    if basis == "Chebyshev":
+        z = rng.uniform(-1, 1, size=N // 2).astype(complex)
+        coeffs = [float(x) for x in rng.uniform(-1, 1, size=deg + 1)]
+        want = np.polynomial.chebyshev.chebval(z.real, coeffs)
+    else:
+        z = rng.uniform(-0.7, 0.7, size=N // 2) + 1j * rng.uniform(-0.7, 0.7, size=N // 2)
+        coeffs = [complex(a, b) for a, b in zip(rng.uniform(-1, 1, size=deg + 1), rng.uniform(-1, 1, size=deg + 1))]
+        want = np.polyval(coeffs[::-1], z)
+    ct = OC.Ct(list(ckks_encrypt(rng, ringQ, sk, z, scale)), scale)
+    pol = PE.Polynomial([PE._cpair(c) for c in coeffs], Basis=basis)
+    res = PE.PolynomialEvaluator(ce).Evaluate(ct, pol, scale)
+    assert res.Scale == scale and res.Degree() == 1 and res.level == len(q) - 1 - deg.bit_length()
+    sub = O.Ring(N, q[: res.level + 1])
+    got = ckks_decrypt(sub, np.stack(res.Value), sk, res.Scale)
+    assert np.max(np.abs(got - want)) < 1e-6, np.max(np.abs(got - want))
