@@ -32,6 +32,7 @@ class Polynomial:
     def __init__(self, coeffs, MaxDeg=None, Lead=True, Lazy=False, Basis="Monomial"):
         self.Coeffs = list(coeffs)
         self.Basis = Basis
+        self.IsOdd = self.IsEven = True  # bignum.NewPolynomial: both set = no parity filtering; clear one for odd / even polys
         self.MaxDeg = len(self.Coeffs) - 1 if MaxDeg is None else MaxDeg
         self.Lead, self.Lazy = Lead, Lazy
         self.Level, self.Scale = 0, 1
@@ -47,19 +48,28 @@ class Polynomial:
         """p = q * X^n + r, resp. q * T_n + r (polynomial.go:32-52 over utils/bignum/polynomial.go:258-314)"""
         if n < self.Degree() >> 1:
             raise ValueError("cannot Factorize: n < p.Degree()/2")
+        even, odd = self.IsEven, self.IsOdd
+        keep = lambda i: self.Coeffs[i] is not None and (not (even or odd) or (i & 1 == 0 and even) or (i & 1 == 1 and odd))
         r = list(self.Coeffs[:n])
-        q = list(self.Coeffs[n:])
-        if self.Basis == "Chebyshev":  # T_i = 2 T_n T_{i-n} - T_{2n-i}
-            for i in range(n + 1, self.Degree() + 1):
+        q = [None] * (self.Degree() - n + 1)
+        q[0] = self.Coeffs[n]
+        for i in range(n + 1, self.Degree() + 1):
+            if not keep(i):
+                continue
+            if self.Basis == "Chebyshev":  # T_i = 2 T_n T_{i-n} - T_{2n-i}
                 j = i - n
                 q[i - n] = _cadd(self.Coeffs[i], self.Coeffs[i])
-                r[n - j] = _csub(r[n - j], self.Coeffs[i])
+                r[n - j] = _csub(r[n - j], self.Coeffs[i]) if r[n - j] is not None else _csub(0, self.Coeffs[i])
+            else:
+                q[i - n] = self.Coeffs[i]
         pr = Polynomial(r, Lead=False, Basis=self.Basis)
         pq = Polynomial(q, Lead=False, Basis=self.Basis)
         pq.MaxDeg = self.MaxDeg
         pr.MaxDeg = n - 1 if self.MaxDeg == self.Degree() else self.MaxDeg - (self.Degree() - n + 1)
         pq.Lead = self.Lead
         pq.Lazy = pr.Lazy = False
+        pq.IsOdd = pr.IsOdd = self.IsOdd
+        pq.IsEven = pr.IsEven = self.IsEven
         return pq, pr
 
 
@@ -261,8 +271,10 @@ class PolynomialEvaluator:
         logDegree = p.Degree().bit_length()
         logSplit = OptimalSplit(logDegree)
         pb.GenPower(1 << (logDegree - 1), False, ev)
+        even, odd = p.IsEven, p.IsOdd
         for i in range((1 << logSplit) - 1, 2, -1):
-            pb.GenPower(i, p.Lazy, ev)
+            if not (even or odd) or (i & 1 == 0 and even) or (i & 1 == 1 and odd):
+                pb.GenPower(i, p.Lazy, ev)
         if self.bgv:
             targetScale = int(targetScale) % ev.t
         else:
@@ -327,7 +339,10 @@ class PolynomialEvaluator:
         """EvaluatePolynomialVectorFromPowerBasis, single polynomial (:239-359, mapping == nil branch)"""
         ev, X = self.eval, pb.Value
         B = X[1].Value[0].batch if hasattr(X[1].Value[0], "batch") else 1
+        even, odd = pol.IsEven, pol.IsOdd
         minimumDegreeNonZeroCoefficient = len(pol.Coeffs) - 1
+        if even and not odd:
+            minimumDegreeNonZeroCoefficient -= 1
         maximumCiphertextDegree = 0
         for i in range(pol.Degree(), 0, -1):
             if i in X:
@@ -335,11 +350,14 @@ class PolynomialEvaluator:
         if minimumDegreeNonZeroCoefficient == 0:
             res = ev.NewCiphertext(1, targetLevel, B)
             res.Scale = targetScale
-            ev.Add(res, pol.Coeffs[0], res)
+            if even:
+                ev.Add(res, pol.Coeffs[0], res)
             return res
         res = ev.NewCiphertext(maximumCiphertextDegree, targetLevel, B)
         res.Scale = targetScale
-        ev.Add(res, pol.Coeffs[0], res)
+        if even:
+            ev.Add(res, pol.Coeffs[0], res)
         for key in range(pol.Degree(), 0, -1):
-            ev.MulThenAdd(X[key], pol.Coeffs[key], res)
+            if not (even or odd) or (key & 1 == 0 and even) or (key & 1 == 1 and odd):
+                ev.MulThenAdd(X[key], pol.Coeffs[key], res)
         return res

@@ -450,11 +450,23 @@ class CKKSCiphertextEvaluator:
 
     def _tensor(self, op0, op1, relin, opOut):
         level = min(op0.level, op1.level, opOut.level)
+        scale = op0.Scale * op1.Scale
+        if op0.Degree() == 0 or op1.Degree() == 0:  # plaintext (x) ciphertext (schemes/ckks/evaluator.go:842-870)
+            pt, ct = (op0, op1) if op0.Degree() == 0 else (op1, op0)
+            r = self.ringQ.AtLevel(level)
+            c0 = Poly(self.ringQ, level + 1, pt.Value[0].batch)
+            r.MForm(pt.Value[0], c0)
+            src = list(ct.Value)
+            self._resize(opOut, max(op0.Degree(), op1.Degree()), level)
+            for a, o in zip(src, opOut.Value):
+                r.MulCoeffsMontgomery(c0, a, o)
+            opOut.Scale = scale
+            return
         self._resize(opOut, 1 if relin else 2, level)
         if relin and self.rlk is None:
             raise KeyError("cannot relinearize: RelinearizationKey is nil")
         self.eval.CKKSMulRelin(level, op0.Value, op1.Value, self.rlk if relin else None, opOut.Value)
-        opOut.Scale = op0.Scale * op1.Scale
+        opOut.Scale = scale
 
     def Mul(self, op0, op1, opOut):
         if isinstance(op1, Ciphertext):

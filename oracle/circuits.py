@@ -749,6 +749,14 @@ class CKKSCtEvaluator:
 
     def _tensor(self, op0, op1, relin, opOut):
         level = min(op0.level, op1.level, opOut.level)
+        if op0.Degree() == 0 or op1.Degree() == 0:  # plaintext (x) ciphertext (schemes/ckks/evaluator.go:842-870)
+            pt, ct = (op0, op1) if op0.Degree() == 0 else (op1, op0)
+            c0 = self.ringQ.unop("MForm", pt.Value[0][: level + 1])
+            vals = [self.ringQ.binop("MulCoeffsMontgomery", c0, v[: level + 1]) for v in ct.Value]
+            scale = op0.Scale * op1.Scale
+            self._set(opOut, vals, level)
+            opOut.Scale = scale
+            return
         a = np.stack([v[: level + 1] for v in op0.Value])
         b = np.stack([v[: level + 1] for v in op1.Value])
         out = self.ev.CKKSMulRelin(a, b, self.rlk if relin else None, relin)

@@ -432,3 +432,27 @@ def test_ckks_polynomial_evaluation(ctx, deg, basis):
         want = PE.PolynomialEvaluator(oce).Evaluate(OC.Ct(list(ct[b]), scale), pol(), scale)
         assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (scale, top - deg.bit_length(), 1)
         assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (deg, basis, b)
+
+
+@pytest.mark.parametrize("kind,K,deg,r", [("cos", 8, 30, 2), ("cos", 12, 40, 3), ("sin", 3, 31, 0)])
+def test_mod1(ctx, kind, K, deg, r):
+    """circuits/ckks/mod1 Evaluator.EvaluateNew (EvalMod: even / odd Chebyshev polynomial incl. a degree-0 baby step,
+    double-angle steps) with the device-resident ckks.Evaluator mirror vs the oracle backend: bit-exact, batch 2."""
+    from fractions import Fraction
+    from lattigo_amd import mod1 as M1
+    from lattigo_amd import schemes as S
+    rg = Rig(ctx, 10, [55] + [45] * 10, [55, 55], 5300 + K)
+    rg.keys([1])
+    B, top = 2, 10
+    gce = S.CKKSCiphertextEvaluator(rg.gev, rg.ggks.keys[1])
+    oce = OC.CKKSCtEvaluator(rg.oev, rg.ogks[1])
+    pm = M1.Mod1Parameters(int(rg.q[0]), LevelQ=top, LogScale=45, Mod1Type=M1.CosContinuous if kind == "cos" else M1.SinContinuous,
+                           K=K, Mod1Degree=deg, DoubleAngle=r)
+    ct = rg.ct(top, B)
+    scale = Fraction(1 << 45)
+    res = M1.Mod1Evaluator(gce, pm).EvaluateNew(S.Ciphertext(rg.up(ct), top, scale))
+    got = np.stack([p.download() for p in res.Value], axis=1)
+    for b in range(B):
+        want = M1.Mod1Evaluator(oce, pm).EvaluateNew(OC.Ct(list(ct[b]), scale))
+        assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (scale, top - pm.Depth(), 1)
+        assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (kind, b)
