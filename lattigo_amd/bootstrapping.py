@@ -64,3 +64,85 @@ def ModUp(ev: Evaluator, ise: InnerSumEvaluator, levelIn: int, ct, scale: float,
                 rQ.MulScalar(c, scalar, c)
     ise.Trace(levelQ, ct, logSlots, ct)  # SubSum X -> (N/dslots) * Y^dslots (:768)
     return ct
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The bootstrapping circuit proper: bootstrapping.Evaluator.bootstrap (circuits/ckks/bootstrapping/evaluator.go:518-560)
+# with the homomorphic DFT steps of circuits/ckks/dft/dft.go:240-340, as control flow over backend adapters.
+# ----------------------------------------------------------------------------------------------------------------
+class DeviceBootstrapBackend:
+    """Adapters binding the driver below to the device-resident operators: `ckks` a schemes.CKKSCiphertextEvaluator,
+    `lte` a lintrans.LinTransEvaluator, `ise` an rlwe.InnerSumEvaluator, Galois keys in `lte.gks`."""
+
+    def __init__(self, ckks, lte, ise, EvkDenseToSparse=None, EvkSparseToDense=None):
+        self.ckks, self.lte, self.ise = ckks, lte, ise
+        self.d2s, self.s2d = EvkDenseToSparse, EvkSparseToDense
+
+    def modup(self, ct, scale, logSlots):
+        from .schemes import Ciphertext
+        ev = self.ckks.eval
+        B, top = ct.Value[0].batch, ev.ringQ.MaxLevel()
+        full = [Poly(ev.ringQ, top + 1, B) for _ in range(2)]
+        for a, b in zip(ct.Value, full):
+            b.CopyLvl(ct.level, a)
+        ModUp(ev, self.ise, ct.level, full, scale, logSlots, self.d2s, self.s2d)
+        return Ciphertext(full, top, ct.Scale * (int(round(scale)) if scale > 1 else 1))
+
+    def lintrans(self, ct, matrix, matrix_scale):
+        from .schemes import Ciphertext
+        level = min(ct.level, matrix.LevelQ)
+        out = [Poly(self.ckks.ringQ, level + 1, ct.Value[0].batch) for _ in range(2)]
+        self.lte.EvaluateMany(ct.level, ct.Value, [matrix], [out])
+        return Ciphertext(out, level, ct.Scale * matrix_scale)
+
+    def conjugate(self, ct):
+        from .schemes import Ciphertext
+        g = self.ckks.ringQ.NthRoot() - 1
+        out = [Poly(self.ckks.ringQ, ct.level + 1, ct.Value[0].batch) for _ in range(2)]
+        self.ckks.eval.Automorphism(ct.level, ct.Value, g, self.lte.gks.GetGaloisKey(g), out)
+        return Ciphertext(out, ct.level, ct.Scale)
+
+
+class Bootstrapper:
+    """bootstrapping.Evaluator.bootstrap for fully packed ciphertexts: ModUp -> CoeffsToSlots -> EvalMod (real and
+    imaginary halves) -> SlotsToCoeffs.  `backend` provides modup / lintrans / conjugate and the ckks evaluator; the encoded
+    DFT matrices (one each here; the reference factorises them, circuits/ckks/dft) and their plaintext scales are inputs."""
+
+    def __init__(self, backend, mod1_evaluator, cts_matrix, cts_scale, stc_matrix, stc_scale, modup_scale: float = 1.0,
+                 logSlots: int | None = None):
+        self.be, self.mod1 = backend, mod1_evaluator
+        self.cts, self.cts_scale, self.stc, self.stc_scale = cts_matrix, cts_scale, stc_matrix, stc_scale
+        self.modup_scale, self.logSlots = modup_scale, logSlots
+
+    def CoeffsToSlots(self, ct):
+        """dft.Evaluator.CoeffsToSlots, SplitRealAndImag (circuits/ckks/dft/dft.go:240-277)"""
+        ev = self.be.ckks
+        zV = self.be.lintrans(ct, self.cts, self.cts_scale)
+        ev.Rescale(zV, zV)
+        ctReal = self.be.conjugate(zV)
+        ctImag = ev.NewCiphertext(1, zV.level, getattr(zV.Value[0], "batch", 1))
+        ev.Sub(zV, ctReal, ctImag)
+        ev.Mul(ctImag, (0, -1), ctImag)  # * -i (a Gaussian integer: no scale change)
+        ev.Add(ctReal, zV, ctReal)
+        return ctReal, ctImag
+
+    def SlotsToCoeffs(self, ctReal, ctImag):
+        """dft.Evaluator.SlotsToCoeffs (:313-333)"""
+        ev = self.be.ckks
+        out = ev.NewCiphertext(1, min(ctReal.level, ctImag.level), getattr(ctReal.Value[0], "batch", 1))
+        ev.Mul(ctImag, (0, 1), out)
+        ev.Add(out, ctReal, out)
+        res = self.be.lintrans(out, self.stc, self.stc_scale)
+        ev.Rescale(res, res)
+        return res
+
+    def Bootstrap(self, ct, work_scale):
+        """ct: level-0 ciphertext.  `work_scale` is the scale metadata given to the raised ciphertext (the reference sets it
+        through ScaleDown / the ModUp message scaling and Mod1Parameters.ScalingFactor)."""
+        logSlots = self.logSlots if self.logSlots is not None else self.be.ckks.ringQ.N.bit_length() - 2
+        up = self.be.modup(ct, self.modup_scale, logSlots)
+        up.Scale = work_scale
+        ctReal, ctImag = self.CoeffsToSlots(up)
+        ctReal = self.mod1.EvaluateNew(ctReal)
+        ctImag = self.mod1.EvaluateNew(ctImag)
+        return self.SlotsToCoeffs(ctReal, ctImag)

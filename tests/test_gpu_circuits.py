@@ -456,3 +456,40 @@ def test_mod1(ctx, kind, K, deg, r):
         want = M1.Mod1Evaluator(oce, pm).EvaluateNew(OC.Ct(list(ct[b]), scale))
         assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (scale, top - pm.Depth(), 1)
         assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (kind, b)
+
+
+def test_toy_bootstrapping_end_to_end(ctx):
+    """bootstrapping.Evaluator.bootstrap (ModUp -> CoeffsToSlots -> EvalMod x2 -> SlotsToCoeffs, circuits/ckks/bootstrapping/
+    evaluator.go:518-560) fully device-resident on the toy instance of tests/bootstrap_fixtures.py: every polynomial of the
+    refreshed ciphertext equals the oracle-backed run bit for bit, and it decrypts to the input slots (BASELINE config 5's
+    pipeline at toy size; batch 2)."""
+    from lattigo_amd import bootstrapping as BS
+    from lattigo_amd import mod1 as M1
+    from lattigo_amd import schemes as S
+    from tests.bootstrap_fixtures import ToyBootstrap
+    rng = rng_for(5400)
+    tb = ToyBootstrap(rng)
+    N, B = tb.N, 2
+    gQ, gP = la.Ring(ctx, N, tb.q), la.Ring(ctx, N, tb.p)
+    gev = la.Evaluator(gQ, gP)
+    ggks = R.GaloisKeySet({g: gev.NewEvaluationKey(k.q, k.p) for g, k in tb.gks.items()})
+    grlk = gev.NewEvaluationKey(tb.rlk.q, tb.rlk.p)
+
+    def up_lt(olt):
+        vec = {k: (la.Poly(gQ, olt.LevelQ + 1).upload(v[0]), la.Poly(gP, len(tb.p)).upload(v[1])) for k, v in olt.Vec.items()}
+        return LT.LinearTransformation(vec, olt.LevelQ, olt.LevelP, olt.slots, olt.N1)
+
+    gce = S.CKKSCiphertextEvaluator(gev, grlk)
+    be = BS.DeviceBootstrapBackend(gce, LT.LinTransEvaluator(gev, ggks), R.InnerSumEvaluator(gev, ggks))
+    boot = BS.Bootstrapper(be, M1.Mod1Evaluator(gce, tb.mod1_params), up_lt(tb.cts), tb.cts_scale, up_lt(tb.stc), tb.stc_scale)
+    zs = [rng.uniform(-1, 1, size=N // 2) + 1j * rng.uniform(-1, 1, size=N // 2) for _ in range(B)]
+    ct0 = np.stack([tb.encrypt_level0(rng, z) for z in zs])  # [B][2][1][N]
+    gct = S.Ciphertext([la.Poly(gQ, 1, B).upload(ct0[:, k]) for k in range(2)], 0, 1)
+    res = boot.Bootstrap(gct, tb.Se)
+    got = np.stack([p.download() for p in res.Value], axis=1)
+    oboot = tb.oracle_bootstrapper()
+    for b in range(B):
+        want = oboot.Bootstrap(OC.Ct(list(ct0[b]), 1), tb.Se)
+        assert (res.level, res.Scale) == (want.level, want.Scale) and res.level >= 1
+        assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), b
+        assert np.max(np.abs(tb.decode(want) - zs[b])) < 1e-5

@@ -371,3 +371,17 @@ def test_mod1_evaluates_the_scaled_sine(kind, K, deg, r):
     want = pm.QDiff * np.sin(2 * np.pi * x) / (2 * np.pi)
     assert np.max(np.abs(got - want)) < 1e-5, np.max(np.abs(got - want))
     assert np.max(np.abs(got.real - pm.QDiff * frac)) < 1e-3  # i.e. x mod 1, up to the cubic term of the sine
+
+
+def test_toy_bootstrapping_refreshes_a_level0_ciphertext():
+    """bootstrapping.Evaluator.bootstrap (circuits/ckks/bootstrapping/evaluator.go:518-560) end to end on a toy instance
+    with the oracle backend: a level-0 encryption of z comes back at a higher level decrypting to z."""
+    from tests.bootstrap_fixtures import ToyBootstrap
+    rng = rng_for(4200)
+    tb = ToyBootstrap(rng)
+    z = rng.uniform(-1, 1, size=tb.N // 2) + 1j * rng.uniform(-1, 1, size=tb.N // 2)
+    ct0 = tb.encrypt_level0(rng, z)
+    res = tb.oracle_bootstrapper().Bootstrap(OC.Ct(list(ct0), 1), tb.Se)
+    assert res.level == tb.stc_level - 1 >= 1 and res.Degree() == 1
+    got = tb.decode(res)
+    assert np.max(np.abs(got - z)) < 1e-5, np.max(np.abs(got - z))  # ~23 bits
