@@ -110,15 +110,26 @@ class Bootstrapper:
 
     def __init__(self, backend, mod1_evaluator, cts_matrix, cts_scale, stc_matrix, stc_scale, modup_scale: float = 1.0,
                  logSlots: int | None = None):
+        """cts_matrix / stc_matrix: one encoded matrix or a list of them (the factors of the homomorphic DFT, applied in
+        order, one level each); cts_scale / stc_scale: the matching plaintext scale(s)"""
         self.be, self.mod1 = backend, mod1_evaluator
-        self.cts, self.cts_scale, self.stc, self.stc_scale = cts_matrix, cts_scale, stc_matrix, stc_scale
+        as_list = lambda m, sc: (list(m), list(sc)) if isinstance(m, (list, tuple)) else ([m], [sc])
+        self.cts, self.cts_scale = as_list(cts_matrix, cts_scale)
+        self.stc, self.stc_scale = as_list(stc_matrix, stc_scale)
         self.modup_scale, self.logSlots = modup_scale, logSlots
+
+    def _dft(self, ct, matrices, scales):
+        """dft.Evaluator.dft (circuits/ckks/dft/dft.go:336-366): one linear transformation + Rescale per level"""
+        ev = self.be.ckks
+        for m, sc in zip(matrices, scales):
+            ct = self.be.lintrans(ct, m, sc)
+            ev.Rescale(ct, ct)
+        return ct
 
     def CoeffsToSlots(self, ct):
         """dft.Evaluator.CoeffsToSlots, SplitRealAndImag (circuits/ckks/dft/dft.go:240-277)"""
         ev = self.be.ckks
-        zV = self.be.lintrans(ct, self.cts, self.cts_scale)
-        ev.Rescale(zV, zV)
+        zV = self._dft(ct, self.cts, self.cts_scale)
         ctReal = self.be.conjugate(zV)
         ctImag = ev.NewCiphertext(1, zV.level, getattr(zV.Value[0], "batch", 1))
         ev.Sub(zV, ctReal, ctImag)
@@ -132,9 +143,7 @@ class Bootstrapper:
         out = ev.NewCiphertext(1, min(ctReal.level, ctImag.level), getattr(ctReal.Value[0], "batch", 1))
         ev.Mul(ctImag, (0, 1), out)
         ev.Add(out, ctReal, out)
-        res = self.be.lintrans(out, self.stc, self.stc_scale)
-        ev.Rescale(res, res)
-        return res
+        return self._dft(out, self.stc, self.stc_scale)
 
     def Bootstrap(self, ct, work_scale):
         """ct: level-0 ciphertext.  `work_scale` is the scale metadata given to the raised ciphertext (the reference sets it
