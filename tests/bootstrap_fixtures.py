@@ -43,37 +43,77 @@ def sparse_ternary(rng, N, h):
     return v
 
 
+def special_fft_layers(N):
+    """U = L_log(n) ... L_1 Bitrev with U[j,k] = zeta_j^k: the radix-2 layers of the CKKS 'special' FFT (the structure the
+    reference factorises its homomorphic DFT on, circuits/ckks/dft/dft.go:368-470), as dense n x n matrices"""
+    n, M = N // 2, 2 * N
+    rot = [pow(5, j, M) for j in range(n)]
+    ksi = np.exp(2j * np.pi * np.arange(M) / M)
+    layers, ln = [], 2
+    while ln <= n:
+        L = np.zeros((n, n), dtype=complex)
+        lenh, lenq = ln >> 1, ln << 2
+        for i in range(0, n, ln):
+            for j in range(lenh):
+                w = ksi[(rot[j] % lenq) * (M // lenq)]
+                L[i + j, i + j], L[i + j, i + j + lenh] = 1, w
+                L[i + j + lenh, i + j], L[i + j + lenh, i + j + lenh] = 1, -w
+        layers.append(L)
+        ln <<= 1
+    return layers
+
+
 class ToyBootstrap:
-    """N = 512, twelve 55-bit moduli (CtS 1, EvalMod 8, StC 1, two left), sparse secret h = 16, Delta = 2^45"""
+    """N = 512, fourteen 55-bit moduli (CoeffsToSlots 2, EvalMod 8, SlotsToCoeffs 2, two left), sparse secret h = 16,
+    Delta = 2^45.  The DFT is factorised into two sparse matrices per direction (groups of four special-FFT layers, 31 and
+    16 diagonals); the bit-reversal is dropped on both sides, EvalMod being slot-wise (as the reference does)."""
 
     def __init__(self, rng, logN=9, K=12, deg=30, r=3, h=16):
         from fractions import Fraction
         from lattigo_amd import mod1 as M1
         self.N = N = 1 << logN
-        self.q, self.p = O.GenModuli(logN + 1, [55] * 12, [55, 55])
+        self.q, self.p = O.GenModuli(logN + 1, [55] * 14, [55, 55])
         self.ringQ, self.ringP = O.Ring(N, self.q), O.Ring(N, self.p)
         self.oev = O.Evaluator(self.ringQ, self.ringP)
         self.sk = SecretKey(rng, self.ringQ, self.ringP, vals=sparse_ternary(rng, N, h))
-        self.top = len(self.q) - 1
+        self.top = top = len(self.q) - 1
         self.Se = Fraction(1 << 55)
         self.Delta = float(1 << 45)
         self.K = K
         n, nth = N // 2, 2 * N
+        layers = special_fft_layers(N)
+        half = len(layers) // 2
+        A = np.eye(n, dtype=complex)
+        for L in layers[:half]:
+            A = L @ A
+        Bm = np.eye(n, dtype=complex)
+        for L in layers[half:]:
+            Bm = L @ Bm
         zeta = ckks_slot_roots(N)
         self.U = zeta[:, None] ** np.arange(n)[None, :]
         q0 = float(self.q[0])
         g = float(self.Se) / (q0 * K) / 2.0
         self.N1 = 16
-        self.cts_scale = Fraction(int(self.q[self.top]))
-        self.stc_level = self.top - 1 - (deg.bit_length() + r)
-        self.stc_scale = Fraction(int(self.q[self.stc_level]))
-        self.cts = dense_matrix_lt(g * np.linalg.inv(self.U), N, self.N1, self.cts_scale, self.top, self.ringQ, self.ringP)
-        self.stc = dense_matrix_lt(self.U, N, self.N1, self.stc_scale, self.stc_level, self.ringQ, self.ringP)
-        rots = [OC.GaloisElement(nth, k) for k in list(range(1, 16)) + list(range(16, n, 16))] + [nth - 1]
-        self.gks = gen_galois_keys(rng, self.ringQ, self.ringP, self.sk, rots)
+        depth = deg.bit_length() + r
+        self.stc_level = top - 2 - depth  # level at which SlotsToCoeffs starts
+        sc = lambda level: Fraction(int(self.q[level]))
+        self.cts_scale = [sc(top), sc(top - 1)]
+        self.stc_scale = [sc(self.stc_level), sc(self.stc_level - 1)]
+        # U^-1 z = P^-1 A^-1 B^-1 z: apply B^-1 (with the gain), then A^-1; the result is in bit-reversed order
+        self.cts = [dense_matrix_lt(g * np.linalg.inv(Bm), N, self.N1, self.cts_scale[0], top, self.ringQ, self.ringP),
+                    dense_matrix_lt(np.linalg.inv(A), N, self.N1, self.cts_scale[1], top - 1, self.ringQ, self.ringP)]
+        self.stc = [dense_matrix_lt(A, N, self.N1, self.stc_scale[0], self.stc_level, self.ringQ, self.ringP),
+                    dense_matrix_lt(Bm, N, self.N1, self.stc_scale[1], self.stc_level - 1, self.ringQ, self.ringP)]
+        rots = set()
+        for lt in self.cts + self.stc:
+            _, r1, r2 = OC.BSGSIndex(list(lt.Vec.keys()), n, self.N1)
+            rots |= set(r1) | set(r2)
+        self.n_diagonals = [len(lt.Vec) for lt in self.cts + self.stc]
+        gal = [OC.GaloisElement(nth, k) for k in sorted(rots) if k] + [nth - 1]
+        self.gks = gen_galois_keys(rng, self.ringQ, self.ringP, self.sk, gal)
         self.rlk = gen_evaluation_key(rng, self.ringQ, self.ringP,
                                       self.ringQ.binop("MulCoeffsMontgomery", self.sk.Q, self.sk.Q), self.sk)
-        self.mod1_params = M1.Mod1Parameters(int(self.q[0]), LevelQ=self.top - 1, LogScale=55, Mod1Type=M1.CosContinuous, K=K,
+        self.mod1_params = M1.Mod1Parameters(int(self.q[0]), LevelQ=top - 2, LogScale=55, Mod1Type=M1.CosContinuous, K=K,
                                              Mod1Degree=deg, DoubleAngle=r)
 
     def encrypt_level0(self, rng, z):

@@ -481,7 +481,8 @@ def test_toy_bootstrapping_end_to_end(ctx):
 
     gce = S.CKKSCiphertextEvaluator(gev, grlk)
     be = BS.DeviceBootstrapBackend(gce, LT.LinTransEvaluator(gev, ggks), R.InnerSumEvaluator(gev, ggks))
-    boot = BS.Bootstrapper(be, M1.Mod1Evaluator(gce, tb.mod1_params), up_lt(tb.cts), tb.cts_scale, up_lt(tb.stc), tb.stc_scale)
+    boot = BS.Bootstrapper(be, M1.Mod1Evaluator(gce, tb.mod1_params), [up_lt(m) for m in tb.cts], tb.cts_scale,
+                           [up_lt(m) for m in tb.stc], tb.stc_scale)
     zs = [rng.uniform(-1, 1, size=N // 2) + 1j * rng.uniform(-1, 1, size=N // 2) for _ in range(B)]
     ct0 = np.stack([tb.encrypt_level0(rng, z) for z in zs])  # [B][2][1][N]
     gct = S.Ciphertext([la.Poly(gQ, 1, B).upload(ct0[:, k]) for k in range(2)], 0, 1)

@@ -382,6 +382,6 @@ def test_toy_bootstrapping_refreshes_a_level0_ciphertext():
     z = rng.uniform(-1, 1, size=tb.N // 2) + 1j * rng.uniform(-1, 1, size=tb.N // 2)
     ct0 = tb.encrypt_level0(rng, z)
     res = tb.oracle_bootstrapper().Bootstrap(OC.Ct(list(ct0), 1), tb.Se)
-    assert res.level == tb.stc_level - 1 >= 1 and res.Degree() == 1
+    assert res.level == tb.stc_level - 2 >= 1 and res.Degree() == 1 and tb.n_diagonals == [16, 31, 31, 16]
     got = tb.decode(res)
     assert np.max(np.abs(got - z)) < 1e-5, np.max(np.abs(got - z))  # ~23 bits
