@@ -2,9 +2,10 @@
 sine evaluated as a Chebyshev polynomial of cos(2 pi (x - 1/4) / 2^r) followed by r double-angle steps -- as a driver over
 the polynomial evaluator (polyeval.py) and the device-resident ckks.Evaluator mirror (schemes.py).
 
-The approximation polynomial is generated here by Chebyshev interpolation in double precision (the reference uses
-arbitrary-precision interpolation, circuits/ckks/mod1/mod1_parameters.go:150-215): same function, same interval, same
-degree; only the continuous sine / cosine types are provided (no Han-Ki discrete cosine, no arcsine)."""
+The approximation polynomial is the truncated Chebyshev series of the same function on the same interval with the same
+degree, computed in 60-digit arithmetic (the reference interpolates at Chebyshev nodes in arbitrary precision,
+circuits/ckks/mod1/mod1_parameters.go:150-215; the two differ by the aliased tail of the series, < 1e-40 here); only the
+continuous sine / cosine types and the Han-Ki discrete cosine (cosine.py) are provided (no arcsine)."""
 from __future__ import annotations
 
 import math
@@ -14,26 +15,82 @@ import numpy as np
 
 from .polyeval import Polynomial, PolynomialEvaluator
 
-SinContinuous, CosContinuous = 1, 2  # mod1.Type (mod1_parameters.go:19-23)
+CosDiscrete, SinContinuous, CosContinuous = 0, 1, 2  # mod1.Type (mod1_parameters.go:19-23)
+
+
+def _pi(prec: int):
+    """pi to `prec` decimal digits (Machin: 16 atan(1/5) - 4 atan(1/239))"""
+    import decimal
+    with decimal.localcontext() as c:
+        c.prec = prec + 10
+
+        def atan_inv(x):
+            x2, term, total, k = decimal.Decimal(x * x), decimal.Decimal(1) / x, decimal.Decimal(0), 0
+            while abs(term) > decimal.Decimal(10) ** -(prec + 8):
+                total += term / (2 * k + 1) if k % 2 == 0 else -term / (2 * k + 1)
+                term /= x2
+                k += 1
+            return total
+
+        return +(16 * atan_inv(5) - 4 * atan_inv(239))
+
+
+def _bessel_j(k: int, a, prec: int):
+    """J_k(a) = sum_m (-1)^m (a/2)^(2m+k) / (m! (m+k)!) in `prec`-digit decimal arithmetic"""
+    import decimal
+    with decimal.localcontext() as c:
+        c.prec = prec + 20  # the alternating series cancels ~e^a / value digits
+        h = a / 2
+        term = h ** k
+        for i in range(2, k + 1):
+            term /= i
+        total, m, h2 = decimal.Decimal(0), 0, h * h
+        while abs(term) > decimal.Decimal(10) ** -(prec + 15) or m < 5:
+            total += term
+            m += 1
+            term = -term * h2 / (m * (m + k))
+        return +total
 
 
 class Mod1Parameters:
-    """mod1.Parameters from a ParametersLiteral (mod1_parameters.go:98-217)"""
+    """mod1.Parameters from a ParametersLiteral (mod1_parameters.go:98-217).  The Chebyshev coefficients of
+    cos(a u) = J_0(a) + 2 sum_{k even} (-1)^(k/2) J_k(a) T_k(u) and sin(a u) = 2 sum_{k odd} (-1)^((k-1)/2) J_k(a) T_k(u)
+    (a = 2 pi K / 2^r) are computed in 60-digit arithmetic: the reduced value x mod 1 is ~2^-8 of the function's range, so
+    double-precision coefficients would cap the precision of the whole bootstrap at ~30 bits relative to it."""
+
+    PREC = 60
 
     def __init__(self, Q0: int, LevelQ: int, LogScale: int, Mod1Type: int, K: int, Mod1Degree: int, DoubleAngle: int = 0,
                  LogMessageRatio: int = 8, Scaling: float = 1.0):
+        import decimal
         self.LevelQ, self.LogDefaultScale, self.Mod1Type, self.LogMessageRatio = LevelQ, LogScale, Mod1Type, LogMessageRatio
         self.DoubleAngle = 0 if Mod1Type == SinContinuous else DoubleAngle
-        scFac = 2.0 ** self.DoubleAngle
-        Kp = K / scFac
         self.K = float(K)
         self.QDiff = float(Q0) / 2.0 ** round(math.log2(float(Q0)))
-        self.Sqrt2Pi = (0.15915494309189535 * self.QDiff * (Scaling or 1.0)) ** (1.0 / scFac)
-        f = (lambda u: np.sin(2 * np.pi * Kp * u)) if Mod1Type == SinContinuous else (lambda u: np.cos(2 * np.pi * Kp * u))
-        coeffs = np.polynomial.chebyshev.chebinterpolate(f, Mod1Degree) * self.Sqrt2Pi
-        drop = 0 if Mod1Type == SinContinuous else 1  # sine: odd polynomial, cosine: even polynomial
-        self.Mod1Poly = Polynomial([None if (i & 1) == drop else (Fraction(float(c)), Fraction(0)) for i, c in enumerate(coeffs)],
-                                   Basis="Chebyshev")
+        pi = _pi(self.PREC)
+        with decimal.localcontext() as c:
+            c.prec = self.PREC
+            qdiff = decimal.Decimal(Q0) / (decimal.Decimal(2) ** round(math.log2(float(Q0))))
+            s2p = qdiff * decimal.Decimal(Scaling or 1.0) / (2 * pi)
+            for _ in range(self.DoubleAngle):
+                s2p = s2p.sqrt()
+            a = 2 * pi * decimal.Decimal(K) / (decimal.Decimal(2) ** self.DoubleAngle)
+            coeffs = []
+            if Mod1Type == CosDiscrete:  # Han-Ki interpolation around the integers; the odd coefficients are dropped (:186-196)
+                from .cosine import ApproximateCos
+                hk = ApproximateCos(K, Mod1Degree, float(1 << LogMessageRatio), self.DoubleAngle)
+                coeffs = [None if (k & 1) else (Fraction(v * s2p), Fraction(0)) for k, v in enumerate(hk)]
+            for k in range(Mod1Degree + 1 if Mod1Type != CosDiscrete else 0):
+                odd = k & 1
+                if (Mod1Type == SinContinuous) != bool(odd):
+                    coeffs.append(None)
+                    continue
+                j = _bessel_j(k, a, self.PREC)
+                sign = -1 if ((k - odd) // 2) & 1 else 1
+                v = (j if k == 0 else 2 * j) * sign * s2p
+                coeffs.append((Fraction(v), Fraction(0)))
+            self.Sqrt2Pi = Fraction(s2p)
+        self.Mod1Poly = Polynomial(coeffs, Basis="Chebyshev")
         if Mod1Type == SinContinuous:
             self.Mod1Poly.IsEven = False
         else:
@@ -74,7 +131,7 @@ class Mod1Evaluator:
         for i in range(evm.DoubleAngle):  # :54-58
             targetScale = targetScale * Qi[res.Level() - depth - evm.DoubleAngle + i + 1]
             targetScale = Fraction(math.sqrt(float(targetScale)))
-        if evm.Mod1Type == CosContinuous:  # change of variable x -> x - 1/4 (:61-68)
+        if evm.Mod1Type in (CosContinuous, CosDiscrete):  # change of variable x -> x - 1/4 (:61-68)
             Kp = evm.K / evm.IntervalShrinkFactor()
             offset = Fraction(-0.5) / (Fraction(2 * Kp) * Fraction(evm.IntervalShrinkFactor()))
             ev.Add(res, (offset, 0), res)
@@ -84,7 +141,7 @@ class Mod1Evaluator:
             sqrt2pi *= sqrt2pi
             ev.MulRelin(res, res, res)
             ev.Add(res, res, res)
-            ev.Add(res, (Fraction(-sqrt2pi), 0), res)
+            ev.Add(res, (-sqrt2pi, 0), res)
             ev.Rescale(res, res)
         res.Scale = ct.Scale  # multiplies back by q (:141)
         return res

@@ -1,6 +1,8 @@
 """Toy CKKS bootstrapping instance for the end-to-end tests (test infrastructure: numpy canonical embedding, dense DFT
 matrices, our own seeded keys).  Full packing (N/2 slots): slots z = U w with U[j,k] = zeta_j^k, w = c_lo + i c_hi the two
 halves of the plaintext coefficient vector, so CoeffsToSlots is multiplication by (a multiple of) U^-1 and SlotsToCoeffs by U."""
+import math
+
 import numpy as np
 
 from oracle import circuits as OC
@@ -134,3 +136,246 @@ class ToyBootstrap:
         from tests.rlwe_fixtures import ckks_decrypt
         sub = O.Ring(self.N, self.q[: res.level + 1])
         return ckks_decrypt(sub, np.stack(res.Value), self.sk, res.Scale) * (2.0 ** 55 / self.Delta)
+
+
+# ---- diagonal-form special FFT (scales to N = 2^16: no dense n x n matrices) --------------------------------------------
+_TW_CACHE = {}
+
+
+def _layer_twiddles(N, ln):
+    if (N, ln) not in _TW_CACHE:
+        _TW_CACHE[(N, ln)] = _layer_twiddles_uncached(N, ln)
+    return _TW_CACHE[(N, ln)]
+
+
+def _layer_twiddles_uncached(N, ln):
+    n, M = N // 2, 2 * N
+    lenh, lenq = ln >> 1, ln << 2
+    j = np.arange(lenh)
+    rot = np.array([pow(5, int(x), M) for x in j]) if lenh <= 4096 else None
+    if rot is None:  # 5^j mod M incrementally
+        rot = np.empty(lenh, dtype=np.int64)
+        g = 1
+        for i in range(lenh):
+            rot[i] = g
+            g = g * 5 % M
+    w = np.exp(2j * np.pi * ((rot % lenq) * (M // lenq)) / M)  # [lenh]
+    return np.tile(w, n // ln)  # per block, indexed by (block, j)
+
+
+def layer_diagonals(N, ln, inverse=False):
+    """special-FFT layer of butterfly span `ln` as {offset: vector} with (A z)[r] = sum_a A[a][r] * z[(r + a) mod n]"""
+    n = N // 2
+    lenh = ln >> 1
+    w = _layer_twiddles(N, ln)  # one twiddle per butterfly, in row order of the first halves
+    first = (np.arange(n) % ln) < lenh
+    d0, dp, dm = np.zeros(n, dtype=complex), np.zeros(n, dtype=complex), np.zeros(n, dtype=complex)
+    if not inverse:  # (u, v) -> (u + w v, u - w v)
+        d0[first], dp[first] = 1.0, w
+        dm[~first], d0[~first] = 1.0, -w
+    else:  # u = (u' + v') / 2, v = (u' - v') / (2 w)
+        d0[first], dp[first] = 0.5, 0.5
+        dm[~first], d0[~first] = 0.5 / w, -0.5 / w
+    out = {0: d0, lenh % n: dp}
+    key = (-lenh) % n
+    out[key] = out.get(key, 0) + dm
+    return out
+
+
+def diag_matmul(A, B, n):
+    """C = A B in diagonal form: C[a + b][r] += A[a][r] * B[b][(r + a) mod n]"""
+    C = {}
+    for a, va in A.items():
+        for b, vb in B.items():
+            k = (a + b) % n
+            t = va * np.roll(vb, -a)
+            C[k] = C[k] + t if k in C else t
+    return {k: v for k, v in C.items() if np.max(np.abs(v)) > 1e-13}
+
+
+def bitrev_indices(n):
+    b = n.bit_length() - 1
+    idx = np.arange(n)
+    out = np.zeros(n, dtype=np.int64)
+    for i in range(b):
+        out |= ((idx >> i) & 1) << (b - 1 - i)
+    return out
+
+
+def special_fft(w_vec, N):
+    """z = U w (slots from the complex half-coefficient vector), O(n log n)"""
+    n = N // 2
+    v = np.asarray(w_vec, dtype=complex)[bitrev_indices(n)].copy()
+    ln = 2
+    while ln <= n:
+        lenh = ln >> 1
+        tw = _layer_twiddles(N, ln).reshape(n // ln, lenh)
+        blk = v.reshape(n // ln, ln)
+        u, t = blk[:, :lenh].copy(), blk[:, lenh:] * tw
+        blk[:, :lenh], blk[:, lenh:] = u + t, u - t
+        ln <<= 1
+    return v
+
+
+def special_ifft(z, N):
+    """w = U^-1 z"""
+    n = N // 2
+    v = np.asarray(z, dtype=complex).copy()
+    ln = n
+    while ln >= 2:
+        lenh = ln >> 1
+        tw = _layer_twiddles(N, ln).reshape(n // ln, lenh)
+        blk = v.reshape(n // ln, ln)
+        a, b = blk[:, :lenh].copy(), blk[:, lenh:].copy()
+        blk[:, :lenh], blk[:, lenh:] = (a + b) / 2, (a - b) / (2 * tw)
+        ln >>= 1
+    out = np.empty(n, dtype=complex)
+    out[bitrev_indices(n)] = v
+    return out
+
+
+def fast_encode_rns(vec, N, scale, moduli):
+    """slot vector -> coefficient-domain residues [limbs][N] (uint64) of round(scale * coefficients), via the special iFFT"""
+    w = special_ifft(vec, N)
+    coeffs = np.concatenate([w.real, w.imag]) * float(scale)
+    ints = np.rint(coeffs).astype(np.int64)
+    out = np.empty((len(moduli), N), dtype=np.uint64)
+    for i, q in enumerate(moduli):
+        out[i] = np.mod(ints, np.int64(q)).astype(np.uint64)
+    return out
+
+
+def run_functional_bootstrap(logN, logq_res, n_stc, evalmod_bits, n_cts, cts_bits, stc_bits, logp, cts_groups, stc_groups, h_dense, h_sparse,
+                             K=16, deg=30, r=3, log_delta=52, log_se=60, ctx=None, seed=5500, min_bits=15, mod1_type=0):
+    """One full bootstrap with real keys and factorised DFT matrices; ctx = None runs it on the oracle backend, a
+    lattigo_amd.Context on the device.  Returns a dict with the precision and timings."""
+    import time
+    from fractions import Fraction
+    from lattigo_amd import bootstrapping as BS
+    from lattigo_amd import lintrans as LT
+    from lattigo_amd import mod1 as M1
+    from tests.helpers import prod, rng_for
+    from tests.rlwe_fixtures import phase
+    device = ctx is not None
+    if device:
+        import lattigo_amd as la
+        from lattigo_amd import rlwe as R
+        from lattigo_amd import schemes as S
+    t_start = time.time()
+    N, n, nth = 1 << logN, 1 << (logN - 1), 2 << logN
+    depth = deg.bit_length() + r
+    q, p = O.GenModuli(logN + 1, list(logq_res) + [stc_bits] * n_stc + [evalmod_bits] * depth + [cts_bits] * n_cts, list(logp))
+    top, LP = len(q) - 1, len(p)
+    rng = rng_for(seed)
+    oQ, oP = O.Ring(N, q), O.Ring(N, p)
+    oev = O.Evaluator(oQ, oP)
+    sk = SecretKey(rng, oQ, oP, vals=sparse_ternary(rng, N, h_dense))
+    sks = SecretKey(rng, oQ, oP, vals=sparse_ternary(rng, N, h_sparse))
+    if device:
+        gQ, gP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+        gev = la.Evaluator(gQ, gP)
+        up_key = lambda k: gev.NewEvaluationKey(k.q, k.p)
+    else:
+        up_key = lambda k: k
+    Se = Fraction(1 << log_se)
+    q0 = float(q[0])
+    gain = float(Se) / (q0 * K) / 2.0
+    lns = [2 << i for i in range(logN - 1)]  # butterfly spans of L_1 .. L_(logN-1):  U = L_last ... L_1 Bitrev
+
+    def group(layers, inverse):
+        acc = None
+        for ln in layers:  # forward: L_b ... L_a (left-multiply); inverse: (L_b ... L_a)^-1 = L_a^-1 ... L_b^-1 (right-multiply)
+            d = layer_diagonals(N, ln, inverse)
+            acc = d if acc is None else (diag_matmul(acc, d, n) if inverse else diag_matmul(d, acc, n))
+        return acc
+
+    stc_top = top - len(cts_groups) - depth
+
+    def build_lt(diags, level, first_gain=1.0):
+        ks = sorted(diags)
+        N1 = LT.FindBestBSGSRatio(ks, n, 1)
+        scale = Fraction(int(q[level]))
+        sub = O.Ring(N, q[: level + 1])
+        vec = {}
+        for k in ks:
+            j0 = ((k // N1) * N1) & (n - 1)
+            v = np.roll(diags[k] * first_gain, j0)
+            rq = sub.unop("MForm", sub.NTT(fast_encode_rns(v, N, scale, q[: level + 1])))
+            rp = oP.unop("MForm", oP.NTT(fast_encode_rns(v, N, scale, p)))
+            vec[k] = (la.Poly(gQ, level + 1).upload(rq), la.Poly(gP, LP).upload(rp)) if device else (rq, rp)
+        _, r1, r2 = LT.BSGSIndex(ks, n, N1)
+        lt = (LT.LinearTransformation if device else OC.LinearTransformation)(vec, level, LP - 1, n, N1)
+        return lt, scale, set(r1) | set(r2)
+
+    cts, cts_sc, stc, stc_sc, rots = [], [], [], [], set()
+    for i, (a, b) in enumerate(cts_groups):
+        lt, sc, rr = build_lt(group(lns[a:b], True), top - i, gain if i == 0 else 1.0)
+        cts.append(lt); cts_sc.append(sc); rots |= rr
+    for i, (a, b) in enumerate(stc_groups):
+        lt, sc, rr = build_lt(group(lns[a:b], False), stc_top - i)
+        stc.append(lt); stc_sc.append(sc); rots |= rr
+    ndiag = sum(len(m.Vec) for m in cts + stc)
+    t_mats = time.time()
+
+    gks = {}
+    for k in sorted(rots):
+        if k:
+            g = OC.GaloisElement(nth, k)
+            gks[g] = up_key(gen_galois_keys(rng, oQ, oP, sk, [g])[g])
+    gks[nth - 1] = up_key(gen_galois_keys(rng, oQ, oP, sk, [nth - 1])[nth - 1])
+    rlk = up_key(gen_evaluation_key(rng, oQ, oP, oQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q), sk))
+    d2s = up_key(gen_evaluation_key(rng, oQ, oP, sk.Q, sks))
+    s2d = up_key(gen_evaluation_key(rng, oQ, oP, sks.Q, sk))
+    t_keys = time.time()
+
+    Delta = float(1 << log_delta)
+    z = rng.uniform(-1, 1, size=n) + 1j * rng.uniform(-1, 1, size=n)
+    r0 = O.Ring(N, q[:1])
+    pt = r0.NTT(fast_encode_rns(z, N, Delta, q[:1]))
+    e = np.clip(np.rint(rng.normal(0.0, 3.2, size=N)), -19, 19).astype(np.int64)
+    c1 = np.stack([rng.integers(0, int(q[0]), size=N, dtype=np.uint64)])
+    c0 = r0.binop("Add", r0.binop("Sub", pt, r0.binop("MulCoeffsMontgomery", c1, sk.Q[:1])), r0.NTT(small_to_rns(e, q[:1])))
+
+    pm = M1.Mod1Parameters(int(q[0]), LevelQ=top - len(cts), LogScale=log_se, Mod1Type=mod1_type, K=K, Mod1Degree=deg,
+                           DoubleAngle=r, LogMessageRatio=int(round(math.log2(q0))) - log_delta)
+    if device:
+        ggks = R.GaloisKeySet(gks)
+        ce = S.CKKSCiphertextEvaluator(gev, rlk)
+        be = BS.DeviceBootstrapBackend(ce, LT.LinTransEvaluator(gev, ggks), R.InnerSumEvaluator(gev, ggks), d2s, s2d)
+        ct_in = S.Ciphertext([la.Poly(gQ, 1).upload(c0), la.Poly(gQ, 1).upload(c1)], 0, 1)
+    else:
+        ce = OC.CKKSCtEvaluator(oev, rlk)
+        be = OC.OracleBootstrapBackend(ce, OC.LinTransEvaluator(oev, gks), OC.InnerSumEvaluator(oev, gks), d2s, s2d)
+        ct_in = OC.Ct([c0, c1], 1)
+    boot = BS.Bootstrapper(be, M1.Mod1Evaluator(ce, pm), cts, cts_sc, stc, stc_sc)
+    if device:
+        boot.Bootstrap(ct_in, Se)  # warm-up (plans, buffer cache)
+        ctx.sync()
+    t0 = time.time()
+    res = boot.Bootstrap(ct_in, Se)
+    if device:
+        ctx.sync()
+    t_boot = time.time() - t0
+    assert res.Degree() == 1 and res.Scale == Se and res.level == len(logq_res) - 1
+
+    lv = res.level
+    sub = O.Ring(N, q[: lv + 1])
+    ct_out = np.stack([v.download()[0][: lv + 1] for v in res.Value]) if device else np.stack(res.Value)
+    ph = sub.INTT(phase(oQ, ct_out, sk.Q))
+    Ql = prod(q[: lv + 1])
+    w = [(Ql // int(qi)) * pow(Ql // int(qi), -1, int(qi)) for qi in q[: lv + 1]]
+    coeffs = np.empty(N)
+    for j in range(N):
+        x = sum(int(ph[i, j]) * w[i] for i in range(lv + 1)) % Ql
+        if x > Ql // 2:
+            x -= Ql
+        coeffs[j] = float(Fraction(x) / Se)
+    got = special_fft(coeffs[:n] + 1j * coeffs[n:], N) * (float(Se) / Delta)
+    errs = np.abs(got - z)
+    err = float(np.max(errs))
+    mean_bits = float(np.mean(-np.log2(np.maximum(errs, 1e-300))))
+    out = {"mean_precision_bits": mean_bits, "logN": logN, "limbs_Q": top + 1, "limbs_P": LP, "dft_diagonals": ndiag, "galois_keys": len(gks),
+           "bootstrap_ms": t_boot * 1e3, "precision_bits": float(-np.log2(err)), "max_slot_error": err, "output_level": lv,
+           "host_setup_s": {"matrices": t_mats - t_start, "keys": t_keys - t_mats}, "backend": "device" if device else "oracle"}
+    assert out["precision_bits"] > min_bits, out
+    return out

@@ -343,7 +343,7 @@ def test_ckks_polynomial_evaluation_decrypts(deg, basis):
     assert np.max(np.abs(got - want)) < 1e-6, np.max(np.abs(got - want))
 
 
-@pytest.mark.parametrize("kind,K,deg,r", [("cos", 8, 30, 2), ("cos", 12, 40, 3), ("sin", 3, 31, 0)])
+@pytest.mark.parametrize("kind,K,deg,r", [("cos", 8, 30, 2), ("cos", 12, 40, 3), ("sin", 3, 31, 0), ("hanki", 16, 30, 3)])
 def test_mod1_evaluates_the_scaled_sine(kind, K, deg, r):
     """circuits/ckks/mod1 Evaluator.EvaluateNew (bootstrapping's EvalMod) with the oracle as the ckks.Evaluator backend:
     slots x / K in, QDiff / (2 pi) * sin(2 pi x) out (= QDiff * (x mod 1) for x close to an integer)."""
@@ -357,9 +357,9 @@ def test_mod1_evaluates_the_scaled_sine(kind, K, deg, r):
     sk = SecretKey(rng, ringQ, ringP)
     rlk = gen_evaluation_key(rng, ringQ, ringP, ringQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q), sk)
     ce = OC.CKKSCtEvaluator(ev, rlk)
-    pm = M1.Mod1Parameters(int(q[0]), LevelQ=len(q) - 1, LogScale=45, Mod1Type=M1.CosContinuous if kind == "cos" else M1.SinContinuous,
-                           K=K, Mod1Degree=deg, DoubleAngle=r)
-    ints = rng.integers(-(K - 1), K, size=N // 2)
+    typ = {"cos": M1.CosContinuous, "sin": M1.SinContinuous, "hanki": M1.CosDiscrete}[kind]
+    pm = M1.Mod1Parameters(int(q[0]), LevelQ=len(q) - 1, LogScale=45, Mod1Type=typ, K=K, Mod1Degree=deg, DoubleAngle=r, LogMessageRatio=6)
+    ints = rng.integers(-(K - 1), K, size=N // 2) if kind != "hanki" else rng.integers(-8, 9, size=N // 2)
     frac = rng.uniform(-2.0 ** -6, 2.0 ** -6, size=N // 2)
     x = ints + frac
     scale = Fraction(1 << 45)
