@@ -145,6 +145,34 @@ class Bootstrapper:
         ev.Add(out, ctReal, out)
         return self._dft(out, self.stc, self.stc_scale)
 
+    def ScaleDown(self, ct, message_ratio: float):
+        """bootstrapping.Evaluator.ScaleDown (circuits/ckks/bootstrapping/evaluator.go:566-610) for a ciphertext that can be
+        brought to level 0: drop the unnecessary primes, multiply by round((Q_level / scale) / MessageRatio) so that the message
+        sits MessageRatio below Q[0]; returns the ciphertext and the scale error factor"""
+        from fractions import Fraction
+        ev = self.be.ckks
+        Q = ev.Q
+        res = ev.CopyNew(ct)
+
+        def modulus(level):
+            m = 1
+            for x in Q[: level + 1]:
+                m *= x
+            return m
+
+        while res.level != 0 and Fraction(modulus(res.level)) / Fraction(res.Scale) >= Fraction(Q[res.level]) * Fraction(message_ratio):
+            (ev._resize(res, res.Degree(), res.level - 1) if hasattr(ev, "_resize") else ev._set(res, res.Value, res.level - 1))
+        if res.level != 0:
+            raise ValueError("ScaleDown: the message is too large to be brought to level 0 (RescaleTo path not built)")
+        scale_up = Fraction(modulus(res.level)) / Fraction(res.Scale) / Fraction(message_ratio)
+        if scale_up < Fraction(1, 2):
+            raise ValueError("initial Q/Scale < 0.5*Q[0]/MessageRatio")
+        k = int(scale_up)  # Scale.BigInt() truncates
+        ev.Mul(res, k, res)
+        res.Scale = Fraction(res.Scale) * k
+        target = Fraction(Q[0]) / Fraction(message_ratio)
+        return res, Fraction(res.Scale) / target
+
     def Bootstrap(self, ct, work_scale):
         """ct: level-0 ciphertext.  `work_scale` is the scale metadata given to the raised ciphertext (the reference sets it
         through ScaleDown / the ModUp message scaling and Mod1Parameters.ScalingFactor)."""

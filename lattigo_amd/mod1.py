@@ -5,7 +5,7 @@ the polynomial evaluator (polyeval.py) and the device-resident ckks.Evaluator mi
 The approximation polynomial is the truncated Chebyshev series of the same function on the same interval with the same
 degree, computed in 60-digit arithmetic (the reference interpolates at Chebyshev nodes in arbitrary precision,
 circuits/ckks/mod1/mod1_parameters.go:150-215; the two differ by the aliased tail of the series, < 1e-40 here); only the
-continuous sine / cosine types and the Han-Ki discrete cosine (cosine.py) are provided (no arcsine)."""
+continuous sine / cosine types, the Han-Ki discrete cosine (cosine.py) and the optional arcsine are provided."""
 from __future__ import annotations
 
 import math
@@ -61,7 +61,7 @@ class Mod1Parameters:
     PREC = 60
 
     def __init__(self, Q0: int, LevelQ: int, LogScale: int, Mod1Type: int, K: int, Mod1Degree: int, DoubleAngle: int = 0,
-                 LogMessageRatio: int = 8, Scaling: float = 1.0):
+                 LogMessageRatio: int = 8, Scaling: float = 1.0, Mod1InvDegree: int = 0):
         import decimal
         self.LevelQ, self.LogDefaultScale, self.Mod1Type, self.LogMessageRatio = LevelQ, LogScale, Mod1Type, LogMessageRatio
         self.DoubleAngle = 0 if Mod1Type == SinContinuous else DoubleAngle
@@ -71,9 +71,21 @@ class Mod1Parameters:
         with decimal.localcontext() as c:
             c.prec = self.PREC
             qdiff = decimal.Decimal(Q0) / (decimal.Decimal(2) ** round(math.log2(float(Q0))))
-            s2p = qdiff * decimal.Decimal(Scaling or 1.0) / (2 * pi)
-            for _ in range(self.DoubleAngle):
-                s2p = s2p.sqrt()
+            self.Mod1InvPoly = None
+            if Mod1InvDegree > 0:  # arcsine series of (1 / 2 pi) asin(x) scaled by qDiff * scaling (:117-137); then sqrt2pi = 1
+                inv = [None] * (Mod1InvDegree + 1)
+                cur = qdiff * decimal.Decimal(Scaling or 1.0) / (2 * pi)
+                inv[1] = (Fraction(cur), Fraction(0))
+                for i in range(3, Mod1InvDegree + 1, 2):
+                    cur = cur * (i * i - 4 * i + 4) / (i * i - i)
+                    inv[i] = (Fraction(cur), Fraction(0))
+                self.Mod1InvPoly = Polynomial(inv, Basis="Monomial")
+                self.Mod1InvPoly.IsEven = False
+                s2p = decimal.Decimal(1)
+            else:
+                s2p = qdiff * decimal.Decimal(Scaling or 1.0) / (2 * pi)
+                for _ in range(self.DoubleAngle):
+                    s2p = s2p.sqrt()
             a = 2 * pi * decimal.Decimal(K) / (decimal.Decimal(2) ** self.DoubleAngle)
             coeffs = []
             if Mod1Type == CosDiscrete:  # Han-Ki interpolation around the integers; the odd coefficients are dropped (:186-196)
@@ -106,7 +118,8 @@ class Mod1Parameters:
         return float(1 << self.LogMessageRatio)
 
     def Depth(self) -> int:
-        return self.Mod1Poly.Degree().bit_length() + self.DoubleAngle
+        inv = self.Mod1InvPoly.Degree().bit_length() if self.Mod1InvPoly is not None else 0
+        return self.Mod1Poly.Degree().bit_length() + self.DoubleAngle + inv
 
 
 class Mod1Evaluator:
@@ -143,5 +156,7 @@ class Mod1Evaluator:
             ev.Add(res, res, res)
             ev.Add(res, (-sqrt2pi, 0), res)
             ev.Rescale(res, res)
+        if evm.Mod1InvPoly is not None:  # arcsine (:121-138)
+            res = self.PolynomialEvaluator.Evaluate(res, evm.Mod1InvPoly, res.Scale)
         res.Scale = ct.Scale  # multiplies back by q (:141)
         return res

@@ -434,7 +434,7 @@ def test_ckks_polynomial_evaluation(ctx, deg, basis):
         assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (deg, basis, b)
 
 
-@pytest.mark.parametrize("kind,K,deg,r", [("cos", 8, 30, 2), ("cos", 12, 40, 3), ("sin", 3, 31, 0), ("hanki", 16, 30, 3)])
+@pytest.mark.parametrize("kind,K,deg,r", [("cos", 8, 30, 2), ("cos", 12, 40, 3), ("sin", 3, 31, 0), ("hanki", 16, 30, 3), ("asin", 8, 30, 1)])
 def test_mod1(ctx, kind, K, deg, r):
     """circuits/ckks/mod1 Evaluator.EvaluateNew (EvalMod: even / odd Chebyshev polynomial incl. a degree-0 baby step,
     double-angle steps) with the device-resident ckks.Evaluator mirror vs the oracle backend: bit-exact, batch 2."""
@@ -446,8 +446,9 @@ def test_mod1(ctx, kind, K, deg, r):
     B, top = 2, 10
     gce = S.CKKSCiphertextEvaluator(rg.gev, rg.ggks.keys[1])
     oce = OC.CKKSCtEvaluator(rg.oev, rg.ogks[1])
-    typ = {"cos": M1.CosContinuous, "sin": M1.SinContinuous, "hanki": M1.CosDiscrete}[kind]
-    pm = M1.Mod1Parameters(int(rg.q[0]), LevelQ=top, LogScale=45, Mod1Type=typ, K=K, Mod1Degree=deg, DoubleAngle=r)
+    typ = {"cos": M1.CosContinuous, "sin": M1.SinContinuous, "hanki": M1.CosDiscrete, "asin": M1.CosContinuous}[kind]
+    pm = M1.Mod1Parameters(int(rg.q[0]), LevelQ=top, LogScale=45, Mod1Type=typ, K=K, Mod1Degree=deg, DoubleAngle=r,
+                           Mod1InvDegree=7 if kind == "asin" else 0)
     ct = rg.ct(top, B)
     scale = Fraction(1 << 45)
     res = M1.Mod1Evaluator(gce, pm).EvaluateNew(S.Ciphertext(rg.up(ct), top, scale))

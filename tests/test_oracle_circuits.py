@@ -385,3 +385,56 @@ def test_toy_bootstrapping_refreshes_a_level0_ciphertext():
     assert res.level == tb.stc_level - 2 >= 1 and res.Degree() == 1 and tb.n_diagonals == [16, 31, 31, 16]
     got = tb.decode(res)
     assert np.max(np.abs(got - z)) < 1e-5, np.max(np.abs(got - z))  # ~23 bits
+
+
+def test_mod1_with_arcsine_is_linear_in_the_message():
+    """Mod1InvDegree > 0 (mod1_parameters.go:117-137, mod1_evaluator.go:121-138): composing the scaled sine with the arcsine
+    series removes the cubic term, so the result is QDiff * (x mod 1) even for a large message ratio 2^-3."""
+    from fractions import Fraction
+    from lattigo_amd import mod1 as M1
+    from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
+    q, p = O.GenModuli(10, [55] + [45] * 12, [55, 55])
+    rng = rng_for(4300)
+    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
+    ev = O.Evaluator(ringQ, ringP)
+    sk = SecretKey(rng, ringQ, ringP)
+    rlk = gen_evaluation_key(rng, ringQ, ringP, ringQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q), sk)
+    ce = OC.CKKSCtEvaluator(ev, rlk)
+    K = 8
+    ints = rng.integers(-(K - 1), K, size=N // 2)
+    frac = rng.uniform(-2.0 ** -3, 2.0 ** -3, size=N // 2)
+    scale = Fraction(1 << 45)
+    ct = OC.Ct(list(ckks_encrypt(rng, ringQ, sk, ((ints + frac) / K).astype(complex), scale)), scale)
+    errs = {}
+    for inv in (0, 7):
+        pm = M1.Mod1Parameters(int(q[0]), LevelQ=len(q) - 1, LogScale=45, Mod1Type=M1.CosContinuous, K=K, Mod1Degree=30, DoubleAngle=2,
+                               Mod1InvDegree=inv)
+        res = M1.Mod1Evaluator(ce, pm).EvaluateNew(ct)
+        assert res.level == len(q) - 1 - pm.Depth()
+        got = ckks_decrypt(O.Ring(N, q[: res.level + 1]), np.stack(res.Value), sk, res.Scale)
+        errs[inv] = np.max(np.abs(got.real - pm.QDiff * frac))
+    assert errs[0] > 1e-3 and errs[7] < errs[0] / 20, errs  # sine alone is off by the cubic term; the degree-7 arcsine removes most of it
+
+
+def test_scale_down_brings_the_message_below_q0():
+    """bootstrapping.Evaluator.ScaleDown (circuits/ckks/bootstrapping/evaluator.go:566-610): unnecessary primes dropped, the
+    ciphertext multiplied by an integer so that Q[0] / scale = MessageRatio; the slots are unchanged."""
+    from fractions import Fraction
+    from types import SimpleNamespace
+    from lattigo_amd import bootstrapping as BS
+    from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
+    q, p = O.GenModuli(10, [55, 45, 45], [55])
+    rng = rng_for(4400)
+    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
+    ev = O.Evaluator(ringQ, ringP)
+    sk = SecretKey(rng, ringQ, ringP)
+    ce = OC.CKKSCtEvaluator(ev, None)
+    z = rng.uniform(-1, 1, size=N // 2) + 1j * rng.uniform(-1, 1, size=N // 2)
+    scale = Fraction(1 << 30)
+    ct = OC.Ct(list(ckks_encrypt(rng, ringQ, sk, z, scale)), scale)  # level 2
+    boot = BS.Bootstrapper(SimpleNamespace(ckks=ce), None, [], [], [], [])
+    res, err_scale = boot.ScaleDown(ct, 256.0)
+    assert res.level == 0 and ct.level == 2
+    assert abs(float(Fraction(q[0]) / res.Scale) / 256.0 - 1) < 1e-6 and abs(float(err_scale) - 1) < 1e-6
+    got = ckks_decrypt(O.Ring(N, q[:1]), np.stack(res.Value), sk, res.Scale)
+    assert np.max(np.abs(got - z)) < 1e-6
