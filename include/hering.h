@@ -84,6 +84,9 @@ int he_poly_download(he_handle poly, uint64_t *dst, size_t n_words);
 int he_poly_upload_limb(he_handle poly, int b, int limb, const uint64_t *src);
 int he_poly_download_limb(he_handle poly, int b, int limb, uint64_t *dst);
 int he_poly_copy(he_handle dst, he_handle src, int level);      /* Poly.CopyLvl */
+/* limbs 0..level of the batch entries [src_b0, src_b0 + nb) of src -> entries [dst_b0, dst_b0 + nb) of dst (regrouping of
+ * independent ciphertexts into one batch, e.g. the real and imaginary halves before EvalMod) */
+int he_poly_copy_batch(he_handle dst, int dst_b0, he_handle src, int src_b0, int nb, int level);
 int he_poly_zero(he_handle poly);
 
 /* ---- NTT: Ring.NTT / NTTLazy / INTT / INTTLazy (ring/ntt.go:127-152) ------------- */

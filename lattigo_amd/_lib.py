@@ -66,7 +66,7 @@ def _declare(L):
         "he_poly_shape": [H, C.POINTER(i), C.POINTER(i), C.POINTER(i)],
         "he_poly_upload": [H, u64p, sz], "he_poly_download": [H, u64p, sz],
         "he_poly_upload_limb": [H, i, i, u64p], "he_poly_download_limb": [H, i, i, u64p],
-        "he_poly_copy": [H, H, i], "he_poly_zero": [H],
+        "he_poly_copy": [H, H, i], "he_poly_copy_batch": [H, i, H, i, i, i], "he_poly_zero": [H],
         "he_ntt": [H, i, H, H], "he_ntt_lazy": [H, i, H, H], "he_intt": [H, i, H, H], "he_intt_lazy": [H, i, H, H],
         "he_subring_ntt_host": [H, i, i, i, u64p, u64p],
         "he_binop": [H, i, i, H, H, H], "he_unop": [H, i, i, H, H], "he_scalarop": [H, i, i, H, C.c_uint64, H],

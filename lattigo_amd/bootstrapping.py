@@ -103,6 +103,31 @@ class DeviceBootstrapBackend:
         return Ciphertext(out, ct.level, ct.Scale)
 
 
+    def stack(self, cts):
+        """independent ciphertexts of equal level / scale / batch -> one ciphertext whose batch is their concatenation"""
+        from .schemes import Ciphertext
+        a = cts[0]
+        B, lv = a.Value[0].batch, a.level
+        out = [Poly(self.ckks.ringQ, lv + 1, B * len(cts)) for _ in range(a.Degree() + 1)]
+        for i, c in enumerate(cts):
+            if (c.level, c.Scale, c.Degree(), c.Value[0].batch) != (lv, a.Scale, a.Degree(), B):
+                raise ValueError("stack: ciphertexts must share level, scale, degree and batch")
+            for o, v in zip(out, c.Value):
+                o.CopyBatch(lv, i * B, v, 0, B)
+        return Ciphertext(out, lv, a.Scale)
+
+    def unstack(self, ct, parts: int):
+        from .schemes import Ciphertext
+        B = ct.Value[0].batch // parts
+        res = []
+        for i in range(parts):
+            vals = [Poly(self.ckks.ringQ, ct.level + 1, B) for _ in ct.Value]
+            for o, v in zip(vals, ct.Value):
+                o.CopyBatch(ct.level, 0, v, i * B, B)
+            res.append(Ciphertext(vals, ct.level, ct.Scale))
+        return res
+
+
 class Bootstrapper:
     """bootstrapping.Evaluator.bootstrap for fully packed ciphertexts: ModUp -> CoeffsToSlots -> EvalMod (real and
     imaginary halves) -> SlotsToCoeffs.  `backend` provides modup / lintrans / conjugate and the ckks evaluator; the encoded
@@ -180,6 +205,9 @@ class Bootstrapper:
         up = self.be.modup(ct, self.modup_scale, logSlots)
         up.Scale = work_scale
         ctReal, ctImag = self.CoeffsToSlots(up)
-        ctReal = self.mod1.EvaluateNew(ctReal)
-        ctImag = self.mod1.EvaluateNew(ctImag)
+        if hasattr(self.be, "stack"):  # the two halves are independent: evaluate EvalMod on them as one batch
+            ctReal, ctImag = self.be.unstack(self.mod1.EvaluateNew(self.be.stack([ctReal, ctImag])), 2)
+        else:
+            ctReal = self.mod1.EvaluateNew(ctReal)
+            ctImag = self.mod1.EvaluateNew(ctImag)
         return self.SlotsToCoeffs(ctReal, ctImag)

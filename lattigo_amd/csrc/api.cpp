@@ -625,6 +625,18 @@ int he_poly_copy(he_handle hdst, he_handle hsrc, int level) {
                              d->batch, hipMemcpyDeviceToDevice, d->ctx->stream));
     return HE_OK;
 }
+int he_poly_copy_batch(he_handle hdst, int dst_b0, he_handle hsrc, int src_b0, int nb, int level) {
+    GET(d, Poly, hdst, T_POLY);
+    GET(s, Poly, hsrc, T_POLY);
+    if (d->N != s->N || level < 0 || d->nlimbs < level + 1 || s->nlimbs < level + 1 || nb <= 0 || dst_b0 < 0 || src_b0 < 0 ||
+        dst_b0 + nb > d->batch || src_b0 + nb > s->batch || d->ctx != s->ctx)
+        return fail(HE_EINVAL, "he_poly_copy_batch: shape mismatch");
+    Scope sc(d->ctx.get());
+    const size_t dpitch = (size_t)d->nlimbs * d->N * 8, spitch = (size_t)s->nlimbs * s->N * 8;
+    HIP_TRY(hipMemcpy2DAsync((char *)d->d + dst_b0 * dpitch, dpitch, (const char *)s->d + src_b0 * spitch, spitch,
+                             (size_t)(level + 1) * d->N * 8, nb, hipMemcpyDeviceToDevice, d->ctx->stream));
+    return HE_OK;
+}
 int he_poly_zero(he_handle h) {
     GET(p, Poly, h, T_POLY);
     Scope sc(p->ctx.get());

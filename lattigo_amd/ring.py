@@ -167,6 +167,10 @@ class Poly:
     def CopyLvl(self, level, src: "Poly"):
         check(load().he_poly_copy(self.h, src.h, level))
 
+    def CopyBatch(self, level, dst_b0: int, src: "Poly", src_b0: int, nb: int):
+        """batch entries [src_b0, src_b0 + nb) of src -> entries [dst_b0, dst_b0 + nb) of self (limbs 0..level)"""
+        check(load().he_poly_copy_batch(self.h, dst_b0, src.h, src_b0, nb, level))
+
     def Zero(self):
         check(load().he_poly_zero(self.h))
 

@@ -106,10 +106,29 @@ def main():
     ctx.prof_begin()
     run()
     prof = ctx.prof_end()
+    # phase timing (host wall clock with a device sync after each phase)
+    phases = {}
+    up = None
+
+    def timed(name, fn):
+        ctx.sync()
+        t = time.perf_counter()
+        out = fn()
+        ctx.sync()
+        phases[name] = round((time.perf_counter() - t) * 1e3, 2)
+        return out
+
+    logSlots = logN - 1
+    up = timed("ModUp", lambda: be.modup(S.Ciphertext(ct0, 0, 1), 256.0, logSlots))
+    up.Scale = Fraction(1 << 60)
+    re_im = timed("CoeffsToSlots", lambda: boot.CoeffsToSlots(up))
+    r1 = timed("EvalMod(real)", lambda: boot.mod1.EvaluateNew(re_im[0]))
+    r2 = timed("EvalMod(imag)", lambda: boot.mod1.EvaluateNew(re_im[1]))
+    timed("SlotsToCoeffs", lambda: boot.SlotsToCoeffs(r1, r2))
     print(json.dumps({"config": "c5-shape", "what": "CKKS bootstrap op trace, logN=16, 25+5 limbs (N16QP1546H192H32 shape), "
                       "synthetic keys / DFT diagonals", "batch": B, "s_per_batch": dt, "bootstraps_per_s": B / dt,
                       "output_level": res.level, "galois_keys": len(gks.keys), "dft_diagonals": ndiag,
-                      "kernel_launches": int(sum(v[0] for v in prof.values())),
+                      "kernel_launches": int(sum(v[0] for v in prof.values())), "phase_ms": phases,
                       "kernel_ms": {k: round(v[1], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}))
 
 
