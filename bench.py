@@ -105,10 +105,12 @@ def main():
     rank, local_rank, world = cp.rank, cp.local_rank, cp.world
     if world > 1:
         import torch
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(int(os.environ.get("HERING_FORCE_DEVICE", local_rank)))
 
     import lattigo_amd as la
-    ctx = la.Context(local_rank if world > 1 else 0)
+    # HERING_FORCE_DEVICE: test hook to exercise the multi-rank path on a box with fewer GPUs than ranks
+    dev = int(os.environ.get("HERING_FORCE_DEVICE", local_rank if world > 1 else 0))
+    ctx = la.Context(dev)
     N, B = 1 << LOGN, args.batch
     q, p = gen_moduli()
     L, alpha = len(q), len(p)
