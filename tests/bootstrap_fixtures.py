@@ -138,111 +138,8 @@ class ToyBootstrap:
         return ckks_decrypt(sub, np.stack(res.Value), self.sk, res.Scale) * (2.0 ** 55 / self.Delta)
 
 
-# ---- diagonal-form special FFT (scales to N = 2^16: no dense n x n matrices) --------------------------------------------
-_TW_CACHE = {}
-
-
-def _layer_twiddles(N, ln):
-    if (N, ln) not in _TW_CACHE:
-        _TW_CACHE[(N, ln)] = _layer_twiddles_uncached(N, ln)
-    return _TW_CACHE[(N, ln)]
-
-
-def _layer_twiddles_uncached(N, ln):
-    n, M = N // 2, 2 * N
-    lenh, lenq = ln >> 1, ln << 2
-    j = np.arange(lenh)
-    rot = np.array([pow(5, int(x), M) for x in j]) if lenh <= 4096 else None
-    if rot is None:  # 5^j mod M incrementally
-        rot = np.empty(lenh, dtype=np.int64)
-        g = 1
-        for i in range(lenh):
-            rot[i] = g
-            g = g * 5 % M
-    w = np.exp(2j * np.pi * ((rot % lenq) * (M // lenq)) / M)  # [lenh]
-    return np.tile(w, n // ln)  # per block, indexed by (block, j)
-
-
-def layer_diagonals(N, ln, inverse=False):
-    """special-FFT layer of butterfly span `ln` as {offset: vector} with (A z)[r] = sum_a A[a][r] * z[(r + a) mod n]"""
-    n = N // 2
-    lenh = ln >> 1
-    w = _layer_twiddles(N, ln)  # one twiddle per butterfly, in row order of the first halves
-    first = (np.arange(n) % ln) < lenh
-    d0, dp, dm = np.zeros(n, dtype=complex), np.zeros(n, dtype=complex), np.zeros(n, dtype=complex)
-    if not inverse:  # (u, v) -> (u + w v, u - w v)
-        d0[first], dp[first] = 1.0, w
-        dm[~first], d0[~first] = 1.0, -w
-    else:  # u = (u' + v') / 2, v = (u' - v') / (2 w)
-        d0[first], dp[first] = 0.5, 0.5
-        dm[~first], d0[~first] = 0.5 / w, -0.5 / w
-    out = {0: d0, lenh % n: dp}
-    key = (-lenh) % n
-    out[key] = out.get(key, 0) + dm
-    return out
-
-
-def diag_matmul(A, B, n):
-    """C = A B in diagonal form: C[a + b][r] += A[a][r] * B[b][(r + a) mod n]"""
-    C = {}
-    for a, va in A.items():
-        for b, vb in B.items():
-            k = (a + b) % n
-            t = va * np.roll(vb, -a)
-            C[k] = C[k] + t if k in C else t
-    return {k: v for k, v in C.items() if np.max(np.abs(v)) > 1e-13}
-
-
-def bitrev_indices(n):
-    b = n.bit_length() - 1
-    idx = np.arange(n)
-    out = np.zeros(n, dtype=np.int64)
-    for i in range(b):
-        out |= ((idx >> i) & 1) << (b - 1 - i)
-    return out
-
-
-def special_fft(w_vec, N):
-    """z = U w (slots from the complex half-coefficient vector), O(n log n)"""
-    n = N // 2
-    v = np.asarray(w_vec, dtype=complex)[bitrev_indices(n)].copy()
-    ln = 2
-    while ln <= n:
-        lenh = ln >> 1
-        tw = _layer_twiddles(N, ln).reshape(n // ln, lenh)
-        blk = v.reshape(n // ln, ln)
-        u, t = blk[:, :lenh].copy(), blk[:, lenh:] * tw
-        blk[:, :lenh], blk[:, lenh:] = u + t, u - t
-        ln <<= 1
-    return v
-
-
-def special_ifft(z, N):
-    """w = U^-1 z"""
-    n = N // 2
-    v = np.asarray(z, dtype=complex).copy()
-    ln = n
-    while ln >= 2:
-        lenh = ln >> 1
-        tw = _layer_twiddles(N, ln).reshape(n // ln, lenh)
-        blk = v.reshape(n // ln, ln)
-        a, b = blk[:, :lenh].copy(), blk[:, lenh:].copy()
-        blk[:, :lenh], blk[:, lenh:] = (a + b) / 2, (a - b) / (2 * tw)
-        ln >>= 1
-    out = np.empty(n, dtype=complex)
-    out[bitrev_indices(n)] = v
-    return out
-
-
-def fast_encode_rns(vec, N, scale, moduli):
-    """slot vector -> coefficient-domain residues [limbs][N] (uint64) of round(scale * coefficients), via the special iFFT"""
-    w = special_ifft(vec, N)
-    coeffs = np.concatenate([w.real, w.imag]) * float(scale)
-    ints = np.rint(coeffs).astype(np.int64)
-    out = np.empty((len(moduli), N), dtype=np.uint64)
-    for i, q in enumerate(moduli):
-        out[i] = np.mod(ints, np.int64(q)).astype(np.uint64)
-    return out
+from lattigo_amd.dft import (bitrev_indices, diag_matmul, fast_encode_rns, layer_diagonals, special_fft,  # noqa: E402,F401
+                             special_ifft)
 
 
 def run_functional_bootstrap(logN, logq_res, n_stc, evalmod_bits, n_cts, cts_bits, stc_bits, logp, cts_groups, stc_groups, h_dense, h_sparse,
@@ -302,18 +199,25 @@ def run_functional_bootstrap(logN, logq_res, n_stc, evalmod_bits, n_cts, cts_bit
             v = np.roll(diags[k] * first_gain, j0)
             rq = sub.unop("MForm", sub.NTT(fast_encode_rns(v, N, scale, q[: level + 1])))
             rp = oP.unop("MForm", oP.NTT(fast_encode_rns(v, N, scale, p)))
-            vec[k] = (la.Poly(gQ, level + 1).upload(rq), la.Poly(gP, LP).upload(rp)) if device else (rq, rp)
+            vec[k] = (rq, rp)
         _, r1, r2 = LT.BSGSIndex(ks, n, N1)
-        lt = (LT.LinearTransformation if device else OC.LinearTransformation)(vec, level, LP - 1, n, N1)
+        lt = OC.LinearTransformation(vec, level, LP - 1, n, N1)
         return lt, scale, set(r1) | set(r2)
 
-    cts, cts_sc, stc, stc_sc, rots = [], [], [], [], set()
-    for i, (a, b) in enumerate(cts_groups):
-        lt, sc, rr = build_lt(group(lns[a:b], True), top - i, gain if i == 0 else 1.0)
-        cts.append(lt); cts_sc.append(sc); rots |= rr
-    for i, (a, b) in enumerate(stc_groups):
-        lt, sc, rr = build_lt(group(lns[a:b], False), stc_top - i)
-        stc.append(lt); stc_sc.append(sc); rots |= rr
+    if device:  # product path: lattigo_amd.dft encodes the factors with the device's NTT / MForm
+        from lattigo_amd import dft as DFT
+        enc = DFT.Encoder(gQ, gP)
+        cts, cts_sc, r_a = DFT.NewMatrices(enc, DFT.HomomorphicEncode, cts_groups, top, gain)
+        stc, stc_sc, r_b = DFT.NewMatrices(enc, DFT.HomomorphicDecode, stc_groups, stc_top)
+        rots = r_a | r_b
+    else:
+        cts, cts_sc, stc, stc_sc, rots = [], [], [], [], set()
+        for i, (a, b) in enumerate(cts_groups):
+            lt, sc, rr = build_lt(group(lns[a:b], True), top - i, gain if i == 0 else 1.0)
+            cts.append(lt); cts_sc.append(sc); rots |= rr
+        for i, (a, b) in enumerate(stc_groups):
+            lt, sc, rr = build_lt(group(lns[a:b], False), stc_top - i)
+            stc.append(lt); stc_sc.append(sc); rots |= rr
     ndiag = sum(len(m.Vec) for m in cts + stc)
     t_mats = time.time()
 

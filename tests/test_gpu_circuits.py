@@ -495,3 +495,42 @@ def test_toy_bootstrapping_end_to_end(ctx):
         assert (res.level, res.Scale) == (want.level, want.Scale) and res.level >= 1
         assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), b
         assert np.max(np.abs(tb.decode(want) - zs[b])) < 1e-5
+
+
+@pytest.mark.gpu
+def test_ckks_encoder_and_dft_factors(ctx):
+    """lattigo_amd.dft: Encode is bit-identical to the oracle's NTT of the same rounded coefficients, Decode inverts it, and the
+    factor lists multiply back to the special FFT (without its bit-reversal) and its inverse."""
+    from fractions import Fraction
+    from lattigo_amd import dft as DFT
+    logN = 9
+    N, n = 1 << logN, 1 << (logN - 1)
+    q, p = O.GenModuli(logN + 1, [55, 45, 45], [56])
+    gQ, gP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+    oQ, oP = O.Ring(N, q), O.Ring(N, p)
+    rng = rng_for(7300)
+    z = rng.uniform(-1, 1, size=n) + 1j * rng.uniform(-1, 1, size=n)
+    enc = DFT.Encoder(gQ, gP)
+    scale = Fraction(1 << 40)
+    pt = enc.Encode(z, 2, scale)
+    assert np.array_equal(pt.download()[0], oQ.NTT(DFT.fast_encode_rns(z, N, scale, q)))
+    assert np.max(np.abs(enc.Decode(pt, scale) - z)) < 2.0 ** -30
+    dq, dp = enc.EncodeQP(z, 1, scale)
+    sub = O.Ring(N, q[:2])
+    assert np.array_equal(dq.download()[0], sub.unop("MForm", sub.NTT(DFT.fast_encode_rns(z, N, scale, q[:2]))))
+    assert np.array_equal(dp.download()[0], oP.unop("MForm", oP.NTT(DFT.fast_encode_rns(z, N, scale, p))))
+
+    def apply(diags, v):
+        return sum(d * np.roll(v, -k) for k, d in diags.items())
+
+    w = rng.uniform(-1, 1, size=n) + 1j * rng.uniform(-1, 1, size=n)
+    br = DFT.bitrev_indices(n)
+    fwd = DFT.factor_diagonals(N, [(0, 4), (4, logN - 1)], False)
+    v = w[br]
+    for f in fwd:
+        v = apply(f, v)
+    assert np.max(np.abs(v - DFT.special_fft(w, N))) < 1e-9
+    inv = DFT.factor_diagonals(N, [(4, logN - 1), (0, 4)], True)
+    for f in inv:
+        v = apply(f, v)
+    assert np.max(np.abs(v[br] - w)) < 1e-9  # bitrev is an involution
