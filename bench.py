@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="independent ciphertext pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicate-keys", choices=["none", "rccl", "host"], default="none",
+                    help="N > 1: rank 0's relinearisation key is replicated to every rank before the timed region (RCCL broadcast "
+                         "into the key's device storage, or gloo through host memory) instead of each rank drawing its own")
     ap.add_argument("--microbench", action="store_true", help="also print NTT/s and the modmul probe to stderr")
     args = ap.parse_args()
 
@@ -120,6 +123,8 @@ def main():
     rng = np.random.Generator(np.random.PCG64(0x1A77160 + 2 + 1000 * rank))
     kq, kp = uniform(rng, q, N, (beta, 2)), uniform(rng, p, N, (beta, 2))
     rlk = ev.NewEvaluationKey(kq, kp)
+    if world > 1 and args.replicate_keys != "none":
+        rlk = cp.ReplicateEvaluationKey(ev, rlk if rank == 0 else None, src=0, transport=args.replicate_keys)
     a = [la.Poly(ringQ, L, B).upload(uniform(rng, q, N, (B,))) for _ in range(2)]
     b = [la.Poly(ringQ, L, B).upload(uniform(rng, q, N, (B,))) for _ in range(2)]
     out = [la.Poly(ringQ, L, B), la.Poly(ringQ, L, B)]

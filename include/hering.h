@@ -225,6 +225,18 @@ int he_evk_create_base2(he_handle eval, int pw2, const int *nj, int n_rns_digits
                         const uint64_t *p, he_handle *evk);
 int he_evk_destroy(he_handle evk);
 
+/* Key replication across GPUs (evaluation keys are replicated on every GPU; the reference has no
+ * counterpart -- its keys live in one address space, core/rlwe/keys.go:380-460).  he_evk_create / he_evk_create_base2 with
+ * q == p == NULL allocate a zeroed key of the given shape; he_evk_device_buffer returns the key's device storage
+ * ([beta][2][nQk + nPk][N] words: the q rows then the p rows of each (digit, component)) after draining the context's
+ * stream, so that the host can fill it GPU-to-GPU (an RCCL broadcast over xGMI) on a stream of its own; he_evk_commit must
+ * follow any external write (it refreshes the derived double-precision copy) once that write has completed. */
+int he_evk_device_buffer(he_handle evk, void **ptr, size_t *bytes);
+int he_evk_commit(he_handle evk);
+/* the key words back on the host, [beta][2][nQk + nPk][N] (GadgetCiphertext.MarshalBinary's payload order per digit is q then p,
+ * core/rlwe/gadgetciphertext.go:110-132) */
+int he_evk_download(he_handle evk, uint64_t *dst, size_t n_words);
+
 /* Decomposer.DecomposeAndSplit (ring/basis_extension.go:381): coefficient-domain
  * p0Q -> digit `digit` extended to p1Q (limbs 0..levelQ except, for multi-limb
  * digits, the digit's own) and p1P (limbs 0..levelP). */

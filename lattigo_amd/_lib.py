@@ -95,6 +95,7 @@ def _declare(L):
         "he_moddown_qp_to_p": [H, i, i, H, H, H],
         "he_evaluator_create": [H, H, HP], "he_evaluator_destroy": [H],
         "he_evk_create": [H, i, i, i, u64p, u64p, HP], "he_evk_destroy": [H],
+        "he_evk_device_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(sz)], "he_evk_commit": [H], "he_evk_download": [H, u64p, sz],
         "he_evk_create_base2": [H, i, C.POINTER(i), i, i, i, u64p, u64p, HP],
         "he_decompose_and_split": [H, i, i, i, i, H, H, H],
         "he_decomp_create": [H, i, HP], "he_decomp_destroy": [H],

@@ -1252,11 +1252,29 @@ int he_evaluator_create(he_handle hq, he_handle hp, he_handle *out) {
 }
 int he_evaluator_destroy(he_handle h) { return unreg(h, T_EVAL); }
 
+// double-precision copy of the key for the fused NTT+MAC kernel, when some key limb is below 2^47 (re-run after the key
+// words change: he_evk_commit)
+static int evk_derive(Evk &k) {
+    BasisExtender &be = *k.ev->be;
+    const int nQk = k.nQk, nPk = k.nPk;
+    const size_t blk = (size_t)(nQk + nPk) * be.Q->N;
+    bool any = false;
+    uint8_t mods[kMaxLimbs];
+    for (int i = 0; i < nQk; i++) { mods[i] = (uint8_t)i; any = any || be.small[i] == 2; }
+    for (int i = 0; i < nPk; i++) { mods[nQk + i] = (uint8_t)(be.LQ + i); any = any || be.small[be.LQ + i] == 2; }
+    if (any && be.d_twdf && k.pw2 == 0) {
+        if (!k.keyd) HIP_TRY(hipMalloc((void **)&k.keyd, (size_t)k.beta * 2 * blk * 8));
+        HIP_TRY(launch_key_to_f64(be.qp, k.d, k.keyd, k.beta * 2, mods, nQk + nPk, be.ctx->stream));
+    }
+    return HE_OK;
+}
+
 static int evk_create_common(he_handle hev, int beta, int nQk, int nPk, const uint64_t *q, const uint64_t *p, int pw2,
                              const int *nj, int n_rns, he_handle *out) {
     GET(ev, Evaluator, hev, T_EVAL);
     BasisExtender &be = *ev->be;
-    if (!q || !p || !out || beta <= 0 || nQk <= 0 || nQk > be.LQ || nPk <= 0 || nPk > be.LP)
+    const bool empty = !q && !p;  // shape only: contents arrive through he_evk_device_buffer + he_evk_commit
+    if ((!empty && (!q || !p)) || !out || beta <= 0 || nQk <= 0 || nQk > be.LQ || nPk <= 0 || nPk > be.LP)
         return fail(HE_EINVAL, "he_evk_create: bad key shape (beta=%d, nQk=%d, nPk=%d)", beta, nQk, nPk);
     auto k = std::make_shared<Evk>();
     k->ev = ev; k->beta = beta; k->nQk = nQk; k->nPk = nPk; k->pw2 = pw2;
@@ -1267,22 +1285,15 @@ static int evk_create_common(he_handle hev, int beta, int nQk, int nPk, const ui
     Scope sc(be.ctx.get());
     const size_t N = be.Q->N, blk = (size_t)(nQk + nPk) * N;
     HIP_TRY(hipMalloc((void **)&k->d, (size_t)beta * 2 * blk * 8));
-    for (int d = 0; d < beta; d++)
-        for (int kk = 0; kk < 2; kk++) {
-            uint64_t *dst = k->d + ((size_t)d * 2 + kk) * blk;
-            HIP_TRY(hipMemcpyAsync(dst, q + ((size_t)d * 2 + kk) * nQk * N, (size_t)nQk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
-            HIP_TRY(hipMemcpyAsync(dst + (size_t)nQk * N, p + ((size_t)d * 2 + kk) * nPk * N, (size_t)nPk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
-        }
-    {   // double-precision copy for the fused NTT+MAC kernel, when some key limb is below 2^47
-        bool any = false;
-        uint8_t mods[kMaxLimbs];
-        for (int i = 0; i < nQk; i++) { mods[i] = (uint8_t)i; any = any || be.small[i] == 2; }
-        for (int i = 0; i < nPk; i++) { mods[nQk + i] = (uint8_t)(be.LQ + i); any = any || be.small[be.LQ + i] == 2; }
-        if (any && be.d_twdf && pw2 == 0) {
-            HIP_TRY(hipMalloc((void **)&k->keyd, (size_t)beta * 2 * blk * 8));
-            HIP_TRY(launch_key_to_f64(be.qp, k->d, k->keyd, beta * 2, mods, nQk + nPk, be.ctx->stream));
-        }
-    }
+    if (empty) HIP_TRY(hipMemsetAsync(k->d, 0, (size_t)beta * 2 * blk * 8, be.ctx->stream));
+    else
+        for (int d = 0; d < beta; d++)
+            for (int kk = 0; kk < 2; kk++) {
+                uint64_t *dst = k->d + ((size_t)d * 2 + kk) * blk;
+                HIP_TRY(hipMemcpyAsync(dst, q + ((size_t)d * 2 + kk) * nQk * N, (size_t)nQk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
+                HIP_TRY(hipMemcpyAsync(dst + (size_t)nQk * N, p + ((size_t)d * 2 + kk) * nPk * N, (size_t)nPk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
+            }
+    if (int rc = evk_derive(*k)) return rc;
     HIP_TRY(hipStreamSynchronize(be.ctx->stream));
     *out = reg(k);
     return HE_OK;
@@ -1303,6 +1314,34 @@ int he_evk_create_base2(he_handle hev, int pw2, const int *nj, int n_rns, int nQ
     return evk_create_common(hev, beta, nQk, nPk, q, p, pw2, nj, n_rns, out);
 }
 int he_evk_destroy(he_handle h) { return unreg(h, T_EVK); }
+
+int he_evk_device_buffer(he_handle hk, void **ptr, size_t *bytes) {
+    GET(k, Evk, hk, T_EVK);
+    if (!ptr || !bytes) return fail(HE_EINVAL, "he_evk_device_buffer: null output");
+    Scope sc(k->ev->be->ctx.get());
+    HIP_TRY(hipStreamSynchronize(k->ev->be->ctx->stream));  // the caller reads / writes it on a stream of its own
+    *ptr = k->d;
+    *bytes = (size_t)k->beta * 2 * (size_t)(k->nQk + k->nPk) * k->ev->be->Q->N * 8;
+    return HE_OK;
+}
+
+int he_evk_download(he_handle hk, uint64_t *dst, size_t n_words) {
+    GET(k, Evk, hk, T_EVK);
+    const size_t words = (size_t)k->beta * 2 * (size_t)(k->nQk + k->nPk) * k->ev->be->Q->N;
+    if (!dst || n_words != words) return fail(HE_EINVAL, "he_evk_download: the key holds %zu words", words);
+    Scope sc(k->ev->be->ctx.get());
+    HIP_TRY(hipStreamSynchronize(k->ev->be->ctx->stream));
+    HIP_TRY(hipMemcpy(dst, k->d, words * 8, hipMemcpyDeviceToHost));
+    return HE_OK;
+}
+
+int he_evk_commit(he_handle hk) {
+    GET(k, Evk, hk, T_EVK);
+    Scope sc(k->ev->be->ctx.get());
+    if (int rc = evk_derive(*k)) return rc;
+    HIP_TRY(hipStreamSynchronize(k->ev->be->ctx->stream));
+    return HE_OK;
+}
 
 namespace {
 // BaseRNSDecompositionVectorSize, core/rlwe/params.go:543-550

@@ -25,19 +25,26 @@ class EvaluationKey:
     (core/rlwe/gadgetciphertext.go:19): q [beta,2,nQk,N], p [beta,2,nPk,N], NTT + Montgomery."""
 
     def __init__(self, evaluator: "Evaluator", q: np.ndarray, p: np.ndarray, BaseTwoDecomposition: int = 0,
-                 BaseTwoDecompositionVectorSize=None):
-        q = np.ascontiguousarray(q, dtype=np.uint64)
-        p = np.ascontiguousarray(p, dtype=np.uint64)
-        assert q.ndim == 4 and p.ndim == 4 and q.shape[:2] == p.shape[:2] and q.shape[1] == 2
-        self.beta, self.nQk, self.nPk = q.shape[0], q.shape[2], p.shape[2]
+                 BaseTwoDecompositionVectorSize=None, shape=None):
+        if shape is not None:  # (beta, nQk, nPk): a zeroed key to be filled on the device (DeviceBuffer / Commit)
+            self.beta, self.nQk, self.nPk = shape
+            q = p = None
+        else:
+            q = np.ascontiguousarray(q, dtype=np.uint64)
+            p = np.ascontiguousarray(p, dtype=np.uint64)
+            assert q.ndim == 4 and p.ndim == 4 and q.shape[:2] == p.shape[:2] and q.shape[1] == 2
+            self.beta, self.nQk, self.nPk = q.shape[0], q.shape[2], p.shape[2]
+        self.N = evaluator.ringQ.N
         self.BaseTwoDecomposition = BaseTwoDecomposition
+        self.BaseTwoDecompositionVectorSize = list(BaseTwoDecompositionVectorSize) if BaseTwoDecomposition else None
         h = H()
+        pq, pp = (None, None) if q is None else (_p(q), _p(p))
         if BaseTwoDecomposition:
             nj = (C.c_int * len(BaseTwoDecompositionVectorSize))(*BaseTwoDecompositionVectorSize)
             check(load().he_evk_create_base2(evaluator.h, BaseTwoDecomposition, nj, len(BaseTwoDecompositionVectorSize),
-                                             self.nQk, self.nPk, _p(q), _p(p), C.byref(h)))
+                                             self.nQk, self.nPk, pq, pp, C.byref(h)))
         else:
-            check(load().he_evk_create(evaluator.h, self.beta, self.nQk, self.nPk, _p(q), _p(p), C.byref(h)))
+            check(load().he_evk_create(evaluator.h, self.beta, self.nQk, self.nPk, pq, pp, C.byref(h)))
         self.h = h.value
 
     def LevelQ(self):
@@ -45,6 +52,26 @@ class EvaluationKey:
 
     def LevelP(self):
         return self.nPk - 1
+
+    def Shape(self):
+        """What a peer needs to allocate the same key: (beta, nQk, nPk, BaseTwoDecomposition, vector sizes)."""
+        return (self.beta, self.nQk, self.nPk, self.BaseTwoDecomposition, self.BaseTwoDecompositionVectorSize)
+
+    def DeviceBuffer(self):
+        """(device pointer, bytes) of the key words [beta][2][nQk + nPk][N]; the context's stream is drained first."""
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        check(load().he_evk_device_buffer(self.h, C.byref(ptr), C.byref(nb)))
+        return ptr.value, nb.value
+
+    def Commit(self):
+        """After an external device-side write of the key words (RCCL broadcast) has completed."""
+        check(load().he_evk_commit(self.h))
+
+    def download(self) -> np.ndarray:
+        """The key words as [beta, 2, nQk + nPk, N] (tests / wire export)."""
+        out = np.empty((self.beta, 2, self.nQk + self.nPk, self.N), dtype=np.uint64)
+        check(load().he_evk_download(self.h, _p(out), out.size))
+        return out
 
     def __del__(self):
         try:

@@ -20,6 +20,23 @@ WORKER = textwrap.dedent("""
     t = cp.max_over_ranks(1.0 + cp.rank)      # rank 1 is the slow one
     n = cp.sum_over_ranks(len(mine))
     assert t == 2.0 and n == 7.0, (t, n)
+    # key replication, host leg: a Galois key in the reference's wire format travels from rank 0 (core/rlwe/keys.go:628)
+    import hashlib
+    import numpy as np
+    from lattigo_amd import wire
+    blob = None
+    if cp.rank == 0:
+        rng = np.random.default_rng(5)
+        kq = rng.integers(0, 1 << 50, size=(2, 2, 3, 64), dtype=np.uint64)
+        kp = rng.integers(0, 1 << 50, size=(2, 2, 1, 64), dtype=np.uint64)
+        blob = wire.galois_key_marshal(5, 128, kq, kp, 0, None)
+    shape = cp.broadcast_object((2, 3, 1, 0, None) if cp.rank == 0 else None)
+    assert shape == (2, 3, 1, 0, None)
+    got = cp.broadcast_bytes(blob, src=0)
+    g, nth, q, p_, base_two, nj = wire.galois_key_unmarshal(got)
+    assert (g, nth) == (5, 128) and q.shape == (2, 2, 3, 64) and p_.shape == (2, 2, 1, 64)
+    digest = int(hashlib.sha256(got).hexdigest()[:12], 16)
+    assert cp.max_over_ranks(digest) == digest == -cp.max_over_ranks(-digest)  # identical bytes on both ranks
     if cp.rank == 0:
         print("AGG", n / t)
     cp.close()

@@ -1,10 +1,13 @@
 """GPU parity, basis extension and key-switch: libhering vs the
 CPU oracle, bit-exact on every output limb, plus decrypt-and-check semantics
 (core/rlwe/rlwe_test.go:666-779 style) on the GPU outputs."""
+import os
+
 import numpy as np
 import pytest
 
 import lattigo_amd as la
+from lattigo_amd import rlwe as R
 from oracle import oracle as O
 from tests.conftest import Pi60, Qi60
 from tests.gpu_common import Pair, ctx  # noqa: F401
@@ -517,3 +520,118 @@ def test_gadget_product_and_moddown_domain_flags(ctx):
             out = [la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gQ, levelQ + 1)]
             gev.ModDown(levelQ, 1, qp, out, ctQPIsNTT=qp_ntt, ctIsNTT=ct_ntt)
             assert np.array_equal(np.stack([c.get() for c in out]), want if ct_ntt else wantc), (levelQ, qp_ntt, ct_ntt)
+
+
+_DEVICE_BUFFER_WORKER = """
+import os, sys
+import torch                              # before libhering: one HIP runtime in the process (lattigo_amd/dist.py)
+sys.path.insert(0, %r)
+import numpy as np
+import lattigo_amd as la
+from lattigo_amd import rlwe as R
+from lattigo_amd.dist import ControlPlane
+from oracle import oracle as O
+from tests.helpers import rng_for, uniform_poly
+from tests.rlwe_fixtures import SecretKey, gen_evaluation_key
+ctx = la.Context(0)
+N = 1 << 11
+q, p = O.GenModuli(12, [55, 45, 45, 45, 45], [46, 46])  # limbs below 2^47: the key also carries its derived f64 copy
+gQ, gP, oQ, oP = la.Ring(ctx, N, q), la.Ring(ctx, N, p), O.Ring(N, q), O.Ring(N, p)
+rng = rng_for(2950)
+oev, gev = O.Evaluator(oQ, oP), la.Evaluator(gQ, gP)
+oevk = gen_evaluation_key(rng, oQ, oP, SecretKey(rng, oQ, oP).Q, SecretKey(rng, oQ, oP))
+src = gev.NewEvaluationKey(oevk.q, oevk.p)
+words = src.download()
+assert np.array_equal(words[:, :, : src.nQk], oevk.q) and np.array_equal(words[:, :, src.nQk:], oevk.p)
+beta, nQk, nPk, base_two, nj = src.Shape()
+peer = R.EvaluationKey(gev, None, None, base_two, nj, shape=(beta, nQk, nPk))
+assert not peer.download().any()
+
+def view(key):
+    ptr, nbytes = key.DeviceBuffer()
+    class W:
+        __cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+    t = torch.as_tensor(W(), device="cuda:0")
+    assert t.data_ptr() == ptr
+    return t
+
+view(peer).copy_(view(src))
+torch.cuda.synchronize()
+peer.Commit()
+cx = uniform_poly(rng, q, N)
+want = oev.GadgetProduct(4, cx, oevk)
+
+def check(key):
+    ct = [la.Poly(gQ, 5), la.Poly(gQ, 5)]
+    gev.GadgetProduct(4, la.Poly(gQ, 5).upload(cx), key, ct)
+    assert np.array_equal(np.stack([c.get() for c in ct]), want)
+
+check(src); check(peer)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29541")
+cp = ControlPlane(init_single=True)       # a one-rank group drives the same broadcast call the multi-GPU path uses
+for transport in ("rccl", "host"):
+    check(cp.ReplicateEvaluationKey(gev, src, src=0, transport=transport))
+cp.close()
+print("DEVICE_BUFFER_OK")
+"""
+
+
+def _run_worker(tmp_path, text, nproc, port):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(text % root)
+    cmd = [sys.executable, str(script)] if nproc == 1 else [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+        "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    return out.stdout
+
+
+def test_key_replication_device_buffer(tmp_path):
+    """SURVEY.md section 8e key replication: an empty key of the same shape, filled device-side through
+    he_evk_device_buffer (the target of the RCCL broadcast) and committed, gives the same gadget product; a one-rank
+    process group then drives ReplicateEvaluationKey over both transports.  In a process of its own: torch's HIP runtime
+    has to be the one libhering binds to."""
+    assert "DEVICE_BUFFER_OK" in _run_worker(tmp_path, _DEVICE_BUFFER_WORKER, 1, 0)
+
+
+_REPLICA_WORKER = """
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+import lattigo_amd as la
+from lattigo_amd.dist import ControlPlane
+from oracle import oracle as O
+from tests.helpers import rng_for, uniform_poly
+from tests.rlwe_fixtures import SecretKey, gen_evaluation_key
+cp = ControlPlane()
+assert cp.world == 2
+ctx = la.Context(0)                      # both ranks on the one GPU of the test box
+q, p = O.GenModuli(11, [55, 45, 45], [46])
+N = 1 << 10
+gQ, gP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+gev = la.Evaluator(gQ, gP)
+key = None
+rng = rng_for(2960)
+cx = uniform_poly(rng, q, N)
+if cp.rank == 0:                         # only rank 0 ever holds the key material on the host
+    oQ, oP = O.Ring(N, q), O.Ring(N, p)
+    key = gev.NewEvaluationKey(*(lambda k: (k.q, k.p))(gen_evaluation_key(rng, oQ, oP, SecretKey(rng, oQ, oP).Q, SecretKey(rng, oQ, oP))))
+key = cp.ReplicateEvaluationKey(gev, key, src=0, transport="host")
+ct = [la.Poly(gQ, 3), la.Poly(gQ, 3)]
+gev.GadgetProduct(2, la.Poly(gQ, 3).upload(cx), key, ct)
+digest = int(hashlib.sha256(np.stack([c.get() for c in ct]).tobytes()).hexdigest()[:12], 16)
+assert cp.max_over_ranks(digest) == digest == -cp.max_over_ranks(-digest)
+if cp.rank == 0:
+    print("REPLICATED", digest)
+cp.close()
+"""
+
+
+def test_key_replication_two_ranks_host_transport(tmp_path):
+    """Two processes (sharing the box's one GPU): rank 1 receives the key from rank 0 and computes the same gadget product."""
+    assert "REPLICATED" in _run_worker(tmp_path, _REPLICA_WORKER, 2, 29543)
