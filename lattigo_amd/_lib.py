@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libhering.so")
+_SO = os.environ.get("HERING_LIB") or os.path.join(_HERE, "libhering.so")  # HERING_LIB: A/B-test another build
 _HDR = os.path.join(os.path.dirname(_HERE), "include", "hering.h")
 
 H = C.c_uint64

@@ -322,15 +322,24 @@ __device__ __forceinline__ double modmul_f64(double a, double w, double q, doubl
     const double c = rint(h * qi);
     return __fma_rn(-c, q, h) + l;
 }
+// exact conversions of integers in [0, 2^52) through the 2^52 exponent trick: two VALU ops each, against four (u64 -> f64) and
+// six (f64 -> u64) for the generic sequences.  Every residue on the double-precision paths is below 2^48.
+__device__ __forceinline__ double u52_to_f64(uint64_t x) {
+    return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 0x1p52;
+}
+__device__ __forceinline__ uint64_t f64_to_u52(double x) {  // x a non-negative integer
+    return (uint64_t)__double_as_longlong(x + 0x1p52) & 0x000FFFFFFFFFFFFFull;
+}
 __device__ __forceinline__ double reduce_f64(double x, double q, double qi) {  // -> |x| < q
     return __fma_rn(-rint(x * qi), q, x);
 }
-__device__ __forceinline__ uint64_t canon_f64(double x, double q, double qi) {  // any |x| < 2^53 -> [0, q)
+__device__ __forceinline__ double canon_f64d(double x, double q, double qi) {  // any |x| < 2^53 -> [0, q), still a double
     double t = __fma_rn(-floor(x * qi), q, x);
     t = t < 0.0 ? t + q : t;
     t = t >= q ? t - q : t;
-    return (uint64_t)t;
+    return t;
 }
+__device__ __forceinline__ uint64_t canon_f64(double x, double q, double qi) { return f64_to_u52(canon_f64d(x, q, qi)); }
 
 template <int G4, bool INV>
 __device__ __forceinline__ void rows_round_f64(double (&x)[16], const double *__restrict__ tw, int rowtw, int s0, int hi0, int tau,
@@ -415,7 +424,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
         for (int k = 0; k < 16; k++) {
             uint64_t v = src[(k << sh0) + tau];
             if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
-            x[k] = (double)v;
+            x[k] = u52_to_f64(v);
         }
 #pragma unroll 1
         for (int rho = 0; rho < NR4; rho++) {
@@ -446,7 +455,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int e = k * T + tau;
-                const double d = lds[lds_phys(e)] - (A.epi_y_f64 ? reinterpret_cast<const double *>(yp)[e] : (double)yp[e]);
+                const double d = lds[lds_phys(e)] - (A.epi_y_f64 ? reinterpret_cast<const double *>(yp)[e] : u52_to_f64(yp[e]));
                 uint64_t v = canon_f64(modmul_f64(d, sp, q, qi), q, qi);
                 if (addw) v = cred(wp[e] + v, mc.q);
                 op[e] = v;
@@ -464,7 +473,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             const int e = k * T + tau;
             uint64_t v = src[e];
             if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
-            lds[lds_phys(e)] = (double)v;
+            lds[lds_phys(e)] = u52_to_f64(v);
         }
         __syncthreads();
         if constexpr (GREM > 0) {
@@ -544,12 +553,12 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
         if (is_own) {  // block-uniform: the digit's own limb is the NTT-domain input itself
             const uint64_t *src = A.own + bz * A.own_bs + (size_t)ql * A.N + rowoff;
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = (double)src[k * T + tau];
+            for (int k = 0; k < 16; k++) x[k] = u52_to_f64(src[k * T + tau]);
         } else {
             const uint64_t *src = A.dec + bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)A.m.dec_limb[l] * A.N + rowoff;
             constexpr int sh0 = LOGB - 4;
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = (double)src[(k << sh0) + tau];
+            for (int k = 0; k < 16; k++) x[k] = u52_to_f64(src[(k << sh0) + tau]);
 #pragma unroll 1
             for (int rho = 0; rho < NR4; rho++) {
                 const int s0 = 4 * rho, sh = LOGB - s0 - 4;
@@ -1265,12 +1274,13 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
 #pragma unroll
         for (int r = 0; r < R; r++) x[r] = src[(size_t)D.src_limb[i] * A.N + (size_t)r * N2];
         const bool src_small = DSTF64 && (q >> kF64Bits) == 0 && A.twd_inv != nullptr;  // block-uniform
+        double xc[R];  // src_small: the canonical coefficients as doubles
         if (src_small) {
             // source modulus below 2^47: the inverse column stages, N^-1 and y_i = x*c_i in exact double arithmetic
             const double qd = (double)q, qid = 1.0 / qd;
             double xd[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) xd[r] = (double)x[r];
+            for (int r = 0; r < R; r++) xd[r] = u52_to_f64(x[r]);
             if constexpr (LOGA > 0) {
                 const double *tw = A.twd_inv + (size_t)mi * A.N;
 #pragma unroll
@@ -1289,7 +1299,10 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                 for (int r = 0; r < R; r++) xd[r] = modmul_f64(xd[r], ninv, qd, qid);
             }
 #pragma unroll
-            for (int r = 0; r < R; r++) x[r] = canon_f64(xd[r], qd, qid);
+            for (int r = 0; r < R; r++) {
+                xc[r] = canon_f64d(xd[r], qd, qid);
+                x[r] = f64_to_u52(xc[r]);
+            }
         } else if constexpr (LOGA > 0) {  // finish the inverse NTT: the LOGA strided stages, N^-1 folded into the last
             const uint64_t *tw = A.tw_inv + (size_t)mi * A.N;
 #pragma unroll
@@ -1320,20 +1333,35 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
             const double rq = 1.0 / qf;
             const bool split = D.src_split[i] != 0;
             const double qd = (double)q, qid = 1.0 / qd, apl = src_small ? (double)imform(ai, q, qinv) : 0.0;
+            const double hq = src_small ? (double)h : 0.0;
+            uint64_t yi[R];
+            double yd[R];
+            if (src_small) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    double t = xc[r] + hq;  // CRed(x + h)
+                    t = t >= qd ? t - qd : t;
+                    yd[r] = canon_f64d(modmul_f64(t, apl, qd, qid), qd, qid);
+                    yi[r] = f64_to_u52(yd[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    yi[r] = mred(cred(x[r] + h, q), ai, q, qinv);
+                    yd[r] = __ull2double_rn(yi[r]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                uint64_t yi;
-                if (src_small) yi = canon_f64(modmul_f64((double)cred(x[r] + h, q), apl, qd, qid), qd, qid);
-                else yi = mred(cred(x[r] + h, q), ai, q, qinv);
                 // fast estimate of fl(y/q); the exact IEEE division is redone below only when the sum lands within
                 // 2^-40 of an integer (|estimate - exact sum| < 2^-42 for <= 32 terms)
-                vi[r] = __dadd_rn(vi[r], __ull2double_rn(yi) * rq);
+                vi[r] = __dadd_rn(vi[r], yd[r] * rq);
                 if constexpr (DSTF64) {
-                    ylds[i * R + r][threadIdx.x] = yi;
-                    yl[r][i] = (double)(split ? (yi & ((1ull << 26) - 1)) : yi);
-                    yh[r][i] = (double)(split ? (yi >> 26) : 0ull);
+                    ylds[i * R + r][threadIdx.x] = yi[r];
+                    yl[r][i] = split ? u52_to_f64(yi[r] & ((1ull << 26) - 1)) : yd[r];
+                    yh[r][i] = split ? u52_to_f64(yi[r] >> 26) : 0.0;
                 } else {
-                    y[r][i] = yi;
+                    y[r][i] = yi[r];
                 }
             }
         }
@@ -1357,7 +1385,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
     }
     uint32_t v[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) v[r] = (uint32_t)(uint64_t)vi[r];
+    for (int r = 0; r < R; r++) v[r] = (uint32_t)vi[r];  // 0 <= vi < 33: one v_cvt_u32_f64 (truncating)
 
     for (int j = 0; j < D.ndst; j++) {
         const int mi = D.dst_mod[j];
@@ -1380,7 +1408,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const uint64_t t = bred_add(ylds[r][threadIdx.x], p, mp.brc0);
-                    o[r] = (double)(((negmask >> r) & 1) ? p - t : t);
+                    o[r] = u52_to_f64(((negmask >> r) & 1) ? p - t : t);
                 }
             } else {
                 const int row = D.dst_row[j];
@@ -1417,7 +1445,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < R; r++) dst[(size_t)r * N2] = (uint64_t)(reduce_f64(o[r], pd, pid) + pd);  // (0, 2p)
+            for (int r = 0; r < R; r++) dst[(size_t)r * N2] = f64_to_u52(reduce_f64(o[r], pd, pid) + pd);  // (0, 2p)
         }
         if (!done) {
             uint64_t o[R];
