@@ -1251,8 +1251,31 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
     constexpr int R = 1 << LOGA;
     const int N2 = A.N >> LOGA;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // the digit's descriptor goes to LDS first: read from global memory, its byte fields cost a vector load and a full wait at
+    // every use (the compiler cannot move them across the destination stores), 24 of them per destination limb
+    __shared__ ModUpDesc Ds;
+    {
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(A.desc + blockIdx.y);
+        uint32_t *l = reinterpret_cast<uint32_t *>(&Ds);
+        for (int w = threadIdx.x; w < (int)(sizeof(ModUpDesc) / 4); w += blockDim.x) l[w] = g[w];
+    }
+    __syncthreads();
     if (c >= N2) return;
-    const ModUpDesc &D = A.desc[blockIdx.y];
+    const ModUpDesc &D = Ds;
+    auto U = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // block-uniform -> SGPR
+    auto U64 = [&](uint64_t v) -> uint64_t { return ((uint64_t)U((uint32_t)(v >> 32)) << 32) | U((uint32_t)v); };
+    const bool single = U(D.single) != 0, reduce_out = U(D.reduce_out) != 0;
+    const int ndst = (int)U(D.ndst);
+    const uint64_t *Da = reinterpret_cast<const uint64_t *>(U64((uint64_t)D.a));
+    const uint64_t *DT = reinterpret_cast<const uint64_t *>(U64((uint64_t)D.T));
+    const uint64_t *Dvt = reinterpret_cast<const uint64_t *>(U64((uint64_t)D.vt));
+    const double *DTd = reinterpret_cast<const double *>(U64((uint64_t)D.Td));
+    const double *Dvtd = reinterpret_cast<const double *>(U64((uint64_t)D.vtd));
+    const size_t dst_off = U64(D.dst_off);
+    uint32_t splitmask = 0;  // bit i: source residue i is split into 26-bit halves
+#pragma unroll
+    for (int i = 0; i < NSRC; i++) splitmask |= (D.src_split[i] != 0 ? 1u : 0u) << i;
+    splitmask = single ? 0u : U(splitmask);
     const size_t bz = blockIdx.z;
     const uint64_t *src = A.src + bz * A.src_bs + c;
 
@@ -1267,18 +1290,18 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
     for (int r = 0; r < R; r++) vi[r] = 0.0;
 #pragma unroll
     for (int i = 0; i < NSRC; i++) {
-        const int mi = D.src_mod[i];
+        const int mi = (int)U(D.src_mod[i]);
         const ModConst mq = A.mc[mi];
         const uint64_t q = mq.q, qinv = mq.qinv, twoq = mq.q << 1;
         uint64_t x[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) x[r] = src[(size_t)D.src_limb[i] * A.N + (size_t)r * N2];
+        for (int r = 0; r < R; r++) x[r] = src[(size_t)U(D.src_limb[i]) * A.N + (size_t)r * N2];
         const bool src_small = DSTF64 && (q >> kF64Bits) == 0 && A.twd_inv != nullptr;  // block-uniform
-        double xc[R];  // src_small: the canonical coefficients as doubles
+        double xd[R];  // src_small: the coefficients as doubles, not yet scaled by N^-1 (LOGA > 0) nor reduced (|xd| < 16q)
+        const double ninv = (src_small && LOGA > 0) ? (double)imform(mq.ninv, q, qinv) : 1.0;
         if (src_small) {
             // source modulus below 2^47: the inverse column stages, N^-1 and y_i = x*c_i in exact double arithmetic
             const double qd = (double)q, qid = 1.0 / qd;
-            double xd[R];
 #pragma unroll
             for (int r = 0; r < R; r++) xd[r] = u52_to_f64(x[r]);
             if constexpr (LOGA > 0) {
@@ -1294,14 +1317,10 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                         xd[r + d] = modmul_f64(U - V, tw[(1 << s) + (r >> (LOGA - s))], qd, qid);
                     }
                 }
-                const double ninv = (double)imform(mq.ninv, q, qinv);
-#pragma unroll
-                for (int r = 0; r < R; r++) xd[r] = modmul_f64(xd[r], ninv, qd, qid);
             }
+            if (single) {  // the centred value needs the canonical coefficient itself
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                xc[r] = canon_f64d(xd[r], qd, qid);
-                x[r] = f64_to_u52(xc[r]);
+                for (int r = 0; r < R; r++) x[r] = canon_f64(LOGA > 0 ? modmul_f64(xd[r], ninv, qd, qid) : xd[r], qd, qid);
             }
         } else if constexpr (LOGA > 0) {  // finish the inverse NTT: the LOGA strided stages, N^-1 folded into the last
             const uint64_t *tw = A.tw_inv + (size_t)mi * A.N;
@@ -1317,7 +1336,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                 }
             }
         }
-        if (D.single) {  // one-limb digit: centred value (ring/basis_extension.go:402-436)
+        if (single) {  // one-limb digit: centred value (ring/basis_extension.go:402-436)
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 uint64_t cv = x[r];
@@ -1328,20 +1347,20 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                 else y[r][i] = cv;
             }
         } else {
-            const uint64_t h = D.src_half[i], ai = D.a[i];
+            const uint64_t h = U64(D.src_half[i]), ai = Da[i];
             const double qf = __ull2double_rn(q);
             const double rq = 1.0 / qf;
-            const bool split = D.src_split[i] != 0;
+            const bool split = (splitmask >> i) & 1;
             const double qd = (double)q, qid = 1.0 / qd, apl = src_small ? (double)imform(ai, q, qinv) : 0.0;
-            const double hq = src_small ? (double)h : 0.0;
             uint64_t yi[R];
             double yd[R];
             if (src_small) {
+                // y = (x N^-1 + h) a = x (N^-1 a) + h a: one product per coefficient, the two block-uniform constants once
+                const double c1 = LOGA > 0 ? canon_f64d(modmul_f64(ninv, apl, qd, qid), qd, qid) : apl;
+                const double c2 = canon_f64d(modmul_f64((double)h, apl, qd, qid), qd, qid);
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    double t = xc[r] + hq;  // CRed(x + h)
-                    t = t >= qd ? t - qd : t;
-                    yd[r] = canon_f64d(modmul_f64(t, apl, qd, qid), qd, qid);
+                    yd[r] = canon_f64d(modmul_f64(xd[r], c1, qd, qid) + c2, qd, qid);
                     yi[r] = f64_to_u52(yd[r]);
                 }
             } else {
@@ -1366,7 +1385,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
             }
         }
     }
-    if (!D.single) {  // exact v = trunc(sum_i fl(fl(y_i)/fl(q_i))) where the estimate is not conclusive (rare)
+    if (!single) {  // exact v = trunc(sum_i fl(fl(y_i)/fl(q_i))) where the estimate is not conclusive (rare)
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const double fr = vi[r] - floor(vi[r]);
@@ -1377,7 +1396,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                     uint64_t yi;
                     if constexpr (DSTF64) yi = ylds[i * R + r][threadIdx.x];
                     else yi = y[r][i];
-                    e = __dadd_rn(e, __ddiv_rn(__ull2double_rn(yi), __ull2double_rn(A.mc[D.src_mod[i]].q)));
+                    e = __dadd_rn(e, __ddiv_rn(__ull2double_rn(yi), __ull2double_rn(A.mc[U(D.src_mod[i])].q)));
                 }
                 vi[r] = e;
             }
@@ -1387,13 +1406,13 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
 #pragma unroll
     for (int r = 0; r < R; r++) v[r] = (uint32_t)vi[r];  // 0 <= vi < 33: one v_cvt_u32_f64 (truncating)
 
-    for (int j = 0; j < D.ndst; j++) {
-        const int mi = D.dst_mod[j];
+    for (int j = 0; j < ndst; j++) {
+        const int mi = (int)U(D.dst_mod[j]);
         const ModConst mp = A.mc[mi];
         const uint64_t p = mp.q, pinv = mp.qinv, twop = mp.q << 1;
         const bool small = (p >> kF64Bits) == 0;  // block-uniform
-        uint64_t *dst = (D.dst_view[j] ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs)) + D.dst_off +
-                        (size_t)D.dst_limb[j] * A.N + c;
+        uint64_t *dst = (U(D.dst_view[j]) ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs)) + dst_off +
+                        (size_t)U(D.dst_limb[j]) * A.N + c;
         // residue y_i of coefficient r as an integer (the mixed variant keeps them as doubles)
         auto Y = [&](int r, int i) -> uint64_t {
             if constexpr (DSTF64) return ylds[i * R + r][threadIdx.x];
@@ -1404,27 +1423,33 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
             done = true;
             const double pd = (double)p, pid = 1.0 / pd;
             double o[R];
-            if (D.single) {
+            if (single) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const uint64_t t = bred_add(ylds[r][threadIdx.x], p, mp.brc0);
                     o[r] = u52_to_f64(((negmask >> r) & 1) ? p - t : t);
                 }
             } else {
-                const int row = D.dst_row[j];
-                const double *Tr = D.Td + (size_t)row * NSRC * 2;
-                const double *vtr = D.vtd + (size_t)row * (NSRC + 1);
-                const double hd = (double)D.dst_half[j];
-                double Tl[NSRC], Th[NSRC];
+                const int row = (int)U(D.dst_row[j]);
+                const double *Tr = DTd + (size_t)row * NSRC * 2;
+                const double *vtr = Dvtd + (size_t)row * (NSRC + 1);
+                const double hd = (double)U64(D.dst_half[j]);
+                double Tl[NSRC], Th[NSRC], vts[NSRC + 1];
 #pragma unroll
                 for (int i = 0; i < NSRC; i++) { Tl[i] = Tr[2 * i]; Th[i] = Tr[2 * i + 1]; }
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    double sacc = vtr[v[r]] - hd;
+                for (int i = 0; i <= NSRC; i++) vts[i] = vtr[i] - hd;  // uniform: the v-correction picked by selects, not a load
 #pragma unroll
-                    for (int i = 0; i < NSRC; i++) {
-                        sacc += modmul_f64(yl[r][i], Tl[i], pd, pid);
-                        if (D.src_split[i]) sacc += modmul_f64(yh[r][i], Th[i], pd, pid);
+                for (int r = 0; r < R; r++) {
+                    double sacc = vts[0];
+#pragma unroll
+                    for (int i = 1; i <= NSRC; i++) sacc = v[r] == (uint32_t)i ? vts[i] : sacc;
+#pragma unroll
+                    for (int i = 0; i < NSRC; i++) sacc += modmul_f64(yl[r][i], Tl[i], pd, pid);
+                    if (splitmask) {
+#pragma unroll
+                        for (int i = 0; i < NSRC; i++)
+                            if ((splitmask >> i) & 1) sacc += modmul_f64(yh[r][i], Th[i], pd, pid);
                     }
                     o[r] = sacc;  // |o| < (2 + 4*NSRC) p
                 }
@@ -1449,17 +1474,17 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
         }
         if (!done) {
             uint64_t o[R];
-            if (D.single) {
+            if (single) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const uint64_t t = bred_add(Y(r, 0), p, mp.brc0);
                     o[r] = ((negmask >> r) & 1) ? p - t : t;
                 }
             } else {
-                const int row = D.dst_row[j];
-                const uint64_t *Tr = D.T + (size_t)row * NSRC;
-                const uint64_t *vtr = D.vt + (size_t)row * (NSRC + 1);
-                const uint64_t hd = D.dst_half[j];
+                const int row = (int)U(D.dst_row[j]);
+                const uint64_t *Tr = DT + (size_t)row * NSRC;
+                const uint64_t *vtr = Dvt + (size_t)row * (NSRC + 1);
+                const uint64_t hd = U64(D.dst_half[j]);
                 uint64_t Tv[NSRC];
 #pragma unroll
                 for (int i = 0; i < NSRC; i++) Tv[i] = Tr[i];
@@ -1470,7 +1495,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                     for (int i = 1; i < NSRC; i++) acc += (u128)Y(r, i) * Tv[i];
                     uint64_t res = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p + vtr[v[r]];
                     res = cred(res + p - hd, p);
-                    if (D.reduce_out) res = bred_add_lazy(res, p, mp.brc0);
+                    if (reduce_out) res = bred_add_lazy(res, p, mp.brc0);
                     o[r] = res;
                 }
             }
