@@ -1403,8 +1403,12 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
         }
     }
     uint32_t v[R];
+    double vd[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) v[r] = (uint32_t)vi[r];  // 0 <= vi < 33: one v_cvt_u32_f64 (truncating)
+    for (int r = 0; r < R; r++) {
+        v[r] = (uint32_t)vi[r];  // 0 <= vi < 33: one v_cvt_u32_f64 (truncating)
+        vd[r] = floor(vi[r]);
+    }
 
     for (int j = 0; j < ndst; j++) {
         const int mi = (int)U(D.dst_mod[j]);
@@ -1434,16 +1438,13 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                 const double *Tr = DTd + (size_t)row * NSRC * 2;
                 const double *vtr = Dvtd + (size_t)row * (NSRC + 1);
                 const double hd = (double)U64(D.dst_half[j]);
-                double Tl[NSRC], Th[NSRC], vts[NSRC + 1];
+                double Tl[NSRC], Th[NSRC];
 #pragma unroll
                 for (int i = 0; i < NSRC; i++) { Tl[i] = Tr[2 * i]; Th[i] = Tr[2 * i + 1]; }
-#pragma unroll
-                for (int i = 0; i <= NSRC; i++) vts[i] = vtr[i] - hd;  // uniform: the v-correction picked by selects, not a load
+                const double vt1 = vtr[1];  // vt[v] = v * vt[1] mod p: the v-correction is one exact fma (v <= NSRC, v * vt1 < 2^50)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    double sacc = vts[0];
-#pragma unroll
-                    for (int i = 1; i <= NSRC; i++) sacc = v[r] == (uint32_t)i ? vts[i] : sacc;
+                    double sacc = __fma_rn(vd[r], vt1, -hd);
 #pragma unroll
                     for (int i = 0; i < NSRC; i++) sacc += modmul_f64(yl[r][i], Tl[i], pd, pid);
                     if (splitmask) {
@@ -1451,7 +1452,7 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                         for (int i = 0; i < NSRC; i++)
                             if ((splitmask >> i) & 1) sacc += modmul_f64(yh[r][i], Th[i], pd, pid);
                     }
-                    o[r] = sacc;  // |o| < (2 + 4*NSRC) p
+                    o[r] = sacc;  // |o| < (2 + 5*NSRC) p
                 }
             }
             if constexpr (LOGA > 0) {
