@@ -523,7 +523,7 @@ struct NttMacKArgs {
 };
 // QF64: every limb of the launch is a Q limb whose accumulators are written as doubles (NttMacArgs::q_out_f64)
 template <int LOGB, bool QF64>
-__global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) ntt_mac_f64_kernel(NttMacKArgs A) {
+__global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2) ntt_mac_f64_kernel(NttMacKArgs A) {
     constexpr int N2 = 1 << LOGB;
     constexpr int T = N2 / 16;
     constexpr int NR4 = LOGB / 4;
@@ -547,18 +547,32 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
     for (int k = 0; k < 16; k++) { acc0[k] = 0.0; acc1[k] = 0.0; }
 
+    // the digit's own limb is the NTT-domain input itself (block-uniform); element k of a thread is word k*T + tau either way
+    auto own_digit = [&](int d) -> bool {
+        return A.m.own_alpha > 0 && A.m.out_view[l] == 0 && ql >= d * A.m.own_alpha && ql < (d + 1) * A.m.own_alpha;
+    };
+    auto digit_src = [&](int d) -> const uint64_t * {
+        return own_digit(d) ? A.own + bz * A.own_bs + (size_t)ql * A.N + rowoff
+                            : A.dec + bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)A.m.dec_limb[l] * A.N + rowoff;
+    };
+    // software pipeline over the digits: the words of digit d + 1 are in flight while digit d is transformed and accumulated
+    uint64_t nx[16];
+    {
+        const uint64_t *src = digit_src(0);
+#pragma unroll
+        for (int k = 0; k < 16; k++) nx[k] = src[k * T + tau];
+    }
     for (int d = 0; d < A.m.beta; d++) {
-        const bool is_own = A.m.own_alpha > 0 && A.m.out_view[l] == 0 && ql >= d * A.m.own_alpha && ql < (d + 1) * A.m.own_alpha;
+        const bool is_own = own_digit(d);
         double x[16];
-        if (is_own) {  // block-uniform: the digit's own limb is the NTT-domain input itself
-            const uint64_t *src = A.own + bz * A.own_bs + (size_t)ql * A.N + rowoff;
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = u52_to_f64(src[k * T + tau]);
-        } else {
-            const uint64_t *src = A.dec + bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)A.m.dec_limb[l] * A.N + rowoff;
-            constexpr int sh0 = LOGB - 4;
+        for (int k = 0; k < 16; k++) x[k] = u52_to_f64(nx[k]);
+        if (d + 1 < A.m.beta) {
+            const uint64_t *src = digit_src(d + 1);
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = u52_to_f64(src[(k << sh0) + tau]);
+            for (int k = 0; k < 16; k++) nx[k] = src[k * T + tau];
+        }
+        if (!is_own) {
 #pragma unroll 1
             for (int rho = 0; rho < NR4; rho++) {
                 const int s0 = 4 * rho, sh = LOGB - s0 - 4;
