@@ -15,6 +15,7 @@
 // outputs are promised (SURVEY.md section 8a note on lazy ranges).
 #include "kernels.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace he {
@@ -127,6 +128,7 @@ struct NttArgs {
     const uint64_t *epi_y2, *epi_w2;
     size_t epi_y2_bs, epi_w2_bs;
     int epi_y_f64;  // f64 kernel only: y holds doubles
+    int nbatch, iters;  // f64 kernel only: a workgroup transforms batch entries blockIdx.x * iters ... (+ iters - 1) of its row
 };
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
@@ -407,19 +409,32 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 
     const int tau = threadIdx.x;
     const int row = blockIdx.z;
-    const unsigned bzi = blockIdx.x;
     const int y = blockIdx.y;
     const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
     const ModConst mc = A.mc[mi];
     const double q = (double)mc.q, qi = 1.0 / q;
     const double *__restrict__ tw = A.twd + (size_t)mi * A.N;
-    const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
-    uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
     const int rowtw = (1 << A.a) + row;
+    const size_t in_off = (size_t)il * A.N + (size_t)row * N2;
 
+    // inverse: software pipeline over the workgroup's batch entries, the words of entry b + 1 are in flight while entry b is
+    // transformed (-12 %).  The forward kernel keeps one entry per workgroup: with the 32 extra registers it drops from four
+    // to two waves per SIMD and runs 1.5x slower.
+    const unsigned b0 = blockIdx.x * (unsigned)A.iters;
+    constexpr bool PIPE = INV && LOGB <= 12;  // 512-thread rows (LOGB = 13) would fall to one workgroup per CU
+    const unsigned b1 = PIPE ? min(b0 + (unsigned)A.iters, (unsigned)A.nbatch) : b0 + 1;  // otherwise iters == 1
+    uint64_t nx[16];
+    if constexpr (INV) {
+        const uint64_t *src0 = A.in + (size_t)b0 * A.in_bs + in_off;
+#pragma unroll
+        for (int k = 0; k < 16; k++) nx[k] = src0[k * T + tau];
+    }
+    for (unsigned bzi = b0; bzi < b1; bzi++) {
+    uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
     double x[16];
     if constexpr (!INV) {
         constexpr int sh0 = LOGB - 4;
+        const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + in_off;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint64_t v = src[(k << sh0) + tau];
@@ -471,9 +486,14 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int e = k * T + tau;
-            uint64_t v = src[e];
+            uint64_t v = nx[k];
             if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
             lds[lds_phys(e)] = u52_to_f64(v);
+        }
+        if constexpr (PIPE) if (bzi + 1 < b1) {
+            const uint64_t *srcn = A.in + (size_t)(bzi + 1) * A.in_bs + in_off;
+#pragma unroll
+            for (int k = 0; k < 16; k++) nx[k] = srcn[k * T + tau];
         }
         __syncthreads();
         if constexpr (GREM > 0) {
@@ -504,6 +524,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = canon_f64(x[k], q, qi);
+    }
+    if (bzi + 1 < b1) __syncthreads();  // LDS is reused by the next entry
     }
 }
 
@@ -778,7 +800,16 @@ static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, const uint8
         D.tab.n++;
     }
     hipError_t e = hipSuccess;
-    if (P[2].tab.n) { dim3 g2(grid.x, P[2].tab.n, grid.z); e = launch_rows_f64<INV>(logb, g2, P[2], s); }
+    if (P[2].tab.n) {
+        // entries per workgroup (inverse only): 2 while the launch still has well over the ~1500 workgroups that fill the chip
+        static const int forced = getenv("HERING_ROWS_ITERS") ? atoi(getenv("HERING_ROWS_ITERS")) : 0;
+        const size_t wgs = (size_t)grid.x * P[2].tab.n * grid.z;
+        int iters = (!INV || logb > 12) ? 1 : forced > 0 ? forced : (wgs >= 6144 ? 2 : 1);
+        if (iters > (int)grid.x) iters = (int)grid.x;
+        P[2].nbatch = (int)grid.x; P[2].iters = iters;
+        dim3 g2((grid.x + iters - 1) / iters, P[2].tab.n, grid.z);
+        e = launch_rows_f64<INV>(logb, g2, P[2], s);
+    }
     if (e == hipSuccess && P[1].tab.n) { dim3 g2(grid.x, P[1].tab.n, grid.z); e = launch_rows_nc<INV, true>(logb, g2, P[1], s); }
     if (e == hipSuccess && P[0].tab.n) { dim3 g2(grid.x, P[0].tab.n, grid.z); e = launch_rows_nc<INV, false>(logb, g2, P[0], s); }
     return e;
