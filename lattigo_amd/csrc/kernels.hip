@@ -255,21 +255,44 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             __syncthreads();
         }
         const bool lazy = (A.flags & NTT_LAZY_OUT) != 0;
+        auto settle = [&](uint64_t v) -> uint64_t {
+            if constexpr (NC) return bred_add_lazy(v, q, mc.brc0);  // [0, 36q) -> [0, 2q)
+            else return v >= twoq ? v - twoq : v;
+        };
+        if (A.epi) {
+            // out = [w +] MRed(x + 2q - y, s); the sixteen y (then w) loads are issued together, not one wait per element
+            const bool second = A.zsplit && (int)bzi >= A.zsplit;
+            const size_t zz = second ? bzi - A.zsplit : bzi;
+            const size_t off = (size_t)ol * A.N + (size_t)row * N2;
+            const uint64_t *yp = (second ? A.epi_y2 + zz * A.epi_y2_bs : A.epi_y + zz * A.epi_y_bs) + off;
+            const uint64_t *wp = (second ? A.epi_w2 + zz * A.epi_w2_bs : A.epi_w + zz * A.epi_w_bs) + off;
+            uint64_t *op = (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs) + off;
+            const bool addw = (second ? A.epi2 : A.epi) == 2;
+            const uint64_t sy = A.epi_s[y];
+            uint64_t yv[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int e = k * T + tau;
-            uint64_t v = lds[lds_phys(e)];
-            if constexpr (NC) v = bred_add_lazy(v, q, mc.brc0);  // [0, 36q) -> [0, 2q)
-            else v = v >= twoq ? v - twoq : v;
-            if (A.epi) {
-                const bool second = A.zsplit && (int)bzi >= A.zsplit;
-                const size_t zz = second ? bzi - A.zsplit : bzi;
-                const size_t off = (size_t)ol * A.N + (size_t)row * N2 + e;
-                const uint64_t yv = second ? A.epi_y2[zz * A.epi_y2_bs + off] : A.epi_y[zz * A.epi_y_bs + off];
-                v = mred(v + twoq - yv, A.epi_s[y], q, qinv);
-                if ((second ? A.epi2 : A.epi) == 2) v = cred((second ? A.epi_w2[zz * A.epi_w2_bs + off] : A.epi_w[zz * A.epi_w_bs + off]) + v, q);
-                (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs)[off] = v;
+            for (int k = 0; k < 16; k++) yv[k] = yp[k * T + tau];
+            if (addw) {
+                uint64_t wv[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) wv[k] = wp[k * T + tau];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int e = k * T + tau;
+                    op[e] = cred(wv[k] + mred(settle(lds[lds_phys(e)]) + twoq - yv[k], sy, q, qinv), q);
+                }
             } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int e = k * T + tau;
+                    op[e] = mred(settle(lds[lds_phys(e)]) + twoq - yv[k], sy, q, qinv);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int e = k * T + tau;
+                uint64_t v = settle(lds[lds_phys(e)]);
                 if (!lazy) v = v >= q ? v - q : v;
                 dst[e] = v;
             }
@@ -467,13 +490,32 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             uint64_t *op = (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs) + (size_t)ol * A.N + (size_t)row * N2;
             const bool addw = (second ? A.epi2 : A.epi) == 2;
             const double sp = (double)imform(A.epi_s[y], mc.q, mc.qinv);
+            // all sixteen y (then w) loads are issued before the first use: with the format / addend tests inside the
+            // element loop every load was followed by its own full wait (32 serialised HBM latencies per thread)
+            double yv[16];
+            if (A.epi_y_f64) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int e = k * T + tau;
-                const double d = lds[lds_phys(e)] - (A.epi_y_f64 ? reinterpret_cast<const double *>(yp)[e] : u52_to_f64(yp[e]));
-                uint64_t v = canon_f64(modmul_f64(d, sp, q, qi), q, qi);
-                if (addw) v = cred(wp[e] + v, mc.q);
-                op[e] = v;
+                for (int k = 0; k < 16; k++) yv[k] = reinterpret_cast<const double *>(yp)[k * T + tau];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) yv[k] = u52_to_f64(yp[k * T + tau]);
+            }
+            if (addw) {
+                uint64_t wv[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) wv[k] = wp[k * T + tau];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int e = k * T + tau;
+                    const uint64_t v = canon_f64(modmul_f64(lds[lds_phys(e)] - yv[k], sp, q, qi), q, qi);
+                    op[e] = cred(wv[k] + v, mc.q);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int e = k * T + tau;
+                    op[e] = canon_f64(modmul_f64(lds[lds_phys(e)] - yv[k], sp, q, qi), q, qi);
+                }
             }
         } else {
 #pragma unroll
