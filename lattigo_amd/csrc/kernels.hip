@@ -1573,15 +1573,20 @@ __global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
                 const uint64_t *Tr = DT + (size_t)row * NSRC;
                 const uint64_t *vtr = Dvt + (size_t)row * (NSRC + 1);
                 const uint64_t hd = U64(D.dst_half[j]);
-                uint64_t Tv[NSRC];
+                uint64_t Tv[NSRC], vts[NSRC + 1];
 #pragma unroll
                 for (int i = 0; i < NSRC; i++) Tv[i] = Tr[i];
+#pragma unroll
+                for (int i = 0; i <= NSRC; i++) vts[i] = vtr[i];  // block-uniform: picked by selects below, not a dependent load per r
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     u128 acc = (u128)Y(r, 0) * Tv[0];
 #pragma unroll
                     for (int i = 1; i < NSRC; i++) acc += (u128)Y(r, i) * Tv[i];
-                    uint64_t res = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p + vtr[v[r]];
+                    uint64_t vsel = vts[0];
+#pragma unroll
+                    for (int i = 1; i <= NSRC; i++) vsel = v[r] == (uint32_t)i ? vts[i] : vsel;
+                    uint64_t res = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p + vsel;
                     res = cred(res + p - hd, p);
                     if (reduce_out) res = bred_add_lazy(res, p, mp.brc0);
                     o[r] = res;
@@ -1752,25 +1757,47 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
     const uint64_t *kp = A.key + (size_t)A.k.key_limb[l] * A.N + x;
     const uint64_t *dp = A.dec + (size_t)A.k.dec_limb[l] * A.N + x;
     const uint64_t *op = A.own + (size_t)A.k.dec_limb[l] * A.N + x;
+    // the digit's own Q limbs come from the NTT-domain input itself (block-uniform choice); entries past the batch re-read the
+    // block's first entry so that every load is unconditional, and digit d + 1 is in flight while digit d is accumulated
+    const int ql = A.k.dec_limb[l];  // Q-limb index for Q limbs
+    size_t boff_own[BB], boff_dec[BB];
+#pragma unroll
+    for (int b = 0; b < BB; b++) {
+        const size_t bb = (size_t)(b0 + b < A.batch ? b0 + b : b0);
+        boff_own[b] = bb * A.own_bs;
+        boff_dec[b] = bb * A.dec_bs;
+    }
+    auto is_own = [&](int d) -> bool {
+        return A.k.own_alpha > 0 && A.k.out_view[l] == 0 && ql >= d * A.k.own_alpha && ql < (d + 1) * A.k.own_alpha;
+    };
+    uint64_t cn[BB], kn0, kn1;
+    auto fetch = [&](int d) {
+        kn0 = kp[(size_t)d * A.k.key_dstride];
+        kn1 = kp[(size_t)d * A.k.key_dstride + A.k.key_kstride];
+        if (is_own(d)) {
+#pragma unroll
+            for (int b = 0; b < BB; b++) cn[b] = op[boff_own[b]];
+        } else {
+#pragma unroll
+            for (int b = 0; b < BB; b++) cn[b] = dp[boff_dec[b] + (size_t)d * A.k.dec_dstride];
+        }
+    };
+    fetch(0);
     for (int d = 0; d < A.k.beta; d++) {
-        const uint64_t k0 = kp[(size_t)d * A.k.key_dstride];
-        const uint64_t k1 = kp[(size_t)d * A.k.key_dstride + A.k.key_kstride];
-        // the digit's own Q limbs come from the NTT-domain input itself (block-uniform branch)
-        const int ql = A.k.dec_limb[l];  // Q-limb index for Q limbs
-        const bool is_own = A.k.own_alpha > 0 && A.k.out_view[l] == 0 && ql >= d * A.k.own_alpha && ql < (d + 1) * A.k.own_alpha;
+        const uint64_t k0 = kn0, k1 = kn1;
+        uint64_t c[BB];
+#pragma unroll
+        for (int b = 0; b < BB; b++) c[b] = cn[b];
+        if (d + 1 < A.k.beta) fetch(d + 1);
 #pragma unroll
         for (int b = 0; b < BB; b++) {
-            if (b0 + b < A.batch) {
-                const uint64_t c = is_own ? op[(size_t)(b0 + b) * A.own_bs]
-                                          : dp[(size_t)(b0 + b) * A.dec_bs + (size_t)d * A.k.dec_dstride];
-                uint64_t ph, pl;
-                mul64wide(c, k0, ph, pl);
-                lo0[b] += pl; hi0[b] += ph + (lo0[b] < pl);
-                hi0[b] = hi0[b] >= q ? hi0[b] - q : hi0[b];
-                mul64wide(c, k1, ph, pl);
-                lo1[b] += pl; hi1[b] += ph + (lo1[b] < pl);
-                hi1[b] = hi1[b] >= q ? hi1[b] - q : hi1[b];
-            }
+            uint64_t ph, pl;
+            mul64wide(c[b], k0, ph, pl);
+            lo0[b] += pl; hi0[b] += ph + (lo0[b] < pl);
+            hi0[b] = hi0[b] >= q ? hi0[b] - q : hi0[b];
+            mul64wide(c[b], k1, ph, pl);
+            lo1[b] += pl; hi1[b] += ph + (lo1[b] < pl);
+            hi1[b] = hi1[b] >= q ? hi1[b] - q : hi1[b];
         }
     }
     const int ol = A.k.out_limb[l];
