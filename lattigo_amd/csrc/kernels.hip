@@ -1333,8 +1333,11 @@ struct ModUpFusedArgs {
 // DSTF64 = false: destinations in 64-bit integer arithmetic (any modulus).
 // DSTF64 = true : only destination moduli below 2^47, the mat-vec and the column stages in exact double-precision
 //                 integer arithmetic (see ntt_rows_f64_kernel); same canonical results.
+#ifndef HE_MODUP_WAVES
+#define HE_MODUP_WAVES 2  // waves per SIMD the register allocation aims at
+#endif
 template <int NSRC, int LOGA, bool DSTF64>
-__global__ void __launch_bounds__(128) modup_fused_kernel(ModUpFusedArgs A) {
+__global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpFusedArgs A) {
     constexpr int R = 1 << LOGA;
     const int N2 = A.N >> LOGA;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
