@@ -407,6 +407,49 @@ __device__ __forceinline__ void rows_round_f64(double (&x)[16], const double *__
         }
     }
 }
+// The fifteen twiddles of one radix-16 round (one group of 16 per thread): stage u of the round uses
+// t[(1 << u) - 1 + j] = tw[(rowtw << (s0 + u)) + (hi0 << u) + j], j < 2^u.  Loading them apart from the butterflies lets a
+// kernel issue the NEXT round's twiddles before the LDS exchange and its barrier, so that their latency (an L2 round trip
+// per round otherwise, exposed at two to four waves per SIMD) overlaps the exchange; the registers are the ones the
+// finished round's twiddles occupied.
+__device__ __forceinline__ void rows_tw16_f64(double (&t)[15], const double *__restrict__ tw, int rowtw, int s0, int hi0) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int base = (rowtw << (s0 + u)) + (hi0 << u);
+#pragma unroll
+        for (int j = 0; j < (1 << u); j++) t[(1 << u) - 1 + j] = tw[base + j];
+    }
+}
+template <bool INV>
+__device__ __forceinline__ void rows_round16_f64(double (&x)[16], const double (&t)[15], double q, double qi) {
+    if constexpr (!INV) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int d = 1 << (3 - u);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k & d) continue;
+                const double r = modmul_f64(x[k + d], t[(1 << u) - 1 + (k >> (4 - u))], q, qi);
+                const double U = x[k];
+                x[k] = U + r;
+                x[k + d] = U - r;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 3; u >= 0; u--) {
+            const int d = 1 << (3 - u);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k & d) continue;
+                const double U = x[k], V = x[k + d];
+                x[k] = U + V;
+                x[k + d] = modmul_f64(U - V, t[(1 << u) - 1 + (k >> (4 - u))], q, qi);
+            }
+        }
+    }
+}
+
 template <int LOGB, int G4>
 __device__ __forceinline__ void rows_lds_xfer_f64(double (&x)[16], double *lds, int tau, int s0, int sh, bool store) {
     constexpr int g = G4, G = 1 << g, W = 16 / G;
@@ -464,11 +507,14 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
             x[k] = u52_to_f64(v);
         }
+        double t16[15];
+        if constexpr (NR4 > 0) rows_tw16_f64(t16, tw, rowtw, 0, tau >> (LOGB - 4));
 #pragma unroll 1
         for (int rho = 0; rho < NR4; rho++) {
             const int s0 = 4 * rho, sh = LOGB - s0 - 4;
             if (rho > 0) rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, false);
-            rows_round_f64<4, false>(x, tw, rowtw, s0, tau >> sh, tau, sh, q, qi);
+            rows_round16_f64<false>(x, t16, q, qi);
+            if (rho + 1 < NR4) rows_tw16_f64(t16, tw, rowtw, s0 + 4, tau >> (sh - 4));  // in flight across the exchange
             rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, true);
             __syncthreads();
         }
@@ -545,6 +591,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, s0, 0, true);
             __syncthreads();
         }
+        double t16[15];
+        if constexpr (NR4 > 0) rows_tw16_f64(t16, tw, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
 #pragma unroll 1
         for (int rho = NR4 - 1; rho >= 0; rho--) {
             const int s0 = 4 * rho, sh = LOGB - s0 - 4;
@@ -552,8 +600,9 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             // the sums X = U + V double per stage: bring everything back below q once per round
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = reduce_f64(x[k], q, qi);
-            rows_round_f64<4, true>(x, tw, rowtw, s0, tau >> sh, tau, sh, q, qi);
+            rows_round16_f64<true>(x, t16, q, qi);
             if (rho > 0) {
+                rows_tw16_f64(t16, tw, rowtw, s0 - 4, tau >> (sh + 4));  // the next round's, in flight across the exchange
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, true);
                 __syncthreads();
             }
@@ -619,6 +668,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
         return own_digit(d) ? A.own + bz * A.own_bs + (size_t)ql * A.N + rowoff
                             : A.dec + bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)A.m.dec_limb[l] * A.N + rowoff;
     };
+    double t16[15];  // twiddles of the coming radix-16 round
+    if constexpr (NR4 > 0) rows_tw16_f64(t16, tw, rowtw, 0, tau >> (LOGB - 4));
     // software pipeline over the digits: the words of digit d + 1 are in flight while digit d is transformed and accumulated
     uint64_t nx[16];
     {
@@ -641,7 +692,10 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
             for (int rho = 0; rho < NR4; rho++) {
                 const int s0 = 4 * rho, sh = LOGB - s0 - 4;
                 if (rho > 0) rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, false);
-                rows_round_f64<4, false>(x, tw, rowtw, s0, tau >> sh, tau, sh, q, qi);
+                rows_round16_f64<false>(x, t16, q, qi);
+                // the next round's twiddles (round 0 of the next digit after the last one) are in flight across the exchange
+                const int sn = rho + 1 < NR4 ? s0 + 4 : 0;
+                rows_tw16_f64(t16, tw, rowtw, sn, tau >> (LOGB - sn - 4));
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, true);
                 __syncthreads();
             }
