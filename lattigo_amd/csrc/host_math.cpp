@@ -127,6 +127,8 @@ static bool build_subring_nth(int logN, uint64_t q, uint64_t nth, SubRingHost &o
     mc.ninv = to_mont(invmod(half % q, q), q);
     mc.r2 = to_mont(to_mont(1, q), q);
     mc.pad0 = mc.pad1 = 0;
+    mc.rq = 1.0 / (double)q;
+    mc.pad2 = 0;
     // smallest generator g >= 3 of Z_q^* (ring/subring.go:181-193)
     std::vector<uint64_t> fac = unique_prime_factors(q - 1);
     uint64_t g = 3;

@@ -524,7 +524,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     const int y = blockIdx.y;
     const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
     const ModConst mc = A.mc[mi];
-    const double q = (double)mc.q, qi = 1.0 / q;
+    const double q = (double)mc.q, qi = mc.rq;
     const double *__restrict__ tw = A.twd + (size_t)mi * A.N;
     const int rowtw = (1 << A.a) + row;
     const size_t in_off = (size_t)il * A.N + (size_t)row * N2;
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
     const size_t bz = blockIdx.x;  // batch fastest: workgroups sharing the key / twiddle rows run together
     const int mi = A.m.mod[l];
     const ModConst mc = A.mc[mi];
-    const double q = (double)mc.q, qi = 1.0 / q;
+    const double q = (double)mc.q, qi = mc.rq;
     const double *__restrict__ tw = A.twd + (size_t)mi * A.N;
     const int rowtw = (1 << A.a) + row;
     const size_t rowoff = (size_t)row * N2;
@@ -1490,7 +1490,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
         const double ninv = (src_small && LOGA > 0) ? (double)imform(mq.ninv, q, qinv) : 1.0;
         if (src_small) {
             // source modulus below 2^47: the inverse column stages, N^-1 and y_i = x*c_i in exact double arithmetic
-            const double qd = (double)q, qid = 1.0 / qd;
+            const double qd = (double)q, qid = mq.rq;
 #pragma unroll
             for (int r = 0; r < R; r++) xd[r] = u52_to_f64(x[r]);
             if constexpr (LOGA > 0) {
@@ -1538,9 +1538,9 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
         } else {
             const uint64_t h = U64(D.src_half[i]), ai = Da[i];
             const double qf = __ull2double_rn(q);
-            const double rq = 1.0 / qf;
+            const double rq = mq.rq;
             const bool split = (splitmask >> i) & 1;
-            const double qd = (double)q, qid = 1.0 / qd, apl = src_small ? (double)imform(ai, q, qinv) : 0.0;
+            const double qd = (double)q, qid = mq.rq, apl = src_small ? (double)imform(ai, q, qinv) : 0.0;
             uint64_t yi[R];
             double yd[R];
             if (src_small) {
@@ -1614,7 +1614,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
         bool done = false;
         if constexpr (DSTF64) if (small) {
             done = true;
-            const double pd = (double)p, pid = 1.0 / pd;
+            const double pd = (double)p, pid = mp.rq;
             double o[R];
             if (single) {
 #pragma unroll

@@ -80,7 +80,7 @@ HE_HD uint64_t mform(uint64_t a, uint64_t q, uint64_t brc0, uint64_t brc1) { ret
 HE_HD uint64_t imform_lazy(uint64_t a, uint64_t q, uint64_t qinv) { return q - mulhi64(a * qinv, q); }
 HE_HD uint64_t imform(uint64_t a, uint64_t q, uint64_t qinv) { return cred(imform_lazy(a, q, qinv), q); }
 
-// Per-modulus constants as the kernels see them (one 64-byte record per RNS limb).
+// Per-modulus constants as the kernels see them (one 80-byte record per RNS limb).
 struct ModConst {
     uint64_t q;      // Modulus
     uint64_t qinv;   // MRedConstant = q^-1 mod 2^64
@@ -89,6 +89,8 @@ struct ModConst {
     uint64_t ninv;   // NInv = MForm(N^-1)
     uint64_t r2;     // 2^128 mod q (MForm(x) = MRed(x, r2)), kernels only
     uint64_t pad0, pad1;
+    double rq;       // 1.0 / (double)q, IEEE-rounded (the f64 kernels would otherwise each spend ~28 VALU ops on the division)
+    uint64_t pad2;   // keeps the record a multiple of 16 bytes
 };
 
 }  // namespace he
