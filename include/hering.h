@@ -75,6 +75,10 @@ int he_ring_roots(he_handle ring, int limb, int dir, uint64_t *out);
 
 /* ---- polynomials: ring.Poly (ring/poly.go:13) as device-resident batches -------- */
 int he_poly_alloc(he_handle ring, int n_limbs, int batch, he_handle *poly);
+/* same shape, contents unspecified: for results and temporaries the next operation overwrites in full (saves the
+ * zero-fill launch ring.NewPoly's semantics require; the reference draws its temporaries from a recycling
+ * buffer pool without clearing them either, core/rlwe/pool.go:12-60, core/rlwe/evaluator.go:20).  HERING_POISON=1 fills them with a pattern. */
+int he_poly_alloc_scratch(he_handle ring, int n_limbs, int batch, he_handle *poly);
 int he_poly_free(he_handle poly);
 int he_poly_shape(he_handle poly, int *n_limbs, int *batch, int *N);
 /* whole-batch transfers of the contiguous [batch][limbs][N] image */

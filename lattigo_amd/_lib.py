@@ -62,7 +62,7 @@ def _declare(L):
         "he_timer_stop": [H, C.POINTER(C.c_float)], "he_device_info": [H, u64p],
         "he_ring_create": [H, i, u64p, i, HP], "he_ring_create_type": [H, i, i, u64p, i, HP], "he_ring_destroy": [H], "he_ring_constant": [H, i, i, u64p],
         "he_ring_roots": [H, i, i, u64p],
-        "he_poly_alloc": [H, i, i, HP], "he_poly_free": [H],
+        "he_poly_alloc": [H, i, i, HP], "he_poly_alloc_scratch": [H, i, i, HP], "he_poly_free": [H],
         "he_poly_shape": [H, C.POINTER(i), C.POINTER(i), C.POINTER(i)],
         "he_poly_upload": [H, u64p, sz], "he_poly_download": [H, u64p, sz],
         "he_poly_upload_limb": [H, i, i, u64p], "he_poly_download_limb": [H, i, i, u64p],

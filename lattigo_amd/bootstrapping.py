@@ -13,7 +13,7 @@ from .rlwe import Decomposition, EvaluationKey, Evaluator, InnerSumEvaluator
 def ApplyEvaluationKey(ev: Evaluator, level: int, ctIn, evk: EvaluationKey, opOut):
     """rlwe.Evaluator.ApplyEvaluationKey, same ring degree (core/rlwe/evaluator_evaluationkey.go:36,98-106)"""
     B = ctIn[0].batch
-    tmp = [Poly(ev.ringQ, level + 1, B), Poly(ev.ringQ, level + 1, B)]
+    tmp = [Poly(ev.ringQ, level + 1, B, zero=False), Poly(ev.ringQ, level + 1, B, zero=False)]
     ev.GadgetProduct(level, ctIn[1], evk, tmp)
     ev.ringQ.AtLevel(level).Add(ctIn[0], tmp[0], opOut[0])
     opOut[1].CopyLvl(level, tmp[1])
@@ -53,7 +53,7 @@ def ModUp(ev: Evaluator, ise: InnerSumEvaluator, levelIn: int, ct, scale: float,
             rQ.MulScalar(ct[0], scalar, ct[0])
         decomp = Decomposition(ev, B)
         check(load().he_decomp_fill(decomp.h, levelQ, levelP, liftQ.h, liftP.h))  # every digit = the lifted poly (:699-705)
-        tmp0 = Poly(ringQ, levelQ + 1, B)
+        tmp0 = Poly(ringQ, levelQ + 1, B, zero=False)
         ev.GadgetProductHoisted(levelQ, decomp, EvkSparseToDense, [tmp0, ct[1]])  # back to the dense key (:733)
         rQ.Add(ct[0], tmp0, ct[0])
     else:
@@ -98,7 +98,7 @@ class DeviceBootstrapBackend:
     def conjugate(self, ct):
         from .schemes import Ciphertext
         g = self.ckks.ringQ.NthRoot() - 1
-        out = [Poly(self.ckks.ringQ, ct.level + 1, ct.Value[0].batch) for _ in range(2)]
+        out = [Poly(self.ckks.ringQ, ct.level + 1, ct.Value[0].batch, zero=False) for _ in range(2)]
         self.ckks.eval.Automorphism(ct.level, ct.Value, g, self.lte.gks.GetGaloisKey(g), out)
         return Ciphertext(out, ct.level, ct.Scale)
 
@@ -108,7 +108,7 @@ class DeviceBootstrapBackend:
         from .schemes import Ciphertext
         a = cts[0]
         B, lv = a.Value[0].batch, a.level
-        out = [Poly(self.ckks.ringQ, lv + 1, B * len(cts)) for _ in range(a.Degree() + 1)]
+        out = [Poly(self.ckks.ringQ, lv + 1, B * len(cts), zero=False) for _ in range(a.Degree() + 1)]
         for i, c in enumerate(cts):
             if (c.level, c.Scale, c.Degree(), c.Value[0].batch) != (lv, a.Scale, a.Degree(), B):
                 raise ValueError("stack: ciphertexts must share level, scale, degree and batch")
@@ -121,7 +121,7 @@ class DeviceBootstrapBackend:
         B = ct.Value[0].batch // parts
         res = []
         for i in range(parts):
-            vals = [Poly(self.ckks.ringQ, ct.level + 1, B) for _ in ct.Value]
+            vals = [Poly(self.ckks.ringQ, ct.level + 1, B, zero=False) for _ in ct.Value]
             for o, v in zip(vals, ct.Value):
                 o.CopyBatch(ct.level, 0, v, i * B, B)
             res.append(Ciphertext(vals, ct.level, ct.Scale))

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/hering.h"
@@ -554,7 +555,7 @@ int he_ring_roots(he_handle h, int limb, int dir, uint64_t *out) {
 // ---------------------------------------------------------------------------------------
 // polynomials
 // ---------------------------------------------------------------------------------------
-int he_poly_alloc(he_handle hring, int n_limbs, int batch, he_handle *out) {
+static int poly_alloc(he_handle hring, int n_limbs, int batch, bool zero, he_handle *out) {
     GET(r, Ring, hring, T_RING);
     if (n_limbs <= 0 || n_limbs > 255 || batch <= 0 || !out) return fail(HE_EINVAL, "he_poly_alloc: bad shape (%d limbs, batch %d)", n_limbs, batch);
     auto p = std::make_shared<Poly>();
@@ -569,10 +570,16 @@ int he_poly_alloc(he_handle hring, int n_limbs, int batch, he_handle *out) {
         p->d = nullptr;
         return fail(HE_ENOMEM, "he_poly_alloc: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
-    HIP_TRY(hipMemsetAsync(p->d, 0, bytes, r->ctx->stream));
+    // scratch polynomials: contents unspecified (a recycled buffer); HERING_POISON=1 fills them with a pattern so that a
+    // read-before-write shows up as a parity failure instead of depending on what the buffer held
+    static const bool poison = getenv("HERING_POISON") && atoi(getenv("HERING_POISON")) != 0;
+    if (zero) HIP_TRY(hipMemsetAsync(p->d, 0, bytes, r->ctx->stream));
+    else if (poison) HIP_TRY(hipMemsetAsync(p->d, 0x5a, bytes, r->ctx->stream));
     *out = reg(p);
     return HE_OK;
 }
+int he_poly_alloc(he_handle hring, int n_limbs, int batch, he_handle *out) { return poly_alloc(hring, n_limbs, batch, true, out); }
+int he_poly_alloc_scratch(he_handle hring, int n_limbs, int batch, he_handle *out) { return poly_alloc(hring, n_limbs, batch, false, out); }
 int he_poly_free(he_handle h) { return unreg(h, T_POLY); }
 int he_poly_shape(he_handle h, int *n_limbs, int *batch, int *N) {
     GET(p, Poly, h, T_POLY);

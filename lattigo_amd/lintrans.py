@@ -91,7 +91,8 @@ class LinTransEvaluator:
         return self._index[galEl]
 
     def _qp(self, levelQ, levelP, B):
-        return (Poly(self.ringQ, levelQ + 1, B), Poly(self.ringP, levelP + 1, B))
+        # scratch: every user below has the next operation overwrite both parts in full
+        return (Poly(self.ringQ, levelQ + 1, B, zero=False), Poly(self.ringP, levelP + 1, B, zero=False))
 
     def _mul_sum(self, levelQ, levelP, terms, out0, out1, accumulate=False):
         """out_k = Reduce([out_k +] sum_i MulCoeffsMontgomeryLazy(pt_i, phi_i(ct_i[k]))) on QP in one pass per ring
@@ -150,9 +151,9 @@ class LinTransEvaluator:
         B = ctIn[0].batch
         c0P, c1P = Poly(self.ringP, levelP + 1, B), Poly(self.ringP, levelP + 1, B)
         c0OutQP, c1OutQP = (opOut[0], c0P), (opOut[1], c1P)
-        ct0TimesP = Poly(self.ringQ, levelQ + 1, B)
+        ct0TimesP = Poly(self.ringQ, levelQ + 1, B, zero=False)
         cQP = [self._qp(levelQ, levelP, B), self._qp(levelQ, levelP, B)]
-        ctInTmp0, ctInTmp1 = Poly(self.ringQ, levelQ + 1, B), Poly(self.ringQ, levelQ + 1, B)
+        ctInTmp0, ctInTmp1 = Poly(self.ringQ, levelQ + 1, B, zero=False), Poly(self.ringQ, levelQ + 1, B, zero=False)
         ctInTmp0.CopyLvl(levelQ, ctIn[0])
         ctInTmp1.CopyLvl(levelQ, ctIn[1])
         P = 1
@@ -189,13 +190,13 @@ class LinTransEvaluator:
         QiOverF = _overflow_margin(self.ringQ.ModuliChain(), levelQ) >> 1
         PiOverF = _overflow_margin(self.ringP.ModuliChain(), levelP) >> 1
         index, _, _ = matrix.BSGSIndex()
-        ctInTmp0, ctInTmp1 = Poly(self.ringQ, levelQ + 1, B), Poly(self.ringQ, levelQ + 1, B)
+        ctInTmp0, ctInTmp1 = Poly(self.ringQ, levelQ + 1, B, zero=False), Poly(self.ringQ, levelQ + 1, B, zero=False)
         ctInTmp0.CopyLvl(levelQ, ctIn[0])
         ctInTmp1.CopyLvl(levelQ, ctIn[1])
         tmp0QP, tmp1QP = self._qp(levelQ, levelP, B), self._qp(levelQ, levelP, B)   # accumulator, inner loop
         cQP = [self._qp(levelQ, levelP, B), self._qp(levelQ, levelP, B)]             # accumulator, outer loop
-        c0OutQP = (opOut[0], Poly(self.ringP, levelP + 1, B))
-        c1OutQP = (opOut[1], Poly(self.ringP, levelP + 1, B))
+        c0OutQP = (opOut[0], Poly(self.ringP, levelP + 1, B, zero=False))  # written by the first giant step
+        c1OutQP = (opOut[1], Poly(self.ringP, levelP + 1, B, zero=False))
         P = 1
         for m in self.ringP.ModuliChain()[: levelP + 1]:
             P *= int(m)

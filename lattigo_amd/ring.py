@@ -100,13 +100,14 @@ class Context:
 class Poly:
     """Device-resident ring.Poly batch (ring/poly.go:13): [batch][limbs][N] uint64."""
 
-    def __init__(self, ring: "Ring", n_limbs: int | None = None, batch: int = 1):
+    def __init__(self, ring: "Ring", n_limbs: int | None = None, batch: int = 1, zero: bool = True):
+        """zero=False: contents unspecified (a result / temporary the next operation overwrites in full)"""
         self.ring = ring
         self.n_limbs = ring.MaxLevel() + 1 if n_limbs is None else n_limbs
         self.batch = batch
         self.N = ring.N
         h = H()
-        check(load().he_poly_alloc(ring.h, self.n_limbs, batch, C.byref(h)))
+        check((load().he_poly_alloc if zero else load().he_poly_alloc_scratch)(ring.h, self.n_limbs, batch, C.byref(h)))
         self.h = h.value
 
     def free(self):

@@ -155,7 +155,7 @@ class Evaluator:
             check(load().he_gadget_product_lazy(self.h, levelQ, cx.h, evk.h, q0.h, p0.h, q1.h, p1.h))
             return
         rQ, rP = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(evk.LevelP())
-        cxNTT = Poly(self.ringQ, levelQ + 1, cx.batch)
+        cxNTT = Poly(self.ringQ, levelQ + 1, cx.batch, zero=False)
         rQ.NTT(cx, cxNTT)
         check(load().he_gadget_product_lazy(self.h, levelQ, cxNTT.h, evk.h, q0.h, p0.h, q1.h, p1.h))
         for q, p in ctQP:  # ringQP.INTT (:121-125)
@@ -194,7 +194,7 @@ class Evaluator:
             check(load().he_gadget_product(self.h, levelQ, cx.h, evk.h, ct[0].h, ct[1].h))
             return
         B = cx.batch
-        ctQP = [(Poly(self.ringQ, levelQ + 1, B), Poly(self.ringP, evk.LevelP() + 1, B)) for _ in range(2)]
+        ctQP = [(Poly(self.ringQ, levelQ + 1, B, zero=False), Poly(self.ringP, evk.LevelP() + 1, B, zero=False)) for _ in range(2)]
         self.GadgetProductLazy(levelQ, cx, evk, ctQP, isNTT=False)
         self.ModDown(levelQ, evk.LevelP(), ctQP, ct, ctQPIsNTT=False, ctIsNTT=False)
 
@@ -294,7 +294,7 @@ class InnerSumEvaluator:
             rQ.MulScalarBigint(a, ninv, b)  # pre-multiplication by (N/n)^-1 (:68-70)
             if not isNTT:
                 rQ.NTT(b, b)
-        buff = [Poly(self.ringQ, level + 1, opOut[0].batch) for _ in range(2)]
+        buff = [Poly(self.ringQ, level + 1, opOut[0].batch, zero=False) for _ in range(2)]
         steps = [self.GaloisElement(1 << i) for i in range(logN, self.logN - 1)]
         if logN == 0:
             steps.append(self.nth_root - 1)  # X -> X^-1 (:97-105)
@@ -313,7 +313,7 @@ class InnerSumEvaluator:
         levelQ, levelP = level, self.ringP.MaxLevel()
         rQ, rP = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(levelP)
         B = ctIn[0].batch
-        ctInNTT = [Poly(self.ringQ, levelQ + 1, B) for _ in range(2)]
+        ctInNTT = [Poly(self.ringQ, levelQ + 1, B, zero=False) for _ in range(2)]
         for a, b in zip(ctIn, ctInNTT):
             if not isNTT:
                 rQ.NTT(a, b)
@@ -420,7 +420,7 @@ class CKKSRotations:
         levelP, B, out = self.eval.ringP.MaxLevel(), ct[0].batch, {}
         for i in rotations:
             if i != 0:
-                out[i] = [(Poly(self.eval.ringQ, level + 1, B), Poly(self.eval.ringP, levelP + 1, B)) for _ in range(2)]
+                out[i] = [(Poly(self.eval.ringQ, level + 1, B, zero=False), Poly(self.eval.ringP, levelP + 1, B, zero=False)) for _ in range(2)]
                 g = GaloisElement(self.nth_root, i)
                 self.eval.AutomorphismHoistedLazy(level, ct, decomp, g, self.gks.GetGaloisKey(g), out[i])
         return out

@@ -17,7 +17,8 @@ class _Base:
         self.eval, self.ringQ = evaluator, evaluator.ringQ
 
     def _tmp(self, level, B):
-        return Poly(self.ringQ, level + 1, B)
+        """a temporary the next operation overwrites in full: contents unspecified (no zero-fill launch)"""
+        return Poly(self.ringQ, level + 1, B, zero=False)
 
     # Evaluator.Add / Sub for operands of equal scale (schemes/ckks/evaluator.go:65,226; schemes/bgv/evaluator.go:168,350
     # -> rlwe evaluateInPlace): component-wise, the operand of higher degree is copied (negated for Sub) beyond the other's
@@ -203,8 +204,12 @@ class BGVCiphertextEvaluator:
     def NewCiphertext(self, degree: int, level: int, batch: int = 1) -> Ciphertext:
         return Ciphertext([Poly(self.ringQ, level + 1, batch) for _ in range(degree + 1)], level, 1)
 
+    def _new_result(self, degree: int, level: int, batch: int) -> Ciphertext:
+        """the result of an XNew method: every component is overwritten in full by the operation that follows"""
+        return Ciphertext([Poly(self.ringQ, level + 1, batch, zero=False) for _ in range(degree + 1)], level, 1)
+
     def CopyNew(self, ct: Ciphertext) -> Ciphertext:
-        out = self.NewCiphertext(ct.Degree(), ct.level, ct.Value[0].batch)
+        out = self._new_result(ct.Degree(), ct.level, ct.Value[0].batch)
         for a, b in zip(ct.Value, out.Value):
             b.CopyLvl(ct.level, a)
         out.Scale = ct.Scale
@@ -289,15 +294,15 @@ class BGVCiphertextEvaluator:
     def MulNew(self, op0: Ciphertext, op1) -> Ciphertext:
         B = op0.Value[0].batch
         if isinstance(op1, Ciphertext):
-            out = self.NewCiphertext(op0.Degree() + op1.Degree(), min(op0.level, op1.level), B)
+            out = self._new_result(op0.Degree() + op1.Degree(), min(op0.level, op1.level), B)
         else:
-            out = self.NewCiphertext(op0.Degree(), op0.level, B)
+            out = self._new_result(op0.Degree(), op0.level, B)
         self.Mul(op0, op1, out)
         return out
 
     def MulRelinNew(self, op0: Ciphertext, op1) -> Ciphertext:
         B = op0.Value[0].batch
-        out = self.NewCiphertext(1, min(op0.level, op1.level) if isinstance(op1, Ciphertext) else op0.level, B)
+        out = self._new_result(1, min(op0.level, op1.level) if isinstance(op1, Ciphertext) else op0.level, B)
         self.MulRelin(op0, op1, out)
         return out
 
@@ -379,6 +384,7 @@ class CKKSCiphertextEvaluator:
         self.imag_unit = [int(self.ringQ.roots(i)[1]) * pow(1 << 64, -1, q) % q for i, q in enumerate(self.Q)]
 
     NewCiphertext = BGVCiphertextEvaluator.NewCiphertext
+    _new_result = BGVCiphertextEvaluator._new_result
     CopyNew = BGVCiphertextEvaluator.CopyNew
     _resize = BGVCiphertextEvaluator._resize
 
