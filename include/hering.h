@@ -264,6 +264,11 @@ int he_gadget_product_hoisted_lazy(he_handle eval, int levelQ, he_handle decomp,
 /* Evaluator.ModDown (:39), NTT in / NTT out */
 int he_moddown(he_handle eval, int levelQ, int levelP, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P,
                he_handle out0, he_handle out1);
+/* BasisExtender.ModDownQPtoQNTT (ring/basis_extension.go:235-256) through the evaluator's fused pipeline (three launches
+ * instead of six: the strided NTT stages ride inside the basis extension and the final (x - p1Q) * P^-1 is the epilogue of
+ * the forward row pass); p1Q in [0, 2q) as the reference's callers provide it, p2Q may alias p1Q; same canonical result
+ * as he_moddown_qp_to_q_ntt. */
+int he_eval_moddown_qp_to_q_ntt(he_handle eval, int levelQ, int levelP, he_handle p1Q, he_handle p1P, he_handle p2Q);
 /* GadgetProduct (:16) and GadgetProductHoisted (:348) */
 int he_gadget_product(he_handle eval, int levelQ, he_handle cx, he_handle evk, he_handle out0, he_handle out1);
 int he_gadget_product_hoisted(he_handle eval, int levelQ, he_handle decomp, he_handle evk, he_handle out0, he_handle out1);

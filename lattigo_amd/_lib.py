@@ -93,7 +93,7 @@ def _declare(L):
         "he_modup_q_to_p": [H, i, i, H, H], "he_modup_p_to_q": [H, i, i, H, H],
         "he_moddown_qp_to_q": [H, i, i, H, H, H], "he_moddown_qp_to_q_ntt": [H, i, i, H, H, H],
         "he_moddown_qp_to_p": [H, i, i, H, H, H],
-        "he_evaluator_create": [H, H, HP], "he_evaluator_destroy": [H],
+        "he_eval_moddown_qp_to_q_ntt": [H, i, i, H, H, H], "he_evaluator_create": [H, H, HP], "he_evaluator_destroy": [H],
         "he_evk_create": [H, i, i, i, u64p, u64p, HP], "he_evk_destroy": [H],
         "he_evk_device_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(sz)], "he_evk_commit": [H], "he_evk_download": [H, u64p, sz],
         "he_evk_create_base2": [H, i, C.POINTER(i), i, i, i, u64p, u64p, HP],

@@ -1963,6 +1963,42 @@ int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, levelP, out0->batch, false)));
     return moddown_pair(*ev, levelQ, levelP, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), out0->view(), out1->view(), out0->batch);
 }
+int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle h1q, he_handle h1p, he_handle h2) {
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(p1q, Poly, h1q, T_POLY);
+    GET(p1p, Poly, h1p, T_POLY);
+    GET(p2, Poly, h2, T_POLY);
+    BasisExtender &be = *ev->be;
+    const char *who = "he_eval_moddown_qp_to_q_ntt";
+    if (levelQ < 0 || levelQ >= be.LQ || levelP < 0 || levelP >= be.LP) return fail(HE_EINVAL, "%s: level out of range", who);
+    TRY(check_be_poly(*p1q, be, levelQ + 1, who));
+    TRY(check_be_poly(*p1p, be, levelP + 1, who));
+    TRY(check_be_poly(*p2, be, levelQ + 1, who));
+    if (p1q->batch != p1p->batch || p1q->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    Scope sc(be.ctx.get());
+    const int B = p1q->batch, N = be.Q->N;
+    const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
+    TRY(be.ctx->arena_reserve(wP + wQ));
+    View sP{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
+    View sQ{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
+    const FusedPlan *plan = nullptr;
+    TRY(get_md_plan(*ev, levelQ, levelP, &plan));
+    // the fused basis extension runs one 128-thread workgroup per 1024 coefficients and batch entry over ALL destination
+    // limbs: below one workgroup per CU the six-launch path, which also spreads the limbs over the grid, has the lower latency
+    const int rowbits = be.Q->logN <= 12 ? be.Q->logN : (be.Q->logN <= 15 ? 12 : 13);  // ntt_row_bits (kernels.hip)
+    const bool wide = (size_t)B * ((size_t)1 << rowbits) / 128 >= 256;
+    if (!plan->ok || !wide) return moddown_q_ntt(be, levelQ, levelP, p1q->view(), p1p->view(), p2->view(), B, sP, sQ);
+    // three launches: INTT rows (P) -> [cols + ModUpPtoQ + cols] -> NTT rows whose epilogue is the last op of the ModDown
+    hipStream_t st = be.ctx->stream;
+    HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), p1p->view(), sP, B, true, NTT_REDUCE_INPUT, st));
+    const FusedGroup &g = plan->groups[0];
+    HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, B, st));
+    NttEpilogue epi;
+    for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
+    epi.y = p1q->view(); epi.has_w = false; epi.w = p1q->view();
+    HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, p2->view(), B, false, 0, st, &epi));
+    return HE_OK;
+}
 int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he_handle hout0, he_handle hout1) {
     GET(ev, Evaluator, hev, T_EVAL);
     GET(cx, Poly, hcx, T_POLY);

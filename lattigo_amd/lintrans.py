@@ -176,8 +176,8 @@ class LinTransEvaluator:
             # AutomorphismNTTWithIndex + MulCoeffsMontgomery[ThenAdd] on QP (:224-241) in one fused pass per ring; the
             # accumulator stays canonical, so the reference's periodic Reduce calls (:243-262) are no-ops here
             self._mul_sum(levelQ, levelP, [(matrix.Vec[k], cQP[0], cQP[1], index)], c0OutQP, c1OutQP, accumulate=i > 0)
-        self.be.ModDownQPtoQNTT(levelQ, levelP, c0OutQP[0], c0OutQP[1], c0OutQP[0])  # sum(phi(c0*P + d0_QP))/P
-        self.be.ModDownQPtoQNTT(levelQ, levelP, c1OutQP[0], c1OutQP[1], c1OutQP[0])  # sum(phi(d1_QP))/P
+        self.eval.ModDownQPtoQNTT(levelQ, levelP, c0OutQP[0], c0OutQP[1], c0OutQP[0])  # sum(phi(c0*P + d0_QP))/P
+        self.eval.ModDownQPtoQNTT(levelQ, levelP, c1OutQP[0], c1OutQP[1], c1OutQP[0])  # sum(phi(d1_QP))/P
         if state:  # rotation by zero
             rQ.MulCoeffsMontgomeryThenAdd(matrix.Vec[0][0], ctInTmp0, c0OutQP[0])
             rQ.MulCoeffsMontgomeryThenAdd(matrix.Vec[0][0], ctInTmp1, c1OutQP[0])
@@ -217,7 +217,7 @@ class LinTransEvaluator:
             self._mul_sum(levelQ, levelP, terms, tmp0QP, tmp1QP)
             if j != 0:
                 # hoisting of the ModDown of sum(sum(phi(d1) * plaintext)) (:397)
-                self.be.ModDownQPtoQNTT(levelQ, levelP, tmp1QP[0], tmp1QP[1], tmp1QP[0])
+                self.eval.ModDownQPtoQNTT(levelQ, levelP, tmp1QP[0], tmp1QP[1], tmp1QP[0])
                 galEl = self.GaloisElement(j)
                 evk = self.gks.GetGaloisKey(galEl)
                 if evk.LevelP() != levelP:
@@ -254,5 +254,5 @@ class LinTransEvaluator:
         if cnt0 % PiOverF != 0:
             rP.Reduce(c0OutQP[1], c0OutQP[1])
             rP.Reduce(c1OutQP[1], c1OutQP[1])
-        self.be.ModDownQPtoQNTT(levelQ, levelP, opOut[0], c0OutQP[1], opOut[0])  # sum(phi(c0 * P + d0_QP))/P
-        self.be.ModDownQPtoQNTT(levelQ, levelP, opOut[1], c1OutQP[1], opOut[1])  # sum(phi(d1_QP))/P
+        self.eval.ModDownQPtoQNTT(levelQ, levelP, opOut[0], c0OutQP[1], opOut[0])  # sum(phi(c0 * P + d0_QP))/P
+        self.eval.ModDownQPtoQNTT(levelQ, levelP, opOut[1], c1OutQP[1], opOut[1])  # sum(phi(d1_QP))/P

@@ -169,6 +169,10 @@ class Evaluator:
 
     # Evaluator.ModDown (:39-97), the four domain combinations of (ctQP.IsNTT, ct.IsNTT); ctQP is modified in place in the
     # NTT -> INTT case, as the reference
+    # BasisExtender.ModDownQPtoQNTT (ring/basis_extension.go:235) on the evaluator's fused pipeline; p2Q may alias p1Q
+    def ModDownQPtoQNTT(self, levelQ, levelP, p1Q: Poly, p1P: Poly, p2Q: Poly):
+        check(load().he_eval_moddown_qp_to_q_ntt(self.h, levelQ, levelP, p1Q.h, p1P.h, p2Q.h))
+
     def ModDown(self, levelQ, levelP, ctQP, ct, ctQPIsNTT: bool = True, ctIsNTT: bool = True):
         (q0, p0), (q1, p1) = ctQP
         if ctQPIsNTT and ctIsNTT:
@@ -349,7 +353,7 @@ class InnerSumEvaluator:
                         state = True
                         if n & (n - 1):
                             for a, o, c in zip(accQP, opOut, ctInNTT):
-                                self.be.ModDownQPtoQNTT(levelQ, levelP, a[0], a[1], o)
+                                self.eval.ModDownQPtoQNTT(levelQ, levelP, a[0], a[1], o)
                                 rQ.Add(o, c, o)
                         else:
                             for o, c in zip(opOut, ctInNTT):
