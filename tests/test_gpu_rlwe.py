@@ -635,3 +635,25 @@ cp.close()
 def test_key_replication_two_ranks_host_transport(tmp_path):
     """Two processes (sharing the box's one GPU): rank 1 receives the key from rank 0 and computes the same gadget product."""
     assert "REPLICATED" in _run_worker(tmp_path, _REPLICA_WORKER, 2, 29543)
+
+
+@pytest.mark.parametrize("logN,batch", [(10, 1), (12, 8), (13, 32), (14, 16)])
+def test_evaluator_moddown_matches_basis_extender(ctx, logN, batch):
+    """he_eval_moddown_qp_to_q_ntt (fused three-launch pipeline when the grid is wide enough, six-launch form otherwise)
+    returns ModDownQPtoQNTT's words (ring/basis_extension.go:235-256), also in place and into a scratch polynomial."""
+    q, p = O.GenModuli(logN + 1, [55, 45, 45, 58, 40], [55, 46])  # every kernel class on both sides
+    pr = Pair(ctx, logN, 5, 2, qmods=q, pmods=p)
+    obe = O.BasisExtender(pr.oQ, pr.oP)
+    gev = la.Evaluator(pr.gQ, pr.gP)
+    rng = rng_for(3100 + logN)
+    for levelQ, levelP in ((4, 1), (2, 0)):
+        xq = np.stack([uniform_poly(rng, q[: levelQ + 1], pr.N) for _ in range(batch)])
+        xp = np.stack([uniform_poly(rng, p[: levelP + 1], pr.N) for _ in range(batch)])
+        want = np.stack([obe.ModDownQPtoQNTT(levelQ, levelP, xq[b], xp[b]) for b in range(batch)])
+        pq = la.Poly(pr.gQ, levelQ + 1, batch).upload(xq)
+        pp = la.Poly(pr.gP, levelP + 1, batch).upload(xp)
+        out = la.Poly(pr.gQ, levelQ + 1, batch, zero=False)
+        gev.ModDownQPtoQNTT(levelQ, levelP, pq, pp, out)
+        assert np.array_equal(out.download(), want), (levelQ, levelP)
+        gev.ModDownQPtoQNTT(levelQ, levelP, pq, pp, pq)  # in place
+        assert np.array_equal(pq.download(), want), ("in place", levelQ, levelP)
