@@ -14,8 +14,10 @@ def prod(xs):
 
 
 def rng_for(config_index: int):
-    """PCG64 seeded with 0x1A77160 + config_index."""
-    return np.random.Generator(np.random.PCG64(0x1A77160 + config_index))
+    """PCG64 seeded with 0x1A77160 + config_index.  HERING_SEED_OFFSET shifts every seed (soak runs of
+    the parity suites on fresh random inputs; golden-vector tests do not draw from here)."""
+    import os
+    return np.random.Generator(np.random.PCG64(0x1A77160 + config_index + 1000003 * int(os.environ.get("HERING_SEED_OFFSET", "0"))))
 
 
 def uniform_poly(rng, moduli, N):
