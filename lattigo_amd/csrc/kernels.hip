@@ -71,6 +71,17 @@ int prof_end(int *counts, float *total_ms) {
 // workgroups of a launch -- the non-temporal hint keeps L2 for the latter (measured -3 % on ntt_mac_f64).
 template <class T> __device__ __forceinline__ T ldnt(const T *p) { return __builtin_nontemporal_load(p); }
 template <class T> __device__ __forceinline__ void stnt(T *p, T v) { __builtin_nontemporal_store(v, p); }
+// the 16-byte forms of the two-coefficients-per-thread kernels
+typedef unsigned long long he_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulonglong2 ldnt2(const uint64_t *p) {
+    const he_u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const he_u64x2 *>(p));
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ __forceinline__ void stnt2(uint64_t *p, ulonglong2 v) {
+    he_u64x2 w;
+    w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<he_u64x2 *>(p));
+}
 
 // ------------------------------------------------------------------------------------
 // butterflies
@@ -1182,17 +1193,17 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
     const ModConst m = A.mc[A.mod[yy]];
     const uint64_t s2 = A.s2[yy], s = (A.dbl && j >= (A.N >> 1)) ? s2 : A.s[yy];
     const size_t bz = blockIdx.z;
-    const ulonglong2 xv = *reinterpret_cast<const ulonglong2 *>(A.x + bz * A.x_bs + (size_t)A.x_limb[yy] * A.N + j);
+    const ulonglong2 xv = ldnt2(A.x + bz * A.x_bs + (size_t)A.x_limb[yy] * A.N + j);
     ulonglong2 yv = make_ulonglong2(0, 0), zv = make_ulonglong2(0, 0);
     if constexpr (ew_reads_y<OP>())
-        yv = *reinterpret_cast<const ulonglong2 *>(A.y + bz * A.y_bs + (size_t)A.y_limb[yy] * A.N + j);
+        yv = ldnt2(A.y + bz * A.y_bs + (size_t)A.y_limb[yy] * A.N + j);
     uint64_t *zp = A.z + bz * A.z_bs + (size_t)A.z_limb[yy] * A.N + j;
     if constexpr (ew_reads_z<OP>())
-        zv = *reinterpret_cast<const ulonglong2 *>(A.w + bz * A.w_bs + (size_t)A.z_limb[yy] * A.N + j);
+        zv = ldnt2(A.w + bz * A.w_bs + (size_t)A.z_limb[yy] * A.N + j);
     ulonglong2 o;
     o.x = ew_apply<OP>(xv.x, yv.x, zv.x, m, s, s2);
     o.y = ew_apply<OP>(xv.y, yv.y, zv.y, m, s, s2);
-    *reinterpret_cast<ulonglong2 *>(zp) = o;
+    stnt2(zp, o);
 }
 
 static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
@@ -1882,10 +1893,10 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
         kn1 = kp[(size_t)d * A.k.key_dstride + A.k.key_kstride];
         if (is_own(d)) {
 #pragma unroll
-            for (int b = 0; b < BB; b++) cn[b] = op[boff_own[b]];
+            for (int b = 0; b < BB; b++) cn[b] = ldnt(&op[boff_own[b]]);
         } else {
 #pragma unroll
-            for (int b = 0; b < BB; b++) cn[b] = dp[boff_dec[b] + (size_t)d * A.k.dec_dstride];
+            for (int b = 0; b < BB; b++) cn[b] = ldnt(&dp[boff_dec[b] + (size_t)d * A.k.dec_dstride]);
         }
     };
     fetch(0);
@@ -1915,8 +1926,8 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
             const uint64_t r1 = cred(mred128_lazy(hi1[b], lo1[b], q, m.qinv), q);
             uint64_t *o0 = isP ? A.o0P + (size_t)(b0 + b) * A.oP0_bs : A.o0Q + (size_t)(b0 + b) * A.oQ0_bs;
             uint64_t *o1 = isP ? A.o1P + (size_t)(b0 + b) * A.oP1_bs : A.o1Q + (size_t)(b0 + b) * A.oQ1_bs;
-            o0[(size_t)ol * A.N + x] = r0;
-            o1[(size_t)ol * A.N + x] = r1;
+            stnt(&o0[(size_t)ol * A.N + x], r0);
+            stnt(&o1[(size_t)ol * A.N + x], r1);
         }
     }
 }
@@ -2091,10 +2102,10 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
     const ModConst m = A.mc[A.mod[yy]];
     const uint64_t q = m.q, qinv = m.qinv, sc = A.s[yy];
     const size_t bz = blockIdx.z, io = (size_t)A.in_limb[yy] * A.N + j, oo = (size_t)A.out_limb[yy] * A.N + j;
-    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(A.a0 + bz * A.a0_bs + io);
-    const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(A.a1 + bz * A.a1_bs + io);
-    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(A.b0 + bz * A.b0_bs + io);
-    const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(A.b1 + bz * A.b1_bs + io);
+    const ulonglong2 a0 = ldnt2(A.a0 + bz * A.a0_bs + io);
+    const ulonglong2 a1 = ldnt2(A.a1 + bz * A.a1_bs + io);
+    const ulonglong2 b0 = ldnt2(A.b0 + bz * A.b0_bs + io);
+    const ulonglong2 b1 = ldnt2(A.b1 + bz * A.b1_bs + io);
     ulonglong2 c0, c1, c2;
     {
         const uint64_t t0 = mred(a0.x, sc, q, qinv), t1 = mred(a1.x, sc, q, qinv);
@@ -2108,9 +2119,9 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
         c2.y = mred(t1, b1.y, q, qinv);
         c1.y = cred(mred(t0, b1.y, q, qinv) + mred(t1, b0.y, q, qinv), q);
     }
-    *reinterpret_cast<ulonglong2 *>(A.c0 + bz * A.c0_bs + oo) = c0;
-    *reinterpret_cast<ulonglong2 *>(A.c1 + bz * A.c1_bs + oo) = c1;
-    *reinterpret_cast<ulonglong2 *>(A.c2 + bz * A.c2_bs + oo) = c2;
+    stnt2(A.c0 + bz * A.c0_bs + oo, c0);
+    stnt2(A.c1 + bz * A.c1_bs + oo, c1);
+    stnt2(A.c2 + bz * A.c2_bs + oo, c2);
 }
 hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *scalar, View a0, View a1, View b0, View b1,
                          View c0, View c1, View c2, int batch, hipStream_t s) {
