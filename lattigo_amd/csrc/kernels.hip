@@ -67,8 +67,10 @@ int prof_end(int *counts, float *total_ms) {
     return n;
 }
 
-// Streaming accesses: polynomial data is read once and written once per pass, while twiddle and key rows are shared by the
-// workgroups of a launch -- the non-temporal hint keeps L2 for the latter (measured -3 % on ntt_mac_f64).
+// Streaming accesses: polynomial data is read once per pass, while twiddle and key rows are shared by the workgroups of a
+// launch -- the non-temporal hint on the loads keeps L2 for the latter.  Stores carry the hint only where the consumer is
+// several large kernels away (decomposition, key-switch accumulators, fused epilogues: +3 % on Rotate); the plain NTT passes,
+// the tensor and the element-wise kernels feed the next launch from the infinity cache and lose 2-5 % with it.
 template <class T> __device__ __forceinline__ T ldnt(const T *p) { return __builtin_nontemporal_load(p); }
 template <class T> __device__ __forceinline__ void stnt(T *p, T v) { __builtin_nontemporal_store(v, p); }
 // the 16-byte forms of the two-coefficients-per-thread kernels
@@ -76,11 +78,6 @@ typedef unsigned long long he_u64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ulonglong2 ldnt2(const uint64_t *p) {
     const he_u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const he_u64x2 *>(p));
     return make_ulonglong2(v.x, v.y);
-}
-__device__ __forceinline__ void stnt2(uint64_t *p, ulonglong2 v) {
-    he_u64x2 w;
-    w.x = v.x; w.y = v.y;
-    __builtin_nontemporal_store(w, reinterpret_cast<he_u64x2 *>(p));
 }
 
 // ------------------------------------------------------------------------------------
@@ -353,7 +350,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
                 const int e = k * T + tau;
                 uint64_t v = settle(lds[lds_phys(e)]);
                 if (!lazy) v = v >= q ? v - q : v;
-                stnt(&dst[e], v);
+                dst[e] = v;
             }
         }
     } else {
@@ -387,7 +384,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
         }
         constexpr int sh0 = LOGB - 4;
 #pragma unroll
-        for (int k = 0; k < 16; k++) stnt(&dst[(k << sh0) + tau], x[k]);
+        for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = x[k];
     }
 }
 
@@ -628,7 +625,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int e = k * T + tau;
-                stnt(&dst[e], canon_f64(lds[lds_phys(e)], q, qi));
+                dst[e] = canon_f64(lds[lds_phys(e)], q, qi);
             }
         }
     } else {
@@ -675,7 +672,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             for (int k = 0; k < 16; k++) x[k] = modmul_f64(reduce_f64(x[k], q, qi), ninv, q, qi);
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++) stnt(&dst[(k << sh0) + tau], canon_f64(x[k], q, qi));
+        for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = canon_f64(x[k], q, qi);
     }
     if (bzi + 1 < b1) __syncthreads();  // LDS is reused by the next entry
     }
@@ -1203,7 +1200,7 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
     ulonglong2 o;
     o.x = ew_apply<OP>(xv.x, yv.x, zv.x, m, s, s2);
     o.y = ew_apply<OP>(xv.y, yv.y, zv.y, m, s, s2);
-    stnt2(zp, o);
+    *reinterpret_cast<ulonglong2 *>(zp) = o;
 }
 
 static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
@@ -2119,9 +2116,9 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
         c2.y = mred(t1, b1.y, q, qinv);
         c1.y = cred(mred(t0, b1.y, q, qinv) + mred(t1, b0.y, q, qinv), q);
     }
-    stnt2(A.c0 + bz * A.c0_bs + oo, c0);
-    stnt2(A.c1 + bz * A.c1_bs + oo, c1);
-    stnt2(A.c2 + bz * A.c2_bs + oo, c2);
+    *reinterpret_cast<ulonglong2 *>(A.c0 + bz * A.c0_bs + oo) = c0;
+    *reinterpret_cast<ulonglong2 *>(A.c1 + bz * A.c1_bs + oo) = c1;
+    *reinterpret_cast<ulonglong2 *>(A.c2 + bz * A.c2_bs + oo) = c2;
 }
 hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *scalar, View a0, View a1, View b0, View b1,
                          View c0, View c1, View c2, int batch, hipStream_t s) {
