@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="independent ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="independent ciphertext pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replicate-keys", choices=["none", "rccl", "host"], default="none",
                     help="N > 1: rank 0's relinearisation key is replicated to every rank before the timed region (RCCL broadcast "

@@ -32,7 +32,7 @@ def load(path):
 
 
 sqb, lds = load(sys.argv[1]), load(sys.argv[2])
-out = {"source": "rocprofv3 --pmc (two passes, tools/pmc_sq.sh) on bench.py --steps 3, batch 64; values are per-launch means summed over the 32 shader engines",
+out = {"source": "rocprofv3 --pmc (two passes, tools/pmc_sq.sh) on bench.py --steps 3, default batch; values are per-launch means summed over the 32 shader engines",
        "notes": "SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES saturates at 8 (32 SIMDs per engine, 4-cycle issue): valu_util = that ratio / 8",
        "kernels": {}}
 for f in [x[1] for x in FAM]:
