@@ -1275,7 +1275,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherArgs A) {
     const uint32_t src = A.index[j];
     const uint64_t *in = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N;
     uint64_t *out = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N;
-    const uint64_t v = in[src];
+    const uint64_t v = ldnt(&in[src]);
     if (ADD) out[j] += v; else out[j] = v;
 }
 hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const uint32_t *index, View out, int batch,
@@ -2039,10 +2039,10 @@ __global__ void __launch_bounds__(256) diag_mac_kernel(const DiagMacKArgs A) {
             if (b0 + b < A.batch) {
                 if (pbs != 0) w = pp[(size_t)(b0 + b) * pbs];
                 uint64_t ph, pl;
-                mul64wide(p0[(size_t)(b0 + b) * bs0], w, ph, pl);
+                mul64wide(ldnt(&p0[(size_t)(b0 + b) * bs0]), w, ph, pl);
                 lo0[b] += pl; hi0[b] += ph + (lo0[b] < pl);
                 hi0[b] = hi0[b] >= q ? hi0[b] - q : hi0[b];
-                mul64wide(p1[(size_t)(b0 + b) * bs1], w, ph, pl);
+                mul64wide(ldnt(&p1[(size_t)(b0 + b) * bs1]), w, ph, pl);
                 lo1[b] += pl; hi1[b] += ph + (lo1[b] < pl);
                 hi1[b] = hi1[b] >= q ? hi1[b] - q : hi1[b];
             }
