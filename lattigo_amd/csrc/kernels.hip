@@ -80,6 +80,13 @@ __device__ __forceinline__ ulonglong2 ldnt2(const uint64_t *p) {
     return make_ulonglong2(v.x, v.y);
 }
 
+// XCD-aware work order (MI355X: 8 XCDs with private L2s, workgroup b runs on XCD b % 8): workgroup `lin` of a launch takes
+// work item (lin % 8) * (n / 8) + lin / 8, so that each XCD walks one contiguous eighth of the work list and the workgroups
+// that share a key / twiddle row (consecutive items, batch fastest) hit the same L2.  Identity when n is not a multiple of 8.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned lin, unsigned n) {
+    return (n & 7u) ? lin : (lin & 7u) * (n >> 3) + (lin >> 3);
+}
+
 // ------------------------------------------------------------------------------------
 // butterflies
 // ------------------------------------------------------------------------------------
@@ -702,9 +709,12 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
     __shared__ double lds[N2 + N2 / 16];
 
     const int tau = threadIdx.x;
-    const int row = blockIdx.z;
-    const int l = blockIdx.y;
-    const size_t bz = blockIdx.x;  // batch fastest: workgroups sharing the key / twiddle rows run together
+    // work list = (row, limb, batch) with the batch fastest: workgroups sharing the key / twiddle rows run together, on one XCD
+    const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned w = xcd_swizzle(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nwg);
+    const size_t bz = w % gridDim.x;
+    const int l = (w / gridDim.x) % gridDim.y;
+    const int row = w / (gridDim.x * gridDim.y);
     const int mi = A.m.mod[l];
     const ModConst mc = A.mc[mi];
     const double q = (double)mc.q, qi = mc.rq;
