@@ -325,15 +325,6 @@ int he_lintrans_mul_sum(he_handle eval, int levelQ, int levelP, int n, const he_
                         const he_handle *index, int accumulate, he_handle out0Q, he_handle out0P, he_handle out1Q,
                         he_handle out1P);
 
-/* ---- diagnostics (not part of the reference surface) --------------------------------- */
-/* per-kernel HIP-event timing on the context's stream: begin, run work, end -> per kernel id
- * launch counts and summed durations (bench.py's roofline leg; adds two events per launch) */
-int he_prof_begin(he_handle ctx);
-int he_prof_end(he_handle ctx, int max_kernels, int *counts, float *total_ms, int *n_kernels);
-const char *he_prof_kernel_name(int id);
-/* dependent-MRedLazy throughput probe: returns modular multiplies per second */
-int he_probe_modmul(he_handle ctx, int iters, double *mults_per_s);
-
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("HERING_LIB") or os.path.join(_HERE, "libhering.so")  # HERING_LIB: A/B-test another build
-_HDR = os.path.join(os.path.dirname(_HERE), "include", "hering.h")
+_INC = os.path.join(os.path.dirname(_HERE), "include")
+_HDRS = [os.path.join(_INC, "hering.h"), os.path.join(_INC, "hering_debug.h")]
 
 H = C.c_uint64
 u64p = C.POINTER(C.c_uint64)
@@ -25,8 +26,8 @@ def lib_path() -> str:
 
 
 def declared_symbols() -> list[str]:
-    """Every function include/hering.h declares (used by the CPU-side export test)."""
-    src = open(_HDR).read()
+    """Every function include/*.h declares (used by the CPU-side export test)."""
+    src = "".join(open(h).read() for h in _HDRS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(he_[a-z0-9_]+)\s*\(", src)))
 

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/hering.h"
+#include "../../include/hering_debug.h"
 #include "host_math.h"
 #include "kernels.h"
 
@@ -319,6 +320,8 @@ struct Evk : Obj {
 struct Decomp : Obj {
     std::shared_ptr<Evaluator> ev;
     int batch = 0, beta_max = 0, width = 0;  // width = LQ + LP limbs per digit
+    // what the buffer currently holds: levels of the last he_decompose_ntt / he_decomp_fill (-1: nothing yet)
+    int fillQ = -1, fillP = -1, fill_beta = 0;
     uint64_t *d = nullptr;
     Decomp() : Obj(T_DECOMP) {}
     ~Decomp() override {
@@ -384,6 +387,7 @@ LimbTab ident_tab(int n, int in0 = 0, int out0 = 0, int mod0 = 0) {
 }
 
 int check_poly(const Poly &p, const Ring &r, int level, const char *who) {
+    if (p.ctx != r.ctx) return fail(HE_EINVAL, "%s: the polynomial belongs to another context", who);
     if (p.N != r.N) return fail(HE_EINVAL, "%s: poly degree %d != ring degree %d", who, p.N, r.N);
     if (level < 0 || level >= r.nmod()) return fail(HE_EINVAL, "%s: level %d out of range [0,%d]", who, level, r.nmod() - 1);
     if (p.nlimbs < level + 1) return fail(HE_EINVAL, "%s: poly has %d limbs, level %d needs %d", who, p.nlimbs, level, level + 1);
@@ -625,8 +629,8 @@ int he_poly_download_limb(he_handle h, int b, int limb, uint64_t *dst) {
 int he_poly_copy(he_handle hdst, he_handle hsrc, int level) {
     GET(d, Poly, hdst, T_POLY);
     GET(s, Poly, hsrc, T_POLY);
-    if (d->N != s->N || d->batch != s->batch || level < 0 || d->nlimbs < level + 1 || s->nlimbs < level + 1)
-        return fail(HE_EINVAL, "he_poly_copy: shape mismatch");
+    if (d->N != s->N || d->batch != s->batch || level < 0 || d->nlimbs < level + 1 || s->nlimbs < level + 1 || d->ctx != s->ctx)
+        return fail(HE_EINVAL, "he_poly_copy: shape or context mismatch");
     Scope sc(d->ctx.get());
     HIP_TRY(hipMemcpy2DAsync(d->d, (size_t)d->nlimbs * d->N * 8, s->d, (size_t)s->nlimbs * s->N * 8, (size_t)(level + 1) * d->N * 8,
                              d->batch, hipMemcpyDeviceToDevice, d->ctx->stream));
@@ -1140,6 +1144,7 @@ int modup_between(BasisExtender &be, bool src_is_q, int levelS, int levelD, View
     return HE_OK;
 }
 int check_be_poly(const Poly &p, const BasisExtender &be, int nl, const char *who) {
+    if (p.ctx != be.ctx) return fail(HE_EINVAL, "%s: the polynomial belongs to another context", who);
     if (p.N != be.Q->N || p.nlimbs < nl) return fail(HE_EINVAL, "%s: poly shape mismatch (needs %d limbs of degree %d)", who, nl, be.Q->N);
     return HE_OK;
 }
@@ -1682,6 +1687,7 @@ int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle 
     if (c2->batch != dec->batch) return fail(HE_EINVAL, "he_decompose_ntt: batch mismatch");
     if (base_rns_size(levelQ, levelP) > dec->beta_max) return fail(HE_EINVAL, "he_decompose_ntt: too many digits");
     Scope sc(be.ctx.get());
+    dec->fillQ = levelQ; dec->fillP = levelP; dec->fill_beta = base_rns_size(levelQ, levelP);
     const int B = c2->batch, N = be.Q->N;
     const size_t w = (size_t)B * (levelQ + 1) * N;
     TRY(be.ctx->arena_reserve(w));
@@ -1738,7 +1744,7 @@ int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP
 }
 // class-2 limbs of the gadget product: forward row NTT + key MAC in one kernel (dec holds the post-column state)
 int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View cx,
-               int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch, bool q_out_f64 = false) {
+               int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch, bool q_out_f64 = false, bool own_reduce = true) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     NttMacArgs a{};
@@ -1759,6 +1765,7 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
     a.key_dstride = 2 * a.key_kstride;
     a.own_alpha = own_alpha;
     a.own_nq = levelQ + 1;
+    a.own_reduce = own_reduce ? 1 : 0;
     a.q_out_f64 = 0;
     const View decv{const_cast<uint64_t *>(dec), dec_bs};
     if (!q_out_f64) {
@@ -1826,7 +1833,7 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
             TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B, 1));
             TRY(ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
             if (acc_q_f64) *acc_q_f64 = want_f64;
-            return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64);
+            return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64, !cx_canonical);
         }
         TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B));
         return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
@@ -1921,6 +1928,15 @@ int check_key(const Evaluator &ev, const Evk &k, int &levelQ, const char *who) {
     levelQ = std::min(levelQ, k.nQk - 1);  // utils.Min(levelQ, gadgetCt.LevelQ())
     return HE_OK;
 }
+// a hoisting buffer is only meaningful for the evaluator and the (levelQ, levelP) digits it was filled at
+int check_decomp(const Evaluator &ev, const Decomp &dec, int levelQ, int levelP, const char *who) {
+    if (dec.ev.get() != &ev) return fail(HE_EINVAL, "%s: decomposition buffer belongs to another evaluator", who);
+    if (dec.fillQ < 0) return fail(HE_EINVAL, "%s: decomposition buffer was never filled", who);
+    if (levelP != dec.fillP || levelQ > dec.fillQ || base_rns_size(levelQ, levelP) > dec.fill_beta)
+        return fail(HE_EINVAL, "%s: decomposition buffer holds %d digits of level (%d,%d), (%d,%d) requested", who, dec.fill_beta,
+                    dec.fillQ, dec.fillP, levelQ, levelP);
+    return HE_OK;
+}
 }  // namespace
 
 int he_gadget_product_lazy(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
@@ -1943,6 +1959,7 @@ int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he
     BasisExtender &be = *ev->be;
     TRY(check_key(*ev, *k, levelQ, "he_gadget_product_hoisted_lazy"));
     if (k->pw2) return fail(HE_EINVAL, "he_gadget_product_hoisted_lazy: method is unsupported for BaseTwoDecomposition != 0");
+    TRY(check_decomp(*ev, *dec, levelQ, k->nPk - 1, "he_gadget_product_hoisted_lazy"));
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, dec->batch, o, "he_gadget_product_hoisted_lazy"));
     Scope sc(be.ctx.get());
@@ -1996,6 +2013,7 @@ int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle
     NttEpilogue epi;
     for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
     epi.y = p1q->view(); epi.has_w = false; epi.w = p1q->view();
+    epi.y_reduce = true;  // p1Q is the caller's: any 64-bit word
     HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, p2->view(), B, false, 0, st, &epi));
     return HE_OK;
 }
@@ -2025,6 +2043,7 @@ int he_gadget_product_hoisted(he_handle hev, int levelQ, he_handle hdec, he_hand
     BasisExtender &be = *ev->be;
     TRY(check_key(*ev, *k, levelQ, "he_gadget_product_hoisted"));
     if (k->pw2) return fail(HE_EINVAL, "he_gadget_product_hoisted: method is unsupported for BaseTwoDecomposition != 0");
+    TRY(check_decomp(*ev, *dec, levelQ, k->nPk - 1, "he_gadget_product_hoisted"));
     TRY(check_be_poly(*out0, be, levelQ + 1, "he_gadget_product_hoisted"));
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product_hoisted"));
     if (out0->batch != dec->batch || out1->batch != dec->batch) return fail(HE_EINVAL, "he_gadget_product_hoisted: batch mismatch");
@@ -2078,6 +2097,7 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     if (out0->batch != B || out1->batch != B || (in1 && in1->batch != B) || (dec && dec->batch != B)) return fail(HE_EINVAL, "%s: batch mismatch", who);
     if (!(gal & 1)) return fail(HE_EINVAL, "%s: Galois element must be odd", who);
     if (dec && k->pw2) return fail(HE_EINVAL, "%s: method is unsupported for BaseTwoDecomposition != 0", who);
+    if (dec) TRY(check_decomp(*ev, *dec, level, k->nPk - 1, who));
     Scope sc(be.ctx.get());
     const int N = be.Q->N;
     const size_t wQ = (size_t)B * (level + 1) * N;
@@ -2115,6 +2135,7 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     if (k->ev.get() != ev.get()) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: key belongs to another evaluator");
     if (k->pw2) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: method is unsupported for BaseTwoDecomposition != 0");
     if (!(gal & 1)) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: Galois element must be odd");
+    TRY(check_decomp(*ev, *dec, levelQ, levelP, "he_automorphism_hoisted_lazy"));
     TRY(check_be_poly(*in0, be, levelQ + 1, "he_automorphism_hoisted_lazy"));
     if (in0->batch != B) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: batch mismatch");
     QPOut o;
@@ -2187,6 +2208,7 @@ int he_decomp_fill(he_handle hdec, int levelQ, int levelP, he_handle hq, he_hand
     TRY(check_be_poly(*sp, be, levelP + 1, who));
     if (sq->batch != d->batch || sp->batch != d->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
     Scope sc(be.ctx.get());
+    d->fillQ = levelQ; d->fillP = levelP; d->fill_beta = d->beta_max;
     const size_t N = be.Q->N;
     for (int dg = 0; dg < d->beta_max; dg++) {
         uint64_t *base = d->d + (size_t)dg * d->dstride();
@@ -2334,7 +2356,7 @@ int he_prof_begin(he_handle hctx) {
     GET(c, Ctx, hctx, T_CTX);
     Scope sc(c.get());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    prof_begin();
+    prof_begin(c->stream);
     return HE_OK;
 }
 int he_prof_end(he_handle hctx, int max_kernels, int *counts, float *total_ms, int *n_kernels) {
@@ -2342,7 +2364,7 @@ int he_prof_end(he_handle hctx, int max_kernels, int *counts, float *total_ms, i
     if (!counts || !total_ms || max_kernels < K_COUNT) return fail(HE_EINVAL, "he_prof_end: need room for %d kernels", (int)K_COUNT);
     Scope sc(c.get());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    prof_end(counts, total_ms);
+    prof_end(c->stream, counts, total_ms);
     if (n_kernels) *n_kernels = K_COUNT;
     return HE_OK;
 }

@@ -59,6 +59,8 @@ struct NttEpilogue {
     // the limbs handled by the double-precision kernel hold y as IEEE doubles (integers, |y| < q) -- the accumulators
     // ntt_mac_f64 wrote with q_out_f64
     bool y_small_f64 = false;
+    // y is caller-supplied (arbitrary 64-bit words): the double-precision kernel reduces it before converting
+    bool y_reduce = false;
     // optional second output set: batch entries >= zsplit use (out2, y2, w2) with index z - zsplit
     // (both components of a ciphertext in one launch)
     int zsplit = 0;
@@ -226,6 +228,7 @@ struct NttMacArgs {
     uint8_t dec_limb[kMaxLimbs], key_limb[kMaxLimbs], out_limb[kMaxLimbs], out_view[kMaxLimbs], mod[kMaxLimbs];
     size_t dec_dstride, key_kstride, key_dstride;
     int own_alpha, own_nq;
+    int own_reduce;  // the own-digit words are caller-supplied (any uint64): reduce them before the conversion to double
     int q_out_f64;   // Q-limb accumulators are written as IEEE doubles (exact integers, |x| < q) for the f64 ModDown epilogue
 };
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
@@ -247,8 +250,8 @@ enum KernelId {
     K_NTT_MAC_F64, K_DIAG_MAC, K_COUNT
 };
 const char *kernel_name(int id);
-void prof_begin();                                   // start recording (one stream at a time)
-int prof_end(int *counts, float *total_ms);          // stop, sync events, fill [K_COUNT] arrays
+void prof_begin(hipStream_t s);                                // start recording the launches enqueued on stream s
+int prof_end(hipStream_t s, int *counts, float *total_ms);     // stop, sync events, fill [K_COUNT] arrays
 
 // throughput probe used by bench.py --microbench (not on the product path)
 hipError_t launch_modmul_probe(uint64_t *buf, size_t n, int iters, uint64_t q, uint64_t qinv, hipStream_t s);

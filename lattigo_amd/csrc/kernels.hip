@@ -15,7 +15,10 @@
 // outputs are promised (SURVEY.md section 8a note on lazy ranges).
 #include "kernels.h"
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace he {
@@ -24,11 +27,15 @@ namespace he {
 // optional per-launch HIP-event timing (off by default; bench.py's roofline leg turns it on)
 // ------------------------------------------------------------------------------------
 namespace {
+// Profiling state is per stream (= per context, see api.cpp) behind one mutex: two contexts may launch from different
+// threads while one of them is being profiled; a launch looks its own stream up and records only there.
 struct ProfRec { int id; hipEvent_t e0, e1; };
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof_recs;
-std::vector<hipEvent_t> g_prof_pool;
-hipEvent_t prof_event() {
+struct ProfState { std::vector<ProfRec> recs; };
+std::mutex g_prof_mu;
+std::atomic<int> g_prof_active{0};                       // number of streams being profiled (fast path: none)
+std::unordered_map<hipStream_t, ProfState> g_prof;       // guarded by g_prof_mu
+std::vector<hipEvent_t> g_prof_pool;                     // guarded by g_prof_mu
+hipEvent_t prof_event_locked() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e;
     (void)hipEventCreate(&e);
@@ -36,11 +43,22 @@ hipEvent_t prof_event() {
 }
 struct ProfScope {
     bool on; int id; hipStream_t s; hipEvent_t e0;
-    ProfScope(int id_, hipStream_t s_) : on(g_prof_on), id(id_), s(s_), e0(nullptr) {
-        if (on) { e0 = prof_event(); (void)hipEventRecord(e0, s); }
+    ProfScope(int id_, hipStream_t s_) : on(false), id(id_), s(s_), e0(nullptr) {
+        if (g_prof_active.load(std::memory_order_relaxed) == 0) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof.find(s) == g_prof.end()) return;
+        on = true;
+        e0 = prof_event_locked();
+        (void)hipEventRecord(e0, s);
     }
     ~ProfScope() {
-        if (on) { hipEvent_t e1 = prof_event(); (void)hipEventRecord(e1, s); g_prof_recs.push_back(ProfRec{id, e0, e1}); }
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        auto it = g_prof.find(s);
+        hipEvent_t e1 = prof_event_locked();
+        (void)hipEventRecord(e1, s);
+        if (it != g_prof.end()) it->second.recs.push_back(ProfRec{id, e0, e1});
+        else { g_prof_pool.push_back(e0); g_prof_pool.push_back(e1); }
     }
 };
 }  // namespace
@@ -51,20 +69,33 @@ const char *kernel_name(int id) {
                                          "ntt_rows_inv_f64", "ntt_mac_f64", "diag_mac"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
-void prof_begin() { g_prof_recs.clear(); g_prof_on = true; }
-int prof_end(int *counts, float *total_ms) {
-    g_prof_on = false;
+void prof_begin(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto ins = g_prof.emplace(s, ProfState{});
+    if (ins.second) g_prof_active.fetch_add(1);
+    for (auto &r : ins.first->second.recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }  // a begin without an end
+    ins.first->second.recs.clear();
+}
+int prof_end(hipStream_t s, int *counts, float *total_ms) {
     for (int i = 0; i < K_COUNT; i++) { counts[i] = 0; total_ms[i] = 0.f; }
-    for (auto &r : g_prof_recs) {
+    std::vector<ProfRec> recs;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        auto it = g_prof.find(s);
+        if (it == g_prof.end()) return 0;
+        recs.swap(it->second.recs);
+        g_prof.erase(it);
+        g_prof_active.fetch_sub(1);
+    }
+    for (auto &r : recs) {
         float ms = 0.f;
         (void)hipEventSynchronize(r.e1);
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         counts[r.id]++; total_ms[r.id] += ms;
-        g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1);
     }
-    int n = (int)g_prof_recs.size();
-    g_prof_recs.clear();
-    return n;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+    return (int)recs.size();
 }
 
 // Streaming accesses: polynomial data is read once per pass, while twiddle and key rows are shared by the workgroups of a
@@ -148,6 +179,7 @@ struct NttArgs {
     const uint64_t *epi_y2, *epi_w2;
     size_t epi_y2_bs, epi_w2_bs;
     int epi_y_f64;  // f64 kernel only: y holds doubles
+    int epi_y_reduce;  // f64 kernel only: y holds arbitrary 64-bit words (reduced before the conversion to double)
     int nbatch, iters;  // f64 kernel only: a workgroup transforms batch entries blockIdx.x * iters ... (+ iters - 1) of its row
 };
 
@@ -607,6 +639,9 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             if (A.epi_y_f64) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) yv[k] = ldnt(&reinterpret_cast<const double *>(yp)[k * T + tau]);
+            } else if (A.epi_y_reduce) {  // caller-supplied y: any uint64
+#pragma unroll
+                for (int k = 0; k < 16; k++) yv[k] = u52_to_f64(bred_add_lazy(ldnt(&yp[k * T + tau]), mc.q, mc.brc0));
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; k++) yv[k] = u52_to_f64(ldnt(&yp[k * T + tau]));
@@ -748,6 +783,10 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
     for (int d = 0; d < A.m.beta; d++) {
         const bool is_own = own_digit(d);
         double x[16];
+        if (is_own && A.m.own_reduce) {  // caller-supplied words (any uint64, as MulCoeffsMontgomeryLazy accepts): bring them below 2^52
+#pragma unroll
+            for (int k = 0; k < 16; k++) nx[k] = bred_add_lazy(nx[k], mc.q, mc.brc0);
+        }
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = u52_to_f64(nx[k]);
         if (d + 1 < A.m.beta) {
@@ -1006,7 +1045,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     A.tab = tab;
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
-    A.epi_y_f64 = 0;
+    A.epi_y_f64 = 0; A.epi_y_reduce = 0;
     dim3 grows(batch, tab.n, 1u << a);
     dim3 gcols((unsigned)(((r.N >> a) + 255) / 256), tab.n, batch);
     hipError_t e;
@@ -1057,9 +1096,10 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
-    A.epi_y_f64 = 0;
+    A.epi_y_f64 = 0; A.epi_y_reduce = 0;
     if (epi) {
         A.epi_y_f64 = epi->y_small_f64 ? 1 : 0;
+        A.epi_y_reduce = epi->y_reduce ? 1 : 0;
         A.epi = epi->has_w ? 2 : 1;
         A.epi_y = epi->y.p; A.epi_y_bs = epi->y.bstride;
         A.epi_w = epi->w.p; A.epi_w_bs = epi->w.bstride;

@@ -24,6 +24,41 @@ const char *lo_last_error(void) { return lo_err; }
 static inline uint64_t mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) >> 64); }
 
 /* ========================================================================== */
+/* Scratch pool                                                                */
+/* ========================================================================== */
+/* The reference draws every temporary polynomial from sync.Pool-backed buffer pools
+ * (ring/pool.go:17, core/rlwe/pool.go:17): a steady-state evaluator call allocates
+ * nothing.  Same here: per-thread free lists keyed by size, so that the timed CPU
+ * baseline (bench.py) does not spend its time in mmap/munmap and page faults. */
+#define POOL_SLOTS 96
+typedef struct { size_t sz, pad; } pool_hdr;
+static __thread struct { size_t sz; void *p; } pool_free_list[POOL_SLOTS];
+static void *pool_get(size_t bytes) {
+    for (int i = 0; i < POOL_SLOTS; i++)
+        if (pool_free_list[i].p && pool_free_list[i].sz == bytes) {
+            void *p = pool_free_list[i].p;
+            pool_free_list[i].p = NULL;
+            return p;
+        }
+    pool_hdr *h = (pool_hdr *)malloc(sizeof(pool_hdr) + bytes);
+    if (!h) return NULL;
+    h->sz = bytes;
+    return h + 1;
+}
+static void pool_put(void *p) {
+    if (!p) return;
+    pool_hdr *h = (pool_hdr *)p - 1;
+    for (int i = 0; i < POOL_SLOTS; i++)
+        if (!pool_free_list[i].p) { pool_free_list[i].p = p; pool_free_list[i].sz = h->sz; return; }
+    free(h);
+}
+/* returns the calling thread's cached scratch to the allocator */
+void lo_pool_release(void) {
+    for (int i = 0; i < POOL_SLOTS; i++)
+        if (pool_free_list[i].p) { free((pool_hdr *)pool_free_list[i].p - 1); pool_free_list[i].p = NULL; }
+}
+
+/* ========================================================================== */
 /* Scalars: ring/modular_reduction.go                                          */
 /* ========================================================================== */
 
@@ -506,10 +541,10 @@ static void intt_ci_core_lazy(const uint64_t *p1, uint64_t *p2, int N, uint64_t 
 void lo_subring_ntt(const lo_subring *s, const uint64_t *p1, uint64_t *p2, int lazy) {
     if (s->nthroot == 4 * (uint64_t)s->N) {
         if (p1 == p2) {  /* the fold reads p1[N-j] after p2[j] is written: go through a copy like a caller would */
-            uint64_t *tmp = (uint64_t *)malloc((size_t)s->N * 8);
+            uint64_t *tmp = (uint64_t *)pool_get((size_t)s->N * 8);
             memcpy(tmp, p1, (size_t)s->N * 8);
             ntt_ci_core_lazy(tmp, p2, s->N, s->q, s->qinv, s->roots_fwd);
-            free(tmp);
+            pool_put(tmp);
         } else ntt_ci_core_lazy(p1, p2, s->N, s->q, s->qinv, s->roots_fwd);
         if (!lazy) for (int i = 0; i < s->N; i++) p2[i] = lo_bred_add(p2[i], s->q, s->brc);
         return;
@@ -673,13 +708,13 @@ static void sub_then_mul_scalar_mont_2q(const lo_subring *s, const uint64_t *x, 
 /* DivFloorByLastModulusNTT, ring/scaling.go:6-23 */
 void lo_div_floor_by_last_modulus_ntt(const lo_ring *r, int level, const uint64_t *p0, uint64_t *p1) {
     int N = r->N;
-    uint64_t *b0 = (uint64_t *)malloc(N * 8), *b1 = (uint64_t *)malloc(N * 8);
+    uint64_t *b0 = (uint64_t *)pool_get(N * 8), *b1 = (uint64_t *)pool_get(N * 8);
     lo_subring_intt(r->s[level], p0 + (size_t)level * N, b0, 1);
     for (int i = 0; i < level; i++) {
         lo_subring_ntt(r->s[i], b0, b1, 1);
         sub_then_mul_scalar_mont_2q(r->s[i], b1, p0 + (size_t)i * N, r->rescale[level - 1][i], p1 + (size_t)i * N);
     }
-    free(b0); free(b1);
+    pool_put(b0); pool_put(b1);
 }
 /* DivFloorByLastModulus, :26-34 */
 void lo_div_floor_by_last_modulus(const lo_ring *r, int level, const uint64_t *p0, uint64_t *p1) {
@@ -690,7 +725,7 @@ void lo_div_floor_by_last_modulus(const lo_ring *r, int level, const uint64_t *p
 /* DivRoundByLastModulusNTT, :101-122 */
 void lo_div_round_by_last_modulus_ntt(const lo_ring *r, int level, const uint64_t *p0, uint64_t *p1) {
     int N = r->N;
-    uint64_t *b0 = (uint64_t *)malloc(N * 8), *b1 = (uint64_t *)malloc(N * 8);
+    uint64_t *b0 = (uint64_t *)pool_get(N * 8), *b1 = (uint64_t *)pool_get(N * 8);
     const lo_subring *sl = r->s[level];
     lo_subring_intt(sl, p0 + (size_t)level * N, b0, 1);
     uint64_t phalf = (sl->q - 1) >> 1;
@@ -702,12 +737,12 @@ void lo_div_round_by_last_modulus_ntt(const lo_ring *r, int level, const uint64_
         lo_subring_ntt(s, b1, b1, 1);
         sub_then_mul_scalar_mont_2q(s, b1, p0 + (size_t)i * N, r->rescale[level - 1][i], p1 + (size_t)i * N);
     }
-    free(b0); free(b1);
+    pool_put(b0); pool_put(b1);
 }
 /* DivRoundByLastModulus, :126-144 */
 void lo_div_round_by_last_modulus(const lo_ring *r, int level, const uint64_t *p0, uint64_t *p1) {
     int N = r->N;
-    uint64_t *b0 = (uint64_t *)malloc(N * 8);
+    uint64_t *b0 = (uint64_t *)pool_get(N * 8);
     const lo_subring *sl = r->s[level];
     uint64_t phalf = (sl->q - 1) >> 1;
     for (int j = 0; j < N; j++) b0[j] = lo_cred(p0[(size_t)level * N + j] + phalf, sl->q);
@@ -720,19 +755,19 @@ void lo_div_round_by_last_modulus(const lo_ring *r, int level, const uint64_t *p
             p1[(size_t)i * N + j] = lo_mred(b0[j] + b1, rc, s->q, s->qinv);     /* vec_ops.go:542 */
         }
     }
-    free(b0);
+    pool_put(b0);
 }
 /* DivRoundByLastModulusManyNTT, :148-174 */
 void lo_div_round_by_last_modulus_many_ntt(const lo_ring *r, int level, int nb, const uint64_t *p0, uint64_t *p1) {
     int N = r->N;
     if (nb == 0) { if (p0 != p1) memcpy(p1, p0, (size_t)(level + 1) * N * 8); return; }
     if (nb > 1) {
-        uint64_t *buff = (uint64_t *)malloc((size_t)(level + 1) * N * 8);
+        uint64_t *buff = (uint64_t *)pool_get((size_t)(level + 1) * N * 8);
         lo_intt(r, level, p0, buff);
         int lv = level;
         for (int i = 0; i < nb; i++) { lo_div_round_by_last_modulus(r, lv, buff, buff); lv--; }
         lo_ntt(r, lv, buff, p1);
-        free(buff);
+        pool_put(buff);
     } else {
         lo_div_round_by_last_modulus_ntt(r, level, p0, p1);
     }
@@ -742,7 +777,7 @@ void lo_div_round_by_last_modulus_many(const lo_ring *r, int level, int nb, cons
     int N = r->N;
     if (nb == 0) { if (p0 != p1) memcpy(p1, p0, (size_t)(level + 1) * N * 8); return; }
     if (nb > 1) {
-        uint64_t *buff = (uint64_t *)malloc((size_t)(level + 1) * N * 8);
+        uint64_t *buff = (uint64_t *)pool_get((size_t)(level + 1) * N * 8);
         int lv = level;
         lo_div_round_by_last_modulus(r, lv, p0, buff); lv--;
         for (int i = 1; i < nb; i++) {
@@ -750,7 +785,7 @@ void lo_div_round_by_last_modulus_many(const lo_ring *r, int level, int nb, cons
             else lo_div_round_by_last_modulus(r, lv, buff, buff);
             lv--;
         }
-        free(buff);
+        pool_put(buff);
     } else {
         lo_div_round_by_last_modulus(r, level, p0, p1);
     }
@@ -759,19 +794,19 @@ void lo_div_round_by_last_modulus_many(const lo_ring *r, int level, int nb, cons
 void lo_div_floor_by_last_modulus_many_ntt(const lo_ring *r, int level, int nb, const uint64_t *p0, uint64_t *p1) {
     int N = r->N;
     if (nb == 0) { if (p0 != p1) memcpy(p1, p0, (size_t)(level + 1) * N * 8); return; }
-    uint64_t *buff = (uint64_t *)malloc((size_t)(level + 1) * N * 8);
+    uint64_t *buff = (uint64_t *)pool_get((size_t)(level + 1) * N * 8);
     lo_intt(r, level, p0, buff);
     int lv = level;
     for (int i = 0; i < nb; i++) { lo_div_floor_by_last_modulus(r, lv, buff, buff); lv--; }
     lo_ntt(r, lv, buff, p1);
-    free(buff);
+    pool_put(buff);
 }
 /* DivFloorByLastModulusMany, :65-99 */
 void lo_div_floor_by_last_modulus_many(const lo_ring *r, int level, int nb, const uint64_t *p0, uint64_t *p1) {
     int N = r->N;
     if (nb == 0) { if (p0 != p1) memcpy(p1, p0, (size_t)(level + 1) * N * 8); return; }
     if (nb > 1) {
-        uint64_t *buff = (uint64_t *)malloc((size_t)(level + 1) * N * 8);
+        uint64_t *buff = (uint64_t *)pool_get((size_t)(level + 1) * N * 8);
         int lv = level;
         lo_div_floor_by_last_modulus(r, lv, p0, buff); lv--;
         for (int i = 1; i < nb; i++) {
@@ -779,7 +814,7 @@ void lo_div_floor_by_last_modulus_many(const lo_ring *r, int level, int nb, cons
             else lo_div_floor_by_last_modulus(r, lv, buff, buff);
             lv--;
         }
-        free(buff);
+        pool_put(buff);
     } else {
         lo_div_floor_by_last_modulus(r, level, p0, p1);
     }
@@ -962,11 +997,11 @@ void lo_modup_q_to_p(const lo_basis_extender *be, int levelQ, int levelP, const 
     uint64_t mods[64], half[64];
     ring_moduli(be->ringQ, mods);
     int nw = moduli_product_half(mods, levelQ + 1, half);
-    uint64_t *buff = (uint64_t *)malloc((size_t)(levelQ + 1) * N * 8);
+    uint64_t *buff = (uint64_t *)pool_get((size_t)(levelQ + 1) * N * 8);
     lo_add_scalar_bigint(be->ringQ, levelQ, polQ, half, nw, buff);
     modup_exact(buff, levelQ + 1, polP, levelP + 1, N, be->ringQ, be->ringP, be->qtop[levelQ]);
     lo_sub_scalar_bigint(be->ringP, levelP, polP, half, nw, polP);
-    free(buff);
+    pool_put(buff);
 }
 /* ModUpPtoQ, :195-210 */
 void lo_modup_p_to_q(const lo_basis_extender *be, int levelP, int levelQ, const uint64_t *polP, uint64_t *polQ) {
@@ -974,28 +1009,28 @@ void lo_modup_p_to_q(const lo_basis_extender *be, int levelP, int levelQ, const 
     uint64_t mods[64], half[64];
     ring_moduli(be->ringP, mods);
     int nw = moduli_product_half(mods, levelP + 1, half);
-    uint64_t *buff = (uint64_t *)malloc((size_t)(levelP + 1) * N * 8);
+    uint64_t *buff = (uint64_t *)pool_get((size_t)(levelP + 1) * N * 8);
     lo_add_scalar_bigint(be->ringP, levelP, polP, half, nw, buff);
     modup_exact(buff, levelP + 1, polQ, levelQ + 1, N, be->ringP, be->ringQ, be->ptoq[levelP]);
     lo_sub_scalar_bigint(be->ringQ, levelQ, polQ, half, nw, polQ);
-    free(buff);
+    pool_put(buff);
 }
 /* ModDownQPtoQ, :215-230 */
 void lo_moddown_qp_to_q(const lo_basis_extender *be, int levelQ, int levelP, const uint64_t *p1Q, const uint64_t *p1P, uint64_t *p2Q) {
     int N = be->ringQ->N;
-    uint64_t *buffQ = (uint64_t *)malloc((size_t)(levelQ + 1) * N * 8);
+    uint64_t *buffQ = (uint64_t *)pool_get((size_t)(levelQ + 1) * N * 8);
     lo_modup_p_to_q(be, levelP, levelQ, p1P, buffQ);
     for (int i = 0; i <= levelQ; i++) {
         const lo_subring *s = be->ringQ->s[i];
         sub_then_mul_scalar_mont_2q(s, buffQ + (size_t)i * N, p1Q + (size_t)i * N, s->q - be->moddown_ptoq[levelP][i], p2Q + (size_t)i * N);
     }
-    free(buffQ);
+    pool_put(buffQ);
 }
 /* ModDownQPtoQNTT, :235-256 */
 void lo_moddown_qp_to_q_ntt(const lo_basis_extender *be, int levelQ, int levelP, const uint64_t *p1Q, const uint64_t *p1P, uint64_t *p2Q) {
     int N = be->ringQ->N;
-    uint64_t *buffP = (uint64_t *)malloc((size_t)(levelP + 1) * N * 8);
-    uint64_t *buffQ = (uint64_t *)malloc((size_t)(levelQ + 1) * N * 8);
+    uint64_t *buffP = (uint64_t *)pool_get((size_t)(levelP + 1) * N * 8);
+    uint64_t *buffQ = (uint64_t *)pool_get((size_t)(levelQ + 1) * N * 8);
     lo_intt_lazy(be->ringP, levelP, p1P, buffP);
     lo_modup_p_to_q(be, levelP, levelQ, buffP, buffQ);
     lo_ntt_lazy(be->ringQ, levelQ, buffQ, buffQ);
@@ -1003,18 +1038,18 @@ void lo_moddown_qp_to_q_ntt(const lo_basis_extender *be, int levelQ, int levelP,
         const lo_subring *s = be->ringQ->s[i];
         sub_then_mul_scalar_mont_2q(s, buffQ + (size_t)i * N, p1Q + (size_t)i * N, s->q - be->moddown_ptoq[levelP][i], p2Q + (size_t)i * N);
     }
-    free(buffP); free(buffQ);
+    pool_put(buffP); pool_put(buffQ);
 }
 /* ModDownQPtoP, :262-277 */
 void lo_moddown_qp_to_p(const lo_basis_extender *be, int levelQ, int levelP, const uint64_t *p1Q, const uint64_t *p1P, uint64_t *p2P) {
     int N = be->ringQ->N;
-    uint64_t *buffP = (uint64_t *)malloc((size_t)(levelP + 1) * N * 8);
+    uint64_t *buffP = (uint64_t *)pool_get((size_t)(levelP + 1) * N * 8);
     lo_modup_q_to_p(be, levelQ, levelP, p1Q, buffP);
     for (int i = 0; i <= levelP; i++) {
         const lo_subring *s = be->ringP->s[i];
         sub_then_mul_scalar_mont_2q(s, buffP + (size_t)i * N, p1P + (size_t)i * N, s->q - be->moddown_qtop[levelQ][i], p2P + (size_t)i * N);
     }
-    free(buffP);
+    pool_put(buffP);
 }
 
 /* NewDecomposer, :320-377 */
@@ -1191,14 +1226,14 @@ void lo_decompose_ntt(const lo_evaluator *e, int levelQ, int levelP, int nbPi, c
                       uint64_t *decompQ, uint64_t *decompP) {
     int N = e->ringQ->N;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
-    uint64_t *buff = (uint64_t *)malloc(szQ * 8);
+    uint64_t *buff = (uint64_t *)pool_get(szQ * 8);
     const uint64_t *polyNTT, *polyInvNTT;
     if (c2_is_ntt) { polyNTT = c2; lo_intt(e->ringQ, levelQ, c2, buff); polyInvNTT = buff; }
     else { polyInvNTT = c2; lo_ntt(e->ringQ, levelQ, c2, buff); polyNTT = buff; }
     int beta = lo_base_rns_decomposition_vector_size(levelQ, levelP);
     for (int i = 0; i < beta; i++)
         decompose_single_ntt(e, levelQ, levelP, nbPi, i, polyNTT, polyInvNTT, decompQ + i * szQ, decompP + i * szP);
-    free(buff);
+    pool_put(buff);
 }
 
 static void reduce_poly(const lo_ring *r, int level, uint64_t *p) { lo_unop(r, level, LO_REDUCE, p, p); }
@@ -1237,8 +1272,8 @@ static void gadget_product_multiple_p_lazy(const lo_evaluator *e, int levelQ, co
                                            uint64_t *ctQ, uint64_t *ctP) {
     int N = e->ringQ->N, levelP = evk->nPk - 1;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
-    uint64_t *cxInv = (uint64_t *)malloc(szQ * 8);
-    uint64_t *c2Q = (uint64_t *)malloc(szQ * 8), *c2P = (uint64_t *)malloc(szP * 8);
+    uint64_t *cxInv = (uint64_t *)pool_get(szQ * 8);
+    uint64_t *c2Q = (uint64_t *)pool_get(szQ * 8), *c2P = (uint64_t *)pool_get(szP * 8);
     lo_intt(e->ringQ, levelQ, cx, cxInv);
     int beta = lo_base_rns_decomposition_vector_size(levelQ, levelP);
     int QiOverF = overflow_margin(e->ringQ, levelQ) >> 1, PiOverF = overflow_margin(e->ringP, levelP) >> 1;
@@ -1250,7 +1285,7 @@ static void gadget_product_multiple_p_lazy(const lo_evaluator *e, int levelQ, co
         reduce++;
     }
     final_reduce(e, levelQ, levelP, reduce, QiOverF, PiOverF, ctQ, ctP);
-    free(cxInv); free(c2Q); free(c2P);
+    pool_put(cxInv); pool_put(c2Q); pool_put(c2P);
 }
 /* gadgetProductSinglePAndBitDecompLazy, :203-338 (ctQP.IsNTT = true): one RNS digit per Q-limb, and for a
  * base-2 gadget (BaseTwoDecomposition = pw2 != 0) one bit window (x >> j*pw2) & mask per stored block */
@@ -1258,9 +1293,9 @@ static void gadget_product_single_p_lazy(const lo_evaluator *e, int levelQ, cons
                                          uint64_t *ctQ, uint64_t *ctP) {
     int N = e->ringQ->N, levelP = evk->nPk - 1;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
-    uint64_t *cxInv = (uint64_t *)malloc(szQ * 8);
-    uint64_t *c2Q = (uint64_t *)malloc(szQ * 8), *c2P = (uint64_t *)malloc(szP * 8);
-    uint64_t *cw = (uint64_t *)malloc((size_t)N * 8), *cwNTT = (uint64_t *)malloc((size_t)N * 8);
+    uint64_t *cxInv = (uint64_t *)pool_get(szQ * 8);
+    uint64_t *c2Q = (uint64_t *)pool_get(szQ * 8), *c2P = (uint64_t *)pool_get(szP * 8);
+    uint64_t *cw = (uint64_t *)pool_get((size_t)N * 8), *cwNTT = (uint64_t *)pool_get((size_t)N * 8);
     lo_intt(e->ringQ, levelQ, cx, cxInv);
     int pw2 = evk->pw2;
     uint64_t mask = pw2 ? (((uint64_t)1 << pw2) - 1) : 0;
@@ -1298,7 +1333,7 @@ static void gadget_product_single_p_lazy(const lo_evaluator *e, int levelQ, cons
         }
     }
     final_reduce(e, levelQ, levelP, reduce, QiOverF, PiOverF, ctQ, ctP);
-    free(cxInv); free(c2Q); free(c2P); free(cw); free(cwNTT);
+    pool_put(cxInv); pool_put(c2Q); pool_put(c2P); pool_put(cw); pool_put(cwNTT);
 }
 /* GadgetProductLazy, :108-127 */
 void lo_gadget_product_lazy(const lo_evaluator *e, int levelQ, const uint64_t *cx, const lo_evk *evk,
@@ -1333,57 +1368,57 @@ void lo_gadget_product(const lo_evaluator *e, int levelQ, const uint64_t *cx, co
     int N = e->ringQ->N, levelP = evk->nPk - 1;
     if (levelQ > evk->nQk - 1) levelQ = evk->nQk - 1;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
-    uint64_t *ctQ = (uint64_t *)malloc(2 * szQ * 8), *ctP = (uint64_t *)malloc(2 * szP * 8);
+    uint64_t *ctQ = (uint64_t *)pool_get(2 * szQ * 8), *ctP = (uint64_t *)pool_get(2 * szP * 8);
     lo_gadget_product_lazy(e, levelQ, cx, evk, ctQ, ctP);
     lo_moddown_ntt(e, levelQ, levelP, ctQ, ctP, ct);
-    free(ctQ); free(ctP);
+    pool_put(ctQ); pool_put(ctP);
 }
 /* GadgetProductHoisted, :348-368 */
 void lo_gadget_product_hoisted(const lo_evaluator *e, int levelQ, const uint64_t *decompQ, const uint64_t *decompP,
                                const lo_evk *evk, uint64_t *ct) {
     int N = e->ringQ->N, levelP = evk->nPk - 1;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
-    uint64_t *ctQ = (uint64_t *)malloc(2 * szQ * 8), *ctP = (uint64_t *)malloc(2 * szP * 8);
+    uint64_t *ctQ = (uint64_t *)pool_get(2 * szQ * 8), *ctP = (uint64_t *)pool_get(2 * szP * 8);
     lo_gadget_product_hoisted_lazy(e, levelQ, decompQ, decompP, evk, ctQ, ctP);
     lo_moddown_ntt(e, levelQ, levelP, ctQ, ctP, ct);
-    free(ctQ); free(ctP);
+    pool_put(ctQ); pool_put(ctP);
 }
 /* Relinearize, core/rlwe/evaluator_evaluationkey.go:117-148 */
 void lo_relinearize(const lo_evaluator *e, int level, const uint64_t *ct_in, const lo_evk *rlk, uint64_t *ct_out) {
     int N = e->ringQ->N;
     size_t sz = (size_t)(level + 1) * N;
-    uint64_t *tmp = (uint64_t *)malloc(2 * sz * 8);
+    uint64_t *tmp = (uint64_t *)pool_get(2 * sz * 8);
     lo_gadget_product(e, level, ct_in + 2 * sz, rlk, tmp);
     lo_binop(e->ringQ, level, LO_ADD, ct_in, tmp, ct_out);
     lo_binop(e->ringQ, level, LO_ADD, ct_in + sz, tmp + sz, ct_out + sz);
-    free(tmp);
+    pool_put(tmp);
 }
 /* Automorphism, core/rlwe/evaluator_automorphism.go:13-54 (ctIn.IsNTT) */
 void lo_automorphism_ct(const lo_evaluator *e, int level, const uint64_t *ct_in, uint64_t galel, const lo_evk *gk, uint64_t *ct_out) {
     int N = e->ringQ->N;
     size_t sz = (size_t)(level + 1) * N;
-    uint64_t *tmp = (uint64_t *)malloc(2 * sz * 8);
-    uint64_t *index = (uint64_t *)malloc((size_t)N * 8);
+    uint64_t *tmp = (uint64_t *)pool_get(2 * sz * 8);
+    uint64_t *index = (uint64_t *)pool_get((size_t)N * 8);
     lo_automorphism_ntt_index(N, 2 * (uint64_t)N, galel, index);
     lo_gadget_product(e, level, ct_in + sz, gk, tmp);
     lo_binop(e->ringQ, level, LO_ADD, tmp, ct_in, tmp);
     lo_automorphism_ntt_with_index(e->ringQ, level, tmp, index, ct_out);
     lo_automorphism_ntt_with_index(e->ringQ, level, tmp + sz, index, ct_out + sz);
-    free(tmp); free(index);
+    pool_put(tmp); pool_put(index);
 }
 /* AutomorphismHoisted, :60-100 */
 void lo_automorphism_hoisted(const lo_evaluator *e, int level, const uint64_t *ct_in, const uint64_t *decompQ,
                              const uint64_t *decompP, uint64_t galel, const lo_evk *gk, uint64_t *ct_out) {
     int N = e->ringQ->N;
     size_t sz = (size_t)(level + 1) * N;
-    uint64_t *tmp = (uint64_t *)malloc(2 * sz * 8);
-    uint64_t *index = (uint64_t *)malloc((size_t)N * 8);
+    uint64_t *tmp = (uint64_t *)pool_get(2 * sz * 8);
+    uint64_t *index = (uint64_t *)pool_get((size_t)N * 8);
     lo_automorphism_ntt_index(N, 2 * (uint64_t)N, galel, index);
     lo_gadget_product_hoisted(e, level, decompQ, decompP, gk, tmp);
     lo_binop(e->ringQ, level, LO_ADD, tmp, ct_in, tmp);
     lo_automorphism_ntt_with_index(e->ringQ, level, tmp, index, ct_out);
     lo_automorphism_ntt_with_index(e->ringQ, level, tmp + sz, index, ct_out + sz);
-    free(tmp); free(index);
+    pool_put(tmp); pool_put(index);
 }
 
 /* AutomorphismHoistedLazy, core/rlwe/evaluator_automorphism.go:104-165 (ctQP.IsNTT).
@@ -1392,8 +1427,8 @@ void lo_automorphism_hoisted_lazy(const lo_evaluator *e, int levelQ, const uint6
                                   const uint64_t *decompP, uint64_t galel, const lo_evk *gk, uint64_t *outQ, uint64_t *outP) {
     int N = e->ringQ->N, levelP = gk->nPk - 1;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
-    uint64_t *tQ = (uint64_t *)malloc(2 * szQ * 8), *tP = (uint64_t *)malloc(2 * szP * 8);
-    uint64_t *index = (uint64_t *)malloc((size_t)N * 8);
+    uint64_t *tQ = (uint64_t *)pool_get(2 * szQ * 8), *tP = (uint64_t *)pool_get(2 * szP * 8);
+    uint64_t *index = (uint64_t *)pool_get((size_t)N * 8);
     lo_automorphism_ntt_index(N, 2 * (uint64_t)N, galel, index);
     lo_gadget_product_hoisted_lazy(e, levelQ, decompQ, decompP, gk, tQ, tP);
     lo_automorphism_ntt_with_index(e->ringQ, levelQ, tQ + szQ, index, outQ + szQ);
@@ -1412,7 +1447,7 @@ void lo_automorphism_hoisted_lazy(const lo_evaluator *e, int levelQ, const uint6
     lo_binop(e->ringQ, levelQ, LO_ADD, tQ, tQ + szQ, tQ);
     lo_automorphism_ntt_with_index(e->ringQ, levelQ, tQ, index, outQ);
     lo_automorphism_ntt_with_index(e->ringP, levelP, tP, index, outP);
-    free(tQ); free(tP); free(index);
+    pool_put(tQ); pool_put(tP); pool_put(index);
 }
 
 /* ========================================================================== */
@@ -1426,17 +1461,17 @@ static void tensor(const lo_evaluator *e, int level, const uint64_t *c00, const 
     int N = e->ringQ->N;
     size_t sz = (size_t)(level + 1) * N;
     uint64_t *c0 = out, *c1 = out + sz;
-    uint64_t *c2 = relin ? (uint64_t *)malloc(sz * 8) : out + 2 * sz;
+    uint64_t *c2 = relin ? (uint64_t *)pool_get(sz * 8) : out + 2 * sz;
     lo_binop(e->ringQ, level, LO_MUL_MONT, c00, op1, c0);
     lo_binop(e->ringQ, level, LO_MUL_MONT, c01, op1 + sz, c2);
     lo_binop(e->ringQ, level, LO_MUL_MONT, c00, op1 + sz, c1);
     lo_binop(e->ringQ, level, LO_MUL_MONT_THEN_ADD, c01, op1, c1);
     if (relin) {
-        uint64_t *tmp = (uint64_t *)malloc(2 * sz * 8);
+        uint64_t *tmp = (uint64_t *)pool_get(2 * sz * 8);
         lo_gadget_product(e, level, c2, rlk, tmp);
         lo_binop(e->ringQ, level, LO_ADD, c0, tmp, c0);
         lo_binop(e->ringQ, level, LO_ADD, c1, tmp + sz, c1);
-        free(tmp); free(c2);
+        pool_put(tmp); pool_put(c2);
     }
 }
 /* CKKS mulRelin, schemes/ckks/evaluator.go:764-872 (degree-1 x degree-1) */
@@ -1444,11 +1479,11 @@ void lo_ckks_mul_relin(const lo_evaluator *e, int level, const uint64_t *op0, co
                        const lo_evk *rlk, int relin, uint64_t *out) {
     int N = e->ringQ->N;
     size_t sz = (size_t)(level + 1) * N;
-    uint64_t *c00 = (uint64_t *)malloc(sz * 8), *c01 = (uint64_t *)malloc(sz * 8);
+    uint64_t *c00 = (uint64_t *)pool_get(sz * 8), *c01 = (uint64_t *)pool_get(sz * 8);
     lo_unop(e->ringQ, level, LO_MFORM, op0, c00);
     lo_unop(e->ringQ, level, LO_MFORM, op0 + sz, c01);
     tensor(e, level, c00, c01, op1, rlk, relin, out);
-    free(c00); free(c01);
+    pool_put(c00); pool_put(c01);
 }
 /* BGV tensorStandard, schemes/bgv/evaluator.go:592-685; tMontgomery :59-62 */
 void lo_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, const uint64_t *op0, const uint64_t *op1,
@@ -1461,21 +1496,63 @@ void lo_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, const uint64
         uint64_t w[2] = {0, t};                               /* t << 64 */
         tmont[i] = lo_mform(words_mod(w, 2, s->q), s->q, s->brc);
     }
-    uint64_t *c00 = (uint64_t *)malloc(sz * 8), *c01 = (uint64_t *)malloc(sz * 8);
+    uint64_t *c00 = (uint64_t *)pool_get(sz * 8), *c01 = (uint64_t *)pool_get(sz * 8);
     lo_mul_rns_scalar_montgomery(e->ringQ, level, op0, tmont, c00);
     lo_mul_rns_scalar_montgomery(e->ringQ, level, op0 + sz, tmont, c01);
     tensor(e, level, c00, c01, op1, rlk, relin, out);
-    free(c00); free(c01);
+    pool_put(c00); pool_put(c01);
 }
 /* CKKS Rescale (schemes/ckks/evaluator.go:477-515) / BGV Rescale
  * (schemes/bgv/evaluator.go:1363-1393): per poly DivRoundByLastModulusManyNTT */
 void lo_rescale(const lo_ring *r, int level, int degree, int nb, const uint64_t *in, uint64_t *out) {
     int N = r->N;
     size_t szin = (size_t)(level + 1) * N, szout = (size_t)(level + 1 - nb) * N;
-    uint64_t *tmp = (uint64_t *)malloc(szin * 8);
+    uint64_t *tmp = (uint64_t *)pool_get(szin * 8);
     for (int i = 0; i <= degree; i++) {
         lo_div_round_by_last_modulus_many_ntt(r, level, nb, in + i * szin, tmp);
         memcpy(out + i * szout, tmp, szout * 8);
     }
-    free(tmp);
+    pool_put(tmp);
+}
+
+/* ========================================================================== */
+/* Timed CPU baseline (bench.py's cpu_baseline leg)                             */
+/* ========================================================================== */
+/* `nthreads` OS threads each repeat one BGV MulRelin on the shared (read-only) evaluator, key and inputs, writing to
+ * their own output, until `seconds` have elapsed -- the shape of the reference's own parallel benchmarks
+ * (b.RunParallel over one evaluator, schemes/ckks/ckks_benchmarks_test.go:95-325; evaluator methods are safe for
+ * concurrent callers since 6.2.0 because scratch comes from pools).  counts[i] = ops finished by thread i;
+ * returns the elapsed wall time in seconds. */
+#include <pthread.h>
+#include <time.h>
+typedef struct {
+    const lo_evaluator *e; int level; uint64_t t; const uint64_t *op0, *op1; const lo_evk *rlk;
+    double deadline; uint64_t count;
+} bench_arg;
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static void *bench_worker(void *vp) {
+    bench_arg *a = (bench_arg *)vp;
+    size_t sz = (size_t)(a->level + 1) * a->e->ringQ->N;
+    uint64_t *out = (uint64_t *)malloc(2 * sz * 8);
+    do {
+        lo_bgv_mul_relin(a->e, a->level, a->t, a->op0, a->op1, a->rlk, 1, out);
+        a->count++;
+    } while (now_s() < a->deadline);
+    free(out);
+    lo_pool_release();
+    return NULL;
+}
+double lo_bench_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, const uint64_t *op0, const uint64_t *op1,
+                              const lo_evk *rlk, int nthreads, double seconds, uint64_t *counts) {
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    bench_arg *args = (bench_arg *)calloc(nthreads, sizeof(bench_arg));
+    double t0 = now_s();
+    for (int i = 0; i < nthreads; i++) {
+        args[i] = (bench_arg){e, level, t, op0, op1, rlk, t0 + seconds, 0};
+        pthread_create(&th[i], NULL, bench_worker, &args[i]);
+    }
+    for (int i = 0; i < nthreads; i++) { pthread_join(th[i], NULL); counts[i] = args[i].count; }
+    double dt = now_s() - t0;
+    free(th); free(args);
+    return dt;
 }

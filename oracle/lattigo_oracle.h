@@ -226,6 +226,12 @@ void lo_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, const uint64
 /* in: [degree+1][level+1][N] -> out: [degree+1][level+1-nb][N] */
 void lo_rescale(const lo_ring *r, int level, int degree, int nb_rescales, const uint64_t *in, uint64_t *out);
 
+/* per-thread scratch pool (the role of ring/pool.go, core/rlwe/pool.go) and the threaded timing loop of bench.py's
+ * cpu_baseline leg (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:95-325) */
+void lo_pool_release(void);
+double lo_bench_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, const uint64_t *op0, const uint64_t *op1,
+                              const lo_evk *rlk, int nthreads, double seconds, uint64_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

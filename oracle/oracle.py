@@ -139,6 +139,8 @@ def _declare(L):
     L.lo_ckks_mul_relin.argtypes = [vp, i, u64p, u64p, ep, i, u64p]
     L.lo_bgv_mul_relin.argtypes = [vp, i, u64, u64p, u64p, ep, i, u64p]
     L.lo_rescale.argtypes = [vp, i, i, i, u64p, u64p]
+    L.lo_bench_bgv_mul_relin.argtypes = [vp, i, u64, u64p, u64p, ep, i, C.c_double, u64p]
+    L.lo_bench_bgv_mul_relin.restype = C.c_double
 
 
 def _p(a: np.ndarray):
@@ -695,6 +697,15 @@ class Evaluator:
         out = np.zeros((2 if relin else 3, level + 1, self.ringQ.N), dtype=np.uint64)
         lib().lo_bgv_mul_relin(self._h, level, t, _p(op0), _p(op1), rlk.ref() if rlk else None, int(relin), _p(out))
         return out
+
+    def BenchBGVMulRelin(self, t, op0, op1, rlk: EvaluationKey, nthreads: int, seconds: float):
+        """bench.py's cpu_baseline leg: `nthreads` OS threads (a C-level pthread loop, no Python in the timed region) each
+        repeat BGVMulRelin on this evaluator until `seconds` have passed; returns (ops finished, elapsed seconds)."""
+        op0, op1 = _c(op0), _c(op1)
+        level = op0.shape[1] - 1
+        counts = np.zeros(nthreads, dtype=np.uint64)
+        dt = lib().lo_bench_bgv_mul_relin(self._h, level, t, _p(op0), _p(op1), rlk.ref(), nthreads, float(seconds), _p(counts))
+        return int(counts.sum()), float(dt)
 
     def Rescale(self, ct, nb=1):
         ct = _c(ct)

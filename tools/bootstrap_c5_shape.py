@@ -42,16 +42,16 @@ def gen_primes(logs, nth, taken):
     return out
 
 
-def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+def build(ctx, B, seed_offset=0):
+    """-> (run, info): run() performs one bootstrap of a batch of B ciphertexts on `ctx` (bench.py --workload c5);
+    info carries the shape facts and the objects main() needs for its phase report."""
     logN = 16
     N, n, nth = 1 << logN, 1 << (logN - 1), 2 << logN
     taken = set()
     q, p = gen_primes(LOGQ, nth, taken), gen_primes(LOGP, nth, taken)
-    ctx = la.Context(0)
     rq, rp = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
     ev = la.Evaluator(rq, rp)
-    rng = np.random.Generator(np.random.PCG64(0x1A77160 + 5))
+    rng = np.random.Generator(np.random.PCG64(0x1A77160 + 5 + seed_offset))
     top, LP = len(q) - 1, len(p)
     beta = (top + 1 + LP - 1) // LP
     kq, kp = uniform(rng, q, N, (beta, 2)), uniform(rng, p, N, (beta, 2))  # one synthetic key image, uploaded per key
@@ -95,6 +95,17 @@ def main():
     def run():
         return boot.Bootstrap(S.Ciphertext(ct0, 0, 1), Fraction(1 << 60))
 
+    info = {"logN": logN, "L": len(q), "alpha": LP, "galois_keys": len(gks.keys), "dft_diagonals": ndiag}
+    run._parts = (boot, be, ct0, gks, ndiag)  # for main()'s phase report
+    return run, info
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    logN = 16
+    ctx = la.Context(0)
+    run, _ = build(ctx, B)
+    boot, be, ct0, gks, ndiag = run._parts
     res = run()
     ctx.sync()
     iters = 3
