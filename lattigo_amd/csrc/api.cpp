@@ -215,7 +215,8 @@ struct ConstPool {
 };
 struct ModUpRef {
     int nsrc = 0, ndst = 0;
-    size_t a = 0, T = 0, vt = 0, Td = 0, vtd = 0;
+    size_t a = 0, T = 0, vt = 0, Td = 0, vtd = 0, fc = 0;
+    const uint64_t *fc_on(const ConstPool &p) const { return p.dev + fc; }
     ModUpDev on(const ConstPool &p) const { return ModUpDev{nsrc, ndst, p.dev + a, p.dev + T, p.dev + vt}; }
     const double *Td_on(const ConstPool &p) const { return reinterpret_cast<const double *>(p.dev + Td); }
     const double *vtd_on(const ConstPool &p) const { return reinterpret_cast<const double *>(p.dev + vtd); }
@@ -240,6 +241,14 @@ static ModUpRef pool_modup(ConstPool &pool, const std::vector<uint64_t> &S, cons
         for (int v = 0; v <= h.nsrc; v++) vtd[(size_t)j * (h.nsrc + 1) + v] = dbits((double)h.vt[(size_t)j * (h.nsrc + 1) + v]);
     }
     r.Td = pool.add(Td); r.vtd = pool.add(vtd);
+    // lean integer path of the fused kernel: per destination {vt[1] 2^64 mod p, (p - floor(prod(S)/2) mod p) 2^64 mod p}
+    std::vector<uint64_t> fc((size_t)h.ndst * 2, 0);
+    for (int j = 0; j < h.ndst; j++) {
+        const uint64_t p = D[j];
+        fc[2 * j] = to_mont(h.vt[(size_t)j * (h.nsrc + 1) + 1], p);
+        fc[2 * j + 1] = to_mont((p - half_product_mod(S, p)) % p, p);
+    }
+    r.fc = pool.add(fc);
     return r;
 }
 
@@ -253,6 +262,7 @@ struct BasisExtender : Obj {
     uint64_t *d_twf = nullptr, *d_twi = nullptr;
     std::vector<uint8_t> small;
     double *d_twdf = nullptr, *d_twdi = nullptr;
+    uint64_t *d_tws = nullptr;
     RingDev qp{};
     ConstPool pool;
     std::vector<ModUpRef> qtop, ptoq;                      // per source level
@@ -266,6 +276,7 @@ struct BasisExtender : Obj {
         if (d_twi) hipFree(d_twi);
         if (d_twdf) hipFree(d_twdf);
         if (d_twdi) hipFree(d_twdi);
+        if (d_tws) hipFree(d_tws);
         pool.release();
     }
     uint64_t modulus(int idx) const { return idx < LQ ? Q->moduli[idx] : P->moduli[idx - LQ]; }
@@ -1088,6 +1099,20 @@ int he_basis_extender_create(he_handle hq, he_handle hp, he_handle *out) {
     for (uint64_t m : P->moduli) be->small.push_back(modulus_class(m));
     TRY(upload_f64_tables(subs, Q->N, &be->d_twdf, &be->d_twdi));
     be->qp = RingDev{Q->logN, Q->N, be->d_mc, be->d_twf, be->d_twi, be->small.data(), be->d_twdf, be->d_twdi};
+    {   // Shoup pairs of the first sixteen forward twiddles (the column stages fused into the basis extension)
+        std::vector<uint64_t> tws(subs.size() * 32, 0);
+        for (size_t i = 0; i < subs.size(); i++) {
+            const ModConst &m = subs[i]->mc;
+            for (int j = 0; j < 16 && j < Q->N; j++) {
+                const uint64_t w = imform(subs[i]->roots_fwd[j], m.q, m.qinv);
+                tws[i * 32 + 2 * j] = w;
+                tws[i * 32 + 2 * j + 1] = (uint64_t)(((u128)w << 64) / m.q);
+            }
+        }
+        HIP_TRY(hipMalloc((void **)&be->d_tws, tws.size() * 8));
+        HIP_TRY(hipMemcpy(be->d_tws, tws.data(), tws.size() * 8, hipMemcpyHostToDevice));
+        be->qp.tws_fwd = be->d_tws;
+    }
     for (int i = 0; i < be->LQ; i++)  // constantsQtoP[i] = GenModUpConstants(Q[:i+1], P)     basis_extension.go:62-65
         be->qtop.push_back(pool_modup(be->pool, std::vector<uint64_t>(Q->moduli.begin(), Q->moduli.begin() + i + 1), P->moduli));
     for (int i = 0; i < be->LP; i++)  // constantsPtoQ[i] = GenModUpConstants(P[:i+1], Q)     :67-70
@@ -1469,6 +1494,20 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
 }
 
 // ---- fused pipeline plans ------------------------------------------------------------------
+// which destinations of a descriptor take the lean integer path of modup_fused_kernel (see there): moduli below 2^58 that are
+// not on the double-precision path, column sums that cannot overflow, and a sum that one Montgomery reduction brings below 2p
+void mark_fast_destinations(const BasisExtender &be, ModUpDesc &D, const std::vector<uint64_t> &basis) {
+    static const bool off = getenv("HERING_NO_FAST_MODUP") && atoi(getenv("HERING_NO_FAST_MODUP")) != 0;
+    uint64_t mx = 0;
+    for (uint64_t m : basis) mx = std::max(mx, m);
+    for (int j = 0; j < D.ndst; j++) {
+        const uint64_t p = be.modulus(D.dst_mod[j]);
+        const bool f64_dst = (p >> 47) == 0 && be.d_twdf != nullptr;
+        const u128 colsum = (u128)(D.nsrc + 1) * ((u128)p + mx + ((u128)1 << 31));
+        D.dst_fast[j] = (!off && !D.single && !D.reduce_out && !f64_dst && (p >> 58) == 0 && D.nsrc + 1 <= 15 && (colsum >> 64) == 0 &&
+                         be.d_tws != nullptr) ? 1 : 0;
+    }
+}
 int upload_plan(Evaluator &ev, const std::vector<ModUpDesc> &descs, FusedPlan &plan) {
     plan.ok = !descs.empty();
     for (const ModUpDesc &d : descs)
@@ -1517,6 +1556,7 @@ int get_dec_plan(Evaluator &ev, int levelQ, int levelP, int nbPi, const FusedPla
             const ModUpDev c = ref.on(ev.pool);
             D.a = c.a; D.T = c.T; D.vt = c.vt;
             D.Td = ref.Td_on(ev.pool); D.vtd = ref.vtd_on(ev.pool);
+            D.fc = ref.fc_on(ev.pool);
             D.reduce_out = modup_out_needs_reduce(basis) ? 1 : 0;
         }
         for (int i = 0; i < D.nsrc; i++) {
@@ -1538,6 +1578,7 @@ int get_dec_plan(Evaluator &ev, int levelQ, int levelP, int nbPi, const FusedPla
             n++;
         }
         D.ndst = n;
+        mark_fast_destinations(be, D, basis);
         descs.push_back(D);
     }
     FusedPlan plan;
@@ -1561,6 +1602,7 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
         const ModUpDev c = be.ptoq[levelP].on(be.pool);
         D.a = c.a; D.T = c.T; D.vt = c.vt;
         D.Td = be.ptoq[levelP].Td_on(be.pool); D.vtd = be.ptoq[levelP].vtd_on(be.pool);
+        D.fc = be.ptoq[levelP].fc_on(be.pool);
         D.reduce_out = modup_out_needs_reduce(basis) ? 1 : 0;
         for (int i = 0; i <= levelP; i++) {
             D.src_limb[i] = (uint8_t)i; D.src_mod[i] = (uint8_t)(be.LQ + i);
@@ -1572,6 +1614,7 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
             D.dst_half[j] = half_product_mod(basis, be.Q->moduli[j]);
         }
         D.ndst = levelQ + 1;
+        mark_fast_destinations(be, D, basis);
         TRY(upload_plan(ev, std::vector<ModUpDesc>{D}, plan));
     }
     auto ins = ev.md_plans.emplace(key, plan);

@@ -37,6 +37,9 @@ struct RingDev {
     const uint8_t *host_small;
     const double *twd_fwd;      // [n_mod][N] plain twiddles as doubles (entries of class-2 moduli only), or null
     const double *twd_inv;
+    // [n_mod][16][2]: {w, floor(w 2^64 / q)} for the plain (non-Montgomery) forward twiddles RootsForward[0..15] -- the column
+    // stages fused into the basis extension use Shoup products on the integer path; null when not built
+    const uint64_t *tws_fwd = nullptr;
 };
 
 // ---- NTT ---------------------------------------------------------------------------
@@ -157,6 +160,10 @@ struct ModUpDesc {
     // double-precision copies for destination moduli below 2^47: Td[row][i] = {T, T*2^26 mod p} (plain integers),
     // vtd[row][v] = vt; a source residue y >= 2^51 is split as y = yh*2^26 + yl (src_split[i])
     const double *Td, *vtd;
+    // lean integer path (destination moduli below 2^58, see modup_fused_kernel): fc[row] = {vt[row][1] 2^64 mod p,
+    // (p - dst_half) 2^64 mod p}; dst_fast[j] marks the destinations that take it
+    const uint64_t *fc;
+    uint8_t dst_fast[kMaxLimbs];
     uint8_t src_split[8];
     uint64_t src_half[8];
     uint8_t src_limb[8], src_mod[8];

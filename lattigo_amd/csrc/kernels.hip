@@ -1489,14 +1489,23 @@ struct ModUpFusedArgs {
     const ModConst *mc;
     const uint64_t *tw_fwd, *tw_inv;
     const double *twd_fwd, *twd_inv;
+    const uint64_t *tws_fwd;
     int N;
 };
+
+// block-uniform 64-bit constants through the scalar cache: the constant address space tells the compiler that the table is
+// never written by a kernel, so a load with a uniform address becomes an s_load instead of a vector load + wait
+typedef const uint64_t __attribute__((address_space(4))) *he_cptr64;
+__device__ __forceinline__ uint64_t ldc(const uint64_t *p, size_t i) { return ((he_cptr64)(uintptr_t)p)[i]; }
+typedef const double __attribute__((address_space(4))) *he_cptrd;
+__device__ __forceinline__ double ldcd(const double *p, size_t i) { return ((he_cptrd)(uintptr_t)p)[i]; }
+__device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }  // v_mad_u64_u32
 
 // DSTF64 = false: destinations in 64-bit integer arithmetic (any modulus).
 // DSTF64 = true : only destination moduli below 2^47, the mat-vec and the column stages in exact double-precision
 //                 integer arithmetic (see ntt_rows_f64_kernel); same canonical results.
 #ifndef HE_MODUP_WAVES
-#define HE_MODUP_WAVES 2  // waves per SIMD the register allocation aims at
+#define HE_MODUP_WAVES 3  // waves per SIMD the register allocation aims at (the LDS footprint allows three)
 #endif
 template <int NSRC, int LOGA, bool DSTF64>
 __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpFusedArgs A) {
@@ -1523,6 +1532,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     const uint64_t *Dvt = reinterpret_cast<const uint64_t *>(U64((uint64_t)D.vt));
     const double *DTd = reinterpret_cast<const double *>(U64((uint64_t)D.Td));
     const double *Dvtd = reinterpret_cast<const double *>(U64((uint64_t)D.vtd));
+    const uint64_t *Dfc = reinterpret_cast<const uint64_t *>(U64((uint64_t)D.fc));
     const size_t dst_off = U64(D.dst_off);
     uint32_t splitmask = 0;  // bit i: source residue i is split into 26-bit halves
 #pragma unroll
@@ -1534,8 +1544,14 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     // mixed variant: the integer residues live in LDS (read back only for the few large destination moduli)
     __shared__ uint64_t ylds[DSTF64 ? NSRC * R : 1][128];
     uint64_t y[DSTF64 ? 1 : R][DSTF64 ? 1 : NSRC];   // integer variant
-    double yl[DSTF64 ? R : 1][DSTF64 ? NSRC : 1];      // double variant: y (or its low 26 bits)
-    double yh[DSTF64 ? R : 1][DSTF64 ? NSRC : 1];      //                 y >> 26 when split
+#ifndef HE_MODUP_Y_LDS
+#define HE_MODUP_Y_LDS 1
+#endif
+    // mixed variant: the residues are parked in LDS as integers; HE_MODUP_Y_LDS = 0 also keeps them in registers as doubles (2 x R x
+    // NSRC registers, two waves per SIMD), = 1 converts them where a destination limb uses them (100 registers, three waves)
+    constexpr bool YREG = DSTF64 && !HE_MODUP_Y_LDS;
+    double yl[YREG ? R : 1][YREG ? NSRC : 1];      // y (or its low 26 bits)
+    double yh[YREG ? R : 1][YREG ? NSRC : 1];      // y >> 26 when split
     double vi[R];
     uint32_t negmask = 0;  // centred-copy path only: bit r = coefficient r was negated
 #pragma unroll
@@ -1628,8 +1644,10 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 vi[r] = __dadd_rn(vi[r], yd[r] * rq);
                 if constexpr (DSTF64) {
                     ylds[i * R + r][threadIdx.x] = yi[r];
-                    yl[r][i] = split ? u52_to_f64(yi[r] & ((1ull << 26) - 1)) : yd[r];
-                    yh[r][i] = split ? u52_to_f64(yi[r] >> 26) : 0.0;
+                    if constexpr (YREG) {
+                        yl[r][i] = split ? u52_to_f64(yi[r] & ((1ull << 26) - 1)) : yd[r];
+                        yh[r][i] = split ? u52_to_f64(yi[r] >> 26) : 0.0;
+                    }
                 } else {
                     y[r][i] = yi[r];
                 }
@@ -1687,24 +1705,32 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
             } else {
                 const int row = (int)U(D.dst_row[j]);
                 const double *Tr = DTd + (size_t)row * NSRC * 2;
-                const double *vtr = Dvtd + (size_t)row * (NSRC + 1);
+                const double vt1 = ldcd(Dvtd, (size_t)row * (NSRC + 1) + 1);  // vt[v] = v * vt[1] mod p: the v-correction is one exact fma (v <= NSRC, v * vt1 < 2^50)
                 const double hd = (double)U64(D.dst_half[j]);
-                double Tl[NSRC], Th[NSRC];
 #pragma unroll
-                for (int i = 0; i < NSRC; i++) { Tl[i] = Tr[2 * i]; Th[i] = Tr[2 * i + 1]; }
-                const double vt1 = vtr[1];  // vt[v] = v * vt[1] mod p: the v-correction is one exact fma (v <= NSRC, v * vt1 < 2^50)
+                for (int r = 0; r < R; r++) o[r] = __fma_rn(vd[r], vt1, -hd);
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    double sacc = __fma_rn(vd[r], vt1, -hd);
+                for (int i = 0; i < NSRC; i++) {
+                    const double Tl = ldcd(Tr, 2 * i), Th = ldcd(Tr, 2 * i + 1);  // block-uniform: scalar loads
+                    if constexpr (YREG) {
 #pragma unroll
-                    for (int i = 0; i < NSRC; i++) sacc += modmul_f64(yl[r][i], Tl[i], pd, pid);
-                    if (splitmask) {
+                        for (int r = 0; r < R; r++) o[r] += modmul_f64(yl[r][i], Tl, pd, pid);
+                        if ((splitmask >> i) & 1) {
 #pragma unroll
-                        for (int i = 0; i < NSRC; i++)
-                            if ((splitmask >> i) & 1) sacc += modmul_f64(yh[r][i], Th[i], pd, pid);
+                            for (int r = 0; r < R; r++) o[r] += modmul_f64(yh[r][i], Th, pd, pid);
+                        }
+                    } else if ((splitmask >> i) & 1) {  // y >= 2^51 possible: y = yh 2^26 + yl, two exact products
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const uint64_t yy = ylds[i * R + r][threadIdx.x];
+                            o[r] += modmul_f64(u52_to_f64(yy & ((1ull << 26) - 1)), Tl, pd, pid);
+                            o[r] += modmul_f64(u52_to_f64(yy >> 26), Th, pd, pid);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; r++) o[r] += modmul_f64(u52_to_f64(ylds[i * R + r][threadIdx.x]), Tl, pd, pid);
                     }
-                    o[r] = sacc;  // |o| < (2 + 5*NSRC) p
-                }
+                }  // |o| < (2 + 5*NSRC) p
             }
             if constexpr (LOGA > 0) {
                 const double *tw = A.twd_fwd + (size_t)mi * A.N;
@@ -1714,7 +1740,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         if (r & d) continue;
-                        const double t = modmul_f64(o[r + d], tw[(1 << s) + (r >> (LOGA - s))], pd, pid);
+                        const double t = modmul_f64(o[r + d], ldcd(tw, (size_t)((1 << s) + (r >> (LOGA - s)))), pd, pid);
                         const double U = o[r];
                         o[r] = U + t;
                         o[r + d] = U - t;
@@ -1723,6 +1749,68 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
             }
 #pragma unroll
             for (int r = 0; r < R; r++) stnt(&dst[(size_t)r * N2], f64_to_u52(reduce_f64(o[r], pd, pid) + pd));  // (0, 2p)
+        }
+        if (!done && !single && U(D.dst_fast[j]) != 0) {
+            // Lean integer path for destination moduli below 2^58 (the 55-bit limbs of the headline chain).  Only the residue
+            // class of the result matters here (the row NTT that follows accepts any word below 10p), so:
+            //  * the v correction and the centring constant join the sum as one more term / the initial value, in Montgomery
+            //    form: acc = sum_i y_i Tm_i + v V1m + C0m, one reduction, no selects, no conditional subtractions;
+            //  * operands are split at 30 bits (y = x1 2^30 + x0, Tm = t1 2^30 + t0) and the partial products are summed by
+            //    column in three 64-bit registers without carries (the host checks (nsrc+1)(p + max q + 2^31) < 2^64), 4
+            //    v_mad_u64_u32 per term instead of a 128-bit multiply-add;
+            //  * the matrix row, the constants and the twiddles are block-uniform and come through the scalar cache;
+            //  * the column butterflies use Shoup products (w, floor(w 2^64 / p)): r = V w - mulhi(V, w') p in [0, 2p) for any
+            //    64-bit V, X = U + r, Y = U + 2p - r -- each stage adds at most 2p to the bound.
+            done = true;
+            const int row = (int)U(D.dst_row[j]);
+            constexpr uint32_t M30 = (1u << 30) - 1;
+            uint32_t t0[NSRC + 1], t1[NSRC + 1];
+#pragma unroll
+            for (int i = 0; i < NSRC; i++) {
+                const uint64_t Tm = ldc(DT, (size_t)row * NSRC + i);
+                t0[i] = (uint32_t)Tm & M30; t1[i] = (uint32_t)(Tm >> 30);
+            }
+            const uint64_t V1 = ldc(Dfc, 2 * (size_t)row), C0 = ldc(Dfc, 2 * (size_t)row + 1);
+            t0[NSRC] = (uint32_t)V1 & M30; t1[NSRC] = (uint32_t)(V1 >> 30);
+            const uint64_t L0 = C0 & M30, M0 = C0 >> 30;
+            uint64_t o[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint64_t Lc = L0, Mc = M0, Hc = 0;
+#pragma unroll
+                for (int i = 0; i < NSRC; i++) {
+                    const uint64_t yy = Y(r, i);
+                    const uint32_t x0 = (uint32_t)yy & M30, x1 = (uint32_t)(yy >> 30);
+                    Lc = mad32(x0, t0[i], Lc);
+                    Mc = mad32(x0, t1[i], Mc);
+                    Mc = mad32(x1, t0[i], Mc);
+                    Hc = mad32(x1, t1[i], Hc);
+                }
+                Lc = mad32(v[r], t0[NSRC], Lc);
+                Mc = mad32(v[r], t1[NSRC], Mc);
+                const u128 acc = (u128)Lc + ((u128)Mc << 30) + ((u128)Hc << 60);
+                o[r] = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p;  // (0, 2p)
+            }
+            if constexpr (LOGA > 0) {
+                const uint64_t *ts = A.tws_fwd + (size_t)mi * 32;
+#pragma unroll
+                for (int s = 0; s < LOGA; s++) {
+                    const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (r & d) continue;
+                        const size_t ix = (size_t)((1 << s) + (r >> (LOGA - s)));
+                        const uint64_t w = ldc(ts, 2 * ix), ws = ldc(ts, 2 * ix + 1);
+                        const uint64_t V = o[r + d];
+                        const uint64_t rr = V * w - mulhi64(V, ws) * p;
+                        const uint64_t Uu = o[r];
+                        o[r] = Uu + rr;
+                        o[r + d] = Uu + twop - rr;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) stnt(&dst[(size_t)r * N2], o[r]);
         }
         if (!done) {
             uint64_t o[R];
@@ -1811,6 +1899,7 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
     A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
     A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.twd_fwd = r.twd_fwd; A.twd_inv = r.twd_inv; A.N = r.N;
+    A.tws_fwd = r.tws_fwd;
     const bool use_f64 = (dst_classes & 2) && r.twd_fwd != nullptr;
     const int n2 = r.N >> a;
     dim3 grid((unsigned)((n2 + 127) / 128), ndesc, batch), block(128);
