@@ -185,6 +185,29 @@ struct NttArgs {
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
 
+// Synchronisation of the LDS exchanges of the row kernels.  With T = 2^LOGB / 16 threads, thread tau = (hi, lo) of round rho
+// holds e = hi 2^(sh+4) + k 2^sh + lo (sh = LOGB - 4 rho - 4), and the exchange that follows the round moves data only inside
+// groups of 2^sh consecutive threads (the consumer of element e is thread (hi 16 + k) 2^(sh-4) + (lo mod 2^(sh-4)), in the same
+// group).  For sh <= 6 the group lies inside one wavefront: LDS operations of a wave are processed in order, so no workgroup
+// barrier is needed, only a compiler fence.  A 4096-row (LOGB = 12) then has ONE barrier (after the first round, sh = 8) instead
+// of three: the second exchange is local to 16 lanes and the last one -- back to a coalesced order for the global accesses -- is
+// made wave-local by letting every wave keep its own contiguous 1024 coefficients (nat_e) instead of the k T + tau interleave.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void rows_sync(int sh) {
+    if (sh <= 6) wave_lds_sync();
+    else __syncthreads();
+}
+// coalesced ("natural") element k of thread tau: wave w owns coefficients [1024 w, 1024 (w+1)), lane l element 64 k + l of them
+template <int T>
+__device__ __forceinline__ int nat_e(int k, int tau) {
+    constexpr int CH = T >= 64 ? 64 : T;
+    return (tau / CH) * (16 * CH) + k * CH + (tau % CH);
+}
+
 // N = 2^n is split into a strided "column" stages and b contiguous "row" stages: rows of 4096 coefficients
 // (b = 12) up to logN = 15, rows of 8192 (b = 13, two 512-thread workgroups per CU) from logN = 16 so that the
 // fused basis extension never holds more than 8 strided coefficients per thread.
@@ -340,14 +363,14 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
             rows_round16<false, NC>(x, t16, q, twoq, qinv, mc, false);
             if (rho + 1 < NR4) rows_tw16(t16, tw, rowtw, s0 + 4, tau >> (sh - 4));  // in flight across the exchange
             rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, true);
-            __syncthreads();
+            rows_sync(sh);
         }
         if constexpr (GREM > 0) {
             constexpr int s0 = 4 * NR4;
             rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, false);
             rows_round<GREM, false, NC>(x, tw, rowtw, s0, 0, tau, 0, q, twoq, qinv, mc, false);
             rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, true);
-            __syncthreads();
+            rows_sync(0);
         }
         const bool lazy = (A.flags & NTT_LAZY_OUT) != 0;
         auto settle = [&](uint64_t v) -> uint64_t {
@@ -366,27 +389,27 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
             const uint64_t sy = A.epi_s[y];
             uint64_t yv[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) yv[k] = ldnt(&yp[k * T + tau]);
+            for (int k = 0; k < 16; k++) yv[k] = ldnt(&yp[nat_e<T>(k, tau)]);
             if (addw) {
                 uint64_t wv[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[k * T + tau]);
+                for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[nat_e<T>(k, tau)]);
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const int e = k * T + tau;
+                    const int e = nat_e<T>(k, tau);
                     stnt(&op[e], cred(wv[k] + mred(settle(lds[lds_phys(e)]) + twoq - yv[k], sy, q, qinv), q));
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const int e = k * T + tau;
+                    const int e = nat_e<T>(k, tau);
                     stnt(&op[e], mred(settle(lds[lds_phys(e)]) + twoq - yv[k], sy, q, qinv));
                 }
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const int e = k * T + tau;
+                const int e = nat_e<T>(k, tau);
                 uint64_t v = settle(lds[lds_phys(e)]);
                 if (!lazy) v = v >= q ? v - q : v;
                 dst[e] = v;
@@ -395,18 +418,18 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int e = k * T + tau;
+            const int e = nat_e<T>(k, tau);  // the wave's own 1024 coefficients: the first exchange stays inside the wave
             uint64_t v = ldnt(&src[e]);
             if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, q, mc.brc0);
             lds[lds_phys(e)] = v;
         }
-        __syncthreads();
+        rows_sync(0);
         if constexpr (GREM > 0) {
             constexpr int s0 = 4 * NR4;
             rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, false);
             rows_round<GREM, true, false>(x, tw, rowtw, s0, 0, tau, 0, q, twoq, qinv, mc, false);
             rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, true);
-            __syncthreads();
+            rows_sync(GREM);
         }
         uint64_t t16[15];
         if constexpr (NR4 > 0) rows_tw16(t16, tw, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
@@ -418,7 +441,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
             if (rho > 0) {
                 rows_tw16(t16, tw, rowtw, s0 - 4, tau >> (sh + 4));  // the next round's, in flight across the exchange
                 rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, true);
-                __syncthreads();
+                rows_sync(sh + 4);  // the consumers are the next round's groups of 2^(sh + 4) threads
             }
         }
         constexpr int sh0 = LOGB - 4;
@@ -591,7 +614,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     if constexpr (INV) {
         const uint64_t *src0 = A.in + (size_t)b0 * A.in_bs + in_off;
 #pragma unroll
-        for (int k = 0; k < 16; k++) nx[k] = ldnt(&src0[k * T + tau]);
+        for (int k = 0; k < 16; k++) nx[k] = ldnt(&src0[nat_e<T>(k, tau)]);
     }
     for (unsigned bzi = b0; bzi < b1; bzi++) {
     uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
@@ -613,14 +636,14 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             if (rho > 0) rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, false);
             rows_round_f64<4, false>(x, tw, rowtw, s0, tau >> sh, tau, sh, q, qi);
             rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, true);
-            __syncthreads();
+            rows_sync(sh);
         }
         if constexpr (GREM > 0) {
             constexpr int s0 = 4 * NR4;
             rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, s0, 0, false);
             rows_round_f64<GREM, false>(x, tw, rowtw, s0, 0, tau, 0, q, qi);
             rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, s0, 0, true);
-            __syncthreads();
+            rows_sync(0);
         }
         if (A.epi) {
             // out = [w +] MRed(x + 2q - y, s) with x the transform: the subtraction and the product by s run in double
@@ -638,42 +661,42 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             double yv[16];
             if (A.epi_y_f64) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) yv[k] = ldnt(&reinterpret_cast<const double *>(yp)[k * T + tau]);
+                for (int k = 0; k < 16; k++) yv[k] = ldnt(&reinterpret_cast<const double *>(yp)[nat_e<T>(k, tau)]);
             } else if (A.epi_y_reduce) {  // caller-supplied y: any uint64
 #pragma unroll
-                for (int k = 0; k < 16; k++) yv[k] = u52_to_f64(bred_add_lazy(ldnt(&yp[k * T + tau]), mc.q, mc.brc0));
+                for (int k = 0; k < 16; k++) yv[k] = u52_to_f64(bred_add_lazy(ldnt(&yp[nat_e<T>(k, tau)]), mc.q, mc.brc0));
             } else {
 #pragma unroll
-                for (int k = 0; k < 16; k++) yv[k] = u52_to_f64(ldnt(&yp[k * T + tau]));
+                for (int k = 0; k < 16; k++) yv[k] = u52_to_f64(ldnt(&yp[nat_e<T>(k, tau)]));
             }
             if (addw) {
                 uint64_t wv[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[k * T + tau]);
+                for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[nat_e<T>(k, tau)]);
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const int e = k * T + tau;
+                    const int e = nat_e<T>(k, tau);
                     const uint64_t v = canon_f64(modmul_f64(lds[lds_phys(e)] - yv[k], sp, q, qi), q, qi);
                     stnt(&op[e], cred(wv[k] + v, mc.q));
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const int e = k * T + tau;
+                    const int e = nat_e<T>(k, tau);
                     stnt(&op[e], canon_f64(modmul_f64(lds[lds_phys(e)] - yv[k], sp, q, qi), q, qi));
                 }
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const int e = k * T + tau;
+                const int e = nat_e<T>(k, tau);
                 dst[e] = canon_f64(lds[lds_phys(e)], q, qi);
             }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int e = k * T + tau;
+            const int e = nat_e<T>(k, tau);
             uint64_t v = nx[k];
             if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
             lds[lds_phys(e)] = u52_to_f64(v);
@@ -681,15 +704,15 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
         if constexpr (PIPE) if (bzi + 1 < b1) {
             const uint64_t *srcn = A.in + (size_t)(bzi + 1) * A.in_bs + in_off;
 #pragma unroll
-            for (int k = 0; k < 16; k++) nx[k] = ldnt(&srcn[k * T + tau]);
+            for (int k = 0; k < 16; k++) nx[k] = ldnt(&srcn[nat_e<T>(k, tau)]);
         }
-        __syncthreads();
+        rows_sync(0);  // the wave filled its own 1024 coefficients: the first exchange stays inside the wave
         if constexpr (GREM > 0) {
             constexpr int s0 = 4 * NR4;
             rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, s0, 0, false);
             rows_round_f64<GREM, true>(x, tw, rowtw, s0, 0, tau, 0, q, qi);
             rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, s0, 0, true);
-            __syncthreads();
+            rows_sync(GREM);
         }
         double t16[15];
         if constexpr (NR4 > 0) rows_tw16_f64(t16, tw, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
@@ -704,7 +727,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             if (rho > 0) {
                 rows_tw16_f64(t16, tw, rowtw, s0 - 4, tau >> (sh + 4));  // the next round's, in flight across the exchange
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, true);
-                __syncthreads();
+                rows_sync(sh + 4);  // the consumers are the next round's groups of 2^(sh + 4) threads
             }
         }
         constexpr int sh0 = LOGB - 4;
@@ -804,7 +827,9 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
                 const int sn = rho + 1 < NR4 ? s0 + 4 : 0;
                 rows_tw16_f64(t16, tw, rowtw, sn, tau >> (LOGB - sn - 4));
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, true);
-                __syncthreads();
+                // the middle exchange of a 4096-row is local to 16 lanes (rows_sync); the last one feeds the cross-wave k T + tau
+                // read below.  (The wave-local nat_e order of the plain row kernels costs this kernel 29 spilled registers.)
+                if (rho + 1 < NR4) rows_sync(sh); else __syncthreads();
             }
             if constexpr (GREM > 0) {
                 constexpr int s0 = 4 * NR4;
