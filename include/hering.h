@@ -213,6 +213,12 @@ int he_moddown_qp_to_p(he_handle be, int levelQ, int levelP, he_handle p1Q, he_h
  *      operator interface of core/rlwe/rlwe.go:10-18.  Ciphertext components are
  *      separate poly handles, as rlwe.Ciphertext.Value []ring.Poly; a QP element
  *      is a (Q handle, P handle) pair, as ringqp.Poly{Q,P} (ring/ringqp/poly.go:17). */
+/* ringP = 0: parameters without special primes (rlwe.ParametersLiteral.P = nil, core/rlwe/params.go:485): levelP = -1 in
+ * every call below.  Such an evaluator serves base-2 gadget keys without a P part -- the reference's own P-less
+ * configuration (core/rlwe/test_params.go:36-46) -- through gadgetProductSinglePAndBitDecompLazy's `ringP == nil`
+ * branches (evaluator_gadget_product.go:284,302,330) and ModDown's `levelP == -1` copy (:74-96); the P handles of a QP
+ * element are then passed as 0.  (With BaseTwoDecomposition = 0 the reference's P-less path is not functional --
+ * DecomposeSingleNTT dereferences the nil ringP, :488 -- and is rejected here.) */
 int he_evaluator_create(he_handle ringQ, he_handle ringP, he_handle *eval);
 int he_evaluator_destroy(he_handle eval);
 
@@ -221,7 +227,8 @@ int he_evaluator_destroy(he_handle eval);
 int he_evk_create(he_handle eval, int beta, int nQk, int nPk, const uint64_t *q, const uint64_t *p, he_handle *evk);
 /* Base-2 gadget (GadgetCiphertext.BaseTwoDecomposition = pw2 != 0, at most one special prime): one RNS digit per
  * Q-limb i with nj[i] = ceil(bits(q_i)/pw2) bit windows (core/rlwe/params.go:523-540); block (i, j) is stored at
- * index sum_{i'<i} nj[i'] + j.  Host image q[sum nj][2][nQk][N], p[sum nj][2][nPk][N].  Such keys are accepted by
+ * index sum_{i'<i} nj[i'] + j.  Host image q[sum nj][2][nQk][N], p[sum nj][2][nPk][N]; nPk = 0 (p = NULL): a key without P part, for
+ * an evaluator created without special primes.  Such keys are accepted by
  * he_gadget_product[_lazy], he_relinearize, he_automorphism_ct and the mul_relin entries
  * (gadgetProductSinglePAndBitDecompLazy, core/rlwe/evaluator_gadget_product.go:203); the hoisted entries reject
  * them, as the reference does (:381-383). */
@@ -261,7 +268,7 @@ int he_gadget_product_lazy(he_handle eval, int levelQ, he_handle cx, he_handle e
 /* GadgetProductHoistedLazy (:379) */
 int he_gadget_product_hoisted_lazy(he_handle eval, int levelQ, he_handle decomp, he_handle evk,
                                    he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P);
-/* Evaluator.ModDown (:39), NTT in / NTT out */
+/* Evaluator.ModDown (:39), NTT in / NTT out; levelP = -1 (no special primes, c0P = c1P = 0): the copy of :76-81 */
 int he_moddown(he_handle eval, int levelQ, int levelP, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P,
                he_handle out0, he_handle out1);
 /* BasisExtender.ModDownQPtoQNTT (ring/basis_extension.go:235-256) through the evaluator's fused pipeline (three launches

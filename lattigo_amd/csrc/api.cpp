@@ -1077,10 +1077,8 @@ int he_automorphism(he_handle hring, int level, he_handle hin, uint64_t gal, he_
 // ---------------------------------------------------------------------------------------
 // basis extension (ring/basis_extension.go)
 // ---------------------------------------------------------------------------------------
-int he_basis_extender_create(he_handle hq, he_handle hp, he_handle *out) {
-    GET(Q, Ring, hq, T_RING);
-    GET(P, Ring, hp, T_RING);
-    if (!out) return fail(HE_EINVAL, "he_basis_extender_create: null output");
+// P may be a ring without moduli (an evaluator over parameters without special primes): LP = 0, no constants
+static int basis_extender_build(std::shared_ptr<Ring> Q, std::shared_ptr<Ring> P, he_handle *out) {
     if (Q->ctx != P->ctx || Q->N != P->N) return fail(HE_EINVAL, "he_basis_extender_create: rings must share context and degree");
     if (Q->type != 0 || P->type != 0) return fail(HE_EINVAL, "he_basis_extender_create: conjugate-invariant rings are not supported here");
     if (Q->nmod() + P->nmod() > kMaxLimbs) return fail(HE_EINVAL, "he_basis_extender_create: more than %d moduli in QP", kMaxLimbs);
@@ -1130,6 +1128,12 @@ int he_basis_extender_create(he_handle hq, he_handle hp, he_handle *out) {
     }
     *out = reg(be);
     return HE_OK;
+}
+int he_basis_extender_create(he_handle hq, he_handle hp, he_handle *out) {
+    GET(Q, Ring, hq, T_RING);
+    GET(P, Ring, hp, T_RING);
+    if (!out) return fail(HE_EINVAL, "he_basis_extender_create: null output");
+    return basis_extender_build(Q, P, out);
 }
 int he_basis_extender_destroy(he_handle h) { return unreg(h, T_BE); }
 
@@ -1255,7 +1259,17 @@ int he_moddown_qp_to_p(he_handle be, int lq, int lp, he_handle a, he_handle b, h
 int he_evaluator_create(he_handle hq, he_handle hp, he_handle *out) {
     if (!out) return fail(HE_EINVAL, "he_evaluator_create: null output");
     he_handle hbe = 0;
-    TRY(he_basis_extender_create(hq, hp, &hbe));
+    if (hp == 0) {
+        // parameters without special primes (rlwe.ParametersLiteral.P = nil): levelP = -1 everywhere.  The evaluator then
+        // serves base-2 gadget keys without a P part (the reference's own P-less set, core/rlwe/test_params.go:36-46) through
+        // gadgetProductSinglePAndBitDecompLazy's `ringP == nil` branches and ModDown's `levelP == -1` copy.
+        GET(Q, Ring, hq, T_RING);
+        auto P = std::make_shared<Ring>();
+        P->ctx = Q->ctx; P->logN = Q->logN; P->N = Q->N; P->type = 0;
+        TRY(basis_extender_build(Q, P, &hbe));
+    } else {
+        TRY(he_basis_extender_create(hq, hp, &hbe));
+    }
     auto be = get<BasisExtender>(hbe, T_BE);
     {  // the evaluator owns its extender; drop the public handle
         std::lock_guard<std::mutex> l(g_mu);
@@ -1310,8 +1324,8 @@ static int evk_create_common(he_handle hev, int beta, int nQk, int nPk, const ui
                              const int *nj, int n_rns, he_handle *out) {
     GET(ev, Evaluator, hev, T_EVAL);
     BasisExtender &be = *ev->be;
-    const bool empty = !q && !p;  // shape only: contents arrive through he_evk_device_buffer + he_evk_commit
-    if ((!empty && (!q || !p)) || !out || beta <= 0 || nQk <= 0 || nQk > be.LQ || nPk <= 0 || nPk > be.LP)
+    const bool empty = !q;  // shape only: contents arrive through he_evk_device_buffer + he_evk_commit
+    if ((!empty && (!q || (!p && nPk > 0))) || !out || beta <= 0 || nQk <= 0 || nQk > be.LQ || nPk < 0 || nPk > be.LP || (nPk == 0 && !pw2))
         return fail(HE_EINVAL, "he_evk_create: bad key shape (beta=%d, nQk=%d, nPk=%d)", beta, nQk, nPk);
     auto k = std::make_shared<Evk>();
     k->ev = ev; k->beta = beta; k->nQk = nQk; k->nPk = nPk; k->pw2 = pw2;
@@ -1328,7 +1342,8 @@ static int evk_create_common(he_handle hev, int beta, int nQk, int nPk, const ui
             for (int kk = 0; kk < 2; kk++) {
                 uint64_t *dst = k->d + ((size_t)d * 2 + kk) * blk;
                 HIP_TRY(hipMemcpyAsync(dst, q + ((size_t)d * 2 + kk) * nQk * N, (size_t)nQk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
-                HIP_TRY(hipMemcpyAsync(dst + (size_t)nQk * N, p + ((size_t)d * 2 + kk) * nPk * N, (size_t)nPk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
+                if (nPk > 0)
+                    HIP_TRY(hipMemcpyAsync(dst + (size_t)nQk * N, p + ((size_t)d * 2 + kk) * nPk * N, (size_t)nPk * N * 8, hipMemcpyHostToDevice, be.ctx->stream));
             }
     if (int rc = evk_derive(*k)) return rc;
     HIP_TRY(hipStreamSynchronize(be.ctx->stream));
@@ -1341,7 +1356,7 @@ int he_evk_create(he_handle hev, int beta, int nQk, int nPk, const uint64_t *q, 
 int he_evk_create_base2(he_handle hev, int pw2, const int *nj, int n_rns, int nQk, int nPk, const uint64_t *q, const uint64_t *p,
                         he_handle *out) {
     if (pw2 <= 0 || pw2 > 62 || !nj || n_rns != nQk) return fail(HE_EINVAL, "he_evk_create_base2: one RNS digit per key Q-limb is required");
-    if (nPk != 1) return fail(HE_EINVAL, "he_evk_create_base2: a base-2 gadget takes exactly one special prime");
+    if (nPk != 0 && nPk != 1) return fail(HE_EINVAL, "he_evk_create_base2: a base-2 gadget takes at most one special prime");
     int beta = 0;
     for (int i = 0; i < n_rns; i++) {
         if (nj[i] <= 0 || nj[i] * pw2 > 64 + pw2) return fail(HE_EINVAL, "he_evk_create_base2: bad window count");
@@ -1382,7 +1397,7 @@ int he_evk_commit(he_handle hk) {
 
 namespace {
 // BaseRNSDecompositionVectorSize, core/rlwe/params.go:543-550
-int base_rns_size(int levelQ, int levelP) { return (levelQ + levelP + 1) / (levelP + 1); }
+int base_rns_size(int levelQ, int levelP) { return levelP == -1 ? levelQ + 1 : (levelQ + levelP + 1) / (levelP + 1); }
 
 // DecomposeAndSplit for one digit (ring/basis_extension.go:381-502): coefficient-domain src
 // (limbs of ringQ) -> dstQ limbs (dstQ_limb0 + j) and dstP limbs (dstP_limb0 + j).
@@ -1691,6 +1706,7 @@ int he_decomp_create(he_handle hev, int batch, he_handle *out) {
     GET(ev, Evaluator, hev, T_EVAL);
     if (batch <= 0 || !out) return fail(HE_EINVAL, "he_decomp_create: bad batch");
     BasisExtender &be = *ev->be;
+    if (be.LP == 0) return fail(HE_EINVAL, "he_decomp_create: hoisted decompositions need special primes (the reference's DecomposeNTT dereferences ringP)");
     auto d = std::make_shared<Decomp>();
     d->ev = ev;
     d->batch = batch;
@@ -1761,17 +1777,22 @@ int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle 
 namespace {
 struct QPOut {
     std::shared_ptr<Poly> q0, p0, q1, p1;
+    View vp0() const { return p0 ? p0->view() : View{nullptr, 0}; }
+    View vp1() const { return p1 ? p1->view() : View{nullptr, 0}; }
 };
 int get_qp_out(he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, const BasisExtender &be, int levelQ, int levelP, int batch,
                QPOut &o, const char *who) {
-    o.q0 = get<Poly>(c0Q, T_POLY); o.p0 = get<Poly>(c0P, T_POLY); o.q1 = get<Poly>(c1Q, T_POLY); o.p1 = get<Poly>(c1P, T_POLY);
-    if (!o.q0 || !o.p0 || !o.q1 || !o.p1) return fail(HE_EHANDLE, "%s: bad output poly handle", who);
+    o.q0 = get<Poly>(c0Q, T_POLY); o.q1 = get<Poly>(c1Q, T_POLY);
+    if (!o.q0 || !o.q1) return fail(HE_EHANDLE, "%s: bad output poly handle", who);
     TRY(check_be_poly(*o.q0, be, levelQ + 1, who));
     TRY(check_be_poly(*o.q1, be, levelQ + 1, who));
+    if (o.q0->batch != batch || o.q1->batch != batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    if (levelP < 0) return HE_OK;  // no special primes: the P handles are ignored (pass 0)
+    o.p0 = get<Poly>(c0P, T_POLY); o.p1 = get<Poly>(c1P, T_POLY);
+    if (!o.p0 || !o.p1) return fail(HE_EHANDLE, "%s: bad output poly handle", who);
     TRY(check_be_poly(*o.p0, be, levelP + 1, who));
     TRY(check_be_poly(*o.p1, be, levelP + 1, who));
-    if (o.q0->batch != batch || o.q1->batch != batch || o.p0->batch != batch || o.p1->batch != batch)
-        return fail(HE_EINVAL, "%s: batch mismatch", who);
+    if (o.p0->batch != batch || o.p1->batch != batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
     return HE_OK;
 }
 
@@ -1936,6 +1957,17 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
     const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
     uint64_t *aQ = be.ctx->arena_take(2 * B * sQw), *aP = be.ctx->arena_take(2 * B * sPw);
     View a0Q{aQ, sQw}, a1Q{aQ + (size_t)B * sQw, sQw}, a0P{aP, sPw}, a1P{aP + (size_t)B * sPw, sPw};
+    if (levelP < 0) {
+        // no special primes: ModDown's levelP == -1 branch is a copy of the (canonical) Q accumulators (:76-81), followed by
+        // the caller's Ring.Add where there is one
+        if (!cx) return fail(HE_EINVAL, "gadget product: a hoisted decomposition needs special primes");
+        TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, View{nullptr, 0}, a1Q, View{nullptr, 0}, cx_canonical, nullptr));
+        const LimbTab tq = ident_tab(levelQ + 1);
+        hipStream_t st = be.ctx->stream;
+        HIP_TRY(launch_ew(be.qp, tq, add0 ? EW_ADD : EW_COPY, a0Q, add0 ? *add0 : a0Q, out0, B, nullptr, nullptr, st));
+        HIP_TRY(launch_ew(be.qp, tq, add1 ? EW_ADD : EW_COPY, a1Q, add1 ? *add1 : a1Q, out1, B, nullptr, nullptr, st));
+        return HE_OK;
+    }
     const FusedPlan *plan = nullptr;
     TRY(get_md_plan(ev, levelQ, levelP, &plan));
     bool acc_f64 = plan->ok;  // the fused ModDown epilogue can read double accumulators
@@ -1993,7 +2025,7 @@ int he_gadget_product_lazy(he_handle hev, int levelQ, he_handle hcx, he_handle h
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, cx->batch, o, "he_gadget_product_lazy"));
     Scope sc(be.ctx.get());
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true, k.get())));
-    return gadget_product_lazy_core(*ev, levelQ, cx->view(), cx->batch, *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view());
+    return gadget_product_lazy_core(*ev, levelQ, cx->view(), cx->batch, *k, o.q0->view(), o.vp0(), o.q1->view(), o.vp1());
 }
 int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he_handle hk, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -2013,7 +2045,20 @@ int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c
     GET(out0, Poly, hout0, T_POLY);
     GET(out1, Poly, hout1, T_POLY);
     BasisExtender &be = *ev->be;
-    if (levelQ < 0 || levelQ >= be.LQ || levelP < 0 || levelP >= be.LP) return fail(HE_EINVAL, "he_moddown: level out of range");
+    if (levelQ < 0 || levelQ >= be.LQ || levelP < -1 || levelP >= be.LP) return fail(HE_EINVAL, "he_moddown: level out of range");
+    if (levelP == -1) {  // ModDown without special primes, NTT -> NTT: ctQP.Value[k].Q.CopyLvl(levelQ, ct.Value[k]) (:76-81)
+        GET(q0, Poly, c0Q, T_POLY);
+        GET(q1, Poly, c1Q, T_POLY);
+        for (Poly *pp : {q0.get(), q1.get(), out0.get(), out1.get()}) {
+            TRY(check_be_poly(*pp, be, levelQ + 1, "he_moddown"));
+            if (pp->batch != out0->batch) return fail(HE_EINVAL, "he_moddown: batch mismatch");
+        }
+        Scope sc(be.ctx.get());
+        const LimbTab tq = ident_tab(levelQ + 1);
+        HIP_TRY(launch_ew(be.qp, tq, EW_COPY, q0->view(), q0->view(), out0->view(), out0->batch, nullptr, nullptr, be.ctx->stream));
+        HIP_TRY(launch_ew(be.qp, tq, EW_COPY, q1->view(), q1->view(), out1->view(), out1->batch, nullptr, nullptr, be.ctx->stream));
+        return HE_OK;
+    }
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, levelP, out0->batch, o, "he_moddown"));
     TRY(check_be_poly(*out0, be, levelQ + 1, "he_moddown"));

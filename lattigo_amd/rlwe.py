@@ -31,14 +31,15 @@ class EvaluationKey:
             q = p = None
         else:
             q = np.ascontiguousarray(q, dtype=np.uint64)
-            p = np.ascontiguousarray(p, dtype=np.uint64)
+            # p = None: a key without P part (parameters without special primes, levelP = -1; base-2 gadgets only)
+            p = np.zeros(q.shape[:2] + (0, q.shape[3]), dtype=np.uint64) if p is None else np.ascontiguousarray(p, dtype=np.uint64)
             assert q.ndim == 4 and p.ndim == 4 and q.shape[:2] == p.shape[:2] and q.shape[1] == 2
             self.beta, self.nQk, self.nPk = q.shape[0], q.shape[2], p.shape[2]
         self.N = evaluator.ringQ.N
         self.BaseTwoDecomposition = BaseTwoDecomposition
         self.BaseTwoDecompositionVectorSize = list(BaseTwoDecompositionVectorSize) if BaseTwoDecomposition else None
         h = H()
-        pq, pp = (None, None) if q is None else (_p(q), _p(p))
+        pq, pp = (None, None) if q is None else (_p(q), _p(p) if p.size else None)
         if BaseTwoDecomposition:
             nj = (C.c_int * len(BaseTwoDecompositionVectorSize))(*BaseTwoDecompositionVectorSize)
             check(load().he_evk_create_base2(evaluator.h, BaseTwoDecomposition, nj, len(BaseTwoDecompositionVectorSize),
@@ -109,10 +110,12 @@ class Decomposition:
 class Evaluator:
     """rlwe.Evaluator (core/rlwe/evaluator.go:12) restricted to the key-switch path."""
 
-    def __init__(self, ringQ: Ring, ringP: Ring):
+    def __init__(self, ringQ: Ring, ringP: Ring | None):
+        """ringP = None: parameters without special primes (rlwe.ParametersLiteral.P = nil): levelP = -1 in every call, keys
+        are base-2 gadgets without a P part and a QP element is a (Q, None) pair."""
         self.ringQ, self.ringP = ringQ, ringP
         h = H()
-        check(load().he_evaluator_create(ringQ.h, ringP.h, C.byref(h)))
+        check(load().he_evaluator_create(ringQ.h, ringP.h if ringP is not None else 0, C.byref(h)))
         self.h = h.value
 
     def __del__(self):
@@ -151,16 +154,19 @@ class Evaluator:
     # domain of cx and of the result (:121-125, :142-152)
     def GadgetProductLazy(self, levelQ, cx: Poly, evk: EvaluationKey, ctQP, isNTT: bool = True):
         (q0, p0), (q1, p1) = ctQP
+        hp = lambda p: p.h if p is not None else 0  # levelP = -1: no P part
         if isNTT:
-            check(load().he_gadget_product_lazy(self.h, levelQ, cx.h, evk.h, q0.h, p0.h, q1.h, p1.h))
+            check(load().he_gadget_product_lazy(self.h, levelQ, cx.h, evk.h, q0.h, hp(p0), q1.h, hp(p1)))
             return
-        rQ, rP = self.ringQ.AtLevel(levelQ), self.ringP.AtLevel(evk.LevelP())
+        rQ = self.ringQ.AtLevel(levelQ)
+        rP = self.ringP.AtLevel(evk.LevelP()) if evk.LevelP() >= 0 else None
         cxNTT = Poly(self.ringQ, levelQ + 1, cx.batch, zero=False)
         rQ.NTT(cx, cxNTT)
-        check(load().he_gadget_product_lazy(self.h, levelQ, cxNTT.h, evk.h, q0.h, p0.h, q1.h, p1.h))
+        check(load().he_gadget_product_lazy(self.h, levelQ, cxNTT.h, evk.h, q0.h, hp(p0), q1.h, hp(p1)))
         for q, p in ctQP:  # ringQP.INTT (:121-125)
             rQ.INTT(q, q)
-            rP.INTT(p, p)
+            if rP is not None:
+                rP.INTT(p, p)
 
     # EvaluatorProvider.GadgetProductHoistedLazy (:379)
     def GadgetProductHoistedLazy(self, levelQ, decomp: Decomposition, evk: EvaluationKey, ctQP):
@@ -175,6 +181,14 @@ class Evaluator:
 
     def ModDown(self, levelQ, levelP, ctQP, ct, ctQPIsNTT: bool = True, ctIsNTT: bool = True):
         (q0, p0), (q1, p1) = ctQP
+        if levelP == -1:  # no special primes (:74-96): a copy, or one NTT / INTT of the Q part
+            rQ = self.ringQ.AtLevel(levelQ)
+            if ctQPIsNTT == ctIsNTT:
+                check(load().he_moddown(self.h, levelQ, -1, q0.h, 0, q1.h, 0, ct[0].h, ct[1].h))
+            else:
+                for q, o in zip((q0, q1), ct):
+                    (rQ.INTT if ctQPIsNTT else rQ.NTT)(q, o)
+            return
         if ctQPIsNTT and ctIsNTT:
             check(load().he_moddown(self.h, levelQ, levelP, q0.h, p0.h, q1.h, p1.h, ct[0].h, ct[1].h))
             return
@@ -198,7 +212,8 @@ class Evaluator:
             check(load().he_gadget_product(self.h, levelQ, cx.h, evk.h, ct[0].h, ct[1].h))
             return
         B = cx.batch
-        ctQP = [(Poly(self.ringQ, levelQ + 1, B, zero=False), Poly(self.ringP, evk.LevelP() + 1, B, zero=False)) for _ in range(2)]
+        ctQP = [(Poly(self.ringQ, levelQ + 1, B, zero=False),
+                 Poly(self.ringP, evk.LevelP() + 1, B, zero=False) if evk.LevelP() >= 0 else None) for _ in range(2)]
         self.GadgetProductLazy(levelQ, cx, evk, ctQP, isNTT=False)
         self.ModDown(levelQ, evk.LevelP(), ctQP, ct, ctQPIsNTT=False, ctIsNTT=False)
 

@@ -1189,6 +1189,7 @@ void lo_decompose_and_split(const lo_decomposer *d, int levelQ, int levelP, int 
 lo_evaluator *lo_evaluator_new(lo_ring *ringQ, lo_ring *ringP) {
     lo_evaluator *e = (lo_evaluator *)calloc(1, sizeof *e);
     e->ringQ = ringQ; e->ringP = ringP;
+    if (!ringP) return e;  /* parameters without special primes (P = nil): levelP = -1 everywhere, no basis extension */
     e->be = lo_basis_extender_new(ringQ, ringP);
     e->dec = lo_decomposer_new(ringQ, ringP);
     return e;
@@ -1257,14 +1258,16 @@ static void periodic_reduce(const lo_evaluator *e, int levelQ, int levelP, int r
     int N = e->ringQ->N;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
     if (reduce % QiOverF == QiOverF - 1) { reduce_poly(e->ringQ, levelQ, ctQ); reduce_poly(e->ringQ, levelQ, ctQ + szQ); }
-    if (reduce % PiOverF == PiOverF - 1) { reduce_poly(e->ringP, levelP, ctP); reduce_poly(e->ringP, levelP, ctP + szP); }
+    /* `if ringP != nil` (:309-312) */
+    if (e->ringP && reduce % PiOverF == PiOverF - 1) { reduce_poly(e->ringP, levelP, ctP); reduce_poly(e->ringP, levelP, ctP + szP); }
 }
 static void final_reduce(const lo_evaluator *e, int levelQ, int levelP, int reduce, int QiOverF, int PiOverF,
                          uint64_t *ctQ, uint64_t *ctP) {
     int N = e->ringQ->N;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
     if (reduce % QiOverF != 0) { reduce_poly(e->ringQ, levelQ, ctQ); reduce_poly(e->ringQ, levelQ, ctQ + szQ); }
-    if (reduce % PiOverF != 0) { reduce_poly(e->ringP, levelP, ctP); reduce_poly(e->ringP, levelP, ctP + szP); }
+    /* `if ringP != nil` (:330-336) */
+    if (e->ringP && reduce % PiOverF != 0) { reduce_poly(e->ringP, levelP, ctP); reduce_poly(e->ringP, levelP, ctP + szP); }
 }
 
 /* gadgetProductMultiplePLazy, :129-201 (ctQP.IsNTT = true) */
@@ -1299,7 +1302,8 @@ static void gadget_product_single_p_lazy(const lo_evaluator *e, int levelQ, cons
     lo_intt(e->ringQ, levelQ, cx, cxInv);
     int pw2 = evk->pw2;
     uint64_t mask = pw2 ? (((uint64_t)1 << pw2) - 1) : 0;
-    int QiOverF = overflow_margin(e->ringQ, levelQ) >> 1, PiOverF = overflow_margin(e->ringP, levelP) >> 1;
+    /* levelP = -1 (ringP == nil, :284,:302): the P loops below do not run and PiOverF is never looked at */
+    int QiOverF = overflow_margin(e->ringQ, levelQ) >> 1, PiOverF = e->ringP ? overflow_margin(e->ringP, levelP) >> 1 : 1;
     int reduce = 0, blk = 0;
     for (int i = 0; i < levelQ + 1; i++) {
         if (mask == 0) lo_decompose_and_split(e->dec, levelQ, levelP, levelP + 1, i, cxInv, c2Q, c2P);
@@ -1360,6 +1364,10 @@ void lo_gadget_product_hoisted_lazy(const lo_evaluator *e, int levelQ, const uin
 void lo_moddown_ntt(const lo_evaluator *e, int levelQ, int levelP, const uint64_t *ctQ, const uint64_t *ctP, uint64_t *ct) {
     int N = e->ringQ->N;
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
+    if (levelP == -1) {  /* :76-81: ctQP.Value[k].Q.CopyLvl(levelQ, ct.Value[k]) */
+        memcpy(ct, ctQ, 2 * szQ * 8);
+        return;
+    }
     lo_moddown_qp_to_q_ntt(e->be, levelQ, levelP, ctQ, ctP, ct);
     lo_moddown_qp_to_q_ntt(e->be, levelQ, levelP, ctQ + szQ, ctP + szP, ct + szQ);
 }

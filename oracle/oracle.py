@@ -604,9 +604,11 @@ def BaseRNSDecompositionVectorSize(levelQ, levelP):
 class Evaluator:
     """Restated rlwe.Evaluator hot path (core/rlwe/evaluator*.go), NTT-domain ciphertexts."""
 
-    def __init__(self, ringQ: Ring, ringP: Ring):
+    def __init__(self, ringQ: Ring, ringP: Ring | None):
+        """ringP = None: parameters without special primes (levelP = -1; base-2 gadget keys only, as the reference's own
+        P-less test set, core/rlwe/test_params.go:36-46)"""
         self.ringQ, self.ringP = ringQ, ringP
-        self._h = lib().lo_evaluator_new(ringQ._h, ringP._h)
+        self._h = lib().lo_evaluator_new(ringQ._h, ringP._h if ringP is not None else None)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -30,7 +30,8 @@ class SecretKey:
         N = ringQ.N
         self.vals = rng.integers(-1, 2, size=N) if vals is None else np.asarray(vals)
         self.Q = ringQ.unop("MForm", ringQ.NTT(small_to_rns(self.vals, ringQ.moduli)))
-        self.P = ringP.unop("MForm", ringP.NTT(small_to_rns(self.vals, ringP.moduli)))
+        # ringP = None: parameters without special primes (core/rlwe/keygenerator.go:64 `if levelP > -1`)
+        self.P = ringP.unop("MForm", ringP.NTT(small_to_rns(self.vals, ringP.moduli))) if ringP is not None else None
 
 
 def automorphism_secret(rng, ringQ, ringP, sk: SecretKey, galel: int) -> SecretKey:
@@ -98,15 +99,15 @@ def noise_log2(ringQ: O.Ring, ntt_poly: np.ndarray) -> float:
 
 def gen_evaluation_key_base2(rng, ringQ: O.Ring, ringP: O.Ring, sk_in_Q: np.ndarray, sk_out: SecretKey, pw2: int,
                              sigma: float = 3.2) -> O.EvaluationKey:
-    """Base-2 gadget key (core/rlwe/gadgetciphertext.go:172-241 with BaseTwoDecomposition = pw2, one P limb):
-    block (i, j) encrypts P * 2^(j*pw2) * skIn on Q-limb i only; nj[i] = ceil(bits(q_i) / pw2)
-    (core/rlwe/params.go:523-540)."""
+    """Base-2 gadget key (core/rlwe/gadgetciphertext.go:172-241 with BaseTwoDecomposition = pw2, one P limb, or none --
+    ringP = None, `levelP != -1` :183 --): block (i, j) encrypts P * 2^(j*pw2) * skIn on Q-limb i only;
+    nj[i] = ceil(bits(q_i) / pw2) (core/rlwe/params.go:523-540)."""
     N = ringQ.N
-    LQ, LP = len(ringQ.moduli), len(ringP.moduli)
-    assert LP == 1
+    LQ, LP = len(ringQ.moduli), (len(ringP.moduli) if ringP is not None else 0)
+    assert LP <= 1
     nj = [(int(q).bit_length() + pw2 - 1) // pw2 for q in ringQ.moduli]
     D = sum(nj)
-    P = prod(ringP.moduli)
+    P = prod(ringP.moduli) if LP else 1
     kq = np.zeros((D, 2, LQ, N), dtype=np.uint64)
     kp = np.zeros((D, 2, LP, N), dtype=np.uint64)
     blk = 0
@@ -114,14 +115,15 @@ def gen_evaluation_key_base2(rng, ringQ: O.Ring, ringP: O.Ring, sk_in_Q: np.ndar
         for j in range(nj[i]):
             e = np.clip(np.rint(rng.normal(0.0, sigma, size=N)), -19, 19).astype(np.int64)
             aQ = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringQ.moduli])
-            aP = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringP.moduli])
             bQ = ringQ.unop("MForm", ringQ.NTT(small_to_rns(e, ringQ.moduli)))
-            bP = ringP.unop("MForm", ringP.NTT(small_to_rns(e, ringP.moduli)))
             bQ = ringQ.binop("MulCoeffsMontgomeryThenSub", aQ, sk_out.Q, bQ)
-            bP = ringP.binop("MulCoeffsMontgomeryThenSub", aP, sk_out.P, bP)
             g = ringQ.MulScalarBigint(sk_in_Q, P << (j * pw2))
             bQ[i] = ringQ.binop("Add", bQ, g)[i]
-            kq[blk, 0], kq[blk, 1], kp[blk, 0], kp[blk, 1] = bQ, aQ, bP, aP
+            kq[blk, 0], kq[blk, 1] = bQ, aQ
+            if LP:
+                aP = np.stack([rng.integers(0, int(q), size=N, dtype=np.uint64) for q in ringP.moduli])
+                bP = ringP.unop("MForm", ringP.NTT(small_to_rns(e, ringP.moduli)))
+                kp[blk, 0], kp[blk, 1] = ringP.binop("MulCoeffsMontgomeryThenSub", aP, sk_out.P, bP), aP
             blk += 1
     return O.EvaluationKey(kq, kp, pw2=pw2, nj=nj)
 

@@ -352,6 +352,64 @@ def test_base2_gadget_product(ctx, pw2):
         gev.GadgetProductHoisted(3, la.Decomposition(gev, 2), gevk, ct)
 
 
+@pytest.mark.parametrize("pw2", [2, 16])
+def test_gadget_product_without_special_primes(ctx, pw2):
+    """levelP = -1 (rlwe.ParametersLiteral.P = nil; the reference's P-less test set, core/rlwe/test_params.go:36-46):
+    GadgetProductLazy / GadgetProduct / ModDown / Relinearize / Automorphism with a base-2 key that has no P part, bit for bit
+    against the oracle (core/rlwe/evaluator_gadget_product.go:74-96,:203-338 with ringP == nil)."""
+    q = [0x200000440001, 0x7fff80001, 0x800280001, 0x7ffd80001, 0x7ffc80001]
+    logN = 10
+    pr = Pair(ctx, logN, len(q), qmods=q)
+    rng = rng_for(2700 + pw2)
+    oev, gev = O.Evaluator(pr.oQ, None), la.Evaluator(pr.gQ, None)
+    sk, sk2 = SecretKey(rng, pr.oQ, None), SecretKey(rng, pr.oQ, None)
+    oevk = gen_evaluation_key_base2(rng, pr.oQ, None, sk.Q, sk2, pw2)
+    gevk = gev.NewEvaluationKey(oevk.q, None, pw2, oevk.nj[: len(q)])
+    assert gevk.LevelP() == -1
+    for levelQ in (4, 3, 0):
+        Qm = q[: levelQ + 1]
+        cx = np.stack([uniform_poly(rng, Qm, pr.N) for _ in range(3)])
+        pcx = la.Poly(pr.gQ, levelQ + 1, 3).upload(cx)
+        qp = [(la.Poly(pr.gQ, levelQ + 1, 3), None) for _ in range(2)]
+        gev.GadgetProductLazy(levelQ, pcx, gevk, qp)
+        ct = [la.Poly(pr.gQ, levelQ + 1, 3), la.Poly(pr.gQ, levelQ + 1, 3)]
+        gev.GadgetProduct(levelQ, pcx, gevk, ct)
+        md = [la.Poly(pr.gQ, levelQ + 1, 3), la.Poly(pr.gQ, levelQ + 1, 3)]
+        gev.ModDown(levelQ, -1, qp, md)
+        for b in range(3):
+            wQ, _ = oev.GadgetProductLazy(levelQ, cx[b], oevk)
+            want = oev.GadgetProduct(levelQ, cx[b], oevk)
+            for k in range(2):
+                assert np.array_equal(qp[k][0].get()[b], wQ[k]), (levelQ, b, k)
+                assert np.array_equal(ct[k].get()[b], want[k]) and np.array_equal(md[k].get()[b], want[k]), (levelQ, b, k)
+        sub = O.Ring(pr.N, Qm)
+        got = np.stack([c.get()[0] for c in ct])
+        noise = noise_log2(pr.oQ, sub.binop("Sub", phase(pr.oQ, got, sk2.Q), sub.binop("MulCoeffsMontgomery", cx[0], sk.Q[: levelQ + 1])))
+        assert noise <= logN + pw2 + 6, noise
+        # coefficient-domain forms of GadgetProduct / ModDown (ct.IsNTT = false)
+        cxc = pr.oQ.INTT(np.concatenate([cx[0], np.zeros((len(q) - levelQ - 1, pr.N), dtype=np.uint64)]))[: levelQ + 1]
+        pc = la.Poly(pr.gQ, levelQ + 1).upload(cxc)
+        ctc = [la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gQ, levelQ + 1)]
+        gev.GadgetProduct(levelQ, pc, gevk, ctc, isNTT=False)
+        wantc = np.stack([sub.INTT(w) for w in oev.GadgetProduct(levelQ, cx[0], oevk)])
+        assert np.array_equal(np.stack([c.get() for c in ctc]), wantc), levelQ
+    # Relinearize and Automorphism sit on the same path
+    level = len(q) - 1
+    ct3 = np.stack([uniform_poly(rng, q, pr.N) for _ in range(3)])
+    p3 = [pr.gQ.NewPoly().upload(c) for c in ct3]
+    out = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
+    gev.Relinearize(level, p3, gevk, out)
+    assert np.array_equal(np.stack([o.get() for o in out]), oev.Relinearize(ct3, oevk))
+    galel = pow(5, 3, 2 * pr.N)
+    gev.Automorphism(level, p3[:2], galel, gevk, out)
+    assert np.array_equal(np.stack([o.get() for o in out]), oev.Automorphism(ct3[:2], galel, oevk))
+    # what the reference cannot do without special primes is rejected: RNS-only keys, hoisted decompositions
+    with pytest.raises(la.HeringError):
+        gev.NewEvaluationKey(oevk.q[: len(q)], None)
+    with pytest.raises(la.HeringError):
+        la.Decomposition(gev)
+
+
 @pytest.mark.parametrize("logN", [9, 10, 12, 13])
 def test_mixed_modulus_sizes_all_kernel_classes(ctx, logN):
     """Chains mixing moduli below 2^47 (double-precision kernels, fused NTT+MAC), below 2^58 (correction-free

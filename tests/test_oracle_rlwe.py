@@ -153,3 +153,27 @@ def test_base2_gadget_product_decrypts(pw2):
         got = phase(ringQ, ct, sk2.Q)
         want = sub.binop("MulCoeffsMontgomery", cx, sk.Q[: levelQ + 1])
         assert noise_log2(ringQ, sub.binop("Sub", got, want)) <= 10 + pw2 + 6
+
+
+@pytest.mark.parametrize("pw2", [2, 16])
+def test_gadget_product_without_special_primes_decrypts(pw2):
+    """Parameters without P (levelP = -1): the reference's third test set (core/rlwe/test_params.go:36-46, "No RNS
+    decomposition, Pw2 decomposition") -- gadgetProductSinglePAndBitDecompLazy with ringP == nil and ModDown's levelP == -1
+    copy (core/rlwe/evaluator_gadget_product.go:74-96,:284,:302,:330).  Noise bound as rlwe_test.go:679."""
+    rng = rng_for(900 + pw2)
+    q = [0x200000440001, 0x7fff80001, 0x800280001, 0x7ffd80001, 0x7ffc80001]  # core/rlwe/test_params.go:11
+    ringQ = O.Ring(N, q)
+    ev = O.Evaluator(ringQ, None)
+    sk, sk2 = SecretKey(rng, ringQ, None), SecretKey(rng, ringQ, None)
+    evk = gen_evaluation_key_base2(rng, ringQ, None, sk.Q, sk2, pw2)
+    assert evk.LevelP() == -1
+    for levelQ in (4, 2, 0):
+        sub = O.Ring(N, q[: levelQ + 1])
+        cx = uniform_poly(rng, sub.moduli, N)
+        ctQ, ctP = ev.GadgetProductLazy(levelQ, cx, evk)
+        assert ctP.shape == (2, 0, N)
+        ct = ev.GadgetProduct(levelQ, cx, evk)
+        assert np.array_equal(ct, ctQ)  # ModDown without P is a copy of the reduced Q accumulators
+        got = phase(ringQ, ct, sk2.Q)
+        want = sub.binop("MulCoeffsMontgomery", cx, sk.Q[: levelQ + 1])
+        assert noise_log2(ringQ, sub.binop("Sub", got, want)) <= 10 + pw2 + 6
