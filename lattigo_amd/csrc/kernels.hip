@@ -1889,9 +1889,11 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     }
 }
 
+// source limbs per digit: up to 8 (the descriptor's arrays) for up to three fused column stages, up to 5 with four (logN = 17:
+// sixteen coefficients per thread; beyond that the residues no longer fit the registers / LDS and the unfused path is used)
 bool modup_fused_supported(int logN, int nsrc) {
     const int a = logN - ntt_row_bits(logN);
-    return nsrc >= 1 && nsrc <= 5 && (a == 0 || a == 2 || a == 3 || a == 4);
+    return nsrc >= 1 && a >= 0 && ((a <= 3 && nsrc <= 8) || (a == 4 && nsrc <= 5));
 }
 
 template <bool F64>
@@ -1900,18 +1902,30 @@ static void launch_modup_fused_variant(int a, int nsrc, dim3 grid, dim3 block, c
 #define HE_MF_A(NS)                                  \
     switch (a) {                                     \
         case 0: HE_MF(NS, 0); break;                 \
+        case 1: HE_MF(NS, 1); break;                 \
         case 2: HE_MF(NS, 2); break;                 \
         case 3: HE_MF(NS, 3); break;                 \
         default: HE_MF(NS, 4); break;                \
+    }
+#define HE_MF_B(NS)                                  \
+    switch (a) {                                     \
+        case 0: HE_MF(NS, 0); break;                 \
+        case 1: HE_MF(NS, 1); break;                 \
+        case 2: HE_MF(NS, 2); break;                 \
+        default: HE_MF(NS, 3); break;                \
     }
     switch (nsrc) {
         case 1: HE_MF_A(1); break;
         case 2: HE_MF_A(2); break;
         case 3: HE_MF_A(3); break;
         case 4: HE_MF_A(4); break;
-        default: HE_MF_A(5); break;
+        case 5: HE_MF_A(5); break;
+        case 6: HE_MF_B(6); break;
+        case 7: HE_MF_B(7); break;
+        default: HE_MF_B(8); break;
     }
 #undef HE_MF_A
+#undef HE_MF_B
 #undef HE_MF
 }
 

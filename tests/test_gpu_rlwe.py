@@ -352,6 +352,50 @@ def test_base2_gadget_product(ctx, pw2):
         gev.GadgetProductHoisted(3, la.Decomposition(gev, 2), gevk, ct)
 
 
+@pytest.mark.parametrize("logN,np_", [(12, 6), (13, 7), (14, 8), (13, 2), (13, 5)])
+def test_fused_pipeline_wide_digits_and_logN13(ctx, logN, np_):
+    """The fused key-switch pipeline at the shapes round 1 sent down the unfused path: digits of 6, 7 and 8 limbs (the
+    reference allows up to 32 source limbs, ring/basis_extension.go:285) and logN = 13 (one fused column stage); moduli of
+    all three arithmetic classes; full and partial trailing digit; GadgetProduct, hoisted form and MulRelin against the oracle."""
+    logq = ([55, 45, 61, 40, 58, 36] * 4)[: 2 * np_ + 1]
+    logp = ([61, 46, 55, 60, 40, 58, 45, 61])[:np_]
+    q, p = O.GenModuli(logN + 1, logq, logp)
+    pr = Pair(ctx, logN, len(q), len(p), qmods=q, pmods=p)
+    rng = rng_for(2800 + logN * 10 + np_)
+    gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+    beta = O.BaseRNSDecompositionVectorSize(len(q) - 1, np_ - 1)
+    kq = np.stack([np.stack([uniform_poly(rng, q, pr.N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, pr.N) for _ in range(2)]) for _ in range(beta)])
+    gevk, oevk = gev.NewEvaluationKey(kq, kp), O.EvaluationKey(kq, kp)
+    for level in (len(q) - 1, len(q) - 2, np_ - 1):
+        Qm = q[: level + 1]
+        cx = np.stack([uniform_poly(rng, Qm, pr.N) for _ in range(2)])
+        pcx = la.Poly(pr.gQ, level + 1, 2).upload(cx)
+        out = [la.Poly(pr.gQ, level + 1, 2), la.Poly(pr.gQ, level + 1, 2)]
+        gev.GadgetProduct(level, pcx, gevk, out)
+        for b in range(2):
+            want = oev.GadgetProduct(level, cx[b], oevk)
+            assert np.array_equal(out[0].get()[b], want[0]) and np.array_equal(out[1].get()[b], want[1]), (level, b)
+        dec = la.Decomposition(gev, 2)
+        gev.DecomposeNTT(level, np_ - 1, np_, pcx, True, dec)
+        dq, dp = oev.DecomposeNTT(level, np_ - 1, np_, cx[1], True)
+        for d in range(dq.shape[0]):
+            for l in range(level + 1):
+                assert np.array_equal(dec.limb(1, d, False, l), dq[d, l]), (level, d, l)
+            for l in range(np_):
+                assert np.array_equal(dec.limb(1, d, True, l), dp[d, l]), (level, d, l)
+        out2 = [la.Poly(pr.gQ, level + 1, 2), la.Poly(pr.gQ, level + 1, 2)]
+        gev.GadgetProductHoisted(level, dec, gevk, out2)
+        assert np.array_equal(out2[0].get(), out[0].get()) and np.array_equal(out2[1].get(), out[1].get())
+    level = len(q) - 1
+    ct0 = np.stack([uniform_poly(rng, q, pr.N) for _ in range(2)])
+    ct1 = np.stack([uniform_poly(rng, q, pr.N) for _ in range(2)])
+    a, b = [pr.gQ.NewPoly().upload(c) for c in ct0], [pr.gQ.NewPoly().upload(c) for c in ct1]
+    o2 = [pr.gQ.NewPoly(), pr.gQ.NewPoly()]
+    gev.CKKSMulRelin(level, a, b, gevk, o2)
+    assert np.array_equal(np.stack([o.get() for o in o2]), oev.CKKSMulRelin(ct0, ct1, oevk, True))
+
+
 @pytest.mark.parametrize("pw2", [2, 16])
 def test_gadget_product_without_special_primes(ctx, pw2):
     """levelP = -1 (rlwe.ParametersLiteral.P = nil; the reference's P-less test set, core/rlwe/test_params.go:36-46):
