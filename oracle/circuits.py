@@ -815,7 +815,7 @@ class CKKSCtEvaluator:
 
 
 class OracleBootstrapBackend:
-    """adapters for lattigo_amd.bootstrapping.Bootstrapper over the oracle (test infrastructure)"""
+    """adapters for lattigo_amd.drivers.bootstrapping.Bootstrapper over the oracle (test infrastructure)"""
 
     def __init__(self, ckks: CKKSCtEvaluator, lte: LinTransEvaluator, ise: InnerSumEvaluator, EvkDenseToSparse=None,
                  EvkSparseToDense=None):

@@ -146,7 +146,7 @@ def test_evaluate_many_shares_the_decomposition_and_levels():
 
 
 def test_host_helpers_of_the_product_match_the_oracle():
-    from lattigo_amd import lintrans as LT
+    from lattigo_amd.drivers import lintrans as LT
     from lattigo_amd import rlwe as R
 
     for diags, slots, N1 in (([0, 1, 2, 3, 9, 200, 511], 256, 8), ([5, 6, 7], 512, 4), (list(range(40)), 64, 16)):
@@ -286,7 +286,7 @@ def _ring_poly_eval(coeffs, m, t):
 def test_bgv_polynomial_evaluation_decrypts(deg):
     """circuits/bgv/polynomial Evaluator.Evaluate (Paterson-Stockmeyer over the power basis, level / scale planning by the
     simulated evaluator) with the oracle as the bgv.Evaluator backend: Dec(p(ct)) = p(m) in R_t, output scale = target."""
-    from lattigo_amd import polyeval as PE
+    from lattigo_amd.drivers import polyeval as PE
     from tests.rlwe_fixtures import bgv_decrypt, bgv_encrypt
     t = 65537
     q, p = O.GenModuli(10, [55, 45, 45, 45, 45, 45, 45], [55, 55])
@@ -316,7 +316,7 @@ def test_ckks_polynomial_evaluation_decrypts(deg, basis):
     """circuits/ckks/polynomial Evaluator.Evaluate (monomial and Chebyshev bases, complex coefficients) with the oracle as
     the ckks.Evaluator backend: the slots of Dec(p(ct)) equal p(slots of ct) to ~1e-7, output scale = target exactly."""
     from fractions import Fraction
-    from lattigo_amd import polyeval as PE
+    from lattigo_amd.drivers import polyeval as PE
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     q, p = O.GenModuli(10, [55] + [45] * 7, [55, 55])
     rng = rng_for(4000 + deg)
@@ -348,7 +348,7 @@ def test_mod1_evaluates_the_scaled_sine(kind, K, deg, r):
     """circuits/ckks/mod1 Evaluator.EvaluateNew (bootstrapping's EvalMod) with the oracle as the ckks.Evaluator backend:
     slots x / K in, QDiff / (2 pi) * sin(2 pi x) out (= QDiff * (x mod 1) for x close to an integer)."""
     from fractions import Fraction
-    from lattigo_amd import mod1 as M1
+    from lattigo_amd.drivers import mod1 as M1
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     q, p = O.GenModuli(10, [55] + [45] * 10, [55, 55])
     rng = rng_for(4100 + K)
@@ -391,7 +391,7 @@ def test_mod1_with_arcsine_is_linear_in_the_message():
     """Mod1InvDegree > 0 (mod1_parameters.go:117-137, mod1_evaluator.go:121-138): composing the scaled sine with the arcsine
     series removes the cubic term, so the result is QDiff * (x mod 1) even for a large message ratio 2^-3."""
     from fractions import Fraction
-    from lattigo_amd import mod1 as M1
+    from lattigo_amd.drivers import mod1 as M1
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     q, p = O.GenModuli(10, [55] + [45] * 12, [55, 55])
     rng = rng_for(4300)
@@ -421,7 +421,7 @@ def test_scale_down_brings_the_message_below_q0():
     ciphertext multiplied by an integer so that Q[0] / scale = MessageRatio; the slots are unchanged."""
     from fractions import Fraction
     from types import SimpleNamespace
-    from lattigo_amd import bootstrapping as BS
+    from lattigo_amd.drivers import bootstrapping as BS
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     q, p = O.GenModuli(10, [55, 45, 45], [55])
     rng = rng_for(4400)

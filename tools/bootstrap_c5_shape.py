@@ -17,11 +17,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lattigo_amd as la  # noqa: E402
 from bench import uniform  # noqa: E402
-from lattigo_amd import bootstrapping as BS  # noqa: E402
-from lattigo_amd import lintrans as LT  # noqa: E402
-from lattigo_amd import mod1 as M1  # noqa: E402
+from lattigo_amd.drivers import bootstrapping as BS  # noqa: E402
+from lattigo_amd.drivers import lintrans as LT  # noqa: E402
+from lattigo_amd.drivers import mod1 as M1  # noqa: E402
 from lattigo_amd import rlwe as R  # noqa: E402
-from lattigo_amd import schemes as S  # noqa: E402
+from lattigo_amd.drivers import schemes as S  # noqa: E402
 
 # moduli of the right sizes, = 1 mod 2^17 (generated once with the reference's prime search; values only set the sizes)
 LOGQ = [60] + [40] * 9 + [39] * 3 + [60] * 8 + [56] * 4
