@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the multi-GPU control plane (lattigo_amd/dist.py): sharding of
+"""world_size-2 and world_size-8 gloo tests of the multi-GPU control plane (lattigo_amd/dist.py): sharding of
 independent ciphertexts, barrier, MAX/SUM over ranks.  Runs on CPU; the per-rank compute is the
 GPU path covered by the `-m gpu` tests."""
 import os
@@ -13,13 +13,15 @@ WORKER = textwrap.dedent("""
     sys.path.insert(0, %r)
     from lattigo_amd.dist import ControlPlane
     cp = ControlPlane()
-    assert cp.world == 2
-    mine = list(cp.shard(7))
-    assert mine == ([0, 2, 4, 6] if cp.rank == 0 else [1, 3, 5])
+    W = cp.world
+    assert W in (2, 8)
+    items = 7 if W == 2 else 29               # ciphertext b goes to rank b mod W (SURVEY.md section 8e)
+    mine = list(cp.shard(items))
+    assert mine == list(range(cp.rank, items, W))
     cp.barrier()
-    t = cp.max_over_ranks(1.0 + cp.rank)      # rank 1 is the slow one
+    t = cp.max_over_ranks(1.0 + cp.rank)      # the last rank is the slow one
     n = cp.sum_over_ranks(len(mine))
-    assert t == 2.0 and n == 7.0, (t, n)
+    assert t == float(W) and n == float(items), (t, n)
     # key replication, host leg: a Galois key in the reference's wire format travels from rank 0 (core/rlwe/keys.go:628)
     import hashlib
     import numpy as np
@@ -38,19 +40,25 @@ WORKER = textwrap.dedent("""
     digest = int(hashlib.sha256(got).hexdigest()[:12], 16)
     assert cp.max_over_ranks(digest) == digest == -cp.max_over_ranks(-digest)  # identical bytes on both ranks
     if cp.rank == 0:
-        print("AGG", n / t)
+        print("AGG", W, n / t)
     cp.close()
 """) % ROOT
 
 
-def test_two_rank_control_plane(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world,agg", [(2, "AGG 2 3.5"), (8, "AGG 8 3.625")])
+def test_control_plane(tmp_path, world, agg):
+    """world size 2, and 8 = one rank per GPU of the node the driver scales to"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ)
     env["MASTER_ADDR"] = "127.0.0.1"
+    env["OMP_NUM_THREADS"] = "1"
     out = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-         "--master-port", "29533", str(script)],
-        capture_output=True, text=True, timeout=300, env=env)
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+         "--master-port", str(29533 + world), str(script)],
+        capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "AGG 3.5" in out.stdout
+    assert agg in out.stdout

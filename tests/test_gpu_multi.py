@@ -1,0 +1,139 @@
+"""Multi-GPU readiness (`-m gpu`; SURVEY.md section 8e: one process per GPU, ciphertexts sharded, keys replicated).
+
+What one GPU can check runs always: every bench.py workload under torch.distributed.run with two ranks sharing the box's GPU
+(HERING_FORCE_DEVICE), each rank's output verified against the oracle.  What needs two or more GPUs enables itself when the
+box has them (the driver's 8-GPU node): the multi-rank RCCL key broadcast over xGMI, and contexts on different devices driven
+alternately from one thread and concurrently from several (every he_* call selects its context's device)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _device_count() -> int:
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                         timeout=300)
+    return int(out.stdout.strip() or 0)
+
+
+@pytest.mark.parametrize("workload,batch", [("c3", 4), ("c4", 2), ("c5", 1)])
+def test_bench_two_ranks_every_workload(workload, batch):
+    """bench.py's multi-rank entry point for BASELINE configs 3, 4 and 5: two ranks (here on one GPU), ciphertexts sharded,
+    keys replicated from rank 0 through the host transport, every rank's last step verified against the oracle."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HERING_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload",
+           workload, "--batch", str(batch), "--no-cpu-baseline", "--no-ntt"] + (["--replicate-keys", "host"] if workload != "c5" else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["batch_per_gpu"] == batch
+    if workload != "c5":
+        assert line["verified"] is True, line["verified_detail"]
+
+
+_RCCL_WORKER = """
+import hashlib, os, sys
+import torch                              # before libhering: one HIP runtime in the process (lattigo_amd/dist.py)
+sys.path.insert(0, %r)
+import numpy as np
+import lattigo_amd as la
+from lattigo_amd.dist import ControlPlane
+from oracle import oracle as O
+from tests.helpers import rng_for, uniform_poly
+cp = ControlPlane()
+dev = cp.local_rank
+torch.cuda.set_device(dev)
+ctx = la.Context(dev)                     # one rank per GPU
+q, p = O.GenModuli(13, [55, 45, 45, 45], [55, 46])
+N = 1 << 12
+gQ, gP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+gev = la.Evaluator(gQ, gP)
+rng = rng_for(2970)                       # same stream on every rank: the same cx; only rank 0 draws a key
+cx = uniform_poly(rng, q, N)
+key = None
+if cp.rank == 0:
+    kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(2)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(2)])
+    key = gev.NewEvaluationKey(kq, kp)
+key = cp.ReplicateEvaluationKey(gev, key, src=0, transport="rccl")   # GPU-to-GPU broadcast into the key's device storage
+ct = [la.Poly(gQ, 4), la.Poly(gQ, 4)]
+gev.GadgetProduct(3, la.Poly(gQ, 4).upload(cx), key, ct)
+got = np.stack([c.get() for c in ct])
+if cp.rank == 0:
+    want = O.Evaluator(O.Ring(N, q), O.Ring(N, p)).GadgetProduct(3, cx, O.EvaluationKey(kq, kp))
+    assert np.array_equal(got, want)
+digest = int(hashlib.sha256(got.tobytes()).hexdigest()[:12], 16)
+assert cp.max_over_ranks(digest) == digest == -cp.max_over_ranks(-digest)   # every rank computed rank 0's (oracle-checked) words
+if cp.rank == 0:
+    print("RCCL_REPLICATED", cp.world)
+cp.close()
+"""
+
+
+def test_multi_rank_rccl_key_replication(tmp_path):
+    """The one RCCL collective of the design (key distribution) with one rank per GPU."""
+    n = min(_device_count(), 8)
+    if n < 2:
+        pytest.skip("needs at least two GPUs (runs on the driver's multi-GPU node)")
+    script = tmp_path / "worker.py"
+    script.write_text(_RCCL_WORKER % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", "29563", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert f"RCCL_REPLICATED {n}" in out.stdout
+
+
+def test_contexts_on_different_devices_select_their_device():
+    """Handles may be used from any OS thread and every call selects its context's device (hering.h conventions): two
+    contexts on two GPUs driven alternately from one thread, then concurrently from two threads."""
+    import lattigo_amd as la
+    from oracle import oracle as O
+    from tests.helpers import rng_for, uniform_poly
+    if _device_count() < 2:
+        pytest.skip("needs at least two GPUs (runs on the driver's multi-GPU node)")
+    N = 1 << 12
+    q, p = O.GenModuli(13, [55, 45, 45], [55])
+    oev = O.Evaluator(O.Ring(N, q), O.Ring(N, p))
+    rng = rng_for(2980)
+    kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(3)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(3)])
+    cxs = [uniform_poly(rng, q, N) for _ in range(2)]
+    wants = [oev.GadgetProduct(2, cx, O.EvaluationKey(kq, kp)) for cx in cxs]
+    envs = []
+    for dev in (0, 1):
+        ctx = la.Context(dev)
+        gQ, gP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+        gev = la.Evaluator(gQ, gP)
+        envs.append((ctx, gQ, gev, gev.NewEvaluationKey(kq, kp)))
+
+    def run(dev, i):
+        ctx, gQ, gev, key = envs[dev]
+        ct = [la.Poly(gQ, 3), la.Poly(gQ, 3)]
+        gev.GadgetProduct(2, la.Poly(gQ, 3).upload(cxs[i]), key, ct)
+        assert np.array_equal(np.stack([c.get() for c in ct]), wants[i]), (dev, i)
+
+    for rep in range(3):  # interleaved on one thread: no call may inherit the other context's device
+        run(0, 0), run(1, 1), run(1, 0), run(0, 1)
+    errs = []
+
+    def worker(dev):
+        try:
+            for rep in range(10):
+                run(dev, rep & 1)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(d,)) for d in (0, 1)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
