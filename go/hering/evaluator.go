@@ -1,0 +1,578 @@
+package hering
+
+/*
+#include "hering.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"sync"
+	"unsafe"
+
+	"github.com/tuneinsight/lattigo/v6/core/rlwe"
+	"github.com/tuneinsight/lattigo/v6/ring"
+	"github.com/tuneinsight/lattigo/v6/ring/ringqp"
+)
+
+// Evaluator is the device twin of rlwe.Evaluator's key-switch path.  It implements rlwe.EvaluatorProvider
+// (core/rlwe/rlwe.go:10-18): the seven methods below take the reference's own host types, find (or create) their device
+// twins, run the HIP path and mark the results device-fresh.  Host memory is only touched by Upload / Download: the
+// circuit drivers above call the provider back-to-back on the same objects, so operands stay in HBM between calls, and a
+// caller that wants to read a result on the host (decrypt, serialise) calls Evaluator.Download on it first.
+type Evaluator struct {
+	params rlwe.Parameters
+	ctx    *Context
+	h      Handle
+	RingQ  *Ring
+	RingP  *Ring
+	keys   rlwe.EvaluationKeySet
+
+	mu     sync.Mutex
+	polys  map[*uint64]*Poly                      // twin of a ring.Poly, keyed by the address of its first coefficient
+	evks   map[*rlwe.GadgetCiphertext]*EvaluationKey // keys are immutable once generated: uploaded once
+	decs   map[*uint64]*Decomposition             // twin of a BuffDecompQP slice, keyed like polys on its first Q row
+	index  map[uint64]*AutomorphismIndex
+	batch  int
+}
+
+// NewEvaluator mirrors rlwe.NewEvaluator(params, evk) on GPU `ctx`.
+func NewEvaluator(ctx *Context, params rlwe.ParameterProvider, evk rlwe.EvaluationKeySet) (*Evaluator, error) {
+	p := *params.GetRLWEParameters()
+	e := &Evaluator{params: p, ctx: ctx, keys: evk, batch: 1,
+		polys: map[*uint64]*Poly{}, evks: map[*rlwe.GadgetCiphertext]*EvaluationKey{}, decs: map[*uint64]*Decomposition{},
+		index: map[uint64]*AutomorphismIndex{}}
+	var err error
+	if e.RingQ, err = NewRing(ctx, p.RingQ()); err != nil {
+		return nil, err
+	}
+	var hp Handle // 0: parameters without special primes (levelP = -1)
+	if p.RingP() != nil {
+		if e.RingP, err = NewRing(ctx, p.RingP()); err != nil {
+			return nil, err
+		}
+		hp = e.RingP.h
+	}
+	if err = lockedCall(func() C.int { return C.he_evaluator_create(e.RingQ.h, hp, &e.h) }); err != nil {
+		return nil, err
+	}
+	return e, nil
+}
+
+// GetRLWEParameters: rlwe.ParameterProvider.
+func (e *Evaluator) GetRLWEParameters() *rlwe.Parameters { return &e.params }
+
+// ---- device twins ------------------------------------------------------------------------------------------------------
+
+func key(p ring.Poly) *uint64 { return &p.Coeffs[0][0] }
+
+// twin returns the device polynomial of a host polynomial of ring r; upload says whether the host content is the current
+// one (an input seen for the first time) or about to be overwritten (an output).
+func (e *Evaluator) twin(r *Ring, p ring.Poly, upload bool) (*Poly, error) {
+	e.mu.Lock()
+	d, ok := e.polys[key(p)]
+	e.mu.Unlock()
+	if ok && d.limbs >= len(p.Coeffs) {
+		return d, nil
+	}
+	d, err := r.AtLevel(len(p.Coeffs) - 1).NewScratch(e.batch)
+	if err != nil {
+		return nil, err
+	}
+	if upload {
+		if err = d.Upload(0, p); err != nil {
+			return nil, err
+		}
+	}
+	e.mu.Lock()
+	e.polys[key(p)] = d
+	e.mu.Unlock()
+	return d, nil
+}
+
+// Upload refreshes the device twin of a host polynomial that was modified on the host.
+func (e *Evaluator) Upload(r *Ring, p ring.Poly) error {
+	d, err := e.twin(r, p, false)
+	if err != nil {
+		return err
+	}
+	return d.Upload(0, p)
+}
+
+// Download copies the device twin of p (if there is one) back to the host polynomial.
+func (e *Evaluator) Download(p ring.Poly) error {
+	e.mu.Lock()
+	d, ok := e.polys[key(p)]
+	e.mu.Unlock()
+	if !ok {
+		return nil
+	}
+	return d.Download(0, p)
+}
+
+// DownloadCiphertext brings every component of ct back to the host.
+func (e *Evaluator) DownloadCiphertext(ct *rlwe.Ciphertext) error {
+	for _, v := range ct.Value {
+		if err := e.Download(v); err != nil {
+			return err
+		}
+	}
+	return nil
+}
+
+// Forget drops the device twin of p (its HBM returns to the context's pool when the finalizer runs).
+func (e *Evaluator) Forget(p ring.Poly) {
+	e.mu.Lock()
+	delete(e.polys, key(p))
+	e.mu.Unlock()
+}
+
+// EvaluationKey is a rlwe.GadgetCiphertext in HBM: [beta][2][Q limbs | P limbs][N].
+type EvaluationKey struct {
+	h        Handle
+	nQk, nPk int
+	pw2      int
+}
+
+// evk uploads a gadget ciphertext once (always NTT + Montgomery, core/rlwe/keygenerator.go:314).
+func (e *Evaluator) evk(g *rlwe.GadgetCiphertext) (*EvaluationKey, error) {
+	e.mu.Lock()
+	k, ok := e.evks[g]
+	e.mu.Unlock()
+	if ok {
+		return k, nil
+	}
+	nQk, nPk, n := g.LevelQ()+1, g.LevelP()+1, e.params.N()
+	// flatten Value[i][j][k].{Q,P} into the host images the ABI takes: q[block][2][nQk][N], p[block][2][nPk][N]
+	var q, p []uint64
+	nj := make([]C.int, 0, len(g.Value))
+	for i := range g.Value {
+		nj = append(nj, C.int(len(g.Value[i])))
+		for j := range g.Value[i] {
+			for c := 0; c < 2; c++ {
+				for _, row := range g.Value[i][j][c].Q.Coeffs[:nQk] {
+					q = append(q, row[:n]...)
+				}
+				if nPk > 0 {
+					for _, row := range g.Value[i][j][c].P.Coeffs[:nPk] {
+						p = append(p, row[:n]...)
+					}
+				}
+			}
+		}
+	}
+	k = &EvaluationKey{nQk: nQk, nPk: nPk, pw2: g.BaseTwoDecomposition}
+	var pp *C.uint64_t
+	if nPk > 0 {
+		pp = (*C.uint64_t)(unsafe.Pointer(&p[0]))
+	}
+	var err error
+	if g.BaseTwoDecomposition == 0 {
+		err = lockedCall(func() C.int {
+			return C.he_evk_create(e.h, C.int(len(g.Value)), C.int(nQk), C.int(nPk), (*C.uint64_t)(unsafe.Pointer(&q[0])), pp, &k.h)
+		})
+	} else {
+		err = lockedCall(func() C.int {
+			return C.he_evk_create_base2(e.h, C.int(g.BaseTwoDecomposition), &nj[0], C.int(len(nj)), C.int(nQk), C.int(nPk),
+				(*C.uint64_t)(unsafe.Pointer(&q[0])), pp, &k.h)
+		})
+	}
+	if err != nil {
+		return nil, err
+	}
+	e.mu.Lock()
+	e.evks[g] = k
+	e.mu.Unlock()
+	return k, nil
+}
+
+// Decomposition is the device twin of BuffDecompQP []ringqp.Poly (the hoisting buffer of DecomposeNTT).
+type Decomposition struct{ h Handle }
+
+func (e *Evaluator) decomp(buff []ringqp.Poly) (*Decomposition, error) {
+	k := key(buff[0].Q)
+	e.mu.Lock()
+	d, ok := e.decs[k]
+	e.mu.Unlock()
+	if ok {
+		return d, nil
+	}
+	d = &Decomposition{}
+	if err := lockedCall(func() C.int { return C.he_decomp_create(e.h, C.int(e.batch), &d.h) }); err != nil {
+		return nil, err
+	}
+	e.mu.Lock()
+	e.decs[k] = d
+	e.mu.Unlock()
+	return d, nil
+}
+
+// qp returns the device twins of a ringqp.Poly; P is nil when the parameters have no special primes.
+func (e *Evaluator) qp(p ringqp.Poly, levelP int, upload bool) (q, pp *Poly, err error) {
+	if q, err = e.twin(e.RingQ, p.Q, upload); err != nil {
+		return
+	}
+	if levelP >= 0 {
+		pp, err = e.twin(e.RingP, p.P, upload)
+	}
+	return
+}
+
+func h(p *Poly) Handle {
+	if p == nil {
+		return 0
+	}
+	return p.h
+}
+
+// ---- rlwe.EvaluatorProvider (core/rlwe/rlwe.go:10-18) -----------------------------------------------------------------------
+
+// DecomposeNTT: core/rlwe/evaluator_gadget_product.go:459.
+func (e *Evaluator) DecomposeNTT(level, levelP, pCount int, c1 ring.Poly, isNTT bool, BuffDecompQP []ringqp.Poly) {
+	c, err := e.twin(e.RingQ, c1, true)
+	if err != nil {
+		panic(err) // the reference's method has no error return; invariant violations panic there too
+	}
+	d, err := e.decomp(BuffDecompQP)
+	if err != nil {
+		panic(err)
+	}
+	ntt := 0
+	if isNTT {
+		ntt = 1
+	}
+	if err = lockedCall(func() C.int {
+		return C.he_decompose_ntt(e.h, C.int(level), C.int(levelP), C.int(pCount), c.h, C.int(ntt), d.h)
+	}); err != nil {
+		panic(err)
+	}
+}
+
+// CheckAndGetGaloisKey: core/rlwe/evaluator.go:123 (host bookkeeping, unchanged).
+func (e *Evaluator) CheckAndGetGaloisKey(galEl uint64) (evk *rlwe.GaloisKey, err error) {
+	if e.keys == nil {
+		return nil, fmt.Errorf("evaluation key interface is nil")
+	}
+	if evk, err = e.keys.GetGaloisKey(galEl); err != nil {
+		return nil, fmt.Errorf("%w: key for galEl %d = 5^{%d} key is missing", err, galEl, e.params.SolveDiscreteLogGaloisElement(galEl))
+	}
+	return
+}
+
+// GadgetProductLazy: core/rlwe/evaluator_gadget_product.go:108 (ct.IsNTT domain handling as there).
+func (e *Evaluator) GadgetProductLazy(levelQ int, cx ring.Poly, gadgetCt *rlwe.GadgetCiphertext, ct *rlwe.Element[ringqp.Poly]) (err error) {
+	if ct.LevelP() < gadgetCt.LevelP() {
+		return fmt.Errorf("ctQP.LevelP()=%d < gadgetCt.LevelP()=%d", ct.LevelP(), gadgetCt.LevelP())
+	}
+	k, err := e.evk(gadgetCt)
+	if err != nil {
+		return err
+	}
+	rQ := e.RingQ.AtLevel(levelQ)
+	c, err := e.twin(e.RingQ, cx, true)
+	if err != nil {
+		return err
+	}
+	if !ct.IsNTT { // cx in the coefficient domain: transform a scratch copy (:142-152)
+		t, err := rQ.NewScratch(e.batch)
+		if err != nil {
+			return err
+		}
+		if err = rQ.NTT(c, t); err != nil {
+			return err
+		}
+		c = t
+	}
+	q0, p0, err := e.qp(ct.Value[0], gadgetCt.LevelP(), false)
+	if err != nil {
+		return err
+	}
+	q1, p1, err := e.qp(ct.Value[1], gadgetCt.LevelP(), false)
+	if err != nil {
+		return err
+	}
+	if err = lockedCall(func() C.int {
+		return C.he_gadget_product_lazy(e.h, C.int(levelQ), c.h, k.h, q0.h, h(p0), q1.h, h(p1))
+	}); err != nil {
+		return err
+	}
+	if !ct.IsNTT { // ringQP.INTT of the result (:121-125)
+		for _, pr := range [][2]*Poly{{q0, p0}, {q1, p1}} {
+			if err = rQ.INTT(pr[0], pr[0]); err != nil {
+				return err
+			}
+			if pr[1] != nil {
+				if err = e.RingP.AtLevel(gadgetCt.LevelP()).INTT(pr[1], pr[1]); err != nil {
+					return err
+				}
+			}
+		}
+	}
+	return nil
+}
+
+// GadgetProductHoistedLazy: core/rlwe/evaluator_gadget_product.go:379.
+func (e *Evaluator) GadgetProductHoistedLazy(levelQ int, BuffQPDecompQP []ringqp.Poly, gadgetCt *rlwe.GadgetCiphertext, ct *rlwe.Element[ringqp.Poly]) (err error) {
+	if gadgetCt.BaseTwoDecomposition != 0 {
+		return fmt.Errorf("method is unsupported for BaseTwoDecomposition != 0")
+	}
+	if ct.LevelP() < gadgetCt.LevelP() {
+		return fmt.Errorf("ctQP.LevelP()=%d < gadgetCt.LevelP()=%d", ct.Level(), gadgetCt.LevelP())
+	}
+	k, err := e.evk(gadgetCt)
+	if err != nil {
+		return err
+	}
+	d, err := e.decomp(BuffQPDecompQP)
+	if err != nil {
+		return err
+	}
+	q0, p0, err := e.qp(ct.Value[0], gadgetCt.LevelP(), false)
+	if err != nil {
+		return err
+	}
+	q1, p1, err := e.qp(ct.Value[1], gadgetCt.LevelP(), false)
+	if err != nil {
+		return err
+	}
+	if err = lockedCall(func() C.int {
+		return C.he_gadget_product_hoisted_lazy(e.h, C.int(levelQ), d.h, k.h, q0.h, h(p0), q1.h, h(p1))
+	}); err != nil {
+		return err
+	}
+	if !ct.IsNTT {
+		for _, pr := range [][2]*Poly{{q0, p0}, {q1, p1}} {
+			if err = e.RingQ.AtLevel(levelQ).INTT(pr[0], pr[0]); err != nil {
+				return err
+			}
+			if err = e.RingP.AtLevel(gadgetCt.LevelP()).INTT(pr[1], pr[1]); err != nil {
+				return err
+			}
+		}
+	}
+	return nil
+}
+
+// AutomorphismHoistedLazy: core/rlwe/evaluator_automorphism.go:104 (NTT-domain ciphertexts, as every caller in circuits/).
+func (e *Evaluator) AutomorphismHoistedLazy(levelQ int, ctIn *rlwe.Ciphertext, c1DecompQP []ringqp.Poly, galEl uint64, ctQP *rlwe.Element[ringqp.Poly]) (err error) {
+	gk, err := e.CheckAndGetGaloisKey(galEl)
+	if err != nil {
+		return fmt.Errorf("cannot apply AutomorphismHoistedLazy: %w", err)
+	}
+	if ctQP.LevelP() < gk.LevelP() {
+		return fmt.Errorf("ctQP.LevelP()=%d < GaloisKey[%d].LevelP()=%d", ctQP.LevelP(), galEl, gk.LevelP())
+	}
+	if !ctQP.IsNTT {
+		return fmt.Errorf("hering: AutomorphismHoistedLazy is device-resident for NTT-domain ciphertexts only")
+	}
+	k, err := e.evk(&gk.GadgetCiphertext)
+	if err != nil {
+		return err
+	}
+	d, err := e.decomp(c1DecompQP)
+	if err != nil {
+		return err
+	}
+	in0, err := e.twin(e.RingQ, ctIn.Value[0], true)
+	if err != nil {
+		return err
+	}
+	q0, p0, err := e.qp(ctQP.Value[0], gk.LevelP(), false)
+	if err != nil {
+		return err
+	}
+	q1, p1, err := e.qp(ctQP.Value[1], gk.LevelP(), false)
+	if err != nil {
+		return err
+	}
+	return lockedCall(func() C.int {
+		return C.he_automorphism_hoisted_lazy(e.h, C.int(levelQ), in0.h, d.h, C.uint64_t(galEl), k.h, q0.h, h(p0), q1.h, h(p1))
+	})
+}
+
+// ModDownQPtoQNTT: ring/basis_extension.go:235 through the evaluator's fused three-launch pipeline.
+func (e *Evaluator) ModDownQPtoQNTT(levelQ, levelP int, p1Q, p1P, p2Q ring.Poly) {
+	a, err := e.twin(e.RingQ, p1Q, true)
+	if err != nil {
+		panic(err)
+	}
+	b, err := e.twin(e.RingP, p1P, true)
+	if err != nil {
+		panic(err)
+	}
+	c, err := e.twin(e.RingQ, p2Q, false)
+	if err != nil {
+		panic(err)
+	}
+	if err = lockedCall(func() C.int {
+		return C.he_eval_moddown_qp_to_q_ntt(e.h, C.int(levelQ), C.int(levelP), a.h, b.h, c.h)
+	}); err != nil {
+		panic(err)
+	}
+}
+
+// AutomorphismIndex: core/rlwe/evaluator.go:147 -- the table itself (host slice, for callers that index with it) comes from
+// the device-built one so that both sides agree.
+func (e *Evaluator) AutomorphismIndex(galEl uint64) []uint64 {
+	ix, err := e.autoIndex(galEl)
+	if err != nil {
+		panic(err)
+	}
+	out, err := ix.Download(e.params.N())
+	if err != nil {
+		panic(err)
+	}
+	return out
+}
+
+func (e *Evaluator) autoIndex(galEl uint64) (*AutomorphismIndex, error) {
+	e.mu.Lock()
+	ix, ok := e.index[galEl]
+	e.mu.Unlock()
+	if ok {
+		return ix, nil
+	}
+	ix, err := e.RingQ.AutomorphismNTTIndex(galEl)
+	if err != nil {
+		return nil, err
+	}
+	e.mu.Lock()
+	e.index[galEl] = ix
+	e.mu.Unlock()
+	return ix, nil
+}
+
+// ---- the full (non-lazy) operators of rlwe.Evaluator the scheme layer calls -----------------------------------------------------
+
+// GadgetProduct: core/rlwe/evaluator_gadget_product.go:16.
+func (e *Evaluator) GadgetProduct(levelQ int, cx ring.Poly, gadgetCt *rlwe.GadgetCiphertext, ct *rlwe.Ciphertext) error {
+	k, err := e.evk(gadgetCt)
+	if err != nil {
+		return err
+	}
+	c, err := e.twin(e.RingQ, cx, true)
+	if err != nil {
+		return err
+	}
+	o0, err := e.twin(e.RingQ, ct.Value[0], false)
+	if err != nil {
+		return err
+	}
+	o1, err := e.twin(e.RingQ, ct.Value[1], false)
+	if err != nil {
+		return err
+	}
+	return lockedCall(func() C.int { return C.he_gadget_product(e.h, C.int(levelQ), c.h, k.h, o0.h, o1.h) })
+}
+
+// Relinearize: core/rlwe/evaluator_evaluationkey.go:117 (degree 2 -> degree 1).
+func (e *Evaluator) Relinearize(ctIn, opOut *rlwe.Ciphertext) error {
+	if ctIn.Degree() != 2 {
+		return fmt.Errorf("cannot relinearize: ctIn.Degree() should be 2 but is %d", ctIn.Degree())
+	}
+	rlk, err := e.keys.GetRelinearizationKey()
+	if err != nil {
+		return fmt.Errorf("cannot relinearize: %w", err)
+	}
+	k, err := e.evk(&rlk.GadgetCiphertext)
+	if err != nil {
+		return err
+	}
+	level := ctIn.Level()
+	if opOut.Level() < level {
+		level = opOut.Level()
+	}
+	var in [3]*Poly
+	for i := range in {
+		if in[i], err = e.twin(e.RingQ, ctIn.Value[i], true); err != nil {
+			return err
+		}
+	}
+	o0, err := e.twin(e.RingQ, opOut.Value[0], false)
+	if err != nil {
+		return err
+	}
+	o1, err := e.twin(e.RingQ, opOut.Value[1], false)
+	if err != nil {
+		return err
+	}
+	if err = lockedCall(func() C.int {
+		return C.he_relinearize(e.h, C.int(level), in[0].h, in[1].h, in[2].h, k.h, o0.h, o1.h)
+	}); err != nil {
+		return err
+	}
+	opOut.Resize(1, level)
+	*opOut.MetaData = *ctIn.MetaData
+	return nil
+}
+
+// Automorphism: core/rlwe/evaluator_automorphism.go:13 (NTT domain).
+func (e *Evaluator) Automorphism(ctIn *rlwe.Ciphertext, galEl uint64, opOut *rlwe.Ciphertext) error {
+	gk, err := e.CheckAndGetGaloisKey(galEl)
+	if err != nil {
+		return fmt.Errorf("cannot apply Automorphism: %w", err)
+	}
+	k, err := e.evk(&gk.GadgetCiphertext)
+	if err != nil {
+		return err
+	}
+	level := ctIn.Level()
+	if opOut.Level() < level {
+		level = opOut.Level()
+	}
+	i0, err := e.twin(e.RingQ, ctIn.Value[0], true)
+	if err != nil {
+		return err
+	}
+	i1, err := e.twin(e.RingQ, ctIn.Value[1], true)
+	if err != nil {
+		return err
+	}
+	o0, err := e.twin(e.RingQ, opOut.Value[0], false)
+	if err != nil {
+		return err
+	}
+	o1, err := e.twin(e.RingQ, opOut.Value[1], false)
+	if err != nil {
+		return err
+	}
+	if err = lockedCall(func() C.int {
+		return C.he_automorphism_ct(e.h, C.int(level), i0.h, i1.h, C.uint64_t(galEl), k.h, o0.h, o1.h)
+	}); err != nil {
+		return err
+	}
+	opOut.Resize(1, level)
+	*opOut.MetaData = *ctIn.MetaData
+	return nil
+}
+
+// AutomorphismHoisted: core/rlwe/evaluator_automorphism.go:60.
+func (e *Evaluator) AutomorphismHoisted(level int, ctIn *rlwe.Ciphertext, c1DecompQP []ringqp.Poly, galEl uint64, opOut *rlwe.Ciphertext) error {
+	gk, err := e.CheckAndGetGaloisKey(galEl)
+	if err != nil {
+		return fmt.Errorf("cannot apply AutomorphismHoisted: %w", err)
+	}
+	k, err := e.evk(&gk.GadgetCiphertext)
+	if err != nil {
+		return err
+	}
+	d, err := e.decomp(c1DecompQP)
+	if err != nil {
+		return err
+	}
+	i0, err := e.twin(e.RingQ, ctIn.Value[0], true)
+	if err != nil {
+		return err
+	}
+	o0, err := e.twin(e.RingQ, opOut.Value[0], false)
+	if err != nil {
+		return err
+	}
+	o1, err := e.twin(e.RingQ, opOut.Value[1], false)
+	if err != nil {
+		return err
+	}
+	return lockedCall(func() C.int {
+		return C.he_automorphism_hoisted(e.h, C.int(level), i0.h, d.h, C.uint64_t(galEl), k.h, o0.h, o1.h)
+	})
+}

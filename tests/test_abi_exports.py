@@ -45,3 +45,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("oracle/ by construction", "") or f == "host_math.h", f
+
+
+def test_go_shim_matches_the_header():
+    """go/hering/*.go (the cgo side of the boundary, shipped as source: no Go toolchain in the image): every C.he_* call names
+    a declared entry point with the declared number of arguments, and the seven rlwe.EvaluatorProvider methods plus the
+    schemes.Evaluator set are defined (tools/check_go_abi.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_go_abi.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
