@@ -77,3 +77,47 @@ def test_ciphertext_roundtrip():
     assert np.array_equal(v2, v) and d["scale"] == 2 ** 30 and d["log_cols"] == 2
     v3, d3 = wire.ciphertext_unmarshal(wire.ciphertext_marshal(v, None))
     assert d3 is None and np.array_equal(v3, v)
+
+
+def test_literal_bytes_assembled_from_the_reference_layout_rules():
+    """Byte strings written out by hand from the reference's layout rules -- Matrix.WriteTo = u64 row count, then every row as a
+    Vector (utils/structs/matrix.go:82-106); Vector.WriteTo = u64 length, then the elements, uint64 elements little-endian
+    (utils/structs/vector.go:82-100, utils/buffer/writer.go:311-325); ringqp.Poly = Q then P (ring/ringqp/poly.go:105-125);
+    GadgetCiphertext = u64 BaseTwoDecomposition, then Value as Matrix[VectorQP] (core/rlwe/gadgetciphertext.go:101-118) -- and
+    compared with lattigo_amd.wire in both directions.  This pins wire.py to the documented layout; it is NOT a comparison with
+    bytes produced by Go (no toolchain here, and the reference holds no regenerable serialised fixture): parity with real Go
+    output remains unpinned."""
+    # ring.Poly{Coeffs: [[1, 2], [0x0102030405060708, 3]]}
+    poly_hex = ("0200000000000000"    # Matrix: 2 rows (limbs)
+                "0200000000000000" "0100000000000000" "0200000000000000"   # Vector len 2: 1, 2
+                "0200000000000000" "0807060504030201" "0300000000000000")  # Vector len 2: 0x0102030405060708, 3
+    coeffs = np.array([[1, 2], [0x0102030405060708, 3]], dtype=np.uint64)
+    assert wire.poly_marshal(coeffs) == bytes.fromhex(poly_hex)
+    assert np.array_equal(wire.poly_unmarshal(bytes.fromhex(poly_hex)), coeffs)
+
+    # GadgetCiphertext{BaseTwoDecomposition: 0, Value: [[ [ {Q:[[10,11]], P:[[20,21]]}, {Q:[[12,13]], P:[[22,23]]} ] ]]}
+    # (one RNS digit, one power-of-two block, the two components of the key; one Q limb, one P limb, N = 2)
+    def u(x):
+        return struct.pack("<Q", x).hex()
+    gct_hex = (u(0) +                      # BaseTwoDecomposition
+               u(1) +                      # Matrix[VectorQP]: 1 row (RNS digits)
+               u(1) +                      # Vector[VectorQP]: 1 block (bit windows of that digit)
+               u(2) +                      # VectorQP = Vector[ringqp.Poly]: 2 components
+               u(1) + u(2) + u(10) + u(11) +   # component 0, Q: Matrix 1 row; Vector len 2: 10, 11
+               u(1) + u(2) + u(20) + u(21) +   # component 0, P
+               u(1) + u(2) + u(12) + u(13) +   # component 1, Q
+               u(1) + u(2) + u(22) + u(23))    # component 1, P
+    kq = np.array([[[[10, 11]], [[12, 13]]]], dtype=np.uint64)   # [beta][2][LQ][N]
+    kp = np.array([[[[20, 21]], [[22, 23]]]], dtype=np.uint64)
+    assert wire.gadget_ciphertext_marshal(kq, kp, 0, [1]) == bytes.fromhex(gct_hex)
+    q2, p2, bt, nj = wire.gadget_ciphertext_unmarshal(bytes.fromhex(gct_hex))
+    assert bt == 0 and nj == [1] and np.array_equal(q2, kq) and np.array_equal(p2, kp)
+    # base-2 gadget: BaseTwoDecomposition = 3, one digit with two bit windows
+    gct2_hex = (u(3) + u(1) + u(2) +
+                u(2) + u(1) + u(2) + u(10) + u(11) + u(1) + u(2) + u(20) + u(21) + u(1) + u(2) + u(12) + u(13) + u(1) + u(2) + u(22) + u(23) +
+                u(2) + u(1) + u(2) + u(30) + u(31) + u(1) + u(2) + u(40) + u(41) + u(1) + u(2) + u(32) + u(33) + u(1) + u(2) + u(42) + u(43))
+    kq2 = np.array([[[[10, 11]], [[12, 13]]], [[[30, 31]], [[32, 33]]]], dtype=np.uint64)
+    kp2 = np.array([[[[20, 21]], [[22, 23]]], [[[40, 41]], [[42, 43]]]], dtype=np.uint64)
+    assert wire.gadget_ciphertext_marshal(kq2, kp2, 3, [2]) == bytes.fromhex(gct2_hex)
+    # GaloisKey = u64 GaloisElement, u64 NthRoot, then the EvaluationKey (core/rlwe/keys.go:628-657)
+    assert wire.galois_key_marshal(5, 8, kq, kp, 0, [1]) == bytes.fromhex(u(5) + u(8) + gct_hex)
