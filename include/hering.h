@@ -64,8 +64,10 @@ int he_device_info(he_handle ctx, uint64_t out[4]);
  *      RescaleConstants (ring/ring.go:329).  Standard (negacyclic) type, NthRoot = 2N. */
 int he_ring_create(he_handle ctx, int logN, const uint64_t *moduli, int n_moduli, he_handle *ring);
 /* ring.NewRingFromType (ring/ring.go:267): ring_type 0 = Standard, 1 = ConjugateInvariant
- * (Z[X+X^-1]/(X^2N+1), NthRoot = 4N; NTT of ring/ntt.go:716-1311).  Conjugate-invariant rings support the
- * ring-level ops (NTT, coefficient-wise, rescale); basis extension / key-switch take standard rings. */
+ * (Z[X+X^-1]/(X^2N+1), NthRoot = 4N; NTT of ring/ntt.go:716-1311).  Conjugate-invariant rings are accepted everywhere a
+ * standard ring is: ring-level ops, rescale (the NTT variants reproduce the reference's lazy INTT words, which are observable
+ * there), automorphisms (index table over NthRoot = 4N, coefficient-domain form of ring/automorphism.go:122-151), basis
+ * extenders and evaluators (Q and P of the same type; they take the unfused launches). */
 int he_ring_create_type(he_handle ctx, int logN, int ring_type, const uint64_t *moduli, int n_moduli, he_handle *ring);
 int he_ring_destroy(he_handle ring);
 /* which = 0: Modulus, 1: MRedConstant, 2: BRedConstant[0], 3: BRedConstant[1], 4: NInv, 5: PrimitiveRoot */

@@ -258,6 +258,7 @@ struct BasisExtender : Obj {
     std::shared_ptr<Ctx> ctx;
     std::shared_ptr<Ring> Q, P;
     int LQ = 0, LP = 0;
+    int type = 0;  // ring type of Q and P: 0 Standard, 1 ConjugateInvariant (NTTs fold around the standard network, no fused plans)
     ModConst *d_mc = nullptr;
     uint64_t *d_twf = nullptr, *d_twi = nullptr;
     std::vector<uint8_t> small;
@@ -671,18 +672,26 @@ int he_poly_zero(he_handle h) {
 // ---------------------------------------------------------------------------------------
 // NTT of a Ring of either type: the conjugate-invariant transform is a fold around the standard
 // network (ring/ntt.go:716-1311)
-static hipError_t ring_ntt(const Ring &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags) {
-    hipStream_t st = r.ctx->stream;
-    if (r.type == 0) return launch_ntt(r.dev, tab, in, out, batch, inverse, flags, st);
+static hipError_t typed_ntt(const RingDev &dev, int type, hipStream_t st, const LimbTab &tab, View in, View out, int batch,
+                            bool inverse, int flags) {
+    if (type == 0) return launch_ntt(dev, tab, in, out, batch, inverse, flags, st);
     LimbTab oo = tab;  // second step works in place on `out`
     for (int i = 0; i < tab.n; i++) oo.in_limb[i] = tab.out_limb[i];
     hipError_t e;
     if (!inverse) {
-        if ((e = launch_ci_fold(r.dev, tab, in, out, batch, false, (flags & NTT_REDUCE_INPUT) != 0, st)) != hipSuccess) return e;
-        return launch_ntt(r.dev, oo, out, out, batch, false, flags & ~NTT_REDUCE_INPUT, st);
+        if ((e = launch_ci_fold(dev, tab, in, out, batch, false, (flags & NTT_REDUCE_INPUT) != 0, st)) != hipSuccess) return e;
+        return launch_ntt(dev, oo, out, out, batch, false, flags & ~NTT_REDUCE_INPUT, st);
     }
-    if ((e = launch_ntt(r.dev, tab, in, out, batch, true, flags, st)) != hipSuccess) return e;
-    return launch_ci_fold(r.dev, oo, out, out, batch, true, false, st);
+    if ((e = launch_ntt(dev, tab, in, out, batch, true, flags, st)) != hipSuccess) return e;
+    return launch_ci_fold(dev, oo, out, out, batch, true, false, st);
+}
+static hipError_t ring_ntt(const Ring &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags) {
+    return typed_ntt(r.dev, r.type, r.ctx->stream, tab, in, out, batch, inverse, flags);
+}
+
+// NTT over the combined QP table of a basis extender / evaluator, of either ring type
+static hipError_t be_ntt(const BasisExtender &be, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags) {
+    return typed_ntt(be.qp, be.type, be.ctx->stream, tab, in, out, batch, inverse, flags);
 }
 
 static int ntt_api(he_handle hring, int level, he_handle h1, he_handle h2, bool inverse, int flags, const char *who) {
@@ -911,7 +920,10 @@ int div_by_last_modulus_ntt(Ring &r, int level, View p0, View p1, int batch, boo
     // b0 = INTTLazy(p0[level])                                                  scaling.go:15 / :110
     LimbTab t_top;
     t_top.n = 1; t_top.in_limb[0] = (uint8_t)level; t_top.out_limb[0] = 0; t_top.mod[0] = (uint8_t)level;
-    HIP_TRY(ring_ntt(r, t_top, p0, sc.s0, batch, true, NTT_REDUCE_INPUT));
+    if (r.type == 1)  // the lazy representative of INTTConjugateInvariantLazy is observable in the other moduli: exact words
+        HIP_TRY(launch_ci_intt_lazy_ref(r.dev, r.sub[level].mc, level, View{p0.p + (size_t)level * r.N, p0.bstride}, sc.s0, batch, st));
+    else
+        HIP_TRY(ring_ntt(r, t_top, p0, sc.s0, batch, true, NTT_REDUCE_INPUT));
     ScalarTab s{};
     const uint64_t qL = r.moduli[level], phalf = (qL - 1) >> 1;
     if (round) {  // b0 += pHalf mod q_L                                          scaling.go:114
@@ -966,7 +978,10 @@ int div_by_last_modulus_coeff(Ring &r, int level, View p0, View p1, int batch, b
     }
     return HE_OK;
 }
-int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, bool round, bool ntt, const char *who) {
+// many: the *Many* entry points.  DivFloorByLastModulusManyNTT always goes INTT -> coefficient-domain steps -> NTT, even for one
+// step (scaling.go:37-62), whereas DivRoundByLastModulusManyNTT(1) is DivRoundByLastModulusNTT (:169-171); on a standard ring
+// the two routes give the same words, on a conjugate-invariant ring the single-step NTT form sees the lazy INTT words.
+int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, bool round, bool ntt, const char *who, bool many = false) {
     GET(r, Ring, hring, T_RING);
     GET(p0, Poly, h0, T_POLY);
     GET(p1, Poly, h1, T_POLY);
@@ -986,11 +1001,7 @@ int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, boo
     RescaleScratch rs;
     rs.s0 = View{r->ctx->arena_take(w0), (size_t)N};
     rs.s1 = View{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
-    if (ntt && nb == 1 && !round && r->type == 1)
-        // the reference feeds the *lazy* representative of INTTConjugateInvariantLazy (which depends on its
-        // unrolled reduction schedule, ring/ntt.go:1160-1311) into a different modulus here; not reproduced
-        return fail(HE_EINVAL, "%s: DivFloorByLastModulusNTT is not supported on conjugate-invariant rings", who);
-    if (ntt && nb == 1) return div_by_last_modulus_ntt(*r, level, p0->view(), p1->view(), B, round, rs);
+    if (ntt && nb == 1 && !(many && !round && r->type == 1)) return div_by_last_modulus_ntt(*r, level, p0->view(), p1->view(), B, round, rs);
     View buf{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
     View cur = p0->view();
     int lv = level;
@@ -1016,7 +1027,7 @@ int he_div_floor_by_last_modulus_ntt(he_handle r, int l, he_handle a, he_handle 
 int he_div_floor_by_last_modulus(he_handle r, int l, he_handle a, he_handle b) { return div_many(r, l, 1, a, b, false, false, "he_div_floor_by_last_modulus"); }
 int he_div_round_by_last_modulus_many_ntt(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, true, true, "he_div_round_by_last_modulus_many_ntt"); }
 int he_div_round_by_last_modulus_many(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, true, false, "he_div_round_by_last_modulus_many"); }
-int he_div_floor_by_last_modulus_many_ntt(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, false, true, "he_div_floor_by_last_modulus_many_ntt"); }
+int he_div_floor_by_last_modulus_many_ntt(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, false, true, "he_div_floor_by_last_modulus_many_ntt", true); }
 int he_div_floor_by_last_modulus_many(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, false, false, "he_div_floor_by_last_modulus_many"); }
 
 // ---------------------------------------------------------------------------------------
@@ -1031,7 +1042,7 @@ int he_automorphism_index_create(he_handle hring, uint64_t gal, he_handle *out) 
     ix->gal = gal;
     Scope sc(r->ctx.get());
     HIP_TRY(hipMalloc((void **)&ix->d, (size_t)r->N * sizeof(uint32_t)));
-    HIP_TRY(launch_build_automorphism_index(r->logN, gal, ix->d, r->ctx->stream));
+    HIP_TRY(launch_build_automorphism_index(r->logN, r->logN + r->type, gal, ix->d, r->ctx->stream));
     *out = reg(ix);
     return HE_OK;
 }
@@ -1070,7 +1081,7 @@ int he_automorphism(he_handle hring, int level, he_handle hin, uint64_t gal, he_
     if (pin->batch != pout->batch) return fail(HE_EINVAL, "he_automorphism: batch mismatch");
     if (pin->d == pout->d) return fail(HE_EINVAL, "he_automorphism: the automorphism cannot be evaluated in place");
     Scope sc(r->ctx.get());
-    HIP_TRY(launch_automorphism_coeff(r->dev, ident_tab(level + 1), pin->view(), gal, pout->view(), pin->batch, r->ctx->stream));
+    HIP_TRY(launch_automorphism_coeff(r->dev, ident_tab(level + 1), pin->view(), gal, pout->view(), pin->batch, r->ctx->stream, r->type == 1));
     return HE_OK;
 }
 
@@ -1080,14 +1091,14 @@ int he_automorphism(he_handle hring, int level, he_handle hin, uint64_t gal, he_
 // P may be a ring without moduli (an evaluator over parameters without special primes): LP = 0, no constants
 static int basis_extender_build(std::shared_ptr<Ring> Q, std::shared_ptr<Ring> P, he_handle *out) {
     if (Q->ctx != P->ctx || Q->N != P->N) return fail(HE_EINVAL, "he_basis_extender_create: rings must share context and degree");
-    if (Q->type != 0 || P->type != 0) return fail(HE_EINVAL, "he_basis_extender_create: conjugate-invariant rings are not supported here");
+    if (P->nmod() > 0 && Q->type != P->type) return fail(HE_EINVAL, "he_basis_extender_create: Q and P must be of the same ring type");
     if (Q->nmod() + P->nmod() > kMaxLimbs) return fail(HE_EINVAL, "he_basis_extender_create: more than %d moduli in QP", kMaxLimbs);
     if (Q->nmod() > 32 || P->nmod() > 32) return fail(HE_EINVAL, "he_basis_extender_create: at most 32 source limbs (ring/basis_extension.go:285)");
     for (uint64_t q : Q->moduli)
         for (uint64_t p : P->moduli)
             if (q == p) return fail(HE_EPARAM, "he_basis_extender_create: Q and P share a modulus");
     auto be = std::make_shared<BasisExtender>();
-    be->ctx = Q->ctx; be->Q = Q; be->P = P; be->LQ = Q->nmod(); be->LP = P->nmod();
+    be->ctx = Q->ctx; be->Q = Q; be->P = P; be->LQ = Q->nmod(); be->LP = P->nmod(); be->type = Q->type;
     Scope sc(Q->ctx.get());
     std::vector<const SubRingHost *> subs;
     for (auto &s : Q->sub) subs.push_back(&s);
@@ -1182,12 +1193,12 @@ int check_be_poly(const Poly &p, const BasisExtender &be, int nl, const char *wh
 int moddown_q_ntt(BasisExtender &be, int levelQ, int levelP, View pQ, View pP, View outQ, int batch, View sP, View sQ) {
     hipStream_t st = be.ctx->stream;
     // ringP.INTTLazy(p1P, buffP)
-    HIP_TRY(launch_ntt(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), pP, sP, batch, true, NTT_REDUCE_INPUT, st));
+    HIP_TRY(be_ntt(be, ident_tab(levelP + 1, 0, 0, be.LQ), pP, sP, batch, true, NTT_REDUCE_INPUT));
     // ModUpPtoQ(buffP) -> buffQ
     TRY(modup_between(be, false, levelP, levelQ, sP, sQ, 0, batch));
     // ringQ.NTTLazy(buffQ, buffQ)
     const bool red = modup_out_needs_reduce(std::vector<uint64_t>(be.P->moduli.begin(), be.P->moduli.begin() + levelP + 1));
-    HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), sQ, sQ, batch, false, NTT_LAZY_OUT | (red ? NTT_REDUCE_INPUT : 0), st));
+    HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), sQ, sQ, batch, false, NTT_LAZY_OUT | (red ? NTT_REDUCE_INPUT : 0)));
     // p2Q_i = MRed(buffQ_i + 2q_i - p1Q_i, q_i - modDownConstants[i])
     ScalarTab s{};
     for (int i = 0; i <= levelQ; i++) s.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
@@ -1471,7 +1482,7 @@ int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2n
             t.n++;
         }
         const bool red = modup_out_needs_reduce(std::vector<uint64_t>(be.Q->moduli.begin() + s0, be.Q->moduli.begin() + e0));
-        HIP_TRY(launch_ntt(be.qp, t, blk, blk, batch, false, red ? NTT_REDUCE_INPUT : 0, st));
+        HIP_TRY(be_ntt(be, t, blk, blk, batch, false, red ? NTT_REDUCE_INPUT : 0));
         // own limbs: copy of the NTT-domain input                         evaluator_gadget_product.go:498-503
         HIP_TRY(launch_ew(be.qp, ident_tab(e0 - s0, s0, s0, s0), EW_COPY, c2ntt, c2ntt, blk, batch, nullptr, nullptr, st));
     }
@@ -1597,7 +1608,9 @@ int get_dec_plan(Evaluator &ev, int levelQ, int levelP, int nbPi, const FusedPla
         descs.push_back(D);
     }
     FusedPlan plan;
-    if (ok && beta * width <= 256) TRY(upload_plan(ev, descs, plan));
+    // (conjugate-invariant rings: the fold sits between the inverse network and the basis extension, and it pairs coefficient j
+    // with N - j -- not thread-local in the fused kernel; those rings take the unfused launches)
+    if (ok && beta * width <= 256 && be.type == 0) TRY(upload_plan(ev, descs, plan));
     auto ins = ev.dec_plans.emplace(key, plan);
     *out = &ins.first->second;
     return HE_OK;
@@ -1613,7 +1626,7 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
     memset(&D, 0, sizeof D);
     D.nsrc = levelP + 1;
     FusedPlan plan;
-    if (D.nsrc <= 8) {
+    if (D.nsrc <= 8 && be.type == 0) {
         const ModUpDev c = be.ptoq[levelP].on(be.pool);
         D.a = c.a; D.T = c.T; D.vt = c.vt;
         D.Td = be.ptoq[levelP].Td_on(be.pool); D.vtd = be.ptoq[levelP].vtd_on(be.pool);
@@ -1766,9 +1779,9 @@ int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle 
             }
             return HE_OK;
         }
-        HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), c2->view(), other, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+        HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), c2->view(), other, B, true, NTT_REDUCE_INPUT));
     } else {
-        HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), c2->view(), other, B, false, NTT_REDUCE_INPUT, be.ctx->stream));
+        HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), c2->view(), other, B, false, NTT_REDUCE_INPUT));
         ntt = other; inv = c2->view();
     }
     return decompose_ntt_into(*ev, levelQ, levelP, nbPi, ntt, inv, dec->d, dec->bstride(), dec->dstride(), B);
@@ -1868,7 +1881,7 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
     View inv{cxinv, (size_t)(levelQ + 1) * N};
     if (k.pw2) {  // base-2 gadget: bit windows of every Q-limb, NTT'd into every limb (evaluator_gadget_product.go:203-338)
         hipStream_t st = be.ctx->stream;
-        HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT, st));
+        HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT));
         MaskSpreadArgs m{};
         m.mask = ((uint64_t)1 << k.pw2) - 1;
         LimbTab t;
@@ -1885,7 +1898,7 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
         HIP_TRY(launch_mask_spread(be.qp, m, inv, dec, bs, ds, B, st));
         for (int d = 0; d < beta; d++) {
             View blk{dec + (size_t)d * ds, bs};
-            HIP_TRY(launch_ntt(be.qp, t, blk, blk, B, false, 0, st));
+            HIP_TRY(be_ntt(be, t, blk, blk, B, false, 0));
         }
         return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
     }
@@ -1902,7 +1915,7 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
         TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B));
         return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
     }
-    HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+    HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT));
     TRY(decompose_ntt_into(ev, levelQ, levelP, levelP + 1, cx, inv, dec, bs, ds, B));
     return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
 }
@@ -1919,10 +1932,10 @@ int moddown_front(Evaluator &ev, int levelQ, int levelP, View accP, View sP, Vie
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT, st));
         return HE_OK;
     }
-    HIP_TRY(launch_ntt(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, NTT_REDUCE_INPUT, st));
+    HIP_TRY(be_ntt(be, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, NTT_REDUCE_INPUT));
     TRY(modup_between(be, false, levelP, levelQ, sP, sQ, 0, nb));
     const bool red = modup_out_needs_reduce(std::vector<uint64_t>(be.P->moduli.begin(), be.P->moduli.begin() + levelP + 1));
-    HIP_TRY(launch_ntt(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT | (red ? NTT_REDUCE_INPUT : 0), st));
+    HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT | (red ? NTT_REDUCE_INPUT : 0)));
     return HE_OK;
 }
 // last op of ModDown, optionally fused with the Ring.Add that every caller applies next:
@@ -2193,7 +2206,7 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
     uint32_t *index = reinterpret_cast<uint32_t *>(be.ctx->arena_take((size_t)N / 2 + 2));
     hipStream_t st = be.ctx->stream;
-    HIP_TRY(launch_build_automorphism_index(be.Q->logN, gal, index, st));
+    HIP_TRY(launch_build_automorphism_index(be.Q->logN, be.Q->logN + be.type, gal, index, st));
     View in1v{nullptr, 0};
     if (in1) in1v = in1->view();
     const View in0v = in0->view();
@@ -2235,7 +2248,7 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     View t0P{be.ctx->arena_take(B * sPw), sPw}, t1P{be.ctx->arena_take(B * sPw), sPw};
     uint32_t *index = reinterpret_cast<uint32_t *>(be.ctx->arena_take((size_t)N / 2 + 2));
     hipStream_t st = be.ctx->stream;
-    HIP_TRY(launch_build_automorphism_index(be.Q->logN, gal, index, st));
+    HIP_TRY(launch_build_automorphism_index(be.Q->logN, be.Q->logN + be.type, gal, index, st));
     TRY(ks_inner(*ev, levelQ, levelP, dec->d, dec->bstride(), dec->dstride(), *k, t0Q, t0P, t1Q, t1P, B));
     const LimbTab tq = ident_tab(levelQ + 1), tp = ident_tab(levelP + 1, 0, 0, be.LQ);
     HIP_TRY(launch_gather(be.qp, tq, t1Q, index, o.q1->view(), B, false, st));

@@ -79,6 +79,10 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
 hipError_t launch_ci_fold(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, bool reduce_input,
                           hipStream_t s);
 
+// INTTConjugateInvariantLazy of ONE limb with the reference's exact lazy words (see kernels.hip); `in` / `out` address that limb
+// (limb stride folded into the pointer), mc_host is the host copy of the modulus record
+hipError_t launch_ci_intt_lazy_ref(const RingDev &r, const ModConst &mc_host, int mod, View in, View out, int batch, hipStream_t s);
+
 // ---- coefficient-wise -----------------------------------------------------------------
 // op codes: 0..16 = he_binop, 100.. = he_unop, 200.. = scalar forms (scalar per limb in sc[])
 enum EwOp {
@@ -122,8 +126,9 @@ hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const ui
                          bool then_add, hipStream_t s);
 // coefficient-domain automorphism X^i -> X^(i*gal) (ring/automorphism.go:153-174)
 hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View in, uint64_t gal, View out, int batch,
-                                     hipStream_t s);
-hipError_t launch_build_automorphism_index(int logN, uint64_t gal, uint32_t *index, hipStream_t s);
+                                     hipStream_t s, bool conjugate_invariant = false);
+// lognth = log2(NthRoot) - 1: logN for the standard ring, logN + 1 for the conjugate-invariant one
+hipError_t launch_build_automorphism_index(int logN, int lognth, uint64_t gal, uint32_t *index, hipStream_t s);
 
 // ---- basis extension -----------------------------------------------------------------------
 // One constant set of GenModUpConstants (ring/basis_extension.go:101) resident on the device.

@@ -1193,6 +1193,61 @@ hipError_t launch_ci_fold(const RingDev &r, const LimbTab &tab, View in, View ou
 }
 
 // ------------------------------------------------------------------------------------
+// INTTConjugateInvariantLazy with the reference's exact lazy words (ring/ntt.go:1104-1152 + the NInv pass :728-737).
+// DivRoundByLastModulusNTT / DivFloorByLastModulusNTT feed that LAZY output of the top limb into the other moduli
+// (ring/scaling.go:15,110), so its representative -- not only its residue class -- is observable there: a word r + q_L instead
+// of r moves the quotient by one.  One launch per Gentleman-Sande stage, every butterfly exactly the reference's invbutterfly
+// (X = U + V, minus 2q when >= 2q; Y = MRedLazy(U + 4q - V, F)), then the fold with roots[1] and MRedLazy by NInv.  Off the hot
+// path: only the rescale of a conjugate-invariant ring takes it, for one limb.
+// ------------------------------------------------------------------------------------
+struct CiRefArgs {
+    const uint64_t *in;
+    uint64_t *out;
+    size_t in_bs, out_bs;
+    ModConst mc;
+    const uint64_t *tw;  // remapped backward table of the modulus: the stage with h blocks uses tw[h + i]
+    int N, t;
+};
+__global__ void __launch_bounds__(256) ci_ref_inv_stage_kernel(CiRefArgs A) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.N / 2) return;
+    const int i = b / A.t, j = b - i * A.t, jx = i * 2 * A.t + j, jy = jx + A.t, h = A.N / (2 * A.t);
+    const uint64_t q = A.mc.q, twoq = q << 1, fourq = q << 2;
+    const uint64_t *src = A.in + (size_t)blockIdx.z * A.in_bs;
+    uint64_t *dst = A.out + (size_t)blockIdx.z * A.out_bs;
+    const uint64_t U = src[jx], V = src[jy], F = A.tw[h + i];
+    uint64_t X = U + V;
+    if (X >= twoq) X -= twoq;
+    dst[jx] = X;
+    dst[jy] = mred_lazy(U + fourq - V, F, q, A.mc.qinv);
+}
+__global__ void __launch_bounds__(256) ci_ref_inv_fold_kernel(CiRefArgs A) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. N/2
+    if (j > A.N / 2) return;
+    const uint64_t q = A.mc.q, qinv = A.mc.qinv, twoq = q << 1, F = A.mc.pad1, ninv = A.mc.ninv;
+    uint64_t *p = A.out + (size_t)blockIdx.z * A.out_bs;
+    if (j == 0) { p[0] = mred_lazy(cred(p[0] << 1, q), ninv, q, qinv); return; }
+    const int jy = A.N - j;
+    const uint64_t a = p[j], b = p[jy];
+    p[j] = mred_lazy(a + twoq - mred_lazy(b, F, q, qinv), ninv, q, qinv);
+    if (jy != j) p[jy] = mred_lazy(b + twoq - mred_lazy(a, F, q, qinv), ninv, q, qinv);
+}
+hipError_t launch_ci_intt_lazy_ref(const RingDev &r, const ModConst &mc_host, int mod, View in, View out, int batch, hipStream_t s) {
+    if (batch <= 0) return hipSuccess;
+    CiRefArgs A;
+    A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride; A.mc = mc_host;
+    A.tw = r.tw_inv + (size_t)mod * r.N; A.N = r.N;
+    ProfScope ps(K_CI_FOLD, s);
+    for (int t = 1; t < r.N; t <<= 1) {
+        A.t = t;
+        hipLaunchKernelGGL(ci_ref_inv_stage_kernel, dim3((unsigned)((r.N / 2 + 255) / 256), 1, batch), dim3(256), 0, s, A);
+        A.in = out.p; A.in_bs = out.bstride;  // the first stage reads p1, the others run in place on p2
+    }
+    hipLaunchKernelGGL(ci_ref_inv_fold_kernel, dim3((unsigned)((r.N / 2 + 1 + 255) / 256), 1, batch), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // coefficient-wise kernels (ring/vec_ops.go): one launch for all limbs x batch.
 // Each thread handles two adjacent coefficients (16-byte accesses).
 // ------------------------------------------------------------------------------------
@@ -1366,20 +1421,22 @@ hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const ui
     return hipGetLastError();
 }
 
-// index[i] = bitrev(((gal*(2*bitrev(i)+1) & (2N-1)) - 1) >> 1)   (ring/automorphism.go:12-34)
-__global__ void build_index_kernel(int logN, uint64_t gal, uint32_t *index) {
+// index[i] = bitrev(((gal*(2*bitrev(i)+1) & (NthRoot-1)) - 1) >> 1), bit reversals over lognth = log2(NthRoot) - 1 bits
+// (ring/automorphism.go:12-34): NthRoot = 2N (lognth = logN) for the standard ring, 4N (lognth = logN + 1) for the
+// conjugate-invariant one (ring/ring.go:254,261)
+__global__ void build_index_kernel(int logN, int lognth, uint64_t gal, uint32_t *index) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t N = 1u << logN;
     if (i >= N) return;
-    const uint64_t mask = 2ull * N - 1;
-    const uint64_t t1 = 2 * (__brevll((uint64_t)i) >> (64 - logN)) + 1;
+    const uint64_t mask = (2ull << lognth) - 1;
+    const uint64_t t1 = 2 * (__brevll((uint64_t)i) >> (64 - lognth)) + 1;
     const uint64_t t2 = (((gal * t1) & mask) - 1) >> 1;
-    index[i] = (uint32_t)(__brevll(t2) >> (64 - logN));
+    index[i] = (uint32_t)(__brevll(t2) >> (64 - lognth));
 }
-hipError_t launch_build_automorphism_index(int logN, uint64_t gal, uint32_t *index, hipStream_t s) {
+hipError_t launch_build_automorphism_index(int logN, int lognth, uint64_t gal, uint32_t *index, hipStream_t s) {
     const unsigned N = 1u << logN;
     ProfScope ps(K_INDEX, s);
-    hipLaunchKernelGGL(build_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, logN, gal, index);
+    hipLaunchKernelGGL(build_index_kernel, dim3((N + 255) / 256), dim3(256), 0, s, logN, lognth, gal, index);
     return hipGetLastError();
 }
 
@@ -1389,7 +1446,7 @@ struct AutoCoeffArgs {
     size_t in_bs, out_bs;
     const ModConst *mc;
     int N, logN;
-    uint64_t gal;
+    uint64_t gal, ginv;  // ginv = gal^-1 mod 2N (conjugate-invariant form only)
     uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs], mod[kMaxLimbs];
 };
 // out[i*gal mod N] = +-in[i]; a negated zero is stored as q, exactly as the reference's
@@ -1402,16 +1459,40 @@ __global__ void __launch_bounds__(256) automorphism_coeff_kernel(AutoCoeffArgs A
     const uint64_t c = (A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N)[i];
     (A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N)[idx] = neg ? q - c : c;
 }
+// Conjugate-invariant ring Z[X + X^-1]/(X^2N + 1) (ring/automorphism.go:122-151): the reference walks i over [0, 2N) and keeps
+// the images i * gal mod 2N that fall below N, reading coefficient i (or 2N - i, negated, for i >= N).  gal is odd, so every
+// image below N has exactly one source: i = x * gal^-1 mod 2N -- the same map as a gather.
+__global__ void __launch_bounds__(256) automorphism_coeff_ci_kernel(AutoCoeffArgs A) {
+    const uint64_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (uint64_t)A.N) return;
+    const uint64_t N = (uint64_t)A.N, mask2 = 2 * N - 1;
+    const uint64_t i = (x * A.ginv) & mask2;
+    uint64_t neg = ((i * A.gal) >> (A.logN + 1)) & 1;
+    uint64_t idx = i;
+    if (i >= N) { idx = 2 * N - i; neg ^= 1; }
+    const uint64_t q = A.mc[A.mod[blockIdx.y]].q;
+    const uint64_t c = (A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N)[idx];
+    (A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N)[x] = neg ? q - c : c;
+}
 hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View in, uint64_t gal, View out, int batch,
-                                     hipStream_t s) {
+                                     hipStream_t s, bool conjugate_invariant) {
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     AutoCoeffArgs A;
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.logN = r.logN;
-    A.gal = gal;
+    A.gal = gal; A.ginv = 0;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
     ProfScope ps(K_AUTO_COEFF, s);
-    hipLaunchKernelGGL(automorphism_coeff_kernel, grid, block, 0, s, A);
+    if (conjugate_invariant) {
+        const uint64_t m = 2ull * r.N;  // inverse of the odd gal modulo the power of two 2N (Newton iteration)
+        uint64_t inv = gal;
+        for (int i = 0; i < 6; i++) inv *= 2 - gal * inv;
+        A.ginv = inv & (m - 1);
+        A.gal = gal & (2 * m - 1);  // only i * gal mod 4N matters (the sign bit is bit log2(2N))
+        hipLaunchKernelGGL(automorphism_coeff_ci_kernel, grid, block, 0, s, A);
+    } else {
+        hipLaunchKernelGGL(automorphism_coeff_kernel, grid, block, 0, s, A);
+    }
     return hipGetLastError();
 }
 

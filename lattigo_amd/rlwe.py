@@ -305,6 +305,9 @@ class InnerSumEvaluator:
                 for a, b in zip(opOut, ctIn):
                     a.CopyLvl(level, b)
             return
+        ci = getattr(self.ringQ, "conjugate_invariant", False)
+        if ci:
+            gap >>= 1  # the last step, phi(5^-1), is skipped on Z[X + X^-1] (core/rlwe/inner_sum.go:60-62)
         Q = 1
         for m in self.ringQ.ModuliChain()[: level + 1]:
             Q *= int(m)
@@ -315,8 +318,8 @@ class InnerSumEvaluator:
                 rQ.NTT(b, b)
         buff = [Poly(self.ringQ, level + 1, opOut[0].batch, zero=False) for _ in range(2)]
         steps = [self.GaloisElement(1 << i) for i in range(logN, self.logN - 1)]
-        if logN == 0:
-            steps.append(self.nth_root - 1)  # X -> X^-1 (:97-105)
+        if logN == 0 and not ci:
+            steps.append(self.nth_root - 1)  # X -> X^-1, standard ring only (:97-105)
         for galEl in steps:
             self.eval.Automorphism(level, opOut, galEl, self.gks.GetGaloisKey(galEl), buff)
             for a, b in zip(opOut, buff):

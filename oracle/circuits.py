@@ -29,14 +29,14 @@ class InnerSumEvaluator:
         self.eval, self.gks = evaluator, gks
         self.ringQ, self.ringP = evaluator.ringQ, evaluator.ringP
         self.be = O.BasisExtender(self.ringQ, self.ringP)
-        self.nth_root = 2 * self.ringQ.N
+        self.nth_root = self.ringQ.NthRoot()
         self.logN = self.ringQ.N.bit_length() - 1
 
     def GaloisElement(self, k):
         return GaloisElement(self.nth_root, k)
 
     def Trace(self, ctIn, logN, isNTT=True):
-        """core/rlwe/inner_sum.go:36-117 (standard ring)"""
+        """core/rlwe/inner_sum.go:36-117 (both ring types: :60-62, :97)"""
         ctIn = np.asarray(ctIn, dtype=np.uint64)
         level = ctIn.shape[1] - 1
         rQ = self.ringQ
@@ -45,13 +45,16 @@ class InnerSumEvaluator:
             gap <<= 1
         if gap <= 1:
             return ctIn.copy()
+        ci = getattr(rQ, "conjugate_invariant", False)
+        if ci:
+            gap >>= 1  # :60-62: the last step, phi(5^-1), is skipped
         ninv = pow(gap, -1, _prod(rQ.moduli[: level + 1]))
         out = np.stack([rQ.MulScalarBigint(ctIn[k], ninv) for k in range(2)])  # :68-70
         if not isNTT:
             out = np.stack([rQ.NTT(out[k]) for k in range(2)])
         steps = [self.GaloisElement(1 << i) for i in range(logN, self.logN - 1)]  # :82
-        if logN == 0:
-            steps.append(self.nth_root - 1)  # :97
+        if logN == 0 and not ci:
+            steps.append(self.nth_root - 1)  # :97 (ringQ.Type() == ring.Standard)
         for galEl in steps:
             buff = self.eval.Automorphism(out, galEl, self.gks[galEl])
             out = np.stack([rQ.binop("Add", out[k], buff[k]) for k in range(2)])

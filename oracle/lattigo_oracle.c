@@ -846,9 +846,25 @@ void lo_automorphism_ntt_with_index_then_add_lazy(const lo_ring *r, int level, c
     for (int i = 0; i <= level; i++)
         for (int j = 0; j < N; j++) pout[(size_t)i * N + j] += pin[(size_t)i * N + index[j]];
 }
-/* Automorphism (coefficient domain, standard ring), :153-174 */
+/* Automorphism (coefficient domain), :113-176: conjugate-invariant branch :122-151, standard ring :153-174 */
 void lo_automorphism(const lo_ring *r, int level, const uint64_t *pin, uint64_t galel, uint64_t *pout) {
     uint64_t N = (uint64_t)r->N, mask = N - 1;
+    if (r->s[0]->nthroot == 4 * N) {  /* Z[X + X^-1]/(X^2N + 1): i runs over [0, 2N), only images below N are kept */
+        mask = 2 * N - 1;
+        int logN2 = bitlen64(mask);
+        for (uint64_t i = 0; i < 2 * N; i++) {
+            uint64_t raw = i * galel, index = raw & mask, tmp = (raw >> logN2) & 1;
+            if (index < N) {
+                uint64_t idx = i;
+                if (idx >= N) { idx = 2 * N - idx; tmp ^= 1; }
+                for (int j = 0; j <= level; j++) {
+                    uint64_t c = pin[(size_t)j * N + idx];
+                    pout[(size_t)j * N + index] = (c * (tmp ^ 1)) | ((r->s[j]->q - c) * tmp);
+                }
+            }
+        }
+        return;
+    }
     int logN = bitlen64(mask);
     for (uint64_t i = 0; i < N; i++) {
         uint64_t raw = i * galel, index = raw & mask, tmp = (raw >> logN) & 1;
@@ -1407,7 +1423,7 @@ void lo_automorphism_ct(const lo_evaluator *e, int level, const uint64_t *ct_in,
     size_t sz = (size_t)(level + 1) * N;
     uint64_t *tmp = (uint64_t *)pool_get(2 * sz * 8);
     uint64_t *index = (uint64_t *)pool_get((size_t)N * 8);
-    lo_automorphism_ntt_index(N, 2 * (uint64_t)N, galel, index);
+    lo_automorphism_ntt_index(N, e->ringQ->s[0]->nthroot, galel, index);
     lo_gadget_product(e, level, ct_in + sz, gk, tmp);
     lo_binop(e->ringQ, level, LO_ADD, tmp, ct_in, tmp);
     lo_automorphism_ntt_with_index(e->ringQ, level, tmp, index, ct_out);
@@ -1421,7 +1437,7 @@ void lo_automorphism_hoisted(const lo_evaluator *e, int level, const uint64_t *c
     size_t sz = (size_t)(level + 1) * N;
     uint64_t *tmp = (uint64_t *)pool_get(2 * sz * 8);
     uint64_t *index = (uint64_t *)pool_get((size_t)N * 8);
-    lo_automorphism_ntt_index(N, 2 * (uint64_t)N, galel, index);
+    lo_automorphism_ntt_index(N, e->ringQ->s[0]->nthroot, galel, index);
     lo_gadget_product_hoisted(e, level, decompQ, decompP, gk, tmp);
     lo_binop(e->ringQ, level, LO_ADD, tmp, ct_in, tmp);
     lo_automorphism_ntt_with_index(e->ringQ, level, tmp, index, ct_out);
@@ -1437,7 +1453,7 @@ void lo_automorphism_hoisted_lazy(const lo_evaluator *e, int levelQ, const uint6
     size_t szQ = (size_t)(levelQ + 1) * N, szP = (size_t)(levelP + 1) * N;
     uint64_t *tQ = (uint64_t *)pool_get(2 * szQ * 8), *tP = (uint64_t *)pool_get(2 * szP * 8);
     uint64_t *index = (uint64_t *)pool_get((size_t)N * 8);
-    lo_automorphism_ntt_index(N, 2 * (uint64_t)N, galel, index);
+    lo_automorphism_ntt_index(N, e->ringQ->s[0]->nthroot, galel, index);
     lo_gadget_product_hoisted_lazy(e, levelQ, decompQ, decompP, gk, tQ, tP);
     lo_automorphism_ntt_with_index(e->ringQ, levelQ, tQ + szQ, index, outQ + szQ);
     lo_automorphism_ntt_with_index(e->ringP, levelP, tP + szP, index, outP + szP);

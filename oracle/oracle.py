@@ -275,7 +275,7 @@ class Ring:
         return len(self.moduli) - 1
 
     def NthRoot(self):
-        return 2 * self.N
+        return (4 if self.conjugate_invariant else 2) * self.N  # ring/ring.go:254,261
 
     def NewPoly(self, level=None):
         level = self.MaxLevel() if level is None else level
@@ -491,7 +491,7 @@ class Ring:
 
     # -- automorphism (ring/automorphism.go)
     def AutomorphismNTTIndex(self, galel):
-        return AutomorphismNTTIndex(self.N, 2 * self.N, galel)
+        return AutomorphismNTTIndex(self.N, self.NthRoot(), galel)
 
     def AutomorphismNTTWithIndex(self, pin, index):
         pin = _c(pin)

@@ -35,7 +35,14 @@ class SecretKey:
 
 
 def automorphism_secret(rng, ringQ, ringP, sk: SecretKey, galel: int) -> SecretKey:
-    """pi_galel(sk) in the coefficient domain (ring/automorphism.go:113)."""
+    """pi_galel(sk) in the coefficient domain (ring/automorphism.go:113); on a conjugate-invariant ring in the NTT domain, as
+    the reference's key generator does for either type (core/rlwe/keygenerator.go:158-169)."""
+    if getattr(ringQ, "conjugate_invariant", False):
+        out = SecretKey.__new__(SecretKey)
+        out.vals = None
+        out.Q = ringQ.AutomorphismNTTWithIndex(sk.Q, ringQ.AutomorphismNTTIndex(galel))
+        out.P = ringP.AutomorphismNTTWithIndex(sk.P, ringP.AutomorphismNTTIndex(galel)) if ringP is not None else None
+        return out
     N = ringQ.N
     out = np.zeros(N, dtype=np.int64)
     for i in range(N):
@@ -83,7 +90,7 @@ def phase(ringQ: O.Ring, ct: np.ndarray, skQ: np.ndarray) -> np.ndarray:
     level = ct.shape[1] - 1
     s = skQ[: level + 1]
     acc = ct[-1].copy()
-    sub = O.Ring(ringQ.N, ringQ.moduli[: level + 1])
+    sub = O.Ring(ringQ.N, ringQ.moduli[: level + 1], getattr(ringQ, "conjugate_invariant", False))
     for i in range(ct.shape[0] - 2, -1, -1):
         acc = sub.binop("Add", sub.binop("MulCoeffsMontgomery", acc, s), ct[i])
     return acc
@@ -91,7 +98,7 @@ def phase(ringQ: O.Ring, ct: np.ndarray, skQ: np.ndarray) -> np.ndarray:
 
 def noise_log2(ringQ: O.Ring, ntt_poly: np.ndarray) -> float:
     level = ntt_poly.shape[0] - 1
-    sub = O.Ring(ringQ.N, ringQ.moduli[: level + 1])
+    sub = O.Ring(ringQ.N, ringQ.moduli[: level + 1], getattr(ringQ, "conjugate_invariant", False))
     c = centered(sub, sub.INTT(ntt_poly), 0)
     m = max(abs(int(x)) for x in c)
     return float(np.log2(m)) if m > 0 else 0.0

@@ -278,20 +278,28 @@ def test_conjugate_invariant_ntt(ctx, logN):
 
 
 def test_conjugate_invariant_rescale(ctx):
-    """ring/scaling.go on a conjugate-invariant ring (the NTT variants go through the folded transform)."""
+    """ring/scaling.go on a conjugate-invariant ring.  The NTT variants feed the LAZY words of INTTConjugateInvariantLazy
+    (ring/ntt.go:1104-1152: a representative in [0, 2q), about one word in a thousand at or above q) into the other moduli, so
+    the representative is observable: the device reproduces the reference's words (a value off by q_L moves the quotient by
+    one).  Several polynomials so that such words are certain to occur."""
     N, Q = 1 << 10, Qi60[:4]
     g, o = la.Ring(ctx, N, Q, conjugate_invariant=True), O.Ring(N, Q, conjugate_invariant=True)
-    x = uniform_poly(rng_for(1600), Q, N)
-    px = la.Poly(g, 4).upload(x)
-    for name in ["DivRoundByLastModulusNTT", "DivRoundByLastModulus", "DivFloorByLastModulus"]:
+    rng = rng_for(1600)
+    lazy_words = 0
+    for trial in range(12):
+        x = uniform_poly(rng, Q, N)
+        lazy_words += int((o.INTTLazy(x)[3] >= np.uint64(Q[3])).sum())
+        px = la.Poly(g, 4).upload(x)
+        for name in ["DivRoundByLastModulusNTT", "DivFloorByLastModulusNTT", "DivRoundByLastModulus", "DivFloorByLastModulus"]:
+            po = g.NewPoly()
+            getattr(g, name)(px, po)
+            assert np.array_equal(po.get()[:3], getattr(o, name)(x)), (name, trial)
         po = g.NewPoly()
-        getattr(g, name)(px, po)
-        assert np.array_equal(po.get()[:3], getattr(o, name)(x)), name
-    with pytest.raises(la.HeringError):  # depends on the reference's lazy INTT representative: rejected, not approximated
-        g.DivFloorByLastModulusNTT(px, g.NewPoly())
-    po = g.NewPoly()
-    g.DivRoundByLastModulusManyNTT(2, px, po)
-    assert np.array_equal(po.get()[:2], o.DivRoundByLastModulusManyNTT(2, x))
+        g.DivRoundByLastModulusManyNTT(2, px, po)
+        assert np.array_equal(po.get()[:2], o.DivRoundByLastModulusManyNTT(2, x))
+        g.DivFloorByLastModulusManyNTT(1, px, po)
+        assert np.array_equal(po.get()[:3], o.DivFloorByLastModulusManyNTT(1, x))
+    assert lazy_words > 0  # the case the exact representative is about did occur
 
 
 def test_remaining_ring_operations(ctx):

@@ -396,6 +396,103 @@ def test_fused_pipeline_wide_digits_and_logN13(ctx, logN, np_):
     assert np.array_equal(np.stack([o.get() for o in o2]), oev.CKKSMulRelin(ct0, ct1, oevk, True))
 
 
+@pytest.mark.parametrize("logN", [10, 13])
+def test_conjugate_invariant_basis_extender_and_evaluator(ctx, logN):
+    """RingType = ConjugateInvariant (Z[X + X^-1]/(X^2N + 1), NthRoot = 4N) through ring.BasisExtender and rlwe.Evaluator:
+    every ModUp / ModDown form, DecomposeNTT, GadgetProduct plain and hoisted, rotations by 5^k (plain, hoisted, hoisted-lazy,
+    coefficient-domain), the automorphism index table, CKKS MulRelin + Rescale and Trace, bit for bit against the oracle
+    (ring/ntt.go:716-1311, ring/automorphism.go:12-34,:122-151, core/rlwe/inner_sum.go:60-62)."""
+    q, p = O.GenModuli(logN + 2, [55, 45, 58, 40, 61], [55, 46])   # = 1 mod 4N; every arithmetic class
+    pr = Pair(ctx, logN, len(q), len(p), qmods=q, pmods=p, ci=True)
+    N, nq, np_ = pr.N, len(q), len(p)
+    rng = rng_for(2900 + logN)
+    assert pr.gQ.NthRoot() == 4 * N
+    obe, gbe = O.BasisExtender(pr.oQ, pr.oP), la.BasisExtender(pr.gQ, pr.gP)
+    for levelQ, levelP in ((nq - 1, np_ - 1), (2, 0)):
+        xq, xp = uniform_poly(rng, q[: levelQ + 1], N), uniform_poly(rng, p[: levelP + 1], N)
+        pq, pp = la.Poly(pr.gQ, levelQ + 1).upload(xq), la.Poly(pr.gP, levelP + 1).upload(xp)
+        oq, op = la.Poly(pr.gQ, levelQ + 1), la.Poly(pr.gP, levelP + 1)
+        gbe.ModUpQtoP(levelQ, levelP, pq, op)
+        assert np.array_equal(op.get(), obe.ModUpQtoP(levelQ, levelP, xq))
+        gbe.ModUpPtoQ(levelP, levelQ, pp, oq)
+        assert np.array_equal(oq.get(), obe.ModUpPtoQ(levelP, levelQ, xp))
+        gbe.ModDownQPtoQ(levelQ, levelP, pq, pp, oq)
+        assert np.array_equal(oq.get(), obe.ModDownQPtoQ(levelQ, levelP, xq, xp))
+        gbe.ModDownQPtoQNTT(levelQ, levelP, pq, pp, oq)
+        assert np.array_equal(oq.get(), obe.ModDownQPtoQNTT(levelQ, levelP, xq, xp))
+        gbe.ModDownQPtoP(levelQ, levelP, pq, pp, op)
+        assert np.array_equal(op.get(), obe.ModDownQPtoP(levelQ, levelP, xq, xp))
+    gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+    sk = SecretKey(rng, pr.oQ, pr.oP)
+    level = nq - 1
+    ct = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(2)])   # [b][k]
+    pct = [la.Poly(pr.gQ, nq, 2).upload(ct[:, k]) for k in range(2)]
+    okey = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, SecretKey(rng, pr.oQ, pr.oP))
+    gkey = gev.NewEvaluationKey(okey.q, okey.p)
+    out = [la.Poly(pr.gQ, nq, 2), la.Poly(pr.gQ, nq, 2)]
+    gev.GadgetProduct(level, pct[1], gkey, out)
+    for b in range(2):
+        want = oev.GadgetProduct(level, ct[b, 1], okey)
+        assert np.array_equal(out[0].get()[b], want[0]) and np.array_equal(out[1].get()[b], want[1]), b
+    dec = la.Decomposition(gev, 2)
+    gev.DecomposeNTT(level, np_ - 1, np_, pct[1], True, dec)
+    dq, dp = oev.DecomposeNTT(level, np_ - 1, np_, ct[1, 1], True)
+    for d in range(dq.shape[0]):
+        for l in range(nq):
+            assert np.array_equal(dec.limb(1, d, False, l), dq[d, l]), (d, l)
+        for l in range(np_):
+            assert np.array_equal(dec.limb(1, d, True, l), dp[d, l]), (d, l)
+    out2 = [la.Poly(pr.gQ, nq, 2), la.Poly(pr.gQ, nq, 2)]
+    gev.GadgetProductHoisted(level, dec, gkey, out2)
+    assert np.array_equal(out2[0].get(), out[0].get()) and np.array_equal(out2[1].get(), out[1].get())
+    for k in (1, 5):
+        galel = pow(5, k, 4 * N)
+        # the index table itself (ring.AutomorphismNTTIndex with NthRoot = 4N)
+        assert np.array_equal(pr.gQ.AutomorphismNTTIndex(galel).download(), pr.oQ.AutomorphismNTTIndex(galel))
+        ogk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, automorphism_secret(rng, pr.oQ, pr.oP, sk, pow(galel, 4 * N - 1, 4 * N)))
+        ggk = gev.NewEvaluationKey(ogk.q, ogk.p)
+        gev.Automorphism(level, pct, galel, ggk, out)
+        want = oev.Automorphism(ct[0], galel, ogk)
+        got = np.stack([o.get()[0] for o in out])
+        assert np.array_equal(got, want), k
+        idx = pr.oQ.AutomorphismNTTIndex(galel)
+        wantp = pr.oQ.AutomorphismNTTWithIndex(phase(pr.oQ, ct[0], sk.Q), idx)
+        assert noise_log2(pr.oQ, pr.oQ.binop("Sub", phase(pr.oQ, got, sk.Q), wantp)) <= logN + 7
+        gev.AutomorphismHoisted(level, pct, dec, galel, ggk, out2)
+        assert np.array_equal(out2[0].get(), out[0].get()) and np.array_equal(out2[1].get(), out[1].get())
+        wQ, wP = oev.AutomorphismHoistedLazy(level, ct[1, 0], dq, dp, galel, ogk)
+        qp = [(la.Poly(pr.gQ, nq, 2), la.Poly(pr.gP, np_, 2)) for _ in range(2)]
+        gev.AutomorphismHoistedLazy(level, pct, dec, galel, ggk, qp)
+        for c in range(2):
+            assert np.array_equal(qp[c][0].get()[1], wQ[c]) and np.array_equal(qp[c][1].get()[1], wP[c]), (k, c)
+        # coefficient domain (ring.Automorphism on Z[X + X^-1])
+        x = uniform_poly(rng, q, N)
+        po = pr.gQ.NewPoly()
+        pr.gQ.Automorphism(pr.gQ.NewPoly().upload(x), galel, po)
+        assert np.array_equal(po.get(), pr.oQ.Automorphism(x, galel)), k
+    o2 = [la.Poly(pr.gQ, nq), la.Poly(pr.gQ, nq)]
+    a, b = [la.Poly(pr.gQ, nq).upload(c) for c in ct[0]], [la.Poly(pr.gQ, nq).upload(c) for c in ct[1]]
+    gev.CKKSMulRelin(level, a, b, gkey, o2)
+    wantm = oev.CKKSMulRelin(ct[0], ct[1], okey, True)
+    assert np.array_equal(np.stack([o.get() for o in o2]), wantm)
+    res = [la.Poly(pr.gQ, nq - 1), la.Poly(pr.gQ, nq - 1)]
+    gev.Rescale(level, 1, o2, res)
+    assert np.array_equal(np.stack([r.get() for r in res]), oev.Rescale(wantm, 1))
+    # Trace: on this ring the last step (phi(5^-1)) and the conjugation do not exist
+    from oracle import circuits as OC
+    nth = 4 * N
+    gks, ogks = R.GaloisKeySet(), {}
+    for i in range(0, logN - 1):
+        g = R.GaloisElement(nth, 1 << i)
+        ogks[g] = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, automorphism_secret(rng, pr.oQ, pr.oP, sk, pow(g, nth - 1, nth)))
+        gks.keys[g] = gev.NewEvaluationKey(ogks[g].q, ogks[g].p)
+    gi, oi = R.InnerSumEvaluator(gev, gks), OC.InnerSumEvaluator(oev, ogks)
+    for logn in (0, logN - 3):
+        tout = [la.Poly(pr.gQ, nq), la.Poly(pr.gQ, nq)]
+        gi.Trace(level, [la.Poly(pr.gQ, nq).upload(c) for c in ct[0]], logn, tout)
+        assert np.array_equal(np.stack([o.get() for o in tout]), oi.Trace(ct[0], logn)), logn
+
+
 @pytest.mark.parametrize("pw2", [2, 16])
 def test_gadget_product_without_special_primes(ctx, pw2):
     """levelP = -1 (rlwe.ParametersLiteral.P = nil; the reference's P-less test set, core/rlwe/test_params.go:36-46):

@@ -177,3 +177,33 @@ def test_gadget_product_without_special_primes_decrypts(pw2):
         got = phase(ringQ, ct, sk2.Q)
         want = sub.binop("MulCoeffsMontgomery", cx, sk.Q[: levelQ + 1])
         assert noise_log2(ringQ, sub.binop("Sub", got, want)) <= 10 + pw2 + 6
+
+
+def test_conjugate_invariant_key_switch_decrypts():
+    """The key-switch on the conjugate-invariant ring Z[X + X^-1]/(X^2N + 1) (RingType = ConjugateInvariant; real-valued
+    CKKS): gadget product, relinearisation-style MulRelin and rotations by 5^k (NthRoot = 4N in the automorphism index,
+    ring/ring.go:261, ring/automorphism.go:12-34) decrypt within the reference's noise bound (core/rlwe/rlwe_test.go:679,725)."""
+    rng = rng_for(950)
+    ringQ, ringP = O.Ring(N, Qi60[:5], True), O.Ring(N, Pi60[:2], True)
+    assert ringQ.NthRoot() == 4 * N
+    ev = O.Evaluator(ringQ, ringP)
+    sk, sk2 = SecretKey(rng, ringQ, ringP), SecretKey(rng, ringQ, ringP)
+    evk = gen_evaluation_key(rng, ringQ, ringP, sk.Q, sk2)
+    for levelQ in (4, 2):
+        sub = O.Ring(N, ringQ.moduli[: levelQ + 1], True)
+        cx = uniform_poly(rng, sub.moduli, N)
+        got = phase(ringQ, ev.GadgetProduct(levelQ, cx, evk), sk2.Q)
+        want = sub.binop("MulCoeffsMontgomery", cx, sk.Q[: levelQ + 1])
+        assert noise_log2(ringQ, sub.binop("Sub", got, want)) <= 10 + 6
+    for k in (1, 3):  # rotations; the conjugation X -> X^-1 does not exist on this ring (core/rlwe/params.go:593)
+        galel = pow(5, k, 4 * N)
+        sk_out = automorphism_secret(rng, ringQ, ringP, sk, pow(galel, 4 * N - 1, 4 * N))
+        gk = gen_evaluation_key(rng, ringQ, ringP, sk.Q, sk_out)
+        ct = np.stack([uniform_poly(rng, ringQ.moduli, N) for _ in range(2)])
+        out = ev.Automorphism(ct, galel, gk)
+        want = ringQ.AutomorphismNTTWithIndex(phase(ringQ, ct, sk.Q), ringQ.AutomorphismNTTIndex(galel))
+        assert noise_log2(ringQ, ringQ.binop("Sub", phase(ringQ, out, sk.Q), want)) <= 10 + 6
+    # coefficient-domain automorphism agrees with the NTT-domain one
+    x = uniform_poly(rng, ringQ.moduli, N)
+    g = pow(5, 7, 4 * N)
+    assert np.array_equal(ringQ.NTT(ringQ.Automorphism(x, g)), ringQ.AutomorphismNTT(ringQ.NTT(x), g))
