@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Copy the summaries of tools/round_artifacts.sh from gpurun_out/ (scratch) into profiles/ (tracked): python tools/collect_profiles.py r02"""
+import collections
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, f"{tag}_bench.json"))
+shutil.copy(os.path.join(G, "bench_configs.jsonl"), os.path.join(P, f"{tag}_bench_other_configs.jsonl"))
+stats = [f for f in os.listdir(os.path.join(G, "prof_final")) if f.endswith("kernel_stats.csv")]
+shutil.copy(os.path.join(G, "prof_final", stats[0]), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
+batch = json.load(open(os.path.join(G, "bench_final.json")))["config"]["batch_per_gpu"]
+out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"),
+                               os.path.join(G, "pmc_FETCH_SIZE", "bench_counter_collection.csv"),
+                               os.path.join(G, "pmc_WRITE_SIZE", "bench_counter_collection.csv"), str(batch)], text=True)
+d = json.loads(out)
+d["workload"] = "c3"
+json.dump(d, open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+# SQ passes: per (kernel, grid) launch group
+groups = {}
+for t in ("sq1", "sq2"):
+    rows = collections.defaultdict(dict)
+    for r in csv.DictReader(open(os.path.join(G, f"pmc_{t}", "b_counter_collection.csv"))):
+        key = (r["Kernel_Name"].split("(")[0].replace("void he::", ""), r["Grid_Size"], r["Dispatch_Id"])
+        rows[key][r["Counter_Name"]] = float(r["Counter_Value"])
+    agg = collections.defaultdict(list)
+    for (name, grid, _), c in rows.items():
+        agg[(name, grid)].append(c)
+    for (name, grid), cs in agg.items():
+        m = {k: sum(c.get(k, 0.0) for c in cs) / len(cs) for k in cs[0]}
+        groups.setdefault(f"{name} grid={grid}", {}).update(m)
+summary = {"source": "rocprofv3 --pmc (two passes, tools/round_artifacts.sh) on bench.py --steps 3; per-launch means, summed over the shader engines",
+           "notes": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles per wave; valu_issue_share = VALU instructions per wave / wave-quad-cycles per wave",
+           "launch_groups": {}}
+for k, m in sorted(groups.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+    if m.get("SQ_WAVES", 0) < 1000:
+        continue
+    w = m["SQ_WAVES"]
+    e = {"waves": round(w), "valu_insts_per_wave": round(m.get("SQ_INSTS_VALU", 0) / w, 1),
+         "wave_quad_cycles_per_wave": round(m.get("SQ_WAVE_CYCLES", 0) / w),
+         "valu_issue_share_of_wave_time": round(m.get("SQ_INSTS_VALU", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), 3),
+         "wait_any_share": round(m.get("SQ_WAIT_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), 3),
+         "wait_inst_any_share": round(m.get("SQ_WAIT_INST_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), 3),
+         "salu_per_wave": round(m.get("SQ_INSTS_SALU", 0) / w, 1), "lds_per_wave": round(m.get("SQ_INSTS_LDS", 0) / w, 1),
+         "vmem_rd_per_wave": round(m.get("SQ_INSTS_VMEM_RD", 0) / w, 1), "vmem_wr_per_wave": round(m.get("SQ_INSTS_VMEM_WR", 0) / w, 1),
+         "smem_per_wave": round(m.get("SQ_INSTS_SMEM", 0) / w, 1)}
+    if m.get("SQ_ACTIVE_INST_LDS", 0) > 0:
+        e["lds_bank_conflict_share"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_ACTIVE_INST_LDS"], 3)
+    summary["launch_groups"][k] = e
+json.dump(summary, open(os.path.join(P, f"{tag}_sq_counters.json"), "w"), indent=1)
+print("profiles written:", sorted(f for f in os.listdir(P) if f.startswith(tag)))
