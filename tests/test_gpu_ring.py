@@ -86,7 +86,7 @@ def test_ntt_matches_oracle(ctx, logN):
 
 @pytest.mark.parametrize("logN", [15, 16])
 def test_ntt_large_roundtrip_and_linearity(ctx, logN):
-    """Full-size property checks (the oracle is only sampled on one limb)."""
+    """Full-size property checks, and every limb against the oracle (it takes milliseconds per limb)."""
     pr = Pair(ctx, logN, 4)
     rng = rng_for(1100 + logN)
     x, y = uniform_poly(rng, pr.q, pr.N), uniform_poly(rng, pr.q, pr.N)
@@ -98,7 +98,7 @@ def test_ntt_large_roundtrip_and_linearity(ctx, logN):
     pr.gQ.NTT(ps, fs)
     pr.gQ.Add(fx, fy, fy)
     assert np.array_equal(fs.get(), fy.get())  # linearity
-    assert np.array_equal(fx.get()[0], pr.oQ.NTT(x)[0])  # oracle on limb 0
+    assert np.array_equal(fx.get(), pr.oQ.NTT(x))  # oracle, every limb
     pr.gQ.INTT(fx, fx)
     assert np.array_equal(fx.get(), x)  # round trip
     # negacyclic convolution theorem: NTT(x * X) = NTT(x) .* NTT(X)

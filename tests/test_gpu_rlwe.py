@@ -233,7 +233,7 @@ def test_rotate(ctx, nq, np_):
 
 def test_full_size_properties_logN15(ctx):
     """BASELINE config 3 shape (logN=15, 12 Q-limbs, 3 P-limbs): hoisted == plain, batch == single,
-    linearity of the gadget product in cx, and one limb of every output checked against the oracle."""
+    linearity of the gadget product in cx, and every limb of both outputs checked against the oracle."""
     logN, nq, np_ = 15, 12, 3
     q, p = O.GenModuli(logN + 1, [55] + [45] * 11, [55] * 3)
     pr = Pair(ctx, logN, nq, np_, qmods=q, pmods=p)
@@ -265,7 +265,7 @@ def test_full_size_properties_logN15(ctx):
 
 
 def _full_size_check(ctx, logN, logq, logp, seed, do_rotate):
-    """Full-size config check: one limb-complete oracle comparison of GadgetProduct (+ Rotate) on a
+    """Full-size config check: limb-complete oracle comparison of GadgetProduct (+ Rotate) for every batch entry on a
     random key, batch of 2, plus hoisted == plain."""
     q, p = O.GenModuli(logN + 1, logq, logp)
     nq, np_ = len(q), len(p)
@@ -283,14 +283,16 @@ def _full_size_check(ctx, logN, logq, logp, seed, do_rotate):
         out = [la.Poly(pr.gQ, level + 1, 2), la.Poly(pr.gQ, level + 1, 2)]
         gev.GadgetProduct(level, pc[1], gevk, out)
         g = [o.get() for o in out]
-        want = oev.GadgetProduct(level, ct[1, 1], oevk)
-        assert np.array_equal(g[0][1], want[0]) and np.array_equal(g[1][1], want[1]), ("GadgetProduct", level)
+        for b in range(2):  # every batch entry, every limb
+            want = oev.GadgetProduct(level, ct[b, 1], oevk)
+            assert np.array_equal(g[0][b], want[0]) and np.array_equal(g[1][b], want[1]), ("GadgetProduct", level, b)
         if do_rotate:
             galel = pow(5, 3, 2 * pr.N)
             out2 = [la.Poly(pr.gQ, level + 1, 2), la.Poly(pr.gQ, level + 1, 2)]
             gev.Automorphism(level, pc, galel, gevk, out2)
-            wantr = oev.Automorphism(ct[0], galel, oevk)
-            assert np.array_equal(out2[0].get()[0], wantr[0]) and np.array_equal(out2[1].get()[0], wantr[1]), ("Rotate", level)
+            for b in range(2):
+                wantr = oev.Automorphism(ct[b], galel, oevk)
+                assert np.array_equal(out2[0].get()[b], wantr[0]) and np.array_equal(out2[1].get()[b], wantr[1]), ("Rotate", level, b)
             dec = la.Decomposition(gev, 2)
             gev.DecomposeNTT(level, np_ - 1, np_, pc[1], True, dec)
             out3 = [la.Poly(pr.gQ, level + 1, 2), la.Poly(pr.gQ, level + 1, 2)]
