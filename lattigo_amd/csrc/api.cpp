@@ -1530,8 +1530,10 @@ void mark_fast_destinations(const BasisExtender &be, ModUpDesc &D, const std::ve
         const uint64_t p = be.modulus(D.dst_mod[j]);
         const bool f64_dst = (p >> 47) == 0 && be.d_twdf != nullptr;
         const u128 colsum = (u128)(D.nsrc + 1) * ((u128)p + mx + ((u128)1 << 31));
-        D.dst_fast[j] = (!off && !D.single && !D.reduce_out && !f64_dst && (p >> 58) == 0 && D.nsrc + 1 <= 15 && (colsum >> 64) == 0 &&
-                         be.d_tws != nullptr) ? 1 : 0;
+        // 1: 30-bit column accumulation + correction-free butterflies (below 2^58); 2: 128-bit accumulation + Harvey-range
+        // butterflies (any modulus); 0: the generic path (single-limb digits, sums that need the extra reduction)
+        const bool lean = !off && !D.single && !D.reduce_out && !f64_dst && be.d_tws != nullptr;
+        D.dst_fast[j] = !lean ? 0 : ((p >> 58) == 0 && D.nsrc + 1 <= 15 && (colsum >> 64) == 0) ? 1 : 2;
     }
 }
 int upload_plan(Evaluator &ev, const std::vector<ModUpDesc> &descs, FusedPlan &plan) {

@@ -1856,6 +1856,47 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
 #pragma unroll
             for (int r = 0; r < R; r++) stnt(&dst[(size_t)r * N2], f64_to_u52(reduce_f64(o[r], pd, pid) + pd));  // (0, 2p)
         }
+        if (!done && !single && U(D.dst_fast[j]) == 2) {
+            // The same folding for the remaining destination moduli (up to 2^62: the 60/61-bit q0 and special primes of the CKKS
+            // chains): acc = C0m + sum_i y_i Tm_i + v V1m in 128 bits, one Montgomery reduction -> [0, 2p); Shoup column
+            // butterflies in the Harvey range ([0, 4p): U is brought below 2p first).
+            done = true;
+            const int row = (int)U(D.dst_row[j]);
+            uint64_t Tm[NSRC + 1];
+#pragma unroll
+            for (int i = 0; i < NSRC; i++) Tm[i] = ldc(DT, (size_t)row * NSRC + i);
+            Tm[NSRC] = ldc(Dfc, 2 * (size_t)row);
+            const uint64_t C0 = ldc(Dfc, 2 * (size_t)row + 1);
+            uint64_t o[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                u128 acc = (u128)C0 + (u128)(uint64_t)v[r] * Tm[NSRC];
+#pragma unroll
+                for (int i = 0; i < NSRC; i++) acc += (u128)Y(r, i) * Tm[i];
+                o[r] = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p;  // (0, 2p)
+            }
+            if constexpr (LOGA > 0) {
+                const uint64_t *ts = A.tws_fwd + (size_t)mi * 32;
+#pragma unroll
+                for (int s = 0; s < LOGA; s++) {
+                    const int d = 1 << (LOGA - 1 - s);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (r & d) continue;
+                        const size_t ix = (size_t)((1 << s) + (r >> (LOGA - s)));
+                        const uint64_t w = ldc(ts, 2 * ix), ws = ldc(ts, 2 * ix + 1);
+                        const uint64_t V = o[r + d];
+                        const uint64_t rr = V * w - mulhi64(V, ws) * p;  // [0, 2p)
+                        uint64_t Uu = o[r];
+                        Uu = Uu >= twop ? Uu - twop : Uu;
+                        o[r] = Uu + rr;
+                        o[r + d] = Uu + twop - rr;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) stnt(&dst[(size_t)r * N2], o[r]);  // [0, 4p)
+        }
         if (!done && !single && U(D.dst_fast[j]) != 0) {
             // Lean integer path for destination moduli below 2^58 (the 55-bit limbs of the headline chain).  Only the residue
             // class of the result matters here (the row NTT that follows accepts any word below 10p), so:
