@@ -40,6 +40,8 @@ struct RingDev {
     // [n_mod][16][2]: {w, floor(w 2^64 / q)} for the plain (non-Montgomery) forward twiddles RootsForward[0..15] -- the column
     // stages fused into the basis extension use Shoup products on the integer path; null when not built
     const uint64_t *tws_fwd = nullptr;
+    // [n_mod][N][2]: the whole forward / backward twiddle tables as Shoup pairs (integer row kernels), or null
+    const uint64_t *tws2_fwd = nullptr, *tws2_inv = nullptr;
 };
 
 // ---- NTT ---------------------------------------------------------------------------

@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -162,6 +163,7 @@ struct NttArgs {
     const ModConst *mc;
     const uint64_t *tw;
     const double *twd;  // same table as plain (non-Montgomery) integers in double precision, moduli < 2^47 only
+    const ulonglong2 *tws;  // same table as Shoup pairs {w, floor(w 2^64 / q)} of the plain twiddles (integer kernels), or null
     int N;
     int a;       // column stages already done (forward) / still to do (inverse)
     int flags;
@@ -307,6 +309,52 @@ __device__ __forceinline__ void rows_round16(uint64_t (&x)[16], const uint64_t (
     }
 }
 
+// Shoup form of the radix-16 round: the twiddle comes with its companion w' = floor(w 2^64 / q), and
+//     r = V w - mulhi(V, w') q   (low 64 bits)   lies in [0, 2q) for ANY 64-bit V
+// -- one high product and two low products (19 vector instructions) against the three wide products of a Montgomery
+// multiplication (26).  Forward: X = U + r, Y = U + 2q - r (NC: no range correction, the bound grows by 2q per stage exactly as
+// bfly_fwd_nc; Harvey form: U is first brought below 2q).  Inverse: X = U + V (minus 2q when >= 2q), Y = Shoup(U + 2q - V).
+__device__ __forceinline__ uint64_t shoup_mul(uint64_t V, ulonglong2 w, uint64_t q) { return V * w.x - mulhi64(V, w.y) * q; }
+__device__ __forceinline__ void rows_tw16s(ulonglong2 (&t)[15], const ulonglong2 *__restrict__ tw, int rowtw, int s0, int hi0) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int base = (rowtw << (s0 + u)) + (hi0 << u);
+#pragma unroll
+        for (int j = 0; j < (1 << u); j++) t[(1 << u) - 1 + j] = tw[base + j];
+    }
+}
+template <bool INV, bool NC>
+__device__ __forceinline__ void rows_round16s(uint64_t (&x)[16], const ulonglong2 (&t)[15], uint64_t q, uint64_t twoq) {
+    if constexpr (!INV) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int d = 1 << (3 - u);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k & d) continue;
+                const uint64_t r = shoup_mul(x[k + d], t[(1 << u) - 1 + (k >> (4 - u))], q);
+                uint64_t U = x[k];
+                if constexpr (!NC) U = U >= twoq ? U - twoq : U;
+                x[k] = U + r;
+                x[k + d] = U + twoq - r;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 3; u >= 0; u--) {
+            const int d = 1 << (3 - u);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k & d) continue;
+                const uint64_t U = x[k], V = x[k + d];
+                const uint64_t X = U + V;
+                x[k] = X >= twoq ? X - twoq : X;
+                x[k + d] = shoup_mul(U + twoq - V, t[(1 << u) - 1 + (k >> (4 - u))], q);
+            }
+        }
+    }
+}
+
 template <int LOGB, int G4>
 __device__ __forceinline__ void rows_lds_xfer(uint64_t (&x)[16], uint64_t *lds, int tau, int s0, int sh, bool store) {
     constexpr int g = G4, G = 1 << g, W = 16 / G;
@@ -322,8 +370,13 @@ __device__ __forceinline__ void rows_lds_xfer(uint64_t (&x)[16], uint64_t *lds, 
     }
 }
 
-template <int LOGB, bool INV, bool NC>
-__global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4) ntt_rows_kernel(NttArgs A) {
+#ifndef HE_ROWS_SHOUP_WAVES
+#define HE_ROWS_SHOUP_WAVES 4
+#endif
+// SHOUP: the radix-16 rounds take their twiddles from the paired table (NttArgs::tws); never with the N^-1 fold of a
+// single-pass inverse (A.scale), which stays on the Montgomery table
+template <int LOGB, bool INV, bool NC, bool SHOUP = false>
+__global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, SHOUP ? HE_ROWS_SHOUP_WAVES : 4) ntt_rows_kernel(NttArgs A) {
     constexpr int N2 = 1 << LOGB;
     constexpr int T = N2 / 16;
     constexpr int NR4 = LOGB / 4;       // full radix-16 rounds
@@ -340,11 +393,13 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
     const ModConst mc = A.mc[mi];
     const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
     const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
+    const ulonglong2 *__restrict__ tws = SHOUP ? A.tws + (size_t)mi * A.N : nullptr;
     const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
     uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
     const int rowtw = (1 << A.a) + row;  // 2^a + r
 
     uint64_t x[16];
+    using TwT = typename std::conditional<SHOUP, ulonglong2, uint64_t>::type;
 
     if constexpr (!INV) {
         constexpr int sh0 = LOGB - 4;
@@ -354,14 +409,21 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = bred_add_lazy(x[k], q, mc.brc0);
         }
-        uint64_t t16[15];
-        if constexpr (NR4 > 0) rows_tw16(t16, tw, rowtw, 0, tau >> (LOGB - 4));
+        TwT t16[15];
+        if constexpr (NR4 > 0) {
+            if constexpr (SHOUP) rows_tw16s(t16, tws, rowtw, 0, tau >> (LOGB - 4));
+            else rows_tw16(t16, tw, rowtw, 0, tau >> (LOGB - 4));
+        }
 #pragma unroll 1
         for (int rho = 0; rho < NR4; rho++) {
             const int s0 = 4 * rho, sh = LOGB - s0 - 4;
             if (rho > 0) rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, false);
-            rows_round16<false, NC>(x, t16, q, twoq, qinv, mc, false);
-            if (rho + 1 < NR4) rows_tw16(t16, tw, rowtw, s0 + 4, tau >> (sh - 4));  // in flight across the exchange
+            if constexpr (SHOUP) rows_round16s<false, NC>(x, t16, q, twoq);
+            else rows_round16<false, NC>(x, t16, q, twoq, qinv, mc, false);
+            if (rho + 1 < NR4) {  // in flight across the exchange
+                if constexpr (SHOUP) rows_tw16s(t16, tws, rowtw, s0 + 4, tau >> (sh - 4));
+                else rows_tw16(t16, tw, rowtw, s0 + 4, tau >> (sh - 4));
+            }
             rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, true);
             rows_sync(sh);
         }
@@ -431,15 +493,21 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
             rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, true);
             rows_sync(GREM);
         }
-        uint64_t t16[15];
-        if constexpr (NR4 > 0) rows_tw16(t16, tw, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
+        TwT t16[15];
+        if constexpr (NR4 > 0) {
+            if constexpr (SHOUP) rows_tw16s(t16, tws, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
+            else rows_tw16(t16, tw, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
+        }
 #pragma unroll 1
         for (int rho = NR4 - 1; rho >= 0; rho--) {
             const int s0 = 4 * rho, sh = LOGB - s0 - 4;
             rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, false);
-            rows_round16<true, false>(x, t16, q, twoq, qinv, mc, A.scale && rho == 0);
+            if constexpr (SHOUP) rows_round16s<true, false>(x, t16, q, twoq);
+            else rows_round16<true, false>(x, t16, q, twoq, qinv, mc, A.scale && rho == 0);
             if (rho > 0) {
-                rows_tw16(t16, tw, rowtw, s0 - 4, tau >> (sh + 4));  // the next round's, in flight across the exchange
+                // the next round's, in flight across the exchange
+                if constexpr (SHOUP) rows_tw16s(t16, tws, rowtw, s0 - 4, tau >> (sh + 4));
+                else rows_tw16(t16, tw, rowtw, s0 - 4, tau >> (sh + 4));
                 rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, true);
                 rows_sync(sh + 4);  // the consumers are the next round's groups of 2^(sh + 4) threads
             }
@@ -981,6 +1049,18 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
 
 template <bool INV, bool NC>
 static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
+    static const bool no_shoup = getenv("HERING_NO_SHOUP_ROWS") && atoi(getenv("HERING_NO_SHOUP_ROWS")) != 0;
+    // Shoup twiddles for the inverse transform at the production row sizes: 0.217 -> 0.198 ms per MulRelin step.  The forward
+    // kernel does not gain: with the paired table it needs 162 registers (three waves per SIMD) and reads twice the twiddle
+    // bytes -- 0.439 against 0.424 ms, the same verdict as round 1's experiment.
+    if constexpr (INV) {
+        if (A.tws && !no_shoup && (logb == 12 || logb == 13) && !A.scale) {
+            ProfScope ps(K_NTT_ROWS_INV, s);
+            if (logb == 12) hipLaunchKernelGGL((ntt_rows_kernel<12, true, false, true>), grid, dim3(256), 0, s, A);
+            else hipLaunchKernelGGL((ntt_rows_kernel<13, true, false, true>), grid, dim3(512), 0, s, A);
+            return hipGetLastError();
+        }
+    }
 #define HE_ROWS_CASE(B)                                                                           \
     case B:                                                                                       \
         { ProfScope ps(INV ? K_NTT_ROWS_INV : K_NTT_ROWS_FWD, s);                                   \
@@ -1077,6 +1157,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     if (!inverse) {
         A.tw = r.tw_fwd;
         A.twd = r.twd_fwd;
+        A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_fwd);
         A.scale = 0;
         if (a > 0) {
             A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
@@ -1095,6 +1176,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     }
     A.tw = r.tw_inv;
     A.twd = r.twd_inv;
+    A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_inv);
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = flags & NTT_REDUCE_INPUT;
     A.scale = (a == 0);
@@ -1139,8 +1221,11 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = flags;
     dim3 grows(batch, tab.n, 1u << a);
-    if (!inverse) { A.tw = r.tw_fwd; A.twd = r.twd_fwd; A.scale = 0; return launch_rows<false>(b, grows, A, r.host_small, s); }
-    A.tw = r.tw_inv; A.twd = r.twd_inv; A.scale = (a == 0);
+    if (!inverse) {
+        A.tw = r.tw_fwd; A.twd = r.twd_fwd; A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_fwd); A.scale = 0;
+        return launch_rows<false>(b, grows, A, r.host_small, s);
+    }
+    A.tw = r.tw_inv; A.twd = r.twd_inv; A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_inv); A.scale = (a == 0);
     return launch_rows<true>(b, grows, A, r.host_small, s);
 }
 
