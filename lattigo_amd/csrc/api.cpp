@@ -951,12 +951,30 @@ int div_by_last_modulus_ntt(Ring &r, int level, View p0, View p1, int batch, boo
     // b0 = INTTLazy(p0[level])                                                  scaling.go:15 / :110
     LimbTab t_top;
     t_top.n = 1; t_top.in_limb[0] = (uint8_t)level; t_top.out_limb[0] = 0; t_top.mod[0] = (uint8_t)level;
-    if (r.type == 1)  // the lazy representative of INTTConjugateInvariantLazy is observable in the other moduli: exact words
-        HIP_TRY(launch_ci_intt_lazy_ref(r.dev, r.sub[level].mc, level, View{p0.p + (size_t)level * r.N, p0.bstride}, sc.s0, batch, st));
-    else
-        HIP_TRY(ring_ntt(r, t_top, p0, sc.s0, batch, true, NTT_REDUCE_INPUT));
-    ScalarTab s{};
     const uint64_t qL = r.moduli[level], phalf = (qL - 1) >> 1;
+    if (r.type == 0) {
+        // standard ring: the whole step is two transforms.  (1) b0 = CRed(INTT(p0[level]) + pHalf): the scalar rides on the
+        // inverse's last pass.  (2) one forward transform per remaining modulus that reads b0, adds q_i - (pHalf mod q_i)
+        // while loading, and applies MRed(. + 2q_i - p0_i, RescaleConstants) while storing.   scaling.go:110-120 (:15-24 floor)
+        uint64_t s_in[kMaxLimbs], s_top[1] = {phalf};
+        HIP_TRY(launch_ntt(r.dev, t_top, p0, sc.s0, batch, true, NTT_REDUCE_INPUT, st, round ? s_top : nullptr));
+        if (level == 0) return HE_OK;
+        LimbTab tin = ident_tab(level);
+        NttEpilogue ep;
+        for (int i = 0; i < level; i++) {
+            const ModConst &m = r.sub[i].mc;
+            tin.in_limb[i] = 0;
+            s_in[i] = round ? m.q - bred_add(phalf, m.q, m.brc0) : 0;
+            ep.s[i] = r.rescale[level - 1][i];
+        }
+        ep.y = p0; ep.has_w = false; ep.y_reduce = true;
+        ep.has_dst = true; ep.dst = p1;
+        HIP_TRY(launch_ntt(r.dev, tin, sc.s0, sc.s1, batch, false, NTT_REDUCE_INPUT | NTT_LAZY_OUT, st, round ? s_in : nullptr, &ep));
+        return HE_OK;
+    }
+    // conjugate-invariant ring: the lazy representative of INTTConjugateInvariantLazy is observable in the other moduli -- exact words
+    HIP_TRY(launch_ci_intt_lazy_ref(r.dev, r.sub[level].mc, level, View{p0.p + (size_t)level * r.N, p0.bstride}, sc.s0, batch, st));
+    ScalarTab s{};
     if (round) {  // b0 += pHalf mod q_L                                          scaling.go:114
         LimbTab t0; t0.n = 1; t0.in_limb[0] = 0; t0.out_limb[0] = 0; t0.mod[0] = (uint8_t)level;
         s.s[0] = phalf;

@@ -48,9 +48,14 @@ struct RingDev {
 enum NttFlags {
     NTT_REDUCE_INPUT = 1,  // inputs are arbitrary 64-bit words: bring them to [0,2q) first
     NTT_LAZY_OUT = 2,      // forward: leave the output in [0,2q) instead of [0,q)
+    NTT_ADD_SCALAR = 4,    // (set by launch_ntt when io_scalar is given)
 };
+struct NttEpilogue;
+// io_scalar (optional, one word per launch limb): forward -- added to the input words before the transform (lazy, then reduced when
+// NTT_REDUCE_INPUT is set); inverse -- out = CRed(INTT(in) + s).  epi (optional, forward only): the epilogue of
+// launch_ntt_rows on the last pass.  Together they make DivRoundByLastModulusNTT two transforms (ring/scaling.go:101-122).
 hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
-                      hipStream_t s);
+                      hipStream_t s, const uint64_t *io_scalar = nullptr, const NttEpilogue *epi = nullptr);
 // only the contiguous-row pass (the last min(logN,12) forward stages / the first ones of the inverse);
 // the strided column stages are then done by the producer / consumer kernel (launch_modup_fused).
 // For logN <= 12 this is the whole transform (inverse: N^-1 included).
@@ -71,6 +76,10 @@ struct NttEpilogue {
     int zsplit = 0;
     View out2, y2, w2;
     bool has_w2 = false;
+    // launch_ntt only: the epilogue pass writes here instead of `out` (which then only carries the column pass's
+    // intermediate), so that dst may alias y
+    bool has_dst = false;
+    View dst;
 };
 hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
                            hipStream_t s, const NttEpilogue *epi = nullptr);

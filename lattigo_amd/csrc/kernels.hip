@@ -180,6 +180,7 @@ struct NttArgs {
     size_t out2_bs;
     const uint64_t *epi_y2, *epi_w2;
     size_t epi_y2_bs, epi_w2_bs;
+    uint64_t io_s[kMaxLimbs];  // NTT_ADD_SCALAR: per launch limb, added to the input words (forward) / to the canonical output (inverse)
     int epi_y_f64;  // f64 kernel only: y holds doubles
     int epi_y_reduce;  // f64 kernel only: y holds arbitrary 64-bit words (reduced before the conversion to double)
     int nbatch, iters;  // f64 kernel only: a workgroup transforms batch entries blockIdx.x * iters ... (+ iters - 1) of its row
@@ -405,6 +406,11 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, S
         constexpr int sh0 = LOGB - 4;
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = ldnt(&src[(k << sh0) + tau]);
+        if (A.flags & NTT_ADD_SCALAR) {
+            const uint64_t sadd = A.io_s[y];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] += sadd;
+        }
         if (A.flags & NTT_REDUCE_INPUT) {
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = bred_add_lazy(x[k], q, mc.brc0);
@@ -513,6 +519,11 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, S
             }
         }
         constexpr int sh0 = LOGB - 4;
+        if ((A.flags & NTT_ADD_SCALAR) && A.scale) {  // single-pass inverse: canonical outputs
+            const uint64_t sadd = A.io_s[y];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = cred(x[k] + sadd, q);
+        }
 #pragma unroll
         for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = x[k];
     }
@@ -693,6 +704,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint64_t v = ldnt(&src[(k << sh0) + tau]);
+            if (A.flags & NTT_ADD_SCALAR) v += A.io_s[y];
             if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
             x[k] = u52_to_f64(v);
         }
@@ -804,8 +816,14 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = modmul_f64(reduce_f64(x[k], q, qi), ninv, q, qi);
         }
+        if ((A.flags & NTT_ADD_SCALAR) && A.scale) {
+            const uint64_t sadd = A.io_s[y];
 #pragma unroll
-        for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = canon_f64(x[k], q, qi);
+            for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = cred(canon_f64(x[k], q, qi) + sadd, mc.q);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[(k << sh0) + tau] = canon_f64(x[k], q, qi);
+        }
     }
     if (bzi + 1 < b1) __syncthreads();  // LDS is reused by the next entry
     }
@@ -1010,6 +1028,11 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
     uint64_t x[R];
 #pragma unroll
     for (int r = 0; r < R; r++) x[r] = src[(size_t)r * N2];
+    if (!INV && (A.flags & NTT_ADD_SCALAR)) {
+        const uint64_t sadd = A.io_s[y];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] += sadd;
+    }
     if (A.flags & NTT_REDUCE_INPUT) {
 #pragma unroll
         for (int r = 0; r < R; r++) x[r] = bred_add_lazy(x[r], q, mc.brc0);
@@ -1042,6 +1065,11 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
                 }
             }
         }
+    }
+    if (INV && (A.flags & NTT_ADD_SCALAR) && A.scale) {  // canonical outputs of the finished inverse
+        const uint64_t sadd = A.io_s[y];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = cred(x[r] + sadd, q);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) dst[(size_t)r * N2] = x[r];
@@ -1105,6 +1133,7 @@ static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, const uint8
         D.tab.out_limb[D.tab.n] = A.tab.out_limb[i];
         D.tab.mod[D.tab.n] = A.tab.mod[i];
         D.epi_s[D.tab.n] = A.epi_s[i];
+        D.io_s[D.tab.n] = A.io_s[i];
         D.tab.n++;
     }
     hipError_t e = hipSuccess;
@@ -1137,11 +1166,26 @@ static hipError_t launch_cols(int loga, dim3 grid, const NttArgs &A, hipStream_t
     return hipGetLastError();
 }
 
+static void set_epilogue(NttArgs &A, const NttEpilogue &epi, int n) {
+    A.epi_y_f64 = epi.y_small_f64 ? 1 : 0;
+    A.epi_y_reduce = epi.y_reduce ? 1 : 0;
+    A.epi = epi.has_w ? 2 : 1;
+    A.epi_y = epi.y.p; A.epi_y_bs = epi.y.bstride;
+    A.epi_w = epi.w.p; A.epi_w_bs = epi.w.bstride;
+    for (int i = 0; i < n; i++) A.epi_s[i] = epi.s[i];
+    if (epi.zsplit > 0) {
+        A.zsplit = epi.zsplit; A.epi2 = epi.has_w2 ? 2 : 1;
+        A.out2 = epi.out2.p; A.out2_bs = epi.out2.bstride;
+        A.epi_y2 = epi.y2.p; A.epi_y2_bs = epi.y2.bstride;
+        A.epi_w2 = epi.w2.p; A.epi_w2_bs = epi.w2.bstride;
+    }
+}
 hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
-                      hipStream_t s) {
+                      hipStream_t s, const uint64_t *io_scalar, const NttEpilogue *epi) {
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     const int n = r.logN;
     if (n < 4 || n > 17) return hipErrorInvalidValue;
+    if (epi && (inverse || epi->zsplit > 0)) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
     NttArgs A;
     A.mc = r.mc;
@@ -1151,6 +1195,8 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
     A.epi_y_f64 = 0; A.epi_y_reduce = 0;
+    const int sflag = io_scalar ? NTT_ADD_SCALAR : 0;
+    for (int i = 0; i < tab.n; i++) A.io_s[i] = io_scalar ? io_scalar[i] : 0;
     dim3 grows(batch, tab.n, 1u << a);
     dim3 gcols((unsigned)(((r.N >> a) + 255) / 256), tab.n, batch);
     hipError_t e;
@@ -1161,31 +1207,39 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
         A.scale = 0;
         if (a > 0) {
             A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
-            A.flags = flags & NTT_REDUCE_INPUT;
+            A.flags = (flags & NTT_REDUCE_INPUT) | sflag;
             if ((e = launch_cols<false>(a, gcols, A, s)) != hipSuccess) return e;
             // second pass in place on `out`: limbs are now addressed by out_limb
             NttArgs B = A;
             for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
             B.in = out.p; B.in_bs = out.bstride;
             B.flags = flags & NTT_LAZY_OUT;
+            if (epi) {
+                set_epilogue(B, *epi, tab.n);
+                if (epi->has_dst) { B.out = epi->dst.p; B.out_bs = epi->dst.bstride; }
+            }
             return launch_rows<false>(b, grows, B, r.host_small, s);
         }
         A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
-        A.flags = flags;
+        A.flags = flags | sflag;
+        if (epi) {
+            set_epilogue(A, *epi, tab.n);
+            if (epi->has_dst) { A.out = epi->dst.p; A.out_bs = epi->dst.bstride; }
+        }
         return launch_rows<false>(b, grows, A, r.host_small, s);
     }
     A.tw = r.tw_inv;
     A.twd = r.twd_inv;
     A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_inv);
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
-    A.flags = flags & NTT_REDUCE_INPUT;
+    A.flags = (flags & NTT_REDUCE_INPUT) | (a == 0 ? sflag : 0);
     A.scale = (a == 0);
     if ((e = launch_rows<true>(b, grows, A, r.host_small, s)) != hipSuccess) return e;
     if (a > 0) {
         NttArgs B = A;
         for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
         B.in = out.p; B.in_bs = out.bstride;
-        B.flags = 0;
+        B.flags = sflag;
         B.scale = 1;
         return launch_cols<true>(a, gcols, B, s);
     }
@@ -1204,6 +1258,7 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
     A.epi_y_f64 = 0; A.epi_y_reduce = 0;
+    for (int i = 0; i < tab.n; i++) A.io_s[i] = 0;
     if (epi) {
         A.epi_y_f64 = epi->y_small_f64 ? 1 : 0;
         A.epi_y_reduce = epi->y_reduce ? 1 : 0;

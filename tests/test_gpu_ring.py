@@ -203,6 +203,30 @@ def test_rescale_all_variants(ctx, mods):
     assert np.array_equal(pin.get()[:3], sub.DivRoundByLastModulusNTT(x[:4]))
 
 
+@pytest.mark.parametrize("logN", [13, 15, 16])
+def test_rescale_two_pass_rings_batched_in_place(ctx, logN):
+    """DivRound/DivFloorByLastModulusNTT where the transform is column pass + row pass (logN > 12): the step is two fused
+    transforms (scalar prologue, MRed epilogue through a scratch intermediate), on a chain that mixes the three modulus classes,
+    with a batch, out of place and in place (p1 aliasing p0), down the whole chain."""
+    qs, _ = O.GenModuli(logN + 1, [60, 45, 36, 58, 55, 40], [])
+    pr = Pair(ctx, logN, len(qs), qmods=qs)
+    rng = rng_for(1310 + logN)
+    B = 3
+    xs = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(B)])
+    for name in ("DivRoundByLastModulusNTT", "DivFloorByLastModulusNTT"):
+        cur = xs.copy()
+        pin = pr.up(pr.gQ, cur, batch=B)
+        for level in range(len(qs) - 1, 0, -1):
+            sub = O.Ring(pr.N, pr.q[: level + 1])
+            want = np.stack([getattr(sub, name)(cur[b, : level + 1]) for b in range(B)])
+            po = la.Poly(pr.gQ, len(qs), B)
+            getattr(pr.gQ.AtLevel(level), name)(pin, po)
+            assert np.array_equal(po.get()[:, :level], want), (name, level, "out of place")
+            getattr(pr.gQ.AtLevel(level), name)(pin, pin)
+            assert np.array_equal(pin.get()[:, :level], want), (name, level, "in place")
+            cur = np.concatenate([want, cur[:, level:]], axis=1)
+
+
 def test_automorphism(ctx):
     pr = Pair(ctx, 11, 3)
     rng = rng_for(1400)
