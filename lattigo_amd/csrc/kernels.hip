@@ -832,6 +832,17 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 // ------------------------------------------------------------------------------------
 // ntt_mac_f64: forward row NTT of every non-own digit fused with the key-switch inner product (see kernels.h)
 // ------------------------------------------------------------------------------------
+#ifdef HE_MAC_STAMPS
+__device__ uint64_t g_mac_stamps[2048 * 64];
+extern "C" int he_debug_mac_stamps(uint64_t *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mac_stamps), (size_t)n * 8);
+}
+// diagnosis build (tools/build_variant.sh stamps "-DHE_MAC_STAMPS=1", tools/mac_timeline.py): s_memtime at the phase boundaries of 512
+// mid-launch workgroups; the compiler may still sink arithmetic below a stamp, so a round and its exchange read as one phase
+#define MAC_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (w >= 5000 && w < 5512 && (tau & 63) == 0) g_mac_stamps[(((w - 5000) * 4 + (tau >> 6)) * 64) + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MAC_STAMP(i) do {} while (0)
+#endif
 struct NttMacKArgs {
     const uint64_t *dec, *own;
     size_t dec_bs, own_bs;
@@ -889,9 +900,11 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
 #pragma unroll
         for (int k = 0; k < 16; k++) nx[k] = ldnt(&src[k * T + tau]);
     }
+    MAC_STAMP(0);
     for (int d = 0; d < A.m.beta; d++) {
         const bool is_own = own_digit(d);
         double x[16];
+        MAC_STAMP(1 + d * 12 + 0);
         if (is_own && A.m.own_reduce) {  // caller-supplied words (any uint64, as MulCoeffsMontgomeryLazy accepts): bring them below 2^52
 #pragma unroll
             for (int k = 0; k < 16; k++) nx[k] = bred_add_lazy(nx[k], mc.q, mc.brc0);
@@ -908,7 +921,9 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
             for (int rho = 0; rho < NR4; rho++) {
                 const int s0 = 4 * rho, sh = LOGB - s0 - 4;
                 if (rho > 0) rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, s0, sh, false);
+                MAC_STAMP(1 + d * 12 + 1 + rho * 3);
                 rows_round16_f64<false>(x, t16, q, qi);
+                MAC_STAMP(1 + d * 12 + 2 + rho * 3);
                 // the next round's twiddles (round 0 of the next digit after the last one) are in flight across the exchange
                 const int sn = rho + 1 < NR4 ? s0 + 4 : 0;
                 rows_tw16_f64(t16, tw, rowtw, sn, tau >> (LOGB - sn - 4));
@@ -916,6 +931,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
                 // the middle exchange of a 4096-row is local to 16 lanes (rows_sync); the last one feeds the cross-wave k T + tau
                 // read below.  (The wave-local nat_e order of the plain row kernels costs this kernel 29 spilled registers.)
                 if (rho + 1 < NR4) rows_sync(sh); else __syncthreads();
+                MAC_STAMP(1 + d * 12 + 3 + rho * 3);
             }
             if constexpr (GREM > 0) {
                 constexpr int s0 = 4 * NR4;
@@ -934,7 +950,9 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
             acc0[k] += modmul_f64(v, k0[k * T + tau], q, qi);
             acc1[k] += modmul_f64(v, k1[k * T + tau], q, qi);
         }
+        MAC_STAMP(1 + d * 12 + 10);
         __syncthreads();  // LDS is reused by the next digit
+        MAC_STAMP(1 + d * 12 + 11);
     }
     const int ol = A.m.out_limb[l];
     const bool isP = A.m.out_view[l] != 0;
@@ -954,7 +972,9 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
             o1[k * T + tau] = canon_f64(acc1[k], q, qi);
         }
     }
+    MAC_STAMP(60);
 }
+
 
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
                               View out0P, View out1Q, View out1P, int batch, hipStream_t s) {
@@ -967,6 +987,15 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
     A.mc = r.mc; A.twd = r.twd_fwd; A.N = r.N; A.a = aa; A.m = a;
     dim3 grid(batch, a.nlimbs, 1u << aa);
+#ifdef HE_MAC_STAMPS
+    {   // diagnosis build only: HERING_MAC_ABL makes the key (1, 8), input (2) and output (4) streams cache-resident
+        static const int abl = getenv("HERING_MAC_ABL") ? atoi(getenv("HERING_MAC_ABL")) : 0;
+        if (abl & 1) { A.m.key_dstride = 0; A.m.key_kstride = 0; }
+        if (abl & 2) { A.dec_bs = 0; A.own_bs = 0; A.m.dec_dstride = 0; }
+        if (abl & 4) { A.oQ0_bs = A.oP0_bs = A.oQ1_bs = A.oP1_bs = 0; }
+        if (abl & 8) { for (int i = 0; i < a.nlimbs; i++) A.m.key_limb[i] = 0; }
+    }
+#endif
     ProfScope ps(K_NTT_MAC_F64, s);
 #define HE_MAC_CASE(B)                                                                                      \
     case B:                                                                                                 \

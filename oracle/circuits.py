@@ -522,10 +522,13 @@ def ExtendBasisSmallNormAndCenter(ringQ, ringP, polyInQ, levelP):
 # bgv.Evaluator at the rlwe.Ciphertext level (numpy arrays), the backend the polynomial evaluator is checked against
 # ---------------------------------------------------------------------------------------------------------------
 class Ct:
-    """Value: list of [limbs][N] arrays (limbs = level + 1), Scale in Z_t"""
+    """Value: list of [limbs][N] arrays (limbs = level + 1); Scale in Z_t (BGV) or an exact Fraction (CKKS)"""
 
     def __init__(self, value, scale=1):
-        self.Value, self.Scale = [np.asarray(v, dtype=np.uint64) for v in value], int(scale)
+        from fractions import Fraction
+        # BGV scales are residues mod t (ints); CKKS scales are exact rationals and must survive CopyNew unrounded
+        self.Value = [np.asarray(v, dtype=np.uint64) for v in value]
+        self.Scale = scale if isinstance(scale, Fraction) else int(scale)
 
     @property
     def level(self):

@@ -126,10 +126,11 @@ class ToyBootstrap:
 
     def oracle_bootstrapper(self):
         from lattigo_amd.drivers import bootstrapping as BS
-        from lattigo_amd.drivers import mod1 as M1
+        from oracle import polyeval_ref as PR
         ce = OC.CKKSCtEvaluator(self.oev, self.rlk)
         be = OC.OracleBootstrapBackend(ce, OC.LinTransEvaluator(self.oev, self.gks), OC.InnerSumEvaluator(self.oev, self.gks))
-        return BS.Bootstrapper(be, M1.Mod1Evaluator(ce, self.mod1_params), self.cts, self.cts_scale, self.stc, self.stc_scale)
+        # EvalMod on the oracle side is the oracle's own restatement (polynomial evaluator + mod1), not the product driver
+        return BS.Bootstrapper(be, PR.Mod1Ref(ce, self.mod1_params), self.cts, self.cts_scale, self.stc, self.stc_scale)
 
     def decode(self, res):
         """slots of the refreshed ciphertext, undoing the (Delta / 2^55) gain of the circuit"""

@@ -387,10 +387,12 @@ def test_ringqp_mirror(ctx):
 
 @pytest.mark.parametrize("deg", [1, 2, 3, 7, 8, 17, 33])
 def test_bgv_polynomial_evaluation(ctx, deg):
-    """circuits/bgv/polynomial Evaluator.Evaluate with the device-resident bgv.Evaluator mirror as the backend vs the oracle
-    backend (whose composition test_oracle_circuits.py pins by decryption): same polynomials, scale and level, batch 2."""
+    """circuits/bgv/polynomial Evaluator.Evaluate: the product driver on the device-resident bgv.Evaluator mirror vs the
+    oracle's own restatement of the evaluator (oracle/polyeval_ref.py, written from the Go sources) on the oracle backend:
+    the same primitive sequence with the same (level, scale, degree) after every call, and the same words; batch 2."""
     from lattigo_amd.drivers import polyeval as PE
     from lattigo_amd.drivers import schemes as S
+    from oracle import polyeval_ref as PR
     rg = Rig(ctx, 10, [55, 45, 45, 45, 45, 45, 45, 45], [55, 55], 5100 + deg)
     rg.keys([1])
     t, B, top = 65537, 2, 7
@@ -400,10 +402,13 @@ def test_bgv_polynomial_evaluation(ctx, deg):
     coeffs = [int(x) for x in rg.rng.integers(0, t, size=deg + 1)]
     coeffs[-1] = coeffs[-1] or 1
     gct = S.Ciphertext(rg.up(ct), top, 3)
-    res = PE.PolynomialEvaluator(gbe).Evaluate(gct, coeffs, 11)
+    gtr = PR.Trace(gbe)
+    res = PE.PolynomialEvaluator(gtr).Evaluate(gct, coeffs, 11)
     got = np.stack([p.download() for p in res.Value], axis=1)  # [B][2][limbs][N]
     for b in range(B):
-        want = PE.PolynomialEvaluator(obe).Evaluate(OC.Ct(list(ct[b]), 3), coeffs, 11)
+        otr = PR.Trace(obe)
+        want = PR.evaluate_polynomial(otr, OC.Ct(list(ct[b]), 3), coeffs, 11)
+        assert gtr.log == otr.log
         assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (11, top - deg.bit_length(), 1)
         assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (deg, b)
     assert np.array_equal(gct.Value[0].download(), ct[:, 0])  # the input ciphertext is left untouched
@@ -412,10 +417,12 @@ def test_bgv_polynomial_evaluation(ctx, deg):
 @pytest.mark.parametrize("deg,basis", [(1, "Monomial"), (7, "Monomial"), (12, "Monomial"), (5, "Chebyshev"), (31, "Chebyshev")])
 def test_ckks_polynomial_evaluation(ctx, deg, basis):
     """circuits/ckks/polynomial Evaluator.Evaluate (complex coefficients, monomial / Chebyshev power bases, exact rational
-    scale planning) with the device-resident ckks.Evaluator mirror vs the oracle backend: bit-exact, batch 2."""
+    scale planning): the product driver on the device-resident ckks.Evaluator mirror vs oracle/polyeval_ref.py on the oracle
+    backend: the same primitive sequence and level / scale schedule, bit-exact words, batch 2."""
     from fractions import Fraction
     from lattigo_amd.drivers import polyeval as PE
     from lattigo_amd.drivers import schemes as S
+    from oracle import polyeval_ref as PR
     rg = Rig(ctx, 10, [55] + [45] * 7, [55, 55], 5200 + deg)
     rg.keys([1])
     B, top = 2, 7
@@ -426,10 +433,13 @@ def test_ckks_polynomial_evaluation(ctx, deg, basis):
     coeffs = [complex(a, b if basis == "Monomial" else 0.0) for a, b in zip(rr.uniform(-1, 1, size=deg + 1), rr.uniform(-1, 1, size=deg + 1))]
     scale = Fraction(1 << 45)
     pol = lambda: PE.Polynomial([PE._cpair(c) for c in coeffs], Basis=basis)
-    res = PE.PolynomialEvaluator(gce).Evaluate(S.Ciphertext(rg.up(ct), top, scale), pol(), scale)
+    gtr = PR.Trace(gce)
+    res = PE.PolynomialEvaluator(gtr).Evaluate(S.Ciphertext(rg.up(ct), top, scale), pol(), scale)
     got = np.stack([p.download() for p in res.Value], axis=1)
     for b in range(B):
-        want = PE.PolynomialEvaluator(oce).Evaluate(OC.Ct(list(ct[b]), scale), pol(), scale)
+        otr = PR.Trace(oce)
+        want = PR.evaluate_polynomial(otr, OC.Ct(list(ct[b]), scale), coeffs, scale, basis)
+        assert gtr.log == otr.log
         assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (scale, top - deg.bit_length(), 1)
         assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (deg, basis, b)
 
@@ -437,10 +447,13 @@ def test_ckks_polynomial_evaluation(ctx, deg, basis):
 @pytest.mark.parametrize("kind,K,deg,r", [("cos", 8, 30, 2), ("cos", 12, 40, 3), ("sin", 3, 31, 0), ("hanki", 16, 30, 3), ("asin", 8, 30, 1)])
 def test_mod1(ctx, kind, K, deg, r):
     """circuits/ckks/mod1 Evaluator.EvaluateNew (EvalMod: even / odd Chebyshev polynomial incl. a degree-0 baby step,
-    double-angle steps) with the device-resident ckks.Evaluator mirror vs the oracle backend: bit-exact, batch 2."""
+    double-angle steps): the product driver on the device-resident ckks.Evaluator mirror vs the oracle's restatement
+    (oracle/polyeval_ref.py evaluate_mod1, fed the same approximation coefficients) on the oracle backend: the same primitive
+    sequence and level / scale schedule, bit-exact words, batch 2."""
     from fractions import Fraction
     from lattigo_amd.drivers import mod1 as M1
     from lattigo_amd.drivers import schemes as S
+    from oracle import polyeval_ref as PR
     rg = Rig(ctx, 10, [55] + [45] * 10, [55, 55], 5300 + K)
     rg.keys([1])
     B, top = 2, 10
@@ -451,10 +464,16 @@ def test_mod1(ctx, kind, K, deg, r):
                            Mod1InvDegree=7 if kind == "asin" else 0)
     ct = rg.ct(top, B)
     scale = Fraction(1 << 45)
-    res = M1.Mod1Evaluator(gce, pm).EvaluateNew(S.Ciphertext(rg.up(ct), top, scale))
+    gtr = PR.Trace(gce)
+    res = M1.Mod1Evaluator(gtr, pm).EvaluateNew(S.Ciphertext(rg.up(ct), top, scale))
     got = np.stack([p.download() for p in res.Value], axis=1)
     for b in range(B):
-        want = M1.Mod1Evaluator(oce, pm).EvaluateNew(OC.Ct(list(ct[b]), scale))
+        otr = PR.Trace(oce)
+        want = PR.evaluate_mod1(otr, OC.Ct(list(ct[b]), scale), level_q=pm.LevelQ, log_scale=pm.LogDefaultScale,
+                                cosine=typ != M1.SinContinuous, K=pm.K, double_angle=pm.DoubleAngle, sqrt2pi=pm.Sqrt2Pi,
+                                poly_coeffs=pm.Mod1Poly.Coeffs, poly_even=pm.Mod1Poly.IsEven, poly_odd=pm.Mod1Poly.IsOdd,
+                                inv_coeffs=None if pm.Mod1InvPoly is None else pm.Mod1InvPoly.Coeffs)
+        assert gtr.log == otr.log
         assert (res.Scale, res.level, res.Degree()) == (want.Scale, want.level, want.Degree()) == (scale, top - pm.Depth(), 1)
         assert np.array_equal(got[b][:, : res.level + 1], np.stack(want.Value)), (kind, b)
 

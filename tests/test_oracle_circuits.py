@@ -438,3 +438,96 @@ def test_scale_down_brings_the_message_below_q0():
     assert abs(float(Fraction(q[0]) / res.Scale) / 256.0 - 1) < 1e-6 and abs(float(err_scale) - 1) < 1e-6
     got = ckks_decrypt(O.Ring(N, q[:1]), np.stack(res.Value), sk, res.Scale)
     assert np.max(np.abs(got - z)) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle/polyeval_ref.py (the independent restatement of the polynomial evaluator) against lattigo_amd/drivers/polyeval.py:
+# same backend, same inputs -> the same sequence of primitive calls with the same (level, scale, degree) after each, and the
+# same words.  The restatement also decrypts to p(m) on its own.
+# ---------------------------------------------------------------------------------------------------------------
+def _poly_rig(seed, logq, t=None):
+    q, p = O.GenModuli(10, logq, [55, 55])
+    rng = rng_for(seed)
+    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
+    ev = O.Evaluator(ringQ, ringP)
+    sk = SecretKey(rng, ringQ, ringP)
+    rlk = gen_evaluation_key(rng, ringQ, ringP, ringQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q), sk)
+    be = OC.BGVCtEvaluator(ev, t, rlk) if t else OC.CKKSCtEvaluator(ev, rlk)
+    return rng, q, ringQ, sk, be
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3, 6, 7, 8, 15, 17, 33, 63])
+def test_polyeval_restatement_matches_the_driver_bgv(deg):
+    from lattigo_amd.drivers import polyeval as PE
+    from oracle import polyeval_ref as PR
+    from tests.rlwe_fixtures import bgv_decrypt, bgv_encrypt
+    t = 65537
+    rng, q, ringQ, sk, be = _poly_rig(6100 + deg, [55] + [45] * 8, t)
+    m = rng.integers(0, t, size=N)
+    ct = OC.Ct(list(bgv_encrypt(rng, ringQ, sk, m, t, 3)), 3)
+    coeffs = [int(x) for x in rng.integers(0, t, size=deg + 1)]
+    coeffs[-1] = coeffs[-1] or 1
+    ta, tb = PR.Trace(be), PR.Trace(be)
+    a = PE.PolynomialEvaluator(ta).Evaluate(ct, coeffs, 11)
+    b = PR.evaluate_polynomial(tb, ct, coeffs, 11)
+    assert ta.log == tb.log and len(ta.log) > deg
+    assert (a.Scale, a.level) == (b.Scale, b.level) and np.array_equal(np.stack(a.Value), np.stack(b.Value))
+    got = bgv_decrypt(O.Ring(N, q[: b.level + 1]), np.stack(b.Value), sk, t, b.Scale)
+    assert np.array_equal(got, _ring_poly_eval(coeffs, m, t))
+
+
+@pytest.mark.parametrize("deg,basis,parity,lazy", [(1, "Monomial", "both", False), (7, "Monomial", "both", False),
+                                                   (12, "Monomial", "both", True), (31, "Monomial", "odd", False),
+                                                   (5, "Chebyshev", "both", False), (16, "Chebyshev", "both", False),
+                                                   (31, "Chebyshev", "both", True), (30, "Chebyshev", "even", False),
+                                                   (31, "Chebyshev", "odd", False), (63, "Chebyshev", "odd", False)])
+def test_polyeval_restatement_matches_the_driver_ckks(deg, basis, parity, lazy):
+    from fractions import Fraction
+    from lattigo_amd.drivers import polyeval as PE
+    from oracle import polyeval_ref as PR
+    from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
+    rng, q, ringQ, sk, ce = _poly_rig(6200 + deg, [55] + [45] * 8)
+    scale = Fraction(1 << 45)
+    z = rng.uniform(-0.8, 0.8, size=N // 2).astype(complex)
+    even, odd = parity in ("both", "even"), parity in ("both", "odd")
+    coeffs = [float(x) for x in rng.uniform(-1, 1, size=deg + 1)]
+    masked = [c if (parity == "both" or (k % 2 == 0) == (parity == "even")) else None for k, c in enumerate(coeffs)]
+    dense = [0.0 if c is None else c for c in masked]
+    want = np.polynomial.chebyshev.chebval(z.real, dense) if basis == "Chebyshev" else np.polyval(dense[::-1], z)
+    ct = OC.Ct(list(ckks_encrypt(rng, ringQ, sk, z, scale)), scale)
+    pol = PE.Polynomial([None if c is None else PE._cpair(c) for c in masked], Basis=basis, Lazy=lazy)
+    pol.IsEven, pol.IsOdd = even, odd
+    ta, tb = PR.Trace(ce), PR.Trace(ce)
+    a = PE.PolynomialEvaluator(ta).Evaluate(ct, pol, scale)
+    b = PR.evaluate_polynomial(tb, ct, masked, scale, basis, even, odd, lazy)
+    assert ta.log == tb.log and len(ta.log) > deg // 2
+    assert (a.Scale, a.level) == (b.Scale, b.level) == (scale, len(q) - 1 - deg.bit_length())
+    assert np.array_equal(np.stack(a.Value), np.stack(b.Value))
+    if lazy:
+        # lazy relinearisation leaves a degree-2 X^3 beside degree-1 powers, and the reference's scalar MulThenAdd resizes its
+        # accumulator to the degree of each operand in turn (schemes/ckks/evaluator.go:936), dropping the degree-2 part again:
+        # both implementations reproduce that word for word; the result is not p(m), in the reference either
+        return
+    got = ckks_decrypt(O.Ring(N, q[: b.level + 1]), np.stack(b.Value), sk, b.Scale)
+    assert np.max(np.abs(got - want)) < 1e-5, np.max(np.abs(got - want))
+
+
+@pytest.mark.parametrize("kind,K,deg,r,inv", [("cos", 8, 30, 2, 0), ("sin", 3, 31, 0, 0), ("hanki", 16, 30, 3, 0), ("cos", 8, 30, 1, 7)])
+def test_mod1_restatement_matches_the_driver(kind, K, deg, r, inv):
+    """oracle/polyeval_ref.py evaluate_mod1 against lattigo_amd/drivers/mod1.py on the same backend: the same primitive
+    sequence with the same (level, scale, degree) after each call, the same words"""
+    from fractions import Fraction
+    from lattigo_amd.drivers import mod1 as M1
+    from oracle import polyeval_ref as PR
+    rng, q, ringQ, sk, ce = _poly_rig(6300 + K, [55] + [45] * 10)
+    typ = {"cos": M1.CosContinuous, "sin": M1.SinContinuous, "hanki": M1.CosDiscrete}[kind]
+    pm = M1.Mod1Parameters(int(q[0]), LevelQ=len(q) - 1, LogScale=45, Mod1Type=typ, K=K, Mod1Degree=deg, DoubleAngle=r,
+                           LogMessageRatio=6, Mod1InvDegree=inv)
+    scale = Fraction(1 << 45)
+    ct = OC.Ct([uniform_poly(rng, q, N) for _ in range(2)], scale)
+    ta, tb = PR.Trace(ce), PR.Trace(ce)
+    a = M1.Mod1Evaluator(ta, pm).EvaluateNew(ct)
+    b = PR.Mod1Ref(tb, pm).EvaluateNew(ct)
+    assert ta.log == tb.log and len(ta.log) > 20
+    assert (a.Scale, a.level) == (b.Scale, b.level) == (scale, len(q) - 1 - pm.Depth())
+    assert np.array_equal(np.stack(a.Value), np.stack(b.Value))

@@ -1,0 +1,35 @@
+"""Phase timeline of ntt_mac_f64 from s_memtime stamps (debug build: bash tools/build_variant.sh stamps "-DHE_MAC_STAMPS=1").
+usage (GPU box): HERING_LIB=lattigo_amd/variants/libhering_stamps.so python tools/mac_timeline.py"""
+import argparse, ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+import lattigo_amd as la
+from lattigo_amd import _lib
+from lattigo_amd.dist import ControlPlane
+ctx = la.Context(0)
+args = argparse.Namespace(replicate_keys="none")
+W = bench.setup_c3(la, ctx, 0, 128, ControlPlane(), args)
+for _ in range(3):
+    W["step"]()
+ctx.sync()
+lib = _lib.load()
+n = 2048 * 64
+buf = (C.c_uint64 * n)()
+rc = lib.he_debug_mac_stamps(buf, n)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 64).astype(np.int64)
+names = ["start", "r0pre", "r0post", "x0", "r1pre", "r1post", "x1", "r2pre", "r2post", "x2(bar)", "mac", "endbar"]
+print("rc", rc, "nonzero rows", int((a[:, 0] > 0).sum()))
+a = a[a[:, 0] > 0]
+for dg in range(4):
+    st = a[:, 1 + 12 * dg: 1 + 12 * dg + 12]
+    full = st[(st > 0).all(axis=1)]
+    own = st[(st[:, 1] == 0) & (st[:, 0] > 0)]
+    if len(full):
+        seg = np.diff(full, axis=1)
+        print("digit", dg, "waves", len(full), {names[i + 1]: int(np.median(seg[:, i])) for i in range(11)}, "sum", int(np.median(seg.sum(axis=1))))
+    if len(own):
+        print("digit", dg, "own waves", len(own), "start->mac", int(np.median(own[:, 10] - own[:, 0])), "mac->endbar", int(np.median(own[:, 11] - own[:, 10])))
+tot = a[:, 60] - a[:, 0]
+print("kernel start -> digit 0:", int(np.median(a[:, 1] - a[:, 0])), "last endbar -> end:", int(np.median(a[:, 60] - a[:, 48])))
+print("wave lifetime median", int(np.median(tot)), "p10", int(np.percentile(tot, 10)), "p90", int(np.percentile(tot, 90)))
