@@ -122,6 +122,39 @@ class Mod1Parameters:
         return self.Mod1Poly.Degree().bit_length() + self.DoubleAngle + inv
 
 
+def _bigfloat_round(x: Fraction, prec: int = 128) -> Fraction:
+    """x rounded to `prec` significant bits, ties to even: what a big.Float of that precision keeps of an exact product
+    (rlwe.Scale.Mul, core/rlwe/scale.go:77-93, ScalePrecision = 128)"""
+    if x == 0:
+        return Fraction(0)
+    e = x.numerator.bit_length() - x.denominator.bit_length()  # 2^(e-1) < x < 2^(e+1)
+    sh = prec - e
+    n = x * Fraction(2) ** sh
+    while n >= 1 << prec:
+        sh -= 1
+        n = x * Fraction(2) ** sh
+    while n < 1 << (prec - 1):
+        sh += 1
+        n = x * Fraction(2) ** sh
+    m, rem = divmod(n.numerator, n.denominator)
+    twice = 2 * rem
+    if twice > n.denominator or (twice == n.denominator and m & 1):
+        m += 1
+    return Fraction(m) / Fraction(2) ** sh
+
+
+def _bigfloat_sqrt(x: Fraction, prec: int = 128) -> Fraction:
+    """sqrt(x) correctly rounded to `prec` bits (big.Float.Sqrt on the 128-bit scale, mod1_evaluator.go:57; Go's Newton iteration
+    carries 32 guard bits, so it returns this value except with probability ~2^-32)"""
+    e = x.numerator.bit_length() - x.denominator.bit_length()
+    k = prec - e // 2 + 1  # sqrt(x) 2^k has prec + 1 or prec + 2 bits
+    t = x * Fraction(4) ** k
+    r = math.isqrt(t.numerator // t.denominator)  # floor(sqrt(x) 2^k)
+    exact = Fraction(r * r) == t
+    # r carries at least one bit below the result's last place: sticky-extend and round once
+    return _bigfloat_round(Fraction(2 * r + (0 if exact else 1), 2) / Fraction(2) ** k, prec)
+
+
 class Mod1Evaluator:
     """mod1.Evaluator (circuits/ckks/mod1/mod1_evaluator.go:17-144)"""
 
@@ -142,8 +175,8 @@ class Mod1Evaluator:
         targetScale = Fraction(res.Scale)
         depth = evm.Mod1Poly.Depth()
         for i in range(evm.DoubleAngle):  # :54-58
-            targetScale = targetScale * Qi[res.Level() - depth - evm.DoubleAngle + i + 1]
-            targetScale = Fraction(math.sqrt(float(targetScale)))
+            targetScale = _bigfloat_round(targetScale * Qi[res.Level() - depth - evm.DoubleAngle + i + 1])
+            targetScale = _bigfloat_sqrt(targetScale)
         if evm.Mod1Type in (CosContinuous, CosDiscrete):  # change of variable x -> x - 1/4 (:61-68)
             Kp = evm.K / evm.IntervalShrinkFactor()
             offset = Fraction(-0.5) / (Fraction(2 * Kp) * Fraction(evm.IntervalShrinkFactor()))

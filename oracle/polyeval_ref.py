@@ -356,6 +356,41 @@ def evaluate_polynomial(ev, ct, coeffs, target_scale, basis="Monomial", even=Tru
 # ------------------------------------------------------------------------------------------------------------------
 # mod1 (circuits/ckks/mod1/mod1_evaluator.go:28-144) around the polynomial; the approximation's coefficients are inputs
 # ------------------------------------------------------------------------------------------------------------------
+def _keep_bits(x, bits=128):
+    """nearest value with a `bits`-bit significand, ties to even (a big.Float result of that precision)"""
+    x = Fraction(x)
+    if x == 0:
+        return x
+    lo, hi = -4096, 4096  # find s with 2^(bits-1) <= x 2^s < 2^bits by bisection on the exponent
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if x * Fraction(2) ** mid >= 1 << (bits - 1):
+            hi = mid
+        else:
+            lo = mid + 1
+    scaled = x * Fraction(2) ** lo
+    down = scaled.numerator // scaled.denominator
+    frac = scaled - down
+    up = frac > Fraction(1, 2) or (frac == Fraction(1, 2) and down % 2 == 1)
+    return Fraction(down + (1 if up else 0)) / Fraction(2) ** lo
+
+
+def _sqrt_bits(x, bits=128):
+    """square root to `bits` bits, correctly rounded: bracket it between consecutive (bits+8)-bit integers, then keep `bits`"""
+    import math
+    x = Fraction(x)
+    shift = 0
+    while x * Fraction(4) ** shift < 1 << (2 * (bits + 8)):
+        shift += 1
+    while shift > 0 and x * Fraction(4) ** (shift - 1) >= 1 << (2 * (bits + 8)):
+        shift -= 1
+    big = x * Fraction(4) ** shift
+    root = math.isqrt(big.numerator // big.denominator)
+    # root <= sqrt(big) < root + 1; the true root is irrational or equal to `root`: a half-unit nudge cannot cross a rounding boundary
+    est = Fraction(root) if Fraction(root * root) == big else Fraction(2 * root + 1, 2)
+    return _keep_bits(est / Fraction(2) ** shift, bits)
+
+
 def evaluate_mod1(ev, ct, *, level_q, log_scale, cosine: bool, K: float, double_angle: int, sqrt2pi, poly_coeffs, poly_even,
                   poly_odd, inv_coeffs=None):
     import math
@@ -372,8 +407,8 @@ def evaluate_mod1(ev, ct, *, level_q, log_scale, cosine: bool, K: float, double_
     d = len(poly_coeffs) - 1
     poly_depth = (d - 1).bit_length() if d > 1 else 0
     goal = Fraction(x.Scale)
-    for i in range(double_angle):  # each squaring doubles the scale exponent: undo it ahead of time, as floats, like the reference
-        goal = Fraction(math.sqrt(float(goal * Q[x.Level() - poly_depth - double_angle + i + 1])))
+    for i in range(double_angle):  # each squaring doubles the scale exponent: undo it ahead of time, in 128-bit floats like the reference
+        goal = _sqrt_bits(_keep_bits(goal * Q[x.Level() - poly_depth - double_angle + i + 1]))
     if cosine:  # cos(2 pi (y - 1/4)) = sin(2 pi y)
         shrink = 2.0 ** double_angle
         shift = Fraction(-0.5) / (Fraction(2 * (K / shrink)) * Fraction(shrink))

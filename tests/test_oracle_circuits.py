@@ -531,3 +531,28 @@ def test_mod1_restatement_matches_the_driver(kind, K, deg, r, inv):
     assert ta.log == tb.log and len(ta.log) > 20
     assert (a.Scale, a.level) == (b.Scale, b.level) == (scale, len(q) - 1 - pm.Depth())
     assert np.array_equal(np.stack(a.Value), np.stack(b.Value))
+
+
+def test_scale_rounding_helpers_agree_and_are_correctly_rounded():
+    """The 128-bit float steps of mod1's target scale (rlwe.Scale.Mul, big.Float.Sqrt; mod1_evaluator.go:54-58): the product
+    driver's helpers and the oracle's (written separately) agree on random rationals, keep 128 significant bits, are within
+    half a unit in the last place, and match a 120-digit decimal square root."""
+    import decimal
+    import random
+    from fractions import Fraction
+    from lattigo_amd.drivers.mod1 import _bigfloat_round, _bigfloat_sqrt
+    from oracle.polyeval_ref import _keep_bits, _sqrt_bits
+    rnd = random.Random(7)
+    decimal.getcontext().prec = 120
+    for _ in range(300):
+        x = Fraction(rnd.getrandbits(rnd.randint(1, 300)) + 1, rnd.getrandbits(rnd.randint(1, 200)) + 1)
+        a, s = _bigfloat_round(x), _bigfloat_sqrt(x)
+        assert a == _keep_bits(x) and s == _sqrt_bits(x)
+        for v in (a, s):
+            n = v.numerator
+            assert n.bit_length() - ((n & -n).bit_length() - 1) <= 128 and v.denominator & (v.denominator - 1) == 0
+        assert abs(a / x - 1) <= Fraction(1, 1 << 128)
+        d = (decimal.Decimal(x.numerator) / decimal.Decimal(x.denominator)).sqrt()
+        assert abs(decimal.Decimal(s.numerator) / decimal.Decimal(s.denominator) / d - 1) < decimal.Decimal(2) ** -127
+    for v in (Fraction(4), Fraction(9, 4), Fraction(1 << 200), Fraction(1, 1 << 78), Fraction(((1 << 128) - 1) ** 2)):
+        assert _bigfloat_sqrt(v) ** 2 == v == _sqrt_bits(v) ** 2  # exact roots stay exact
