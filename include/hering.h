@@ -94,6 +94,9 @@ int he_poly_copy(he_handle dst, he_handle src, int level);      /* Poly.CopyLvl 
  * independent ciphertexts into one batch, e.g. the real and imaginary halves before EvalMod) */
 int he_poly_copy_batch(he_handle dst, int dst_b0, he_handle src, int src_b0, int nb, int level);
 int he_poly_zero(he_handle poly);
+/* the polynomial's device storage ([batch][n_limbs][N] words) for transports that move device memory themselves (an RCCL
+ * all-reduce of partial key-switch accumulators); drains the context's stream first */
+int he_poly_device_buffer(he_handle poly, void **ptr, size_t *bytes);
 
 /* ---- NTT: Ring.NTT / NTTLazy / INTT / INTTLazy (ring/ntt.go:127-152) ------------- */
 int he_ntt(he_handle ring, int level, he_handle p1, he_handle p2);
@@ -270,6 +273,13 @@ int he_gadget_product_lazy(he_handle eval, int levelQ, he_handle cx, he_handle e
 /* GadgetProductHoistedLazy (:379) */
 int he_gadget_product_hoisted_lazy(he_handle eval, int levelQ, he_handle decomp, he_handle evk,
                                    he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P);
+/* The same inner product over the digits [digit_begin, digit_end) only: sum_d decomp_d (.) evk_d, canonical.  The sum
+ * over a partition of the digits, reduced once more, equals he_gadget_product_hoisted_lazy's output -- the primitive for
+ * splitting ONE key switch over several GPUs by digit (each rank holds its digits of the key; the partial accumulators
+ * are summed across ranks: lattigo_amd/dist.py SplitGadgetProductHoisted).  An empty range zeroes
+ * the outputs.  Same restrictions as he_gadget_product_hoisted_lazy (:379-456). */
+int he_gadget_product_hoisted_lazy_digits(he_handle eval, int levelQ, he_handle decomp, he_handle evk, int digit_begin, int digit_end,
+                                          he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P);
 /* Evaluator.ModDown (:39), NTT in / NTT out; levelP = -1 (no special primes, c0P = c1P = 0): the copy of :76-81 */
 int he_moddown(he_handle eval, int levelQ, int levelP, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P,
                he_handle out0, he_handle out1);

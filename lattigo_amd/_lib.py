@@ -104,6 +104,8 @@ def _declare(L):
         "he_decompose_ntt": [H, i, i, i, H, i, H],
         "he_gadget_product_lazy": [H, i, H, H, H, H, H, H],
         "he_gadget_product_hoisted_lazy": [H, i, H, H, H, H, H, H],
+        "he_gadget_product_hoisted_lazy_digits": [H, i, H, H, i, i, H, H, H, H],
+        "he_poly_device_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(sz)],
         "he_moddown": [H, i, i, H, H, H, H, H, H],
         "he_gadget_product": [H, i, H, H, H, H], "he_gadget_product_hoisted": [H, i, H, H, H, H],
         "he_relinearize": [H, i, H, H, H, H, H, H],

@@ -691,6 +691,15 @@ int he_poly_copy_batch(he_handle hdst, int dst_b0, he_handle hsrc, int src_b0, i
                              (size_t)(level + 1) * d->N * 8, nb, hipMemcpyDeviceToDevice, d->ctx->stream));
     return HE_OK;
 }
+int he_poly_device_buffer(he_handle h, void **ptr, size_t *bytes) {
+    GET(p, Poly, h, T_POLY);
+    if (!ptr || !bytes) return fail(HE_EINVAL, "he_poly_device_buffer: null output");
+    Scope sc(p->ctx.get());
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));  // the caller reads / writes it on a stream of its own
+    *ptr = p->d;
+    *bytes = (size_t)p->batch * p->nlimbs * p->N * 8;
+    return HE_OK;
+}
 int he_poly_zero(he_handle h) {
     GET(p, Poly, h, T_POLY);
     Scope sc(p->ctx.get());
@@ -1543,12 +1552,20 @@ int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2n
 // inner product of a decomposition with a key (gadgetProductMultiplePLazyHoisted :401-453)
 // limb_filter: 0 = every limb, 1 = only limbs NOT of class 2 (the fused f64 NTT+MAC kernel takes the others)
 int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View o0Q,
-             View o0P, View o1Q, View o1P, int batch, const View *own = nullptr, int own_alpha = 0, int limb_filter = 0) {
+             View o0P, View o1Q, View o1P, int batch, const View *own = nullptr, int own_alpha = 0, int limb_filter = 0,
+             int digit_begin = 0, int digit_end = -1) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     KsArgs a{};
     a.beta = k.pw2 ? k.prefix[levelQ + 1] : base_rns_size(levelQ, levelP);
     if (a.beta > k.beta) return fail(HE_EINVAL, "gadget product: key has %d digits, %d needed", k.beta, a.beta);
+    const uint64_t *keyp = k.d;
+    if (digit_end >= 0) {  // a sub-range of the digits (he_gadget_product_hoisted_lazy_digits): shift both operands
+        if (own || digit_begin < 0 || digit_end > a.beta || digit_begin >= digit_end) return fail(HE_EINVAL, "gadget product: bad digit range");
+        dec += (size_t)digit_begin * dec_ds;
+        keyp += (size_t)digit_begin * 2 * (size_t)(k.nQk + k.nPk) * N;
+        a.beta = digit_end - digit_begin;
+    }
     int n = 0;
     for (int j = 0; j <= levelQ; j++) {
         if (limb_filter == 1 && be.small[j] == 2) continue;
@@ -1566,7 +1583,7 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
     a.own_alpha = own ? own_alpha : 0;
     a.own_nq = levelQ + 1;
     const View decv{const_cast<uint64_t *>(dec), dec_bs};
-    HIP_TRY(launch_ks_inner(be.qp, a, decv, own ? *own : decv, k.d, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
+    HIP_TRY(launch_ks_inner(be.qp, a, decv, own ? *own : decv, keyp, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
     return HE_OK;
 }
 
@@ -2105,6 +2122,29 @@ int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, dec->batch, o, "he_gadget_product_hoisted_lazy"));
     Scope sc(be.ctx.get());
     return ks_inner(*ev, levelQ, k->nPk - 1, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), dec->batch);
+}
+int he_gadget_product_hoisted_lazy_digits(he_handle hev, int levelQ, he_handle hdec, he_handle hk, int digit_begin, int digit_end,
+                                          he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
+    const char *who = "he_gadget_product_hoisted_lazy_digits";
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(dec, Decomp, hdec, T_DECOMP);
+    GET(k, Evk, hk, T_EVK);
+    BasisExtender &be = *ev->be;
+    TRY(check_key(*ev, *k, levelQ, who));
+    if (k->pw2) return fail(HE_EINVAL, "%s: method is unsupported for BaseTwoDecomposition != 0", who);
+    TRY(check_decomp(*ev, *dec, levelQ, k->nPk - 1, who));
+    const int beta = base_rns_size(levelQ, k->nPk - 1);
+    if (digit_begin < 0 || digit_end > beta || digit_begin > digit_end) return fail(HE_EINVAL, "%s: digits [%d,%d) outside [0,%d)", who, digit_begin, digit_end, beta);
+    QPOut o;
+    TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, dec->batch, o, who));
+    Scope sc(be.ctx.get());
+    if (digit_begin == digit_end) {  // an empty share contributes zero
+        for (Poly *pp : {o.q0.get(), o.p0.get(), o.q1.get(), o.p1.get()})
+            HIP_TRY(hipMemsetAsync(pp->d, 0, (size_t)pp->batch * pp->nlimbs * pp->N * 8, be.ctx->stream));
+        return HE_OK;
+    }
+    return ks_inner(*ev, levelQ, k->nPk - 1, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(),
+                    dec->batch, nullptr, 0, 0, digit_begin, digit_end);
 }
 int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, he_handle hout0, he_handle hout1) {
     GET(ev, Evaluator, hev, T_EVAL);

@@ -113,6 +113,67 @@ class ControlPlane:
             return key
         return EvaluationKey(evaluator, words[:, :, :nQk], words[:, :, nQk:], base_two, nj)
 
+    # ---- one key switch split over the ranks by digit ("RCCL ... when a single op is split") ----------
+    @staticmethod
+    def digit_range(beta: int, rank: int, world: int) -> range:
+        """contiguous share of the beta digits of the RNS decomposition (ranks beyond beta get an empty share)"""
+        return range(beta * rank // world, beta * (rank + 1) // world)
+
+    def AllReduceSumPolys(self, polys, rings, transport: str = "rccl"):
+        """In place: every polynomial becomes the limb-wise sum over the ranks, reduced to [0, q).  Inputs canonical; the word
+        sum of `world` canonical residues must not wrap (world * q < 2^64, checked)."""
+        if self._dist is None:
+            return
+        for p, r in zip(polys, rings):
+            if self.world * max(int(q) for q in r.moduli) >= 1 << 64:
+                raise ValueError("AllReduceSumPolys: world * q exceeds 64 bits")
+        if transport == "rccl":
+            import torch
+            dev = rings[0].ctx.device_id
+            group = self._rccl_group(dev)
+            views = []
+            for p in polys:
+                ptr, nbytes = p.DeviceBuffer()  # drains the context's stream
+
+                class _DeviceWords:
+                    __cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+                views.append(torch.as_tensor(_DeviceWords(), device=f"cuda:{dev}"))
+            for t in views:  # two's-complement addition of the 64-bit words = addition mod 2^64
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize(dev)
+        elif transport == "host":
+            import numpy as np
+            import torch
+            for p in polys:
+                w = p.download()
+                t = torch.from_numpy(w.view(np.int64))
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+                p.upload(w)
+        else:
+            raise ValueError("transport is 'rccl' or 'host'")
+        for p, r in zip(polys, rings):
+            r.AtLevel(p.n_limbs - 1).Reduce(p, p)
+
+    def SplitGadgetProductHoisted(self, evaluator, levelQ: int, decomp, evk, ct, transport: str = "rccl"):
+        """Evaluator.GadgetProductHoisted with the digits of the inner product shared out over the ranks: every rank holds
+        the same decomposition (decomp, from DecomposeNTT) and needs only ITS digits of the key to be meaningful; it
+        accumulates digits digit_range(beta, rank, world), the four partial (Q, P) accumulators are summed across the ranks
+        (RCCL all-reduce over xGMI, or gloo through the host) and every rank finishes with ModDown.  Bit-identical to the
+        unsplit call.  This trades a 2 (L + alpha)-limb all-reduce per ciphertext for 1/world of the key memory and of the
+        inner-product work: the decomposition and the ModDown are not split."""
+        from .ring import Poly
+        rQ, rP = evaluator.ringQ, evaluator.ringP
+        levelP = evk.LevelP()
+        from .rlwe import BaseRNSDecompositionVectorSize
+        beta = BaseRNSDecompositionVectorSize(levelQ, levelP)
+        share = self.digit_range(beta, self.rank, self.world)
+        B = decomp.batch
+        ctQP = [(Poly(rQ, levelQ + 1, B, zero=False), Poly(rP, levelP + 1, B, zero=False)) for _ in range(2)]
+        evaluator.GadgetProductHoistedLazyDigits(levelQ, decomp, evk, share.start, share.stop, ctQP)
+        self.AllReduceSumPolys([ctQP[0][0], ctQP[0][1], ctQP[1][0], ctQP[1][1]], [rQ, rP, rQ, rP], transport)
+        evaluator.ModDown(levelQ, levelP, ctQP, ct)
+
     def shard(self, n_items: int) -> range:
         """Ciphertext b goes to rank b mod world (independent units, embarrassingly parallel)."""
         return range(self.rank, n_items, self.world)

@@ -121,6 +121,12 @@ class Poly:
         except Exception:
             pass
 
+    def DeviceBuffer(self):
+        """(device pointer, bytes) of the words [batch][n_limbs][N]; the context's stream is drained first."""
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        check(load().he_poly_device_buffer(self.h, C.byref(ptr), C.byref(nb)))
+        return ptr.value, nb.value
+
     def Level(self):
         return self.n_limbs - 1
 

@@ -173,6 +173,12 @@ class Evaluator:
         (q0, p0), (q1, p1) = ctQP
         check(load().he_gadget_product_hoisted_lazy(self.h, levelQ, decomp.h, evk.h, q0.h, p0.h, q1.h, p1.h))
 
+    def GadgetProductHoistedLazyDigits(self, levelQ, decomp: Decomposition, evk: EvaluationKey, digit_begin: int, digit_end: int, ctQP):
+        """the inner product of GadgetProductHoistedLazy over the digits [digit_begin, digit_end) only (canonical): the
+        per-rank share when one key switch is split over several GPUs by digit (dist.SplitGadgetProductHoisted)"""
+        (q0, p0), (q1, p1) = ctQP
+        check(load().he_gadget_product_hoisted_lazy_digits(self.h, levelQ, decomp.h, evk.h, digit_begin, digit_end, q0.h, p0.h, q1.h, p1.h))
+
     # Evaluator.ModDown (:39-97), the four domain combinations of (ctQP.IsNTT, ct.IsNTT); ctQP is modified in place in the
     # NTT -> INTT case, as the reference
     # BasisExtender.ModDownQPtoQNTT (ring/basis_extension.go:235) on the evaluator's fused pipeline; p2Q may alias p1Q

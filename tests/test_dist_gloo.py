@@ -62,3 +62,15 @@ def test_control_plane(tmp_path, world, agg):
         capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert agg in out.stdout
+
+
+def test_digit_shares_partition_the_decomposition():
+    """ControlPlane.digit_range (single key switch split by digit): contiguous, disjoint, covering, balanced to one digit; ranks
+    beyond beta get an empty share"""
+    from lattigo_amd.dist import ControlPlane
+    for beta in range(1, 13):
+        for world in range(1, 10):
+            shares = [ControlPlane.digit_range(beta, r, world) for r in range(world)]
+            assert [d for s in shares for d in s] == list(range(beta))
+            sizes = [len(s) for s in shares]
+            assert max(sizes) - min(sizes) <= 1

@@ -137,3 +137,73 @@ def test_contexts_on_different_devices_select_their_device():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+_SPLIT_WORKER = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import lattigo_amd as la
+from lattigo_amd.dist import ControlPlane
+from lattigo_amd import rlwe as R
+from oracle import oracle as O
+from tests.helpers import rng_for, uniform_poly
+cp = ControlPlane()
+ctx = la.Context(int(os.environ.get("HERING_FORCE_DEVICE", cp.local_rank)))
+q, p = O.GenModuli(14, [55, 45, 45, 45, 45, 45, 45], [55, 46])      # beta = 4 digits of alpha = 2 limbs
+N, L, B = 1 << 13, 7, 2
+gQ, gP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+gev = la.Evaluator(gQ, gP)
+rng = rng_for(2990)                       # the same stream on every rank: same key, same input
+beta = 4
+kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(beta)])
+kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(beta)])
+cx = np.stack([uniform_poly(rng, q, N) for _ in range(B)])
+share = cp.digit_range(beta, cp.rank, cp.world)
+kq_r, kp_r = kq.copy(), kp.copy()         # a rank only needs its digits: poison the others
+for d in range(beta):
+    if d not in share:
+        kq_r[d] = 0x5A5A5A5A; kp_r[d] = 0x5A5A5A5A
+key = gev.NewEvaluationKey(kq_r, kp_r)
+pcx = la.Poly(gQ, L, B).upload(cx)
+dec = R.Decomposition(gev, B)
+gev.DecomposeNTT(L - 1, len(p) - 1, len(p), pcx, True, dec)
+ct = [la.Poly(gQ, L, B), la.Poly(gQ, L, B)]
+cp.SplitGadgetProductHoisted(gev, L - 1, dec, key, ct, transport=%r)
+got = np.stack([c.get() for c in ct], axis=1)      # [B][2][L][N]
+oev = O.Evaluator(O.Ring(N, q), O.Ring(N, p))
+for b in range(B):
+    want = oev.GadgetProduct(L - 1, cx[b], O.EvaluationKey(kq, kp))
+    assert np.array_equal(got[b], want), (cp.rank, b)
+if cp.rank == 0:
+    print("SPLIT_OK", cp.world)
+cp.close()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_key_switch_split_over_ranks_by_digit(tmp_path, world):
+    """SURVEY.md section 8e's single-op split: every rank holds only its digits of the key (the others poisoned), accumulates
+    them with he_gadget_product_hoisted_lazy_digits, the partial accumulators are all-reduced (here: gloo through the host,
+    ranks sharing the box's GPU) and ModDown finishes: every rank's result equals the oracle's GadgetProduct bit for bit."""
+    script = tmp_path / "worker.py"
+    script.write_text(_SPLIT_WORKER % (ROOT, "host"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29565 + world), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", HERING_FORCE_DEVICE="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert f"SPLIT_OK {world}" in out.stdout
+
+
+def test_one_key_switch_split_over_gpus_rccl(tmp_path):
+    """the same with one rank per GPU and the all-reduce over RCCL / xGMI, in place on the accumulators' device storage"""
+    n = min(_device_count(), 4)
+    if n < 2:
+        pytest.skip("needs at least two GPUs (runs on the driver's multi-GPU node)")
+    script = tmp_path / "worker.py"
+    script.write_text("import torch\n" + (_SPLIT_WORKER % (ROOT, "rccl")).replace('os.environ.get("HERING_FORCE_DEVICE", cp.local_rank)', "cp.local_rank"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", "29569", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert f"SPLIT_OK {n}" in out.stdout
