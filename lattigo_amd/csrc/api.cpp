@@ -1767,7 +1767,7 @@ size_t ks_scratch_words(const BasisExtender &be, int levelQ, int levelP, int bat
 
 namespace {
 int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, uint64_t *dec,
-                    size_t dec_bs, int batch, int ntt_filter = 0);
+                    size_t dec_bs, int batch, int ntt_filter = 0, bool f64_raw = false);
 }
 int he_decompose_and_split(he_handle hev, int levelQ, int levelP, int nbPi, int digit, he_handle h0, he_handle h1q, he_handle h1p) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -1882,16 +1882,26 @@ int get_qp_out(he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, const
 // DecomposeNTT through the fused kernels: `rows_inv` = inverse ROWS pass of the NTT-domain input.
 // Own limbs are NOT written (ks_inner reads them from the input; he_decompose_ntt copies them).
 int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, uint64_t *dec,
-                    size_t dec_bs, int batch, int ntt_filter) {
+                    size_t dec_bs, int batch, int ntt_filter, bool f64_raw) {
     BasisExtender &be = *ev.be;
     const View dv{dec, dec_bs};
     for (const FusedGroup &g : plan.groups)
-        HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, g.dst_classes, rows_inv, dv, dv, batch, be.ctx->stream));
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, g.dst_classes, rows_inv, dv, dv, batch, be.ctx->stream, f64_raw));
     return dec_rows_ntt(ev, levelQ, levelP, nbPi, dec, dec_bs, batch, ntt_filter);
 }
 // class-2 limbs of the gadget product: forward row NTT + key MAC in one kernel (dec holds the post-column state)
+// May the basis extension hand unreduced doubles to the double-precision row kernels (launch_modup_fused f64_raw)?
+static bool f64_raw_ok(const BasisExtender &be, int levelQ, int levelP, int nsrc) {
+    static const bool off = getenv("HERING_NO_F64_RAW") && atoi(getenv("HERING_NO_F64_RAW")) != 0;
+    if (off) return false;
+    uint64_t mx = 0;
+    for (int j = 0; j <= levelQ; j++) if (be.small[j] == 2) mx = std::max(mx, be.Q->moduli[j]);
+    for (int j = 0; j <= levelP; j++) if (be.small[be.LQ + j] == 2) mx = std::max(mx, be.P->moduli[j]);
+    return mx != 0 && modup_f64_raw_ok(be.Q->logN, nsrc, mx);
+}
 int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View cx,
-               int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch, bool q_out_f64 = false, bool own_reduce = true) {
+               int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch, bool q_out_f64 = false, bool own_reduce = true,
+               bool dec_f64 = false) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     NttMacArgs a{};
@@ -1913,6 +1923,7 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
     a.own_alpha = own_alpha;
     a.own_nq = levelQ + 1;
     a.own_reduce = own_reduce ? 1 : 0;
+    a.dec_f64 = dec_f64 ? 1 : 0;
     a.q_out_f64 = 0;
     const View decv{const_cast<uint64_t *>(dec), dec_bs};
     if (!q_out_f64) {
@@ -1977,10 +1988,14 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
     if (plan->ok) {
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, cx_canonical ? 0 : NTT_REDUCE_INPUT, be.ctx->stream));
         if (k.keyd) {  // limbs below 2^47: NTT + MAC fused; the rest: row NTT then ks_inner
-            TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B, 1));
+            // the double-precision limbs of the decomposition are read by ntt_mac_f64 only: they stay doubles in between
+            int max_nsrc = 1;
+            for (const FusedGroup &g : plan->groups) max_nsrc = std::max(max_nsrc, g.nsrc);
+            const bool raw = f64_raw_ok(be, levelQ, levelP, max_nsrc);
+            TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B, 1, raw));
             TRY(ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
             if (acc_q_f64) *acc_q_f64 = want_f64;
-            return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64, !cx_canonical);
+            return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64, !cx_canonical, raw);
         }
         TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B));
         return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
@@ -2066,13 +2081,14 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         hipStream_t st = be.ctx->stream;
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), View{aP, sPw}, sP, 2 * B, true, 0, st));  // canonical accumulators
         const FusedGroup &g = plan->groups[0];
-        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, 2 * B, st));
+        const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);  // the extension's double-precision outputs stay doubles up to the row kernel
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, 2 * B, st, raw));
         NttEpilogue epi;
         for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
         epi.y = a0Q; epi.has_w = add0 != nullptr; epi.w = add0 ? *add0 : a0Q;
         epi.y_small_f64 = acc_f64;
         epi.zsplit = B; epi.out2 = out1; epi.y2 = a1Q; epi.has_w2 = add1 != nullptr; epi.w2 = add1 ? *add1 : a1Q;
-        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, out0, 2 * B, false, 0, st, &epi));
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, out0, 2 * B, false, raw ? NTT_INPUT_F64 : 0, st, &epi));
         return HE_OK;
     }
     TRY(moddown_front(ev, levelQ, levelP, View{aP, sPw}, sP, sQ, 2 * B, true));  // accumulators of ks_inner / ntt_mac: canonical

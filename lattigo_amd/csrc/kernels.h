@@ -49,6 +49,7 @@ enum NttFlags {
     NTT_REDUCE_INPUT = 1,  // inputs are arbitrary 64-bit words: bring them to [0,2q) first
     NTT_LAZY_OUT = 2,      // forward: leave the output in [0,2q) instead of [0,q)
     NTT_ADD_SCALAR = 4,    // (set by launch_ntt when io_scalar is given)
+    NTT_INPUT_F64 = 8,     // launch_ntt_rows, forward: the limbs of the double-precision class hold doubles (launch_modup_fused f64_raw)
 };
 struct NttEpilogue;
 // io_scalar (optional, one word per launch limb): forward -- added to the input words before the transform (lazy, then reduced when
@@ -191,7 +192,9 @@ struct ModUpDesc {
 bool modup_fused_supported(int logN, int nsrc);
 // dst_classes: bit 0 = some destination modulus is >= 2^47 (integer path), bit 1 = some is below (double path)
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
-                              View dstA, View dstB, int batch, hipStream_t s);
+                              View dstA, View dstB, int batch, hipStream_t s, bool f64_raw = false);
+// f64_raw is exact only while the unreduced doubles stay below 2^53 through the remaining forward stages
+bool modup_f64_raw_ok(int logN, int nsrc, uint64_t max_small_modulus);
 
 // base-2 gadget decomposition (ring.MaskVec, ring/vec_ops.go:870, as used by
 // core/rlwe/evaluator_gadget_product.go:256-258): block b = (RNS digit i, window j) gets
@@ -251,6 +254,7 @@ struct NttMacArgs {
     uint8_t dec_limb[kMaxLimbs], key_limb[kMaxLimbs], out_limb[kMaxLimbs], out_view[kMaxLimbs], mod[kMaxLimbs];
     size_t dec_dstride, key_kstride, key_dstride;
     int own_alpha, own_nq;
+    int dec_f64;     // the decomposed (non-own) words are doubles (launch_modup_fused f64_raw)
     int own_reduce;  // the own-digit words are caller-supplied (any uint64): reduce them before the conversion to double
     int q_out_f64;   // Q-limb accumulators are written as IEEE doubles (exact integers, |x| < q) for the f64 ModDown epilogue
 };

@@ -701,12 +701,17 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     if constexpr (!INV) {
         constexpr int sh0 = LOGB - 4;
         const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + in_off;
+        if (A.flags & NTT_INPUT_F64) {  // doubles left by the basis extension (|x| < 64 q, see launch_modup_fused)
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            uint64_t v = ldnt(&src[(k << sh0) + tau]);
-            if (A.flags & NTT_ADD_SCALAR) v += A.io_s[y];
-            if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
-            x[k] = u52_to_f64(v);
+            for (int k = 0; k < 16; k++) x[k] = __longlong_as_double((long long)ldnt(&src[(k << sh0) + tau]));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint64_t v = ldnt(&src[(k << sh0) + tau]);
+                if (A.flags & NTT_ADD_SCALAR) v += A.io_s[y];
+                if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
+                x[k] = u52_to_f64(v);
+            }
         }
         // (twiddles loaded inside the round: prefetching them across the exchange, as the inverse kernel and ntt_mac_f64 do,
         // measured 2 % slower here at four waves per SIMD)
@@ -909,8 +914,13 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
 #pragma unroll
             for (int k = 0; k < 16; k++) nx[k] = bred_add_lazy(nx[k], mc.q, mc.brc0);
         }
+        if (A.m.dec_f64 && !is_own) {  // the basis extension left doubles (launch_modup_fused, f64_raw)
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = u52_to_f64(nx[k]);
+            for (int k = 0; k < 16; k++) x[k] = __longlong_as_double((long long)nx[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = u52_to_f64(nx[k]);
+        }
         if (d + 1 < A.m.beta) {
             const uint64_t *src = digit_src(d + 1);
 #pragma unroll
@@ -1766,6 +1776,8 @@ struct ModUpFusedArgs {
     const double *twd_fwd, *twd_inv;
     const uint64_t *tws_fwd;
     int N;
+    int f64_raw;  // double-precision destinations are stored as the doubles they are (|x| < 64 p, unreduced): the consumer is a
+                  // double-precision row kernel told so (NttMacArgs::dec_f64 / NTT_INPUT_F64), six instructions per word saved here
 };
 
 // block-uniform 64-bit constants through the scalar cache: the constant address space tells the compiler that the table is
@@ -2022,8 +2034,13 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                     }
                 }
             }
+            if (A.f64_raw) {
 #pragma unroll
-            for (int r = 0; r < R; r++) stnt(&dst[(size_t)r * N2], f64_to_u52(reduce_f64(o[r], pd, pid) + pd));  // (0, 2p)
+                for (int r = 0; r < R; r++) stnt(&dst[(size_t)r * N2], (uint64_t)__double_as_longlong(o[r]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) stnt(&dst[(size_t)r * N2], f64_to_u52(reduce_f64(o[r], pd, pid) + pd));  // (0, 2p)
+            }
         }
         if (!done && !single && U(D.dst_fast[j]) == 2) {
             // The same folding for the remaining destination moduli (up to 2^62: the 60/61-bit q0 and special primes of the CKKS
@@ -2220,12 +2237,18 @@ static void launch_modup_fused_variant(int a, int nsrc, dim3 grid, dim3 block, c
 #undef HE_MF
 }
 
+bool modup_f64_raw_ok(int logN, int nsrc, uint64_t max_small_modulus) {
+    // |o| < (2 + 5 nsrc) p after the matrix-vector sum, + 2p per forward stage (column and row): everything must stay below 2^53
+    const long double bound = (long double)(2 + 5 * nsrc + 2 * logN) * (long double)max_small_modulus;
+    return bound < 0x1p53L;
+}
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
-                              View dstA, View dstB, int batch, hipStream_t s) {
+                              View dstA, View dstB, int batch, hipStream_t s, bool f64_raw) {
     if (ndesc <= 0 || batch <= 0) return hipSuccess;
     if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
     const int a = r.logN - ntt_row_bits(r.logN);
     ModUpFusedArgs A;
+    A.f64_raw = f64_raw ? 1 : 0;
     A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
     A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.twd_fwd = r.twd_fwd; A.twd_inv = r.twd_inv; A.N = r.N;
