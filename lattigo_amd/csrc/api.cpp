@@ -2013,8 +2013,9 @@ int moddown_front(Evaluator &ev, int levelQ, int levelP, View accP, View sP, Vie
     if (plan->ok) {
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, canonical ? 0 : NTT_REDUCE_INPUT, st));
         const FusedGroup &g = plan->groups[0];
-        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, nb, st));
-        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT, st));
+        const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, nb, st, raw));
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT | (raw ? NTT_INPUT_F64 : 0), st));
         return HE_OK;
     }
     HIP_TRY(be_ntt(be, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, NTT_REDUCE_INPUT));
@@ -2219,12 +2220,13 @@ int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle
     hipStream_t st = be.ctx->stream;
     HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), p1p->view(), sP, B, true, NTT_REDUCE_INPUT, st));
     const FusedGroup &g = plan->groups[0];
-    HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, B, st));
+    const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);
+    HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, B, st, raw));
     NttEpilogue epi;
     for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
     epi.y = p1q->view(); epi.has_w = false; epi.w = p1q->view();
     epi.y_reduce = true;  // p1Q is the caller's: any 64-bit word
-    HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, p2->view(), B, false, 0, st, &epi));
+    HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, p2->view(), B, false, raw ? NTT_INPUT_F64 : 0, st, &epi));
     return HE_OK;
 }
 int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he_handle hout0, he_handle hout1) {
