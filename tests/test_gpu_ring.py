@@ -420,3 +420,38 @@ def test_inverse_ntt_two_entries_per_workgroup(ctx, batch):
     # all entries: INTT is injective, so the round trip pins the ones not compared above
     gq.NTT(py, py)
     assert np.array_equal(py.download(), x)
+
+
+@pytest.mark.gpu
+def test_transforms_and_rescale_logN14_large_batch(ctx):
+    """Stand-alone transforms and the fused rescale at logN = 14 with a large batch (96 entries x 4 limbs, all three modulus
+    classes): NTT / INTT / NTTLazy and DivRound / DivFloorByLastModulusNTT, sampled entries against the oracle, the round trip
+    and the in-place rescale on every entry.  (Written for the one-pass variant of these transforms -- the whole limb resident in
+    a 1024-thread workgroup's LDS -- which measured slower than the two passes and was removed; kept as the large-batch case.)"""
+    logN, B = 14, 96
+    qs, _ = O.GenModuli(logN + 1, [60, 45, 55, 40], [])
+    pr = Pair(ctx, logN, len(qs), qmods=qs)
+    rng = rng_for(1320)
+    x = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(B)])
+    px, py, pz = pr.up(pr.gQ, x, batch=B), la.Poly(pr.gQ, len(qs), B), la.Poly(pr.gQ, len(qs), B)
+    pr.gQ.NTT(px, py)
+    got = py.get()
+    keep = (0, B // 2, B - 1)
+    for b in keep:
+        assert np.array_equal(got[b], pr.oQ.NTT(x[b])), b
+    pr.gQ.INTT(py, pz)
+    assert np.array_equal(pz.get(), x)
+    pr.gQ.NTTLazy(px, pz)
+    lz = pz.get()
+    assert np.all(lz < 2 * np.array(pr.q, dtype=np.uint64)[None, :, None])
+    for b in keep:
+        assert np.array_equal(pr.oQ.unop("Reduce", lz[b]), got[b])
+    for name in ("DivRoundByLastModulusNTT", "DivFloorByLastModulusNTT"):
+        po = la.Poly(pr.gQ, len(qs), B)
+        getattr(pr.gQ, name)(py, po)
+        res = po.get()
+        for b in keep:
+            assert np.array_equal(res[b, : len(qs) - 1], getattr(pr.oQ, name)(got[b])), (name, b)
+        pin = la.Poly(pr.gQ, len(qs), B).upload(got)
+        getattr(pr.gQ, name)(pin, pin)  # in place
+        assert np.array_equal(pin.get()[:, : len(qs) - 1], res[:, : len(qs) - 1]), name
