@@ -311,6 +311,35 @@ func (e *Evaluator) GadgetProductLazy(levelQ int, cx ring.Poly, gadgetCt *rlwe.G
 	return nil
 }
 
+// GadgetProductHoistedLazyDigits is the inner product of GadgetProductHoistedLazy over the RNS digits [digitBegin, digitEnd)
+// only (NTT domain, canonical): the per-GPU share when one key switch is split over several devices by digit -- each device
+// holds its digits of the key, the partial (Q, P) accumulators are summed across devices (RCCL all-reduce on
+// he_poly_device_buffer storage) and reduced before ModDown.  No counterpart in the reference (one address space).
+func (e *Evaluator) GadgetProductHoistedLazyDigits(levelQ int, BuffQPDecompQP []ringqp.Poly, gadgetCt *rlwe.GadgetCiphertext, digitBegin, digitEnd int, ct *rlwe.Element[ringqp.Poly]) (err error) {
+	if gadgetCt.BaseTwoDecomposition != 0 {
+		return fmt.Errorf("method is unsupported for BaseTwoDecomposition != 0")
+	}
+	k, err := e.evk(gadgetCt)
+	if err != nil {
+		return err
+	}
+	d, err := e.decomp(BuffQPDecompQP)
+	if err != nil {
+		return err
+	}
+	q0, p0, err := e.qp(ct.Value[0], gadgetCt.LevelP(), false)
+	if err != nil {
+		return err
+	}
+	q1, p1, err := e.qp(ct.Value[1], gadgetCt.LevelP(), false)
+	if err != nil {
+		return err
+	}
+	return lockedCall(func() C.int {
+		return C.he_gadget_product_hoisted_lazy_digits(e.h, C.int(levelQ), d.h, k.h, C.int(digitBegin), C.int(digitEnd), q0.h, h(p0), q1.h, h(p1))
+	})
+}
+
 // GadgetProductHoistedLazy: core/rlwe/evaluator_gadget_product.go:379.
 func (e *Evaluator) GadgetProductHoistedLazy(levelQ int, BuffQPDecompQP []ringqp.Poly, gadgetCt *rlwe.GadgetCiphertext, ct *rlwe.Element[ringqp.Poly]) (err error) {
 	if gadgetCt.BaseTwoDecomposition != 0 {
