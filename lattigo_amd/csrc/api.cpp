@@ -2049,8 +2049,14 @@ int moddown_pair(Evaluator &ev, int levelQ, int levelP, View c0Q, View c0P, View
 }
 // full GadgetProduct: out_k = [add_k +] GadgetProduct(cx)_k.  Both components share every launch
 // (accumulators are laid out [2][B] so ModDown runs once over 2B entries).
+// the four inputs of a ciphertext product whose c0 / c1 the fused ModDown epilogue forms itself (NttEpilogue::tensor)
+struct TensorIn {
+    View a0, a1, b0, b1;
+    const uint64_t *ts;  // per Q limb
+};
 int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp *hoisted, const Evk &k, View out0, View out1, int B,
-                        const View *add0 = nullptr, const View *add1 = nullptr, bool cx_canonical = false) {
+                        const View *add0 = nullptr, const View *add1 = nullptr, bool cx_canonical = false,
+                        const TensorIn *tin = nullptr) {
     BasisExtender &be = *ev.be;
     const int levelP = k.nPk - 1, N = be.Q->N;
     const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
@@ -2089,9 +2095,15 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         epi.y = a0Q; epi.has_w = add0 != nullptr; epi.w = add0 ? *add0 : a0Q;
         epi.y_small_f64 = acc_f64;
         epi.zsplit = B; epi.out2 = out1; epi.y2 = a1Q; epi.has_w2 = add1 != nullptr; epi.w2 = add1 ? *add1 : a1Q;
+        if (tin) {
+            epi.tensor = true; epi.has_w = epi.has_w2 = false;
+            epi.ta0 = tin->a0; epi.ta1 = tin->a1; epi.tb0 = tin->b0; epi.tb1 = tin->b1;
+            for (int i = 0; i <= levelQ; i++) epi.ts[i] = tin->ts[i];
+        }
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, out0, 2 * B, false, raw ? NTT_INPUT_F64 : 0, st, &epi));
         return HE_OK;
     }
+    if (tin) return fail(HE_EINVAL, "gadget product: tensor-mode epilogue without a fused ModDown plan");
     TRY(moddown_front(ev, levelQ, levelP, View{aP, sPw}, sP, sQ, 2 * B, true));  // accumulators of ks_inner / ntt_mac: canonical
     TRY(moddown_back(ev, levelQ, levelP, sQ, a0Q, out0, add0, B));
     TRY(moddown_back(ev, levelQ, levelP, View{sQ.p + (size_t)B * sQw, sQw}, a1Q, out1, add1, B));
@@ -2549,9 +2561,24 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
     }
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k.get()) + wQ));
     View c2{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
+    const View o0v = out0->view(), o1v = out1->view();
+    // With a fused ModDown the tensor kernel forms c2 only: c0 / c1 are computed from the inputs where they are added, in the
+    // ModDown epilogue (24 limbs of writes and 24 of reads fewer; the inputs' second read comes from L2).  Not when an output
+    // aliases an input: the epilogue of one component would overwrite words the other still reads.
+    static const bool no_fuse = getenv("HERING_NO_TENSOR_EPILOGUE") && atoi(getenv("HERING_NO_TENSOR_EPILOGUE")) != 0;
+    const FusedPlan *mdplan = nullptr;
+    TRY(get_md_plan(*ev, level, k->nPk - 1, &mdplan));
+    bool alias = false;
+    for (Poly *o : {out0.get(), out1.get()})
+        for (Poly *in : {a0.get(), a1.get(), b0.get(), b1.get()}) alias = alias || o->d == in->d;
+    if (mdplan->ok && k->nPk > 0 && !alias && !no_fuse) {
+        HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), View{nullptr, 0},
+                              View{nullptr, 0}, c2, B, st));
+        TensorIn tin{a0->view(), a1->view(), b0->view(), b1->view(), sc_.data()};
+        return gadget_product_core(*ev, level, &c2, nullptr, *k, o0v, o1v, B, nullptr, nullptr, true, &tin);
+    }
     HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),
                           out1->view(), c2, B, st));
-    const View o0v = out0->view(), o1v = out1->view();
     return gadget_product_core(*ev, level, &c2, nullptr, *k, o0v, o1v, B, &o0v, &o1v, true);  // c2 from the tensor kernel: canonical
 }
 int he_ckks_mul_relin(he_handle ev, int level, he_handle a0, he_handle a1, he_handle b0, he_handle b1, he_handle rlk, he_handle o0, he_handle o1, he_handle o2) {

@@ -77,6 +77,13 @@ struct NttEpilogue {
     int zsplit = 0;
     View out2, y2, w2;
     bool has_w2 = false;
+    // tensor mode (fused MulRelin; launch_ntt_rows with zsplit = B): the addend of a component is formed from the four
+    // inputs of the ciphertext product instead of being read back -- w0 = T(a0, b0), w1 = CRed(T(a0, b1) + T(a1, b0)),
+    // T(x, y) = MRed(MRed(x, ts[limb]), y) (schemes/bgv/evaluator.go:634-647) -- and the two components of an entry are given
+    // workgroups eight apart in launch order (the same XCD, back to back), so that the second one finds a0 / b0 in that L2
+    bool tensor = false;
+    View ta0, ta1, tb0, tb1;
+    uint64_t ts[kMaxLimbs];
     // launch_ntt only: the epilogue pass writes here instead of `out` (which then only carries the column pass's
     // intermediate), so that dst may alias y
     bool has_dst = false;

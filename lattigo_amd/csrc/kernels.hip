@@ -180,6 +180,10 @@ struct NttArgs {
     size_t out2_bs;
     const uint64_t *epi_y2, *epi_w2;
     size_t epi_y2_bs, epi_w2_bs;
+    int epi_tensor;            // tensor-mode epilogue (NttEpilogue::tensor)
+    const uint64_t *ta0, *ta1, *tb0, *tb1;
+    size_t ta0_bs, ta1_bs, tb0_bs, tb1_bs;
+    uint64_t epi_ts[kMaxLimbs];
     uint64_t io_s[kMaxLimbs];  // NTT_ADD_SCALAR: per launch limb, added to the input words (forward) / to the canonical output (inverse)
     int epi_y_f64;  // f64 kernel only: y holds doubles
     int epi_y_reduce;  // f64 kernel only: y holds arbitrary 64-bit words (reduced before the conversion to double)
@@ -388,7 +392,13 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, S
     // (same limb and row) are dispatched together and hit it in L2
     const int tau = threadIdx.x;
     const int row = blockIdx.z;
-    const unsigned bzi = blockIdx.x;
+    unsigned bzi = blockIdx.x;
+    if (!INV && A.epi_tensor) {
+        // launch order: [8 entries, component 0][the same 8 entries, component 1]... -> input entry = comp * zsplit + entry
+        const unsigned ent = (bzi >> 4) * 8 + (bzi & 7);
+        if ((int)ent >= A.zsplit) return;
+        bzi = ((bzi >> 3) & 1) * (unsigned)A.zsplit + ent;
+    }
     const int y = blockIdx.y;
     const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
     const ModConst mc = A.mc[mi];
@@ -458,7 +468,33 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, S
             uint64_t yv[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) yv[k] = ldnt(&yp[nat_e<T>(k, tau)]);
-            if (addw) {
+            if (A.epi_tensor) {
+                // the addend from the product's inputs, eight coefficients at a time (plain loads: the other component's
+                // workgroup reads the same rows from L2)
+                const size_t toff = (size_t)ol * A.N + (size_t)row * N2;
+                const uint64_t *pa0 = A.ta0 + zz * A.ta0_bs + toff, *pa1 = A.ta1 + zz * A.ta1_bs + toff;
+                const uint64_t *pb0 = A.tb0 + zz * A.tb0_bs + toff, *pb1 = A.tb1 + zz * A.tb1_bs + toff;
+                const uint64_t ts = A.epi_ts[y];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint64_t u[8], v[8], wv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); u[k] = pa0[e]; v[k] = second ? pb1[e] : pb0[e]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) wv[k] = mred(mred(u[k], ts, q, qinv), v[k], q, qinv);
+                    if (second) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); u[k] = pa1[e]; v[k] = pb0[e]; }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) wv[k] = cred(wv[k] + mred(mred(u[k], ts, q, qinv), v[k], q, qinv), q);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int e = nat_e<T>(8 * h + k, tau);
+                        stnt(&op[e], cred(wv[k] + mred(settle(lds[lds_phys(e)]) + twoq - yv[8 * h + k], sy, q, qinv), q));
+                    }
+                }
+            } else if (addw) {
                 uint64_t wv[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[nat_e<T>(k, tau)]);
@@ -686,7 +722,12 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     // inverse: software pipeline over the workgroup's batch entries, the words of entry b + 1 are in flight while entry b is
     // transformed (-12 %).  The forward kernel keeps one entry per workgroup: with the 32 extra registers it drops from four
     // to two waves per SIMD and runs 1.5x slower.
-    const unsigned b0 = blockIdx.x * (unsigned)A.iters;
+    unsigned b0 = blockIdx.x * (unsigned)A.iters;
+    if (!INV && A.epi_tensor) {  // see ntt_rows_kernel
+        const unsigned ent = (b0 >> 4) * 8 + (b0 & 7);
+        if ((int)ent >= A.zsplit) return;
+        b0 = ((b0 >> 3) & 1) * (unsigned)A.zsplit + ent;
+    }
     constexpr bool PIPE = INV && LOGB <= 12;  // 512-thread rows (LOGB = 13) would fall to one workgroup per CU
     const unsigned b1 = PIPE ? min(b0 + (unsigned)A.iters, (unsigned)A.nbatch) : b0 + 1;  // otherwise iters == 1
     uint64_t nx[16];
@@ -754,7 +795,35 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
 #pragma unroll
                 for (int k = 0; k < 16; k++) yv[k] = u52_to_f64(ldnt(&yp[nat_e<T>(k, tau)]));
             }
-            if (addw) {
+            if (A.epi_tensor) {
+                // addend = x y (ts 2^-128 mod q) from the product's inputs (caller words: reduced first), all in doubles; one
+                // canonical reduction of addend + (transform - y) s gives the reference's word
+                const size_t toff = (size_t)ol * A.N + (size_t)row * N2;
+                const uint64_t *pa0 = A.ta0 + zz * A.ta0_bs + toff, *pa1 = A.ta1 + zz * A.ta1_bs + toff;
+                const uint64_t *pb0 = A.tb0 + zz * A.tb0_bs + toff, *pb1 = A.tb1 + zz * A.tb1_bs + toff;
+                const double tsp = (double)imform(imform(A.epi_ts[y], mc.q, mc.qinv), mc.q, mc.qinv);
+                auto ld = [&](const uint64_t *p, int e) -> double { return u52_to_f64(bred_add_lazy(p[e], mc.q, mc.brc0)); };
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    double u[8], v[8], wv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); u[k] = ld(pa0, e); v[k] = ld(second ? pb1 : pb0, e); }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) wv[k] = modmul_f64(u[k], v[k], q, qi);
+                    if (second) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); u[k] = ld(pa1, e); v[k] = ld(pb0, e); }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) wv[k] += modmul_f64(u[k], v[k], q, qi);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int e = nat_e<T>(8 * h + k, tau);
+                        const double t = modmul_f64(wv[k], tsp, q, qi) + modmul_f64(lds[lds_phys(e)] - yv[8 * h + k], sp, q, qi);
+                        stnt(&op[e], canon_f64(t, q, qi));
+                    }
+                }
+            } else if (addw) {
                 uint64_t wv[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[nat_e<T>(k, tau)]);
@@ -1173,6 +1242,7 @@ static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, const uint8
         D.tab.mod[D.tab.n] = A.tab.mod[i];
         D.epi_s[D.tab.n] = A.epi_s[i];
         D.io_s[D.tab.n] = A.io_s[i];
+        D.epi_ts[D.tab.n] = A.epi_ts[i];
         D.tab.n++;
     }
     hipError_t e = hipSuccess;
@@ -1212,6 +1282,12 @@ static void set_epilogue(NttArgs &A, const NttEpilogue &epi, int n) {
     A.epi_y = epi.y.p; A.epi_y_bs = epi.y.bstride;
     A.epi_w = epi.w.p; A.epi_w_bs = epi.w.bstride;
     for (int i = 0; i < n; i++) A.epi_s[i] = epi.s[i];
+    A.epi_tensor = epi.tensor ? 1 : 0;
+    if (epi.tensor) {
+        A.ta0 = epi.ta0.p; A.ta1 = epi.ta1.p; A.tb0 = epi.tb0.p; A.tb1 = epi.tb1.p;
+        A.ta0_bs = epi.ta0.bstride; A.ta1_bs = epi.ta1.bstride; A.tb0_bs = epi.tb0.bstride; A.tb1_bs = epi.tb1.bstride;
+        for (int i = 0; i < n; i++) A.epi_ts[i] = epi.ts[i];
+    }
     if (epi.zsplit > 0) {
         A.zsplit = epi.zsplit; A.epi2 = epi.has_w2 ? 2 : 1;
         A.out2 = epi.out2.p; A.out2_bs = epi.out2.bstride;
@@ -1233,7 +1309,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     A.tab = tab;
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
-    A.epi_y_f64 = 0; A.epi_y_reduce = 0;
+    A.epi_y_f64 = 0; A.epi_y_reduce = 0; A.epi_tensor = 0;
     const int sflag = io_scalar ? NTT_ADD_SCALAR : 0;
     for (int i = 0; i < tab.n; i++) A.io_s[i] = io_scalar ? io_scalar[i] : 0;
     dim3 grows(batch, tab.n, 1u << a);
@@ -1298,23 +1374,15 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
     A.epi_y_f64 = 0; A.epi_y_reduce = 0;
     for (int i = 0; i < tab.n; i++) A.io_s[i] = 0;
+    A.epi_tensor = 0;
     if (epi) {
-        A.epi_y_f64 = epi->y_small_f64 ? 1 : 0;
-        A.epi_y_reduce = epi->y_reduce ? 1 : 0;
-        A.epi = epi->has_w ? 2 : 1;
-        A.epi_y = epi->y.p; A.epi_y_bs = epi->y.bstride;
-        A.epi_w = epi->w.p; A.epi_w_bs = epi->w.bstride;
-        for (int i = 0; i < tab.n; i++) A.epi_s[i] = epi->s[i];
-        if (epi->zsplit > 0) {
-            A.zsplit = epi->zsplit; A.epi2 = epi->has_w2 ? 2 : 1;
-            A.out2 = epi->out2.p; A.out2_bs = epi->out2.bstride;
-            A.epi_y2 = epi->y2.p; A.epi_y2_bs = epi->y2.bstride;
-            A.epi_w2 = epi->w2.p; A.epi_w2_bs = epi->w2.bstride;
-        }
+        if (epi->tensor && (epi->zsplit <= 0 || batch != 2 * epi->zsplit)) return hipErrorInvalidValue;
+        set_epilogue(A, *epi, tab.n);
     }
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = flags;
-    dim3 grows(batch, tab.n, 1u << a);
+    // tensor mode: both components of 8 entries per 16 consecutive workgroups (see NttEpilogue::tensor)
+    dim3 grows(A.epi_tensor ? (unsigned)((epi->zsplit + 7) / 8 * 16) : (unsigned)batch, tab.n, 1u << a);
     if (!inverse) {
         A.tw = r.tw_fwd; A.twd = r.twd_fwd; A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_fwd); A.scale = 0;
         return launch_rows<false>(b, grows, A, r.host_small, s);
@@ -2591,6 +2659,14 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
     const ModConst m = A.mc[A.mod[yy]];
     const uint64_t q = m.q, qinv = m.qinv, sc = A.s[yy];
     const size_t bz = blockIdx.z, io = (size_t)A.in_limb[yy] * A.N + j, oo = (size_t)A.out_limb[yy] * A.N + j;
+    if (!A.c0) {  // c2 only (the fused MulRelin forms c0 / c1 in the ModDown epilogue, NttEpilogue::tensor)
+        const ulonglong2 a1 = ldnt2(A.a1 + bz * A.a1_bs + io), b1 = ldnt2(A.b1 + bz * A.b1_bs + io);
+        ulonglong2 c2;
+        c2.x = mred(mred(a1.x, sc, q, qinv), b1.x, q, qinv);
+        c2.y = mred(mred(a1.y, sc, q, qinv), b1.y, q, qinv);
+        *reinterpret_cast<ulonglong2 *>(A.c2 + bz * A.c2_bs + oo) = c2;
+        return;
+    }
     const ulonglong2 a0 = ldnt2(A.a0 + bz * A.a0_bs + io);
     const ulonglong2 a1 = ldnt2(A.a1 + bz * A.a1_bs + io);
     const ulonglong2 b0 = ldnt2(A.b0 + bz * A.b0_bs + io);
