@@ -112,6 +112,15 @@ __device__ __forceinline__ ulonglong2 ldnt2(const uint64_t *p) {
     return make_ulonglong2(v.x, v.y);
 }
 
+// block-uniform 64-bit constants through the scalar cache: the constant address space tells the compiler that the table is
+// never written by a kernel, so a load with a uniform address becomes an s_load instead of a vector load + wait
+typedef const uint64_t __attribute__((address_space(4))) *he_cptr64;
+__device__ __forceinline__ uint64_t ldc(const uint64_t *p, size_t i) { return ((he_cptr64)(uintptr_t)p)[i]; }
+typedef const double __attribute__((address_space(4))) *he_cptrd;
+__device__ __forceinline__ double ldcd(const double *p, size_t i) { return ((he_cptrd)(uintptr_t)p)[i]; }
+__device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }  // v_mad_u64_u32
+
+
 // XCD-aware work order (MI355X: 8 XCDs with private L2s, workgroup b runs on XCD b % 8): workgroup `lin` of a launch takes
 // work item (lin % 8) * (n / 8) + lin / 8, so that each XCD walks one contiguous eighth of the work list and the workgroups
 // that share a key / twiddle row (consecutive items, batch fastest) hit the same L2.  Identity when n is not a multiple of 8.
@@ -1055,6 +1064,256 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
 }
 
 
+
+// ------------------------------------------------------------------------------------
+// ntt_mac_f64 at the production row sizes (4096 / 8192 coefficients): persistent workgroups, digits prefetched by LDS-DMA.
+//
+// What the plain kernel above loses (tools/mac_timeline.py, round 2): a fresh workgroup's first digit costs 30 k cycles against
+// 13 k for the later ones (its first loads have nothing to hide behind); vector loads return in order, so every twiddle wait
+// queued behind the prefetch of the next digit is a wait for that prefetch; and at 252 registers the compiler has no room to
+// batch the key loads.  Here:
+//  * the launch has as many workgroups as the chip holds at once (two per CU) and each walks its share of the work list; the
+//    first digit of item i + 1 is the prefetch target of the last digit of item i, so only a workgroup's very first digit is cold.
+//    XCD-aware order as before: the workgroups of one XCD walk one contiguous eighth of the (row, limb, batch) list side by
+//    side, so those sharing a key / twiddle row use one L2;
+//  * the next digit's words go from HBM straight into LDS (`global_load_lds_dwordx4`, no staging registers): every wave fetches
+//    exactly the 16 x 64 words its own threads will read (lanes 0-31 the words of element k = 2j, lanes 32-63 those of 2j + 1,
+//    per instruction j), into its own 8 KiB of LDS -- no workgroup barrier guards the buffer, only the wave's own vmcnt;
+//  * round-0 twiddles are block-uniform (scalar registers), round-1 twiddles (16 groups x 15 per row) sit in LDS, so the only
+//    ordinary vector loads of a digit are the round-2 twiddles and the two key rows, issued as three explicit batches in the
+//    order they are needed (the DMA is issued after the first, and has the whole digit to land).
+// Bit-identical to the plain kernel (same arithmetic on the same operands).
+// ------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void *he_lds_ptr;
+__device__ __forceinline__ unsigned lds_byte_addr(const void *p) { return (unsigned)(uintptr_t)(he_lds_ptr)p; }
+// one LDS-DMA instruction: lane i's 16 bytes at gsrc land at LDS byte lds_dst + 16 i (lds_dst wave-uniform).  hipcc does not
+// count it: completion is the caller's own s_waitcnt vmcnt (MI355X_MICROARCH.md: only the issuing wave's vmcnt orders its reads)
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+struct NttMacDmaArgs {
+    NttMacKArgs k;
+    unsigned nbatch, nitems;  // work list = (row, limb, batch entry), batch fastest; nitems = rows * limbs * nbatch
+    // per launch limb: mod | key_limb << 8 | dec_limb << 16 | out_limb << 24 | out_view << 32 -- ONE scalar load per work item (a
+    // byte picked from the by-value arrays with a run-time index is a vector load, and waiting for it would drain the prefetch)
+    uint64_t limb_info[kMaxLimbs];
+};
+template <int LOGB, bool QF64>
+__global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(NttMacDmaArgs AA) {
+    static_assert(LOGB == 12 || LOGB == 13, "production row sizes only");
+    constexpr int N2 = 1 << LOGB;
+    constexpr int T = N2 / 16;
+    constexpr int GREM = LOGB % 4;
+    const NttMacKArgs &A = AA.k;
+    __shared__ double lds[N2 + N2 / 16];  // transform tile
+    __shared__ double pbuf[N2];           // the coming digit: wave w owns words [1024 w, 1024 (w + 1)), word 64 k + lane = element k T + tau
+    __shared__ double tw1s[16 * 15];      // round-1 twiddles of the item's row: [tau >> (LOGB - 8)][15]
+
+    const unsigned tau = threadIdx.x, lane = tau & 63u;
+    const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(tau >> 6));
+    const unsigned G = gridDim.x, g = blockIdx.x;
+    const bool xcd = ((G | AA.nitems) & 7u) == 0;
+    const unsigned span = xcd ? AA.nitems >> 3 : AA.nitems, stride = xcd ? G >> 3 : G;
+    const unsigned first = xcd ? g >> 3 : g, base = xcd ? (g & 7u) * span : 0u;
+    auto item_of = [&](unsigned t) -> unsigned { const unsigned i = first + t * stride; return i < span ? base + i : ~0u; };
+
+    struct Item {
+        size_t bz, rowoff;
+        int ql, rowtw, out_limb, mi;
+        bool isP;
+        double q, qi;
+        const double *tw, *kbase;
+    };
+    auto decode = [&](unsigned w) -> Item {
+        Item it;
+        it.bz = w % AA.nbatch;
+        const int l = (int)((w / AA.nbatch) % (unsigned)A.m.nlimbs);
+        const int row = (int)(w / (AA.nbatch * (unsigned)A.m.nlimbs));
+        const uint64_t info = AA.limb_info[l];
+        const int mi = (int)(info & 0xff);
+        it.mi = mi;
+        // modulus record through the scalar cache (ModConst: word 0 = q, word 8 = 1 / q as a double)
+        const uint64_t *mcw = reinterpret_cast<const uint64_t *>(A.mc + mi);
+        it.q = (double)ldc(mcw, 0); it.qi = __longlong_as_double((long long)ldc(mcw, 8));
+        it.tw = A.twd + (size_t)mi * A.N;
+        it.rowtw = (1 << A.a) + row;
+        it.rowoff = (size_t)row * N2;
+        it.kbase = A.keyd + (size_t)((info >> 8) & 0xff) * A.N + it.rowoff;
+        it.ql = (int)((info >> 16) & 0xff);
+        it.out_limb = (int)((info >> 24) & 0xff);
+        it.isP = ((info >> 32) & 0xff) != 0;
+        return it;
+    };
+    // the digit's own limb is the NTT-domain input itself (block-uniform)
+    auto own_digit = [&](const Item &it, int d) -> bool {
+        return A.m.own_alpha > 0 && !it.isP && it.ql >= d * A.m.own_alpha && it.ql < (d + 1) * A.m.own_alpha;
+    };
+    auto digit_src = [&](const Item &it, int d) -> const uint64_t * {
+        return own_digit(it, d) ? A.own + it.bz * A.own_bs + (size_t)it.ql * A.N + it.rowoff
+                                : A.dec + it.bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)it.ql * A.N + it.rowoff;
+    };
+    // LDS-DMA of one digit row: instruction j moves elements {2j, 2j + 1} x (this wave's 64 columns)
+    const unsigned pw_addr = lds_byte_addr(pbuf) + wv * 8192u;
+    auto dma_digit = [&](const uint64_t *src, unsigned lane) {
+        const uint64_t *gp = src + ((lane >> 5) * T + 64u * wv + 2u * (lane & 31u));
+#pragma unroll
+        for (int j = 0; j < 8; j++) glds16(gp + (size_t)j * 2 * T, pw_addr + (unsigned)j * 1024u);
+    };
+
+    unsigned t = 0;
+    unsigned w = item_of(0);
+    if (w == ~0u) return;
+    Item cur = decode(w);
+    dma_digit(digit_src(cur, 0), lane);
+    for (;;) {
+        double acc0[16], acc1[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { acc0[k] = 0.0; acc1[k] = 0.0; }
+        const double q = cur.q, qi = cur.qi;
+        // round-1 twiddles of this row -> LDS (consumed after the first exchange barrier of the first transformed digit; the
+        // previous item's readers are all past their last round 1: every wave crossed that digit's later barriers)
+        if (tau < 240u) {
+            const unsigned hi = tau / 15u, idx = tau - hi * 15u, u = 31u - (unsigned)__builtin_clz(idx + 1u), j = idx + 1u - (1u << u);
+            tw1s[tau] = cur.tw[((unsigned)cur.rowtw << (4 + u)) + (hi << u) + j];  // its wait is the first digit's (below)
+        }
+        bool more = false;
+        for (int d = 0; d < A.m.beta; d++) {
+            const bool is_own = own_digit(cur, d);
+            // loop-invariant address arithmetic is recomputed per digit from an opaque copy of the thread index: hoisted out of
+            // the loops it costs more registers than the kernel has
+            unsigned tau_d = threadIdx.x;
+            asm volatile("" : "+v"(tau_d));
+            const unsigned tau = tau_d, lane = tau & 63u;
+            const double *pw = pbuf + wv * 1024u + lane;
+            // the digit in flight has landed (this also retires every older vector load of the wave)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint64_t xi[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) xi[k] = (uint64_t)__double_as_longlong(pw[k * 64]);
+            double x[16];
+            if (is_own && A.m.own_reduce) {  // caller-supplied words (any uint64, as MulCoeffsMontgomeryLazy accepts): bring them below 2^52
+#pragma unroll
+                for (int k = 0; k < 16; k++) xi[k] = bred_add_lazy(xi[k], ldc(reinterpret_cast<const uint64_t *>(A.mc + cur.mi), 0), ldc(reinterpret_cast<const uint64_t *>(A.mc + cur.mi), 2));
+            }
+            if (A.m.dec_f64 && !is_own) {  // the basis extension left doubles (launch_modup_fused, f64_raw)
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = __longlong_as_double((long long)xi[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = u52_to_f64(xi[k]);
+            }
+            // what the prefetch buffer receives next (block-uniform): the next digit, or the next item's first
+            const bool last = d + 1 == A.m.beta;
+            const uint64_t *nsrc;
+            if (!last) {
+                nsrc = digit_src(cur, d + 1);
+            } else {
+                w = item_of(++t);
+                more = w != ~0u;
+                nsrc = more ? digit_src(decode(w), 0) : nullptr;
+            }
+            const double *k0p = cur.kbase + (size_t)d * A.m.key_dstride + tau, *k1p = k0p + A.m.key_kstride;
+            double kk0[16], kk1[16];
+            if (!is_own) {
+                // round-2 twiddles first, then the DMA: ordinary loads issued after it could only return after it
+                double t2[15];
+                rows_tw16_f64(t2, cur.tw, cur.rowtw, 8, tau >> (LOGB - 12));
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the buffer have returned
+                if (nsrc) dma_digit(nsrc, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                {   // round 0: the fifteen twiddles are the same for every thread of the workgroup -> scalar cache, scalar registers
+                    double t0[15];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int j = 0; j < (1 << u); j++) t0[(1 << u) - 1 + j] = ldcd(cur.tw, (size_t)(((unsigned)cur.rowtw << u) + j));
+                    rows_round16_f64<false>(x, t0, q, qi);
+                }
+                __syncthreads();  // every wave is done with the tile (previous digit's last read) -- and tw1s is in place
+                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 0, LOGB - 4, true);
+                __syncthreads();
+                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, false);
+                {
+                    double t1[15];
+                    const double *tp = tw1s + (tau >> (LOGB - 8)) * 15u;
+#pragma unroll
+                    for (int i = 0; i < 15; i++) t1[i] = tp[i];
+                    rows_round16_f64<false>(x, t1, q, qi);
+                }
+                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, true);
+                rows_sync(LOGB - 8);
+                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, false);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 16; k++) kk0[k] = k0p[(unsigned)(k * T)];
+                __builtin_amdgcn_sched_barrier(0);
+                rows_round16_f64<false>(x, t2, q, qi);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
+                __builtin_amdgcn_sched_barrier(0);
+                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, true);
+                if constexpr (GREM > 0) {
+                    rows_sync(LOGB - 12);
+                    rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, 12, 0, false);
+                    rows_round_f64<GREM, false>(x, cur.tw, cur.rowtw, 12, 0, tau, 0, q, qi);
+                    rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, 12, 0, true);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = lds[lds_phys(k * T + tau)];
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (nsrc) dma_digit(nsrc, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 16; k++) kk0[k] = k0p[(unsigned)(k * T)];
+#pragma unroll
+                for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc0[k] += modmul_f64(x[k], kk0[k], q, qi);
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc1[k] += modmul_f64(x[k], kk1[k], q, qi);
+        }
+        const int ol = cur.out_limb;
+        uint64_t *o0 = (cur.isP ? A.o0P + cur.bz * A.oP0_bs : A.o0Q + cur.bz * A.oQ0_bs) + (size_t)ol * A.N + cur.rowoff + tau;
+        uint64_t *o1 = (cur.isP ? A.o1P + cur.bz * A.oP1_bs : A.o1Q + cur.bz * A.oQ1_bs) + (size_t)ol * A.N + cur.rowoff + tau;
+        if constexpr (QF64) {  // the f64 ModDown epilogue reads these as doubles
+            double *d0 = reinterpret_cast<double *>(o0), *d1 = reinterpret_cast<double *>(o1);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                stnt(&d0[(unsigned)(k * T)], reduce_f64(acc0[k], q, qi));
+                stnt(&d1[(unsigned)(k * T)], reduce_f64(acc1[k], q, qi));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                o0[(unsigned)(k * T)] = canon_f64(acc0[k], q, qi);
+                o1[(unsigned)(k * T)] = canon_f64(acc1[k], q, qi);
+            }
+        }
+        if (!more) break;
+        cur = decode(w);
+    }
+}
+
+// workgroups the chip holds at once at this kernel's occupancy (two per CU with 256 threads, one with 512)
+static unsigned mac_resident_workgroups(int logb) {
+    static const unsigned cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return (unsigned)n;
+    }();
+    static const unsigned forced = getenv("HERING_MAC_WGS") ? (unsigned)atoi(getenv("HERING_MAC_WGS")) : 0u;
+    return forced ? forced : (logb >= 13 ? cus : 2u * cus);
+}
+
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
                               View out0P, View out1Q, View out1P, int batch, hipStream_t s) {
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
@@ -1065,6 +1324,33 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
     A.mc = r.mc; A.twd = r.twd_fwd; A.N = r.N; A.a = aa; A.m = a;
+    static const bool plain_only = getenv("HERING_MAC_PLAIN") && atoi(getenv("HERING_MAC_PLAIN")) != 0;
+    if ((b == 12 || b == 13) && !plain_only) {
+        NttMacDmaArgs D;
+        D.k = A;
+        D.nbatch = (unsigned)batch;
+        D.nitems = (unsigned)batch * (unsigned)a.nlimbs * (1u << aa);
+        for (int i = 0; i < a.nlimbs; i++)
+            D.limb_info[i] = (uint64_t)a.mod[i] | (uint64_t)a.key_limb[i] << 8 | (uint64_t)a.dec_limb[i] << 16 |
+                             (uint64_t)a.out_limb[i] << 24 | (uint64_t)a.out_view[i] << 32;
+        // as many workgroups as run at once, every one with the same number of items (rounded up)
+        unsigned G = mac_resident_workgroups(b);
+        if (D.nitems <= G) G = D.nitems;
+        else {
+            const unsigned per = (D.nitems + G - 1) / G;
+            G = (D.nitems + per - 1) / per;
+            if ((D.nitems & 7u) == 0) G = (G + 7u) & ~7u;
+        }
+        ProfScope ps(K_NTT_MAC_F64, s);
+        if (b == 12) {
+            if (a.q_out_f64) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, true>), dim3(G), dim3(256), 0, s, D);
+            else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false>), dim3(G), dim3(256), 0, s, D);
+        } else {
+            if (a.q_out_f64) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, true>), dim3(G), dim3(512), 0, s, D);
+            else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, false>), dim3(G), dim3(512), 0, s, D);
+        }
+        return hipGetLastError();
+    }
     dim3 grid(batch, a.nlimbs, 1u << aa);
 #ifdef HE_MAC_STAMPS
     {   // diagnosis build only: HERING_MAC_ABL makes the key (1, 8), input (2) and output (4) streams cache-resident
@@ -1847,14 +2133,6 @@ struct ModUpFusedArgs {
     int f64_raw;  // double-precision destinations are stored as the doubles they are (|x| < 64 p, unreduced): the consumer is a
                   // double-precision row kernel told so (NttMacArgs::dec_f64 / NTT_INPUT_F64), six instructions per word saved here
 };
-
-// block-uniform 64-bit constants through the scalar cache: the constant address space tells the compiler that the table is
-// never written by a kernel, so a load with a uniform address becomes an s_load instead of a vector load + wait
-typedef const uint64_t __attribute__((address_space(4))) *he_cptr64;
-__device__ __forceinline__ uint64_t ldc(const uint64_t *p, size_t i) { return ((he_cptr64)(uintptr_t)p)[i]; }
-typedef const double __attribute__((address_space(4))) *he_cptrd;
-__device__ __forceinline__ double ldcd(const double *p, size_t i) { return ((he_cptrd)(uintptr_t)p)[i]; }
-__device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }  // v_mad_u64_u32
 
 // DSTF64 = false: destinations in 64-bit integer arithmetic (any modulus).
 // DSTF64 = true : only destination moduli below 2^47, the mat-vec and the column stages in exact double-precision
