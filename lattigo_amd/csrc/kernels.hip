@@ -1084,6 +1084,64 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
 //    order they are needed (the DMA is issued after the first, and has the whole digit to land).
 // Bit-identical to the plain kernel (same arithmetic on the same operands).
 // ------------------------------------------------------------------------------------
+
+// The same forward radix-16 round with the instruction order pinned for a LONE wave: a dependent v_*_f64 issues every ~10 cycles,
+// an independent one every ~5 (tools/latency_probe.hip); two waves on a SIMD hide that between them, but a wave whose partner is
+// parked at a barrier or a load runs the compiler's back-to-back dependent sequence (mul -> mul -> rndne -> fma -> add) at half
+// rate.  Here four butterflies advance together, one sub-operation at a time, and scheduling barriers keep the groups apart, so
+// every instruction's producer is at least three instructions behind it.
+#ifndef HE_MAC_ILP
+#define HE_MAC_ILP 1
+#endif
+__device__ __forceinline__ void rows_round16_f64_ilp(double (&x)[16], const double (&t)[15], double q, double qi) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int d = 1 << (3 - u);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            int kk[4];
+            {
+                int n = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {  // the butterflies (k, k + d) of this stage, four at a time
+                    if ((k & d) || n >= 4) continue;
+                    int cnt = 0;
+#pragma unroll
+                    for (int k2 = 0; k2 < k; k2++) if (!(k2 & d)) cnt++;
+                    if (cnt < 4 * half) continue;
+                    kk[n++] = k;
+                }
+            }
+            double h[4], l[4], c[4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) h[i] = x[kk[i] + d] * t[(1 << u) - 1 + (kk[i] >> (4 - u))];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                l[i] = __fma_rn(x[kk[i] + d], t[(1 << u) - 1 + (kk[i] >> (4 - u))], -h[i]);
+                c[i] = h[i] * qi;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) c[i] = rint(c[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) h[i] = __fma_rn(-c[i], q, h[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) h[i] = h[i] + l[i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double U = x[kk[i]];
+                x[kk[i]] = U + h[i];
+                x[kk[i] + d] = U - h[i];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
 typedef __attribute__((address_space(3))) void *he_lds_ptr;
 __device__ __forceinline__ unsigned lds_byte_addr(const void *p) { return (unsigned)(uintptr_t)(he_lds_ptr)p; }
 // one LDS-DMA instruction: lane i's 16 bytes at gsrc land at LDS byte lds_dst + 16 i (lds_dst wave-uniform).  hipcc does not
@@ -1100,6 +1158,15 @@ struct NttMacDmaArgs {
     // byte picked from the by-value arrays with a run-time index is a vector load, and waiting for it would drain the prefetch)
     uint64_t limb_info[kMaxLimbs];
 };
+#ifdef HE_MAC_STAMPS
+// diagnosis build: s_memtime at the phase boundaries of every workgroup's item number HE_MAC_STAMP_ITEM (tools/mac_timeline.py --dma)
+#ifndef HE_MAC_STAMP_ITEM
+#define HE_MAC_STAMP_ITEM 10
+#endif
+#define MAC_STAMP2(i) do { __builtin_amdgcn_sched_barrier(0); if (t_cur == HE_MAC_STAMP_ITEM && g < 512u && (threadIdx.x & 63u) == 0) g_mac_stamps[((g * 4 + (threadIdx.x >> 6)) * 64) + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MAC_STAMP2(i) do {} while (0)
+#endif
 template <int LOGB, bool QF64>
 __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(NttMacDmaArgs AA) {
     static_assert(LOGB == 12 || LOGB == 13, "production row sizes only");
@@ -1168,6 +1235,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
     Item cur = decode(w);
     dma_digit(digit_src(cur, 0), lane);
     for (;;) {
+        const unsigned t_cur = t; (void)t_cur;
+        MAC_STAMP2(0);
         double acc0[16], acc1[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) { acc0[k] = 0.0; acc1[k] = 0.0; }
@@ -1187,6 +1256,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
             asm volatile("" : "+v"(tau_d));
             const unsigned tau = tau_d, lane = tau & 63u;
             const double *pw = pbuf + wv * 1024u + lane;
+            MAC_STAMP2(1 + d * 12 + 0);
             // the digit in flight has landed (this also retires every older vector load of the wave)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             uint64_t xi[16];
@@ -1204,6 +1274,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #pragma unroll
                 for (int k = 0; k < 16; k++) x[k] = u52_to_f64(xi[k]);
             }
+            MAC_STAMP2(1 + d * 12 + 1);
             // what the prefetch buffer receives next (block-uniform): the next digit, or the next item's first
             const bool last = d + 1 == A.m.beta;
             const uint64_t *nsrc;
@@ -1224,37 +1295,43 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the buffer have returned
                 if (nsrc) dma_digit(nsrc, lane);
                 __builtin_amdgcn_sched_barrier(0);
+                MAC_STAMP2(1 + d * 12 + 2);
                 {   // round 0: the fifteen twiddles are the same for every thread of the workgroup -> scalar cache, scalar registers
                     double t0[15];
 #pragma unroll
                     for (int u = 0; u < 4; u++)
 #pragma unroll
                         for (int j = 0; j < (1 << u); j++) t0[(1 << u) - 1 + j] = ldcd(cur.tw, (size_t)(((unsigned)cur.rowtw << u) + j));
-                    rows_round16_f64<false>(x, t0, q, qi);
+                    if constexpr (HE_MAC_ILP) rows_round16_f64_ilp(x, t0, q, qi); else rows_round16_f64<false>(x, t0, q, qi);
                 }
+                MAC_STAMP2(1 + d * 12 + 3);
                 __syncthreads();  // every wave is done with the tile (previous digit's last read) -- and tw1s is in place
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 0, LOGB - 4, true);
                 __syncthreads();
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, false);
+                MAC_STAMP2(1 + d * 12 + 4);
                 {
                     double t1[15];
                     const double *tp = tw1s + (tau >> (LOGB - 8)) * 15u;
 #pragma unroll
                     for (int i = 0; i < 15; i++) t1[i] = tp[i];
-                    rows_round16_f64<false>(x, t1, q, qi);
+                    if constexpr (HE_MAC_ILP) rows_round16_f64_ilp(x, t1, q, qi); else rows_round16_f64<false>(x, t1, q, qi);
                 }
+                MAC_STAMP2(1 + d * 12 + 5);
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, true);
                 rows_sync(LOGB - 8);
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, false);
+                MAC_STAMP2(1 + d * 12 + 6);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 16; k++) kk0[k] = k0p[(unsigned)(k * T)];
                 __builtin_amdgcn_sched_barrier(0);
-                rows_round16_f64<false>(x, t2, q, qi);
+                if constexpr (HE_MAC_ILP) rows_round16_f64_ilp(x, t2, q, qi); else rows_round16_f64<false>(x, t2, q, qi);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
                 __builtin_amdgcn_sched_barrier(0);
+                MAC_STAMP2(1 + d * 12 + 7);
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, true);
                 if constexpr (GREM > 0) {
                     rows_sync(LOGB - 12);
@@ -1275,10 +1352,13 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
                 __builtin_amdgcn_sched_barrier(0);
             }
+            MAC_STAMP2(1 + d * 12 + 8);
 #pragma unroll
             for (int k = 0; k < 16; k++) acc0[k] += modmul_f64(x[k], kk0[k], q, qi);
+            MAC_STAMP2(1 + d * 12 + 9);
 #pragma unroll
             for (int k = 0; k < 16; k++) acc1[k] += modmul_f64(x[k], kk1[k], q, qi);
+            MAC_STAMP2(1 + d * 12 + 10);
         }
         const int ol = cur.out_limb;
         uint64_t *o0 = (cur.isP ? A.o0P + cur.bz * A.oP0_bs : A.o0Q + cur.bz * A.oQ0_bs) + (size_t)ol * A.N + cur.rowoff + tau;
@@ -1297,6 +1377,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 o1[(unsigned)(k * T)] = canon_f64(acc1[k], q, qi);
             }
         }
+        MAC_STAMP2(60);
         if (!more) break;
         cur = decode(w);
     }

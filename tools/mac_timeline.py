@@ -19,17 +19,23 @@ buf = (C.c_uint64 * n)()
 rc = lib.he_debug_mac_stamps(buf, n)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 64).astype(np.int64)
 names = ["start", "r0pre", "r0post", "x0", "r1pre", "r1post", "x1", "r2pre", "r2post", "x2(bar)", "mac", "endbar"]
+if "--dma" in sys.argv:  # the persistent LDS-DMA kernel: item HE_MAC_STAMP_ITEM of every workgroup
+    names = ["start", "dma-wait+read", "tw2+dma issue", "round0", "bar+x1", "round1", "x2", "k0+round2+k1", "x3(bar)", "mac0", "mac1", "-"]
 print("rc", rc, "nonzero rows", int((a[:, 0] > 0).sum()))
 a = a[a[:, 0] > 0]
 for dg in range(4):
     st = a[:, 1 + 12 * dg: 1 + 12 * dg + 12]
-    full = st[(st > 0).all(axis=1)]
-    own = st[(st[:, 1] == 0) & (st[:, 0] > 0)]
+    full = st[(st[:, :11] > 0).all(axis=1)][:, :11] if "--dma" in sys.argv else st[(st > 0).all(axis=1)]
+    dma = "--dma" in sys.argv
+    own = st[(st[:, 2 if dma else 1] == 0) & (st[:, 0] > 0)]
     if len(full):
         seg = np.diff(full, axis=1)
-        print("digit", dg, "waves", len(full), {names[i + 1]: int(np.median(seg[:, i])) for i in range(11)}, "sum", int(np.median(seg.sum(axis=1))))
-    if len(own):
+        print("digit", dg, "waves", len(full), {names[i + 1]: int(np.median(seg[:, i])) for i in range(seg.shape[1])}, "sum", int(np.median(seg.sum(axis=1))))
+    if len(own) and dma:
+        print("digit", dg, "own waves", len(own), {"dma-wait+read": int(np.median(own[:, 1] - own[:, 0])), "dma+key issue": int(np.median(own[:, 8] - own[:, 1])),
+              "mac0": int(np.median(own[:, 9] - own[:, 8])), "mac1": int(np.median(own[:, 10] - own[:, 9]))})
+    elif len(own):
         print("digit", dg, "own waves", len(own), "start->mac", int(np.median(own[:, 10] - own[:, 0])), "mac->endbar", int(np.median(own[:, 11] - own[:, 10])))
 tot = a[:, 60] - a[:, 0]
-print("kernel start -> digit 0:", int(np.median(a[:, 1] - a[:, 0])), "last endbar -> end:", int(np.median(a[:, 60] - a[:, 48])))
+print("item start -> digit 0:", int(np.median(a[:, 1] - a[:, 0])), "last digit's end -> item end:", int(np.median(a[:, 60] - a[:, 47 if "--dma" in sys.argv else 48])))
 print("wave lifetime median", int(np.median(tot)), "p10", int(np.percentile(tot, 10)), "p90", int(np.percentile(tot, 90)))
