@@ -7,14 +7,20 @@ BGV, logN=15, 12 Q-limbs (LogQ=[55,45x11]), 3 P-limbs (LogP=[55x3]), T=65537, ct
 ciphertext pairs already resident in HBM.  Synthetic inputs: coefficients uniform in [0, q_i), PCG64 seed
 0x1A77160 + 2.
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--workload c3|c4|c5]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--workload c2|c3|c4|c5]
 
+--workload c2: BASELINE configs[1], CKKS logN=14, 8-level chain: Evaluator.Mul (degree 2) + Rescale;
 --workload c4: BASELINE configs[3], CKKS logN=16, 20+4 limbs, Rotate (automorphism + Galois key-switch);
 --workload c5: BASELINE configs[4], the operation trace of one CKKS bootstrap at the N16QP1546H192H32 shape.
 N > 1: launched by torch.distributed.run, one rank per GPU; independent ciphertexts are sharded across ranks (weak
 scaling, no data-path collective -- SURVEY.md section 8e); ranks synchronise only for the barrier around the timed region
 and the MAX over ranks of the elapsed time.  After the timed region the output of the LAST step is checked against the CPU
 oracle on three batch entries per rank ("verified"; a mismatch makes the run fail).  Prints ONE JSON line on rank 0.
+
+Byte accounting: per-kernel algorithmic bytes come from the launchers themselves (he_prof_end_bytes:
+every polynomial stream a launch reads or writes, once), per-op algorithmic bytes from the per-primitive formulas of SURVEY.md
+section 8(d) accumulated at the C ABI over the timed operation trace (he_alg_bytes) -- for c3 both are checked against the
+closed forms below, so the model cannot drift from the pipeline again.
 """
 from __future__ import annotations
 
@@ -37,6 +43,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 # GenModuli outputs (core/rlwe/params.go:811) for the configs, pinned (tests/test_gpu_headline.py checks c3 against the
 # oracle's restated GenModuli)
+C2_Q = [1125899908022273, 1099511922689, 1099512938497, 1099510054913, 1099514314753, 1099514478593, 1099508121601,
+        1099507695617]                      # CKKS logN=14, LogQ=[50,40x7] (schemes/ckks/ckks_benchmarks_test.go:24-32)
+C2_P = [1152921504606748673]                # LogP=[60]
 C4_Q = [1152921504606584833, 35184372744193, 35184373006337, 35184368025601, 35184376545281, 35184377331713, 35184378511361,
         35184379035649, 35184365273089, 35184380870657, 35184363569153, 35184382967809, 35184383229953, 35184383754241,
         35184385196033, 35184358850561, 35184386899969, 35184388734977, 35184355704833, 35184353083393]
@@ -75,31 +84,38 @@ def physical_cores():
         return None
 
 
-def cpu_baseline(q, p, kq, kp, seconds=12.0):
-    """The restated reference (oracle/, a scalar C port) timed on the host cores: independent MulRelin calls on one shared
-    evaluator from n OS threads -- a C-level pthread loop with pooled scratch, the shape of the reference's own parallel
-    benchmarks (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:95-325; scratch from core/rlwe/pool.go).  Thread counts
-    1 / 16 / 64 / all logical CPUs are reported so that the scaling is visible; `value` is the best of them."""
+def cpu_baseline(kind, N, q, p, kq, kp, unit, what, seconds=12.0, t=0, gal=0):
+    """The restated reference (oracle/, a scalar C port -- NOT Lattigo's Go code, which cannot be built here) timed on the host
+    cores: independent calls on one shared evaluator from n OS threads -- a C-level pthread loop with pooled scratch, the shape
+    of the reference's own parallel benchmarks (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:95-325; scratch from
+    core/rlwe/pool.go).  Every thread is pinned to one CPU and works on its own first-touched copy of the inputs and the key
+    (NUMA placement; round 2's shared copy made the rate fall beyond 16 threads).  Thread counts 1 / 16 / 64 / physical cores /
+    logical CPUs are reported so that the scaling is visible; `value` is the best of them."""
     from oracle import oracle as O
-    N = 1 << LOGN
     logical = os.cpu_count() or 1
-    ringQ, ringP = O.Ring(N, q), O.Ring(N, p)
-    ev = O.Evaluator(ringQ, ringP)
-    rlk = O.EvaluationKey(kq, kp)
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    phys = physical_cores()
+    ev = O.Evaluator(O.Ring(N, q), O.Ring(N, p))
+    key = O.EvaluationKey(kq, kp) if kq is not None else None
     rng = np.random.Generator(np.random.PCG64(0x1A77160 + 2))
-    ct0, ct1 = uniform(rng, q, N, (2,)), uniform(rng, q, N, (2,))
-    counts = sorted({1, min(16, logical), min(64, logical), logical})
+    ct0 = uniform(rng, q, N, (2,))
+    ct1 = uniform(rng, q, N, (2,)) if kind != "rotate" else None
+    counts = sorted({1, min(16, logical), min(64, logical), min(phys or logical, logical), logical})
     per = seconds / len(counts)
     sweep, best = {}, (0.0, 1, "")
     for n in counts:
-        done, dt = ev.BenchBGVMulRelin(T, ct0, ct1, rlk, n, per)
+        done, dt = ev.BenchOp(kind, ct0, ct1, key, t=t, gal=gal, nthreads=n, seconds=per)
         rate = done / dt
         sweep[str(n)] = rate
         if rate > best[0]:
-            best = (rate, n, f"{done} BGV MulRelin (logN=15, 12+3 limbs) on {n} threads in {dt:.1f}s")
-    return {"value": best[0], "unit": "ctxt-mul+relin ops/s", "cores": best[1], "kind": "port", "sample": best[2],
-            "threads_sweep_ops_s": sweep, "logical_cpus": logical, "physical_cores": physical_cores(),
-            "single_thread_ops_s": sweep["1"]}
+            best = (rate, n, f"{done} {what} on {n} pinned threads in {dt:.1f}s")
+    return {"value": best[0], "unit": unit, "cores": best[1], "kind": "port", "sample": best[2],
+            "threads_sweep_ops_s": sweep, "logical_cpus": logical, "physical_cores": phys,
+            "single_thread_ops_s": sweep["1"],
+            "note": "scalar C restatement of the reference (oracle/), one pinned thread per CPU with private copies of inputs and key; not the Go code"}
 
 
 # -------------------------------------------------------------------------------------------------------------------
@@ -162,16 +178,19 @@ def setup_c3(la, ctx, rank, B, cp, args):
     nsq, nsp = sum(small_q), sum(small_p)
     n_small = nsq + nsp
     n_big = L + alpha - n_small
-    # algorithmic bytes per step of each kernel family (what the kernel must read + write once for B ciphertexts; twiddles /
-    # constants excluded, resident); see DESIGN.md section 4 for the pipeline these follow
+    # algorithmic bytes per step of each kernel family in closed form (what the kernel must read + write once for B ciphertexts;
+    # twiddles / constants excluded, resident), for the pipeline of DESIGN.md section 4 WITH the tensor product formed in the ModDown
+    # epilogue: the tensor kernel reads a1, b1 and writes c2; the forward rows of the epilogue read the extension, the
+    # accumulator and the four inputs of the product (shared by the two components of an entry) and write the result.  main()
+    # checks the library's own per-launch accounting against these.
     kernel_bytes = {
         "ntt_mac_f64": ((dec_small + nsq) * B + 2 * beta * n_small + 2 * n_small * B) * limb,
-        "ntt_rows_fwd_f64": 4 * 2 * nsq * limb * B,
-        "ntt_rows_fwd": (2 * dec_big + 4 * 2 * (L - nsq)) * limb * B,
+        "ntt_rows_fwd_f64": (2 * (1 + 1 + 1) + 4) * nsq * limb * B,
+        "ntt_rows_fwd": (2 * dec_big + (2 * (1 + 1 + 1) + 4) * (L - nsq)) * limb * B,
         "ntt_rows_inv_f64": 2 * (nsq + 2 * nsp) * limb * B,
         "ntt_rows_inv": 2 * ((L - nsq) + 2 * (alpha - nsp)) * limb * B,
         "ks_inner": (beta * n_big * B + 2 * beta * n_big + 2 * n_big * B) * limb,
-        "tensor": 7 * L * limb * B,
+        "tensor": 3 * L * limb * B,
         "modup": (L + nonown + 2 * alpha + 2 * L) * limb * B,
     }
     return {
@@ -181,10 +200,56 @@ def setup_c3(la, ctx, rank, B, cp, args):
         # serves the B ciphertexts of a step, so the batch-amortised figure is 6L limbs + key / B
         "alg_bytes_per_op": (6 * L + 2 * beta * (L + alpha)) * limb,
         "alg_bytes_per_op_amortised": 6 * L * limb + 2 * beta * (L + alpha) * limb / B,
-        "cpu": lambda: cpu_baseline(q, p, np.ascontiguousarray(kq), np.ascontiguousarray(kp)),
+        "cpu": lambda: cpu_baseline("bgv_mulrelin", N, q, p, np.ascontiguousarray(kq), np.ascontiguousarray(kp),
+                                    "ctxt-mul+relin ops/s", "BGV MulRelin (logN=15, 12+3 limbs)", t=T),
         "config": {"workload": "BGV logN=15, 12 Q-limbs [55,45x11] + 3 P-limbs [55x3], T=65537: ct x ct MulRelin "
                                "(tensor + gadget product + ModDown), inputs resident in HBM",
                    "batch_per_gpu": B, "logN": LOGN, "L": L, "alpha": alpha, "beta": beta},
+    }
+
+
+def setup_c2(la, ctx, rank, B, cp, args):
+    """BASELINE configs[1]: CKKS logN=14, 8-level chain, Evaluator.Mul (degree-2 result, no relinearisation) + Rescale of the
+    three polynomials (schemes/ckks/evaluator.go:764-872, :477-515; the reference's BenchmarkCKKS Mul / Rescale pair)."""
+    logN, q, p = 14, C2_Q, C2_P
+    N, L = 1 << logN, len(q)
+    ringQ, ringP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+    ev = la.Evaluator(ringQ, ringP)
+    rng = np.random.Generator(np.random.PCG64(0x1A77160 + 1 + 1000 * rank))
+    keep = pick_entries(B)
+    host_in, a, b = [], [], []
+    for dst in (a, a, b, b):
+        h = uniform(rng, q, N, (B,))
+        dst.append(la.Poly(ringQ, L, B).upload(h))
+        host_in.append(h[keep].copy())
+        del h
+    o3 = [la.Poly(ringQ, L, B) for _ in range(3)]
+    r3 = [la.Poly(ringQ, L - 1, B) for _ in range(3)]
+
+    def step():
+        ev.CKKSMulRelin(L - 1, a, b, None, o3)
+        ev.Rescale(L - 1, 1, o3, r3)
+
+    def verify():
+        from oracle import oracle as O
+        oev = O.Evaluator(O.Ring(N, q), O.Ring(N, p))
+        for i, e in enumerate(keep):
+            want = oev.Rescale(oev.CKKSMulRelin(np.stack([host_in[0][i], host_in[1][i]]), np.stack([host_in[2][i], host_in[3][i]]), None, False))
+            for k in range(3):
+                for limb in range(L - 1):
+                    if not np.array_equal(r3[k].download_limb(e, limb), want[k][limb]):
+                        return False, f"batch entry {e}, component {k}, limb {limb} differs from the oracle"
+        return True, f"entries {keep} x {L - 1} limbs x 3 components equal oracle Rescale(Mul)"
+
+    limb = N * 8
+    return {
+        "metric": "ciphertext mul+rescale ops/s", "unit": "ctxt-mul+rescale ops/s", "step": step, "units": B, "verify": verify,
+        "kernel_bytes": None,
+        "alg_bytes_per_op": (7 * L + 3 * (2 * L - 1)) * limb,  # SURVEY.md section 8(d), C2: Mul 7 L + Rescale 3 (2L - 1) = 12.625 MiB
+        "alg_bytes_per_op_amortised": (7 * L + 3 * (2 * L - 1)) * limb,
+        "cpu": lambda: cpu_baseline("ckks_mul_rescale", N, q, p, None, None, "ctxt-mul+rescale ops/s", "CKKS Mul + Rescale (logN=14, 8 limbs)"),
+        "config": {"workload": "CKKS logN=14, 8 Q-limbs [50,40x7] (+ 1 P-limb, unused): ct x ct Mul (degree 2) + Rescale of the three "
+                               "polynomials, inputs resident in HBM", "batch_per_gpu": B, "logN": logN, "L": L},
     }
 
 
@@ -228,10 +293,10 @@ def setup_c4(la, ctx, rank, B, cp, args):
     limb = N * 8
     return {
         "metric": "ciphertext rotate ops/s", "unit": "ctxt-rotate ops/s", "step": step, "units": B, "verify": verify,
-        "kernel_bytes": {},
+        "kernel_bytes": None,
         "alg_bytes_per_op": (4 * L + 2 * beta * (L + alpha)) * limb,  # 160 MiB
         "alg_bytes_per_op_amortised": 4 * L * limb + 2 * beta * (L + alpha) * limb / B,
-        "cpu": None,
+        "cpu": lambda: cpu_baseline("rotate", N, q, p, kq, kp, "ctxt-rotate ops/s", "CKKS Rotate (logN=16, 20+4 limbs)", gal=gal),
         "config": {"workload": "CKKS logN=16, 20 Q-limbs [60,45x19] + 4 P-limbs [61x4]: Rotate (automorphism + Galois "
                                "key-switch), inputs resident in HBM, Galois key replicated on every GPU",
                    "batch_per_gpu": B, "logN": logN, "L": L, "alpha": alpha, "beta": beta},
@@ -243,7 +308,8 @@ def setup_c5(la, ctx, rank, B, cp, args):
     import bootstrap_c5_shape as C5
     run, info = C5.build(ctx, B, seed_offset=1000 * rank)
     return {
-        "metric": "bootstraps/s", "unit": "ctxt-bootstraps/s", "step": run, "units": B, "verify": None, "kernel_bytes": {},
+        "metric": "bootstraps/s", "unit": "ctxt-bootstraps/s", "step": run, "units": B, "verify": None, "kernel_bytes": None,
+        # no closed form: summed over the operation trace by the library (he_alg_bytes), see main()
         "alg_bytes_per_op": None, "alg_bytes_per_op_amortised": None, "cpu": None,
         "config": dict({"workload": "CKKS bootstrap operation trace at the N16QP1546H192H32 shape (logN=16, 25+5 limbs; "
                                     "ModUp, CoeffsToSlots, EvalMod x2, SlotsToCoeffs), synthetic keys and DFT diagonals, "
@@ -251,7 +317,7 @@ def setup_c5(la, ctx, rank, B, cp, args):
     }
 
 
-WORKLOADS = {"c3": (setup_c3, 128), "c4": (setup_c4, 16), "c5": (setup_c5, 4)}
+WORKLOADS = {"c2": (setup_c2, 128), "c3": (setup_c3, 128), "c4": (setup_c4, 32), "c5": (setup_c5, 8)}
 
 
 def ntt_rates(la, ctx):
@@ -285,9 +351,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed configuration's output")
     ap.add_argument("--no-ntt", action="store_true", help="skip the stand-alone NTT/s measurement")
-    ap.add_argument("--replicate-keys", choices=["none", "rccl", "host"], default="none",
+    ap.add_argument("--no-b1", action="store_true", help="skip the single-ciphertext (batch 1) rate / latency measurement")
+    ap.add_argument("--replicate-keys", choices=["auto", "none", "rccl", "host"], default="auto",
                     help="N > 1: rank 0's evaluation key is replicated to every rank before the timed region (RCCL broadcast "
-                         "into the key's device storage, or gloo through host memory) instead of each rank drawing its own")
+                         "into the key's device storage, or gloo through host memory) instead of each rank drawing its own; "
+                         "auto = rccl when the node has a GPU per rank, none otherwise")
     ap.add_argument("--microbench", action="store_true", help="also report the modular-multiply probe")
     args = ap.parse_args()
 
@@ -297,6 +365,12 @@ def main():
     if world > 1:
         import torch
         torch.cuda.set_device(int(os.environ.get("HERING_FORCE_DEVICE", local_rank)))
+    if args.replicate_keys == "auto":
+        args.replicate_keys = "none"
+        if world > 1 and "HERING_FORCE_DEVICE" not in os.environ:
+            import torch
+            if torch.cuda.device_count() >= world:
+                args.replicate_keys = "rccl"
 
     import lattigo_amd as la
     # HERING_FORCE_DEVICE: test hook to exercise the multi-rank path on a box with fewer GPUs than ranks
@@ -317,14 +391,19 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    ctx.alg_bytes(reset=True)
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
         step()
     ev_ms = ctx.timer_stop()
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = cp.max_over_ranks(elapsed)
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = cp.max_over_ranks(elapsed_rank)
+    elapsed_min = -cp.max_over_ranks(-elapsed_rank)
+    alg_trace = ctx.alg_bytes(reset=True)  # SURVEY 8(d) per-primitive bytes of the timed steps (key per entry, key per call)
+    # what the control plane and (when keys were replicated over RCCL) the RCCL communicator saw
+    ranks_seen = {"control_plane_gloo": int(cp.sum_over_ranks(1.0)), "rccl": cp.rccl_world() if hasattr(cp, "rccl_world") else None}
 
     # ---- parity of what was timed: the output of the last timed step against the oracle, on every rank ------------
     verified, vmsg = None, "skipped"
@@ -346,17 +425,21 @@ def main():
     ctx.prof_begin()
     for _ in range(args.steps):
         step()
-    prof = ctx.prof_end()
+    prof = ctx.prof_end_bytes()  # {kernel: (launches, ms, algorithmic bytes of those launches -- counted by the launchers)}
     total_ms = sum(v[1] for v in prof.values())
-    dom_name, (dom_launches, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1])
-    kb = W["kernel_bytes"]
-    dom_bytes_launch = kb.get(dom_name, 0) * args.steps / max(dom_launches, 1)
+    dom_name, (dom_launches, dom_ms, dom_bytes) = max(prof.items(), key=lambda kv: kv[1][1])
+    kb = {k: v[2] / args.steps for k, v in prof.items()}  # per step
+    kb_check = None
+    if W["kernel_bytes"]:  # closed forms of this workload's pipeline: the library's accounting must agree
+        bad = {k: (kb.get(k), v) for k, v in W["kernel_bytes"].items() if abs(kb.get(k, 0.0) - v) > 0.005 * v}
+        kb_check = "library launch accounting == closed forms of DESIGN.md section 4" if not bad else f"MISMATCH {bad}"
+    dom_bytes_launch = dom_bytes / max(dom_launches, 1)
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     achieved = dom_bytes_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 and dom_bytes_launch else None
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass of this command (FETCH_SIZE x 2 +
     # WRITE_SIZE, the gfx950 correction of the microarch guide; tools/round_artifacts.sh): NOT measured by this run
     traffic, traffic_src = None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "pmc_traffic" in f and f.endswith(".json")), reverse=True):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if pmc.get("batch") == B and pmc.get("workload", "c3") == args.workload and dom_name in pmc.get("kernels", {}):
@@ -364,20 +447,39 @@ def main():
                 break
         except Exception:
             pass
+    kernel_GBs = {k: kb[k] / (v[1] / args.steps * 1e-3) / 1e9 for k, v in prof.items() if kb.get(k) and v[1] > 0}
+    over_peak = {k: g for k, g in kernel_GBs.items() if g > HBM_PEAK_GBS}
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": dom_avg_ms, "launches": dom_launches, "alg_bytes_per_launch": dom_bytes_launch or None,
                 "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
-                "kernel_GBs": {k: kb[k] / (v[1] / args.steps * 1e-3) / 1e9 for k, v in prof.items() if k in kb and v[1] > 0},
-                "kernel_time_sum_ms_per_step": total_ms / args.steps}
-    if W["alg_bytes_per_op"]:
-        per_gpu = value / world
-        roofline["whole_op"] = {
-            "alg_bytes_per_op": W["alg_bytes_per_op"], "achieved_GBs": W["alg_bytes_per_op"] * per_gpu / 1e9,
-            "frac": W["alg_bytes_per_op"] * per_gpu / 1e9 / HBM_PEAK_GBS,
-            "alg_bytes_per_op_batch_amortised": W["alg_bytes_per_op_amortised"],
-            "achieved_GBs_batch_amortised": W["alg_bytes_per_op_amortised"] * per_gpu / 1e9,
-            "frac_batch_amortised": W["alg_bytes_per_op_amortised"] * per_gpu / 1e9 / HBM_PEAK_GBS}
+                "kernel_launches_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+                "kernel_alg_bytes_per_step": {k: kb[k] for k in sorted(kb, key=lambda k: -prof[k][1])},
+                "kernel_GBs": kernel_GBs, "kernel_bytes_check": kb_check,
+                "kernel_bytes_source": "he_prof_end_bytes: every polynomial stream a launch reads or writes, once (csrc/kernels.hip)",
+                "kernel_time_sum_ms_per_step": total_ms / args.steps,
+                "kernel_time_note": "per-launch HIP events inflate kernel times by ~3 %: the sum may exceed ms_per_step"}
+    # per-op algorithmic bytes: SURVEY 8(d)'s per-primitive formulas summed over the timed operation trace by the library
+    per_op_trace = alg_trace[0] / (W["units"] * args.steps)
+    per_op_trace_am = alg_trace[1] / (W["units"] * args.steps)
+    alg_op = W["alg_bytes_per_op"] or per_op_trace
+    alg_op_am = W["alg_bytes_per_op_amortised"] or per_op_trace_am
+    per_gpu = value / world
+    roofline["whole_op"] = {
+        "alg_bytes_per_op": alg_op, "achieved_GBs": alg_op * per_gpu / 1e9, "frac": alg_op * per_gpu / 1e9 / HBM_PEAK_GBS,
+        "alg_bytes_per_op_batch_amortised": alg_op_am, "achieved_GBs_batch_amortised": alg_op_am * per_gpu / 1e9,
+        "frac_batch_amortised": alg_op_am * per_gpu / 1e9 / HBM_PEAK_GBS,
+        "alg_bytes_per_op_from_trace": per_op_trace,
+        "source": ("closed form of SURVEY.md section 8(d); the library's per-primitive accounting of the timed trace gives "
+                   f"{per_op_trace / 2**20:.2f} MiB") if W["alg_bytes_per_op"] else
+                  "SURVEY.md section 8(d) per-primitive formulas summed over the timed operation trace (he_alg_bytes)"}
+    problems = []
+    if over_peak:
+        problems.append(f"kernel_GBs above the HBM peak (stale byte model?): {over_peak}")
+    if kb_check and kb_check.startswith("MISMATCH"):
+        problems.append(kb_check)
+    if W["alg_bytes_per_op"] and abs(per_op_trace - W["alg_bytes_per_op"]) > 0.005 * W["alg_bytes_per_op"]:
+        problems.append(f"per-op trace accounting {per_op_trace} != closed form {W['alg_bytes_per_op']}")
 
     cfg = dict(W["config"])
     cfg["parallelism"] = f"{world} independent replicas, ciphertext-sharded"
@@ -387,8 +489,38 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": cfg, "verified": verified, "verified_detail": vmsg,
         "hip_event_ms_per_step": ev_ms / args.steps,
+        "rank_ms_per_step": {"min": elapsed_min / args.steps * 1e3, "max": elapsed / args.steps * 1e3},
+        "ranks_seen": ranks_seen, "replicate_keys": args.replicate_keys,
         "roofline": roofline,
     }
+    if problems:
+        line["accounting_problems"] = problems
+    if not args.no_b1 and world == 1 and args.workload != "c5" and B != 1:
+        # single-ciphertext figures ("report best and B=1"): the same operation on ONE ciphertext
+        W1 = setup(la, ctx, rank, 1, cp, args)
+        for _ in range(5):
+            W1["step"]()
+        ctx.sync()
+        n1 = 200
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            W1["step"]()
+        ctx.sync()
+        dt1 = (time.perf_counter() - t1) / n1
+        line["b1"] = {"batch": 1, "ops_per_s": 1.0 / dt1, "latency_ms": dt1 * 1e3,
+                      "note": "one ciphertext per call, back-to-back calls on one stream, host wall clock incl. launch overhead"}
+        del W1
+    elif args.workload == "c5" and world == 1 and not args.no_b1 and B != 1:
+        W1 = setup(la, ctx, rank, 1, cp, args)
+        W1["step"]()
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            W1["step"]()
+        ctx.sync()
+        dt1 = (time.perf_counter() - t1) / 3
+        line["b1"] = {"batch": 1, "ops_per_s": 1.0 / dt1, "latency_ms": dt1 * 1e3, "note": "one ciphertext per bootstrap"}
+        del W1
     if not args.no_ntt:
         line["ntt"] = ntt_rates(la, ctx)
         line["ntt_limb_per_s"] = line["ntt"]["logN15_L12"]["limb_ntt_per_s"]
@@ -403,6 +535,8 @@ def main():
     cp.close()
     if verified is False:
         sys.exit(3)
+    if problems:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

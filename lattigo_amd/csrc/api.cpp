@@ -67,6 +67,15 @@ struct Ctx : Obj {
     uint64_t *arena = nullptr;
     size_t arena_words = 0, arena_used = 0;
     std::mutex mu;
+    // Algorithmic HBM bytes of the primitives called on this context, by the per-primitive formulas of SURVEY.md section 8(d)
+    // (ideal single pass: every operand read once, every result written once; twiddles / constants / index tables excluded):
+    // [0] with an evaluation key charged to every batch entry, [1] with one key read serving the whole batch.  bench.py sums
+    // them over a workload's operation trace (he_alg_bytes, hering_debug.h); accounted where a call takes the context lock.
+    double alg_bytes[2] = {0.0, 0.0};
+    void acct(double per_entry_limbs, double shared_limbs, int batch, int N) {
+        alg_bytes[0] += (per_entry_limbs + shared_limbs) * batch * (double)N * 8.0;
+        alg_bytes[1] += (per_entry_limbs * batch + shared_limbs) * (double)N * 8.0;
+    }
     // size-keyed cache of polynomial buffers: the drivers above the ABI allocate and drop temporaries per call, and
     // hipMalloc/hipFree synchronise the device.  Reuse is stream-ordered (one stream per context), so a buffer can be
     // handed out again without waiting for the kernels that last touched it.
@@ -294,6 +303,7 @@ struct FusedGroup {
     ModUpDesc *dev;
     int n, nsrc;
     int dst_classes;  // bit 0: some destination modulus >= 2^47, bit 1: some below
+    int total_limbs;  // source + destination limbs over the group's descriptors
 };
 struct FusedPlan {
     bool ok = false;
@@ -441,7 +451,7 @@ int upload_shoup_tables(const std::vector<const SubRingHost *> &subs, int N, uin
     bool any = false;
     for (auto *s : subs) any = any || modulus_class(s->mc.q) != 2;
     if (!any || n == 0) return HE_OK;
-    std::vector<uint64_t> tf, ti(n * (size_t)N * 2, 0);
+    std::vector<uint64_t> ti(n * (size_t)N * 2, 0);
     for (size_t i = 0; i < n; i++) {
         const ModConst &m = subs[i]->mc;
         if (modulus_class(m.q) == 2) continue;  // double-precision limbs never take the integer kernels when twd exists
@@ -450,8 +460,7 @@ int upload_shoup_tables(const std::vector<const SubRingHost *> &subs, int N, uin
             ti[(i * (size_t)N + j) * 2] = wi; ti[(i * (size_t)N + j) * 2 + 1] = (uint64_t)(((u128)wi << 64) / m.q);
         }
     }
-    // only the backward table is in use (the forward kernel does not gain from the paired twiddles, see launch_rows_nc)
-    (void)tf;
+    // only the backward table exists (the forward kernel does not gain from the paired twiddles, see launch_rows_nc): *d_f stays null
     HIP_TRY(hipMalloc((void **)d_i, ti.size() * 8));
     HIP_TRY(hipMemcpy(*d_i, ti.data(), ti.size() * 8, hipMemcpyHostToDevice));
     return HE_OK;
@@ -675,6 +684,7 @@ int he_poly_copy(he_handle hdst, he_handle hsrc, int level) {
     if (d->N != s->N || d->batch != s->batch || level < 0 || d->nlimbs < level + 1 || s->nlimbs < level + 1 || d->ctx != s->ctx)
         return fail(HE_EINVAL, "he_poly_copy: shape or context mismatch");
     Scope sc(d->ctx.get());
+    d->ctx->acct(2.0 * (level + 1), 0, d->batch, d->N);
     HIP_TRY(hipMemcpy2DAsync(d->d, (size_t)d->nlimbs * d->N * 8, s->d, (size_t)s->nlimbs * s->N * 8, (size_t)(level + 1) * d->N * 8,
                              d->batch, hipMemcpyDeviceToDevice, d->ctx->stream));
     return HE_OK;
@@ -686,6 +696,7 @@ int he_poly_copy_batch(he_handle hdst, int dst_b0, he_handle hsrc, int src_b0, i
         dst_b0 + nb > d->batch || src_b0 + nb > s->batch || d->ctx != s->ctx)
         return fail(HE_EINVAL, "he_poly_copy_batch: shape mismatch");
     Scope sc(d->ctx.get());
+    d->ctx->acct(2.0 * (level + 1), 0, nb, d->N);
     const size_t dpitch = (size_t)d->nlimbs * d->N * 8, spitch = (size_t)s->nlimbs * s->N * 8;
     HIP_TRY(hipMemcpy2DAsync((char *)d->d + dst_b0 * dpitch, dpitch, (const char *)s->d + src_b0 * spitch, spitch,
                              (size_t)(level + 1) * d->N * 8, nb, hipMemcpyDeviceToDevice, d->ctx->stream));
@@ -742,6 +753,7 @@ static int ntt_api(he_handle hring, int level, he_handle h1, he_handle h2, bool 
     TRY(check_poly(*p2, *r, level, who));
     if (p1->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
     Scope sc(r->ctx.get());
+    r->ctx->acct(2.0 * (level + 1), 0, p1->batch, r->N);  // NTT / INTT: 2 L limbs
     HIP_TRY(ring_ntt(*r, ident_tab(level + 1), p1->view(), p2->view(), p1->batch, inverse, flags | NTT_REDUCE_INPUT));
     return HE_OK;
 }
@@ -786,6 +798,11 @@ int he_binop(he_handle hring, int level, int op, he_handle h1, he_handle h2, he_
     if (p1->batch != p3->batch) v1.bstride = 0;
     if (p2->batch != p3->batch) v2.bstride = 0;
     Scope sc(r->ctx.get());
+    {   // binary 3 L, ...ThenAdd / ...ThenSub 4 L; a batch-1 operand is read once for the whole batch
+        const bool then = op == EW_MUL_BARRETT_THEN_ADD || op == EW_MUL_BARRETT_THEN_ADD_LAZY || (op >= EW_MUL_MONT_THEN_ADD && op <= EW_MUL_MONT_LAZY_THEN_SUB_LAZY);
+        const double sh = (double)(v1.bstride == 0 && p3->batch > 1) + (double)(v2.bstride == 0 && p3->batch > 1);
+        r->ctx->acct(((then ? 4.0 : 3.0) - sh) * (level + 1), sh * (level + 1), p3->batch, r->N);
+    }
     HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), op, v1, v2, p3->view(), p3->batch, nullptr, nullptr, r->ctx->stream));
     return HE_OK;
 }
@@ -798,11 +815,13 @@ int he_unop(he_handle hring, int level, int op, he_handle h1, he_handle h2) {
     TRY(check_poly(*p2, *r, level, "he_unop"));
     if (p1->batch != p2->batch) return fail(HE_EINVAL, "he_unop: batch mismatch");
     Scope sc(r->ctx.get());
+    r->ctx->acct(2.0 * (level + 1), 0, p2->batch, r->N);  // unary: 2 L
     HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), EW_NEG + op, p1->view(), p1->view(), p2->view(), p2->batch, nullptr, nullptr, r->ctx->stream));
     return HE_OK;
 }
 // scalar given per limb (already what the kernel consumes)
 static int scalar_launch(Ring &r, int level, int ewop, Poly &p1, Poly &p2, const ScalarTab &st) {
+    r.ctx->acct((ewop == EW_MUL_SCALAR_MONT_THEN_ADD ? 3.0 : 2.0) * (level + 1), 0, p2.batch, r.N);  // unary (3 L with the addend)
     HIP_TRY(launch_ew(r.dev, ident_tab(level + 1), ewop, p1.view(), p1.view(), p2.view(), p2.batch, &st, nullptr, r.ctx->stream));
     return HE_OK;
 }
@@ -882,6 +901,7 @@ int he_double_rns_scalarop(he_handle hring, int level, int op, he_handle h1, con
     }
     static const int ops[4] = {EW_ADD_SCALAR, EW_SUB_SCALAR, EW_MUL_SCALAR_MONT, EW_MUL_SCALAR_MONT_THEN_ADD};
     Scope sc(r->ctx.get());
+    r->ctx->acct((op == 3 ? 3.0 : 2.0) * (level + 1), 0, p2->batch, r->N);
     HIP_TRY(launch_ew_double(r->dev, ident_tab(level + 1), ops[op], p1->view(), p2->view(), p2->batch, &st, r->ctx->stream));
     return HE_OK;
 }
@@ -897,6 +917,7 @@ static int shift_api(he_handle hring, int level, he_handle h1, int k, he_handle 
     int kk = k % period;
     if (kk < 0) kk += period;
     Scope sc(r->ctx.get());
+    r->ctx->acct(2.0 * (level + 1), 0, B, N);
     View in = p1->view();
     const LimbTab tab = ident_tab(level + 1);
     if (p1->d == p2->d) {  // in place: stage the input (the reference rotates in place / through a temporary)
@@ -925,6 +946,7 @@ int he_mul_by_vector_montgomery(he_handle hring, int level, he_handle h1, he_han
     View vv = v->view();
     vv.bstride = 0;  // the same vector for every batch entry and (through the limb override) every limb
     Scope sc(r->ctx.get());
+    r->ctx->acct((then_add_lazy ? 3.0 : 2.0) * (level + 1), 1.0, p2->batch, r->N);
     HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), then_add_lazy ? EW_MUL_MONT_THEN_ADD_LAZY : EW_MUL_MONT, vv, p1->view(), p2->view(),
                       p2->batch, nullptr, zeros, r->ctx->stream));
     return HE_OK;
@@ -1047,6 +1069,7 @@ int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, boo
     if (nb < 0 || nb > level) return fail(HE_EINVAL, "%s: cannot divide %d times at level %d", who, nb, level);
     if (p1->N != r->N || p1->nlimbs < level + 1 - nb || p0->batch != p1->batch) return fail(HE_EINVAL, "%s: output shape mismatch", who);
     Scope sc(r->ctx.get());
+    for (int i = 0; i < nb; i++) r->ctx->acct(2.0 * (level - i + 1) - 1.0, 0, p0->batch, r->N);  // rescale: (2 L - 1) per polynomial and step
     hipStream_t st = r->ctx->stream;
     const int B = p0->batch, N = r->N;
     if (nb == 0) {
@@ -1125,6 +1148,7 @@ static int gather_api(he_handle hring, int level, he_handle hin, he_handle hidx,
     if (ix->N != r->N || pin->batch != pout->batch) return fail(HE_EINVAL, "%s: shape mismatch", who);
     if (pin->d == pout->d) return fail(HE_EINVAL, "%s: the automorphism cannot be evaluated in place", who);
     Scope sc(r->ctx.get());
+    r->ctx->acct((add ? 3.0 : 2.0) * (level + 1), 0, pin->batch, r->N);  // automorphism: 2 L (+ L for ...ThenAddLazy)
     HIP_TRY(launch_gather(r->dev, ident_tab(level + 1), pin->view(), ix->d, pout->view(), pin->batch, add, r->ctx->stream));
     return HE_OK;
 }
@@ -1139,6 +1163,7 @@ int he_automorphism(he_handle hring, int level, he_handle hin, uint64_t gal, he_
     if (pin->batch != pout->batch) return fail(HE_EINVAL, "he_automorphism: batch mismatch");
     if (pin->d == pout->d) return fail(HE_EINVAL, "he_automorphism: the automorphism cannot be evaluated in place");
     Scope sc(r->ctx.get());
+    r->ctx->acct(2.0 * (level + 1), 0, pin->batch, r->N);
     HIP_TRY(launch_automorphism_coeff(r->dev, ident_tab(level + 1), pin->view(), gal, pout->view(), pin->batch, r->ctx->stream, r->type == 1));
     return HE_OK;
 }
@@ -1276,6 +1301,7 @@ int he_modup_q_to_p(he_handle hbe, int levelQ, int levelP, he_handle hq, he_hand
     TRY(check_be_poly(*pp, *be, levelP + 1, "he_modup_q_to_p"));
     if (pq->batch != pp->batch) return fail(HE_EINVAL, "he_modup_q_to_p: batch mismatch");
     Scope sc(be->ctx.get());
+    be->ctx->acct(levelQ + 1 + levelP + 1, 0, pq->batch, be->Q->N);  // ModUp: L_src + L_dst
     return modup_between(*be, true, levelQ, levelP, pq->view(), pp->view(), 0, pq->batch);
 }
 int he_modup_p_to_q(he_handle hbe, int levelP, int levelQ, he_handle hp, he_handle hq) {
@@ -1287,6 +1313,7 @@ int he_modup_p_to_q(he_handle hbe, int levelP, int levelQ, he_handle hp, he_hand
     TRY(check_be_poly(*pp, *be, levelP + 1, "he_modup_p_to_q"));
     if (pq->batch != pp->batch) return fail(HE_EINVAL, "he_modup_p_to_q: batch mismatch");
     Scope sc(be->ctx.get());
+    be->ctx->acct(levelQ + 1 + levelP + 1, 0, pq->batch, be->Q->N);
     return modup_between(*be, false, levelP, levelQ, pp->view(), pq->view(), 0, pq->batch);
 }
 static int moddown_api(he_handle hbe, int levelQ, int levelP, he_handle h1q, he_handle h1p, he_handle h2, int kind, const char *who) {
@@ -1301,6 +1328,7 @@ static int moddown_api(he_handle hbe, int levelQ, int levelP, he_handle h1q, he_
     if (p1q->batch != p1p->batch || p1q->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
     Scope sc(be->ctx.get());
     const int B = p1q->batch, N = be->Q->N;
+    be->ctx->acct(kind == 2 ? levelQ + 1 + 2.0 * (levelP + 1) : 2.0 * (levelQ + 1) + levelP + 1, 0, B, N);  // ModDown: 2 L + alpha
     const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
     TRY(be->ctx->arena_reserve(wP + wQ));
     View sP{be->ctx->arena_take(wP), (size_t)(levelP + 1) * N};
@@ -1620,7 +1648,9 @@ int upload_plan(Evaluator &ev, const std::vector<ModUpDesc> &descs, FusedPlan &p
         int cls = 0;
         for (size_t k = i; k < j; k++)
             for (int t = 0; t < descs[k].ndst; t++) cls |= (ev.be->modulus(descs[k].dst_mod[t]) >> 47) ? 1 : 2;
-        plan.groups.push_back(FusedGroup{dev + i, (int)(j - i), descs[i].nsrc, cls});
+        int limbs = 0;
+        for (size_t k = i; k < j; k++) limbs += descs[k].nsrc + descs[k].ndst;
+        plan.groups.push_back(FusedGroup{dev + i, (int)(j - i), descs[i].nsrc, cls, limbs});
         i = j;
     }
     return HE_OK;
@@ -1691,12 +1721,13 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
     auto it = ev.md_plans.find(key);
     if (it != ev.md_plans.end()) { *out = &it->second; return HE_OK; }
     BasisExtender &be = *ev.be;
-    std::vector<uint64_t> basis(be.P->moduli.begin(), be.P->moduli.begin() + levelP + 1);
+    std::vector<uint64_t> basis;
+    if (levelP >= 0) basis.assign(be.P->moduli.begin(), be.P->moduli.begin() + levelP + 1);
     ModUpDesc D;
     memset(&D, 0, sizeof D);
     D.nsrc = levelP + 1;
     FusedPlan plan;
-    if (D.nsrc <= 8 && be.type == 0) {
+    if (levelP >= 0 && D.nsrc <= 8 && be.type == 0) {  // levelP = -1 (no special primes): ModDown is a copy, no plan (plan.ok stays false)
         const ModUpDev c = be.ptoq[levelP].on(be.pool);
         D.a = c.a; D.T = c.T; D.vt = c.vt;
         D.Td = be.ptoq[levelP].Td_on(be.pool); D.vtd = be.ptoq[levelP].vtd_on(be.pool);
@@ -1782,6 +1813,7 @@ int he_decompose_and_split(he_handle hev, int levelQ, int levelP, int nbPi, int 
     TRY(check_be_poly(*p1p, be, levelP + 1, "he_decompose_and_split"));
     if (p0->batch != p1q->batch || p0->batch != p1p->batch) return fail(HE_EINVAL, "he_decompose_and_split: batch mismatch");
     Scope sc(be.ctx.get());
+    be.ctx->acct(std::min(nbPi, levelQ + 1 - digit * nbPi) + levelQ + 1 + levelP + 1, 0, p0->batch, be.Q->N);  // ModUp of one digit
     return decompose_digit(*ev, levelQ, levelP, nbPi, digit, p0->view(), p1q->view(), 0, p1p->view(), 0, p0->batch);
 }
 
@@ -1829,7 +1861,9 @@ int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle 
     if (c2->batch != dec->batch) return fail(HE_EINVAL, "he_decompose_ntt: batch mismatch");
     if (base_rns_size(levelQ, levelP) > dec->beta_max) return fail(HE_EINVAL, "he_decompose_ntt: too many digits");
     Scope sc(be.ctx.get());
-    dec->fillQ = levelQ; dec->fillP = levelP; dec->fill_beta = base_rns_size(levelQ, levelP);
+    be.ctx->acct(levelQ + 1 + (double)base_rns_size(levelQ, levelP) * (levelQ + levelP + 2), 0, c2->batch, be.Q->N);  // DecomposeNTT: L in, beta (L + alpha) out
+    dec->fillQ = -1;  // not filled until every launch below has been enqueued (check_decomp refuses a partial buffer)
+    auto filled = [&]() { dec->fillQ = levelQ; dec->fillP = levelP; dec->fill_beta = base_rns_size(levelQ, levelP); return HE_OK; };
     const int B = c2->batch, N = be.Q->N;
     const size_t w = (size_t)B * (levelQ + 1) * N;
     TRY(be.ctx->arena_reserve(w));
@@ -1847,14 +1881,15 @@ int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle 
                 View blk{dec->d + (size_t)d * dec->dstride(), dec->bstride()};
                 HIP_TRY(launch_ew(be.qp, ident_tab(e0 - s0, s0, s0, s0), EW_COPY, c2->view(), c2->view(), blk, B, nullptr, nullptr, be.ctx->stream));
             }
-            return HE_OK;
+            return filled();
         }
         HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), c2->view(), other, B, true, NTT_REDUCE_INPUT));
     } else {
         HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), c2->view(), other, B, false, NTT_REDUCE_INPUT));
         ntt = other; inv = c2->view();
     }
-    return decompose_ntt_into(*ev, levelQ, levelP, nbPi, ntt, inv, dec->d, dec->bstride(), dec->dstride(), B);
+    TRY(decompose_ntt_into(*ev, levelQ, levelP, nbPi, ntt, inv, dec->d, dec->bstride(), dec->dstride(), B));
+    return filled();
 }
 
 namespace {
@@ -1886,7 +1921,7 @@ int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP
     BasisExtender &be = *ev.be;
     const View dv{dec, dec_bs};
     for (const FusedGroup &g : plan.groups)
-        HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, g.dst_classes, rows_inv, dv, dv, batch, be.ctx->stream, f64_raw));
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, g.dst_classes, rows_inv, dv, dv, batch, be.ctx->stream, f64_raw, g.total_limbs));
     return dec_rows_ntt(ev, levelQ, levelP, nbPi, dec, dec_bs, batch, ntt_filter);
 }
 // class-2 limbs of the gadget product: forward row NTT + key MAC in one kernel (dec holds the post-column state)
@@ -2014,7 +2049,7 @@ int moddown_front(Evaluator &ev, int levelQ, int levelP, View accP, View sP, Vie
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), accP, sP, nb, true, canonical ? 0 : NTT_REDUCE_INPUT, st));
         const FusedGroup &g = plan->groups[0];
         const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);
-        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, nb, st, raw));
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, nb, st, raw, g.total_limbs));
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, sQ, nb, false, NTT_LAZY_OUT | (raw ? NTT_INPUT_F64 : 0), st));
         return HE_OK;
     }
@@ -2089,7 +2124,7 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), View{aP, sPw}, sP, 2 * B, true, 0, st));  // canonical accumulators
         const FusedGroup &g = plan->groups[0];
         const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);  // the extension's double-precision outputs stay doubles up to the row kernel
-        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, 2 * B, st, raw));
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, 2 * B, st, raw, g.total_limbs));
         NttEpilogue epi;
         for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
         epi.y = a0Q; epi.has_w = add0 != nullptr; epi.w = add0 ? *add0 : a0Q;
@@ -2126,6 +2161,12 @@ int check_decomp(const Evaluator &ev, const Decomp &dec, int levelQ, int levelP,
 }
 }  // namespace
 
+// limbs of an evaluation key's 2 beta rows at (levelQ, levelP): read once per call, shared by the batch
+static double key_limbs(const Evk &k, int levelQ) {
+    const int levelP = k.nPk - 1;
+    const int beta = k.pw2 ? k.prefix[levelQ + 1] : base_rns_size(levelQ, levelP);
+    return 2.0 * beta * (levelQ + levelP + 2);
+}
 int he_gadget_product_lazy(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
     GET(ev, Evaluator, hev, T_EVAL);
     GET(cx, Poly, hcx, T_POLY);
@@ -2136,6 +2177,7 @@ int he_gadget_product_lazy(he_handle hev, int levelQ, he_handle hcx, he_handle h
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, cx->batch, o, "he_gadget_product_lazy"));
     Scope sc(be.ctx.get());
+    be.ctx->acct(levelQ + 1 + 2.0 * (levelQ + k->nPk + 1), key_limbs(*k, levelQ), cx->batch, be.Q->N);  // cx in, two QP accumulators out, key
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true, k.get())));
     return gadget_product_lazy_core(*ev, levelQ, cx->view(), cx->batch, *k, o.q0->view(), o.vp0(), o.q1->view(), o.vp1());
 }
@@ -2150,6 +2192,7 @@ int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, dec->batch, o, "he_gadget_product_hoisted_lazy"));
     Scope sc(be.ctx.get());
+    be.ctx->acct(key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + k->nPk + 1), key_limbs(*k, levelQ), dec->batch, be.Q->N);  // decomposition in, accumulators out, key
     return ks_inner(*ev, levelQ, k->nPk - 1, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), dec->batch);
 }
 int he_gadget_product_hoisted_lazy_digits(he_handle hev, int levelQ, he_handle hdec, he_handle hk, int digit_begin, int digit_end,
@@ -2167,9 +2210,15 @@ int he_gadget_product_hoisted_lazy_digits(he_handle hev, int levelQ, he_handle h
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, dec->batch, o, who));
     Scope sc(be.ctx.get());
-    if (digit_begin == digit_end) {  // an empty share contributes zero
-        for (Poly *pp : {o.q0.get(), o.p0.get(), o.q1.get(), o.p1.get()})
-            HIP_TRY(hipMemsetAsync(pp->d, 0, (size_t)pp->batch * pp->nlimbs * pp->N * 8, be.ctx->stream));
+    be.ctx->acct((double)(digit_end - digit_begin) * (levelQ + k->nPk + 1) + 2.0 * (levelQ + k->nPk + 1),
+                 2.0 * (digit_end - digit_begin) * (levelQ + k->nPk + 1), dec->batch, be.Q->N);
+    if (digit_begin == digit_end) {  // an empty share contributes zero -- to the limbs a non-empty share writes (levels + 1), not above
+        const int lv[4] = {levelQ + 1, k->nPk, levelQ + 1, k->nPk};
+        int i = 0;
+        for (Poly *pp : {o.q0.get(), o.p0.get(), o.q1.get(), o.p1.get()}) {
+            HIP_TRY(hipMemset2DAsync(pp->d, (size_t)pp->nlimbs * pp->N * 8, 0, (size_t)lv[i] * pp->N * 8, pp->batch, be.ctx->stream));
+            i++;
+        }
         return HE_OK;
     }
     return ks_inner(*ev, levelQ, k->nPk - 1, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(),
@@ -2189,6 +2238,7 @@ int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c
             if (pp->batch != out0->batch) return fail(HE_EINVAL, "he_moddown: batch mismatch");
         }
         Scope sc(be.ctx.get());
+        be.ctx->acct(4.0 * (levelQ + 1), 0, out0->batch, be.Q->N);
         const LimbTab tq = ident_tab(levelQ + 1);
         HIP_TRY(launch_ew(be.qp, tq, EW_COPY, q0->view(), q0->view(), out0->view(), out0->batch, nullptr, nullptr, be.ctx->stream));
         HIP_TRY(launch_ew(be.qp, tq, EW_COPY, q1->view(), q1->view(), out1->view(), out1->batch, nullptr, nullptr, be.ctx->stream));
@@ -2200,6 +2250,7 @@ int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_moddown"));
     if (out1->batch != out0->batch) return fail(HE_EINVAL, "he_moddown: batch mismatch");
     Scope sc(be.ctx.get());
+    be.ctx->acct(2.0 * (2.0 * (levelQ + 1) + levelP + 1), 0, out0->batch, be.Q->N);  // ModDown of both components: 2 (2 L + alpha)
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, levelP, out0->batch, false)));
     return moddown_pair(*ev, levelQ, levelP, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), out0->view(), out1->view(), out0->batch);
 }
@@ -2217,6 +2268,7 @@ int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle
     if (p1q->batch != p1p->batch || p1q->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
     Scope sc(be.ctx.get());
     const int B = p1q->batch, N = be.Q->N;
+    be.ctx->acct(2.0 * (levelQ + 1) + levelP + 1, 0, B, N);  // ModDownQPtoQNTT: 2 L + alpha
     const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
     TRY(be.ctx->arena_reserve(wP + wQ));
     View sP{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
@@ -2233,7 +2285,7 @@ int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle
     HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), p1p->view(), sP, B, true, NTT_REDUCE_INPUT, st));
     const FusedGroup &g = plan->groups[0];
     const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);
-    HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, B, st, raw));
+    HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, B, st, raw, g.total_limbs));
     NttEpilogue epi;
     for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
     epi.y = p1q->view(); epi.has_w = false; epi.w = p1q->view();
@@ -2254,6 +2306,7 @@ int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product"));
     if (out0->batch != cx->batch || out1->batch != cx->batch) return fail(HE_EINVAL, "he_gadget_product: batch mismatch");
     Scope sc(be.ctx.get());
+    be.ctx->acct(3.0 * (levelQ + 1), key_limbs(*k, levelQ), cx->batch, be.Q->N);  // GadgetProduct: 3 L + 2 beta (L + alpha)
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true, k.get())));
     const View cxv = cx->view();
     return gadget_product_core(*ev, levelQ, &cxv, nullptr, *k, out0->view(), out1->view(), cx->batch);
@@ -2272,6 +2325,7 @@ int he_gadget_product_hoisted(he_handle hev, int levelQ, he_handle hdec, he_hand
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product_hoisted"));
     if (out0->batch != dec->batch || out1->batch != dec->batch) return fail(HE_EINVAL, "he_gadget_product_hoisted: batch mismatch");
     Scope sc(be.ctx.get());
+    be.ctx->acct(key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + 1), key_limbs(*k, levelQ), dec->batch, be.Q->N);  // hoisted: decomposition in, 2 L out, key
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, dec->batch, false)));
     return gadget_product_core(*ev, levelQ, nullptr, dec.get(), *k, out0->view(), out1->view(), dec->batch);
 }
@@ -2293,6 +2347,7 @@ int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_
     }
     Scope sc(be.ctx.get());
     const int B = in0->batch, N = be.Q->N;
+    be.ctx->acct(5.0 * (std::min(level, k->nQk - 1) + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, N);  // Relinearize: 3 L in, 2 L out, key
     (void)N;
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k.get())));
     const View in2v = in2->view(), in0v = in0->view(), in1v = in1->view();
@@ -2324,6 +2379,8 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     if (dec) TRY(check_decomp(*ev, *dec, level, k->nPk - 1, who));
     Scope sc(be.ctx.get());
     const int N = be.Q->N;
+    // Rotate: (4 L + 2 beta (L + alpha)); hoisted: the decomposition replaces the second input
+    be.ctx->acct(dec ? 3.0 * (level + 1) + key_limbs(*k, level) / 2 : 4.0 * (level + 1), key_limbs(*k, level), B, N);
     const size_t wQ = (size_t)B * (level + 1) * N;
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, !dec, k.get()) + 2 * wQ + (size_t)N));
     View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
@@ -2365,6 +2422,7 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, levelP, B, o, "he_automorphism_hoisted_lazy"));
     Scope sc(be.ctx.get());
+    be.ctx->acct(levelQ + 1 + key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + levelP + 2), key_limbs(*k, levelQ), B, N);
     const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
     TRY(be.ctx->arena_reserve(2 * B * (sQw + sPw) + N + 64));
     View t0Q{be.ctx->arena_take(B * sQw), sQw}, t1Q{be.ctx->arena_take(B * sQw), sQw};
@@ -2418,6 +2476,7 @@ int he_centered_lift(he_handle hev, int strict, he_handle hsrc, int first_q, int
     a.ndst = n;
     if (n > kMaxLimbs) return fail(HE_EINVAL, "%s: too many destination limbs", who);
     Scope sc(be.ctx.get());
+    be.ctx->acct(1.0 + n, 0, src->batch, be.Q->N);
     HIP_TRY(launch_center_copy(be.qp, a, src->view(), dq->view(), dp ? dp->view() : dq->view(), src->batch, be.ctx->stream, strict & 3));
     return HE_OK;
 }
@@ -2432,7 +2491,8 @@ int he_decomp_fill(he_handle hdec, int levelQ, int levelP, he_handle hq, he_hand
     TRY(check_be_poly(*sp, be, levelP + 1, who));
     if (sq->batch != d->batch || sp->batch != d->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
     Scope sc(be.ctx.get());
-    d->fillQ = levelQ; d->fillP = levelP; d->fill_beta = d->beta_max;
+    be.ctx->acct(levelQ + levelP + 2 + (double)d->beta_max * (levelQ + levelP + 2), 0, d->batch, be.Q->N);
+    d->fillQ = -1;  // see he_decompose_ntt
     const size_t N = be.Q->N;
     for (int dg = 0; dg < d->beta_max; dg++) {
         uint64_t *base = d->d + (size_t)dg * d->dstride();
@@ -2441,6 +2501,7 @@ int he_decomp_fill(he_handle hdec, int levelQ, int levelP, he_handle hq, he_hand
         HIP_TRY(hipMemcpy2DAsync(base + (size_t)be.LQ * N, d->bstride() * 8, sp->d, sp->view().bstride * 8,
                                  (size_t)(levelP + 1) * N * 8, d->batch, hipMemcpyDeviceToDevice, be.ctx->stream));
     }
+    d->fillQ = levelQ; d->fillP = levelP; d->fill_beta = d->beta_max;
     return HE_OK;
 }
 
@@ -2504,6 +2565,11 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
         keep.push_back(tp); keep.push_back(c0p); keep.push_back(c1p);
     }
     Scope sc(be.ctx.get());
+    {   // per term: the plaintext diagonal (shared by the batch when it has batch 1) and both ciphertext components; two outputs
+        double per = 2.0, shared = 0.0;
+        for (int i = 0; i < n; i++) { per += 2.0; if (ap.pt_bs[i]) per += 1.0; else shared += 1.0; }
+        be.ctx->acct(per * (levelQ + levelP + 2), shared * (levelQ + levelP + 2), B, be.Q->N);
+    }
     hipStream_t st = be.ctx->stream;
     HIP_TRY(launch_diag_mac(be.qp, aq, o.q0->view(), o.q1->view(), B, st));
     HIP_TRY(launch_diag_mac(be.qp, ap, o.p0->view(), o.p1->view(), B, st));
@@ -2552,6 +2618,8 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
     }
     Scope sc(be.ctx.get());
     const int N = be.Q->N;
+    if (k) be.ctx->acct(6.0 * (level + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, N);  // MulRelin: 6 L + 2 beta (L + alpha)
+    else be.ctx->acct(7.0 * (level + 1), 0, B, N);                                                // Mul: 4 L in, 3 L out
     const size_t wQ = (size_t)B * (level + 1) * N;
     hipStream_t st = be.ctx->stream;
     if (!k) {
@@ -2566,12 +2634,13 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
     // ModDown epilogue (24 limbs of writes and 24 of reads fewer; the inputs' second read comes from L2).  Not when an output
     // aliases an input: the epilogue of one component would overwrite words the other still reads.
     static const bool no_fuse = getenv("HERING_NO_TENSOR_EPILOGUE") && atoi(getenv("HERING_NO_TENSOR_EPILOGUE")) != 0;
-    const FusedPlan *mdplan = nullptr;
-    TRY(get_md_plan(*ev, level, k->nPk - 1, &mdplan));
     bool alias = false;
     for (Poly *o : {out0.get(), out1.get()})
         for (Poly *in : {a0.get(), a1.get(), b0.get(), b1.get()}) alias = alias || o->d == in->d;
-    if (mdplan->ok && k->nPk > 0 && !alias && !no_fuse) {
+    const FusedPlan *mdplan = nullptr;
+    const bool may_fuse = k->nPk > 0 && !alias && !no_fuse;  // a P-less (base-2) key has no ModDown to fuse into
+    if (may_fuse) TRY(get_md_plan(*ev, level, k->nPk - 1, &mdplan));
+    if (may_fuse && mdplan->ok) {
         HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), View{nullptr, 0},
                               View{nullptr, 0}, c2, B, st));
         TensorIn tin{a0->view(), a1->view(), b0->view(), b1->view(), sc_.data()};
@@ -2605,6 +2674,22 @@ int he_prof_end(he_handle hctx, int max_kernels, int *counts, float *total_ms, i
     HIP_TRY(hipStreamSynchronize(c->stream));
     prof_end(c->stream, counts, total_ms);
     if (n_kernels) *n_kernels = K_COUNT;
+    return HE_OK;
+}
+int he_prof_end_bytes(he_handle hctx, int max_kernels, int *counts, float *total_ms, double *total_bytes, int *n_kernels) {
+    GET(c, Ctx, hctx, T_CTX);
+    if (!counts || !total_ms || !total_bytes || max_kernels < K_COUNT) return fail(HE_EINVAL, "he_prof_end_bytes: need room for %d kernels", (int)K_COUNT);
+    Scope sc(c.get());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prof_end(c->stream, counts, total_ms, total_bytes);
+    if (n_kernels) *n_kernels = K_COUNT;
+    return HE_OK;
+}
+int he_alg_bytes(he_handle hctx, int reset, double out[2]) {
+    GET(c, Ctx, hctx, T_CTX);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (out) { out[0] = c->alg_bytes[0]; out[1] = c->alg_bytes[1]; }
+    if (reset) c->alg_bytes[0] = c->alg_bytes[1] = 0.0;
     return HE_OK;
 }
 const char *he_prof_kernel_name(int id) { return kernel_name(id); }

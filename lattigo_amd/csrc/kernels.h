@@ -198,8 +198,9 @@ struct ModUpDesc {
 // all descriptors must share nsrc; returns hipErrorInvalidValue when (nsrc, logN) has no fused kernel
 bool modup_fused_supported(int logN, int nsrc);
 // dst_classes: bit 0 = some destination modulus is >= 2^47 (integer path), bit 1 = some is below (double path)
+// total_limbs: source + destination limbs over the descriptors (the launch's algorithmic traffic, for the profiling leg)
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
-                              View dstA, View dstB, int batch, hipStream_t s, bool f64_raw = false);
+                              View dstA, View dstB, int batch, hipStream_t s, bool f64_raw = false, int total_limbs = 0);
 // f64_raw is exact only while the unreduced doubles stay below 2^53 through the remaining forward stages
 bool modup_f64_raw_ok(int logN, int nsrc, uint64_t max_small_modulus);
 
@@ -285,7 +286,7 @@ enum KernelId {
 };
 const char *kernel_name(int id);
 void prof_begin(hipStream_t s);                                // start recording the launches enqueued on stream s
-int prof_end(hipStream_t s, int *counts, float *total_ms);     // stop, sync events, fill [K_COUNT] arrays
+int prof_end(hipStream_t s, int *counts, float *total_ms, double *total_bytes = nullptr);  // stop, sync events, fill [K_COUNT] arrays
 
 // throughput probe used by bench.py --microbench (not on the product path)
 hipError_t launch_modmul_probe(uint64_t *buf, size_t n, int iters, uint64_t q, uint64_t qinv, hipStream_t s);

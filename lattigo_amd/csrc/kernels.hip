@@ -30,7 +30,7 @@ namespace he {
 namespace {
 // Profiling state is per stream (= per context, see api.cpp) behind one mutex: two contexts may launch from different
 // threads while one of them is being profiled; a launch looks its own stream up and records only there.
-struct ProfRec { int id; hipEvent_t e0, e1; };
+struct ProfRec { int id; hipEvent_t e0, e1; double bytes; };
 struct ProfState { std::vector<ProfRec> recs; };
 std::mutex g_prof_mu;
 std::atomic<int> g_prof_active{0};                       // number of streams being profiled (fast path: none)
@@ -42,9 +42,12 @@ hipEvent_t prof_event_locked() {
     (void)hipEventCreate(&e);
     return e;
 }
+// `bytes` = the ALGORITHMIC HBM bytes of the launch: every polynomial stream the kernel must read or write, once (a key row
+// shared by the batch counts once; twiddles, constants and index tables are resident and excluded) -- the numerator of the
+// per-kernel roofline figures bench.py reports, kept next to the launch so that it cannot drift from the pipeline
 struct ProfScope {
-    bool on; int id; hipStream_t s; hipEvent_t e0;
-    ProfScope(int id_, hipStream_t s_) : on(false), id(id_), s(s_), e0(nullptr) {
+    bool on; int id; hipStream_t s; hipEvent_t e0; double bytes;
+    ProfScope(int id_, hipStream_t s_, double bytes_ = 0.0) : on(false), id(id_), s(s_), e0(nullptr), bytes(bytes_) {
         if (g_prof_active.load(std::memory_order_relaxed) == 0) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof.find(s) == g_prof.end()) return;
@@ -58,7 +61,7 @@ struct ProfScope {
         auto it = g_prof.find(s);
         hipEvent_t e1 = prof_event_locked();
         (void)hipEventRecord(e1, s);
-        if (it != g_prof.end()) it->second.recs.push_back(ProfRec{id, e0, e1});
+        if (it != g_prof.end()) it->second.recs.push_back(ProfRec{id, e0, e1, bytes});
         else { g_prof_pool.push_back(e0); g_prof_pool.push_back(e1); }
     }
 };
@@ -77,8 +80,8 @@ void prof_begin(hipStream_t s) {
     for (auto &r : ins.first->second.recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }  // a begin without an end
     ins.first->second.recs.clear();
 }
-int prof_end(hipStream_t s, int *counts, float *total_ms) {
-    for (int i = 0; i < K_COUNT; i++) { counts[i] = 0; total_ms[i] = 0.f; }
+int prof_end(hipStream_t s, int *counts, float *total_ms, double *total_bytes) {
+    for (int i = 0; i < K_COUNT; i++) { counts[i] = 0; total_ms[i] = 0.f; if (total_bytes) total_bytes[i] = 0.0; }
     std::vector<ProfRec> recs;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -93,6 +96,7 @@ int prof_end(hipStream_t s, int *counts, float *total_ms) {
         (void)hipEventSynchronize(r.e1);
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         counts[r.id]++; total_ms[r.id] += ms;
+        if (total_bytes) total_bytes[r.id] += r.bytes;
     }
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
@@ -197,6 +201,7 @@ struct NttArgs {
     int epi_y_f64;  // f64 kernel only: y holds doubles
     int epi_y_reduce;  // f64 kernel only: y holds arbitrary 64-bit words (reduced before the conversion to double)
     int nbatch, iters;  // f64 kernel only: a workgroup transforms batch entries blockIdx.x * iters ... (+ iters - 1) of its row
+    int nbatch_prof = 0;  // host only: batch entries of the launch when grid.x is not their number (rows_bytes)
 };
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
@@ -1405,8 +1410,10 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
     A.mc = r.mc; A.twd = r.twd_fwd; A.N = r.N; A.a = aa; A.m = a;
+    // beta digits in (an own digit is the input limb itself), two key rows per digit shared by the batch, two accumulators out
+    const double mac_bytes = ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0;
     static const bool plain_only = getenv("HERING_MAC_PLAIN") && atoi(getenv("HERING_MAC_PLAIN")) != 0;
-    if ((b == 12 || b == 13) && !plain_only) {
+    if (b == 13 || (b == 12 && !plain_only)) {  // (the plain kernel has no 8192-row instantiation: it would spill)
         NttMacDmaArgs D;
         D.k = A;
         D.nbatch = (unsigned)batch;
@@ -1422,7 +1429,7 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
             G = (D.nitems + per - 1) / per;
             if ((D.nitems & 7u) == 0) G = (G + 7u) & ~7u;
         }
-        ProfScope ps(K_NTT_MAC_F64, s);
+        ProfScope ps(K_NTT_MAC_F64, s, mac_bytes);
         if (b == 12) {
             if (a.q_out_f64) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, true>), dim3(G), dim3(256), 0, s, D);
             else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false>), dim3(G), dim3(256), 0, s, D);
@@ -1442,7 +1449,7 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
         if (abl & 8) { for (int i = 0; i < a.nlimbs; i++) A.m.key_limb[i] = 0; }
     }
 #endif
-    ProfScope ps(K_NTT_MAC_F64, s);
+    ProfScope ps(K_NTT_MAC_F64, s, mac_bytes);
 #define HE_MAC_CASE(B)                                                                                      \
     case B:                                                                                                 \
         if (a.q_out_f64) hipLaunchKernelGGL((ntt_mac_f64_kernel<B, true>), grid, dim3((1 << B) / 16), 0, s, A);  \
@@ -1450,7 +1457,7 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
         break;
     switch (b) {
         HE_MAC_CASE(4) HE_MAC_CASE(5) HE_MAC_CASE(6) HE_MAC_CASE(7) HE_MAC_CASE(8) HE_MAC_CASE(9) HE_MAC_CASE(10)
-        HE_MAC_CASE(11) HE_MAC_CASE(12) HE_MAC_CASE(13)
+        HE_MAC_CASE(11) HE_MAC_CASE(12)
         default: return hipErrorInvalidValue;
     }
 #undef HE_MAC_CASE
@@ -1550,6 +1557,14 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
     for (int r = 0; r < R; r++) dst[(size_t)r * N2] = x[r];
 }
 
+// algorithmic bytes of one row-pass launch: in + out per (entry, limb), plus the epilogue's streams -- y, the addend w or, in
+// tensor mode, the four inputs of the product shared by the two components of an entry (two per component)
+static double rows_bytes(dim3 grid, const NttArgs &A, int logb) {
+    const double entries = A.epi_tensor ? 2.0 * A.zsplit : (A.nbatch_prof > 0 ? (double)A.nbatch_prof : (double)grid.x);
+    double streams = 2.0;
+    if (A.epi) streams += 1.0 + (A.epi_tensor ? 2.0 : (A.epi == 2 || (A.zsplit && A.epi2 == 2)) ? 1.0 : 0.0);
+    return entries * grid.y * grid.z * (double)(1u << logb) * 8.0 * streams;
+}
 template <bool INV, bool NC>
 static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
     static const bool no_shoup = getenv("HERING_NO_SHOUP_ROWS") && atoi(getenv("HERING_NO_SHOUP_ROWS")) != 0;
@@ -1558,7 +1573,7 @@ static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStrea
     // bytes -- 0.439 against 0.424 ms, the same verdict as round 1's experiment.
     if constexpr (INV) {
         if (A.tws && !no_shoup && (logb == 12 || logb == 13) && !A.scale) {
-            ProfScope ps(K_NTT_ROWS_INV, s);
+            ProfScope ps(K_NTT_ROWS_INV, s, rows_bytes(grid, A, logb));
             if (logb == 12) hipLaunchKernelGGL((ntt_rows_kernel<12, true, false, true>), grid, dim3(256), 0, s, A);
             else hipLaunchKernelGGL((ntt_rows_kernel<13, true, false, true>), grid, dim3(512), 0, s, A);
             return hipGetLastError();
@@ -1566,7 +1581,7 @@ static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStrea
     }
 #define HE_ROWS_CASE(B)                                                                           \
     case B:                                                                                       \
-        { ProfScope ps(INV ? K_NTT_ROWS_INV : K_NTT_ROWS_FWD, s);                                   \
+        { ProfScope ps(INV ? K_NTT_ROWS_INV : K_NTT_ROWS_FWD, s, rows_bytes(grid, A, B));                                 \
         hipLaunchKernelGGL((ntt_rows_kernel<B, INV, NC>), grid, dim3((1 << B) / 16), 0, s, A); }   \
         break;
     switch (logb) {
@@ -1581,7 +1596,7 @@ template <bool INV>
 static hipError_t launch_rows_f64(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
 #define HE_ROWSF_CASE(B)                                                                          \
     case B:                                                                                       \
-        { ProfScope ps(INV ? K_NTT_ROWS_INV_F64 : K_NTT_ROWS_FWD_F64, s);                           \
+        { ProfScope ps(INV ? K_NTT_ROWS_INV_F64 : K_NTT_ROWS_FWD_F64, s, rows_bytes(grid, A, B));                         \
         hipLaunchKernelGGL((ntt_rows_f64_kernel<B, INV>), grid, dim3((1 << B) / 16), 0, s, A); }   \
         break;
     switch (logb) {
@@ -1619,7 +1634,7 @@ static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, const uint8
         const size_t wgs = (size_t)grid.x * P[2].tab.n * grid.z;
         int iters = (!INV || logb > 12) ? 1 : forced > 0 ? forced : (wgs >= 6144 ? 2 : 1);
         if (iters > (int)grid.x) iters = (int)grid.x;
-        P[2].nbatch = (int)grid.x; P[2].iters = iters;
+        P[2].nbatch = (int)grid.x; P[2].iters = iters; P[2].nbatch_prof = (int)grid.x;
         dim3 g2((grid.x + iters - 1) / iters, P[2].tab.n, grid.z);
         e = launch_rows_f64<INV>(logb, g2, P[2], s);
     }
@@ -1631,7 +1646,7 @@ template <bool INV>
 static hipError_t launch_cols(int loga, dim3 grid, const NttArgs &A, hipStream_t s) {
 #define HE_COLS_CASE(Av)                                                                 \
     case Av:                                                                             \
-        { ProfScope ps(INV ? K_NTT_COLS_INV : K_NTT_COLS_FWD, s);                          \
+        { ProfScope ps(INV ? K_NTT_COLS_INV : K_NTT_COLS_FWD, s, 2.0 * A.tab.n * grid.z * (double)A.N * 8.0);                        \
         hipLaunchKernelGGL((ntt_cols_kernel<Av, INV>), grid, dim3(256), 0, s, A); }       \
         break;
     switch (loga) {
@@ -1801,7 +1816,7 @@ hipError_t launch_ci_fold(const RingDev &r, const LimbTab &tab, View in, View ou
     A.inverse = inverse; A.reduce_input = reduce_input;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
     dim3 grid((unsigned)((r.N / 2 + 1 + 255) / 256), tab.n, batch), block(256);
-    ProfScope ps(K_CI_FOLD, s);
+    ProfScope ps(K_CI_FOLD, s, 2.0 * tab.n * batch * (double)r.N * 8.0);
     hipLaunchKernelGGL(ci_fold_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
@@ -1851,7 +1866,7 @@ hipError_t launch_ci_intt_lazy_ref(const RingDev &r, const ModConst &mc_host, in
     CiRefArgs A;
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride; A.mc = mc_host;
     A.tw = r.tw_inv + (size_t)mod * r.N; A.N = r.N;
-    ProfScope ps(K_CI_FOLD, s);
+    ProfScope ps(K_CI_FOLD, s, 2.0 * (r.logN + 1) * batch * (double)r.N * 8.0);  // one pass per stage (off the hot path)
     for (int t = 1; t < r.N; t <<= 1) {
         A.t = t;
         hipLaunchKernelGGL(ci_ref_inv_stage_kernel, dim3((unsigned)((r.N / 2 + 255) / 256), 1, batch), dim3(256), 0, s, A);
@@ -1979,7 +1994,13 @@ static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, V
         A.s2[i] = sc ? sc->s2[i] : 0;
     }
     dim3 grid((unsigned)((r.N / 2 + 255) / 256), tab.n, batch), block(256);
-    ProfScope ps(K_EW, s);
+    // x in, z out, plus y and the addend where the formula has them
+    const bool ew_y = (op >= 0 && op < 100) || op == EW_SUB_THEN_MUL_SCALAR_MONT_2Q || op == EW_DIVROUND_COEFF || op == EW_SUBMUL2Q_THEN_ADD;
+    const bool ew_z = op == EW_MUL_BARRETT_THEN_ADD || op == EW_MUL_BARRETT_THEN_ADD_LAZY || op == EW_MUL_MONT_THEN_ADD ||
+                      op == EW_MUL_MONT_THEN_ADD_LAZY || op == EW_MUL_MONT_LAZY_THEN_ADD_LAZY || op == EW_MUL_MONT_THEN_SUB ||
+                      op == EW_MUL_MONT_THEN_SUB_LAZY || op == EW_MUL_MONT_LAZY_THEN_SUB_LAZY || op == EW_MUL_SCALAR_MONT_THEN_ADD ||
+                      op == EW_SUBMUL2Q_THEN_ADD;
+    ProfScope ps(K_EW, s, (2.0 + ew_y + ew_z) * tab.n * batch * (double)r.N * 8.0);
 #define HE_EW_CASE(O) \
     case O: hipLaunchKernelGGL((ew_kernel<O>), grid, block, 0, s, A); break;
     switch (op) {
@@ -2029,7 +2050,7 @@ hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const ui
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.index = index; A.N = r.N;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
-    ProfScope ps(K_GATHER, s);
+    ProfScope ps(K_GATHER, s, (then_add ? 3.0 : 2.0) * tab.n * batch * (double)r.N * 8.0);
     if (then_add) hipLaunchKernelGGL((gather_kernel<true>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((gather_kernel<false>), grid, block, 0, s, A);
     return hipGetLastError();
@@ -2096,7 +2117,7 @@ hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View 
     A.gal = gal; A.ginv = 0;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
-    ProfScope ps(K_AUTO_COEFF, s);
+    ProfScope ps(K_AUTO_COEFF, s, 2.0 * tab.n * batch * (double)r.N * 8.0);
     if (conjugate_invariant) {
         const uint64_t m = 2ull * r.N;  // inverse of the odd gal modulo the power of two 2N (Newton iteration)
         uint64_t inv = gal;
@@ -2182,7 +2203,7 @@ hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a,
     if (nchunk > 4) nchunk = 4;
     A.nchunk = nchunk;
     dim3 grid(bx, nchunk, batch), block(64);
-    ProfScope ps(K_MODUP, s);
+    ProfScope ps(K_MODUP, s, (double)(a.nsrc + a.ndst) * batch * (double)r.N * 8.0);
     switch (a.nsrc) {
         case 1: hipLaunchKernelGGL((modup_kernel<1>), grid, block, 0, s, A); break;
         case 2: hipLaunchKernelGGL((modup_kernel<2>), grid, block, 0, s, A); break;
@@ -2221,6 +2242,10 @@ struct ModUpFusedArgs {
 #ifndef HE_MODUP_WAVES
 #define HE_MODUP_WAVES 3  // waves per SIMD the register allocation aims at (the LDS footprint allows three)
 #endif
+// The all-integer variant keeps the residues in registers (2 R NSRC of them, beside NSRC matrix entries per destination): only
+// the shapes that fit the three-wave register budget without spilling are instantiated (modup_int_light); every other shape
+// takes the LDS-parking variant, whatever the classes of its destination moduli (it handles integer destinations too)
+constexpr bool modup_int_light(int nsrc, int loga) { return 2 * (1 << loga) * nsrc + 4 * nsrc <= 48; }
 template <int NSRC, int LOGA, bool DSTF64>
 __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpFusedArgs A) {
     constexpr int R = 1 << LOGA;
@@ -2633,7 +2658,7 @@ bool modup_fused_supported(int logN, int nsrc) {
 
 template <bool F64>
 static void launch_modup_fused_variant(int a, int nsrc, dim3 grid, dim3 block, const ModUpFusedArgs &A, hipStream_t s) {
-#define HE_MF(NS, LA) hipLaunchKernelGGL((modup_fused_kernel<NS, LA, F64>), grid, block, 0, s, A)
+#define HE_MF(NS, LA) do { if constexpr (F64 || modup_int_light(NS, LA)) hipLaunchKernelGGL((modup_fused_kernel<NS, LA, F64>), grid, block, 0, s, A); } while (0)
 #define HE_MF_A(NS)                                  \
     switch (a) {                                     \
         case 0: HE_MF(NS, 0); break;                 \
@@ -2670,7 +2695,7 @@ bool modup_f64_raw_ok(int logN, int nsrc, uint64_t max_small_modulus) {
     return bound < 0x1p53L;
 }
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
-                              View dstA, View dstB, int batch, hipStream_t s, bool f64_raw) {
+                              View dstA, View dstB, int batch, hipStream_t s, bool f64_raw, int total_limbs) {
     if (ndesc <= 0 || batch <= 0) return hipSuccess;
     if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
     const int a = r.logN - ntt_row_bits(r.logN);
@@ -2680,10 +2705,10 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
     A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.twd_fwd = r.twd_fwd; A.twd_inv = r.twd_inv; A.N = r.N;
     A.tws_fwd = r.tws_fwd;
-    const bool use_f64 = (dst_classes & 2) && r.twd_fwd != nullptr;
+    const bool use_f64 = ((dst_classes & 2) && r.twd_fwd != nullptr) || !modup_int_light(nsrc, a);
     const int n2 = r.N >> a;
     dim3 grid((unsigned)((n2 + 127) / 128), ndesc, batch), block(128);
-    ProfScope ps(K_MODUP, s);
+    ProfScope ps(K_MODUP, s, (double)total_limbs * batch * (double)r.N * 8.0);
     if (use_f64) launch_modup_fused_variant<true>(a, nsrc, grid, block, A, s);   // mixed: f64 for small destinations
     else launch_modup_fused_variant<false>(a, nsrc, grid, block, A, s);
     return hipGetLastError();
@@ -2722,7 +2747,7 @@ hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, Vi
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
     A.mc = r.mc; A.N = r.N; A.m = a; A.strict = strict;
     dim3 grid((unsigned)((r.N + 255) / 256), a.ndst, batch), block(256);
-    ProfScope ps(K_CENTER, s);
+    ProfScope ps(K_CENTER, s, (double)(1 + a.ndst) * batch * (double)r.N * 8.0);
     hipLaunchKernelGGL(center_copy_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
@@ -2752,7 +2777,7 @@ hipError_t launch_mask_spread(const RingDev &r, const MaskSpreadArgs &a, View sr
     MaskSpreadKArgs A;
     A.src = src.p; A.src_bs = src.bstride; A.dec = dec; A.dec_bs = dec_bs; A.dec_ds = dec_ds; A.N = r.N; A.m = a;
     dim3 grid((unsigned)((r.N + 255) / 256), a.nblk, batch), block(256);
-    ProfScope ps(K_MASK_SPREAD, s);
+    ProfScope ps(K_MASK_SPREAD, s, ((double)a.nblk * a.ndst + a.ndst) * batch * (double)r.N * 8.0);
     hipLaunchKernelGGL(mask_spread_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
@@ -2859,7 +2884,8 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own
     A.mc = r.mc; A.N = r.N; A.batch = batch; A.k = a;
     const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
     dim3 grid((unsigned)((r.N + 255) / 256), a.nlimbs, (batch + bb - 1) / bb), block(256);
-    ProfScope ps(K_KS_INNER, s);
+    // beta digits in, two key rows per digit shared by the batch, two accumulators out
+    ProfScope ps(K_KS_INNER, s, ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0);
     if (bb == 4) hipLaunchKernelGGL((ks_inner_kernel<4>), grid, block, 0, s, A);
     else if (bb == 2) hipLaunchKernelGGL((ks_inner_kernel<2>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((ks_inner_kernel<1>), grid, block, 0, s, A);
@@ -2913,7 +2939,7 @@ static hipError_t launch_shift_impl(const RingDev &r, const LimbTab &tab, View i
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.k = k; A.monomial = monomial;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
-    ProfScope ps(K_GATHER, s);
+    ProfScope ps(K_GATHER, s, 2.0 * tab.n * batch * (double)r.N * 8.0);
     hipLaunchKernelGGL(shift_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }
@@ -2992,7 +3018,14 @@ hipError_t launch_diag_mac(const RingDev &r, const DiagMacArgs &a, View out0, Vi
     A.mc = r.mc; A.N = r.N; A.batch = batch;
     const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
     dim3 grid((unsigned)((r.N + 255) / 256), a.nlimbs, (batch + bb - 1) / bb), block(256);
-    ProfScope ps(K_DIAG_MAC, s);
+    // per term the plaintext diagonal (shared by the batch unless it has a batch stride) and the two ciphertext components; the two
+    // accumulators out (and in, when accumulating)
+    double dm_limbs = (a.accumulate ? 4.0 : 2.0) * batch;
+    for (int i = 0; i < a.n; i++) {
+        if (!a.c0[i] && !a.c1[i]) continue;
+        dm_limbs += (a.pt_bs[i] ? (double)batch : 1.0) + (a.c0[i] ? batch : 0) + (a.c1[i] ? batch : 0);
+    }
+    ProfScope ps(K_DIAG_MAC, s, dm_limbs * a.nlimbs * (double)r.N * 8.0);
     if (bb == 4) hipLaunchKernelGGL((diag_mac_kernel<4>), grid, block, 0, s, A);
     else if (bb == 2) hipLaunchKernelGGL((diag_mac_kernel<2>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((diag_mac_kernel<1>), grid, block, 0, s, A);
@@ -3059,7 +3092,8 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
         A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; A.s[i] = scalar[i];
     }
     dim3 grid((unsigned)((r.N / 2 + 255) / 256), tab.n, batch), block(256);
-    ProfScope ps(K_TENSOR, s);
+    // a1, b1 -> c2 always; a0, b0 -> c0, c1 when those outputs exist
+    ProfScope ps(K_TENSOR, s, (c0.p ? 7.0 : 3.0) * tab.n * batch * (double)r.N * 8.0);
     hipLaunchKernelGGL(tensor_kernel, grid, block, 0, s, A);
     return hipGetLastError();
 }

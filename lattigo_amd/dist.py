@@ -44,6 +44,16 @@ class ControlPlane:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return float(t.item())
 
+    def rccl_world(self):
+        """Ranks of the RCCL communicator as RCCL itself counts them (an all-reduce of ones on the device), or None when no RCCL
+        group was created in this process (no key replication / split key switch over RCCL took place)."""
+        if self._rccl is None or self._dist is None:
+            return None
+        import torch
+        t = torch.ones(1, dtype=torch.int64, device=f"cuda:{torch.cuda.current_device()}")
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._rccl)
+        return int(t.item())
+
     def broadcast_object(self, obj, src: int = 0):
         if self._dist is None:
             return obj
@@ -165,6 +175,7 @@ class ControlPlane:
         from .ring import Poly
         rQ, rP = evaluator.ringQ, evaluator.ringP
         levelP = evk.LevelP()
+        levelQ = min(levelQ, evk.LevelQ())  # utils.Min(levelQ, gadgetCt.LevelQ()), as the unsplit call (and the C side) does
         from .rlwe import BaseRNSDecompositionVectorSize
         beta = BaseRNSDecompositionVectorSize(levelQ, levelP)
         share = self.digit_range(beta, self.rank, self.world)

@@ -91,6 +91,20 @@ class Context:
         check(load().he_prof_end(self.h, n, counts, ms, C.byref(nk)))
         return {load().he_prof_kernel_name(i).decode(): (int(counts[i]), float(ms[i])) for i in range(nk.value) if counts[i]}
 
+    def prof_end_bytes(self) -> dict:
+        """{kernel name: (launches, total ms, algorithmic bytes)} since prof_begin() (hering_debug.h)."""
+        n = 32
+        counts, ms, by, nk = (C.c_int * n)(), (C.c_float * n)(), (C.c_double * n)(), C.c_int()
+        check(load().he_prof_end_bytes(self.h, n, counts, ms, by, C.byref(nk)))
+        return {load().he_prof_kernel_name(i).decode(): (int(counts[i]), float(ms[i]), float(by[i])) for i in range(nk.value) if counts[i]}
+
+    def alg_bytes(self, reset: bool = False):
+        """(bytes with the key charged per batch entry, bytes with the key read once per call) of the primitives called on this
+        context since the last reset, by SURVEY.md section 8(d)'s per-primitive formulas (hering_debug.h)."""
+        out = (C.c_double * 2)()
+        check(load().he_alg_bytes(self.h, int(reset), out))
+        return float(out[0]), float(out[1])
+
     def probe_modmul(self, iters=256) -> float:
         out = C.c_double()
         check(load().he_probe_modmul(self.h, iters, C.byref(out)))

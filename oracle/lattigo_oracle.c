@@ -8,6 +8,7 @@
  * arithmetic, same evaluation order wherever the order is observable (lazy
  * representatives, float64 accumulation).
  */
+#define _GNU_SOURCE /* pthread_setaffinity_np, CPU_SET (the timed CPU baseline at the end of the file) */
 #include "lattigo_oracle.h"
 
 #include <math.h>
@@ -1542,41 +1543,95 @@ void lo_rescale(const lo_ring *r, int level, int degree, int nb, const uint64_t 
 /* ========================================================================== */
 /* Timed CPU baseline (bench.py's cpu_baseline leg)                             */
 /* ========================================================================== */
-/* `nthreads` OS threads each repeat one BGV MulRelin on the shared (read-only) evaluator, key and inputs, writing to
- * their own output, until `seconds` have elapsed -- the shape of the reference's own parallel benchmarks
- * (b.RunParallel over one evaluator, schemes/ckks/ckks_benchmarks_test.go:95-325; evaluator methods are safe for
- * concurrent callers since 6.2.0 because scratch comes from pools).  counts[i] = ops finished by thread i;
- * returns the elapsed wall time in seconds. */
+/* `nthreads` OS threads each repeat one operation on the shared (read-only) evaluator until `seconds` have elapsed -- the shape
+ * of the reference's own parallel benchmarks (b.RunParallel over one evaluator, schemes/ckks/ckks_benchmarks_test.go:95-325;
+ * evaluator methods are safe for concurrent callers since 6.2.0 because scratch comes from pools).
+ * kind 0: BGV MulRelin(op0, op1, key)        (schemes/bgv/evaluator.go:592-667)
+ * kind 1: Automorphism(op0, gal, key)        (core/rlwe/evaluator_automorphism.go:13-51; CKKS Rotate)
+ * kind 2: CKKS Mul (degree 2) + Rescale      (schemes/ckks/evaluator.go:764-872, :477-515), key unused
+ * Placement (round 3): every thread is pinned to one CPU of the process's affinity set and works on its OWN first-touched copy
+ * of the inputs and of the key -- with one shared copy, first touched by the calling thread, every other NUMA node read the
+ * key over the fabric and the rate FELL beyond 16 threads.  The evaluator's tables (twiddles, basis-extension constants:
+ * a few MB, read-only) stay shared.  counts[i] = ops finished by thread i; returns the elapsed wall time in seconds. */
 #include <pthread.h>
+#include <sched.h>
 #include <time.h>
 typedef struct {
-    const lo_evaluator *e; int level; uint64_t t; const uint64_t *op0, *op1; const lo_evk *rlk;
+    int kind, cpu, private_copy;
+    const lo_evaluator *e; int level; uint64_t t, gal; const uint64_t *op0, *op1; const lo_evk *key;
     double deadline; uint64_t count;
+    pthread_barrier_t *start;
 } bench_arg;
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static uint64_t *dup_words(const uint64_t *src, size_t n) {
+    uint64_t *d = (uint64_t *)malloc(n * 8);
+    memcpy(d, src, n * 8);  /* first touch by the calling (pinned) thread */
+    return d;
+}
 static void *bench_worker(void *vp) {
     bench_arg *a = (bench_arg *)vp;
-    size_t sz = (size_t)(a->level + 1) * a->e->ringQ->N;
-    uint64_t *out = (uint64_t *)malloc(2 * sz * 8);
+    if (a->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(a->cpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
+    const int N = a->e->ringQ->N;
+    const size_t sz = (size_t)(a->level + 1) * N;
+    const uint64_t *op0 = a->op0, *op1 = a->op1;
+    lo_evk key;
+    if (a->key) key = *a->key;
+    uint64_t *own[4] = {NULL, NULL, NULL, NULL};
+    if (a->private_copy) {
+        op0 = own[0] = dup_words(a->op0, 2 * sz);
+        if (a->op1) op1 = own[1] = dup_words(a->op1, 2 * sz);
+        if (a->key) {
+            key.q = own[2] = dup_words(a->key->q, (size_t)a->key->beta * 2 * a->key->nQk * N);
+            if (a->key->p) key.p = own[3] = dup_words(a->key->p, (size_t)a->key->beta * 2 * a->key->nPk * N);
+        }
+    }
+    uint64_t *out = (uint64_t *)malloc(3 * sz * 8), *out2 = (uint64_t *)malloc(3 * sz * 8);
+    /* one untimed call: page in the scratch pools and the outputs */
+    if (a->kind == 0) lo_bgv_mul_relin(a->e, a->level, a->t, op0, op1, &key, 1, out);
+    else if (a->kind == 1) lo_automorphism_ct(a->e, a->level, op0, a->gal, &key, out);
+    else { lo_ckks_mul_relin(a->e, a->level, op0, op1, NULL, 0, out); lo_rescale(a->e->ringQ, a->level, 2, 1, out, out2); }
+    pthread_barrier_wait(a->start);
+    a->deadline += now_s();
     do {
-        lo_bgv_mul_relin(a->e, a->level, a->t, a->op0, a->op1, a->rlk, 1, out);
+        if (a->kind == 0) lo_bgv_mul_relin(a->e, a->level, a->t, op0, op1, &key, 1, out);
+        else if (a->kind == 1) lo_automorphism_ct(a->e, a->level, op0, a->gal, &key, out);
+        else { lo_ckks_mul_relin(a->e, a->level, op0, op1, NULL, 0, out); lo_rescale(a->e->ringQ, a->level, 2, 1, out, out2); }
         a->count++;
     } while (now_s() < a->deadline);
-    free(out);
+    free(out); free(out2);
+    for (int i = 0; i < 4; i++) free(own[i]);
     lo_pool_release();
     return NULL;
 }
-double lo_bench_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, const uint64_t *op0, const uint64_t *op1,
-                              const lo_evk *rlk, int nthreads, double seconds, uint64_t *counts) {
+double lo_bench_op(const lo_evaluator *e, int kind, int level, uint64_t t, uint64_t gal, const uint64_t *op0, const uint64_t *op1,
+                   const lo_evk *key, int nthreads, double seconds, int pin, int private_copy, uint64_t *counts) {
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
     bench_arg *args = (bench_arg *)calloc(nthreads, sizeof(bench_arg));
-    double t0 = now_s();
+    /* the CPUs this process may run on, in order: thread i goes to the i-th of them (round robin) */
+    cpu_set_t allowed;
+    int cpus[CPU_SETSIZE], ncpu = 0;
+    if (pin && sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[ncpu++] = c;
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, NULL, (unsigned)nthreads + 1);
     for (int i = 0; i < nthreads; i++) {
-        args[i] = (bench_arg){e, level, t, op0, op1, rlk, t0 + seconds, 0};
+        args[i] = (bench_arg){kind, ncpu > 0 ? cpus[i % ncpu] : -1, private_copy, e, level, t, gal, op0, op1, key, seconds, 0, &start};
         pthread_create(&th[i], NULL, bench_worker, &args[i]);
     }
+    pthread_barrier_wait(&start);  /* every thread has its copies and has run once */
+    const double t0 = now_s();
     for (int i = 0; i < nthreads; i++) { pthread_join(th[i], NULL); counts[i] = args[i].count; }
-    double dt = now_s() - t0;
+    const double dt = now_s() - t0;
+    pthread_barrier_destroy(&start);
     free(th); free(args);
     return dt;
+}
+double lo_bench_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, const uint64_t *op0, const uint64_t *op1,
+                              const lo_evk *rlk, int nthreads, double seconds, uint64_t *counts) {
+    return lo_bench_op(e, 0, level, t, 0, op0, op1, rlk, nthreads, seconds, 1, 1, counts);
 }

@@ -141,6 +141,8 @@ def _declare(L):
     L.lo_rescale.argtypes = [vp, i, i, i, u64p, u64p]
     L.lo_bench_bgv_mul_relin.argtypes = [vp, i, u64, u64p, u64p, ep, i, C.c_double, u64p]
     L.lo_bench_bgv_mul_relin.restype = C.c_double
+    L.lo_bench_op.argtypes = [vp, i, i, u64, u64, u64p, u64p, ep, i, C.c_double, i, i, u64p]
+    L.lo_bench_op.restype = C.c_double
 
 
 def _p(a: np.ndarray):
@@ -707,6 +709,18 @@ class Evaluator:
         level = op0.shape[1] - 1
         counts = np.zeros(nthreads, dtype=np.uint64)
         dt = lib().lo_bench_bgv_mul_relin(self._h, level, t, _p(op0), _p(op1), rlk.ref(), nthreads, float(seconds), _p(counts))
+        return int(counts.sum()), float(dt)
+
+    def BenchOp(self, kind: str, op0, op1=None, key: EvaluationKey | None = None, t: int = 0, gal: int = 0, nthreads: int = 1,
+                seconds: float = 1.0, pin: bool = True, private_copy: bool = True):
+        """The generalised timed loop (lo_bench_op): kind "bgv_mulrelin" | "rotate" | "ckks_mul_rescale"; returns (ops, seconds)."""
+        kinds = {"bgv_mulrelin": 0, "rotate": 1, "ckks_mul_rescale": 2}
+        op0 = _c(op0)
+        op1 = _c(op1) if op1 is not None else None
+        level = op0.shape[1] - 1
+        counts = np.zeros(nthreads, dtype=np.uint64)
+        dt = lib().lo_bench_op(self._h, kinds[kind], level, t, gal, _p(op0), _p(op1) if op1 is not None else None,
+                               key.ref() if key else None, nthreads, float(seconds), int(pin), int(private_copy), _p(counts))
         return int(counts.sum()), float(dt)
 
     def Rescale(self, ct, nb=1):

@@ -69,6 +69,65 @@ def test_full_size_config3_bgv_mulrelin_logN15(ctx, B):
     assert np.array_equal(out[0].get(), got[0]) and np.array_equal(out[1].get(), got[1])
 
 
+@pytest.mark.parametrize("scheme", ["bgv", "ckks"])
+def test_full_size_mulrelin_aliasing_squaring_lazy_inputs(ctx, scheme):
+    """The tensor-in-the-ModDown-epilogue path at the headline shape (logN = 15, 12 + 3 limbs, double-precision and integer
+    limbs mixed) under the operand patterns the reference's callers use: the squaring branch (op0 is op1,
+    schemes/bgv/evaluator.go:640-644, schemes/ckks/evaluator.go:812-816), outputs aliasing an input (MulRelin(res, res, res),
+    circuits/ckks/mod1/mod1_evaluator.go:120-135), which must fall back to the three-output tensor kernel, and lazy input
+    words in [0, 2q), which the double-precision limbs reduce before converting.  Every limb of every batch entry."""
+    logN, q, p, t = _bench_config()
+    N, L, alpha, B = 1 << logN, len(q), len(p), 3
+    beta = (L + alpha - 1) // alpha
+    pr = Pair(ctx, logN, L, alpha, qmods=q, pmods=p)
+    rng = rng_for(77 + len(scheme))
+    gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+    kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(beta)])
+    grlk, orlk = gev.NewEvaluationKey(kq, kp), O.EvaluationKey(kq, kp)
+    import bench
+    if scheme == "bgv":
+        gmul = lambda a, b, out: gev.BGVMulRelin(L - 1, t, a, b, grlk, out)
+        omul = lambda a, b: oev.BGVMulRelin(t, a, b, orlk, True)
+    else:
+        gmul = lambda a, b, out: gev.CKKSMulRelin(L - 1, a, b, grlk, out)
+        omul = lambda a, b: oev.CKKSMulRelin(a, b, orlk, True)
+    lazy = lambda: np.stack([np.stack([rng.integers(0, 2 * int(m), size=N, dtype=np.uint64) for m in q]) for _ in range(B)])
+    ct0 = [bench.uniform(rng, q, N, (B,)), lazy()]   # [k][b][limb][N]; the second component holds words up to 2q - 1
+    ct1 = [lazy(), bench.uniform(rng, q, N, (B,))]
+    want = [omul(np.stack([ct0[0][e], ct0[1][e]]), np.stack([ct1[0][e], ct1[1][e]])) for e in range(B)]
+    want_sq = [omul(np.stack([ct0[0][e], ct0[1][e]]), np.stack([ct0[0][e], ct0[1][e]])) for e in range(B)]
+
+    def check(out, ref, what):
+        got = [o.get() for o in out]
+        for e in range(B):
+            assert np.array_equal(got[0][e], ref[e][0]) and np.array_equal(got[1][e], ref[e][1]), (scheme, what, e)
+
+    fresh = lambda ct: [la.Poly(pr.gQ, L, B).upload(c) for c in ct]
+    # lazy words through the fused path (no aliasing)
+    a, b, out = fresh(ct0), fresh(ct1), [la.Poly(pr.gQ, L, B), la.Poly(pr.gQ, L, B)]
+    gmul(a, b, out)
+    check(out, want, "lazy inputs")
+    # squaring: both operands are the same handles, separate output
+    gmul(a, a, out)
+    check(out, want_sq, "op0 is op1")
+    # output aliases the first operand / the second operand
+    a, b = fresh(ct0), fresh(ct1)
+    gmul(a, b, a)
+    check(a, want, "out is op0")
+    a, b = fresh(ct0), fresh(ct1)
+    gmul(a, b, b)
+    check(b, want, "out is op1")
+    # crossed aliasing: out0 is op1[1], out1 is op0[0]
+    a, b = fresh(ct0), fresh(ct1)
+    gmul(a, b, [b[1], a[0]])
+    check([b[1], a[0]], want, "crossed")
+    # in-place squaring, as mod1's double-angle steps do
+    a = fresh(ct0)
+    gmul(a, a, a)
+    check(a, want_sq, "MulRelin(res, res, res)")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # class boundaries
 # ---------------------------------------------------------------------------------------------------------------

@@ -546,6 +546,14 @@ def test_gadget_product_without_special_primes(ctx, pw2):
     galel = pow(5, 3, 2 * pr.N)
     gev.Automorphism(level, p3[:2], galel, gevk, out)
     assert np.array_equal(np.stack([o.get() for o in out]), oev.Automorphism(ct3[:2], galel, oevk))
+    # MulRelin with the P-less key (schemes/ckks/evaluator.go:764-872, schemes/bgv/evaluator.go:592-667): no ModDown to fuse the
+    # tensor into -- the three-output tensor kernel followed by the copy branch of the gadget product
+    a, b = ct3[:2], np.stack([uniform_poly(rng, q, pr.N) for _ in range(2)])
+    pa, pb = [pr.gQ.NewPoly().upload(c) for c in a], [pr.gQ.NewPoly().upload(c) for c in b]
+    gev.CKKSMulRelin(level, pa, pb, gevk, out)
+    assert np.array_equal(np.stack([o.get() for o in out]), oev.CKKSMulRelin(a, b, oevk, True))
+    gev.BGVMulRelin(level, 65537, pa, pb, gevk, out)
+    assert np.array_equal(np.stack([o.get() for o in out]), oev.BGVMulRelin(65537, a, b, oevk, True))
     # what the reference cannot do without special primes is rejected: RNS-only keys, hoisted decompositions
     with pytest.raises(la.HeringError):
         gev.NewEvaluationKey(oevk.q[: len(q)], None)

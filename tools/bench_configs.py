@@ -4,6 +4,7 @@
   ntt limb-NTT/s at logN = 15 and 16 on the config-3 / config-4 chains
   c2  CKKS logN=14, LogQ=[50,40x7], LogP=[60]: Mul+Rescale and MulRelin+Rescale
   c4  CKKS logN=16, LogQ=[60,45x19], LogP=[61x4]: Rotate (automorphism + Galois key-switch)
+  int61  CKKS logN=15, 8 + 4 limbs of 61 bits (the reference's ring test primes): MulRelin on the all-integer kernels
 Synthetic uniform inputs, HIP-event timing on the context stream, one JSON line per measurement."""
 import json
 import os
@@ -11,7 +12,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import lattigo_amd as la  # noqa: E402
 from bench import uniform  # noqa: E402
 
@@ -137,6 +139,29 @@ def main():
     ms = timed(ctx, lambda: ise.InnerSum(L - 1, ct, 1, 64, o2), 3, warm=1)
     out.append({"config": "innersum", "what": "CKKS logN=16 L=20 alpha=4: InnerSum(batch=1, n=64) (6 hoisted rotations)",
                 "batch": B, "ms": ms, "ops_per_s": B / (ms * 1e-3)})
+    # ---- an all-integer chain: the reference's own 61-bit ring test primes (ring/test_params.go:15-32), logN = 15, 8 + 4 limbs.
+    # No modulus below 2^47: every kernel takes its integer path (Harvey-form row transforms, the LDS-parking basis extension of
+    # a 4-limb digit with three column stages, 128-bit inner product)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Pi60, Qi60
+    N, q61, p61, B = 1 << 15, Qi60[:8], Pi60[:4], 64
+    rq, rp = la.Ring(ctx, N, q61), la.Ring(ctx, N, p61)
+    ev = la.Evaluator(rq, rp)
+    L, beta = len(q61), 2
+    rlk = ev.NewEvaluationKey(uniform(rng, q61, N, (beta, 2)), uniform(rng, p61, N, (beta, 2)))
+    a = [la.Poly(rq, L, B).upload(uniform(rng, q61, N, (B,))) for _ in range(2)]
+    b = [la.Poly(rq, L, B).upload(uniform(rng, q61, N, (B,))) for _ in range(2)]
+    o2 = [la.Poly(rq, L, B) for _ in range(2)]
+    ms = timed(ctx, lambda: ev.CKKSMulRelin(L - 1, a, b, rlk, o2), 10)
+    ctx.prof_begin()
+    ev.CKKSMulRelin(L - 1, a, b, rlk, o2)
+    prof = ctx.prof_end_bytes()
+    limb = N * 8
+    out.append({"config": "int61", "what": "CKKS logN=15, 8 Q + 4 P limbs of 61 bits (ring/test_params.go primes): MulRelin, all-integer kernels",
+                "batch": B, "ms": ms, "ops_per_s": B / (ms * 1e-3),
+                "alg_GBs": B * (6 * L + 2 * beta * (L + 4)) * limb / (ms * 1e-3) / 1e9,
+                "kernel_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+                "kernel_GBs": {k: round(v[2] / (v[1] * 1e-3) / 1e9) for k, v in prof.items() if v[1] > 0}})
     for line in out:
         print(json.dumps(line))
 
