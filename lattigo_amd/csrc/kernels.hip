@@ -2281,7 +2281,19 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     const uint64_t *src = A.src + bz * A.src_bs + c;
 
     // mixed variant: the integer residues live in LDS (read back only for the few large destination moduli)
-    __shared__ uint64_t ylds[DSTF64 ? NSRC * R : 1][128];
+    // Long digits (NSRC > 3 with three column stages: 8 residues per source and thread) keep the first KREG sources' residues in
+    // registers and park only the rest: with all of them in LDS a 128-thread workgroup needs NSRC KiB x 8 (40 KiB at the
+    // bootstrapping shape, NSRC = 5) and a CU holds three of them -- 1.5 waves per SIMD for an instruction-bound kernel.
+#ifndef HE_MODUP_KREG_MAX
+#define HE_MODUP_KREG_MAX 3
+#endif
+    constexpr int KREG = (DSTF64 && LOGA == 3 && NSRC > 3) ? (NSRC - 3 < HE_MODUP_KREG_MAX ? NSRC - 3 : HE_MODUP_KREG_MAX) : 0;
+    __shared__ uint64_t ylds[DSTF64 ? (NSRC - KREG) * R : 1][128];
+    uint64_t yreg[KREG ? R : 1][KREG ? KREG : 1];
+    auto ypark = [&](int r, int i, uint64_t v) {  // (r, i are compile-time constants after unrolling)
+        if (i < KREG) yreg[r][i] = v; else ylds[(i - KREG) * R + r][threadIdx.x] = v;
+    };
+    auto ytake = [&](int r, int i) -> uint64_t { return i < KREG ? yreg[r][i] : ylds[(i - KREG) * R + r][threadIdx.x]; };
     uint64_t y[DSTF64 ? 1 : R][DSTF64 ? 1 : NSRC];   // integer variant
 #ifndef HE_MODUP_Y_LDS
 #define HE_MODUP_Y_LDS 1
@@ -2350,7 +2362,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 const bool ng = cv >= (q >> 1);
                 negmask |= (uint32_t)ng << r;
                 cv = ng ? q - cv : cv;
-                if constexpr (DSTF64) ylds[i * R + r][threadIdx.x] = cv;
+                if constexpr (DSTF64) ypark(r, i, cv);
                 else y[r][i] = cv;
             }
         } else {
@@ -2382,7 +2394,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 // 2^-40 of an integer (|estimate - exact sum| < 2^-42 for <= 32 terms)
                 vi[r] = __dadd_rn(vi[r], yd[r] * rq);
                 if constexpr (DSTF64) {
-                    ylds[i * R + r][threadIdx.x] = yi[r];
+                    ypark(r, i, yi[r]);
                     if constexpr (YREG) {
                         yl[r][i] = split ? u52_to_f64(yi[r] & ((1ull << 26) - 1)) : yd[r];
                         yh[r][i] = split ? u52_to_f64(yi[r] >> 26) : 0.0;
@@ -2402,7 +2414,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
 #pragma unroll
                 for (int i = 0; i < NSRC; i++) {
                     uint64_t yi;
-                    if constexpr (DSTF64) yi = ylds[i * R + r][threadIdx.x];
+                    if constexpr (DSTF64) yi = ytake(r, i);
                     else yi = y[r][i];
                     e = __dadd_rn(e, __ddiv_rn(__ull2double_rn(yi), __ull2double_rn(A.mc[U(D.src_mod[i])].q)));
                 }
@@ -2419,6 +2431,14 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     }
 
     for (int j = 0; j < ndst; j++) {
+        if constexpr (KREG > 0) {
+            // the register-resident residues are made opaque per destination: otherwise their conversions (to double, to 26- and
+            // 30-bit halves) are hoisted out of this loop and kept live -- 80 registers instead of 16
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int i = 0; i < KREG; i++) asm volatile("" : "+v"(yreg[r][i]));
+        }
         const int mi = (int)U(D.dst_mod[j]);
         const ModConst mp = A.mc[mi];
         const uint64_t p = mp.q, pinv = mp.qinv, twop = mp.q << 1;
@@ -2427,7 +2447,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                         (size_t)U(D.dst_limb[j]) * A.N + c;
         // residue y_i of coefficient r as an integer (the mixed variant keeps them as doubles)
         auto Y = [&](int r, int i) -> uint64_t {
-            if constexpr (DSTF64) return ylds[i * R + r][threadIdx.x];
+            if constexpr (DSTF64) return ytake(r, i);
             else return y[r][i];
         };
         bool done = false;
@@ -2438,7 +2458,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
             if (single) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const uint64_t t = bred_add(ylds[r][threadIdx.x], p, mp.brc0);
+                    const uint64_t t = bred_add(ytake(r, 0), p, mp.brc0);
                     o[r] = u52_to_f64(((negmask >> r) & 1) ? p - t : t);
                 }
             } else {
@@ -2461,13 +2481,13 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                     } else if ((splitmask >> i) & 1) {  // y >= 2^51 possible: y = yh 2^26 + yl, two exact products
 #pragma unroll
                         for (int r = 0; r < R; r++) {
-                            const uint64_t yy = ylds[i * R + r][threadIdx.x];
+                            const uint64_t yy = ytake(r, i);
                             o[r] += modmul_f64(u52_to_f64(yy & ((1ull << 26) - 1)), Tl, pd, pid);
                             o[r] += modmul_f64(u52_to_f64(yy >> 26), Th, pd, pid);
                         }
                     } else {
 #pragma unroll
-                        for (int r = 0; r < R; r++) o[r] += modmul_f64(u52_to_f64(ylds[i * R + r][threadIdx.x]), Tl, pd, pid);
+                        for (int r = 0; r < R; r++) o[r] += modmul_f64(u52_to_f64(ytake(r, i)), Tl, pd, pid);
                     }
                 }  // |o| < (2 + 5*NSRC) p
             }
