@@ -20,6 +20,16 @@ import (
 // twins, run the HIP path and mark the results device-fresh.  Host memory is only touched by Upload / Download: the
 // circuit drivers above call the provider back-to-back on the same objects, so operands stay in HBM between calls, and a
 // caller that wants to read a result on the host (decrypt, serialise) calls Evaluator.Download on it first.
+//
+// STALENESS CONTRACT (applies to every method below that takes a ring.Poly / rlwe.Ciphertext / ringqp.Poly; each repeats it):
+//   - a twin is keyed on the address of the host polynomial's first coefficient.  The FIRST time a host polynomial is seen as an
+//     input its words are uploaded; afterwards the DEVICE copy is the authoritative one and the host words are NOT read again;
+//   - a caller that modifies a host polynomial on the host after its first use (encoder, sampler, CopyLvl, a CPU ring call)
+//     MUST call Upload(ring, p) before passing it in again, or the device computes on the old words -- silently;
+//   - results exist on the device only: the host words of an output are stale until Download / DownloadCiphertext / Sync;
+//   - Sync() downloads every output twin that has not been downloaded since it was last written (a full barrier: after it the
+//     host view equals the device view for everything this evaluator produced);
+//   - Forget(p) drops a twin; the cache holds at most MaxTwins twins and is emptied (after a Sync) when it would grow beyond.
 type Evaluator struct {
 	params rlwe.Parameters
 	ctx    *Context
@@ -28,8 +38,14 @@ type Evaluator struct {
 	RingP  *Ring
 	keys   rlwe.EvaluationKeySet
 
+	// MaxTwins bounds the twin cache (0: DefaultMaxTwins): the key pointers keep every host polynomial alive and every twin
+	// resident in HBM, so a long circuit without Forget would otherwise grow without limit
+	MaxTwins int
+
 	mu     sync.Mutex
 	polys  map[*uint64]*Poly                      // twin of a ring.Poly, keyed by the address of its first coefficient
+	hosts  map[*uint64]ring.Poly                  // the host polynomial of each twin (for Sync)
+	dirty  map[*uint64]bool                       // twins written on the device since their last Download
 	evks   map[*rlwe.GadgetCiphertext]*EvaluationKey // keys are immutable once generated: uploaded once
 	decs   map[*uint64]*Decomposition             // twin of a BuffDecompQP slice, keyed like polys on its first Q row
 	index  map[uint64]*AutomorphismIndex
@@ -40,7 +56,8 @@ type Evaluator struct {
 func NewEvaluator(ctx *Context, params rlwe.ParameterProvider, evk rlwe.EvaluationKeySet) (*Evaluator, error) {
 	p := *params.GetRLWEParameters()
 	e := &Evaluator{params: p, ctx: ctx, keys: evk, batch: 1,
-		polys: map[*uint64]*Poly{}, evks: map[*rlwe.GadgetCiphertext]*EvaluationKey{}, decs: map[*uint64]*Decomposition{},
+		polys: map[*uint64]*Poly{}, hosts: map[*uint64]ring.Poly{}, dirty: map[*uint64]bool{},
+		evks: map[*rlwe.GadgetCiphertext]*EvaluationKey{}, decs: map[*uint64]*Decomposition{},
 		index: map[uint64]*AutomorphismIndex{}}
 	var err error
 	if e.RingQ, err = NewRing(ctx, p.RingQ()); err != nil {
@@ -66,14 +83,35 @@ func (e *Evaluator) GetRLWEParameters() *rlwe.Parameters { return &e.params }
 
 func key(p ring.Poly) *uint64 { return &p.Coeffs[0][0] }
 
+// DefaultMaxTwins is the twin-cache bound when Evaluator.MaxTwins is 0.
+const DefaultMaxTwins = 4096
+
 // twin returns the device polynomial of a host polynomial of ring r; upload says whether the host content is the current
 // one (an input seen for the first time) or about to be overwritten (an output).
 func (e *Evaluator) twin(r *Ring, p ring.Poly, upload bool) (*Poly, error) {
 	e.mu.Lock()
 	d, ok := e.polys[key(p)]
+	if ok && !upload {
+		e.dirty[key(p)] = true // an output: the device copy is about to become newer than the host's
+	}
 	e.mu.Unlock()
 	if ok && d.limbs >= len(p.Coeffs) {
 		return d, nil
+	}
+	max := e.MaxTwins
+	if max == 0 {
+		max = DefaultMaxTwins
+	}
+	e.mu.Lock()
+	full := len(e.polys) >= max
+	e.mu.Unlock()
+	if full { // bound the cache: bring the host up to date, then start over (twins still referenced by callers stay valid)
+		if err := e.Sync(); err != nil {
+			return nil, err
+		}
+		e.mu.Lock()
+		e.polys, e.hosts, e.dirty = map[*uint64]*Poly{}, map[*uint64]ring.Poly{}, map[*uint64]bool{}
+		e.mu.Unlock()
 	}
 	d, err := r.AtLevel(len(p.Coeffs) - 1).NewScratch(e.batch)
 	if err != nil {
@@ -86,8 +124,40 @@ func (e *Evaluator) twin(r *Ring, p ring.Poly, upload bool) (*Poly, error) {
 	}
 	e.mu.Lock()
 	e.polys[key(p)] = d
+	e.hosts[key(p)] = p
+	if !upload {
+		e.dirty[key(p)] = true
+	}
 	e.mu.Unlock()
 	return d, nil
+}
+
+// Sync downloads every twin that was written on the device since its last Download, so that the host view of everything this
+// evaluator produced is current (see the staleness contract at the type).  It waits for the context's stream.
+func (e *Evaluator) Sync() error {
+	e.mu.Lock()
+	todo := make([]*uint64, 0, len(e.dirty))
+	for k, d := range e.dirty {
+		if d {
+			todo = append(todo, k)
+		}
+	}
+	e.mu.Unlock()
+	for _, k := range todo {
+		e.mu.Lock()
+		d, host := e.polys[k], e.hosts[k]
+		e.mu.Unlock()
+		if d == nil {
+			continue
+		}
+		if err := d.Download(0, host); err != nil {
+			return err
+		}
+		e.mu.Lock()
+		e.dirty[k] = false
+		e.mu.Unlock()
+	}
+	return e.ctx.Sync()
 }
 
 // Upload refreshes the device twin of a host polynomial that was modified on the host.
@@ -96,6 +166,9 @@ func (e *Evaluator) Upload(r *Ring, p ring.Poly) error {
 	if err != nil {
 		return err
 	}
+	e.mu.Lock()
+	e.dirty[key(p)] = false // host and device agree after the upload
+	e.mu.Unlock()
 	return d.Upload(0, p)
 }
 
@@ -107,7 +180,13 @@ func (e *Evaluator) Download(p ring.Poly) error {
 	if !ok {
 		return nil
 	}
-	return d.Download(0, p)
+	if err := d.Download(0, p); err != nil {
+		return err
+	}
+	e.mu.Lock()
+	e.dirty[key(p)] = false
+	e.mu.Unlock()
+	return nil
 }
 
 // DownloadCiphertext brings every component of ct back to the host.
@@ -124,6 +203,8 @@ func (e *Evaluator) DownloadCiphertext(ct *rlwe.Ciphertext) error {
 func (e *Evaluator) Forget(p ring.Poly) {
 	e.mu.Lock()
 	delete(e.polys, key(p))
+	delete(e.hosts, key(p))
+	delete(e.dirty, key(p))
 	e.mu.Unlock()
 }
 
@@ -228,6 +309,8 @@ func h(p *Poly) Handle {
 // ---- rlwe.EvaluatorProvider (core/rlwe/rlwe.go:10-18) -----------------------------------------------------------------------
 
 // DecomposeNTT: core/rlwe/evaluator_gadget_product.go:459.
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) DecomposeNTT(level, levelP, pCount int, c1 ring.Poly, isNTT bool, BuffDecompQP []ringqp.Poly) {
 	c, err := e.twin(e.RingQ, c1, true)
 	if err != nil {
@@ -260,6 +343,8 @@ func (e *Evaluator) CheckAndGetGaloisKey(galEl uint64) (evk *rlwe.GaloisKey, err
 }
 
 // GadgetProductLazy: core/rlwe/evaluator_gadget_product.go:108 (ct.IsNTT domain handling as there).
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) GadgetProductLazy(levelQ int, cx ring.Poly, gadgetCt *rlwe.GadgetCiphertext, ct *rlwe.Element[ringqp.Poly]) (err error) {
 	if ct.LevelP() < gadgetCt.LevelP() {
 		return fmt.Errorf("ctQP.LevelP()=%d < gadgetCt.LevelP()=%d", ct.LevelP(), gadgetCt.LevelP())
@@ -315,6 +400,8 @@ func (e *Evaluator) GadgetProductLazy(levelQ int, cx ring.Poly, gadgetCt *rlwe.G
 // only (NTT domain, canonical): the per-GPU share when one key switch is split over several devices by digit -- each device
 // holds its digits of the key, the partial (Q, P) accumulators are summed across devices (RCCL all-reduce on
 // he_poly_device_buffer storage) and reduced before ModDown.  No counterpart in the reference (one address space).
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) GadgetProductHoistedLazyDigits(levelQ int, BuffQPDecompQP []ringqp.Poly, gadgetCt *rlwe.GadgetCiphertext, digitBegin, digitEnd int, ct *rlwe.Element[ringqp.Poly]) (err error) {
 	if gadgetCt.BaseTwoDecomposition != 0 {
 		return fmt.Errorf("method is unsupported for BaseTwoDecomposition != 0")
@@ -341,6 +428,8 @@ func (e *Evaluator) GadgetProductHoistedLazyDigits(levelQ int, BuffQPDecompQP []
 }
 
 // GadgetProductHoistedLazy: core/rlwe/evaluator_gadget_product.go:379.
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) GadgetProductHoistedLazy(levelQ int, BuffQPDecompQP []ringqp.Poly, gadgetCt *rlwe.GadgetCiphertext, ct *rlwe.Element[ringqp.Poly]) (err error) {
 	if gadgetCt.BaseTwoDecomposition != 0 {
 		return fmt.Errorf("method is unsupported for BaseTwoDecomposition != 0")
@@ -383,6 +472,8 @@ func (e *Evaluator) GadgetProductHoistedLazy(levelQ int, BuffQPDecompQP []ringqp
 }
 
 // AutomorphismHoistedLazy: core/rlwe/evaluator_automorphism.go:104 (NTT-domain ciphertexts, as every caller in circuits/).
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) AutomorphismHoistedLazy(levelQ int, ctIn *rlwe.Ciphertext, c1DecompQP []ringqp.Poly, galEl uint64, ctQP *rlwe.Element[ringqp.Poly]) (err error) {
 	gk, err := e.CheckAndGetGaloisKey(galEl)
 	if err != nil {
@@ -420,6 +511,8 @@ func (e *Evaluator) AutomorphismHoistedLazy(levelQ int, ctIn *rlwe.Ciphertext, c
 }
 
 // ModDownQPtoQNTT: ring/basis_extension.go:235 through the evaluator's fused three-launch pipeline.
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) ModDownQPtoQNTT(levelQ, levelP int, p1Q, p1P, p2Q ring.Poly) {
 	a, err := e.twin(e.RingQ, p1Q, true)
 	if err != nil {
@@ -474,6 +567,8 @@ func (e *Evaluator) autoIndex(galEl uint64) (*AutomorphismIndex, error) {
 // ---- the full (non-lazy) operators of rlwe.Evaluator the scheme layer calls -----------------------------------------------------
 
 // GadgetProduct: core/rlwe/evaluator_gadget_product.go:16.
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) GadgetProduct(levelQ int, cx ring.Poly, gadgetCt *rlwe.GadgetCiphertext, ct *rlwe.Ciphertext) error {
 	k, err := e.evk(gadgetCt)
 	if err != nil {
@@ -495,6 +590,8 @@ func (e *Evaluator) GadgetProduct(levelQ int, cx ring.Poly, gadgetCt *rlwe.Gadge
 }
 
 // Relinearize: core/rlwe/evaluator_evaluationkey.go:117 (degree 2 -> degree 1).
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) Relinearize(ctIn, opOut *rlwe.Ciphertext) error {
 	if ctIn.Degree() != 2 {
 		return fmt.Errorf("cannot relinearize: ctIn.Degree() should be 2 but is %d", ctIn.Degree())
@@ -536,6 +633,8 @@ func (e *Evaluator) Relinearize(ctIn, opOut *rlwe.Ciphertext) error {
 }
 
 // Automorphism: core/rlwe/evaluator_automorphism.go:13 (NTT domain).
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) Automorphism(ctIn *rlwe.Ciphertext, galEl uint64, opOut *rlwe.Ciphertext) error {
 	gk, err := e.CheckAndGetGaloisKey(galEl)
 	if err != nil {
@@ -576,6 +675,8 @@ func (e *Evaluator) Automorphism(ctIn *rlwe.Ciphertext, galEl uint64, opOut *rlw
 }
 
 // AutomorphismHoisted: core/rlwe/evaluator_automorphism.go:60.
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (e *Evaluator) AutomorphismHoisted(level int, ctIn *rlwe.Ciphertext, c1DecompQP []ringqp.Poly, galEl uint64, opOut *rlwe.Ciphertext) error {
 	gk, err := e.CheckAndGetGaloisKey(galEl)
 	if err != nil {

@@ -38,11 +38,15 @@ func check(rc C.int) error {
 	return errors.New("hering: " + C.GoString(C.he_last_error()))
 }
 
-// lockedCall runs f on a pinned OS thread so that a non-zero status and its message are read on the same thread.
-func lockedCall(f func() C.int) error {
+// lockedCall runs f on a pinned OS thread so that a non-zero status and its message are read on the same thread.  `keep` lists
+// the Go objects whose handles f passes to C: handles are plain integers, so without it the collector could run a finalizer
+// (he_*_destroy / he_poly_free) on an object whose last Go reference was the read of its handle, while the call is in flight.
+func lockedCall(f func() C.int, keep ...any) error {
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
-	return check(f())
+	err := check(f())
+	runtime.KeepAlive(keep)
+	return err
 }
 
 // Context owns one HIP stream on one GPU; all work of the objects created from it is enqueued there.
@@ -72,7 +76,12 @@ type Ring struct {
 	n     int
 	level int
 	host  *ring.Ring
+	own   *ringOwner // shared by every AtLevel copy: the handle lives as long as any of them
 }
+
+// ringOwner carries the finalizer of a ring handle.  AtLevel copies hold a pointer to it, so he_ring_destroy runs only when the
+// original AND every copy are unreachable (a finalizer on the original alone would pull the handle from under the copies).
+type ringOwner struct{ h Handle }
 
 // NewRing mirrors ring.NewRingFromType for an existing reference ring.
 func NewRing(ctx *Context, r *ring.Ring) (*Ring, error) {
@@ -88,11 +97,12 @@ func NewRing(ctx *Context, r *ring.Ring) (*Ring, error) {
 	if err != nil {
 		return nil, err
 	}
-	runtime.SetFinalizer(d, func(d *Ring) { C.he_ring_destroy(d.h) })
+	d.own = &ringOwner{h: d.h}
+	runtime.SetFinalizer(d.own, func(o *ringOwner) { C.he_ring_destroy(o.h) })
 	return d, nil
 }
 
-// AtLevel: ring.Ring.AtLevel (ring/ring.go:186).
+// AtLevel: ring.Ring.AtLevel (ring/ring.go:186).  The copy shares the handle and its owner.
 func (r *Ring) AtLevel(level int) *Ring { c := *r; c.level = level; return &c }
 
 // Level, N as the reference.

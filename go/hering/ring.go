@@ -11,49 +11,49 @@ import "unsafe"
 // ring/automorphism.go).  Outputs are caller-allocated and last, in-place aliasing as the reference allows it.
 
 func (r *Ring) NTT(p1, p2 *Poly) error {
-	return lockedCall(func() C.int { return C.he_ntt(r.h, C.int(r.level), p1.h, p2.h) })
+	return lockedCall(func() C.int { return C.he_ntt(r.h, C.int(r.level), p1.h, p2.h) }, r, p1, p2)
 }
 func (r *Ring) NTTLazy(p1, p2 *Poly) error {
-	return lockedCall(func() C.int { return C.he_ntt_lazy(r.h, C.int(r.level), p1.h, p2.h) })
+	return lockedCall(func() C.int { return C.he_ntt_lazy(r.h, C.int(r.level), p1.h, p2.h) }, r, p1, p2)
 }
 func (r *Ring) INTT(p1, p2 *Poly) error {
-	return lockedCall(func() C.int { return C.he_intt(r.h, C.int(r.level), p1.h, p2.h) })
+	return lockedCall(func() C.int { return C.he_intt(r.h, C.int(r.level), p1.h, p2.h) }, r, p1, p2)
 }
 func (r *Ring) INTTLazy(p1, p2 *Poly) error {
-	return lockedCall(func() C.int { return C.he_intt_lazy(r.h, C.int(r.level), p1.h, p2.h) })
+	return lockedCall(func() C.int { return C.he_intt_lazy(r.h, C.int(r.level), p1.h, p2.h) }, r, p1, p2)
 }
 
 func (r *Ring) Add(p1, p2, p3 *Poly) error {
-	return lockedCall(func() C.int { return C.he_add(r.h, C.int(r.level), p1.h, p2.h, p3.h) })
+	return lockedCall(func() C.int { return C.he_add(r.h, C.int(r.level), p1.h, p2.h, p3.h) }, r, p1, p2, p3)
 }
 func (r *Ring) Sub(p1, p2, p3 *Poly) error {
-	return lockedCall(func() C.int { return C.he_sub(r.h, C.int(r.level), p1.h, p2.h, p3.h) })
+	return lockedCall(func() C.int { return C.he_sub(r.h, C.int(r.level), p1.h, p2.h, p3.h) }, r, p1, p2, p3)
 }
 func (r *Ring) Neg(p1, p2 *Poly) error {
-	return lockedCall(func() C.int { return C.he_neg(r.h, C.int(r.level), p1.h, p2.h) })
+	return lockedCall(func() C.int { return C.he_neg(r.h, C.int(r.level), p1.h, p2.h) }, r, p1, p2)
 }
 func (r *Ring) Reduce(p1, p2 *Poly) error {
-	return lockedCall(func() C.int { return C.he_reduce(r.h, C.int(r.level), p1.h, p2.h) })
+	return lockedCall(func() C.int { return C.he_reduce(r.h, C.int(r.level), p1.h, p2.h) }, r, p1, p2)
 }
 func (r *Ring) MForm(p1, p2 *Poly) error {
-	return lockedCall(func() C.int { return C.he_mform(r.h, C.int(r.level), p1.h, p2.h) })
+	return lockedCall(func() C.int { return C.he_mform(r.h, C.int(r.level), p1.h, p2.h) }, r, p1, p2)
 }
 func (r *Ring) IMForm(p1, p2 *Poly) error {
-	return lockedCall(func() C.int { return C.he_imform(r.h, C.int(r.level), p1.h, p2.h) })
+	return lockedCall(func() C.int { return C.he_imform(r.h, C.int(r.level), p1.h, p2.h) }, r, p1, p2)
 }
 func (r *Ring) MulCoeffsMontgomery(p1, p2, p3 *Poly) error {
-	return lockedCall(func() C.int { return C.he_mul_coeffs_montgomery(r.h, C.int(r.level), p1.h, p2.h, p3.h) })
+	return lockedCall(func() C.int { return C.he_mul_coeffs_montgomery(r.h, C.int(r.level), p1.h, p2.h, p3.h) }, r, p1, p2, p3)
 }
 func (r *Ring) MulCoeffsMontgomeryThenAdd(p1, p2, p3 *Poly) error {
-	return lockedCall(func() C.int { return C.he_mul_coeffs_montgomery_then_add(r.h, C.int(r.level), p1.h, p2.h, p3.h) })
+	return lockedCall(func() C.int { return C.he_mul_coeffs_montgomery_then_add(r.h, C.int(r.level), p1.h, p2.h, p3.h) }, r, p1, p2, p3)
 }
 func (r *Ring) MulCoeffsMontgomeryLazy(p1, p2, p3 *Poly) error {
-	return lockedCall(func() C.int { return C.he_mul_coeffs_montgomery_lazy(r.h, C.int(r.level), p1.h, p2.h, p3.h) })
+	return lockedCall(func() C.int { return C.he_mul_coeffs_montgomery_lazy(r.h, C.int(r.level), p1.h, p2.h, p3.h) }, r, p1, p2, p3)
 }
 func (r *Ring) MulCoeffsMontgomeryLazyThenAddLazy(p1, p2, p3 *Poly) error {
 	return lockedCall(func() C.int {
 		return C.he_mul_coeffs_montgomery_lazy_then_add_lazy(r.h, C.int(r.level), p1.h, p2.h, p3.h)
-	})
+	}, r, p1, p2, p3)
 }
 
 // MulScalar / AddScalar: ring/operations.go:201,151 (selector values of enum he_scalar_op in hering.h).

@@ -102,16 +102,24 @@ func (s *SchemeEvaluator) addSub(op0 *rlwe.Ciphertext, op1 rlwe.Operand, opOut *
 	return nil
 }
 
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) Add(op0 *rlwe.Ciphertext, op1 rlwe.Operand, opOut *rlwe.Ciphertext) error {
 	return s.addSub(op0, op1, opOut, false)
 }
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) Sub(op0 *rlwe.Ciphertext, op1 rlwe.Operand, opOut *rlwe.Ciphertext) error {
 	return s.addSub(op0, op1, opOut, true)
 }
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) AddNew(op0 *rlwe.Ciphertext, op1 rlwe.Operand) (*rlwe.Ciphertext, error) {
 	out := rlwe.NewCiphertext(s, op0.Degree(), op0.Level())
 	return out, s.Add(op0, op1, out)
 }
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) SubNew(op0 *rlwe.Ciphertext, op1 rlwe.Operand) (*rlwe.Ciphertext, error) {
 	out := rlwe.NewCiphertext(s, op0.Degree(), op0.Level())
 	return out, s.Sub(op0, op1, out)
@@ -181,16 +189,24 @@ func (s *SchemeEvaluator) mul(op0 *rlwe.Ciphertext, op1 rlwe.Operand, opOut *rlw
 	return nil
 }
 
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) Mul(op0 *rlwe.Ciphertext, op1 rlwe.Operand, opOut *rlwe.Ciphertext) error {
 	return s.mul(op0, op1, opOut, false)
 }
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) MulRelin(op0 *rlwe.Ciphertext, op1 rlwe.Operand, opOut *rlwe.Ciphertext) error {
 	return s.mul(op0, op1, opOut, true)
 }
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) MulNew(op0 *rlwe.Ciphertext, op1 rlwe.Operand) (*rlwe.Ciphertext, error) {
 	out := rlwe.NewCiphertext(s, 2, op0.Level())
 	return out, s.Mul(op0, op1, out)
 }
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) MulRelinNew(op0 *rlwe.Ciphertext, op1 rlwe.Operand) (*rlwe.Ciphertext, error) {
 	out := rlwe.NewCiphertext(s, 1, op0.Level())
 	return out, s.MulRelin(op0, op1, out)
@@ -198,6 +214,8 @@ func (s *SchemeEvaluator) MulRelinNew(op0 *rlwe.Ciphertext, op1 rlwe.Operand) (*
 
 // MulThenAdd: opOut += op0 * op1 (schemes/ckks/evaluator.go:1081, schemes/bgv/evaluator.go:1230); the ct x ct product goes
 // through the device tensor into a scratch ciphertext, the accumulation is a device Add.
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) MulThenAdd(op0 *rlwe.Ciphertext, op1 rlwe.Operand, opOut *rlwe.Ciphertext) error {
 	c1, ok := s.ct(op1)
 	if !ok || op0.Degree() != 1 || c1.Degree() != 1 {
@@ -214,10 +232,14 @@ func (s *SchemeEvaluator) MulThenAdd(op0 *rlwe.Ciphertext, op1 rlwe.Operand, opO
 }
 
 // Relinearize: schemes.Evaluator.Relinearize(op0, op1) -> rlwe.Evaluator.Relinearize.
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) Relinearize(op0, op1 *rlwe.Ciphertext) error { return s.Evaluator.Relinearize(op0, op1) }
 
 // Rescale: per component DivRoundByLastModulusManyNTT (schemes/ckks/evaluator.go:477-515, schemes/bgv/evaluator.go:1363); how
 // many levels to drop and the new scale are the scheme's decision (RescaleTo).
+// Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
+// outputs are written on the device only (Download / Sync before reading them on the host).
 func (s *SchemeEvaluator) Rescale(op0, op1 *rlwe.Ciphertext) error {
 	nb, err := s.RescaleTo(op0, op1)
 	if err != nil || nb == 0 {

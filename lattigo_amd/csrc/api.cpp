@@ -312,6 +312,10 @@ struct FusedPlan {
 struct Evaluator : Obj {
     std::shared_ptr<BasisExtender> be;
     ConstPool pool;
+    // automorphism index tables by Galois element, built on first use and kept (the reference caches them the same way:
+    // Evaluator.automorphismIndex, core/rlwe/evaluator.go:81-86,:190-205); N x 4 bytes each
+    std::unordered_map<uint64_t, uint32_t *> auto_index;
+    static constexpr size_t kAutoIndexCap = 4096;
     // dec[nbPi-2][digit][j]: source = first j+2 limbs of the digit, target = all Q then P[:nbPi]
     std::vector<std::vector<std::vector<ModUpRef>>> dec;
     std::map<std::tuple<int, int, int>, FusedPlan> dec_plans;  // (levelQ, levelP, nbPi)
@@ -322,6 +326,7 @@ struct Evaluator : Obj {
         hipSetDevice(be->ctx->dev);
         hipStreamSynchronize(be->ctx->stream);
         for (ModUpDesc *p : plan_mem) hipFree(p);
+        for (auto &kv : auto_index) hipFree(kv.second);
         pool.release();
     }
 };
@@ -2355,6 +2360,24 @@ int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_
 }
 
 // Automorphism / AutomorphismHoisted (core/rlwe/evaluator_automorphism.go:13-100), NTT domain
+// the evaluator's cached index table of a Galois element (built once, on the context's stream: later launches are ordered after it)
+static int cached_auto_index(Evaluator &ev, uint64_t gal, const uint32_t **out) {
+    auto it = ev.auto_index.find(gal);
+    if (it != ev.auto_index.end()) { *out = it->second; return HE_OK; }
+    BasisExtender &be = *ev.be;
+    if (ev.auto_index.size() >= Evaluator::kAutoIndexCap) {  // a bound on the memory a long-running caller can pin
+        HIP_TRY(hipStreamSynchronize(be.ctx->stream));
+        for (auto &kv : ev.auto_index) (void)hipFree(kv.second);
+        ev.auto_index.clear();
+    }
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)be.Q->N * sizeof(uint32_t)));
+    hipError_t e = launch_build_automorphism_index(be.Q->logN, be.Q->logN + be.type, gal, d, be.ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(HE_EDEVICE, "automorphism index: %s", hipGetErrorString(e)); }
+    ev.auto_index.emplace(gal, d);
+    *out = d;
+    return HE_OK;
+}
 static int automorphism_common(he_handle hev, int level, he_handle hin0, he_handle hin1, he_handle hdec, uint64_t gal, he_handle hk,
                                he_handle hout0, he_handle hout1, const char *who) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -2384,9 +2407,9 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     const size_t wQ = (size_t)B * (level + 1) * N;
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, !dec, k.get()) + 2 * wQ + (size_t)N));
     View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
-    uint32_t *index = reinterpret_cast<uint32_t *>(be.ctx->arena_take((size_t)N / 2 + 2));
+    const uint32_t *index = nullptr;
+    TRY(cached_auto_index(*ev, gal, &index));
     hipStream_t st = be.ctx->stream;
-    HIP_TRY(launch_build_automorphism_index(be.Q->logN, be.Q->logN + be.type, gal, index, st));
     View in1v{nullptr, 0};
     if (in1) in1v = in1->view();
     const View in0v = in0->view();
@@ -2427,9 +2450,9 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     TRY(be.ctx->arena_reserve(2 * B * (sQw + sPw) + N + 64));
     View t0Q{be.ctx->arena_take(B * sQw), sQw}, t1Q{be.ctx->arena_take(B * sQw), sQw};
     View t0P{be.ctx->arena_take(B * sPw), sPw}, t1P{be.ctx->arena_take(B * sPw), sPw};
-    uint32_t *index = reinterpret_cast<uint32_t *>(be.ctx->arena_take((size_t)N / 2 + 2));
+    const uint32_t *index = nullptr;
+    TRY(cached_auto_index(*ev, gal, &index));
     hipStream_t st = be.ctx->stream;
-    HIP_TRY(launch_build_automorphism_index(be.Q->logN, be.Q->logN + be.type, gal, index, st));
     TRY(ks_inner(*ev, levelQ, levelP, dec->d, dec->bstride(), dec->dstride(), *k, t0Q, t0P, t1Q, t1P, B));
     const LimbTab tq = ident_tab(levelQ + 1), tp = ident_tab(levelP + 1, 0, 0, be.LQ);
     HIP_TRY(launch_gather(be.qp, tq, t1Q, index, o.q1->view(), B, false, st));
