@@ -816,17 +816,38 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
                 const uint64_t *pa0 = A.ta0 + zz * A.ta0_bs + toff, *pa1 = A.ta1 + zz * A.ta1_bs + toff;
                 const uint64_t *pb0 = A.tb0 + zz * A.tb0_bs + toff, *pb1 = A.tb1 + zz * A.tb1_bs + toff;
                 const double tsp = (double)imform(imform(A.epi_ts[y], mc.q, mc.qinv), mc.q, mc.qinv);
-                auto ld = [&](const uint64_t *p, int e) -> double { return u52_to_f64(bred_add_lazy(p[e], mc.q, mc.brc0)); };
+                // caller words may be any 64-bit representative (as MRed accepts them); every pipeline of this library hands over
+                // words below 2q, which convert as they are -- the Barrett reduction (a dozen integer instructions per word, up to
+                // 64 words per thread) runs only for a wave that actually met a larger word
+                const uint64_t twoq_u = mc.q << 1;
+                auto cvt8 = [&](uint64_t (&w)[8], double (&d)[8]) {
+                    bool big = false;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) big = big || w[k] >= twoq_u;
+#ifndef HE_EPI_ALWAYS_REDUCE
+#define HE_EPI_ALWAYS_REDUCE 0  // 1: the unconditional reduction of round 2 (A/B builds)
+#endif
+                    if (HE_EPI_ALWAYS_REDUCE || __any(big)) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) w[k] = bred_add_lazy(w[k], mc.q, mc.brc0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) d[k] = u52_to_f64(w[k]);
+                };
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     double u[8], v[8], wv[8];
+                    uint64_t ur[8], vr[8];
+                    const uint64_t *pv = second ? pb1 : pb0;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); u[k] = ld(pa0, e); v[k] = ld(second ? pb1 : pb0, e); }
+                    for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); ur[k] = pa0[e]; vr[k] = pv[e]; }
+                    cvt8(ur, u); cvt8(vr, v);
 #pragma unroll
                     for (int k = 0; k < 8; k++) wv[k] = modmul_f64(u[k], v[k], q, qi);
                     if (second) {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); u[k] = ld(pa1, e); v[k] = ld(pb0, e); }
+                        for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); ur[k] = pa1[e]; vr[k] = pb0[e]; }
+                        cvt8(ur, u); cvt8(vr, v);
 #pragma unroll
                         for (int k = 0; k < 8; k++) wv[k] += modmul_f64(u[k], v[k], q, qi);
                     }
@@ -1090,63 +1111,6 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
 // Bit-identical to the plain kernel (same arithmetic on the same operands).
 // ------------------------------------------------------------------------------------
 
-// The same forward radix-16 round with the instruction order pinned for a LONE wave: a dependent v_*_f64 issues every ~10 cycles,
-// an independent one every ~5 (tools/latency_probe.hip); two waves on a SIMD hide that between them, but a wave whose partner is
-// parked at a barrier or a load runs the compiler's back-to-back dependent sequence (mul -> mul -> rndne -> fma -> add) at half
-// rate.  Here four butterflies advance together, one sub-operation at a time, and scheduling barriers keep the groups apart, so
-// every instruction's producer is at least three instructions behind it.
-#ifndef HE_MAC_ILP
-#define HE_MAC_ILP 1
-#endif
-__device__ __forceinline__ void rows_round16_f64_ilp(double (&x)[16], const double (&t)[15], double q, double qi) {
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int d = 1 << (3 - u);
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            int kk[4];
-            {
-                int n = 0;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {  // the butterflies (k, k + d) of this stage, four at a time
-                    if ((k & d) || n >= 4) continue;
-                    int cnt = 0;
-#pragma unroll
-                    for (int k2 = 0; k2 < k; k2++) if (!(k2 & d)) cnt++;
-                    if (cnt < 4 * half) continue;
-                    kk[n++] = k;
-                }
-            }
-            double h[4], l[4], c[4];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) h[i] = x[kk[i] + d] * t[(1 << u) - 1 + (kk[i] >> (4 - u))];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                l[i] = __fma_rn(x[kk[i] + d], t[(1 << u) - 1 + (kk[i] >> (4 - u))], -h[i]);
-                c[i] = h[i] * qi;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) c[i] = rint(c[i]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) h[i] = __fma_rn(-c[i], q, h[i]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) h[i] = h[i] + l[i];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const double U = x[kk[i]];
-                x[kk[i]] = U + h[i];
-                x[kk[i] + d] = U - h[i];
-            }
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
 typedef __attribute__((address_space(3))) void *he_lds_ptr;
 __device__ __forceinline__ unsigned lds_byte_addr(const void *p) { return (unsigned)(uintptr_t)(he_lds_ptr)p; }
 // one LDS-DMA instruction: lane i's 16 bytes at gsrc land at LDS byte lds_dst + 16 i (lds_dst wave-uniform).  hipcc does not
@@ -1307,7 +1271,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                     for (int u = 0; u < 4; u++)
 #pragma unroll
                         for (int j = 0; j < (1 << u); j++) t0[(1 << u) - 1 + j] = ldcd(cur.tw, (size_t)(((unsigned)cur.rowtw << u) + j));
-                    if constexpr (HE_MAC_ILP) rows_round16_f64_ilp(x, t0, q, qi); else rows_round16_f64<false>(x, t0, q, qi);
+                    rows_round16_f64<false>(x, t0, q, qi);
                 }
                 MAC_STAMP2(1 + d * 12 + 3);
                 __syncthreads();  // every wave is done with the tile (previous digit's last read) -- and tw1s is in place
@@ -1320,7 +1284,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                     const double *tp = tw1s + (tau >> (LOGB - 8)) * 15u;
 #pragma unroll
                     for (int i = 0; i < 15; i++) t1[i] = tp[i];
-                    if constexpr (HE_MAC_ILP) rows_round16_f64_ilp(x, t1, q, qi); else rows_round16_f64<false>(x, t1, q, qi);
+                    rows_round16_f64<false>(x, t1, q, qi);
                 }
                 MAC_STAMP2(1 + d * 12 + 5);
                 rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, true);
@@ -1331,7 +1295,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #pragma unroll
                 for (int k = 0; k < 16; k++) kk0[k] = k0p[(unsigned)(k * T)];
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (HE_MAC_ILP) rows_round16_f64_ilp(x, t2, q, qi); else rows_round16_f64<false>(x, t2, q, qi);
+                rows_round16_f64<false>(x, t2, q, qi);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];

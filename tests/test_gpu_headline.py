@@ -93,8 +93,12 @@ def test_full_size_mulrelin_aliasing_squaring_lazy_inputs(ctx, scheme):
         gmul = lambda a, b, out: gev.CKKSMulRelin(L - 1, a, b, grlk, out)
         omul = lambda a, b: oev.CKKSMulRelin(a, b, orlk, True)
     lazy = lambda: np.stack([np.stack([rng.integers(0, 2 * int(m), size=N, dtype=np.uint64) for m in q]) for _ in range(B)])
+    # any 64-bit word is a valid operand of MRed: x + m q for random m, up to 2^64 - 1 (the double-precision limbs take their
+    # reduce-first path for these)
+    wild = lambda: np.stack([np.stack([rng.integers(0, 1 << 63, size=N, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=N, dtype=np.uint64)
+                                       for _ in q]) for _ in range(B)])
     ct0 = [bench.uniform(rng, q, N, (B,)), lazy()]   # [k][b][limb][N]; the second component holds words up to 2q - 1
-    ct1 = [lazy(), bench.uniform(rng, q, N, (B,))]
+    ct1 = [wild(), bench.uniform(rng, q, N, (B,))]
     want = [omul(np.stack([ct0[0][e], ct0[1][e]]), np.stack([ct1[0][e], ct1[1][e]])) for e in range(B)]
     want_sq = [omul(np.stack([ct0[0][e], ct0[1][e]]), np.stack([ct0[0][e], ct0[1][e]])) for e in range(B)]
 

@@ -9,19 +9,25 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 tag = sys.argv[1]
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, f"{tag}_bench.json"))
 shutil.copy(os.path.join(G, "bench_configs.jsonl"), os.path.join(P, f"{tag}_bench_other_configs.jsonl"))
 stats = [f for f in os.listdir(os.path.join(G, "prof_final")) if f.endswith("kernel_stats.csv")]
 shutil.copy(os.path.join(G, "prof_final", stats[0]), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
-batch = json.load(open(os.path.join(G, "bench_final.json")))["config"]["batch_per_gpu"]
-out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"),
-                               os.path.join(G, "pmc_FETCH_SIZE", "bench_counter_collection.csv"),
-                               os.path.join(G, "pmc_WRITE_SIZE", "bench_counter_collection.csv"), str(batch)], text=True)
-d = json.loads(out)
-d["workload"] = "c3"
-json.dump(d, open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+# PMC traffic per workload (tools/round_artifacts.sh: bench.py --steps S --warmup 1, profiling leg = S more steps)
+for w, steps in (("c3", 5), ("c4", 5), ("c5", 2)):
+    f = os.path.join(G, f"pmc_FETCH_SIZE_{w}", "bench_counter_collection.csv")
+    wr = os.path.join(G, f"pmc_WRITE_SIZE_{w}", "bench_counter_collection.csv")
+    if not (os.path.exists(f) and os.path.exists(wr)):
+        print("no PMC pass for", w)
+        continue
+    import bench
+    batch = bench.WORKLOADS[w][1]
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f, wr, str(batch), w, str(1 + 2 * steps)], text=True)
+    d = json.loads(out)
+    json.dump(d, open(os.path.join(P, f"{tag}_pmc_traffic.json" if w == "c3" else f"{tag}_pmc_traffic_{w}.json"), "w"), indent=1)
 # SQ passes: per (kernel, grid) launch group
 groups = {}
 for t in ("sq1", "sq2"):
