@@ -2259,14 +2259,15 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     };
     auto ytake = [&](int r, int i) -> uint64_t { return i < KREG ? yreg[r][i] : ylds[(i - KREG) * R + r][threadIdx.x]; };
     uint64_t y[DSTF64 ? 1 : R][DSTF64 ? 1 : NSRC];   // integer variant
-#ifndef HE_MODUP_Y_LDS
-#define HE_MODUP_Y_LDS 1
+    // Short digits (NSRC <= 3, up to 8 coefficients per thread) also keep every residue that fits a double (source modulus
+    // below 2^51: no 26-bit split) as a double in registers: the double-precision destinations -- most of them at the headline
+    // shape -- then take their operand without an LDS read and a conversion per (term, destination).  48 registers; the kernel
+    // stays within the three-wave budget.
+#ifndef HE_MODUP_YD
+#define HE_MODUP_YD 1
 #endif
-    // mixed variant: the residues are parked in LDS as integers; HE_MODUP_Y_LDS = 0 also keeps them in registers as doubles (2 x R x
-    // NSRC registers, two waves per SIMD), = 1 converts them where a destination limb uses them (100 registers, three waves)
-    constexpr bool YREG = DSTF64 && !HE_MODUP_Y_LDS;
-    double yl[YREG ? R : 1][YREG ? NSRC : 1];      // y (or its low 26 bits)
-    double yh[YREG ? R : 1][YREG ? NSRC : 1];      // y >> 26 when split
+    constexpr bool YD = DSTF64 && HE_MODUP_YD && NSRC <= 3 && LOGA <= 3 && KREG == 0;
+    double ydreg[YD ? R : 1][YD ? NSRC : 1];
     double vi[R];
     uint32_t negmask = 0;  // centred-copy path only: bit r = coefficient r was negated
 #pragma unroll
@@ -2359,10 +2360,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 vi[r] = __dadd_rn(vi[r], yd[r] * rq);
                 if constexpr (DSTF64) {
                     ypark(r, i, yi[r]);
-                    if constexpr (YREG) {
-                        yl[r][i] = split ? u52_to_f64(yi[r] & ((1ull << 26) - 1)) : yd[r];
-                        yh[r][i] = split ? u52_to_f64(yi[r] >> 26) : 0.0;
-                    }
+                    if constexpr (YD) ydreg[r][i] = yd[r];  // (used only when the source is not split)
                 } else {
                     y[r][i] = yi[r];
                 }
@@ -2435,20 +2433,16 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
 #pragma unroll
                 for (int i = 0; i < NSRC; i++) {
                     const double Tl = ldcd(Tr, 2 * i), Th = ldcd(Tr, 2 * i + 1);  // block-uniform: scalar loads
-                    if constexpr (YREG) {
-#pragma unroll
-                        for (int r = 0; r < R; r++) o[r] += modmul_f64(yl[r][i], Tl, pd, pid);
-                        if ((splitmask >> i) & 1) {
-#pragma unroll
-                            for (int r = 0; r < R; r++) o[r] += modmul_f64(yh[r][i], Th, pd, pid);
-                        }
-                    } else if ((splitmask >> i) & 1) {  // y >= 2^51 possible: y = yh 2^26 + yl, two exact products
+                    if ((splitmask >> i) & 1) {  // y >= 2^51 possible: y = yh 2^26 + yl, two exact products
 #pragma unroll
                         for (int r = 0; r < R; r++) {
                             const uint64_t yy = ytake(r, i);
                             o[r] += modmul_f64(u52_to_f64(yy & ((1ull << 26) - 1)), Tl, pd, pid);
                             o[r] += modmul_f64(u52_to_f64(yy >> 26), Th, pd, pid);
                         }
+                    } else if constexpr (YD) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) o[r] += modmul_f64(ydreg[r][i], Tl, pd, pid);
                     } else {
 #pragma unroll
                         for (int r = 0; r < R; r++) o[r] += modmul_f64(u52_to_f64(ytake(r, i)), Tl, pd, pid);
