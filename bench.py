@@ -84,13 +84,31 @@ def physical_cores():
         return None
 
 
+def cpu_quota_cores():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.  The GPU boxes of
+    this pool expose 256 logical CPUs but grant 16: beyond that many busy threads the kernel throttles the whole group, which is
+    what made the thread sweeps of rounds 1-2 peak at 16 threads and FALL beyond."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(kind, N, q, p, kq, kp, unit, what, seconds=12.0, t=0, gal=0):
     """The restated reference (oracle/, a scalar C port -- NOT Lattigo's Go code, which cannot be built here) timed on the host
     cores: independent calls on one shared evaluator from n OS threads -- a C-level pthread loop with pooled scratch, the shape
     of the reference's own parallel benchmarks (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:95-325; scratch from
     core/rlwe/pool.go).  Every thread is pinned to one CPU and works on its own first-touched copy of the inputs and the key
-    (NUMA placement; round 2's shared copy made the rate fall beyond 16 threads).  Thread counts 1 / 16 / 64 / physical cores /
-    logical CPUs are reported so that the scaling is visible; `value` is the best of them."""
+    (NUMA placement).  Thread counts 1 / half the usable cores / the usable cores / twice that are reported so that the scaling is
+    visible; "usable" = min(logical CPUs in the affinity set, the cgroup's CPU quota) -- the quota, not the socket, is what the
+    container gets; `value` is the best of the sweep and `cores` the thread count that gave it."""
     from oracle import oracle as O
     logical = os.cpu_count() or 1
     try:
@@ -98,12 +116,14 @@ def cpu_baseline(kind, N, q, p, kq, kp, unit, what, seconds=12.0, t=0, gal=0):
     except (AttributeError, OSError):
         pass
     phys = physical_cores()
+    quota = cpu_quota_cores()
+    usable = max(1, min(logical, int(quota))) if quota else min(logical, phys or logical)
     ev = O.Evaluator(O.Ring(N, q), O.Ring(N, p))
     key = O.EvaluationKey(kq, kp) if kq is not None else None
     rng = np.random.Generator(np.random.PCG64(0x1A77160 + 2))
     ct0 = uniform(rng, q, N, (2,))
     ct1 = uniform(rng, q, N, (2,)) if kind != "rotate" else None
-    counts = sorted({1, min(16, logical), min(64, logical), min(phys or logical, logical), logical})
+    counts = sorted({1, max(1, usable // 2), usable, min(logical, 2 * usable)})
     per = seconds / len(counts)
     sweep, best = {}, (0.0, 1, "")
     for n in counts:
@@ -113,7 +133,8 @@ def cpu_baseline(kind, N, q, p, kq, kp, unit, what, seconds=12.0, t=0, gal=0):
         if rate > best[0]:
             best = (rate, n, f"{done} {what} on {n} pinned threads in {dt:.1f}s")
     return {"value": best[0], "unit": unit, "cores": best[1], "kind": "port", "sample": best[2],
-            "threads_sweep_ops_s": sweep, "logical_cpus": logical, "physical_cores": phys,
+            "threads_sweep_ops_s": sweep, "logical_cpus": logical, "physical_cores": phys, "cgroup_cpu_quota_cores": quota,
+            "usable_cores": usable,
             "single_thread_ops_s": sweep["1"],
             "note": "scalar C restatement of the reference (oracle/), one pinned thread per CPU with private copies of inputs and key; not the Go code"}
 
@@ -317,7 +338,8 @@ def setup_c5(la, ctx, rank, B, cp, args):
     }
 
 
-WORKLOADS = {"c2": (setup_c2, 128), "c3": (setup_c3, 128), "c4": (setup_c4, 32), "c5": (setup_c5, 8)}
+# default batches from sweeps on MI355X (round 3): c2 128 -> 256: 204k -> 221k; c4 16 / 32 / 64: 8.6k / 9.2k / 9.6k; c5 8 / 16 / 24: 73 / 82 / 85
+WORKLOADS = {"c2": (setup_c2, 256), "c3": (setup_c3, 128), "c4": (setup_c4, 64), "c5": (setup_c5, 16)}
 
 
 def ntt_rates(la, ctx):
@@ -351,6 +373,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed configuration's output")
     ap.add_argument("--no-ntt", action="store_true", help="skip the stand-alone NTT/s measurement")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the per-kernel HIP-event leg (and with it the roofline object): for runs under rocprofv3 --pmc, whose "
+                         "counter collection does not survive the tens of thousands of events a bootstrap trace records")
     ap.add_argument("--no-b1", action="store_true", help="skip the single-ciphertext (batch 1) rate / latency measurement")
     ap.add_argument("--replicate-keys", choices=["auto", "none", "rccl", "host"], default="auto",
                     help="N > 1: rank 0's evaluation key is replicated to every rank before the timed region (RCCL broadcast "
@@ -421,6 +446,12 @@ def main():
     ops = world * W["units"] * args.steps
     value = ops / elapsed
 
+    if args.no_kernel_timing:
+        print(json.dumps({"metric": W["metric"], "value": value, "unit": W["unit"], "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "verified": verified, "roofline": None,
+                          "config": dict(W["config"])}), flush=True)
+        cp.close()
+        return
     # ---- roofline leg: per-kernel HIP-event timing over an identical region --------------------------------------
     ctx.prof_begin()
     for _ in range(args.steps):

@@ -135,23 +135,32 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned lin, unsigned n) {
 // ------------------------------------------------------------------------------------
 // butterflies
 // ------------------------------------------------------------------------------------
+// The butterflies take their Montgomery products through mred_lazy_w32 (modarith.h: two 32-bit reduction rounds, 8 v_mad_u64_u32 +
+// 2 v_mul_lo_u32 + a few adds instead of the 11 multiplies and ~15 carry instructions of the full-width form): only the residue
+// class of a butterfly output matters, and the operands satisfy its domain (V + q < 2^64, w < q).  HE_BFLY_W32 = 0 restores the
+// full-width products for A/B builds.
+#ifndef HE_BFLY_W32
+#define HE_BFLY_W32 1
+#endif
+__device__ __forceinline__ uint64_t bfly_mul(uint64_t v, uint64_t w, uint64_t q, uint64_t qinv) {
+    if constexpr (HE_BFLY_W32) return mred_lazy_w32(v, w, q, qinv);
+    else return mred_lazy(v, w, q, qinv);
+}
 // forward: U,V in [0,4q) -> X,Y in [0,4q)
 __device__ __forceinline__ void bfly_fwd(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t twoq, uint64_t qinv) {
     uint64_t U = a >= twoq ? a - twoq : a;
-    uint64_t V = mred_lazy(b, w, q, qinv);
+    uint64_t V = bfly_mul(b, w, q, qinv);
     a = U + V;
     b = U + twoq - V;
 }
 // forward without range correction, for q < 2^58: every output is below (input bound + 2q), so the
 // 15 stages of a logN=16 transform stay below 34q < 2^64; one Barrett reduction at the very end.
-//   d = V*w*2^-64 - q (signed, |d| < q);  X = U + q + d,  Y = U + q - d
+//   r = V*w*2^-64 in [0, 2q);  X = U + r,  Y = U + 2q - r
 __device__ __forceinline__ void bfly_fwd_nc(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t qinv) {
-    uint64_t ahi, alo;
-    mul64wide(b, w, ahi, alo);
-    const uint64_t d = ahi - mulhi64(alo * qinv, q);
-    const uint64_t uq = a + q;
-    a = uq + d;
-    b = uq - d;
+    const uint64_t r = bfly_mul(b, w, q, qinv);
+    const uint64_t u = a;
+    a = u + r;
+    b = u + (q << 1) - r;
 }
 constexpr int kNoCorrBits = 58;
 // inverse: U,V in [0,2q) -> X,Y in [0,2q)
@@ -159,7 +168,7 @@ __device__ __forceinline__ void bfly_inv(uint64_t &a, uint64_t &b, uint64_t w, u
     uint64_t U = a, V = b;
     uint64_t X = U + V;
     a = X >= twoq ? X - twoq : X;
-    b = mred_lazy(U + twoq - V, w, q, qinv);
+    b = mred_lazy(U + twoq - V, w, q, qinv);  // (the word-serial form costs the generic inverse row kernel its fourth wave: spills)
 }
 // last inverse stage with N^-1 folded in: outputs canonical
 __device__ __forceinline__ void bfly_inv_scaled(uint64_t &a, uint64_t &b, uint64_t wn, uint64_t ninv, uint64_t q,

@@ -41,6 +41,33 @@ HE_HD uint64_t mred(uint64_t x, uint64_t y, uint64_t q, uint64_t qinv) {
     uint64_t r = mred_lazy(x, y, q, qinv);
     return r >= q ? r - q : r;
 }
+// The same residue by two 32-bit reduction rounds (word-serial Montgomery, "CIOS"): x*y*2^-64 mod q in [0, 2q) for
+// q < 2^62 and x < 2^63, y < 2^62 (any lazy operand of the kernels: < 4q).  gfx950 has no 64-bit multiplier; the full-width form
+// above costs 11 multiplies and ~15 carry / select instructions (a 64x64->128 product, a 64-bit low product and a 64x64 high
+// product), this one 8 v_mad_u64_u32 + 2 v_mul_lo_u32 + ~6 adds: the running sum never exceeds 96 bits and every partial
+// product is a 32x32+64 multiply-add.  m = -T q^-1 mod 2^64 is the same number either way (computed word by word here), so the
+// result is the same element of [0, 2q) as mred_lazy's EXCEPT when T q^-1 = 0 mod 2^64, where the reference's formula returns
+// r + q: use it where only the residue class matters (butterflies, canonical MRed), never for an API-visible *Lazy word.
+HE_HD uint64_t mred_lazy_w32(uint64_t x, uint64_t y, uint64_t q, uint64_t qinv) {
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
+    const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32), nq = (uint32_t)(0 - qinv);  // -q^-1 mod 2^32
+    // round 0: T = x * y0 (96 bits) ; T' = (T + m q) / 2^32
+    const uint64_t t = (uint64_t)x0 * y0;
+    const uint64_t u = (uint64_t)x1 * y0 + (t >> 32);           // T = u 2^32 + lo32(t)
+    uint32_t m = (uint32_t)t * nq;
+    uint64_t c = (uint64_t)m * q0 + (uint32_t)t;                // low word cancels
+    const uint64_t v = (uint64_t)m * q1 + u + (c >> 32);        // T' < 2^64 (see the bounds above)
+    // round 1: T'' = T' + x * y1 2^32-aligned ; r = (T'' + m q) / 2^32
+    const uint64_t a = (uint64_t)x0 * y1 + (uint32_t)v;         // T'' = b 2^32 + lo32(a)
+    const uint64_t b = (uint64_t)x1 * y1 + (a >> 32) + (v >> 32);
+    m = (uint32_t)a * nq;
+    c = (uint64_t)m * q0 + (uint32_t)a;
+    return (uint64_t)m * q1 + b + (c >> 32);
+}
+HE_HD uint64_t mred_w32(uint64_t x, uint64_t y, uint64_t q, uint64_t qinv) {  // canonical: equals mred
+    const uint64_t r = mred_lazy_w32(x, y, q, qinv);
+    return r >= q ? r - q : r;
+}
 // Montgomery reduction of a 128-bit value (hi,lo) -> [0, 2q) when hi < q.
 HE_HD uint64_t mred128_lazy(uint64_t hi, uint64_t lo, uint64_t q, uint64_t qinv) {
     uint64_t H = mulhi64(lo * qinv, q);

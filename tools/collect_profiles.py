@@ -16,7 +16,7 @@ shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, f"{tag}_bench.j
 shutil.copy(os.path.join(G, "bench_configs.jsonl"), os.path.join(P, f"{tag}_bench_other_configs.jsonl"))
 stats = [f for f in os.listdir(os.path.join(G, "prof_final")) if f.endswith("kernel_stats.csv")]
 shutil.copy(os.path.join(G, "prof_final", stats[0]), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
-# PMC traffic per workload (tools/round_artifacts.sh: bench.py --steps S --warmup 1, profiling leg = S more steps)
+# PMC traffic per workload (tools/round_artifacts.sh: bench.py --steps S --warmup 1 --no-kernel-timing)
 for w, steps in (("c3", 5), ("c4", 5), ("c5", 2)):
     f = os.path.join(G, f"pmc_FETCH_SIZE_{w}", "bench_counter_collection.csv")
     wr = os.path.join(G, f"pmc_WRITE_SIZE_{w}", "bench_counter_collection.csv")
@@ -25,7 +25,7 @@ for w, steps in (("c3", 5), ("c4", 5), ("c5", 2)):
         continue
     import bench
     batch = bench.WORKLOADS[w][1]
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f, wr, str(batch), w, str(1 + 2 * steps)], text=True)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f, wr, str(batch), w, str(1 + steps)], text=True)
     d = json.loads(out)
     json.dump(d, open(os.path.join(P, f"{tag}_pmc_traffic.json" if w == "c3" else f"{tag}_pmc_traffic_{w}.json"), "w"), indent=1)
 # SQ passes: per (kernel, grid) launch group

@@ -4,10 +4,10 @@ R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_* $R/gpurun_out/prof_final
 BARGS="--no-cpu-baseline --no-verify --no-ntt --no-b1"
 # PMC traffic: separate FETCH_SIZE / WRITE_SIZE passes (kernel trace only, as the guide prescribes); steps of bench.py's step() per
-# run = warmup + steps + the profiling leg's `steps`
+# run = warmup + steps (no HIP-event leg under the profiler)
 for W in c3 c4 c5; do
   S=5; [ $W = c5 ] && S=2
-  for C in FETCH_SIZE WRITE_SIZE; do timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${C}_$W -o bench -- python $R/bench.py --workload $W --steps $S --warmup 1 $BARGS > $R/gpurun_out/pmc_${C}_$W.log 2>&1; done
+  for C in FETCH_SIZE WRITE_SIZE; do timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${C}_$W -o bench -- python $R/bench.py --workload $W --steps $S --warmup 1 --no-kernel-timing $BARGS > $R/gpurun_out/pmc_${C}_$W.log 2>&1; done
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o bench -- python $R/bench.py --steps 20 --warmup 3 $BARGS > $R/gpurun_out/bench_final_prof.log 2>&1
 bash $R/tools/prof_pass.sh sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" --no-b1 > /dev/null
