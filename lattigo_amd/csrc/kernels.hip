@@ -383,8 +383,28 @@ __device__ __forceinline__ void rows_round16s(uint64_t (&x)[16], const ulonglong
     }
 }
 
+// A radix-16 round (one group of sixteen per thread, W = 1): element k of the thread is e0 | (k << sh) with
+// e0 = (hi << (LOGB - s0)) + lo, and because bits [sh, sh + 4) of e0 are clear, lds_phys(e) = lds_phys(e0) + c_k with
+// c_k = (k << sh) + ((k << sh) >> 4) -- a compile-time constant where the call site knows sh (LDS offset immediates), a scalar
+// otherwise: one base address per exchange instead of a shift / add / shift / add chain per element.
+#ifndef HE_XFER16
+#define HE_XFER16 1  // 0: the per-element address arithmetic of rounds 1-2 (A/B builds)
+#endif
+template <int LOGB, class Tw>
+__device__ __forceinline__ void rows_lds_xfer16(Tw (&x)[16], Tw *lds, int tau, int s0, int sh, bool store) {
+    const unsigned ut = (unsigned)tau, hi = ut >> sh, lo = ut & ((1u << sh) - 1u);
+    const unsigned e0 = (hi << (LOGB - s0)) + lo;
+    Tw *p = lds + (e0 + (e0 >> 4));
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const unsigned c = ((unsigned)k << sh) + (((unsigned)k << sh) >> 4);
+        if (store) p[c] = x[k];
+        else x[k] = p[c];
+    }
+}
 template <int LOGB, int G4>
 __device__ __forceinline__ void rows_lds_xfer(uint64_t (&x)[16], uint64_t *lds, int tau, int s0, int sh, bool store) {
+    if constexpr (G4 == 4 && HE_XFER16) { rows_lds_xfer16<LOGB>(x, lds, tau, s0, sh, store); return; }
     constexpr int g = G4, G = 1 << g, W = 16 / G;
 #pragma unroll
     for (int w = 0; w < W; w++) {
@@ -711,6 +731,7 @@ __device__ __forceinline__ void rows_round16_f64(double (&x)[16], const double (
 
 template <int LOGB, int G4>
 __device__ __forceinline__ void rows_lds_xfer_f64(double (&x)[16], double *lds, int tau, int s0, int sh, bool store) {
+    if constexpr (G4 == 4 && HE_XFER16) { rows_lds_xfer16<LOGB>(x, lds, tau, s0, sh, store); return; }
     constexpr int g = G4, G = 1 << g, W = 16 / G;
 #pragma unroll
     for (int w = 0; w < W; w++) {
