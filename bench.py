@@ -3,7 +3,7 @@
 
 Default workload (BASELINE.json configs[2], the one its metric "ciphertext-mul+relin ops/s at logN=15" is quoted on):
 BGV, logN=15, 12 Q-limbs (LogQ=[55,45x11]), 3 P-limbs (LogP=[55x3]), T=65537, ct x ct Mul + Relinearize
-(schemes/bgv/evaluator.go:592 tensorStandard + GadgetProduct).  A "step" is one MulRelin over a batch of B independent
+(schemes/bgv/evaluator.go:592 tensorStandard + GadgetProduct).  A "step" is one MulRelin over a batch of B (default 256) independent
 ciphertext pairs already resident in HBM.  Synthetic inputs: coefficients uniform in [0, q_i), PCG64 seed
 0x1A77160 + 2.
 
@@ -338,8 +338,10 @@ def setup_c5(la, ctx, rank, B, cp, args):
     }
 
 
-# default batches from sweeps on MI355X (round 3): c2 128 -> 256: 204k -> 221k; c4 16 / 32 / 64: 8.6k / 9.2k / 9.6k; c5 8 / 16 / 24: 73 / 82 / 85
-WORKLOADS = {"c2": (setup_c2, 256), "c3": (setup_c3, 128), "c4": (setup_c4, 64), "c5": (setup_c5, 16)}
+# default batches from sweeps on MI355X (round 3): c2 128 -> 256: 204k -> 221k; c3 64 / 128 / 192 / 256 / 512: 33.9k / 36.6k / 37.5k /
+# 37.8k / 38.0k on one box (the persistent NTT+MAC kernel's tail shrinks with more items per workgroup; flat beyond 256);
+# c4 16 / 32 / 64 / 128: 8.6k / 9.2k / 9.6k / 9.8k; c5 8 / 16 / 32: 73 / 84 / 85
+WORKLOADS = {"c2": (setup_c2, 256), "c3": (setup_c3, 256), "c4": (setup_c4, 64), "c5": (setup_c5, 16)}
 
 
 def ntt_rates(la, ctx):

@@ -56,3 +56,20 @@ def test_go_shim_matches_the_header():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_go_abi.py")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_cpu_quota_probe_reads_cgroup_files(tmp_path, monkeypatch):
+    """bench.py reports the container's CPU quota with the CPU baseline (the thread sweep is meaningless beyond it)."""
+    import builtins
+    import bench
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("1600000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert bench.cpu_quota_cores() == 16.0

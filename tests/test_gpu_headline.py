@@ -132,6 +132,49 @@ def test_full_size_mulrelin_aliasing_squaring_lazy_inputs(ctx, scheme):
     check(a, want_sq, "MulRelin(res, res, res)")
 
 
+def test_byte_accounting_matches_the_survey_formulas(ctx):
+    """The two byte counters bench.py's roofline figures rest on (hering_debug.h): he_alg_bytes accumulates SURVEY.md section
+    8(d)'s per-primitive formulas at the C ABI (NTT 2L, binary 3L, MulRelin 6L + 2 beta (L + alpha) limbs of N * 8 bytes, times
+    the batch; the key charged per entry / once per call), he_prof_end_bytes sums what every launch of a primitive must read
+    and write once."""
+    logN, q, p, t = _bench_config()
+    logN = 12  # the same chain on a small ring: one 4096-row per limb
+    q, p = O.GenModuli(logN + 1, [55] + [45] * 11, [55] * 3)
+    N, L, alpha, B = 1 << logN, len(q), len(p), 5
+    beta = (L + alpha - 1) // alpha
+    pr = Pair(ctx, logN, L, alpha, qmods=q, pmods=p)
+    rng = rng_for(4242)
+    gev = la.Evaluator(pr.gQ, pr.gP)
+    kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(beta)])
+    rlk = gev.NewEvaluationKey(kq, kp)
+    import bench
+    a = [la.Poly(pr.gQ, L, B).upload(bench.uniform(rng, q, N, (B,))) for _ in range(2)]
+    b = [la.Poly(pr.gQ, L, B).upload(bench.uniform(rng, q, N, (B,))) for _ in range(2)]
+    out = [la.Poly(pr.gQ, L, B), la.Poly(pr.gQ, L, B)]
+    limb = N * 8
+    ctx.alg_bytes(reset=True)
+    pr.gQ.NTT(a[0], out[0])
+    assert ctx.alg_bytes(reset=True) == (2 * L * limb * B, 2 * L * limb * B)
+    pr.gQ.Add(a[0], a[1], out[0])
+    pr.gQ.MulCoeffsMontgomeryThenAdd(a[0], a[1], out[0])
+    assert ctx.alg_bytes(reset=True)[0] == (3 + 4) * L * limb * B
+    gev.BGVMulRelin(L - 1, t, a, b, rlk, out)
+    per_entry, per_call = ctx.alg_bytes(reset=True)
+    assert per_entry == (6 * L + 2 * beta * (L + alpha)) * limb * B
+    assert per_call == 6 * L * limb * B + 2 * beta * (L + alpha) * limb
+    # launch accounting of the same call: the pipeline of DESIGN.md section 4 (12 + 3 limbs, 11 + 0 of them below 2^47)
+    ctx.prof_begin()
+    gev.BGVMulRelin(L - 1, t, a, b, rlk, out)
+    prof = ctx.prof_end_bytes()
+    small_q = sum(m < (1 << 47) for m in q)
+    assert prof["tensor"][2] == 3 * L * limb * B
+    assert prof["modup"][2] == (L + (beta * (L + alpha) - L) + 2 * alpha + 2 * L) * limb * B
+    assert prof["ntt_rows_fwd_f64"][2] == 10 * small_q * limb * B
+    total = sum(v[2] for v in prof.values())
+    assert 6 * per_entry > total > per_entry  # the realised pipeline moves more than the ideal single pass, within a small factor
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # class boundaries
 # ---------------------------------------------------------------------------------------------------------------
