@@ -266,6 +266,8 @@ def run_functional_bootstrap(logN, logq_res, n_stc, evalmod_bits, n_cts, cts_bit
     lv = res.level
     sub = O.Ring(N, q[: lv + 1])
     ct_out = np.stack([v.download()[0][: lv + 1] for v in res.Value]) if device else np.stack(res.Value)
+    import hashlib
+    ct_digest = hashlib.sha256(np.ascontiguousarray(ct_out, dtype=np.uint64).tobytes()).hexdigest()  # the refreshed ciphertext's words
     ph = sub.INTT(phase(oQ, ct_out, sk.Q))
     Ql = prod(q[: lv + 1])
     w = [(Ql // int(qi)) * pow(Ql // int(qi), -1, int(qi)) for qi in q[: lv + 1]]
@@ -281,6 +283,7 @@ def run_functional_bootstrap(logN, logq_res, n_stc, evalmod_bits, n_cts, cts_bit
     mean_bits = float(np.mean(-np.log2(np.maximum(errs, 1e-300))))
     out = {"mean_precision_bits": mean_bits, "logN": logN, "limbs_Q": top + 1, "limbs_P": LP, "dft_diagonals": ndiag, "galois_keys": len(gks),
            "bootstrap_ms": t_boot * 1e3, "precision_bits": float(-np.log2(err)), "max_slot_error": err, "output_level": lv,
-           "host_setup_s": {"matrices": t_mats - t_start, "keys": t_keys - t_mats}, "backend": "device" if device else "oracle"}
+           "host_setup_s": {"matrices": t_mats - t_start, "keys": t_keys - t_mats}, "backend": "device" if device else "oracle",
+           "ct_sha256": ct_digest, "seed": seed}
     assert out["precision_bits"] > min_bits, out
     return out
