@@ -2363,7 +2363,6 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
         } else {
             const uint64_t h = U64(D.src_half[i]), ai = Da[i];
             const double rq = mq.rq;
-            const bool split = (splitmask >> i) & 1;
             const double qd = (double)q, qid = mq.rq, apl = src_small ? (double)imform(ai, q, qinv) : 0.0;
             uint64_t yi[R];
             double yd[R];
