@@ -16,6 +16,7 @@
 #include "kernels.h"
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <mutex>
@@ -1988,6 +1989,18 @@ static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, V
         A.s2[i] = sc ? sc->s2[i] : 0;
     }
     dim3 grid((unsigned)((r.N / 2 + 255) / 256), tab.n, batch), block(256);
+    {   // HERING_EW_STATS=1: launches and limb-units per element-wise op, printed at exit (diagnosis of driver-level traces)
+        static const bool stats = getenv("HERING_EW_STATS") && atoi(getenv("HERING_EW_STATS")) != 0;
+        if (stats) {
+            static std::mutex mu;
+            static std::unordered_map<int, std::pair<long, double>> cnt;
+            static const int reg = atexit([] { for (auto &kv : cnt) fprintf(stderr, "ew op %d: %ld launches, %.0f limb-entries\n", kv.first, kv.second.first, kv.second.second); });
+            (void)reg;
+            std::lock_guard<std::mutex> lk(mu);
+            auto &c = cnt[op];
+            c.first++; c.second += (double)tab.n * batch;
+        }
+    }
     // x in, z out, plus y and the addend where the formula has them
     const bool ew_y = (op >= 0 && op < 100) || op == EW_SUB_THEN_MUL_SCALAR_MONT_2Q || op == EW_DIVROUND_COEFF || op == EW_SUBMUL2Q_THEN_ADD;
     const bool ew_z = op == EW_MUL_BARRETT_THEN_ADD || op == EW_MUL_BARRETT_THEN_ADD_LAZY || op == EW_MUL_MONT_THEN_ADD ||
