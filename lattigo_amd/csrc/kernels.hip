@@ -143,22 +143,63 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned lin, unsigned n) {
 #ifndef HE_BFLY_W32
 #define HE_BFLY_W32 1
 #endif
+// Row kernels (HE_BFLY_ASM): the same product as ONE hand-written sequence of 16 instructions.  hipcc turns every form of it
+// into 21-26: the 64-bit addend of v_mad_u64_u32 must be an (even-aligned) register pair, so each "high word, zero-extended" is a
+// v_mov_b32 into a fresh pair, and a carry costs a 64-bit compare + select.  By column instead: L = x0 w0, M = x0 w1 + x1 w0,
+// H = x1 w1 are three aligned 64-bit accumulators (for q < 2^61 and x < 4q the middle column cannot overflow: x1 w0 < 2^63,
+// x0 w1 < 2^61), the two reduction rounds add m q0 / m q1 to (L, M) then (M, H), and what crosses from one accumulator to the
+// next is a 32-bit word or a carry -- v_add_co / v_addc on the HIGH or LOW half of a pair.  Halves of a pair cannot be named
+// through asm operands, so the seven scratch registers are fixed (v116..v122, declared clobbered: inside the 128-register
+// budget of the four-wave row kernels), which is why only the row kernels take this form.
+//   8 v_mad_u64_u32 + 2 v_mul_lo_u32 + 6 v_add(c)_co_u32, result (T + m q) / 2^64 in [0, 2q) as mred_lazy_w32.
+#ifndef HE_BFLY_ASM
+#define HE_BFLY_ASM 1
+#endif
+__device__ __forceinline__ uint64_t mred_lazy_col_asm(uint64_t x, uint64_t w, uint64_t q, uint64_t qinv) {
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32), nq = (uint32_t)(0 - qinv);
+    uint64_t r;
+    asm("v_mad_u64_u32 v[116:117], vcc, %[x0], %[w0], 0\n\t"               // L = x0 w0
+        "v_mad_u64_u32 v[118:119], vcc, %[x0], %[w1], 0\n\t"               // M = x0 w1
+        "v_mad_u64_u32 v[120:121], vcc, %[x1], %[w1], 0\n\t"               // H = x1 w1
+        "v_mad_u64_u32 v[118:119], vcc, %[x1], %[w0], v[118:119]\n\t"      // M += x1 w0            (no overflow, see above)
+        "v_mul_lo_u32 v122, v116, %[nq]\n\t"                               // m = L.lo (-q^-1) mod 2^32
+        "v_mad_u64_u32 v[116:117], vcc, v122, %[q0], v[116:117]\n\t"       // L += m q0: L.lo = 0, carry
+        "v_addc_co_u32_e64 v119, vcc, 0, v119, vcc\n\t"                    //   -> bit 32 of M
+        "v_mad_u64_u32 v[118:119], vcc, v122, %[q1], v[118:119]\n\t"       // M += m q1
+        "v_add_co_u32_e32 v118, vcc, v118, v117\n\t"                       // M += L.hi             (T + m q) / 2^32 = M + H 2^32
+        "v_addc_co_u32_e64 v119, vcc, 0, v119, vcc\n\t"
+        "v_mul_lo_u32 v122, v118, %[nq]\n\t"                               // m = M.lo (-q^-1) mod 2^32
+        "v_mad_u64_u32 v[118:119], vcc, v122, %[q0], v[118:119]\n\t"       // M += m q0: M.lo = 0, carry
+        "v_addc_co_u32_e64 v121, vcc, 0, v121, vcc\n\t"                    //   -> bit 32 of H
+        "v_add_co_u32_e32 v120, vcc, v120, v119\n\t"                       // H += M.hi
+        "v_addc_co_u32_e64 v121, vcc, 0, v121, vcc\n\t"
+        "v_mad_u64_u32 %[r], vcc, v122, %[q1], v[120:121]"                   // r = H + m q1 in [0, 2q)
+        : [r] "=v"(r)
+        : [x0] "v"(x0), [x1] "v"(x1), [w0] "v"(w0), [w1] "v"(w1), [q0] "s"(q0), [q1] "s"(q1), [nq] "s"(nq)
+        : "v116", "v117", "v118", "v119", "v120", "v121", "v122", "vcc");
+    return r;
+}
+template <bool ROWS = false>
 __device__ __forceinline__ uint64_t bfly_mul(uint64_t v, uint64_t w, uint64_t q, uint64_t qinv) {
-    if constexpr (HE_BFLY_W32) return mred_lazy_w32(v, w, q, qinv);
+    if constexpr (HE_BFLY_ASM && ROWS) return mred_lazy_col_asm(v, w, q, qinv);
+    else if constexpr (HE_BFLY_W32) return mred_lazy_w32(v, w, q, qinv);
     else return mred_lazy(v, w, q, qinv);
 }
 // forward: U,V in [0,4q) -> X,Y in [0,4q)
+template <bool ROWS = false>
 __device__ __forceinline__ void bfly_fwd(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t twoq, uint64_t qinv) {
     uint64_t U = a >= twoq ? a - twoq : a;
-    uint64_t V = bfly_mul(b, w, q, qinv);
+    uint64_t V = bfly_mul<ROWS>(b, w, q, qinv);
     a = U + V;
     b = U + twoq - V;
 }
 // forward without range correction, for q < 2^58: every output is below (input bound + 2q), so the
 // 15 stages of a logN=16 transform stay below 34q < 2^64; one Barrett reduction at the very end.
 //   r = V*w*2^-64 in [0, 2q);  X = U + r,  Y = U + 2q - r
+template <bool ROWS = false>
 __device__ __forceinline__ void bfly_fwd_nc(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t qinv) {
-    const uint64_t r = bfly_mul(b, w, q, qinv);
+    const uint64_t r = bfly_mul<ROWS>(b, w, q, qinv);
     const uint64_t u = a;
     a = u + r;
     b = u + (q << 1) - r;
@@ -169,7 +210,9 @@ __device__ __forceinline__ void bfly_inv(uint64_t &a, uint64_t &b, uint64_t w, u
     uint64_t U = a, V = b;
     uint64_t X = U + V;
     a = X >= twoq ? X - twoq : X;
-    b = mred_lazy(U + twoq - V, w, q, qinv);  // (the word-serial form costs the generic inverse row kernel its fourth wave: spills)
+    // (either word-serial form -- C++ or hand-written -- costs the generic inverse row kernel its fourth wave: 27-45 spills; the
+    // production row sizes take the Shoup kernel anyway)
+    b = mred_lazy(U + twoq - V, w, q, qinv);
 }
 // last inverse stage with N^-1 folded in: outputs canonical
 __device__ __forceinline__ void bfly_inv_scaled(uint64_t &a, uint64_t &b, uint64_t wn, uint64_t ninv, uint64_t q,
@@ -272,8 +315,8 @@ __device__ __forceinline__ void rows_round(uint64_t (&x)[16], const uint64_t *__
                 for (int k = 0; k < G; k++) {
                     if (k & d) continue;
                     const uint64_t wv = tw[base + (k >> (g - u))];
-                    if constexpr (NC) bfly_fwd_nc(x[w * G + k], x[w * G + k + d], wv, q, qinv);
-                    else bfly_fwd(x[w * G + k], x[w * G + k + d], wv, q, twoq, qinv);
+                    if constexpr (NC) bfly_fwd_nc<true>(x[w * G + k], x[w * G + k + d], wv, q, qinv);
+                    else bfly_fwd<true>(x[w * G + k], x[w * G + k + d], wv, q, twoq, qinv);
                 }
             }
         }
@@ -318,8 +361,8 @@ __device__ __forceinline__ void rows_round16(uint64_t (&x)[16], const uint64_t (
             for (int k = 0; k < 16; k++) {
                 if (k & d) continue;
                 const uint64_t wv = t[(1 << u) - 1 + (k >> (4 - u))];
-                if constexpr (NC) bfly_fwd_nc(x[k], x[k + d], wv, q, qinv);
-                else bfly_fwd(x[k], x[k + d], wv, q, twoq, qinv);
+                if constexpr (NC) bfly_fwd_nc<true>(x[k], x[k + d], wv, q, qinv);
+                else bfly_fwd<true>(x[k], x[k + d], wv, q, twoq, qinv);
             }
         }
     } else {
