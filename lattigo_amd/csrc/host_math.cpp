@@ -108,7 +108,9 @@ bool build_subring_ci(int logN, uint64_t q, SubRingHost &out, std::string &err) 
 }
 static bool build_subring_nth(int logN, uint64_t q, uint64_t nth, SubRingHost &out, std::string &err) {
     const uint64_t N = 1ull << logN;
-    if (q >> 62) { err = "modulus must be below 2^62 (lazy butterflies keep values in [0,4q))"; return false; }
+    // as the reference: its inverse butterfly forms U + 4q - V in 64 bits ("not possible ... if Q > 61 bits", ring/ntt.go:169),
+    // and the word-serial Montgomery products of the integer butterflies here need 5q < 2^64
+    if (q >> 61) { err = "modulus must be below 2^61 (the reference's own limit, ring/ntt.go:169)"; return false; }
     if (!is_prime_u64(q)) { err = "invalid modulus: " + std::to_string(q) + " is not prime"; return false; }
     if ((q & (nth - 1)) != 1) { err = "invalid modulus: " + std::to_string(q) + " != 1 mod NthRoot"; return false; }
     ModConst &mc = out.mc;

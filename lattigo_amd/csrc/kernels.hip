@@ -2558,7 +2558,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
             }
         }
         if (!done && !single && U(D.dst_fast[j]) == 2) {
-            // The same folding for the remaining destination moduli (up to 2^62: the 60/61-bit q0 and special primes of the CKKS
+            // The same folding for the remaining destination moduli (up to 2^61: the 60/61-bit q0 and special primes of the CKKS
             // chains): acc = C0m + sum_i y_i Tm_i + v V1m in 128 bits, one Montgomery reduction -> [0, 2p); Shoup column
             // butterflies in the Harvey range ([0, 4p): U is brought below 2p first).
             done = true;

@@ -42,7 +42,8 @@ HE_HD uint64_t mred(uint64_t x, uint64_t y, uint64_t q, uint64_t qinv) {
     return r >= q ? r - q : r;
 }
 // The same residue by two 32-bit reduction rounds (word-serial Montgomery, "CIOS"): x*y*2^-64 mod q in [0, 2q) for
-// q < 2^62 and x < 2^63, y < 2^62 (any lazy operand of the kernels: < 4q).  gfx950 has no 64-bit multiplier; the full-width form
+// q < 2^61 (the largest modulus the library accepts, as the reference), x + q < 2^64 (any lazy operand of the kernels: x < 4q)
+// and y < q.  gfx950 has no 64-bit multiplier; the full-width form
 // above costs 11 multiplies and ~15 carry / select instructions (a 64x64->128 product, a 64-bit low product and a 64x64 high
 // product), this one 8 v_mad_u64_u32 + 2 v_mul_lo_u32 + ~6 adds: the running sum never exceeds 96 bits and every partial
 // product is a 32x32+64 multiply-add.  m = -T q^-1 mod 2^64 is the same number either way (computed word by word here), so the

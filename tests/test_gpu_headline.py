@@ -203,19 +203,21 @@ def _worst_case_inputs(rng, q, N):
 
 
 @pytest.mark.parametrize("logN", [15, 16, 17])
-@pytest.mark.parametrize("bits", [47, 58])
+@pytest.mark.parametrize("bits", [47, 58, 61])
 def test_ntt_class_boundary_moduli(ctx, logN, bits):
     """Largest primes of the double-precision (< 2^47) and correction-free (< 2^58) classes, plus the smallest primes
-    just ABOVE each boundary (which must take the next class), worst-case inputs, forward and inverse, lazy forms."""
+    just ABOVE each boundary (which must take the next class), worst-case inputs, forward and inverse, lazy forms.  2^61 is
+    the largest modulus size the reference's butterflies support (ring/ntt.go:169) and this library accepts: its largest
+    NTT-friendly primes sit at the edge of the word-serial Montgomery products' domain (5q < 2^64)."""
     N = 1 << logN
     below = primes_below(bits, logN + 1, 2)
     above, qq = [], (1 << bits) + 1
-    while len(above) < 1:
+    while len(above) < (1 if bits < 61 else 0):
         if O.IsPrime(qq):
             above.append(qq)
         qq += 1 << (logN + 1)
     moduli = below + above
-    assert below[0] < (1 << bits) <= above[0] and (1 << bits) - below[0] < (1 << (logN + 8))
+    assert below[0] < (1 << bits) and (not above or (1 << bits) <= above[0]) and (1 << bits) - below[0] < (1 << (logN + 8))
     pr = Pair(ctx, logN, len(moduli), qmods=moduli)
     rng = rng_for(4700 + bits + logN)
     cases = [np.stack(c) for c in zip(*[_worst_case_inputs(rng, q, N) for q in moduli])]
@@ -237,7 +239,7 @@ def test_ntt_class_boundary_moduli(ctx, logN, bits):
     # beyond the reference's domain (it assumes words below 2q): this library reduces arbitrary 64-bit words first, so the
     # transform of x and of x mod q agree
     for w in (36, None):
-        x = np.stack([np.full(N, (w * q - 1) if w else (1 << 64) - 1, dtype=np.uint64) for q in moduli])
+        x = np.stack([np.full(N, (min(w, ((1 << 64) - 1) // q) * q - 1) if w else (1 << 64) - 1, dtype=np.uint64) for q in moduli])
         px, py, pz = pr.gQ.NewPoly().upload(x), pr.gQ.NewPoly(), pr.gQ.NewPoly()
         xr = pr.oQ.unop("Reduce", x)
         pr.gQ.NTT(px, py)

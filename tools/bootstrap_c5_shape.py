@@ -33,8 +33,9 @@ def gen_primes(logs, nth, taken):
     out = []
     for b in logs:
         x = (1 << b) + 1
+        step = nth if b < 61 else -nth  # 61-bit primes are searched downwards: moduli stay below 2^61 (ring/ntt.go:169)
         while True:
-            x += nth
+            x += step
             if x not in taken and pow(2, x - 1, x) == 1 and all(pow(a, x - 1, x) == 1 for a in (3, 5, 7, 11)):
                 out.append(x)
                 taken.add(x)
