@@ -162,7 +162,6 @@ struct Ring : Obj {
     uint64_t *d_twf = nullptr, *d_twi = nullptr;
     std::vector<uint8_t> small;
     double *d_twdf = nullptr, *d_twdi = nullptr;
-    uint64_t *d_tw2f = nullptr, *d_tw2i = nullptr;
     RingDev dev{};
     Ring() : Obj(T_RING) {}
     ~Ring() override {
@@ -173,8 +172,6 @@ struct Ring : Obj {
         if (d_twi) hipFree(d_twi);
         if (d_twdf) hipFree(d_twdf);
         if (d_twdi) hipFree(d_twdi);
-        if (d_tw2f) hipFree(d_tw2f);
-        if (d_tw2i) hipFree(d_tw2i);
     }
     int nmod() const { return (int)moduli.size(); }
 };
@@ -248,7 +245,7 @@ static ModUpRef pool_modup(ConstPool &pool, const std::vector<uint64_t> &S, cons
         for (int i = 0; i < h.nsrc; i++) {
             const uint64_t t = mulmod(h.T[(size_t)j * h.nsrc + i], rinv, p);
             Td[((size_t)j * h.nsrc + i) * 2] = dbits((double)t);
-            Td[((size_t)j * h.nsrc + i) * 2 + 1] = dbits((double)mulmod(t, (1ull << 26) % p, p));
+            Td[((size_t)j * h.nsrc + i) * 2 + 1] = dbits((double)mulmod(t, (1ull << kYSplitBits) % p, p));
         }
         for (int v = 0; v <= h.nsrc; v++) vtd[(size_t)j * (h.nsrc + 1) + v] = dbits((double)h.vt[(size_t)j * (h.nsrc + 1) + v]);
     }
@@ -275,7 +272,7 @@ struct BasisExtender : Obj {
     uint64_t *d_twf = nullptr, *d_twi = nullptr;
     std::vector<uint8_t> small;
     double *d_twdf = nullptr, *d_twdi = nullptr;
-    uint64_t *d_tws = nullptr, *d_tw2f = nullptr, *d_tw2i = nullptr;
+    uint64_t *d_tws = nullptr;
     RingDev qp{};
     ConstPool pool;
     std::vector<ModUpRef> qtop, ptoq;                      // per source level
@@ -290,8 +287,6 @@ struct BasisExtender : Obj {
         if (d_twdf) hipFree(d_twdf);
         if (d_twdi) hipFree(d_twdi);
         if (d_tws) hipFree(d_tws);
-        if (d_tw2f) hipFree(d_tw2f);
-        if (d_tw2i) hipFree(d_tw2i);
         pool.release();
     }
     uint64_t modulus(int idx) const { return idx < LQ ? Q->moduli[idx] : P->moduli[idx - LQ]; }
@@ -449,27 +444,6 @@ int upload_f64_tables(const std::vector<const SubRingHost *> &subs, int N, doubl
     HIP_TRY(hipMemcpy(*d_i, ti.data(), ti.size() * sizeof(double), hipMemcpyHostToDevice));
     return HE_OK;
 }
-// the twiddle tables once more as Shoup pairs {w, floor(w 2^64 / q)} of the plain twiddles, for the integer row kernels
-int upload_shoup_tables(const std::vector<const SubRingHost *> &subs, int N, uint64_t **d_f, uint64_t **d_i) {
-    const size_t n = subs.size();
-    *d_f = *d_i = nullptr;
-    bool any = false;
-    for (auto *s : subs) any = any || modulus_class(s->mc.q) != 2;
-    if (!any || n == 0) return HE_OK;
-    std::vector<uint64_t> ti(n * (size_t)N * 2, 0);
-    for (size_t i = 0; i < n; i++) {
-        const ModConst &m = subs[i]->mc;
-        if (modulus_class(m.q) == 2) continue;  // double-precision limbs never take the integer kernels when twd exists
-        for (int j = 0; j < N; j++) {
-            const uint64_t wi = imform(subs[i]->roots_bwd[j], m.q, m.qinv);
-            ti[(i * (size_t)N + j) * 2] = wi; ti[(i * (size_t)N + j) * 2 + 1] = (uint64_t)(((u128)wi << 64) / m.q);
-        }
-    }
-    // only the backward table exists (the forward kernel does not gain from the paired twiddles, see launch_rows_nc): *d_f stays null
-    HIP_TRY(hipMalloc((void **)d_i, ti.size() * 8));
-    HIP_TRY(hipMemcpy(*d_i, ti.data(), ti.size() * 8, hipMemcpyHostToDevice));
-    return HE_OK;
-}
 int upload_tables(const std::vector<const SubRingHost *> &subs, int N, ModConst **d_mc, uint64_t **d_twf, uint64_t **d_twi) {
     const size_t n = subs.size();
     std::vector<ModConst> mc(n);
@@ -582,8 +556,6 @@ int he_ring_create_type(he_handle hctx, int logN, int ring_type, const uint64_t 
     TRY(upload_f64_tables(subs, r->N, &r->d_twdf, &r->d_twdi));
     r->dev = RingDev{logN, r->N, r->d_mc, r->d_twf, r->d_twi, r->small.data(), r->d_twdf, r->d_twdi};
     if (ring_type == 0) {  // (the conjugate-invariant tables are remapped; the class test below does not apply to its fold twiddles)
-        TRY(upload_shoup_tables(subs, r->N, &r->d_tw2f, &r->d_tw2i));
-        r->dev.tws2_fwd = r->d_tw2f; r->dev.tws2_inv = r->d_tw2i;
     }
     *out = reg(r);
     return HE_OK;
@@ -1210,8 +1182,6 @@ static int basis_extender_build(std::shared_ptr<Ring> Q, std::shared_ptr<Ring> P
         HIP_TRY(hipMemcpy(be->d_tws, tws.data(), tws.size() * 8, hipMemcpyHostToDevice));
         be->qp.tws_fwd = be->d_tws;
     }
-    TRY(upload_shoup_tables(subs, Q->N, &be->d_tw2f, &be->d_tw2i));
-    be->qp.tws2_fwd = be->d_tw2f; be->qp.tws2_inv = be->d_tw2i;
     for (int i = 0; i < be->LQ; i++)  // constantsQtoP[i] = GenModUpConstants(Q[:i+1], P)     basis_extension.go:62-65
         be->qtop.push_back(pool_modup(be->pool, std::vector<uint64_t>(Q->moduli.begin(), Q->moduli.begin() + i + 1), P->moduli));
     for (int i = 0; i < be->LP; i++)  // constantsPtoQ[i] = GenModUpConstants(P[:i+1], Q)     :67-70

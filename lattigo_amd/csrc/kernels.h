@@ -40,8 +40,6 @@ struct RingDev {
     // [n_mod][16][2]: {w, floor(w 2^64 / q)} for the plain (non-Montgomery) forward twiddles RootsForward[0..15] -- the column
     // stages fused into the basis extension use Shoup products on the integer path; null when not built
     const uint64_t *tws_fwd = nullptr;
-    // [n_mod][N][2]: the whole forward / backward twiddle tables as Shoup pairs (integer row kernels), or null
-    const uint64_t *tws2_fwd = nullptr, *tws2_inv = nullptr;
 };
 
 // ---- NTT ---------------------------------------------------------------------------
@@ -178,11 +176,17 @@ hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, Vi
 // every destination limb], a = logN - 12.  Sources are the output of the inverse ROWS pass, destinations
 // feed the forward ROWS pass, so the strided "column" passes never touch HBM on their own.
 // One descriptor per digit, resident in device memory (built once per (levelQ, levelP) plan).
+#ifndef HE_MODUP_MAGIC
+#define HE_MODUP_MAGIC 1  // split residues: exact running sum of the products, one reduction per coefficient (0: one modmul_f64 each)
+#endif
+// a source residue of 2^51 and above is split y = yh 2^kYSplitBits + yl for the double-precision destinations (both halves fit
+// 32 bits for moduli below 2^61)
+constexpr int kYSplitBits = HE_MODUP_MAGIC ? 29 : 26;
 struct ModUpDesc {
     int nsrc, ndst, single, reduce_out;
     const uint64_t *a, *T, *vt;
-    // double-precision copies for destination moduli below 2^47: Td[row][i] = {T, T*2^26 mod p} (plain integers),
-    // vtd[row][v] = vt; a source residue y >= 2^51 is split as y = yh*2^26 + yl (src_split[i])
+    // double-precision copies for destination moduli below 2^47: Td[row][i] = {T, T*2^kYSplitBits mod p} (plain integers),
+    // vtd[row][v] = vt; a source residue y >= 2^51 is split as y = yh*2^kYSplitBits + yl (src_split[i])
     const double *Td, *vtd;
     // lean integer path (destination moduli below 2^58, see modup_fused_kernel): fc[row] = {vt[row][1] 2^64 mod p,
     // (p - dst_half) 2^64 mod p}; dst_fast[j] marks the destinations that take it

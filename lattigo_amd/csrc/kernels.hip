@@ -211,8 +211,23 @@ __device__ __forceinline__ void bfly_inv(uint64_t &a, uint64_t &b, uint64_t w, u
     uint64_t X = U + V;
     a = X >= twoq ? X - twoq : X;
     // (either word-serial form -- C++ or hand-written -- costs the generic inverse row kernel its fourth wave: 27-45 spills; the
-    // production row sizes take the Shoup kernel anyway)
+    // production row sizes take the lean variant of the kernel, which has the hand-written form)
     b = mred_lazy(U + twoq - V, w, q, qinv);
+}
+// the same two butterflies with the hand-written product (kernels with register room for its fixed scratch: the fused basis
+// extension, HE_MODUP_ASM)
+__device__ __forceinline__ void bfly_inv_asm(uint64_t &a, uint64_t &b, uint64_t w, uint64_t q, uint64_t twoq, uint64_t qinv) {
+    const uint64_t U = a, V = b, X = U + V;
+    a = X >= twoq ? X - twoq : X;
+    b = mred_lazy_col_asm(U + twoq - V, w, q, qinv);
+}
+__device__ __forceinline__ void bfly_inv_scaled_asm(uint64_t &a, uint64_t &b, uint64_t wn, uint64_t ninv, uint64_t q,
+                                                    uint64_t twoq, uint64_t qinv) {
+    const uint64_t U = a, V = b;
+    uint64_t X = U + V;
+    X = X >= twoq ? X - twoq : X;  // the sequence wants its operand below 4q (U, V in [0, 2q): U + V is)
+    a = cred(mred_lazy_col_asm(X, ninv, q, qinv), q);
+    b = cred(mred_lazy_col_asm(U + twoq - V, wn, q, qinv), q);
 }
 // last inverse stage with N^-1 folded in: outputs canonical
 __device__ __forceinline__ void bfly_inv_scaled(uint64_t &a, uint64_t &b, uint64_t wn, uint64_t ninv, uint64_t q,
@@ -229,7 +244,6 @@ struct NttArgs {
     const ModConst *mc;
     const uint64_t *tw;
     const double *twd;  // same table as plain (non-Montgomery) integers in double precision, moduli < 2^47 only
-    const ulonglong2 *tws;  // same table as Shoup pairs {w, floor(w 2^64 / q)} of the plain twiddles (integer kernels), or null
     int N;
     int a;       // column stages already done (forward) / still to do (inverse)
     int flags;
@@ -381,48 +395,19 @@ __device__ __forceinline__ void rows_round16(uint64_t (&x)[16], const uint64_t (
     }
 }
 
-// Shoup form of the radix-16 round: the twiddle comes with its companion w' = floor(w 2^64 / q), and
-//     r = V w - mulhi(V, w') q   (low 64 bits)   lies in [0, 2q) for ANY 64-bit V
-// -- one high product and two low products (19 vector instructions) against the three wide products of a Montgomery
-// multiplication (26).  Forward: X = U + r, Y = U + 2q - r (NC: no range correction, the bound grows by 2q per stage exactly as
-// bfly_fwd_nc; Harvey form: U is first brought below 2q).  Inverse: X = U + V (minus 2q when >= 2q), Y = Shoup(U + 2q - V).
-__device__ __forceinline__ uint64_t shoup_mul(uint64_t V, ulonglong2 w, uint64_t q) { return V * w.x - mulhi64(V, w.y) * q; }
-__device__ __forceinline__ void rows_tw16s(ulonglong2 (&t)[15], const ulonglong2 *__restrict__ tw, int rowtw, int s0, int hi0) {
+// inverse radix-16 round without the N^-1 fold, products through the hand-written column Montgomery sequence (the production
+// inverse row kernel: x[k + d] = (U + 2q - V) w with U + 2q - V < 4q, inside the sequence's domain)
+__device__ __forceinline__ void rows_round16_inv_asm(uint64_t (&x)[16], const uint64_t (&t)[15], uint64_t q, uint64_t twoq, uint64_t qinv) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int base = (rowtw << (s0 + u)) + (hi0 << u);
+    for (int u = 3; u >= 0; u--) {
+        const int d = 1 << (3 - u);
 #pragma unroll
-        for (int j = 0; j < (1 << u); j++) t[(1 << u) - 1 + j] = tw[base + j];
-    }
-}
-template <bool INV, bool NC>
-__device__ __forceinline__ void rows_round16s(uint64_t (&x)[16], const ulonglong2 (&t)[15], uint64_t q, uint64_t twoq) {
-    if constexpr (!INV) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int d = 1 << (3 - u);
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (k & d) continue;
-                const uint64_t r = shoup_mul(x[k + d], t[(1 << u) - 1 + (k >> (4 - u))], q);
-                uint64_t U = x[k];
-                if constexpr (!NC) U = U >= twoq ? U - twoq : U;
-                x[k] = U + r;
-                x[k + d] = U + twoq - r;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int u = 3; u >= 0; u--) {
-            const int d = 1 << (3 - u);
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (k & d) continue;
-                const uint64_t U = x[k], V = x[k + d];
-                const uint64_t X = U + V;
-                x[k] = X >= twoq ? X - twoq : X;
-                x[k + d] = shoup_mul(U + twoq - V, t[(1 << u) - 1 + (k >> (4 - u))], q);
-            }
+        for (int k = 0; k < 16; k++) {
+            if (k & d) continue;
+            const uint64_t U = x[k], V = x[k + d];
+            const uint64_t X = U + V;
+            x[k] = X >= twoq ? X - twoq : X;
+            x[k + d] = mred_lazy_col_asm(U + twoq - V, t[(1 << u) - 1 + (k >> (4 - u))], q, qinv);
         }
     }
 }
@@ -462,13 +447,12 @@ __device__ __forceinline__ void rows_lds_xfer(uint64_t (&x)[16], uint64_t *lds, 
     }
 }
 
-#ifndef HE_ROWS_SHOUP_WAVES
-#define HE_ROWS_SHOUP_WAVES 4
-#endif
-// SHOUP: the radix-16 rounds take their twiddles from the paired table (NttArgs::tws); never with the N^-1 fold of a
-// single-pass inverse (A.scale), which stays on the Montgomery table
-template <int LOGB, bool INV, bool NC, bool SHOUP = false>
-__global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, SHOUP ? HE_ROWS_SHOUP_WAVES : 4) ntt_rows_kernel(NttArgs A) {
+// LEAN (inverse, production row sizes): no N^-1 fold (A.scale == 0 by contract) and the products through the hand-written
+// Montgomery sequence -- without the fold's code the kernel keeps its four waves per SIMD with the sequence's fixed scratch
+// registers (the generic inverse spills 27-45 with them).  Round 2 ran this variant on Shoup twiddle pairs (19 instructions per
+// product and twice the twiddle bytes); the 16-instruction sequence on the ordinary table is 4 % faster and needs no second table.
+template <int LOGB, bool INV, bool NC, bool LEAN = false>
+__global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4) ntt_rows_kernel(NttArgs A) {
     constexpr int N2 = 1 << LOGB;
     constexpr int T = N2 / 16;
     constexpr int NR4 = LOGB / 4;       // full radix-16 rounds
@@ -491,13 +475,12 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, S
     const ModConst mc = A.mc[mi];
     const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
     const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
-    const ulonglong2 *__restrict__ tws = SHOUP ? A.tws + (size_t)mi * A.N : nullptr;
     const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
     uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
     const int rowtw = (1 << A.a) + row;  // 2^a + r
 
     uint64_t x[16];
-    using TwT = typename std::conditional<SHOUP, ulonglong2, uint64_t>::type;
+    static_assert(!LEAN || INV, "the lean variant is an inverse kernel");
 
     if constexpr (!INV) {
         constexpr int sh0 = LOGB - 4;
@@ -512,21 +495,14 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, S
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = bred_add_lazy(x[k], q, mc.brc0);
         }
-        TwT t16[15];
-        if constexpr (NR4 > 0) {
-            if constexpr (SHOUP) rows_tw16s(t16, tws, rowtw, 0, tau >> (LOGB - 4));
-            else rows_tw16(t16, tw, rowtw, 0, tau >> (LOGB - 4));
-        }
+        uint64_t t16[15];
+        if constexpr (NR4 > 0) rows_tw16(t16, tw, rowtw, 0, tau >> (LOGB - 4));
 #pragma unroll 1
         for (int rho = 0; rho < NR4; rho++) {
             const int s0 = 4 * rho, sh = LOGB - s0 - 4;
             if (rho > 0) rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, false);
-            if constexpr (SHOUP) rows_round16s<false, NC>(x, t16, q, twoq);
-            else rows_round16<false, NC>(x, t16, q, twoq, qinv, mc, false);
-            if (rho + 1 < NR4) {  // in flight across the exchange
-                if constexpr (SHOUP) rows_tw16s(t16, tws, rowtw, s0 + 4, tau >> (sh - 4));
-                else rows_tw16(t16, tw, rowtw, s0 + 4, tau >> (sh - 4));
-            }
+            rows_round16<false, NC>(x, t16, q, twoq, qinv, mc, false);
+            if (rho + 1 < NR4) rows_tw16(t16, tw, rowtw, s0 + 4, tau >> (sh - 4));  // in flight across the exchange
             rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, true);
             rows_sync(sh);
         }
@@ -622,21 +598,17 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, S
             rows_lds_xfer<LOGB, GREM>(x, lds, tau, s0, 0, true);
             rows_sync(GREM);
         }
-        TwT t16[15];
-        if constexpr (NR4 > 0) {
-            if constexpr (SHOUP) rows_tw16s(t16, tws, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
-            else rows_tw16(t16, tw, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
-        }
+        uint64_t t16[15];
+        if constexpr (NR4 > 0) rows_tw16(t16, tw, rowtw, 4 * (NR4 - 1), tau >> (LOGB - 4 * NR4));
 #pragma unroll 1
         for (int rho = NR4 - 1; rho >= 0; rho--) {
             const int s0 = 4 * rho, sh = LOGB - s0 - 4;
             rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, false);
-            if constexpr (SHOUP) rows_round16s<true, false>(x, t16, q, twoq);
+            if constexpr (LEAN) rows_round16_inv_asm(x, t16, q, twoq, qinv);
             else rows_round16<true, false>(x, t16, q, twoq, qinv, mc, A.scale && rho == 0);
             if (rho > 0) {
                 // the next round's, in flight across the exchange
-                if constexpr (SHOUP) rows_tw16s(t16, tws, rowtw, s0 - 4, tau >> (sh + 4));
-                else rows_tw16(t16, tw, rowtw, s0 - 4, tau >> (sh + 4));
+                rows_tw16(t16, tw, rowtw, s0 - 4, tau >> (sh + 4));
                 rows_lds_xfer<LOGB, 4>(x, lds, tau, s0, sh, true);
                 rows_sync(sh + 4);  // the consumers are the next round's groups of 2^(sh + 4) threads
             }
@@ -1605,12 +1577,10 @@ static double rows_bytes(dim3 grid, const NttArgs &A, int logb) {
 }
 template <bool INV, bool NC>
 static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
-    static const bool no_shoup = getenv("HERING_NO_SHOUP_ROWS") && atoi(getenv("HERING_NO_SHOUP_ROWS")) != 0;
-    // Shoup twiddles for the inverse transform at the production row sizes: 0.217 -> 0.198 ms per MulRelin step.  The forward
-    // kernel does not gain: with the paired table it needs 162 registers (three waves per SIMD) and reads twice the twiddle
-    // bytes -- 0.439 against 0.424 ms, the same verdict as round 1's experiment.
+    static const bool no_lean = getenv("HERING_NO_LEAN_INV_ROWS") && atoi(getenv("HERING_NO_LEAN_INV_ROWS")) != 0;
+    // the production row sizes without the N^-1 fold: the lean inverse variant (see ntt_rows_kernel)
     if constexpr (INV) {
-        if (A.tws && !no_shoup && (logb == 12 || logb == 13) && !A.scale) {
+        if (!no_lean && (logb == 12 || logb == 13) && !A.scale) {
             ProfScope ps(K_NTT_ROWS_INV, s, rows_bytes(grid, A, logb));
             if (logb == 12) hipLaunchKernelGGL((ntt_rows_kernel<12, true, false, true>), grid, dim3(256), 0, s, A);
             else hipLaunchKernelGGL((ntt_rows_kernel<13, true, false, true>), grid, dim3(512), 0, s, A);
@@ -1738,7 +1708,6 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     if (!inverse) {
         A.tw = r.tw_fwd;
         A.twd = r.twd_fwd;
-        A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_fwd);
         A.scale = 0;
         if (a > 0) {
             A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
@@ -1765,7 +1734,6 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     }
     A.tw = r.tw_inv;
     A.twd = r.twd_inv;
-    A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_inv);
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = (flags & NTT_REDUCE_INPUT) | (a == 0 ? sflag : 0);
     A.scale = (a == 0);
@@ -1804,10 +1772,10 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     // tensor mode: both components of 8 entries per 16 consecutive workgroups (see NttEpilogue::tensor)
     dim3 grows(A.epi_tensor ? (unsigned)((epi->zsplit + 7) / 8 * 16) : (unsigned)batch, tab.n, 1u << a);
     if (!inverse) {
-        A.tw = r.tw_fwd; A.twd = r.twd_fwd; A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_fwd); A.scale = 0;
+        A.tw = r.tw_fwd; A.twd = r.twd_fwd; A.scale = 0;
         return launch_rows<false>(b, grows, A, r.host_small, s);
     }
-    A.tw = r.tw_inv; A.twd = r.twd_inv; A.tws = reinterpret_cast<const ulonglong2 *>(r.tws2_inv); A.scale = (a == 0);
+    A.tw = r.tw_inv; A.twd = r.twd_inv; A.scale = (a == 0);
     return launch_rows<true>(b, grows, A, r.host_small, s);
 }
 
@@ -2289,6 +2257,9 @@ struct ModUpFusedArgs {
 // DSTF64 = false: destinations in 64-bit integer arithmetic (any modulus).
 // DSTF64 = true : only destination moduli below 2^47, the mat-vec and the column stages in exact double-precision
 //                 integer arithmetic (see ntt_rows_f64_kernel); same canonical results.
+#ifndef HE_MODUP_ASM
+#define HE_MODUP_ASM 1  // integer source stages, y_i and lean-destination butterflies through mred_lazy_col_asm (0: compiler forms)
+#endif
 #ifndef HE_MODUP_WAVES
 #define HE_MODUP_WAVES 3  // waves per SIMD the register allocation aims at (the LDS footprint allows three)
 #endif
@@ -2323,7 +2294,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     const double *Dvtd = reinterpret_cast<const double *>(U64((uint64_t)D.vtd));
     const uint64_t *Dfc = reinterpret_cast<const uint64_t *>(U64((uint64_t)D.fc));
     const size_t dst_off = U64(D.dst_off);
-    uint32_t splitmask = 0;  // bit i: source residue i is split into 26-bit halves
+    uint32_t splitmask = 0;  // bit i: source residue i is split at kYSplitBits
 #pragma unroll
     for (int i = 0; i < NSRC; i++) splitmask |= (D.src_split[i] != 0 ? 1u : 0u) << i;
     splitmask = single ? 0u : U(splitmask);
@@ -2346,7 +2317,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     auto ytake = [&](int r, int i) -> uint64_t { return i < KREG ? yreg[r][i] : ylds[(i - KREG) * R + r][threadIdx.x]; };
     uint64_t y[DSTF64 ? 1 : R][DSTF64 ? 1 : NSRC];   // integer variant
     // Short digits (NSRC <= 3, up to 8 coefficients per thread) also keep every residue that fits a double (source modulus
-    // below 2^51: no 26-bit split) as a double in registers: the double-precision destinations -- most of them at the headline
+    // below 2^51: no split) as a double in registers: the double-precision destinations -- most of them at the headline
     // shape -- then take their operand without an LDS read and a conversion per (term, destination).  48 registers; the kernel
     // stays within the three-wave budget.
 #ifndef HE_MODUP_YD
@@ -2401,8 +2372,13 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 for (int r = 0; r < R; r++) {
                     if (r & d) continue;
                     const uint64_t wv = tw[(1 << s) + (r >> (LOGA - s))];
+#if HE_MODUP_ASM
+                    if (s == 0) bfly_inv_scaled_asm(x[r], x[r + d], mred(wv, mq.ninv, q, qinv), mq.ninv, q, twoq, qinv);
+                    else bfly_inv_asm(x[r], x[r + d], wv, q, twoq, qinv);
+#else
                     if (s == 0) bfly_inv_scaled(x[r], x[r + d], mred(wv, mq.ninv, q, qinv), mq.ninv, q, twoq, qinv);
                     else bfly_inv(x[r], x[r + d], wv, q, twoq, qinv);
+#endif
                 }
             }
         }
@@ -2434,7 +2410,11 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
             } else {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
+#if HE_MODUP_ASM
+                    yi[r] = cred(mred_lazy_col_asm(cred(x[r] + h, q), ai, q, qinv), q);
+#else
                     yi[r] = mred(cred(x[r] + h, q), ai, q, qinv);
+#endif
                     yd[r] = __ull2double_rn(yi[r]);
                 }
             }
@@ -2515,16 +2495,70 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 const double hd = (double)U64(D.dst_half[j]);
 #pragma unroll
                 for (int r = 0; r < R; r++) o[r] = __fma_rn(vd[r], vt1, -hd);
+#if HE_MODUP_MAGIC
+                // Residues that do not fit a double (source modulus of 2^51 and above: the special primes in ModDown, q0 in the
+                // decomposition) are split y = yh 2^29 + yl and their 2 x (split sources) products with {T, T 2^29 mod p} are
+                // summed EXACTLY before one reduction: H runs in the binade [2^84, 2^85) (every product is below 2^79, at most
+                // sixteen of them), so each fma rounds the running sum to a multiple of 2^32; the part it dropped,
+                // l = a w - (H' - H), is an integer below 2^31 recovered exactly by a second fma and summed in L.  Four
+                // operations per product and one reduction per coefficient, against seven per product for modmul_f64.
+                if (splitmask) {
+                    constexpr double C = 0x1p84;
+                    constexpr uint32_t ML = (1u << kYSplitBits) - 1u;
+                    double Tl[NSRC], Th[NSRC];
+#pragma unroll
+                    for (int i = 0; i < NSRC; i++) { Tl[i] = ldcd(Tr, 2 * i); Th[i] = ldcd(Tr, 2 * i + 1); }
+                    auto piece = [](double a, double w, double &H, double &L) {
+                        const double Hn = __fma_rn(a, w, H);
+                        L += __fma_rn(a, w, -(Hn - H));
+                        H = Hn;
+                    };
+                    auto finish = [&](int r, double H, double L) {
+                        const double Hs = H - C;
+                        o[r] += __fma_rn(-rint(Hs * pid), pd, Hs) + L;
+                    };
+                    if (splitmask == (1u << NSRC) - 1u) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            double H = C, L = 0.0;
+#pragma unroll
+                            for (int i = 0; i < NSRC; i++) {
+                                const uint64_t yy = ytake(r, i);
+                                piece((double)((uint32_t)yy & ML), Tl[i], H, L);
+                                piece((double)(uint32_t)(yy >> kYSplitBits), Th[i], H, L);
+                            }
+                            finish(r, H, L);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            double H = C, L = 0.0;
+#pragma unroll
+                            for (int i = 0; i < NSRC; i++) {
+                                if (!((splitmask >> i) & 1)) continue;
+                                const uint64_t yy = ytake(r, i);
+                                piece((double)((uint32_t)yy & ML), Tl[i], H, L);
+                                piece((double)(uint32_t)(yy >> kYSplitBits), Th[i], H, L);
+                            }
+                            finish(r, H, L);
+                        }
+                    }
+                }
+#endif
 #pragma unroll
                 for (int i = 0; i < NSRC; i++) {
-                    const double Tl = ldcd(Tr, 2 * i), Th = ldcd(Tr, 2 * i + 1);  // block-uniform: scalar loads
-                    if ((splitmask >> i) & 1) {  // y >= 2^51 possible: y = yh 2^26 + yl, two exact products
+                    const double Tl = ldcd(Tr, 2 * i);  // block-uniform: scalar loads
+                    [[maybe_unused]] const double Th = ldcd(Tr, 2 * i + 1);
+                    if ((splitmask >> i) & 1) {
+#if !HE_MODUP_MAGIC
+                        // y >= 2^51 possible: y = yh 2^26 + yl, two exact products
 #pragma unroll
                         for (int r = 0; r < R; r++) {
                             const uint64_t yy = ytake(r, i);
-                            o[r] += modmul_f64(u52_to_f64(yy & ((1ull << 26) - 1)), Tl, pd, pid);
-                            o[r] += modmul_f64(u52_to_f64(yy >> 26), Th, pd, pid);
+                            o[r] += modmul_f64(u52_to_f64(yy & ((1ull << kYSplitBits) - 1)), Tl, pd, pid);
+                            o[r] += modmul_f64(u52_to_f64(yy >> kYSplitBits), Th, pd, pid);
                         }
+#endif
                     } else if constexpr (YD) {
 #pragma unroll
                         for (int r = 0; r < R; r++) o[r] += modmul_f64(ydreg[r][i], Tl, pd, pid);
@@ -2577,7 +2611,8 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 o[r] = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p;  // (0, 2p)
             }
             if constexpr (LOGA > 0) {
-                const uint64_t *ts = A.tws_fwd + (size_t)mi * 32;
+                [[maybe_unused]] const uint64_t *ts = A.tws_fwd + (size_t)mi * 32;
+                [[maybe_unused]] const uint64_t *twm = A.tw_fwd + (size_t)mi * A.N;
 #pragma unroll
                 for (int s = 0; s < LOGA; s++) {
                     const int d = 1 << (LOGA - 1 - s);
@@ -2585,9 +2620,13 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                     for (int r = 0; r < R; r++) {
                         if (r & d) continue;
                         const size_t ix = (size_t)((1 << s) + (r >> (LOGA - s)));
-                        const uint64_t w = ldc(ts, 2 * ix), ws = ldc(ts, 2 * ix + 1);
                         const uint64_t V = o[r + d];
+#if HE_MODUP_ASM
+                        const uint64_t rr = mred_lazy_col_asm(V, ldc(twm, ix), p, pinv);  // [0, 2p)
+#else
+                        const uint64_t w = ldc(ts, 2 * ix), ws = ldc(ts, 2 * ix + 1);
                         const uint64_t rr = V * w - mulhi64(V, ws) * p;  // [0, 2p)
+#endif
                         uint64_t Uu = o[r];
                         Uu = Uu >= twop ? Uu - twop : Uu;
                         o[r] = Uu + rr;
@@ -2640,7 +2679,8 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 o[r] = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p;  // (0, 2p)
             }
             if constexpr (LOGA > 0) {
-                const uint64_t *ts = A.tws_fwd + (size_t)mi * 32;
+                [[maybe_unused]] const uint64_t *ts = A.tws_fwd + (size_t)mi * 32;
+                [[maybe_unused]] const uint64_t *twm = A.tw_fwd + (size_t)mi * A.N;
 #pragma unroll
                 for (int s = 0; s < LOGA; s++) {
                     const int d = 1 << (LOGA - 1 - s);
@@ -2648,9 +2688,13 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                     for (int r = 0; r < R; r++) {
                         if (r & d) continue;
                         const size_t ix = (size_t)((1 << s) + (r >> (LOGA - s)));
-                        const uint64_t w = ldc(ts, 2 * ix), ws = ldc(ts, 2 * ix + 1);
                         const uint64_t V = o[r + d];
+#if HE_MODUP_ASM
+                        const uint64_t rr = mred_lazy_col_asm(V, ldc(twm, ix), p, pinv);
+#else
+                        const uint64_t w = ldc(ts, 2 * ix), ws = ldc(ts, 2 * ix + 1);
                         const uint64_t rr = V * w - mulhi64(V, ws) * p;
+#endif
                         const uint64_t Uu = o[r];
                         o[r] = Uu + rr;
                         o[r + d] = Uu + twop - rr;
