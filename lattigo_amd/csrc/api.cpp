@@ -224,8 +224,9 @@ struct ConstPool {
 };
 struct ModUpRef {
     int nsrc = 0, ndst = 0;
-    size_t a = 0, T = 0, vt = 0, Td = 0, vtd = 0, fc = 0;
+    size_t a = 0, T = 0, vt = 0, Td = 0, vtd = 0, fc = 0, t60 = 0;
     const uint64_t *fc_on(const ConstPool &p) const { return p.dev + fc; }
+    const uint64_t *t60_on(const ConstPool &p) const { return p.dev + t60; }
     ModUpDev on(const ConstPool &p) const { return ModUpDev{nsrc, ndst, p.dev + a, p.dev + T, p.dev + vt}; }
     const double *Td_on(const ConstPool &p) const { return reinterpret_cast<const double *>(p.dev + Td); }
     const double *vtd_on(const ConstPool &p) const { return reinterpret_cast<const double *>(p.dev + vtd); }
@@ -258,6 +259,18 @@ static ModUpRef pool_modup(ConstPool &pool, const std::vector<uint64_t> &S, cons
         fc[2 * j + 1] = to_mont((p - half_product_mod(S, p)) % p, p);
     }
     r.fc = pool.add(fc);
+    // the same lean path with its sum reduced at radix 2^30 (R = 2^60, see modup_fused_kernel): per destination
+    // {T[i] 2^60 mod p ..., vt[1] 2^60 mod p, (p - floor(prod(S)/2) mod p) 2^60 mod p}
+    std::vector<uint64_t> t60((size_t)h.ndst * (h.nsrc + 2), 0);
+    for (int j = 0; j < h.ndst; j++) {
+        const uint64_t p = D[j];
+        const uint64_t rinv = invmod(to_mont(1, p), p);  // 2^-64 mod p
+        auto m60 = [&](uint64_t x) { return (uint64_t)(((u128)(x % p) << 60) % p); };
+        for (int i = 0; i < h.nsrc; i++) t60[(size_t)j * (h.nsrc + 2) + i] = m60(mulmod(h.T[(size_t)j * h.nsrc + i], rinv, p));
+        t60[(size_t)j * (h.nsrc + 2) + h.nsrc] = m60(h.vt[(size_t)j * (h.nsrc + 1) + 1]);
+        t60[(size_t)j * (h.nsrc + 2) + h.nsrc + 1] = m60((p - half_product_mod(S, p)) % p);
+    }
+    r.t60 = pool.add(t60);
     return r;
 }
 
@@ -1601,10 +1614,15 @@ void mark_fast_destinations(const BasisExtender &be, ModUpDesc &D, const std::ve
         const uint64_t p = be.modulus(D.dst_mod[j]);
         const bool f64_dst = (p >> 47) == 0 && be.d_twdf != nullptr;
         const u128 colsum = (u128)(D.nsrc + 1) * ((u128)p + mx + ((u128)1 << 31));
+        // radix-2^30 reduction of the lean sum (HE_MODUP_R60): the middle column takes (nsrc + 1) (x1 t0 + x0 t1) + m p1 + a carry,
+        // and the result (sum + m p) / 2^60 stays below 2p only while (nsrc + 1) max q <= 2^60
+        const u128 midcol = (u128)(D.nsrc + 1) * ((((u128)(mx >> 30) + 1) << 30) + (((u128)(p >> 30) + 1) << 30)) +
+                            (((u128)(p >> 30) + 1) << 30) + ((u128)1 << 35);
+        const bool r60 = (midcol >> 64) == 0 && (u128)(D.nsrc + 1) * mx <= ((u128)1 << 60) && D.nsrc + 2 <= 15;
         // 1: 30-bit column accumulation + correction-free butterflies (below 2^58); 2: 128-bit accumulation + Harvey-range
         // butterflies (any modulus); 0: the generic path (single-limb digits, sums that need the extra reduction)
         const bool lean = !off && !D.single && !D.reduce_out && !f64_dst && be.d_tws != nullptr;
-        D.dst_fast[j] = !lean ? 0 : ((p >> 58) == 0 && D.nsrc + 1 <= 15 && (colsum >> 64) == 0) ? 1 : 2;
+        D.dst_fast[j] = !lean ? 0 : ((p >> 58) == 0 && D.nsrc + 1 <= 15 && (colsum >> 64) == 0) ? (HE_MODUP_R60 && r60 ? 3 : 1) : 2;
     }
 }
 int upload_plan(Evaluator &ev, const std::vector<ModUpDesc> &descs, FusedPlan &plan) {
@@ -1657,7 +1675,7 @@ int get_dec_plan(Evaluator &ev, int levelQ, int levelP, int nbPi, const FusedPla
             const ModUpDev c = ref.on(ev.pool);
             D.a = c.a; D.T = c.T; D.vt = c.vt;
             D.Td = ref.Td_on(ev.pool); D.vtd = ref.vtd_on(ev.pool);
-            D.fc = ref.fc_on(ev.pool);
+            D.fc = ref.fc_on(ev.pool); D.t60 = ref.t60_on(ev.pool);
             D.reduce_out = modup_out_needs_reduce(basis) ? 1 : 0;
         }
         for (int i = 0; i < D.nsrc; i++) {
@@ -1706,7 +1724,7 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
         const ModUpDev c = be.ptoq[levelP].on(be.pool);
         D.a = c.a; D.T = c.T; D.vt = c.vt;
         D.Td = be.ptoq[levelP].Td_on(be.pool); D.vtd = be.ptoq[levelP].vtd_on(be.pool);
-        D.fc = be.ptoq[levelP].fc_on(be.pool);
+        D.fc = be.ptoq[levelP].fc_on(be.pool); D.t60 = be.ptoq[levelP].t60_on(be.pool);
         D.reduce_out = modup_out_needs_reduce(basis) ? 1 : 0;
         for (int i = 0; i <= levelP; i++) {
             D.src_limb[i] = (uint8_t)i; D.src_mod[i] = (uint8_t)(be.LQ + i);

@@ -182,6 +182,9 @@ hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, Vi
 // a source residue of 2^51 and above is split y = yh 2^kYSplitBits + yl for the double-precision destinations (both halves fit
 // 32 bits for moduli below 2^61)
 constexpr int kYSplitBits = HE_MODUP_MAGIC ? 29 : 26;
+#ifndef HE_MODUP_R60
+#define HE_MODUP_R60 1  // 0: the lean integer destinations always assemble their 128-bit sum (dst_fast 1)
+#endif
 struct ModUpDesc {
     int nsrc, ndst, single, reduce_out;
     const uint64_t *a, *T, *vt;
@@ -191,6 +194,9 @@ struct ModUpDesc {
     // lean integer path (destination moduli below 2^58, see modup_fused_kernel): fc[row] = {vt[row][1] 2^64 mod p,
     // (p - dst_half) 2^64 mod p}; dst_fast[j] marks the destinations that take it
     const uint64_t *fc;
+    // dst_fast = 3: the lean path with the sum reduced at radix 2^30; t60[row] = {T[i] 2^60 mod p (nsrc of them), vt[1] 2^60 mod p,
+    // (p - dst_half) 2^60 mod p}
+    const uint64_t *t60;
     uint8_t dst_fast[kMaxLimbs];
     uint8_t src_split[8];
     uint64_t src_half[8];

@@ -2648,16 +2648,25 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
             //  * the matrix row, the constants and the twiddles are block-uniform and come through the scalar cache;
             //  * the column butterflies use Shoup products (w, floor(w 2^64 / p)): r = V w - mulhi(V, w') p in [0, 2p) for any
             //    64-bit V, X = U + r, Y = U + 2p - r -- each stage adds at most 2p to the bound.
+            //  * dst_fast = 3 (HE_MODUP_R60; the host checks the column bounds): the three columns are reduced where they are, at
+            //    radix 2^30 -- m0 = L (-p^-1) mod 2^30 clears the low column, its carry joins the middle one, m1 clears that, and
+            //    the high column is the result (sum + (m0 + m1 2^30) p) / 2^60 in (0, 2p), the constants being in 2^60-Montgomery
+            //    form: 4 v_mad_u64_u32 + 2 v_mul_lo_u32 + shifts, instead of assembling a 128-bit sum (two 64-bit shifts, two
+            //    128-bit additions) and reducing it with a 64 x 64 low and a 64 x 64 high product.
             done = true;
             const int row = (int)U(D.dst_row[j]);
             constexpr uint32_t M30 = (1u << 30) - 1;
+            const bool r60 = HE_MODUP_R60 && DSTF64 && U(D.dst_fast[j]) == 3;  // block-uniform (the all-integer variant has no register room for both forms: it keeps the 128-bit sum)
+            const uint64_t *Dt60 = reinterpret_cast<const uint64_t *>(U64((uint64_t)D.t60));
             uint32_t t0[NSRC + 1], t1[NSRC + 1];
 #pragma unroll
             for (int i = 0; i < NSRC; i++) {
-                const uint64_t Tm = ldc(DT, (size_t)row * NSRC + i);
+                const uint64_t Tm = r60 ? ldc(Dt60, (size_t)row * (NSRC + 2) + i) : ldc(DT, (size_t)row * NSRC + i);
                 t0[i] = (uint32_t)Tm & M30; t1[i] = (uint32_t)(Tm >> 30);
             }
-            const uint64_t V1 = ldc(Dfc, 2 * (size_t)row), C0 = ldc(Dfc, 2 * (size_t)row + 1);
+            const uint64_t V1 = r60 ? ldc(Dt60, (size_t)row * (NSRC + 2) + NSRC) : ldc(Dfc, 2 * (size_t)row);
+            const uint64_t C0 = r60 ? ldc(Dt60, (size_t)row * (NSRC + 2) + NSRC + 1) : ldc(Dfc, 2 * (size_t)row + 1);
+            const uint32_t p0 = (uint32_t)p & M30, p1 = (uint32_t)(p >> 30), nq30 = (uint32_t)(0 - pinv) & M30;
             t0[NSRC] = (uint32_t)V1 & M30; t1[NSRC] = (uint32_t)(V1 >> 30);
             const uint64_t L0 = C0 & M30, M0 = C0 >> 30;
             uint64_t o[R];
@@ -2675,8 +2684,17 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 }
                 Lc = mad32(v[r], t0[NSRC], Lc);
                 Mc = mad32(v[r], t1[NSRC], Mc);
-                const u128 acc = (u128)Lc + ((u128)Mc << 30) + ((u128)Hc << 60);
-                o[r] = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p;  // (0, 2p)
+                if (r60) {
+                    const uint32_t m0 = ((uint32_t)Lc * nq30) & M30;
+                    Lc = mad32(m0, p0, Lc);
+                    Mc = mad32(m0, p1, Mc) + (Lc >> 30);
+                    const uint32_t m1 = ((uint32_t)Mc * nq30) & M30;
+                    Mc = mad32(m1, p0, Mc);
+                    o[r] = mad32(m1, p1, Hc) + (Mc >> 30);  // (0, 2p)
+                } else {
+                    const u128 acc = (u128)Lc + ((u128)Mc << 30) + ((u128)Hc << 60);
+                    o[r] = (uint64_t)(acc >> 64) - mulhi64((uint64_t)acc * pinv, p) + p;  // (0, 2p)
+                }
             }
             if constexpr (LOGA > 0) {
                 [[maybe_unused]] const uint64_t *ts = A.tws_fwd + (size_t)mi * 32;
