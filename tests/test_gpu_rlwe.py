@@ -866,3 +866,37 @@ def test_evaluator_moddown_matches_basis_extender(ctx, logN, batch):
         assert np.array_equal(out.download(), want), (levelQ, levelP)
         gev.ModDownQPtoQNTT(levelQ, levelP, pq, pp, pq)  # in place
         assert np.array_equal(pq.download(), want), ("in place", levelQ, levelP)
+
+
+@pytest.mark.parametrize("logN,logq,logp", [(13, [55, 45, 45, 45], [55, 55, 55]), (13, [60, 45, 40, 36], [61, 61, 61, 61]),
+                                            (12, [45, 45, 58], [61, 55])])
+def test_moddown_split_residues_at_their_extremes(ctx, logN, logq, logp):
+    """ModDown from special primes of 2^51 and above into double-precision limbs: the residues y_i = (x_i + P/2)(P/p_i)^-1 do
+    not fit a double, the kernel splits them at 29 bits and sums the products exactly in one binade before a single reduction.
+    Drive every source's y_i through 0, 1, p_i - 1 and the values around the split point and the top of its high half, in all
+    combinations across the sources, and require ModDownQPtoQNTT's words (ring/basis_extension.go:235-256)."""
+    import itertools
+    q, p = O.GenModuli(logN + 1, logq, logp)
+    pr = Pair(ctx, logN, len(q), len(p), qmods=q, pmods=p)
+    obe = O.BasisExtender(pr.oQ, pr.oP)
+    gev = la.Evaluator(pr.gQ, pr.gP)
+    rng = rng_for(3300 + logN)
+    levelQ, levelP = len(q) - 1, len(p) - 1
+    P = prod(p)
+    half = P >> 1
+    xp = uniform_poly(rng, p, pr.N)  # coefficient domain
+    cands = [[0, 1, m - 1, (1 << 29) - 1, 1 << 29, m - (1 << 29), ((m >> 29) << 29) - 1] for m in p]
+    for col, ys in enumerate(itertools.islice(itertools.product(*cands), pr.N)):
+        for i, (m, y) in enumerate(zip(p, ys)):
+            xp[i, col] = (y * (P // m) - half) % m
+    xpn = pr.oP.NTT(xp)
+    xq = uniform_poly(rng, q, pr.N)
+    want = obe.ModDownQPtoQNTT(levelQ, levelP, xq, xpn)
+    batch = 8  # wide enough for the fused three-launch pipeline (he_eval_moddown_qp_to_q_ntt)
+    pq = la.Poly(pr.gQ, levelQ + 1, batch).upload(np.stack([xq] * batch))
+    pp = la.Poly(pr.gP, levelP + 1, batch).upload(np.stack([xpn] * batch))
+    out = la.Poly(pr.gQ, levelQ + 1, batch, zero=False)
+    gev.ModDownQPtoQNTT(levelQ, levelP, pq, pp, out)
+    got = out.download()
+    for b in range(batch):
+        assert np.array_equal(got[b], want), b
