@@ -65,6 +65,41 @@ func NewContext(device int) (*Context, error) {
 // Sync waits for everything enqueued on the context.
 func (c *Context) Sync() error { return lockedCall(func() C.int { return C.he_ctx_sync(c.h) }) }
 
+// Graph is a captured sequence of calls on a Context (he_graph_*, include/hering.h): one enqueue replays them all.
+type Graph struct {
+	ctx *Context
+	h   Handle
+}
+
+// Capture records the device work f enqueues on c instead of executing it.  f must have run once before (plans and scratch are
+// built on first use) and must not upload, download or Sync.  The replay reads and writes the same device polynomials.
+func (c *Context) Capture(f func() error) (*Graph, error) {
+	if err := lockedCall(func() C.int { return C.he_graph_begin(c.h) }); err != nil {
+		return nil, err
+	}
+	ferr := f()
+	g := &Graph{ctx: c}
+	err := lockedCall(func() C.int { return C.he_graph_end(c.h, &g.h) })
+	if ferr != nil {
+		if err == nil {
+			C.he_graph_destroy(g.h)
+		}
+		return nil, ferr
+	}
+	if err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(g, func(g *Graph) { C.he_graph_destroy(g.h) })
+	return g, nil
+}
+
+// Launch enqueues the captured sequence on the context's stream.
+func (g *Graph) Launch() error {
+	err := lockedCall(func() C.int { return C.he_graph_launch(g.h) })
+	runtime.KeepAlive(g)
+	return err
+}
+
 // Version of the loaded library.
 func Version() string { return C.GoString(C.he_version()) }
 

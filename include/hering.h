@@ -60,6 +60,20 @@ int he_timer_stop(he_handle ctx, float *elapsed_ms);
 /* device facts for reports: out[0]=CU count, out[1]=LDS bytes/CU, out[2]=clock kHz, out[3]=total HBM bytes */
 int he_device_info(he_handle ctx, uint64_t out[4]);
 
+/* ---- replayable launch sequences (hipGraph).  No counterpart in the reference (a Go loop has no launch queue to shorten):
+ * between he_graph_begin and he_graph_end the calls made on `ctx` are recorded instead of executed, with the handles they were
+ * given; he_graph_launch replays the whole sequence as ONE enqueue on the context's stream -- for latency-bound chains of small
+ * calls (a single-ciphertext MulRelin is eleven launches, a bootstrap several thousand).  Contract:
+ *  - run the sequence once before capturing it (plans, index tables and the scratch arena are built on first use);
+ *  - captured calls must be device work only: he_poly_upload / he_poly_download / he_ctx_sync fail while capturing;
+ *  - the replay reads and writes the SAME polynomials; temporaries released during the capture stay reserved for the graph
+ *    until he_graph_destroy; scalars passed by value are frozen at their captured values. */
+int he_graph_begin(he_handle ctx);
+int he_graph_end(he_handle ctx, he_handle *graph);
+int he_graph_launch(he_handle graph);
+int he_graph_nodes(he_handle graph, int *nodes);  /* kernel / memset / copy nodes recorded */
+int he_graph_destroy(he_handle graph);
+
 /* ---- ring: ring.NewRing (ring/ring.go:207), SubRing tables (ring/subring.go:99-159),
  *      RescaleConstants (ring/ring.go:329).  Standard (negacyclic) type, NthRoot = 2N. */
 int he_ring_create(he_handle ctx, int logN, const uint64_t *moduli, int n_moduli, he_handle *ring);

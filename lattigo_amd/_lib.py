@@ -121,6 +121,8 @@ def _declare(L):
         "he_prof_begin": [H], "he_prof_end": [H, i, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(i)],
         "he_prof_end_bytes": [H, i, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i)],
         "he_alg_bytes": [H, i, C.POINTER(C.c_double)],
+        "he_graph_begin": [H], "he_graph_end": [H, HP], "he_graph_launch": [H], "he_graph_nodes": [H, C.POINTER(i)],
+        "he_graph_destroy": [H],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

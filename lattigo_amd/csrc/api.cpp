@@ -51,7 +51,7 @@ int fail(int code, const char *fmt, ...) {
         if (_r != HE_OK) return _r; \
     } while (0)
 
-enum ObjType { T_CTX = 1, T_RING, T_POLY, T_INDEX, T_BE, T_EVAL, T_EVK, T_DECOMP };
+enum ObjType { T_CTX = 1, T_RING, T_POLY, T_INDEX, T_BE, T_EVAL, T_EVK, T_DECOMP, T_GRAPH };
 
 struct Obj {
     ObjType type;
@@ -81,6 +81,10 @@ struct Ctx : Obj {
     // handed out again without waiting for the kernels that last touched it.
     std::multimap<size_t, void *> pool;
     std::mutex pool_mu;  // own lock: the pool is used while an API call already holds `mu`
+    // he_graph_begin .. he_graph_end: the stream is capturing.  Buffers released meanwhile are parked here instead of going back
+    // to the pool -- the captured launches address them, so they belong to the graph until it is destroyed.
+    bool capturing = false;
+    std::vector<std::pair<size_t, void *>> capture_hold;
     size_t pool_bytes = 0;
     static constexpr size_t kPoolCap = (size_t)48 << 30;
     hipError_t pool_take(size_t bytes, void **out) {
@@ -105,6 +109,7 @@ struct Ctx : Obj {
     void pool_give(size_t bytes, void *p) {
         {
             std::lock_guard<std::mutex> lk(pool_mu);
+            if (capturing) { capture_hold.emplace_back(bytes, p); return; }
             if (pool_bytes + bytes <= kPoolCap) {
                 pool.emplace(bytes, p);
                 pool_bytes += bytes;
@@ -135,6 +140,8 @@ struct Ctx : Obj {
     // reserve the total a call needs up front (growing invalidates earlier pointers)
     int arena_reserve(size_t words) {
         if (words <= arena_words) return HE_OK;
+        if (capturing)
+            return fail(HE_EINVAL, "graph capture: the scratch arena would have to grow (run the sequence once before capturing it)");
         HIP_TRY(hipStreamSynchronize(stream));
         if (arena) HIP_TRY(hipFree(arena));
         arena = nullptr;
@@ -174,6 +181,24 @@ struct Ring : Obj {
         if (d_twdi) hipFree(d_twdi);
     }
     int nmod() const { return (int)moduli.size(); }
+};
+
+// a captured launch sequence (he_graph_*): the instantiated hipGraph plus the buffers its nodes address that were released
+// while it was being captured
+struct Graph : Obj {
+    std::shared_ptr<Ctx> ctx;
+    hipGraphExec_t exec = nullptr;
+    int nodes = 0;
+    std::vector<std::pair<size_t, void *>> hold;
+    Graph() : Obj(T_GRAPH) {}
+    ~Graph() override {
+        hipSetDevice(ctx->dev);
+        if (exec) {
+            hipStreamSynchronize(ctx->stream);  // a replay may still be in flight
+            hipGraphExecDestroy(exec);
+        }
+        for (auto &b : hold) ctx->pool_give(b.first, b.second);
+    }
 };
 
 struct Poly : Obj {
@@ -505,6 +530,7 @@ int he_ctx_create(int device_id, he_handle *out) {
 int he_ctx_destroy(he_handle h) { return unreg(h, T_CTX); }
 int he_ctx_sync(he_handle h) {
     GET(c, Ctx, h, T_CTX);
+    if (c->capturing) return fail(HE_EINVAL, "he_ctx_sync: the context is capturing a graph (he_graph_end first)");
     HIP_TRY(hipSetDevice(c->dev));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return HE_OK;
@@ -638,6 +664,7 @@ int he_poly_upload(he_handle h, const uint64_t *src, size_t n_words) {
     GET(p, Poly, h, T_POLY);
     const size_t total = (size_t)p->batch * p->nlimbs * p->N;
     if (!src || n_words != total) return fail(HE_EINVAL, "he_poly_upload: expected %zu words, got %zu", total, n_words);
+    if (p->ctx->capturing) return fail(HE_EINVAL, "he_poly_upload: host transfers cannot be captured in a graph");
     Scope sc(p->ctx.get());
     HIP_TRY(hipMemcpyAsync(p->d, src, total * 8, hipMemcpyHostToDevice, p->ctx->stream));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
@@ -647,6 +674,7 @@ int he_poly_download(he_handle h, uint64_t *dst, size_t n_words) {
     GET(p, Poly, h, T_POLY);
     const size_t total = (size_t)p->batch * p->nlimbs * p->N;
     if (!dst || n_words != total) return fail(HE_EINVAL, "he_poly_download: expected %zu words, got %zu", total, n_words);
+    if (p->ctx->capturing) return fail(HE_EINVAL, "he_poly_download: host transfers cannot be captured in a graph");
     Scope sc(p->ctx.get());
     HIP_TRY(hipMemcpyAsync(dst, p->d, total * 8, hipMemcpyDeviceToHost, p->ctx->stream));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
@@ -655,6 +683,7 @@ int he_poly_download(he_handle h, uint64_t *dst, size_t n_words) {
 int he_poly_upload_limb(he_handle h, int b, int limb, const uint64_t *src) {
     GET(p, Poly, h, T_POLY);
     if (!src || b < 0 || b >= p->batch || limb < 0 || limb >= p->nlimbs) return fail(HE_EINVAL, "he_poly_upload_limb: bad index");
+    if (p->ctx->capturing) return fail(HE_EINVAL, "he_poly_upload_limb: host transfers cannot be captured in a graph");
     Scope sc(p->ctx.get());
     HIP_TRY(hipMemcpyAsync(p->d + ((size_t)b * p->nlimbs + limb) * p->N, src, (size_t)p->N * 8, hipMemcpyHostToDevice, p->ctx->stream));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
@@ -663,6 +692,7 @@ int he_poly_upload_limb(he_handle h, int b, int limb, const uint64_t *src) {
 int he_poly_download_limb(he_handle h, int b, int limb, uint64_t *dst) {
     GET(p, Poly, h, T_POLY);
     if (!dst || b < 0 || b >= p->batch || limb < 0 || limb >= p->nlimbs) return fail(HE_EINVAL, "he_poly_download_limb: bad index");
+    if (p->ctx->capturing) return fail(HE_EINVAL, "he_poly_download_limb: host transfers cannot be captured in a graph");
     Scope sc(p->ctx.get());
     HIP_TRY(hipMemcpyAsync(dst, p->d + ((size_t)b * p->nlimbs + limb) * p->N, (size_t)p->N * 8, hipMemcpyDeviceToHost, p->ctx->stream));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
@@ -2669,10 +2699,67 @@ int he_bgv_mul_relin(he_handle ev, int level, uint64_t t, he_handle a0, he_handl
 }
 
 // ---------------------------------------------------------------------------------------
+// replayable launch sequences (hipGraph)
+// ---------------------------------------------------------------------------------------
+int he_graph_begin(he_handle hctx) {
+    GET(c, Ctx, hctx, T_CTX);
+    Scope sc(c.get());
+    if (c->capturing) return fail(HE_EINVAL, "he_graph_begin: the context is already capturing");
+    if (prof_active(c->stream)) return fail(HE_EINVAL, "he_graph_begin: kernel profiling is active on this context (he_prof_end first)");
+    // relaxed: calls that are not stream work (a pool miss falling through to hipMalloc) stay legal on this thread
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    c->capturing = true;
+    return HE_OK;
+}
+int he_graph_end(he_handle hctx, he_handle *out) {
+    GET(c, Ctx, hctx, T_CTX);
+    if (!out) return fail(HE_EINVAL, "he_graph_end: null output");
+    Scope sc(c.get());
+    if (!c->capturing) return fail(HE_EINVAL, "he_graph_end: the context is not capturing");
+    auto g = std::make_shared<Graph>();
+    g->ctx = c;
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        c->capturing = false;
+        g->hold.swap(c->capture_hold);  // released with the graph, also when the capture failed
+    }
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (e != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        return fail(HE_EDEVICE, "he_graph_end: the capture was invalidated (%s): a captured call synchronised, allocated or copied "
+                    "from the host", hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+    size_t nodes = 0;
+    (void)hipGraphGetNodes(graph, nullptr, &nodes);
+    g->nodes = (int)nodes;
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(HE_EDEVICE, "he_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+    *out = reg(g);
+    return HE_OK;
+}
+int he_graph_launch(he_handle h) {
+    GET(g, Graph, h, T_GRAPH);
+    Scope sc(g->ctx.get());
+    if (g->ctx->capturing) return fail(HE_EINVAL, "he_graph_launch: the context is capturing");
+    HIP_TRY(hipGraphLaunch(g->exec, g->ctx->stream));
+    return HE_OK;
+}
+int he_graph_nodes(he_handle h, int *nodes) {
+    GET(g, Graph, h, T_GRAPH);
+    if (nodes) *nodes = g->nodes;
+    return HE_OK;
+}
+int he_graph_destroy(he_handle h) { return unreg(h, T_GRAPH); }
+
+// ---------------------------------------------------------------------------------------
 // diagnostics
 // ---------------------------------------------------------------------------------------
 int he_prof_begin(he_handle hctx) {
     GET(c, Ctx, hctx, T_CTX);
+    if (c->capturing) return fail(HE_EINVAL, "he_prof_begin: the context is capturing a graph");
     Scope sc(c.get());
     HIP_TRY(hipStreamSynchronize(c->stream));
     prof_begin(c->stream);

@@ -296,6 +296,7 @@ enum KernelId {
 };
 const char *kernel_name(int id);
 void prof_begin(hipStream_t s);                                // start recording the launches enqueued on stream s
+bool prof_active(hipStream_t s);                               // is stream s being recorded?
 int prof_end(hipStream_t s, int *counts, float *total_ms, double *total_bytes = nullptr);  // stop, sync events, fill [K_COUNT] arrays
 
 // throughput probe used by bench.py --microbench (not on the product path)

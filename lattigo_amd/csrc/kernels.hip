@@ -74,6 +74,11 @@ const char *kernel_name(int id) {
                                          "ntt_rows_inv_f64", "ntt_mac_f64", "diag_mac"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
+bool prof_active(hipStream_t s) {
+    if (g_prof_active.load(std::memory_order_relaxed) == 0) return false;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return g_prof.find(s) != g_prof.end();
+}
 void prof_begin(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     auto ins = g_prof.emplace(s, ProfState{});

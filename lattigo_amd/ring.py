@@ -45,6 +45,45 @@ def _words(x: int) -> np.ndarray:
     return np.array(w, dtype=np.uint64)
 
 
+class Graph:
+    """A captured sequence of calls (he_graph_*).  Objects created inside the `with` block keep their buffers for the life of
+    the graph: hold on to the ones whose results you want to read after a replay."""
+
+    def __init__(self, ctx):
+        self.ctx, self.h = ctx, None
+
+    def __enter__(self):
+        check(load().he_graph_begin(self.ctx.h))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = H()
+        rc = load().he_graph_end(self.ctx.h, C.byref(h))
+        if et is None:
+            check(rc)
+            self.h = h.value
+        return False
+
+    def launch(self):
+        check(load().he_graph_launch(self.h))
+
+    def nodes(self) -> int:
+        n = C.c_int()
+        check(load().he_graph_nodes(self.h, C.byref(n)))
+        return int(n.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().he_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One HIP device + stream (one per process/GPU)."""
 
@@ -67,6 +106,11 @@ class Context:
 
     def sync(self):
         check(load().he_ctx_sync(self.h))
+
+    def capture(self):
+        """`with ctx.capture() as g: <calls>` records the calls made on this context into a replayable hipGraph
+        (he_graph_begin / he_graph_end, include/hering.h); `g.launch()` enqueues the whole sequence at once."""
+        return Graph(self)
 
     def timer_start(self):
         check(load().he_timer_start(self.h))

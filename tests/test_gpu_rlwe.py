@@ -900,3 +900,67 @@ def test_moddown_split_residues_at_their_extremes(ctx, logN, logq, logp):
     got = out.download()
     for b in range(batch):
         assert np.array_equal(got[b], want), b
+
+
+def test_captured_graph_replays_a_call_sequence(ctx):
+    """he_graph_begin / he_graph_end / he_graph_launch (include/hering.h): a MulRelin -> Rescale -> Automorphism chain, with a
+    temporary created inside the sequence, is recorded once and replayed on NEW input data uploaded into the same polynomials;
+    every replay must give the oracle's bits.  Host transfers and sync are refused while capturing."""
+    pr, rng, oev, gev, sk = _setup(ctx, 12, 5, 2, 3400)
+    sk_sq = pr.oQ.binop("MulCoeffsMontgomery", sk.Q, sk.Q)
+    orlk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk_sq, sk)
+    grlk = gev.NewEvaluationKey(orlk.q, orlk.p)
+    galel = 5
+    sk_out = automorphism_secret(rng, pr.oQ, pr.oP, sk, pow(galel, 2 * pr.N - 1, 2 * pr.N))
+    ogk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, sk_out)
+    ggk = gev.NewEvaluationKey(ogk.q, ogk.p)
+    level = 4
+    a = [pr.gQ.NewPoly() for _ in range(2)]
+    b = [pr.gQ.NewPoly() for _ in range(2)]
+    res = [la.Poly(pr.gQ, level) for _ in range(2)]
+    rot = [la.Poly(pr.gQ, level) for _ in range(2)]
+
+    def chain():
+        tmp = [pr.gQ.NewPoly() for _ in range(2)]  # lives only inside the call sequence
+        gev.CKKSMulRelin(level, a, b, grlk, tmp)
+        gev.Rescale(level, 1, tmp, res)
+        gev.Automorphism(level - 1, res, galel, ggk, rot)
+
+    def fill():
+        ct0 = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(2)])
+        ct1 = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(2)])
+        for k in range(2):
+            a[k].upload(ct0[k])
+            b[k].upload(ct1[k])
+        want_res = oev.Rescale(oev.CKKSMulRelin(ct0, ct1, orlk, True), 1)
+        return want_res, oev.Automorphism(want_res, galel, ogk)
+
+    def outputs():
+        return np.stack([r.get() for r in res]), np.stack([r.get() for r in rot])
+
+    def clear():
+        for r in res + rot:
+            r.upload(np.zeros((level, pr.N), dtype=np.uint64))
+
+    want = fill()
+    chain()  # first run: builds plans, index tables, scratch
+    got = outputs()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    with ctx.capture() as g:
+        chain()
+        with pytest.raises(la.HeringError):
+            a[0].get()
+        with pytest.raises(la.HeringError):
+            ctx.sync()
+    assert g.nodes() >= 10
+    for _ in range(3):  # the first replay on the captured data, then new data through the same handles
+        clear()
+        g.launch()
+        got = outputs()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        want = fill()
+    g.close()
+    # the buffers the graph held are back in the pool; eager calls go on working
+    chain()
+    got = outputs()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
