@@ -16,6 +16,9 @@ shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, f"{tag}_bench.j
 shutil.copy(os.path.join(G, "bench_configs.jsonl"), os.path.join(P, f"{tag}_bench_other_configs.jsonl"))
 stats = [f for f in os.listdir(os.path.join(G, "prof_final")) if f.endswith("kernel_stats.csv")]
 shutil.copy(os.path.join(G, "prof_final", stats[0]), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
+for probe in ("instr_probe", "hbm_probe"):
+    if os.path.exists(os.path.join(G, probe + ".txt")):
+        shutil.copy(os.path.join(G, probe + ".txt"), os.path.join(P, f"{tag}_{probe}.txt"))
 # PMC traffic per workload (tools/round_artifacts.sh: bench.py --steps S --warmup 1 --no-kernel-timing)
 for w, steps in (("c3", 5), ("c4", 5), ("c5", 2)):
     f = os.path.join(G, f"pmc_FETCH_SIZE_{w}", "bench_counter_collection.csv")

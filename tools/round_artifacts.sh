@@ -17,3 +17,5 @@ rm -f gpurun_out/bench_configs.jsonl gpurun_out/bench_configs.err
 for w in c2 c4 c5; do timeout 600 python bench.py --workload $w --steps 10 --no-ntt >> gpurun_out/bench_configs.jsonl 2>> gpurun_out/bench_configs.err; done
 timeout 300 python tools/bench_configs.py >> gpurun_out/bench_configs.jsonl 2>> gpurun_out/bench_configs.err
 timeout 200 python tools/ntt_prof.py >> gpurun_out/bench_configs.jsonl 2>> gpurun_out/bench_configs.err
+# machine probes behind DESIGN.md's ceilings: instruction issue rates and what HBM gives a streaming kernel by read : write mix
+for p in instr_probe hbm_probe; do hipcc --offload-arch=gfx950 -O3 $R/tools/$p.hip -o /tmp/$p 2>/dev/null && /tmp/$p > $R/gpurun_out/$p.txt 2>&1; done
