@@ -345,11 +345,40 @@ def setup_c4(la, ctx, rank, B, cp, args):
     }
 
 
+def c5_cpu_baseline(la, ctx, shape, trace_bytes_per_bootstrap):
+    """Bounded CPU sample for the bootstrap trace: the trace is a few thousand ring / key-switch calls, four fifths of its
+    algorithmic bytes key switches; a whole bootstrap on the scalar oracle takes about a minute per core (tests/golden/
+    gen_c5_digest.py).  The sample is its dominant primitive at its top level -- Rotate at logN = 16, 25 + 5 limbs -- timed like
+    the c4 baseline, and converted to bootstraps/s through SURVEY 8(d) bytes: rate x (bytes of one Rotate, as the library
+    accounts it) / (bytes of one bootstrap trace, same accounting)."""
+    N, q, p = shape["N"], shape["q"], shape["p"]
+    ev, rq = shape["ev"], shape["rq"]
+    ct = [la.Poly(rq, len(q)), la.Poly(rq, len(q))]
+    out = [la.Poly(rq, len(q)), la.Poly(rq, len(q))]
+    ctx.alg_bytes(reset=True)
+    ev.Automorphism(len(q) - 1, ct, shape["gal"], shape["key"], out)
+    ctx.sync()
+    rot_bytes = ctx.alg_bytes(reset=True)[0]
+    r = cpu_baseline("rotate", N, q, p, shape["kq"], shape["kp"], "ctxt-rotate ops/s", "CKKS Rotate (logN=16, 25+5 limbs)",
+                     gal=shape["gal"])
+    scale = rot_bytes / trace_bytes_per_bootstrap
+    r["sample"] += (f"; one Rotate = {rot_bytes / 2**20:.0f} MiB of the {trace_bytes_per_bootstrap / 2**30:.1f} GiB one bootstrap trace "
+                    "moves (SURVEY 8(d) accounting by the library): rates scaled by that ratio")
+    r["rotate_ops_s"] = r["value"]
+    r["value"] *= scale
+    r["unit"] = "ctxt-bootstraps/s"
+    r["single_thread_ops_s"] *= scale
+    r["threads_sweep_ops_s"] = {k: v * scale for k, v in r["threads_sweep_ops_s"].items()}
+    r["note"] += "; an extrapolation from the trace's dominant primitive, not a timed bootstrap"
+    return r
+
+
 def setup_c5(la, ctx, rank, B, cp, args):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bootstrap_c5_shape as C5
     run, info = C5.build(ctx, B, seed_offset=1000 * rank)
     return {
+        "cpu_c5": lambda trace_bytes: c5_cpu_baseline(la, ctx, run._shape, trace_bytes),
         "metric": "bootstraps/s", "unit": "ctxt-bootstraps/s", "step": run, "units": B, "verify": None, "kernel_bytes": None,
         # no closed form: summed over the operation trace by the library (he_alg_bytes), see main()
         "alg_bytes_per_op": None, "alg_bytes_per_op_amortised": None, "cpu": None,
@@ -582,6 +611,11 @@ def main():
         line["ntt_limb_per_s"] = line["ntt"]["logN15_L12"]["limb_ntt_per_s"]
     if args.microbench:
         line["modmul_per_s"] = ctx.probe_modmul(256)
+    if not args.no_cpu_baseline and world == 1 and W.get("cpu_c5") is not None:
+        try:
+            line["cpu_baseline"] = W["cpu_c5"](per_op_trace)
+        except Exception as e:
+            line["cpu_baseline"] = {"error": str(e)}
     if not args.no_cpu_baseline and world == 1 and W["cpu"] is not None:
         try:
             line["cpu_baseline"] = W["cpu"]()

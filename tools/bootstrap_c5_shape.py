@@ -98,6 +98,7 @@ def build(ctx, B, seed_offset=0):
 
     info = {"logN": logN, "L": len(q), "alpha": LP, "galois_keys": len(gks.keys), "dft_diagonals": ndiag}
     run._parts = (boot, be, ct0, gks, ndiag)  # for main()'s phase report
+    run._shape = {"N": N, "q": q, "p": p, "kq": kq, "kp": kp, "ev": ev, "rq": rq, "key": rlk, "gal": R.GaloisElement(nth, 1)}  # bench.py's CPU leg
     return run, info
 
 
