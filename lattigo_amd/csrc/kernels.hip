@@ -2255,6 +2255,9 @@ struct ModUpFusedArgs {
     const double *twd_fwd, *twd_inv;
     const uint64_t *tws_fwd;
     int N;
+    int nchunk;   // small grids: the destinations of a digit are shared out over nchunk workgroups (blockIdx.y = digit * nchunk + chunk),
+                  // each redoing the source stage -- a launch of a few hundred workgroups is the latency of ONE wave walking all
+                  // its destinations, and the chip is idle anyway
     int f64_raw;  // double-precision destinations are stored as the doubles they are (|x| < 64 p, unreduced): the consumer is a
                   // double-precision row kernel told so (NttMacArgs::dec_f64 / NTT_INPUT_F64), six instructions per word saved here
 };
@@ -2281,7 +2284,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     // every use (the compiler cannot move them across the destination stores), 24 of them per destination limb
     __shared__ ModUpDesc Ds;
     {
-        const uint32_t *g = reinterpret_cast<const uint32_t *>(A.desc + blockIdx.y);
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(A.desc + (A.nchunk > 1 ? blockIdx.y / (unsigned)A.nchunk : blockIdx.y));
         uint32_t *l = reinterpret_cast<uint32_t *>(&Ds);
         for (int w = threadIdx.x; w < (int)(sizeof(ModUpDesc) / 4); w += blockDim.x) l[w] = g[w];
     }
@@ -2462,7 +2465,13 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
         vd[r] = floor(vi[r]);
     }
 
-    for (int j = 0; j < ndst; j++) {
+    int jlo = 0, jhi = ndst;
+    if (A.nchunk > 1) {
+        const int per = (ndst + A.nchunk - 1) / A.nchunk, ch = (int)(blockIdx.y % (unsigned)A.nchunk);
+        jlo = ch * per;
+        jhi = min(ndst, jlo + per);
+    }
+    for (int j = jlo; j < jhi; j++) {
         if constexpr (KREG > 0) {
             // the register-resident residues are made opaque per destination: otherwise their conversions (to double, to 26- and
             // 30-bit halves) are hoisted out of this loop and kept live -- 80 registers instead of 16
@@ -2837,7 +2846,13 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
     A.tws_fwd = r.tws_fwd;
     const bool use_f64 = ((dst_classes & 2) && r.twd_fwd != nullptr) || !modup_int_light(nsrc, a);
     const int n2 = r.N >> a;
-    dim3 grid((unsigned)((n2 + 127) / 128), ndesc, batch), block(128);
+    // fewer than four workgroups per CU: split the destinations (up to four ways) instead of leaving the chip idle
+    static const int force_chunk = getenv("HERING_MODUP_NCHUNK") ? atoi(getenv("HERING_MODUP_NCHUNK")) : 0;
+    const long wgs = (long)((n2 + 127) / 128) * ndesc * batch;
+    int nchunk = force_chunk > 0 ? force_chunk : (wgs >= 1024 ? 1 : (int)std::min<long>(4, 1024 / std::max<long>(wgs, 1)));
+    if (nchunk < 1) nchunk = 1;
+    A.nchunk = nchunk;
+    dim3 grid((unsigned)((n2 + 127) / 128), ndesc * nchunk, batch), block(128);
     ProfScope ps(K_MODUP, s, (double)total_limbs * batch * (double)r.N * 8.0);
     if (use_f64) launch_modup_fused_variant<true>(a, nsrc, grid, block, A, s);   // mixed: f64 for small destinations
     else launch_modup_fused_variant<false>(a, nsrc, grid, block, A, s);
