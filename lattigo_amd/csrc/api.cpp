@@ -1644,10 +1644,10 @@ void mark_fast_destinations(const BasisExtender &be, ModUpDesc &D, const std::ve
         const uint64_t p = be.modulus(D.dst_mod[j]);
         const bool f64_dst = (p >> 47) == 0 && be.d_twdf != nullptr;
         const u128 colsum = (u128)(D.nsrc + 1) * ((u128)p + mx + ((u128)1 << 31));
-        // radix-2^30 reduction of the lean sum (HE_MODUP_R60): the middle column takes (nsrc + 1) (x1 t0 + x0 t1) + m p1 + a carry,
+        // radix-2^30 reduction of the lean sum (HE_MODUP_R60): the middle column takes (nsrc + 1) (x1 t0 + x0 t1) + m0 p1 + a carry + m1 p0,
         // and the result (sum + m p) / 2^60 stays below 2p only while (nsrc + 1) max q <= 2^60
         const u128 midcol = (u128)(D.nsrc + 1) * ((((u128)(mx >> 30) + 1) << 30) + (((u128)(p >> 30) + 1) << 30)) +
-                            (((u128)(p >> 30) + 1) << 30) + ((u128)1 << 35);
+                            (((u128)(p >> 30) + 1) << 30) + ((u128)1 << 35) + ((u128)1 << 60);  // ... + m0 p1 + carry + m1 p0
         const bool r60 = (midcol >> 64) == 0 && (u128)(D.nsrc + 1) * mx <= ((u128)1 << 60) && D.nsrc + 2 <= 15;
         // 1: 30-bit column accumulation + correction-free butterflies (below 2^58); 2: 128-bit accumulation + Harvey-range
         // butterflies (any modulus); 0: the generic path (single-limb digits, sums that need the extra reduction)
