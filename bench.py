@@ -160,6 +160,26 @@ def cpu_baseline(kind, N, q, p, kq, kp, unit, what, seconds=12.0, t=0, gal=0):
             "note": "scalar C restatement of the reference (oracle/), one pinned thread per CPU with private copies of inputs and key; not the Go code"}
 
 
+def replicate_key(cp, ev, key, rank, args):
+    """N > 1: rank 0's key on every rank (one-time setup, before the timed region).  A transport that fails on any rank is
+    given up by ALL ranks together (the outcome is agreed over the gloo control plane): rccl -> host -> each rank keeps the
+    key it drew itself, so that a broken transport costs the replication, not the measurement.  -> (key, replicated?)"""
+    if cp.world == 1 or args.replicate_keys.startswith("none"):
+        return key, False
+    for transport in ([args.replicate_keys, "host"] if args.replicate_keys == "rccl" else [args.replicate_keys]):
+        ok, out = 1.0, None
+        try:
+            out = cp.ReplicateEvaluationKey(ev, key if rank == 0 else None, src=0, transport=transport)
+        except Exception as e:  # noqa: BLE001 -- any failure of the transport
+            sys.stderr.write(f"[rank {rank}] key replication over {transport} failed: {e}\n")
+            ok = 0.0
+        if cp.sum_over_ranks(ok) == cp.world:
+            args.replicate_keys = transport
+            return out, True
+    args.replicate_keys = "none (transports failed)"
+    return key, False
+
+
 # -------------------------------------------------------------------------------------------------------------------
 # workloads: each returns step(), the units one step processes, a verifier of the last step's output and report fields
 # -------------------------------------------------------------------------------------------------------------------
@@ -177,8 +197,8 @@ def setup_c3(la, ctx, rank, B, cp, args):
     rng = np.random.Generator(np.random.PCG64(0x1A77160 + 2 + 1000 * rank))
     kq, kp = uniform(rng, q, N, (beta, 2)), uniform(rng, p, N, (beta, 2))
     rlk = ev.NewEvaluationKey(kq, kp)
-    if cp.world > 1 and args.replicate_keys != "none":
-        rlk = cp.ReplicateEvaluationKey(ev, rlk if rank == 0 else None, src=0, transport=args.replicate_keys)
+    rlk, replicated = replicate_key(cp, ev, rlk, rank, args)
+    if replicated:
         kw = rlk.download()
         kq, kp = kw[:, :, :L], kw[:, :, L:]
     keep = pick_entries(B)
@@ -305,8 +325,7 @@ def setup_c4(la, ctx, rank, B, cp, args):
     krng = np.random.Generator(np.random.PCG64(0x1A77160 + 3))
     kq, kp = uniform(krng, q, N, (beta, 2)), uniform(krng, p, N, (beta, 2))
     gk = ev.NewEvaluationKey(kq, kp)
-    if cp.world > 1 and args.replicate_keys != "none":
-        gk = cp.ReplicateEvaluationKey(ev, gk if rank == 0 else None, src=0, transport=args.replicate_keys)
+    gk, _ = replicate_key(cp, ev, gk, rank, args)
     rng = np.random.Generator(np.random.PCG64(0x1A77160 + 3 + 1000 * (rank + 1)))
     keep = pick_entries(B)
     ct, host_in = [], []
@@ -480,7 +499,7 @@ def main():
     elapsed_min = -cp.max_over_ranks(-elapsed_rank)
     alg_trace = ctx.alg_bytes(reset=True)  # SURVEY 8(d) per-primitive bytes of the timed steps (key per entry, key per call)
     # what the control plane and (when keys were replicated over RCCL) the RCCL communicator saw
-    ranks_seen = {"control_plane_gloo": int(cp.sum_over_ranks(1.0)), "rccl": cp.rccl_world() if hasattr(cp, "rccl_world") else None}
+    ranks_seen = {"control_plane_gloo": int(cp.sum_over_ranks(1.0)), "rccl": cp.rccl_world() if args.replicate_keys == "rccl" else None}
 
     # ---- parity of what was timed: the output of the last timed step against the oracle, on every rank ------------
     verified, vmsg = None, "skipped"
