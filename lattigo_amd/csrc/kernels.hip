@@ -871,20 +871,58 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
                 // words below 2q, which convert as they are -- the Barrett reduction (a dozen integer instructions per word, up to
                 // 64 words per thread) runs only for a wave that actually met a larger word
                 const uint64_t twoq_u = mc.q << 1;
-                auto cvt8 = [&](uint64_t (&w)[8], double (&d)[8]) {
-                    bool big = false;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) big = big || w[k] >= twoq_u;
 #ifndef HE_EPI_ALWAYS_REDUCE
 #define HE_EPI_ALWAYS_REDUCE 0  // 1: the unconditional reduction of round 2 (A/B builds)
 #endif
+#ifndef HE_EPI_SHARED_FIRST
+#define HE_EPI_SHARED_FIRST 1  // 0: round 2's order (component 1 reads a0, b1 then a1, b0)
+#endif
+                auto cvtn = [&](auto &w, auto &d) {
+                    constexpr int n = (int)(sizeof(w) / sizeof(w[0]));
+                    bool big = false;
+#pragma unroll
+                    for (int k = 0; k < n; k++) big = big || w[k] >= twoq_u;
                     if (HE_EPI_ALWAYS_REDUCE || __any(big)) {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) w[k] = bred_add_lazy(w[k], mc.q, mc.brc0);
+                        for (int k = 0; k < n; k++) w[k] = bred_add_lazy(w[k], mc.q, mc.brc0);
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; k++) d[k] = u52_to_f64(w[k]);
+                    for (int k = 0; k < n; k++) d[k] = u52_to_f64(w[k]);
                 };
+#if HE_EPI_SHARED_FIRST
+                // Both components of an entry read a0 and b0 -- in two workgroups that the launch order puts on one XCD, a few
+                // microseconds apart.  Component 1 used to read a0, b1 first and a1, b0 a phase later: by then the XCD's 4 MB L2
+                // (turned over every ~6 us at this kernel's rate) had dropped b0, and 73 % of those second reads went to HBM
+                // (PMC: 6.98 GB fetched per launch against 5.9 GB of distinct data).  Now both components issue the SAME a0 / b0
+                // loads at the same point of the program, four coefficients at a time, and component 1 adds its a1 / b1 loads to
+                // the same batch.
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    uint64_t r0[4], r1[4], r2[4], r3[4];
+                    double u[4], v[4], u2[4], v2[4], wv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const int e = nat_e<T>(4 * h + k, tau); r0[k] = pa0[e]; r1[k] = pb0[e]; }
+                    if (second) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const int e = nat_e<T>(4 * h + k, tau); r2[k] = pa1[e]; r3[k] = pb1[e]; }
+                    }
+                    cvtn(r0, u); cvtn(r1, v);
+                    if (second) {
+                        cvtn(r2, u2); cvtn(r3, v2);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) wv[k] = modmul_f64(u[k], v2[k], q, qi) + modmul_f64(u2[k], v[k], q, qi);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) wv[k] = modmul_f64(u[k], v[k], q, qi);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int e = nat_e<T>(4 * h + k, tau);
+                        const double t = modmul_f64(wv[k], tsp, q, qi) + modmul_f64(lds[lds_phys(e)] - yv[4 * h + k], sp, q, qi);
+                        stnt(&op[e], canon_f64(t, q, qi));
+                    }
+                }
+#else
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     double u[8], v[8], wv[8];
@@ -892,13 +930,13 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
                     const uint64_t *pv = second ? pb1 : pb0;
 #pragma unroll
                     for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); ur[k] = pa0[e]; vr[k] = pv[e]; }
-                    cvt8(ur, u); cvt8(vr, v);
+                    cvtn(ur, u); cvtn(vr, v);
 #pragma unroll
                     for (int k = 0; k < 8; k++) wv[k] = modmul_f64(u[k], v[k], q, qi);
                     if (second) {
 #pragma unroll
                         for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); ur[k] = pa1[e]; vr[k] = pb0[e]; }
-                        cvt8(ur, u); cvt8(vr, v);
+                        cvtn(ur, u); cvtn(vr, v);
 #pragma unroll
                         for (int k = 0; k < 8; k++) wv[k] += modmul_f64(u[k], v[k], q, qi);
                     }
@@ -909,6 +947,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
                         stnt(&op[e], canon_f64(t, q, qi));
                     }
                 }
+#endif
             } else if (addw) {
                 uint64_t wv[16];
 #pragma unroll
