@@ -66,8 +66,9 @@ int he_device_info(he_handle ctx, uint64_t out[4]);
  * calls (a single-ciphertext MulRelin is eleven launches, a bootstrap several thousand).  Contract:
  *  - run the sequence once before capturing it (plans, index tables and the scratch arena are built on first use);
  *  - captured calls must be device work only: he_poly_upload / he_poly_download / he_ctx_sync fail while capturing;
- *  - the replay reads and writes the SAME polynomials; temporaries released during the capture stay reserved for the graph
- *    until he_graph_destroy; scalars passed by value are frozen at their captured values. */
+ *  - the replay reads and writes the SAME polynomials: every handle passed to a captured call must outlive the graph (the
+ *    temporaries created AND released during the capture are kept for it until he_graph_destroy, and so is the context's
+ *    scratch arena); scalars passed by value are frozen at their captured values. */
 int he_graph_begin(he_handle ctx);
 int he_graph_end(he_handle ctx, he_handle *graph);
 int he_graph_launch(he_handle graph);

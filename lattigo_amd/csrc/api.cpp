@@ -85,6 +85,17 @@ struct Ctx : Obj {
     // to the pool -- the captured launches address them, so they belong to the graph until it is destroyed.
     bool capturing = false;
     std::vector<std::pair<size_t, void *>> capture_hold;
+    // captured launches address the scratch arena too: while a graph of this context is alive, an arena that has to grow is
+    // retired (kept until the last graph is destroyed) instead of freed
+    int live_graphs = 0;
+    std::vector<uint64_t *> retired_arenas;
+    void graph_released() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--live_graphs > 0) return;
+        hipStreamSynchronize(stream);
+        for (uint64_t *a : retired_arenas) hipFree(a);
+        retired_arenas.clear();
+    }
     size_t pool_bytes = 0;
     static constexpr size_t kPoolCap = (size_t)48 << 30;
     hipError_t pool_take(size_t bytes, void **out) {
@@ -143,7 +154,8 @@ struct Ctx : Obj {
         if (capturing)
             return fail(HE_EINVAL, "graph capture: the scratch arena would have to grow (run the sequence once before capturing it)");
         HIP_TRY(hipStreamSynchronize(stream));
-        if (arena) HIP_TRY(hipFree(arena));
+        if (arena && live_graphs > 0) retired_arenas.push_back(arena);
+        else if (arena) HIP_TRY(hipFree(arena));
         arena = nullptr;
         arena_words = 0;
         size_t want = words + words / 4;
@@ -198,7 +210,9 @@ struct Graph : Obj {
             hipGraphExecDestroy(exec);
         }
         for (auto &b : hold) ctx->pool_give(b.first, b.second);
+        if (counted) ctx->graph_released();
     }
+    bool counted = false;  // this graph is included in ctx->live_graphs
 };
 
 struct Poly : Obj {
@@ -2737,6 +2751,8 @@ int he_graph_end(he_handle hctx, he_handle *out) {
     g->nodes = (int)nodes;
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return fail(HE_EDEVICE, "he_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+    c->live_graphs++;  // (under the context lock held by `sc`; released by the graph's destructor, which runs outside any call)
+    g->counted = true;
     *out = reg(g);
     return HE_OK;
 }

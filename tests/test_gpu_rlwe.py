@@ -953,6 +953,10 @@ def test_captured_graph_replays_a_call_sequence(ctx):
         with pytest.raises(la.HeringError):
             ctx.sync()
     assert g.nodes() >= 10
+    # an eager call that needs a (much) larger scratch arena: the arena the graph's launches address must survive its growth
+    big = [[la.Poly(pr.gQ, len(pr.q), 16) for _ in range(2)] for _ in range(3)]
+    gev.CKKSMulRelin(level, big[0], big[1], grlk, big[2])
+    ctx.sync()
     for _ in range(3):  # the first replay on the captured data, then new data through the same handles
         clear()
         g.launch()
