@@ -20,7 +20,7 @@ for probe in ("instr_probe", "hbm_probe"):
     if os.path.exists(os.path.join(G, probe + ".txt")):
         shutil.copy(os.path.join(G, probe + ".txt"), os.path.join(P, f"{tag}_{probe}.txt"))
 # PMC traffic per workload (tools/round_artifacts.sh: bench.py --steps S --warmup 1 --no-kernel-timing)
-for w, steps in (("c3", 5), ("c4", 5), ("c5", 2)):
+for w, steps in (("c2", 5), ("c3", 5), ("c4", 5), ("c5", 2)):
     f = os.path.join(G, f"pmc_FETCH_SIZE_{w}", "bench_counter_collection.csv")
     wr = os.path.join(G, f"pmc_WRITE_SIZE_{w}", "bench_counter_collection.csv")
     if not (os.path.exists(f) and os.path.exists(wr)):

@@ -1,11 +1,11 @@
 # Round artefacts on the GPU box (gpurun_out/ is merged back; tools/collect_profiles.py copies the summaries into profiles/):
-#   bash tools/round_artifacts.sh          -> bench line, rocprofv3 kernel stats of the same command, PMC traffic (c3, c4, c5) + SQ passes
+#   bash tools/round_artifacts.sh          -> bench line, rocprofv3 kernel stats of the same command, PMC traffic (c2, c3, c4, c5) + SQ passes
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_* $R/gpurun_out/prof_final
 BARGS="--no-cpu-baseline --no-verify --no-ntt --no-b1"
 # PMC traffic: separate FETCH_SIZE / WRITE_SIZE passes (kernel trace only, as the guide prescribes); steps of bench.py's step() per
 # run = warmup + steps (no HIP-event leg under the profiler)
-for W in c3 c4 c5; do
+for W in c2 c3 c4 c5; do
   S=5; [ $W = c5 ] && S=2
   for C in FETCH_SIZE WRITE_SIZE; do timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${C}_$W -o bench -- python $R/bench.py --workload $W --steps $S --warmup 1 --no-kernel-timing $BARGS > $R/gpurun_out/pmc_${C}_$W.log 2>&1; done
 done
