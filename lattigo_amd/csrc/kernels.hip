@@ -160,6 +160,19 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned lin, unsigned n) {
 #ifndef HE_BFLY_ASM
 #define HE_BFLY_ASM 1
 #endif
+// gfx940 / gfx950: a VALU instruction that reads VCC (a carry-in) wants two wait states after the VALU instruction that wrote it
+// -- hipcc pads its own carry chains with `s_nop 1` (llvm's VALUWriteSGPRVALURead rule), and nothing pads an asm string.  The
+// sequence ran bit-exact without the pads through every suite of this round, which is no evidence for a hazard that shows on
+// "some waves of some launches": it carries them.  An s_nop costs the wave two issue cycles, not the SIMD (HE_BFLY_VCC_PAD = 0
+// for A/B builds).
+#ifndef HE_BFLY_VCC_PAD
+#define HE_BFLY_VCC_PAD 1
+#endif
+#if HE_BFLY_VCC_PAD
+#define HE_VCC_PAD "s_nop 1\n\t"
+#else
+#define HE_VCC_PAD
+#endif
 __device__ __forceinline__ uint64_t mred_lazy_col_asm(uint64_t x, uint64_t w, uint64_t q, uint64_t qinv) {
     const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
     const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32), nq = (uint32_t)(0 - qinv);
@@ -170,14 +183,18 @@ __device__ __forceinline__ uint64_t mred_lazy_col_asm(uint64_t x, uint64_t w, ui
         "v_mad_u64_u32 v[118:119], vcc, %[x1], %[w0], v[118:119]\n\t"      // M += x1 w0            (no overflow, see above)
         "v_mul_lo_u32 v122, v116, %[nq]\n\t"                               // m = L.lo (-q^-1) mod 2^32
         "v_mad_u64_u32 v[116:117], vcc, v122, %[q0], v[116:117]\n\t"       // L += m q0: L.lo = 0, carry
+        HE_VCC_PAD
         "v_addc_co_u32_e64 v119, vcc, 0, v119, vcc\n\t"                    //   -> bit 32 of M
         "v_mad_u64_u32 v[118:119], vcc, v122, %[q1], v[118:119]\n\t"       // M += m q1
         "v_add_co_u32_e32 v118, vcc, v118, v117\n\t"                       // M += L.hi             (T + m q) / 2^32 = M + H 2^32
+        HE_VCC_PAD
         "v_addc_co_u32_e64 v119, vcc, 0, v119, vcc\n\t"
         "v_mul_lo_u32 v122, v118, %[nq]\n\t"                               // m = M.lo (-q^-1) mod 2^32
         "v_mad_u64_u32 v[118:119], vcc, v122, %[q0], v[118:119]\n\t"       // M += m q0: M.lo = 0, carry
+        HE_VCC_PAD
         "v_addc_co_u32_e64 v121, vcc, 0, v121, vcc\n\t"                    //   -> bit 32 of H
         "v_add_co_u32_e32 v120, vcc, v120, v119\n\t"                       // H += M.hi
+        HE_VCC_PAD
         "v_addc_co_u32_e64 v121, vcc, 0, v121, vcc\n\t"
         "v_mad_u64_u32 %[r], vcc, v122, %[q1], v[120:121]"                   // r = H + m q1 in [0, 2q)
         : [r] "=v"(r)
