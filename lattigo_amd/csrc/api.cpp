@@ -1971,9 +1971,11 @@ static bool f64_raw_ok(const BasisExtender &be, int levelQ, int levelP, int nsrc
     for (int j = 0; j <= levelP; j++) if (be.small[be.LQ + j] == 2) mx = std::max(mx, be.P->moduli[j]);
     return mx != 0 && modup_f64_raw_ok(be.Q->logN, nsrc, mx);
 }
+// epi (optional): the ModDown epilogue runs in the kernel (NttMacEpilogue; sp / tsp indexed by Q LIMB here, compacted below);
+// the caller guarantees that no P limb is of the double-precision class
 int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View cx,
                int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch, bool q_out_f64 = false, bool own_reduce = true,
-               bool dec_f64 = false) {
+               bool dec_f64 = false, const NttMacEpilogue *epi = nullptr) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     NttMacArgs a{};
@@ -1998,6 +2000,15 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
     a.dec_f64 = dec_f64 ? 1 : 0;
     a.q_out_f64 = 0;
     const View decv{const_cast<uint64_t *>(dec), dec_bs};
+    if (epi) {
+        NttMacEpilogue e = *epi;
+        for (int i = 0; i < n; i++) {
+            if (a.out_view[i]) return fail(HE_EINVAL, "ks_mac_f64: epilogue with a double-precision P limb");
+            e.sp[i] = epi->sp[a.out_limb[i]]; e.tsp[i] = epi->tsp[a.out_limb[i]];
+        }
+        HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream, &e));
+        return HE_OK;
+    }
     if (!q_out_f64) {
         HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
         return HE_OK;
@@ -2021,8 +2032,17 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
 // cx_canonical: cx was produced by this library and is known to be in [0, q) (skips the input reduction of the first pass)
 // acc_q_f64 (in/out): on entry, whether the caller can take the Q-limb accumulators of the moduli below 2^47 as doubles; on
 // return, whether they were written that way (only the fused NTT+MAC path does)
+// defer (optional, in/out): when `want` is set and the call takes the fused NTT + MAC path, the launch over the double-precision
+// limbs is NOT made: `deferred` is set and the fields describe it, so that the caller can run it after the basis extension of
+// the P part with the ModDown epilogue inside (gadget_product_core)
+struct MacDefer {
+    bool want = false, deferred = false;
+    const uint64_t *dec = nullptr;
+    size_t bs = 0, ds = 0;
+    bool raw = false, own_reduce = true;
+};
 int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P,
-                             bool cx_canonical = false, bool *acc_q_f64 = nullptr) {
+                             bool cx_canonical = false, bool *acc_q_f64 = nullptr, MacDefer *defer = nullptr) {
     const bool want_f64 = acc_q_f64 && *acc_q_f64;
     if (acc_q_f64) *acc_q_f64 = false;
     BasisExtender &be = *ev.be;
@@ -2066,6 +2086,10 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
             const bool raw = f64_raw_ok(be, levelQ, levelP, max_nsrc);
             TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B, 1, raw));
             TRY(ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
+            if (defer && defer->want) {
+                defer->deferred = true; defer->dec = dec; defer->bs = bs; defer->ds = ds; defer->raw = raw; defer->own_reduce = !cx_canonical;
+                return HE_OK;
+            }
             if (acc_q_f64) *acc_q_f64 = want_f64;
             return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64, !cx_canonical, raw);
         }
@@ -2148,7 +2172,17 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
     const FusedPlan *plan = nullptr;
     TRY(get_md_plan(ev, levelQ, levelP, &plan));
     bool acc_f64 = plan->ok;  // the fused ModDown epilogue can read double accumulators
-    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical, &acc_f64));
+    // ModDown inside the NTT + MAC kernel: possible when the P part does not depend on that kernel (no P limb of the
+    // double-precision class) -- then the P accumulators come from ks_inner alone, are extended first, and the kernel over the
+    // double-precision Q limbs forms the final outputs against its accumulators in registers (NttMacEpilogue)
+    static const bool no_mac_epi = getenv("HERING_NO_MAC_EPILOGUE") && atoi(getenv("HERING_NO_MAC_EPILOGUE")) != 0;
+    MacDefer defer;
+    if (cx && plan->ok && k.keyd && !k.pw2 && !no_mac_epi && ntt_mac_epilogue_supported(be.Q->logN)) {
+        // (the kernel writes the outputs while other workgroups still read cx -- the digits' own limbs: not when they alias)
+        defer.want = out0.p != cx->p && out1.p != cx->p;
+        for (int j = 0; j <= levelP; j++) defer.want = defer.want && be.small[be.LQ + j] != 2;
+    }
+    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical, &acc_f64, &defer));
     else {
         acc_f64 = false;
         TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
@@ -2162,6 +2196,42 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         const FusedGroup &g = plan->groups[0];
         const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);  // the extension's double-precision outputs stay doubles up to the row kernel
         HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, 2 * B, st, raw, g.total_limbs));
+        if (defer.deferred) {
+            NttMacEpilogue me;
+            me.ext = sQ; me.ext_f64 = raw;
+            me.out0 = out0; me.out1 = out1;
+            me.has_w0 = add0 != nullptr && !tin; me.has_w1 = add1 != nullptr && !tin;
+            me.w0 = add0 ? *add0 : out0; me.w1 = add1 ? *add1 : out1;
+            me.tensor = tin != nullptr;
+            if (tin) { me.ta0 = tin->a0; me.ta1 = tin->a1; me.tb0 = tin->b0; me.tb1 = tin->b1; }
+            LimbTab ti;  // the Q limbs the integer kernels own: their epilogue stays with the forward rows
+            ti.n = 0;
+            NttEpilogue epi;
+            for (int i = 0; i <= levelQ; i++) {
+                const ModConst &m = be.Q->sub[i].mc;
+                const uint64_t si = be.Q->moduli[i] - be.md_ptoq[levelP][i];
+                me.sp[i] = (double)imform(si, m.q, m.qinv);
+                me.tsp[i] = tin ? (double)imform(imform(tin->ts[i], m.q, m.qinv), m.q, m.qinv) : 0.0;
+                if (be.small[i] == 2) continue;
+                ti.in_limb[ti.n] = ti.out_limb[ti.n] = ti.mod[ti.n] = (uint8_t)i;
+                epi.s[ti.n] = si;
+                if (tin) epi.ts[ti.n] = tin->ts[i];
+                ti.n++;
+            }
+            TRY(ks_mac_f64(ev, levelQ, levelP, defer.dec, defer.bs, defer.ds, k, *cx, levelP + 1, a0Q, a0P, a1Q, a1P, B, false,
+                           defer.own_reduce, defer.raw, &me));
+            if (ti.n > 0) {
+                epi.y = a0Q; epi.has_w = add0 != nullptr; epi.w = add0 ? *add0 : a0Q;
+                epi.y_small_f64 = false;
+                epi.zsplit = B; epi.out2 = out1; epi.y2 = a1Q; epi.has_w2 = add1 != nullptr; epi.w2 = add1 ? *add1 : a1Q;
+                if (tin) {
+                    epi.tensor = true; epi.has_w = epi.has_w2 = false;
+                    epi.ta0 = tin->a0; epi.ta1 = tin->a1; epi.tb0 = tin->b0; epi.tb1 = tin->b1;
+                }
+                HIP_TRY(launch_ntt_rows(be.qp, ti, sQ, out0, 2 * B, false, 0, st, &epi));
+            }
+            return HE_OK;
+        }
         NttEpilogue epi;
         for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
         epi.y = a0Q; epi.has_w = add0 != nullptr; epi.w = add0 ? *add0 : a0Q;

@@ -276,8 +276,27 @@ struct NttMacArgs {
     int own_reduce;  // the own-digit words are caller-supplied (any uint64): reduce them before the conversion to double
     int q_out_f64;   // Q-limb accumulators are written as IEEE doubles (exact integers, |x| < q) for the f64 ModDown epilogue
 };
+// ModDown epilogue fused into the NTT + MAC kernel (production row sizes; every limb of the launch a Q limb of the
+// double-precision class): after the key inner product of a (limb, row) the kernel transforms that row of the basis-extended P
+// part of BOTH accumulators -- `ext`, [2 * batch] entries as launch_modup_fused left them, component c of entry b at c * batch + b
+// -- and writes
+//     out_c = [w_c +] MRed(NTT(ext_c) + 2q - acc_c, s[limb])        (the last op of ModDownQPtoQNTT, as NttEpilogue)
+// against the accumulator still in registers: the Q accumulators are never written or read back, and the forward-row + epilogue
+// launch over these limbs disappears.  tensor: w_c is formed from the product's inputs (NttEpilogue::tensor).
+// sp[i] = IMForm(s[i]) and tsp[i] = IMForm(IMForm(ts[i])) as doubles, by launch limb.  out0Q / out1Q of the launch are unused.
+struct NttMacEpilogue {
+    View ext;
+    bool ext_f64 = false;  // the extension's words are doubles (launch_modup_fused f64_raw)
+    View out0, out1;
+    bool has_w0 = false, has_w1 = false;
+    View w0, w1;
+    bool tensor = false;
+    View ta0, ta1, tb0, tb1;
+    double sp[kMaxLimbs], tsp[kMaxLimbs];
+};
+bool ntt_mac_epilogue_supported(int logN);
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
-                              View out0P, View out1Q, View out1P, int batch, hipStream_t s);
+                              View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi = nullptr);
 // keyd[i] = (double)IMForm(key[i]) for the limbs of class 2 (plain residues < 2^47), 0 elsewhere
 hipError_t launch_key_to_f64(const RingDev &r, const uint64_t *key, double *keyd, int nblocks, const uint8_t *limb_mod_host,
                              int nlimbs, hipStream_t s);

@@ -1227,8 +1227,18 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the ModDown epilogue of NttMacEpilogue in kernel form (strides in words; sp / tsp = IMForm(s), IMForm(IMForm(ts)) as doubles)
+struct MacEpiK {
+    const uint64_t *ext; size_t ext_bs;
+    uint64_t *out0, *out1; size_t out0_bs, out1_bs;
+    const uint64_t *w0, *w1; size_t w0_bs, w1_bs;
+    const uint64_t *ta0, *ta1, *tb0, *tb1; size_t ta0_bs, ta1_bs, tb0_bs, tb1_bs;
+    int ext_f64, tensor, has_w0, has_w1;
+    double sp[kMaxLimbs], tsp[kMaxLimbs];
+};
 struct NttMacDmaArgs {
     NttMacKArgs k;
+    MacEpiK e;
     unsigned nbatch, nitems;  // work list = (row, limb, batch entry), batch fastest; nitems = rows * limbs * nbatch
     // per launch limb: mod | key_limb << 8 | dec_limb << 16 | out_limb << 24 | out_view << 32 -- ONE scalar load per work item (a
     // byte picked from the by-value arrays with a run-time index is a vector load, and waiting for it would drain the prefetch)
@@ -1243,7 +1253,11 @@ struct NttMacDmaArgs {
 #else
 #define MAC_STAMP2(i) do {} while (0)
 #endif
-template <int LOGB, bool QF64>
+// EPI: the ModDown epilogue runs in this kernel (NttMacEpilogue): after the digits of an item, the rows of the two basis-extended
+// accumulators' P parts arrive through the same prefetch chain as two more "digits", are transformed like them, and
+// out_c = [w_c +] (NTT(ext_c) - acc_c) s is formed against the accumulator still in registers -- the Q accumulators are never
+// written, and the separate forward-row + epilogue launch (HBM-bound, next to this latency-bound kernel) is gone.
+template <int LOGB, bool QF64, bool EPI = false>
 __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(NttMacDmaArgs AA) {
     static_assert(LOGB == 12 || LOGB == 13, "production row sizes only");
     constexpr int N2 = 1 << LOGB;
@@ -1264,7 +1278,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 
     struct Item {
         size_t bz, rowoff;
-        int ql, rowtw, out_limb, mi;
+        int ql, rowtw, out_limb, mi, l;
         bool isP;
         double q, qi;
         const double *tw, *kbase;
@@ -1275,6 +1289,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
         const int l = (int)((w / AA.nbatch) % (unsigned)A.m.nlimbs);
         const int row = (int)(w / (AA.nbatch * (unsigned)A.m.nlimbs));
         const uint64_t info = AA.limb_info[l];
+        it.l = l;
         const int mi = (int)(info & 0xff);
         it.mi = mi;
         // modulus record through the scalar cache (ModConst: word 0 = q, word 8 = 1 / q as a double)
@@ -1293,7 +1308,10 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
     auto own_digit = [&](const Item &it, int d) -> bool {
         return A.m.own_alpha > 0 && !it.isP && it.ql >= d * A.m.own_alpha && it.ql < (d + 1) * A.m.own_alpha;
     };
+    const int nd = A.m.beta + (EPI ? 2 : 0);  // EPI: "digits" beta, beta + 1 = the extension rows of components 0, 1
     auto digit_src = [&](const Item &it, int d) -> const uint64_t * {
+        if (EPI && d >= A.m.beta)
+            return AA.e.ext + ((size_t)(d - A.m.beta) * AA.nbatch + it.bz) * AA.e.ext_bs + (size_t)it.ql * A.N + it.rowoff;
         return own_digit(it, d) ? A.own + it.bz * A.own_bs + (size_t)it.ql * A.N + it.rowoff
                                 : A.dec + it.bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)it.ql * A.N + it.rowoff;
     };
@@ -1324,6 +1342,75 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
             tw1s[tau] = cur.tw[((unsigned)cur.rowtw << (4 + u)) + (hi << u) + j];  // its wait is the first digit's (below)
         }
         bool more = false;
+        // forward row transform of x (element k T + tau in, the same order out), with the prefetch of `nsrc` and -- digits only --
+        // the two key rows issued where they hide best
+        auto transform = [&](int nk, auto read_back, double (&x)[16], unsigned tau, unsigned lane, const uint64_t *nsrc, const double *k0p,
+                             const double *k1p, double (&kk0)[16], double (&kk1)[16]) {
+            // read_back = false: the result stays in the tile (element e at lds_phys(e)) for the caller to pick up
+            // nk (block-uniform): rows of sixteen words fetched on the way -- 2 (k0p and k1p), 1 (k0p), 0
+            // round-2 twiddles first, then the DMA: ordinary loads issued after it could only return after it
+            double t2[15];
+            rows_tw16_f64(t2, cur.tw, cur.rowtw, 8, tau >> (LOGB - 12));
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the buffer have returned
+            if (nsrc) dma_digit(nsrc, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // round 0: the fifteen twiddles are the same for every thread of the workgroup -> scalar cache, scalar registers
+                double t0[15];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int j = 0; j < (1 << u); j++) t0[(1 << u) - 1 + j] = ldcd(cur.tw, (size_t)(((unsigned)cur.rowtw << u) + j));
+                rows_round16_f64<false>(x, t0, q, qi);
+            }
+            __syncthreads();  // every wave is done with the tile (previous digit's last read) -- and tw1s is in place
+            rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 0, LOGB - 4, true);
+            __syncthreads();
+            rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, false);
+            {
+                double t1[15];
+                const double *tp = tw1s + (tau >> (LOGB - 8)) * 15u;
+#pragma unroll
+                for (int i = 0; i < 15; i++) t1[i] = tp[i];
+                rows_round16_f64<false>(x, t1, q, qi);
+            }
+            rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, true);
+            rows_sync(LOGB - 8);
+            rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, false);
+            __builtin_amdgcn_sched_barrier(0);
+            if (nk >= 1) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) kk0[k] = k0p[(unsigned)(k * T)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rows_round16_f64<false>(x, t2, q, qi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (nk >= 2) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, true);
+            if constexpr (GREM > 0) {
+                rows_sync(LOGB - 12);
+                rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, 12, 0, false);
+                rows_round_f64<GREM, false>(x, cur.tw, cur.rowtw, 12, 0, tau, 0, q, qi);
+                rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, 12, 0, true);
+            }
+            __syncthreads();
+            if constexpr (decltype(read_back)::value) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = lds[lds_phys(k * T + tau)];
+            }
+        };
+        // the prefetch buffer's next content after source `d` of the current item (block-uniform): the item's next source, or the
+        // next item's first digit (then `w`, `more` describe that item)
+        auto next_src = [&](int d) -> const uint64_t * {
+            if (d + 1 < nd) return digit_src(cur, d + 1);
+            w = item_of(++t);
+            more = w != ~0u;
+            return more ? digit_src(decode(w), 0) : nullptr;
+        };
         for (int d = 0; d < A.m.beta; d++) {
             const bool is_own = own_digit(cur, d);
             // loop-invariant address arithmetic is recomputed per digit from an opaque copy of the thread index: hoisted out of
@@ -1351,73 +1438,11 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 for (int k = 0; k < 16; k++) x[k] = u52_to_f64(xi[k]);
             }
             MAC_STAMP2(1 + d * 12 + 1);
-            // what the prefetch buffer receives next (block-uniform): the next digit, or the next item's first
-            const bool last = d + 1 == A.m.beta;
-            const uint64_t *nsrc;
-            if (!last) {
-                nsrc = digit_src(cur, d + 1);
-            } else {
-                w = item_of(++t);
-                more = w != ~0u;
-                nsrc = more ? digit_src(decode(w), 0) : nullptr;
-            }
+            const uint64_t *nsrc = next_src(d);
             const double *k0p = cur.kbase + (size_t)d * A.m.key_dstride + tau, *k1p = k0p + A.m.key_kstride;
             double kk0[16], kk1[16];
             if (!is_own) {
-                // round-2 twiddles first, then the DMA: ordinary loads issued after it could only return after it
-                double t2[15];
-                rows_tw16_f64(t2, cur.tw, cur.rowtw, 8, tau >> (LOGB - 12));
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the buffer have returned
-                if (nsrc) dma_digit(nsrc, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                MAC_STAMP2(1 + d * 12 + 2);
-                {   // round 0: the fifteen twiddles are the same for every thread of the workgroup -> scalar cache, scalar registers
-                    double t0[15];
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-#pragma unroll
-                        for (int j = 0; j < (1 << u); j++) t0[(1 << u) - 1 + j] = ldcd(cur.tw, (size_t)(((unsigned)cur.rowtw << u) + j));
-                    rows_round16_f64<false>(x, t0, q, qi);
-                }
-                MAC_STAMP2(1 + d * 12 + 3);
-                __syncthreads();  // every wave is done with the tile (previous digit's last read) -- and tw1s is in place
-                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 0, LOGB - 4, true);
-                __syncthreads();
-                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, false);
-                MAC_STAMP2(1 + d * 12 + 4);
-                {
-                    double t1[15];
-                    const double *tp = tw1s + (tau >> (LOGB - 8)) * 15u;
-#pragma unroll
-                    for (int i = 0; i < 15; i++) t1[i] = tp[i];
-                    rows_round16_f64<false>(x, t1, q, qi);
-                }
-                MAC_STAMP2(1 + d * 12 + 5);
-                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 4, LOGB - 8, true);
-                rows_sync(LOGB - 8);
-                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, false);
-                MAC_STAMP2(1 + d * 12 + 6);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < 16; k++) kk0[k] = k0p[(unsigned)(k * T)];
-                __builtin_amdgcn_sched_barrier(0);
-                rows_round16_f64<false>(x, t2, q, qi);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
-                __builtin_amdgcn_sched_barrier(0);
-                MAC_STAMP2(1 + d * 12 + 7);
-                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, true);
-                if constexpr (GREM > 0) {
-                    rows_sync(LOGB - 12);
-                    rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, 12, 0, false);
-                    rows_round_f64<GREM, false>(x, cur.tw, cur.rowtw, 12, 0, tau, 0, q, qi);
-                    rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, 12, 0, true);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < 16; k++) x[k] = lds[lds_phys(k * T + tau)];
+                transform(2, std::true_type{}, x, tau, lane, nsrc, k0p, k1p, kk0, kk1);
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (nsrc) dma_digit(nsrc, lane);
@@ -1436,10 +1461,125 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
             for (int k = 0; k < 16; k++) acc1[k] += modmul_f64(x[k], kk1[k], q, qi);
             MAC_STAMP2(1 + d * 12 + 10);
         }
+        if constexpr (EPI) {
+            // the two extension rows, through the same prefetch chain as two more digits
+#pragma unroll 1
+            for (int c = 0; c < 2; c++) {
+                unsigned tau_d = threadIdx.x;
+                asm volatile("" : "+v"(tau_d));
+                const unsigned tau = tau_d, lane = tau & 63u;
+                const double *pw = pbuf + wv * 1024u + lane;
+                MAC_STAMP2(48 + c * 4 + 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                double x[16];
+                if (AA.e.ext_f64) {  // doubles left by the basis extension (launch_modup_fused, f64_raw)
+#pragma unroll
+                    for (int k = 0; k < 16; k++) x[k] = pw[k * 64];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) x[k] = u52_to_f64((uint64_t)__double_as_longlong(pw[k * 64]));
+                }
+                const uint64_t *nsrc = next_src(A.m.beta + c);
+                // x = NTT(ext_c) comes back in the accumulators' order (element k T + tau): the last op of ModDownQPtoQNTT against
+                // the accumulator in registers (arithmetic of ntt_rows_f64_kernel's epilogue, word for word).  The operands it
+                // needs from memory are requested before / while the transform runs, in the registers the key rows use in a digit.
+                const bool second = c != 0;
+                const size_t off = (size_t)cur.out_limb * A.N + cur.rowoff + tau;
+                uint64_t *op = (second ? AA.e.out1 + cur.bz * AA.e.out1_bs : AA.e.out0 + cur.bz * AA.e.out0_bs) + off;
+                const double sp = AA.e.sp[cur.l];
+                const uint64_t *mcw = reinterpret_cast<const uint64_t *>(A.mc + cur.mi);
+                const uint64_t qu = ldc(mcw, 0);
+                const bool tensor = AA.e.tensor != 0, addw = !tensor && (second ? AA.e.has_w1 : AA.e.has_w0) != 0;
+                double kd0[16], kd1[16];  // (unused: no key rows on the way)
+                MAC_STAMP2(48 + c * 4 + 1);
+                transform(0, std::true_type{}, x, tau, lane, nsrc, nullptr, nullptr, kd0, kd1);
+                MAC_STAMP2(48 + c * 4 + 2);
+                if (tensor) {
+                    const double tsp = AA.e.tsp[cur.l];
+                    const uint64_t *pa0 = AA.e.ta0 + cur.bz * AA.e.ta0_bs + off, *pa1 = AA.e.ta1 + cur.bz * AA.e.ta1_bs + off;
+                    const uint64_t *pb0 = AA.e.tb0 + cur.bz * AA.e.tb0_bs + off, *pb1 = AA.e.tb1 + cur.bz * AA.e.tb1_bs + off;
+                    const uint64_t twoq_u = qu << 1, brc0 = ldc(mcw, 2);
+                    // caller words may be any 64-bit representative (as MRed accepts them); every pipeline of this library hands over
+                    // words below 2q, which convert as they are -- the Barrett reduction runs only for a wave that met a larger one
+                    constexpr int NB = 4;  // coefficients per batch (keeping the next batch's operands in flight as well measured equal: the phase is
+                                           // bound by its arithmetic, ~50 double-precision operations per coefficient, not by these loads)
+                    auto cvtb = [&](uint64_t (&w)[NB], double (&dd)[NB]) {
+                        bool big = false;
+#pragma unroll
+                        for (int k = 0; k < NB; k++) big = big || w[k] >= twoq_u;
+                        if (__any(big)) {
+#pragma unroll
+                            for (int k = 0; k < NB; k++) w[k] = bred_add_lazy(w[k], qu, brc0);
+                        }
+#pragma unroll
+                        for (int k = 0; k < NB; k++) dd[k] = u52_to_f64(w[k]);
+                    };
+                    uint64_t A0[NB], A1[NB], A2[NB], A3[NB];
+                    auto issue = [&](auto hc, uint64_t (&r0)[NB], uint64_t (&r1)[NB], uint64_t (&r2)[NB], uint64_t (&r3)[NB]) {
+                        constexpr int h = decltype(hc)::value;
+#pragma unroll
+                        for (int k = 0; k < NB; k++) { const unsigned e = (unsigned)((NB * h + k) * T); r0[k] = pa0[e]; r1[k] = pb0[e]; }
+                        if (second) {
+#pragma unroll
+                            for (int k = 0; k < NB; k++) { const unsigned e = (unsigned)((NB * h + k) * T); r2[k] = pa1[e]; r3[k] = pb1[e]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    auto finish = [&](auto hc, uint64_t (&r0)[NB], uint64_t (&r1)[NB], uint64_t (&r2)[NB], uint64_t (&r3)[NB]) {
+                        constexpr int h = decltype(hc)::value;
+                        double u[NB], v[NB], u2[NB], v2[NB], wv[NB];
+                        cvtb(r0, u); cvtb(r1, v);
+                        if (second) {
+                            cvtb(r2, u2); cvtb(r3, v2);
+#pragma unroll
+                            for (int k = 0; k < NB; k++) wv[k] = modmul_f64(u[k], v2[k], q, qi) + modmul_f64(u2[k], v[k], q, qi);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NB; k++) wv[k] = modmul_f64(u[k], v[k], q, qi);
+                        }
+#pragma unroll
+                        for (int k = 0; k < NB; k++) {
+                            const int i = NB * h + k;
+                            const double yi = reduce_f64(acc0[i], q, qi);  // (|y| < q: x - y stays an exact integer below 2^53, as with the separate epilogue)
+                            const double tt = modmul_f64(wv[k], tsp, q, qi) + modmul_f64(x[i] - yi, sp, q, qi);
+                            stnt(&op[(unsigned)(i * T)], canon_f64(tt, q, qi));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+#define HE_H(n) std::integral_constant<int, n>{}
+                    issue(HE_H(0), A0, A1, A2, A3); finish(HE_H(0), A0, A1, A2, A3);
+                    issue(HE_H(1), A0, A1, A2, A3); finish(HE_H(1), A0, A1, A2, A3);
+                    issue(HE_H(2), A0, A1, A2, A3); finish(HE_H(2), A0, A1, A2, A3);
+                    issue(HE_H(3), A0, A1, A2, A3); finish(HE_H(3), A0, A1, A2, A3);
+#undef HE_H
+                } else if (addw) {
+                    const uint64_t *wp = (second ? AA.e.w1 + cur.bz * AA.e.w1_bs : AA.e.w0 + cur.bz * AA.e.w0_bs) + off;
+                    uint64_t wv[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[(unsigned)(k * T)]);
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const uint64_t v = canon_f64(modmul_f64(x[k] - reduce_f64(acc0[k], q, qi), sp, q, qi), q, qi);
+                        stnt(&op[(unsigned)(k * T)], cred(wv[k] + v, qu));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        stnt(&op[(unsigned)(k * T)], canon_f64(modmul_f64(x[k] - reduce_f64(acc0[k], q, qi), sp, q, qi), q, qi));
+                }
+                MAC_STAMP2(48 + c * 4 + 3);
+                // the second pass works on the other accumulator through the same names (a run-time choice between the two
+                // arrays inside the pass would put both in scratch memory)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc0[k] = acc1[k];
+            }
+        }
         const int ol = cur.out_limb;
         uint64_t *o0 = (cur.isP ? A.o0P + cur.bz * A.oP0_bs : A.o0Q + cur.bz * A.oQ0_bs) + (size_t)ol * A.N + cur.rowoff + tau;
         uint64_t *o1 = (cur.isP ? A.o1P + cur.bz * A.oP1_bs : A.o1Q + cur.bz * A.oQ1_bs) + (size_t)ol * A.N + cur.rowoff + tau;
-        if constexpr (QF64) {  // the f64 ModDown epilogue reads these as doubles
+        if constexpr (EPI) {
+            (void)o0; (void)o1;  // the epilogue wrote the final outputs
+        } else if constexpr (QF64) {  // the f64 ModDown epilogue reads these as doubles
             double *d0 = reinterpret_cast<double *>(o0), *d1 = reinterpret_cast<double *>(o1);
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -1471,22 +1611,40 @@ static unsigned mac_resident_workgroups(int logb) {
     return forced ? forced : (logb >= 13 ? cus : 2u * cus);
 }
 
+bool ntt_mac_epilogue_supported(int logN) {
+    const int b = ntt_row_bits(logN);
+    return b == 12 || b == 13;
+}
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
-                              View out0P, View out1Q, View out1P, int batch, hipStream_t s) {
+                              View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi) {
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     if (!r.twd_fwd || !keyd) return hipErrorInvalidValue;
     const int b = ntt_row_bits(r.logN), aa = r.logN - b;
+    if (epi && !ntt_mac_epilogue_supported(r.logN)) return hipErrorInvalidValue;
     NttMacKArgs A;
     A.dec = dec.p; A.dec_bs = dec.bstride; A.own = own.p; A.own_bs = own.bstride; A.keyd = keyd;
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
     A.mc = r.mc; A.twd = r.twd_fwd; A.N = r.N; A.a = aa; A.m = a;
     // beta digits in (an own digit is the input limb itself), two key rows per digit shared by the batch, two accumulators out
-    const double mac_bytes = ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0;
+    double mac_bytes = ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0;
+    // with the epilogue: + the two extension rows, + the addends (w0 / w1) or the four inputs of the product, per entry and limb
+    if (epi) mac_bytes += (2.0 + (epi->tensor ? 4.0 : (epi->has_w0 ? 1.0 : 0.0) + (epi->has_w1 ? 1.0 : 0.0))) * batch * a.nlimbs * (double)r.N * 8.0;
     static const bool plain_only = getenv("HERING_MAC_PLAIN") && atoi(getenv("HERING_MAC_PLAIN")) != 0;
-    if (b == 13 || (b == 12 && !plain_only)) {  // (the plain kernel has no 8192-row instantiation: it would spill)
+    if (epi || b == 13 || (b == 12 && !plain_only)) {  // (the plain kernel has no 8192-row instantiation: it would spill)
         NttMacDmaArgs D;
         D.k = A;
+        D.e = MacEpiK{};
+        if (epi) {
+            D.e.ext = epi->ext.p; D.e.ext_bs = epi->ext.bstride; D.e.ext_f64 = epi->ext_f64 ? 1 : 0;
+            D.e.out0 = epi->out0.p; D.e.out0_bs = epi->out0.bstride; D.e.out1 = epi->out1.p; D.e.out1_bs = epi->out1.bstride;
+            D.e.has_w0 = epi->has_w0 ? 1 : 0; D.e.has_w1 = epi->has_w1 ? 1 : 0;
+            D.e.w0 = epi->w0.p; D.e.w0_bs = epi->w0.bstride; D.e.w1 = epi->w1.p; D.e.w1_bs = epi->w1.bstride;
+            D.e.tensor = epi->tensor ? 1 : 0;
+            D.e.ta0 = epi->ta0.p; D.e.ta0_bs = epi->ta0.bstride; D.e.ta1 = epi->ta1.p; D.e.ta1_bs = epi->ta1.bstride;
+            D.e.tb0 = epi->tb0.p; D.e.tb0_bs = epi->tb0.bstride; D.e.tb1 = epi->tb1.p; D.e.tb1_bs = epi->tb1.bstride;
+            for (int i = 0; i < a.nlimbs; i++) { D.e.sp[i] = epi->sp[i]; D.e.tsp[i] = epi->tsp[i]; }
+        }
         D.nbatch = (unsigned)batch;
         D.nitems = (unsigned)batch * (unsigned)a.nlimbs * (1u << aa);
         for (int i = 0; i < a.nlimbs; i++)
@@ -1501,7 +1659,10 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
             if ((D.nitems & 7u) == 0) G = (G + 7u) & ~7u;
         }
         ProfScope ps(K_NTT_MAC_F64, s, mac_bytes);
-        if (b == 12) {
+        if (epi) {
+            if (b == 12) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false, true>), dim3(G), dim3(256), 0, s, D);
+            else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, false, true>), dim3(G), dim3(512), 0, s, D);
+        } else if (b == 12) {
             if (a.q_out_f64) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, true>), dim3(G), dim3(256), 0, s, D);
             else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false>), dim3(G), dim3(256), 0, s, D);
         } else {

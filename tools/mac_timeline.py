@@ -36,6 +36,13 @@ for dg in range(4):
               "mac0": int(np.median(own[:, 9] - own[:, 8])), "mac1": int(np.median(own[:, 10] - own[:, 9]))})
     elif len(own):
         print("digit", dg, "own waves", len(own), "start->mac", int(np.median(own[:, 10] - own[:, 0])), "mac->endbar", int(np.median(own[:, 11] - own[:, 10])))
+if "--dma" in sys.argv and (a[:, 48] > 0).any():  # fused ModDown epilogue: the two extension phases
+    e = a[(a[:, 48:56] > 0).all(axis=1)]
+    for c in range(2):
+        b = 48 + 4 * c
+        print("ext", c, "waves", len(e), {"dma-wait+read": int(np.median(e[:, b + 1] - e[:, b])), "transform": int(np.median(e[:, b + 2] - e[:, b + 1])),
+              "epilogue": int(np.median(e[:, b + 3] - e[:, b + 2]))})
+    print("last digit's end -> ext 0:", int(np.median(e[:, 48] - e[:, 47])), " ext 0 end -> ext 1:", int(np.median(e[:, 52] - e[:, 51])))
 tot = a[:, 60] - a[:, 0]
 print("item start -> digit 0:", int(np.median(a[:, 1] - a[:, 0])), "last digit's end -> item end:", int(np.median(a[:, 60] - a[:, 47 if "--dma" in sys.argv else 48])))
 print("wave lifetime median", int(np.median(tot)), "p10", int(np.percentile(tot, 10)), "p90", int(np.percentile(tot, 90)))
