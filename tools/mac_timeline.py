@@ -23,7 +23,15 @@ if "--dma" in sys.argv:  # the persistent LDS-DMA kernel: item HE_MAC_STAMP_ITEM
     names = ["start", "dma-wait+read", "tw2+dma issue", "round0", "bar+x1", "round1", "x2", "k0+round2+k1", "x3(bar)", "mac0", "mac1", "-"]
 print("rc", rc, "nonzero rows", int((a[:, 0] > 0).sum()))
 a = a[a[:, 0] > 0]
-for dg in range(4):
+if "--dma" in sys.argv:  # the persistent kernel stamps a digit at: start, words read, transform + key rows done, MAC 0 done, MAC 1 done
+    for dg in range(4):
+        st = a[:, 1 + 12 * dg: 1 + 12 * dg + 12][:, [0, 1, 8, 9, 10]]
+        ok = st[(st > 0).all(axis=1)]
+        if len(ok):
+            seg = np.diff(ok, axis=1)
+            print("digit", dg, "waves", len(ok), dict(zip(["dma-wait+read", "transform+keys (own digit: keys only)", "mac0", "mac1"], (int(np.median(seg[:, i])) for i in range(4)))),
+                  "sum", int(np.median(seg.sum(axis=1))))
+for dg in range(4 if "--dma" not in sys.argv else 0):
     st = a[:, 1 + 12 * dg: 1 + 12 * dg + 12]
     full = st[(st[:, :11] > 0).all(axis=1)][:, :11] if "--dma" in sys.argv else st[(st > 0).all(axis=1)]
     dma = "--dma" in sys.argv
