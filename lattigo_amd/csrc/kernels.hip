@@ -1501,8 +1501,9 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                     const uint64_t twoq_u = qu << 1, brc0 = ldc(mcw, 2);
                     // caller words may be any 64-bit representative (as MRed accepts them); every pipeline of this library hands over
                     // words below 2q, which convert as they are -- the Barrett reduction runs only for a wave that met a larger one
-                    constexpr int NB = 4;  // coefficients per batch (keeping the next batch's operands in flight as well measured equal: the phase is
-                                           // bound by its arithmetic, ~50 double-precision operations per coefficient, not by these loads)
+                    constexpr int NB = 4;  // coefficients per batch.  Each batch waits ~2 000 cycles for its operands (tools/mac_timeline.py);
+                                           // the next batch in flight as well measured equal (a batch's arithmetic covers a quarter of
+                                           // that), and the registers that could hold a whole row early are what the transform runs on
                     auto cvtb = [&](uint64_t (&w)[NB], double (&dd)[NB]) {
                         bool big = false;
 #pragma unroll
