@@ -1501,7 +1501,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                     const uint64_t twoq_u = qu << 1, brc0 = ldc(mcw, 2);
                     // caller words may be any 64-bit representative (as MRed accepts them); every pipeline of this library hands over
                     // words below 2q, which convert as they are -- the Barrett reduction runs only for a wave that met a larger one
-                    constexpr int NB = 4;  // coefficients per batch.  Each batch waits ~2 000 cycles for its operands (tools/mac_timeline.py);
+                    constexpr int NB = LOGB == 12 ? 8 : 4;  // coefficients per batch (eight spill six registers in the 8192-row kernel).  Each batch waits ~2 000 cycles for its operands (tools/mac_timeline.py);
                                            // the next batch in flight as well measured equal (a batch's arithmetic covers a quarter of
                                            // that), and the registers that could hold a whole row early are what the transform runs on
                     auto cvtb = [&](uint64_t (&w)[NB], double (&dd)[NB]) {
@@ -1550,8 +1550,10 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #define HE_H(n) std::integral_constant<int, n>{}
                     issue(HE_H(0), A0, A1, A2, A3); finish(HE_H(0), A0, A1, A2, A3);
                     issue(HE_H(1), A0, A1, A2, A3); finish(HE_H(1), A0, A1, A2, A3);
-                    issue(HE_H(2), A0, A1, A2, A3); finish(HE_H(2), A0, A1, A2, A3);
-                    issue(HE_H(3), A0, A1, A2, A3); finish(HE_H(3), A0, A1, A2, A3);
+                    if constexpr (NB < 8) {
+                        issue(HE_H(2), A0, A1, A2, A3); finish(HE_H(2), A0, A1, A2, A3);
+                        issue(HE_H(3), A0, A1, A2, A3); finish(HE_H(3), A0, A1, A2, A3);
+                    }
 #undef HE_H
                 } else if (addw) {
                     const uint64_t *wp = (second ? AA.e.w1 + cur.bz * AA.e.w1_bs : AA.e.w0 + cur.bz * AA.e.w0_bs) + off;
