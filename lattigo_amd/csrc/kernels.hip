@@ -1548,8 +1548,21 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                         __builtin_amdgcn_sched_barrier(0);
                     };
 #define HE_H(n) std::integral_constant<int, n>{}
-                    issue(HE_H(0), A0, A1, A2, A3); finish(HE_H(0), A0, A1, A2, A3);
-                    issue(HE_H(1), A0, A1, A2, A3); finish(HE_H(1), A0, A1, A2, A3);
+                    if (NB == 8 && !second) {
+                        // component 0 has two operand rows, not four: all sixteen coefficients' words in ONE request (the second
+                        // eight in the registers component 1 uses for a1, b1)
+#pragma unroll
+                        for (int k = 0; k < NB; k++) {
+                            const unsigned e = (unsigned)(k * T), e2 = (unsigned)((NB + k) * T);
+                            A0[k] = pa0[e]; A1[k] = pb0[e]; A2[k] = pa0[e2]; A3[k] = pb0[e2];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        finish(HE_H(0), A0, A1, A0, A1);
+                        finish(HE_H(1), A2, A3, A2, A3);
+                    } else {
+                        issue(HE_H(0), A0, A1, A2, A3); finish(HE_H(0), A0, A1, A2, A3);
+                        issue(HE_H(1), A0, A1, A2, A3); finish(HE_H(1), A0, A1, A2, A3);
+                    }
                     if constexpr (NB < 8) {
                         issue(HE_H(2), A0, A1, A2, A3); finish(HE_H(2), A0, A1, A2, A3);
                         issue(HE_H(3), A0, A1, A2, A3); finish(HE_H(3), A0, A1, A2, A3);
