@@ -968,3 +968,31 @@ def test_captured_graph_replays_a_call_sequence(ctx):
     chain()
     got = outputs()
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("logN", [13, 15])
+def test_gadget_product_output_aliasing_its_input(ctx, logN):
+    """GadgetProduct with an output polynomial that IS the input cx (core/rlwe/evaluator_gadget_product.go:26-56 reads cx completely
+    before it writes ct): the pipeline with the ModDown epilogue inside the NTT + MAC kernel writes outputs while other workgroups
+    still read cx, so the library must notice the aliasing and take the other pipeline -- same words either way."""
+    q, p = O.GenModuli(logN + 1, [55, 45, 45, 45, 45, 45], [55, 55])
+    pr = Pair(ctx, logN, len(q), len(p), qmods=q, pmods=p)
+    rng = rng_for(3500 + logN)
+    gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+    sk, sk2 = SecretKey(rng, pr.oQ, pr.oP), SecretKey(rng, pr.oQ, pr.oP)
+    oevk = gen_evaluation_key(rng, pr.oQ, pr.oP, sk.Q, sk2)
+    gevk = gev.NewEvaluationKey(oevk.q, oevk.p)
+    level, B = len(q) - 1, 8
+    cx = np.stack([uniform_poly(rng, q, pr.N) for _ in range(B)])
+    want = np.stack([oev.GadgetProduct(level, cx[b], oevk) for b in range(B)])  # [B][2][limbs][N]
+    # separate outputs: the fused pipeline
+    pcx = la.Poly(pr.gQ, len(q), B).upload(cx)
+    out = [la.Poly(pr.gQ, len(q), B), la.Poly(pr.gQ, len(q), B)]
+    gev.GadgetProduct(level, pcx, gevk, out)
+    assert np.array_equal(out[0].get(), want[:, 0]) and np.array_equal(out[1].get(), want[:, 1])
+    for k in range(2):  # output k is cx itself
+        pcx = la.Poly(pr.gQ, len(q), B).upload(cx)
+        other = la.Poly(pr.gQ, len(q), B)
+        outs = [pcx, other] if k == 0 else [other, pcx]
+        gev.GadgetProduct(level, pcx, gevk, outs)
+        assert np.array_equal(outs[0].get(), want[:, 0]) and np.array_equal(outs[1].get(), want[:, 1]), k
