@@ -249,14 +249,17 @@ def setup_c3(la, ctx, rank, B, cp, args):
     # kernel (NttMacEpilogue): its launch then also reads the two extension rows and the four inputs and writes the final
     # outputs in place of the accumulators, and the double-precision forward-row launch does not exist.
     mac_epilogue = nsp == 0 and nsq > 0 and os.environ.get("HERING_NO_MAC_EPILOGUE", "0") in ("", "0")
+    prod_in = nsq > 0 and os.environ.get("HERING_NO_PROD_PROLOGUE", "0") in ("", "0")
     kernel_bytes = {
         "ntt_mac_f64": ((dec_small + nsq) * B + 2 * beta * n_small + 2 * n_small * B + (6 * nsq * B if mac_epilogue else 0)) * limb,
         "ntt_rows_fwd_f64": (2 * (1 + 1 + 1) + 4) * nsq * limb * B,
         "ntt_rows_fwd": (2 * dec_big + (2 * (1 + 1 + 1) + 4) * (L - nsq)) * limb * B,
-        "ntt_rows_inv_f64": 2 * (nsq + 2 * nsp) * limb * B,
+        # (the inverse rows of the double-precision limbs form c2 = T(a1, b1) themselves: two inputs in, c2 and the transform out;
+        # the tensor kernel covers the integer-class limbs only)
+        "ntt_rows_inv_f64": ((4 if prod_in else 2) * nsq + 2 * 2 * nsp) * limb * B,
         "ntt_rows_inv": 2 * ((L - nsq) + 2 * (alpha - nsp)) * limb * B,
         "ks_inner": (beta * n_big * B + 2 * beta * n_big + 2 * n_big * B) * limb,
-        "tensor": 3 * L * limb * B,
+        "tensor": 3 * (L - nsq if prod_in else L) * limb * B,
         "modup": (L + nonown + 2 * alpha + 2 * L) * limb * B,
     }
     if mac_epilogue:

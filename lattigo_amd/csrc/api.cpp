@@ -2032,6 +2032,14 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
 // cx_canonical: cx was produced by this library and is known to be in [0, q) (skips the input reduction of the first pass)
 // acc_q_f64 (in/out): on entry, whether the caller can take the Q-limb accumulators of the moduli below 2^47 as doubles; on
 // return, whether they were written that way (only the fused NTT+MAC path does)
+// the four inputs of a ciphertext product whose c0 / c1 the fused ModDown epilogue forms itself (NttEpilogue::tensor)
+struct TensorIn {
+    View a0, a1, b0, b1;
+    const uint64_t *ts;  // per Q limb
+    // cx is the (not yet computed) degree-2 term T(a1, b1): gadget_product_lazy_core forms it -- in the inverse row pass itself for
+    // the limbs of the double-precision class where that pass has the prologue (NttProdIn), by launch_tensor otherwise
+    bool make_c2 = false;
+};
 // defer (optional, in/out): when `want` is set and the call takes the fused NTT + MAC path, the launch over the double-precision
 // limbs is NOT made: `deferred` is set and the fields describe it, so that the caller can run it after the basis extension of
 // the P part with the ModDown epilogue inside (gadget_product_core)
@@ -2042,7 +2050,7 @@ struct MacDefer {
     bool raw = false, own_reduce = true;
 };
 int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P,
-                             bool cx_canonical = false, bool *acc_q_f64 = nullptr, MacDefer *defer = nullptr) {
+                             bool cx_canonical = false, bool *acc_q_f64 = nullptr, MacDefer *defer = nullptr, const TensorIn *tin = nullptr) {
     const bool want_f64 = acc_q_f64 && *acc_q_f64;
     if (acc_q_f64) *acc_q_f64 = false;
     BasisExtender &be = *ev.be;
@@ -2052,6 +2060,26 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
     uint64_t *cxinv = be.ctx->arena_take(wq);
     uint64_t *dec = be.ctx->arena_take((size_t)B * bs);
     View inv{cxinv, (size_t)(levelQ + 1) * N};
+    const FusedPlan *plan = nullptr;
+    if (!k.pw2) TRY(get_dec_plan(ev, levelQ, levelP, levelP + 1, &plan));
+    const bool make_c2 = tin && tin->make_c2;
+    static const bool no_prod_in = getenv("HERING_NO_PROD_PROLOGUE") && atoi(getenv("HERING_NO_PROD_PROLOGUE")) != 0;
+    const bool prod_in = make_c2 && plan && plan->ok && be.d_twdi != nullptr && ntt_prod_in_supported(be.Q->logN) && !no_prod_in;
+    if (make_c2) {
+        // cx = T(a1, b1): everywhere by the tensor kernel, or -- prod_in -- only on the integer-class limbs, the others being formed
+        // by the inverse row pass below
+        LimbTab tt;
+        tt.n = 0;
+        uint64_t tsv[kMaxLimbs];
+        for (int i = 0; i <= levelQ; i++) {
+            if (prod_in && be.small[i] == 2) continue;
+            tt.in_limb[tt.n] = tt.out_limb[tt.n] = tt.mod[tt.n] = (uint8_t)i;
+            tsv[tt.n] = tin->ts[i];
+            tt.n++;
+        }
+        if (tt.n > 0)
+            HIP_TRY(launch_tensor(be.qp, tt, tsv, tin->a0, tin->a1, tin->b0, tin->b1, View{nullptr, 0}, View{nullptr, 0}, cx, B, be.ctx->stream));
+    }
     if (k.pw2) {  // base-2 gadget: bit windows of every Q-limb, NTT'd into every limb (evaluator_gadget_product.go:203-338)
         hipStream_t st = be.ctx->stream;
         HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT));
@@ -2075,10 +2103,15 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
         }
         return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
     }
-    const FusedPlan *plan = nullptr;
-    TRY(get_dec_plan(ev, levelQ, levelP, levelP + 1, &plan));
     if (plan->ok) {
-        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, cx_canonical ? 0 : NTT_REDUCE_INPUT, be.ctx->stream));
+        if (prod_in) {
+            NttProdIn pin;
+            pin.a = tin->a1; pin.b = tin->b1; pin.c = cx;
+            for (int i = 0; i <= levelQ; i++) pin.ts[i] = tin->ts[i];
+            HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, 0, be.ctx->stream, nullptr, &pin));
+        } else {
+            HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), cx, inv, B, true, cx_canonical ? 0 : NTT_REDUCE_INPUT, be.ctx->stream));
+        }
         if (k.keyd) {  // limbs below 2^47: NTT + MAC fused; the rest: row NTT then ks_inner
             // the double-precision limbs of the decomposition are read by ntt_mac_f64 only: they stay doubles in between
             int max_nsrc = 1;
@@ -2145,11 +2178,6 @@ int moddown_pair(Evaluator &ev, int levelQ, int levelP, View c0Q, View c0P, View
 }
 // full GadgetProduct: out_k = [add_k +] GadgetProduct(cx)_k.  Both components share every launch
 // (accumulators are laid out [2][B] so ModDown runs once over 2B entries).
-// the four inputs of a ciphertext product whose c0 / c1 the fused ModDown epilogue forms itself (NttEpilogue::tensor)
-struct TensorIn {
-    View a0, a1, b0, b1;
-    const uint64_t *ts;  // per Q limb
-};
 int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp *hoisted, const Evk &k, View out0, View out1, int B,
                         const View *add0 = nullptr, const View *add1 = nullptr, bool cx_canonical = false,
                         const TensorIn *tin = nullptr) {
@@ -2182,7 +2210,7 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         defer.want = out0.p != cx->p && out1.p != cx->p;
         for (int j = 0; j <= levelP; j++) defer.want = defer.want && be.small[be.LQ + j] != 2;
     }
-    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical, &acc_f64, &defer));
+    if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical, &acc_f64, &defer, tin));
     else {
         acc_f64 = false;
         TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
@@ -2766,9 +2794,8 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
     const bool may_fuse = k->nPk > 0 && !alias && !no_fuse;  // a P-less (base-2) key has no ModDown to fuse into
     if (may_fuse) TRY(get_md_plan(*ev, level, k->nPk - 1, &mdplan));
     if (may_fuse && mdplan->ok) {
-        HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), View{nullptr, 0},
-                              View{nullptr, 0}, c2, B, st));
-        TensorIn tin{a0->view(), a1->view(), b0->view(), b1->view(), sc_.data()};
+        // (c2 = T(a1, b1) is formed on the way: by the inverse row pass for the double-precision limbs, by the tensor kernel for the others)
+        TensorIn tin{a0->view(), a1->view(), b0->view(), b1->view(), sc_.data(), true};
         return gadget_product_core(*ev, level, &c2, nullptr, *k, o0v, o1v, B, nullptr, nullptr, true, &tin);
     }
     HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),

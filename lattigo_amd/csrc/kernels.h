@@ -87,8 +87,17 @@ struct NttEpilogue {
     bool has_dst = false;
     View dst;
 };
+// Optional prologue of the INVERSE row pass over the limbs of the double-precision class (production row sizes): the input is
+// formed in the kernel as the degree-2 term of a ciphertext product, c = T(a, b) = MRed(MRed(a, ts[limb]), b), canonical, and
+// also written to `c` (limb-indexed like `in`) -- the tensor pass over those limbs and the read-back of its output disappear.
+// The integer-class limbs of the launch read `in` as usual (the caller's tensor pass covers them).  ts by tab position.
+struct NttProdIn {
+    View a, b, c;
+    uint64_t ts[kMaxLimbs];
+};
+bool ntt_prod_in_supported(int logN);
 hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
-                           hipStream_t s, const NttEpilogue *epi = nullptr);
+                           hipStream_t s, const NttEpilogue *epi = nullptr, const NttProdIn *prod = nullptr);
 
 // conjugate-invariant fold (ring/ntt.go:764-769 forward, :1146-1151 backward), pairs (j, N-j) per thread:
 //   forward : out[j] = in[j] + 2q - MRedLazy(in[N-j], F), out[0] = in[0]          (F = ModConst.pad0)

@@ -291,6 +291,7 @@ struct NttArgs {
     int epi_y_reduce;  // f64 kernel only: y holds arbitrary 64-bit words (reduced before the conversion to double)
     int nbatch, iters;  // f64 kernel only: a workgroup transforms batch entries blockIdx.x * iters ... (+ iters - 1) of its row
     int nbatch_prof = 0;  // host only: batch entries of the launch when grid.x is not their number (rows_bytes)
+    int tprod = 0;  // f64 inverse kernel only (NttProdIn): the input is formed here as T(ta1, tb1) with epi_ts, and also written to out2
 };
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
@@ -783,8 +784,9 @@ __device__ __forceinline__ void rows_lds_xfer_f64(double (&x)[16], double *lds, 
     }
 }
 
-template <int LOGB, bool INV>
+template <int LOGB, bool INV, bool TP = false>
 __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) ntt_rows_f64_kernel(NttArgs A) {
+    static_assert(!TP || INV, "the product prologue belongs to the inverse transform");
     constexpr int N2 = 1 << LOGB;
     constexpr int T = N2 / 16;
     constexpr int NR4 = LOGB / 4;
@@ -810,10 +812,10 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
         if ((int)ent >= A.zsplit) return;
         b0 = ((b0 >> 3) & 1) * (unsigned)A.zsplit + ent;
     }
-    constexpr bool PIPE = INV && LOGB <= 12;  // 512-thread rows (LOGB = 13) would fall to one workgroup per CU
+    constexpr bool PIPE = INV && LOGB <= 12 && !TP;  // 512-thread rows (LOGB = 13) would fall to one workgroup per CU
     const unsigned b1 = PIPE ? min(b0 + (unsigned)A.iters, (unsigned)A.nbatch) : b0 + 1;  // otherwise iters == 1
     uint64_t nx[16];
-    if constexpr (INV) {
+    if constexpr (INV && !TP) {
         const uint64_t *src0 = A.in + (size_t)b0 * A.in_bs + in_off;
 #pragma unroll
         for (int k = 0; k < 16; k++) nx[k] = ldnt(&src0[nat_e<T>(k, tau)]);
@@ -990,12 +992,44 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             }
         }
     } else {
+        if constexpr (TP) {
+            // the transform's input is formed here: c2 = T(a1, b1) = MRed(MRed(a1, ts), b1) of the ciphertext product
+            // (schemes/bgv/evaluator.go:634-647), canonical -- also written out (the digits' own limbs of the key inner product
+            // read it) -- instead of a separate pass writing it and this one reading it back.  Caller words may be any 64-bit
+            // representative; the Barrett reduction runs only for a wave that met one of 2q or above.
+            const size_t off = (size_t)il * A.N + (size_t)row * N2;
+            const uint64_t *pa = A.ta1 + (size_t)bzi * A.ta1_bs + off, *pb = A.tb1 + (size_t)bzi * A.tb1_bs + off;
+            uint64_t *pc = A.out2 + (size_t)bzi * A.out2_bs + off;
+            const double tsp = (double)imform(imform(A.epi_ts[y], mc.q, mc.qinv), mc.q, mc.qinv);
+            const uint64_t twoq_u = mc.q << 1;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint64_t ua[8], ub[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const int e = nat_e<T>(8 * h + k, tau); ua[k] = ldnt(&pa[e]); ub[k] = ldnt(&pb[e]); }
+                bool big = false;
+#pragma unroll
+                for (int k = 0; k < 8; k++) big = big || ua[k] >= twoq_u || ub[k] >= twoq_u;
+                if (__any(big)) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { ua[k] = bred_add_lazy(ua[k], mc.q, mc.brc0); ub[k] = bred_add_lazy(ub[k], mc.q, mc.brc0); }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int e = nat_e<T>(8 * h + k, tau);
+                    const double c = canon_f64d(modmul_f64(modmul_f64(u52_to_f64(ua[k]), u52_to_f64(ub[k]), q, qi), tsp, q, qi), q, qi);
+                    stnt(&pc[e], f64_to_u52(c));
+                    lds[lds_phys(e)] = c;
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int e = nat_e<T>(k, tau);
             uint64_t v = nx[k];
             if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
             lds[lds_phys(e)] = u52_to_f64(v);
+        }
         }
         if constexpr (PIPE) if (bzi + 1 < b1) {
             const uint64_t *srcn = A.in + (size_t)(bzi + 1) * A.in_bs + in_off;
@@ -1627,6 +1661,10 @@ static unsigned mac_resident_workgroups(int logb) {
     return forced ? forced : (logb >= 13 ? cus : 2u * cus);
 }
 
+bool ntt_prod_in_supported(int logN) {
+    const int b = ntt_row_bits(logN);
+    return b == 12 || b == 13;
+}
 bool ntt_mac_epilogue_supported(int logN) {
     const int b = ntt_row_bits(logN);
     return b == 12 || b == 13;
@@ -1809,7 +1847,7 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
 // tensor mode, the four inputs of the product shared by the two components of an entry (two per component)
 static double rows_bytes(dim3 grid, const NttArgs &A, int logb) {
     const double entries = A.epi_tensor ? 2.0 * A.zsplit : (A.nbatch_prof > 0 ? (double)A.nbatch_prof : (double)grid.x);
-    double streams = 2.0;
+    double streams = A.tprod ? 4.0 : 2.0;  // (product prologue: two inputs read, the product and the transform written)
     if (A.epi) streams += 1.0 + (A.epi_tensor ? 2.0 : (A.epi == 2 || (A.zsplit && A.epi2 == 2)) ? 1.0 : 0.0);
     return entries * grid.y * grid.z * (double)(1u << logb) * 8.0 * streams;
 }
@@ -1840,6 +1878,15 @@ static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStrea
 }
 template <bool INV>
 static hipError_t launch_rows_f64(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
+    if constexpr (INV) {
+        if (A.tprod) {  // product prologue (NttProdIn): production row sizes, one entry per workgroup
+            if (logb != 12 && logb != 13) return hipErrorInvalidValue;
+            ProfScope ps(K_NTT_ROWS_INV_F64, s, rows_bytes(grid, A, logb));
+            if (logb == 12) hipLaunchKernelGGL((ntt_rows_f64_kernel<12, true, true>), grid, dim3(256), 0, s, A);
+            else hipLaunchKernelGGL((ntt_rows_f64_kernel<13, true, true>), grid, dim3(512), 0, s, A);
+            return hipGetLastError();
+        }
+    }
 #define HE_ROWSF_CASE(B)                                                                          \
     case B:                                                                                       \
         { ProfScope ps(INV ? K_NTT_ROWS_INV_F64 : K_NTT_ROWS_FWD_F64, s, rows_bytes(grid, A, B));                         \
@@ -1878,12 +1925,13 @@ static hipError_t launch_rows(int logb, dim3 grid, const NttArgs &A, const uint8
         // entries per workgroup (inverse only): 2 while the launch still has well over the ~1500 workgroups that fill the chip
         static const int forced = getenv("HERING_ROWS_ITERS") ? atoi(getenv("HERING_ROWS_ITERS")) : 0;
         const size_t wgs = (size_t)grid.x * P[2].tab.n * grid.z;
-        int iters = (!INV || logb > 12) ? 1 : forced > 0 ? forced : (wgs >= 6144 ? 2 : 1);
+        int iters = (!INV || logb > 12 || P[2].tprod) ? 1 : forced > 0 ? forced : (wgs >= 6144 ? 2 : 1);
         if (iters > (int)grid.x) iters = (int)grid.x;
         P[2].nbatch = (int)grid.x; P[2].iters = iters; P[2].nbatch_prof = (int)grid.x;
         dim3 g2((grid.x + iters - 1) / iters, P[2].tab.n, grid.z);
         e = launch_rows_f64<INV>(logb, g2, P[2], s);
     }
+    P[0].tprod = P[1].tprod = 0;  // (the integer kernels read their input as it is)
     if (e == hipSuccess && P[1].tab.n) { dim3 g2(grid.x, P[1].tab.n, grid.z); e = launch_rows_nc<INV, true>(logb, g2, P[1], s); }
     if (e == hipSuccess && P[0].tab.n) { dim3 g2(grid.x, P[0].tab.n, grid.z); e = launch_rows_nc<INV, false>(logb, g2, P[0], s); }
     return e;
@@ -1988,11 +2036,12 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
 }
 
 hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
-                           hipStream_t s, const NttEpilogue *epi) {
+                           hipStream_t s, const NttEpilogue *epi, const NttProdIn *prod) {
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     const int n = r.logN;
     if (n < 4 || n > 17) return hipErrorInvalidValue;
     if (epi && inverse) return hipErrorInvalidValue;
+    if (prod && (!inverse || !r.twd_inv || !ntt_prod_in_supported(n))) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
     NttArgs A;
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
@@ -2007,6 +2056,12 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     }
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
     A.flags = flags;
+    if (prod) {
+        A.tprod = 1;
+        A.ta1 = prod->a.p; A.ta1_bs = prod->a.bstride; A.tb1 = prod->b.p; A.tb1_bs = prod->b.bstride;
+        A.out2 = prod->c.p; A.out2_bs = prod->c.bstride;
+        for (int i = 0; i < tab.n; i++) A.epi_ts[i] = prod->ts[i];
+    }
     // tensor mode: both components of 8 entries per 16 consecutive workgroups (see NttEpilogue::tensor)
     dim3 grows(A.epi_tensor ? (unsigned)((epi->zsplit + 7) / 8 * 16) : (unsigned)batch, tab.n, 1u << a);
     if (!inverse) {

@@ -168,7 +168,10 @@ def test_byte_accounting_matches_the_survey_formulas(ctx):
     gev.BGVMulRelin(L - 1, t, a, b, rlk, out)
     prof = ctx.prof_end_bytes()
     small_q = sum(m < (1 << 47) for m in q)
-    assert prof["tensor"][2] == 3 * L * limb * B
+    # c2 = T(a1, b1): the tensor kernel on the integer-class limbs, the inverse rows themselves on the others (two inputs in, c2
+    # and the transform out)
+    assert prof["tensor"][2] == 3 * (L - small_q) * limb * B
+    assert prof["ntt_rows_inv_f64"][2] == 4 * small_q * limb * B
     assert prof["modup"][2] == (L + (beta * (L + alpha) - L) + 2 * alpha + 2 * L) * limb * B
     # the ModDown epilogue of the double-precision limbs runs inside the NTT + MAC kernel (no special prime is below 2^47): beta
     # digits in, two key rows per digit for the batch, then two extension rows + the four inputs of the product in, two outputs
