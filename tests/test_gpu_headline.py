@@ -98,7 +98,7 @@ def test_full_size_mulrelin_aliasing_squaring_lazy_inputs(ctx, scheme):
     wild = lambda: np.stack([np.stack([rng.integers(0, 1 << 63, size=N, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=N, dtype=np.uint64)
                                        for _ in q]) for _ in range(B)])
     ct0 = [bench.uniform(rng, q, N, (B,)), lazy()]   # [k][b][limb][N]; the second component holds words up to 2q - 1
-    ct1 = [wild(), bench.uniform(rng, q, N, (B,))]
+    ct1 = [wild(), wild()]  # (b1 too: the product prologue of the inverse rows and component 1 of the epilogue meet such words)
     want = [omul(np.stack([ct0[0][e], ct0[1][e]]), np.stack([ct1[0][e], ct1[1][e]])) for e in range(B)]
     want_sq = [omul(np.stack([ct0[0][e], ct0[1][e]]), np.stack([ct0[0][e], ct0[1][e]])) for e in range(B)]
 
