@@ -1635,3 +1635,41 @@ double lo_bench_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, cons
                               const lo_evk *rlk, int nthreads, double seconds, uint64_t *counts) {
     return lo_bench_op(e, 0, level, t, 0, op0, op1, rlk, nthreads, seconds, 1, 1, counts);
 }
+
+/* Checker for whole batches (bench.py / tests verify EVERY entry of a timed batch): entry b of `nb` independent inputs through
+ * the same operation kinds as lo_bench_op, entries dealt round-robin to `nthreads` OS threads.  op0 / op1: [nb][2][level+1][N];
+ * out: [nb][ncomp][level_out+1][N] with (ncomp, level_out) = (2, level) for kinds 0 / 1 and (3, level - 1) for kind 2. */
+typedef struct {
+    int kind, tid, nthreads, nb;
+    const lo_evaluator *e; int level; uint64_t t, gal; const uint64_t *op0, *op1; const lo_evk *key; uint64_t *out;
+} batch_arg;
+static void *batch_worker(void *vp) {
+    batch_arg *a = (batch_arg *)vp;
+    const int N = a->e->ringQ->N;
+    const size_t sz = (size_t)(a->level + 1) * N;
+    const size_t osz = a->kind == 2 ? 3 * (size_t)a->level * N : 2 * sz;
+    uint64_t *tmp = a->kind == 2 ? (uint64_t *)malloc(3 * sz * 8) : NULL;
+    for (int b = a->tid; b < a->nb; b += a->nthreads) {
+        const uint64_t *x0 = a->op0 + (size_t)b * 2 * sz, *x1 = a->op1 ? a->op1 + (size_t)b * 2 * sz : NULL;
+        uint64_t *o = a->out + (size_t)b * osz;
+        if (a->kind == 0) lo_bgv_mul_relin(a->e, a->level, a->t, x0, x1, a->key, 1, o);
+        else if (a->kind == 1) lo_automorphism_ct(a->e, a->level, x0, a->gal, a->key, o);
+        else { lo_ckks_mul_relin(a->e, a->level, x0, x1, NULL, 0, tmp); lo_rescale(a->e->ringQ, a->level, 2, 1, tmp, o); }
+    }
+    free(tmp);
+    lo_pool_release();
+    return NULL;
+}
+void lo_batch_op(const lo_evaluator *e, int kind, int level, uint64_t t, uint64_t gal, const uint64_t *op0, const uint64_t *op1,
+                 const lo_evk *key, int nb, int nthreads, uint64_t *out) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > nb) nthreads = nb;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    batch_arg *args = (batch_arg *)calloc(nthreads, sizeof(batch_arg));
+    for (int i = 0; i < nthreads; i++) {
+        args[i] = (batch_arg){kind, i, nthreads, nb, e, level, t, gal, op0, op1, key, out};
+        pthread_create(&th[i], NULL, batch_worker, &args[i]);
+    }
+    for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+    free(th); free(args);
+}

@@ -231,6 +231,10 @@ void lo_rescale(const lo_ring *r, int level, int degree, int nb_rescales, const 
 void lo_pool_release(void);
 double lo_bench_bgv_mul_relin(const lo_evaluator *e, int level, uint64_t t, const uint64_t *op0, const uint64_t *op1,
                               const lo_evk *rlk, int nthreads, double seconds, uint64_t *counts);
+/* every entry of a batch through one operation kind of lo_bench_op, on nthreads OS threads (checker for timed batches):
+ * op0 / op1 [nb][2][level+1][N] -> out [nb][2][level+1][N] (kinds 0, 1) or [nb][3][level][N] (kind 2) */
+void lo_batch_op(const lo_evaluator *e, int kind, int level, uint64_t t, uint64_t gal, const uint64_t *op0, const uint64_t *op1,
+                 const lo_evk *key, int nb, int nthreads, uint64_t *out);
 /* generalised form: kind 0 BGV MulRelin, 1 Automorphism (Rotate), 2 CKKS Mul + Rescale; pin = one CPU per thread,
  * private_copy = per-thread first-touched copies of the inputs and the key (see lattigo_oracle.c) */
 double lo_bench_op(const lo_evaluator *e, int kind, int level, uint64_t t, uint64_t gal, const uint64_t *op0, const uint64_t *op1,

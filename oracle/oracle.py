@@ -143,6 +143,7 @@ def _declare(L):
     L.lo_bench_bgv_mul_relin.restype = C.c_double
     L.lo_bench_op.argtypes = [vp, i, i, u64, u64, u64p, u64p, ep, i, C.c_double, i, i, u64p]
     L.lo_bench_op.restype = C.c_double
+    L.lo_batch_op.argtypes = [vp, i, i, u64, u64, u64p, u64p, ep, i, i, u64p]
 
 
 def _p(a: np.ndarray):
@@ -722,6 +723,26 @@ class Evaluator:
         dt = lib().lo_bench_op(self._h, kinds[kind], level, t, gal, _p(op0), _p(op1) if op1 is not None else None,
                                key.ref() if key else None, nthreads, float(seconds), int(pin), int(private_copy), _p(counts))
         return int(counts.sum()), float(dt)
+
+    def BatchOp(self, kind: str, op0, op1=None, key: EvaluationKey | None = None, t: int = 0, gal: int = 0, nthreads: int = 0):
+        """Every entry of a batch through one operation (lo_batch_op): op0 / op1 [B][2][L][N] -> [B][2][L][N] ("bgv_mulrelin",
+        "rotate") or [B][3][L-1][N] ("ckks_mul_rescale"), entries dealt to `nthreads` OS threads (default: the CPUs this process
+        may use).  The checker for whole timed batches (bench.py, tests/test_gpu_headline.py)."""
+        kinds = {"bgv_mulrelin": 0, "rotate": 1, "ckks_mul_rescale": 2}
+        op0 = _c(op0)
+        op1 = _c(op1) if op1 is not None else None
+        B, level = op0.shape[0], op0.shape[2] - 1
+        if nthreads <= 0:
+            try:
+                nthreads = len(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                nthreads = os.cpu_count() or 1
+            nthreads = min(nthreads, 32)
+        shape = (B, 3, level, self.ringQ.N) if kind == "ckks_mul_rescale" else (B, 2, level + 1, self.ringQ.N)
+        out = np.zeros(shape, dtype=np.uint64)
+        lib().lo_batch_op(self._h, kinds[kind], level, t, gal, _p(op0), _p(op1) if op1 is not None else None,
+                          key.ref() if key else None, B, nthreads, _p(out))
+        return out
 
     def Rescale(self, ct, nb=1):
         ct = _c(ct)

@@ -2,9 +2,10 @@
 
 * BASELINE config 3 exactly as bench.py runs it (same moduli, T, launch shapes): BGV ct x ct MulRelin at logN=15,
   12+3 limbs, at the batch sizes whose launch configurations differ (batch 9: odd, one entry per workgroup;
-  batch 128: bench default, two-entries-per-workgroup inverse rows, XCD-swizzled NTT+MAC, wide fused ModDown),
-  every limb of the first / middle / last batch entry against the oracle (schemes/bgv/evaluator.go:592-685), plus
-  Relinearize(degree-2 result) == MulRelin.
+  batch 128: two-entries-per-workgroup inverse rows, XCD-swizzled NTT+MAC, wide fused ModDown; batch 256: the bench
+  default -- persistent 512-workgroup NTT+MAC work list; batch 255: the same list without the XCD swizzle, ragged tail),
+  every limb of EVERY batch entry against the oracle (schemes/bgv/evaluator.go:592-685; oracle.Evaluator.BatchOp on the
+  host's cores), plus Relinearize(degree-2 result) == MulRelin.
 * Boundary moduli of the two fast arithmetic classes: the largest NTT-friendly primes below 2^47 (double-precision
   kernels, exactness argument "34q + input < 2^53") and below 2^58 (correction-free integer butterflies,
   "34q / 36q < 2^64") at logN = 16 and 17, on worst-case inputs (all q-1, alternating 0 / q-1, non-canonical words up
@@ -33,7 +34,7 @@ def test_bench_moduli_are_the_restated_GenModuli():
     assert list(oq) == q and list(op) == p
 
 
-@pytest.mark.parametrize("B", [9, 128])
+@pytest.mark.parametrize("B", [9, 128, 255, 256])
 def test_full_size_config3_bgv_mulrelin_logN15(ctx, B):
     logN, q, p, t = _bench_config()
     N, L, alpha = 1 << logN, len(q), len(p)
@@ -52,9 +53,12 @@ def test_full_size_config3_bgv_mulrelin_logN15(ctx, B):
     out = [la.Poly(pr.gQ, L, B), la.Poly(pr.gQ, L, B)]
     gev.BGVMulRelin(L - 1, t, a, b, grlk, out)
     got = [o.get() for o in out]
-    for e in sorted({0, B // 2, B - 1}):
-        want = oev.BGVMulRelin(t, np.stack([ct0[0][e], ct0[1][e]]), np.stack([ct1[0][e], ct1[1][e]]), orlk, True)
-        assert np.array_equal(got[0][e], want[0]) and np.array_equal(got[1][e], want[1]), (B, e)
+    for b0 in range(0, B, 64):  # every entry, in chunks that bound the host copies
+        b1 = min(B, b0 + 64)
+        want = oev.BatchOp("bgv_mulrelin", np.stack([ct0[0][b0:b1], ct0[1][b0:b1]], axis=1),
+                           np.stack([ct1[0][b0:b1], ct1[1][b0:b1]], axis=1), orlk, t=t)
+        for k in range(2):
+            assert np.array_equal(got[k][b0:b1], want[:, k]), (B, k, b0 + int(np.argwhere(got[k][b0:b1] != want[:, k])[0][0]))
     # the degree-2 result relinearised separately is the same ciphertext (core/rlwe/evaluator_evaluationkey.go:117-148)
     out3 = [la.Poly(pr.gQ, L, B) for _ in range(3)]
     gev.BGVMulRelin(L - 1, t, a, b, None, out3)
