@@ -401,6 +401,94 @@ def setup_c5(la, ctx, rank, B, cp, args):
     }
 
 
+def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), iters=40, max_batch=64, window_us=30):
+    """What the reference's own interface delivers: its operator API takes ONE ciphertext per call (schemes/schemes.go:14-28) and
+    scales by concurrent callers (b.RunParallel over evaluators sharing tables and keys, schemes/ckks/ckks_benchmarks_test.go:
+    116-207).  K OS threads (pthreads inside the library, he_debug_concurrent_mul_relin), each repeating MulRelin on its own
+    batch-1 ciphertexts at the headline shape:
+      * separate_contexts: one context (= HIP stream), ring, evaluator and key copy per caller -- K independent streams of
+        single-ciphertext launches sharing the GPU (what existed before round 4);
+      * coalesced: all callers on ONE evaluator with its submission queue on (he_evaluator_set_coalescing): calls waiting at
+        the same time become one batched launch over the callers' own polynomials;
+      * coalesced_sync_each: the same with every caller waiting for its result (he_ctx_sync) before its next call.
+    Every caller's output is compared with the oracle afterwards."""
+    from lattigo_amd.rlwe import ConcurrentMulRelin
+    from oracle import oracle as O
+    N = 1 << LOGN
+    q, p = gen_moduli()
+    L, alpha = len(q), len(p)
+    beta = (L + alpha - 1) // alpha
+    kmax = max(ks)
+    rng = np.random.Generator(np.random.PCG64(0x1A77160 + 77))
+    kq, kp = uniform(rng, q, N, (beta, 2)), uniform(rng, p, N, (beta, 2))
+    host = [uniform(rng, q, N, (kmax,)) for _ in range(4)]  # a0, a1, b0, b1: [K][L][N]
+    want = O.Evaluator(O.Ring(N, q), O.Ring(N, p)).BatchOp(
+        "bgv_mulrelin", np.stack([host[0], host[1]], axis=1), np.stack([host[2], host[3]], axis=1), O.EvaluationKey(kq, kp), t=T)
+
+    def callers_on(c, n):
+        ringQ, ringP = la.Ring(c, N, q), la.Ring(c, N, p)
+        ev = la.Evaluator(ringQ, ringP)
+        rlk = ev.NewEvaluationKey(kq, kp)
+        mk = lambda k: ([la.Poly(ringQ, L).upload(host[0][k]), la.Poly(ringQ, L).upload(host[1][k])],
+                        [la.Poly(ringQ, L).upload(host[2][k]), la.Poly(ringQ, L).upload(host[3][k])],
+                        [la.Poly(ringQ, L, zero=False), la.Poly(ringQ, L, zero=False)])
+        return ev, rlk, [mk(k) for k in n]
+
+    def check(callers, base=0):
+        for i, cl in enumerate(callers):
+            got = np.stack([o.download()[0] for o in cl[5]])
+            if not np.array_equal(got, want[base + i]):
+                return False
+        return True
+
+    out = {"K": list(ks), "iters_per_caller": iters, "max_batch": max_batch, "window_us": window_us, "unit": "ctxt-mul+relin ops/s",
+           "note": "K OS threads, one batch-1 MulRelin per call (he_debug_concurrent_mul_relin); host wall clock from the common "
+                   "start to the last caller's final sync"}
+    ok = True
+    # one shared evaluator, submission queue on
+    ev, rlk, cs = callers_on(ctx, range(kmax))
+    shared = [(ctx, ev, a, b, rlk, o) for a, b, o in cs]
+    ev.SetCoalescing(max_batch, window_us)
+    for name, sync_each in (("coalesced", False), ("coalesced_sync_each", True)):
+        rates = []
+        for K in ks:
+            ConcurrentMulRelin(shared[:K], L - 1, 3, t=T, sync_each=sync_each)
+            for cl in shared[:K]:
+                cl[5][0].Zero(); cl[5][1].Zero()
+            s0 = ev.CoalescingStats()
+            wall = ConcurrentMulRelin(shared[:K], L - 1, iters, t=T, sync_each=sync_each)
+            s1 = ev.CoalescingStats()
+            rates.append(K * iters / wall)
+            out.setdefault(name + "_mean_batch", []).append((s1["calls"] - s0["calls"]) / max(1, s1["launches"] - s0["launches"]))
+            ok = ok and check(shared[:K])
+        out[name] = rates
+    ev.SetCoalescing(0, 0)
+    # the same handles with the queue off: K threads serialising on one context's stream
+    rates = []
+    for K in ks:
+        ConcurrentMulRelin(shared[:K], L - 1, 3, t=T)
+        wall = ConcurrentMulRelin(shared[:K], L - 1, iters, t=T)
+        rates.append(K * iters / wall)
+        ok = ok and check(shared[:K])
+    out["one_context_uncoalesced"] = rates
+    del shared, cs, ev, rlk
+    # one context per caller
+    sep = []
+    for k in range(kmax):
+        c = la.Context(ctx.device_id)
+        e, r, cl = callers_on(c, [k])
+        sep.append((c, e, cl[0][0], cl[0][1], r, cl[0][2]))
+    rates = []
+    for K in ks:
+        ConcurrentMulRelin(sep[:K], L - 1, 3, t=T)
+        wall = ConcurrentMulRelin(sep[:K], L - 1, iters, t=T)
+        rates.append(K * iters / wall)
+        ok = ok and check(sep[:K])
+    out["separate_contexts"] = rates
+    out["verified"] = bool(ok)
+    return out
+
+
 # default batches from sweeps on MI355X (round 3): c2 128 / 256 / 512 / 1024 / 2048: 204k / 223k / 243k / 257k / 263k (a logN = 14, 8-limb
 # ciphertext is small: the launches need the larger batch to fill the chip); c3 64 / 128 / 192 / 256 / 512: 33.9k / 36.6k / 37.5k /
 # 37.8k / 38.0k on one box (the persistent NTT+MAC kernel's tail shrinks with more items per workgroup; flat beyond 256);
@@ -443,6 +531,7 @@ def main():
                     help="skip the per-kernel HIP-event leg (and with it the roofline object): for runs under rocprofv3 --pmc, whose "
                          "counter collection does not survive the tens of thousands of events a bootstrap trace records")
     ap.add_argument("--no-b1", action="store_true", help="skip the single-ciphertext (batch 1) rate / latency measurement")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent single-ciphertext callers measurement (c3)")
     ap.add_argument("--replicate-keys", choices=["auto", "none", "rccl", "host"], default="auto",
                     help="N > 1: rank 0's evaluation key is replicated to every rank before the timed region (RCCL broadcast "
                          "into the key's device storage, or gloo through host memory) instead of each rank drawing its own; "
@@ -592,8 +681,6 @@ def main():
         "ranks_seen": ranks_seen, "replicate_keys": args.replicate_keys,
         "roofline": roofline,
     }
-    if problems:
-        line["accounting_problems"] = problems
     if not args.no_b1 and world == 1 and args.workload != "c5" and B != 1:
         # single-ciphertext figures ("report best and B=1"): the same operation on ONE ciphertext
         W1 = setup(la, ctx, rank, 1, cp, args)
@@ -622,6 +709,14 @@ def main():
         line["b1"] = {"batch": 1, "ops_per_s": 1.0 / dt1, "latency_ms": dt1 * 1e3, "note": "one ciphertext per bootstrap"}
         line["b1"]["graph"] = graph_replay(la, ctx, W1["step"], 5)
         del W1
+    if not args.no_concurrent and world == 1 and args.workload == "c3":
+        try:
+            line["concurrent_b1"] = concurrent_b1(la, ctx)
+            if line["concurrent_b1"]["verified"] is False:
+                problems.append("concurrent_b1: a caller's output differs from the oracle")
+        except la.HeringError as e:
+            line["concurrent_b1"] = {"error": str(e)}
+            problems.append(f"concurrent_b1 failed: {e}")
     if not args.no_ntt:
         line["ntt"] = ntt_rates(la, ctx)
         line["ntt_limb_per_s"] = line["ntt"]["logN15_L12"]["limb_ntt_per_s"]
@@ -637,6 +732,8 @@ def main():
             line["cpu_baseline"] = W["cpu"]()
         except Exception as e:  # the oracle is optional test infrastructure
             line["cpu_baseline"] = {"error": str(e)}
+    if problems:
+        line["accounting_problems"] = problems
     print(json.dumps(line), flush=True)
     cp.close()
     if verified is False:

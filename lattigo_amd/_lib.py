@@ -123,6 +123,8 @@ def _declare(L):
         "he_alg_bytes": [H, i, C.POINTER(C.c_double)],
         "he_graph_begin": [H], "he_graph_end": [H, HP], "he_graph_launch": [H], "he_graph_nodes": [H, C.POINTER(i)],
         "he_graph_destroy": [H],
+        "he_evaluator_set_coalescing": [H, i, i], "he_evaluator_coalescing_stats": [H, u64p],
+        "he_debug_concurrent_mul_relin": [i, i, i, i, i, C.c_uint64, HP, HP, HP, HP, HP, HP, HP, HP, HP, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +23,8 @@
 #include <unordered_map>
 #include <cstdlib>
 #include <vector>
+#include <pthread.h>
+#include <sched.h>
 
 #include "../../include/hering.h"
 #include "../../include/hering_debug.h"
@@ -356,8 +361,43 @@ struct FusedPlan {
     bool ok = false;
     std::vector<FusedGroup> groups;
 };
+// Submission queue of an evaluator (he_evaluator_set_coalescing): concurrent single-ciphertext calls of one operation are
+// gathered into ONE batched launch over an entry table of the callers' own polynomials (View::tab).  The reference's unit of
+// parallelism is a goroutine per ciphertext on CPU cores (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:116-207, over
+// evaluators that share their tables, core/rlwe/evaluator.go:200-227); a GPU wants those callers in one grid.  Flat combining:
+// a caller files its request; whoever finds no leader becomes the leader, gathers for at most `window_us` (no limit while two
+// earlier batches are still in flight on the device -- waiting is free then), launches every pending request of the oldest
+// request's key as one batch, marks them done and hands the role over.  A call returns once its batch is ENQUEUED on the
+// context's stream (the library's usual contract: results are visible after he_ctx_sync / a download).
+struct Poly;
+struct Evk;
+struct CoReq {
+    // key: requests are batched together only when all of this matches
+    int level = 0;
+    bool bgv = false, alias = false;
+    uint64_t t = 0;
+    std::shared_ptr<Evk> key;
+    std::shared_ptr<Poly> a0, a1, b0, b1, o0, o1;
+    std::chrono::steady_clock::time_point arrived;
+    bool done = false;
+    int rc = 0;
+    std::string err;
+    bool same_key(const CoReq &o) const { return level == o.level && bgv == o.bgv && alias == o.alias && t == o.t && key == o.key; }
+};
+struct Coalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<CoReq *> pending;
+    bool leader = false;
+    int max_batch = 0, window_us = 0;
+    size_t *d_tab = nullptr;  // [6][max_batch] entry offsets; one table is enough (stream order, see launch_tab_fill)
+    std::deque<hipEvent_t> inflight;  // one event per launched batch, oldest first
+    std::vector<hipEvent_t> free_events;
+    uint64_t n_calls = 0, n_launches = 0, n_max = 0, n_fallback = 0;  // he_evaluator_coalescing_stats
+};
 struct Evaluator : Obj {
     std::shared_ptr<BasisExtender> be;
+    std::unique_ptr<Coalescer> co;
     ConstPool pool;
     // automorphism index tables by Galois element, built on first use and kept (the reference caches them the same way:
     // Evaluator.automorphismIndex, core/rlwe/evaluator.go:81-86,:190-205); N x 4 bytes each
@@ -374,6 +414,11 @@ struct Evaluator : Obj {
         hipStreamSynchronize(be->ctx->stream);
         for (ModUpDesc *p : plan_mem) hipFree(p);
         for (auto &kv : auto_index) hipFree(kv.second);
+        if (co) {
+            if (co->d_tab) hipFree(co->d_tab);
+            for (hipEvent_t e : co->inflight) hipEventDestroy(e);
+            for (hipEvent_t e : co->free_events) hipEventDestroy(e);
+        }
         pool.release();
     }
 };
@@ -1433,6 +1478,39 @@ int he_evaluator_create(he_handle hq, he_handle hp, he_handle *out) {
     return HE_OK;
 }
 int he_evaluator_destroy(he_handle h) { return unreg(h, T_EVAL); }
+int he_evaluator_set_coalescing(he_handle h, int max_batch, int window_us) {
+    GET(ev, Evaluator, h, T_EVAL);
+    if (max_batch < 0 || max_batch > 1024 || window_us < 0 || window_us > 100000)
+        return fail(HE_EINVAL, "he_evaluator_set_coalescing: max_batch in [0, 1024], window_us in [0, 100000]");
+    Ctx *c = ev->be->ctx.get();
+    Scope sc(c);
+    if (ev->co) {
+        std::lock_guard<std::mutex> lk(ev->co->mu);
+        if (!ev->co->pending.empty() || ev->co->leader) return fail(HE_EINVAL, "he_evaluator_set_coalescing: calls are in flight on this evaluator");
+    }
+    if (max_batch <= 1) {  // off: later calls launch directly (the object stays: another thread may be looking at it)
+        if (ev->co) { std::lock_guard<std::mutex> lk(ev->co->mu); ev->co->max_batch = 0; }
+        return HE_OK;
+    }
+    if (!ev->co) ev->co.reset(new Coalescer());
+    std::lock_guard<std::mutex> lk(ev->co->mu);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // launches that read the old table
+    if (ev->co->d_tab) HIP_TRY(hipFree(ev->co->d_tab));
+    ev->co->d_tab = nullptr;
+    HIP_TRY(hipMalloc((void **)&ev->co->d_tab, (size_t)6 * max_batch * sizeof(size_t)));
+    ev->co->max_batch = max_batch;
+    ev->co->window_us = window_us;
+    return HE_OK;
+}
+int he_evaluator_coalescing_stats(he_handle h, uint64_t out[4]) {
+    GET(ev, Evaluator, h, T_EVAL);
+    if (!out) return fail(HE_EINVAL, "he_evaluator_coalescing_stats: null output");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!ev->co) return HE_OK;
+    std::lock_guard<std::mutex> lk(ev->co->mu);
+    out[0] = ev->co->n_calls; out[1] = ev->co->n_launches; out[2] = ev->co->n_max; out[3] = ev->co->n_fallback;
+    return HE_OK;
+}
 
 // double-precision copy of the key for the fused NTT+MAC kernel, when some key limb is below 2^47 (re-run after the key
 // words change: he_evk_commit)
@@ -2730,6 +2808,165 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
 }
 
 // CKKS mulRelin / BGV tensorStandard (schemes/ckks/evaluator.go:764-872, schemes/bgv/evaluator.go:592-685)
+// The launches of one call over B entries; the caller holds the context (Scope).  `alias`: some output is an input of its own
+// entry.  The views may carry entry tables (a coalesced batch) when mul_relin_tables_ok() said so.
+static int mul_relin_core(Evaluator &ev, int level, bool bgv, uint64_t t, Evk *k, View a0, View a1, View b0, View b1, View o0v, View o1v,
+                          View o2v, int B, bool alias) {
+    BasisExtender &be = *ev.be;
+    std::vector<uint64_t> sc_(level + 1);
+    for (int i = 0; i <= level; i++) {
+        const ModConst &m = be.Q->sub[i].mc;
+        if (bgv) {  // tMontgomery = MForm(t * 2^64 mod q)                     schemes/bgv/evaluator.go:59-62
+            const uint64_t w[2] = {0, t};
+            sc_[i] = mform(words_mod(w, 2, m.q), m.q, m.brc0, m.brc1);
+        } else {    // MForm(x) = MRed(x, 2^128 mod q)
+            sc_[i] = m.r2;
+        }
+    }
+    const int N = be.Q->N;
+    if (k) be.ctx->acct(6.0 * (level + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, N);  // MulRelin: 6 L + 2 beta (L + alpha)
+    else be.ctx->acct(7.0 * (level + 1), 0, B, N);                                                // Mul: 4 L in, 3 L out
+    const size_t wQ = (size_t)B * (level + 1) * N;
+    hipStream_t st = be.ctx->stream;
+    if (!k) {
+        HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0, a1, b0, b1, o0v, o1v, o2v, B, st));
+        return HE_OK;
+    }
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k) + wQ));
+    View c2{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
+    // With a fused ModDown the tensor kernel forms c2 only: c0 / c1 are computed from the inputs where they are added, in the
+    // ModDown epilogue (24 limbs of writes and 24 of reads fewer; the inputs' second read comes from L2).  Not when an output
+    // aliases an input: the epilogue of one component would overwrite words the other still reads.
+    static const bool no_fuse = getenv("HERING_NO_TENSOR_EPILOGUE") && atoi(getenv("HERING_NO_TENSOR_EPILOGUE")) != 0;
+    const FusedPlan *mdplan = nullptr;
+    const bool may_fuse = k->nPk > 0 && !alias && !no_fuse;  // a P-less (base-2) key has no ModDown to fuse into
+    if (may_fuse) TRY(get_md_plan(ev, level, k->nPk - 1, &mdplan));
+    if (may_fuse && mdplan->ok) {
+        // (c2 = T(a1, b1) is formed on the way: by the inverse row pass for the double-precision limbs, by the tensor kernel for the others)
+        TensorIn tin{a0, a1, b0, b1, sc_.data(), true};
+        return gadget_product_core(ev, level, &c2, nullptr, *k, o0v, o1v, B, nullptr, nullptr, true, &tin);
+    }
+    HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0, a1, b0, b1, o0v, o1v, c2, B, st));
+    return gadget_product_core(ev, level, &c2, nullptr, *k, o0v, o1v, B, &o0v, &o1v, true);  // c2 from the tensor kernel: canonical
+}
+// May a coalesced MulRelin address its callers' polynomials through entry tables?  Every launch that touches them must be one
+// of the table-capable ones (kernels.h, View::tab): that is the case exactly when ModDown runs through the fused plan -- then
+// the inputs are read by the tensor kernel, the product prologue and the epilogues only, and the outputs written by the epilogues.
+static int mul_relin_tables_ok(Evaluator &ev, int level, const Evk &k, bool *ok) {
+    *ok = false;
+    if (k.nPk <= 0) return HE_OK;
+    const FusedPlan *mdplan = nullptr;
+    TRY(get_md_plan(ev, level, k.nPk - 1, &mdplan));
+    *ok = mdplan->ok;
+    return HE_OK;
+}
+
+namespace {
+// ---- coalescing of concurrent single-ciphertext calls (struct Coalescer) ---------------------------------------------
+int co_inflight(Coalescer &c) {  // batches still running or queued on the device (caller holds c.mu)
+    while (!c.inflight.empty() && hipEventQuery(c.inflight.front()) == hipSuccess) {
+        c.free_events.push_back(c.inflight.front());
+        c.inflight.pop_front();
+    }
+    (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    return (int)c.inflight.size();
+}
+// one batched launch for `batch` (all of one key); returns the status every request of the batch gets
+int co_run(Evaluator &ev, Coalescer &c, const std::vector<CoReq *> &batch, hipEvent_t done_ev) {
+    BasisExtender &be = *ev.be;
+    const CoReq &r0 = *batch[0];
+    const int B = (int)batch.size(), N = be.Q->N;
+    Scope sc(be.ctx.get());
+    bool tables = false;
+    if (B > 1) TRY(mul_relin_tables_ok(ev, r0.level, *r0.key, &tables));
+    int rc = HE_OK;
+    if (B == 1 || !tables) {
+        // one entry, or a shape whose pipeline has launches without entry tables (unfused ModDown): one call per request
+        if (B > 1) c.n_fallback += (uint64_t)B;
+        for (CoReq *r : batch) {
+            be.ctx->arena_reset();
+            rc = mul_relin_core(ev, r->level, r->bgv, r->t, r->key.get(), r->a0->view(), r->a1->view(), r->b0->view(), r->b1->view(),
+                                r->o0->view(), r->o1->view(), View{nullptr, 0}, 1, r->alias);
+            if (rc != HE_OK) break;
+        }
+    } else {
+        // entry tables: row s of the table holds, per entry, the word offset of that entry's polynomial from entry 0's
+        std::vector<size_t> vals((size_t)6 * B);
+        const std::shared_ptr<Poly> CoReq::*slot[6] = {&CoReq::a0, &CoReq::a1, &CoReq::b0, &CoReq::b1, &CoReq::o0, &CoReq::o1};
+        View v[6];
+        for (int sidx = 0; sidx < 6; sidx++) {
+            uint64_t *base = ((*batch[0]).*slot[sidx])->d;
+            for (int z = 0; z < B; z++) vals[(size_t)sidx * B + z] = (size_t)((((*batch[z]).*slot[sidx])->d) - base);
+            v[sidx] = View{base, 0, c.d_tab + (size_t)sidx * B};
+        }
+        HIP_TRY(launch_tab_fill(c.d_tab, vals.data(), 6 * B, be.ctx->stream));
+        rc = mul_relin_core(ev, r0.level, r0.bgv, r0.t, r0.key.get(), v[0], v[1], v[2], v[3], v[4], v[5], View{nullptr, 0}, B, r0.alias);
+    }
+    (void)N;
+    if (rc == HE_OK && done_ev) HIP_TRY(hipEventRecord(done_ev, be.ctx->stream));
+    return rc;
+}
+// the calling thread is the leader: serve batches until its own request is done (caller holds lk on c.mu)
+void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mine) {
+    using clock = std::chrono::steady_clock;
+    hipSetDevice(ev.be->ctx->dev);
+    while (!mine.done) {
+        // gather: up to max_batch requests, for at most window_us after the oldest arrived -- or for as long as the device
+        // still has two batches of this queue ahead of it
+        for (;;) {
+            if ((int)c.pending.size() >= c.max_batch) break;
+            const bool busy = co_inflight(c) >= 2;
+            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - c.pending.front()->arrived).count();
+            if (!busy && waited >= c.window_us) break;
+            if (busy) {
+                c.cv.wait_for(lk, std::chrono::microseconds(100));  // arrivals notify
+            } else {  // a few microseconds: a timed futex wait would oversleep by the timer slack
+                lk.unlock();
+                sched_yield();
+                lk.lock();
+            }
+        }
+        std::vector<CoReq *> batch;
+        const CoReq &head = *c.pending.front();
+        for (auto it = c.pending.begin(); it != c.pending.end() && (int)batch.size() < c.max_batch;) {
+            if ((*it)->same_key(head)) { batch.push_back(*it); it = c.pending.erase(it); }
+            else ++it;
+        }
+        hipEvent_t e = nullptr;
+        if (!c.free_events.empty()) { e = c.free_events.back(); c.free_events.pop_back(); }
+        else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
+        lk.unlock();
+        const int rc = co_run(ev, c, batch, e);
+        const std::string msg = rc ? g_err : std::string();
+        lk.lock();
+        if (e) { if (rc == HE_OK) c.inflight.push_back(e); else c.free_events.push_back(e); }
+        for (CoReq *r : batch) { r->rc = rc; r->err = msg; r->done = true; }
+        c.cv.notify_all();
+    }
+}
+int co_submit(Evaluator &ev, CoReq &r) {
+    Coalescer &c = *ev.co;
+    std::unique_lock<std::mutex> lk(c.mu);
+    r.arrived = std::chrono::steady_clock::now();
+    c.pending.push_back(&r);
+    c.cv.notify_all();  // a gathering leader counts arrivals
+    while (!r.done) {
+        if (!c.leader) {
+            c.leader = true;
+            co_lead(ev, c, lk, r);
+            c.leader = false;
+            c.cv.notify_all();  // whoever still waits takes over
+        } else {
+            c.cv.wait(lk);
+        }
+    }
+    lk.unlock();
+    if (r.rc != HE_OK) return fail(r.rc, "%s", r.err.c_str());
+    return HE_OK;
+}
+}  // namespace
+
 static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_handle ha0, he_handle ha1, he_handle hb0, he_handle hb1,
                             he_handle hk, he_handle hout0, he_handle hout1, he_handle hout2, const char *who) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -2759,48 +2996,20 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
         TRY(check_be_poly(*p, be, level + 1, who));
         if (p->batch != B) return fail(HE_EINVAL, "%s: batch mismatch", who);
     }
-    std::vector<uint64_t> sc_(level + 1);
-    for (int i = 0; i <= level; i++) {
-        const ModConst &m = be.Q->sub[i].mc;
-        if (bgv) {  // tMontgomery = MForm(t * 2^64 mod q)                     schemes/bgv/evaluator.go:59-62
-            const uint64_t w[2] = {0, t};
-            sc_[i] = mform(words_mod(w, 2, m.q), m.q, m.brc0, m.brc1);
-        } else {    // MForm(x) = MRed(x, 2^128 mod q)
-            sc_[i] = m.r2;
-        }
-    }
-    Scope sc(be.ctx.get());
-    const int N = be.Q->N;
-    if (k) be.ctx->acct(6.0 * (level + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, N);  // MulRelin: 6 L + 2 beta (L + alpha)
-    else be.ctx->acct(7.0 * (level + 1), 0, B, N);                                                // Mul: 4 L in, 3 L out
-    const size_t wQ = (size_t)B * (level + 1) * N;
-    hipStream_t st = be.ctx->stream;
-    if (!k) {
-        HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),
-                              out1->view(), out2->view(), B, st));
-        return HE_OK;
-    }
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k.get()) + wQ));
-    View c2{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
-    const View o0v = out0->view(), o1v = out1->view();
-    // With a fused ModDown the tensor kernel forms c2 only: c0 / c1 are computed from the inputs where they are added, in the
-    // ModDown epilogue (24 limbs of writes and 24 of reads fewer; the inputs' second read comes from L2).  Not when an output
-    // aliases an input: the epilogue of one component would overwrite words the other still reads.
-    static const bool no_fuse = getenv("HERING_NO_TENSOR_EPILOGUE") && atoi(getenv("HERING_NO_TENSOR_EPILOGUE")) != 0;
     bool alias = false;
     for (Poly *o : {out0.get(), out1.get()})
         for (Poly *in : {a0.get(), a1.get(), b0.get(), b1.get()}) alias = alias || o->d == in->d;
-    const FusedPlan *mdplan = nullptr;
-    const bool may_fuse = k->nPk > 0 && !alias && !no_fuse;  // a P-less (base-2) key has no ModDown to fuse into
-    if (may_fuse) TRY(get_md_plan(*ev, level, k->nPk - 1, &mdplan));
-    if (may_fuse && mdplan->ok) {
-        // (c2 = T(a1, b1) is formed on the way: by the inverse row pass for the double-precision limbs, by the tensor kernel for the others)
-        TensorIn tin{a0->view(), a1->view(), b0->view(), b1->view(), sc_.data(), true};
-        return gadget_product_core(*ev, level, &c2, nullptr, *k, o0v, o1v, B, nullptr, nullptr, true, &tin);
+    // a single-ciphertext MulRelin on an evaluator with a submission queue joins it (not while the context records a graph:
+    // a captured sequence must be this thread's own launches)
+    if (k && B == 1 && ev->co && ev->co->max_batch > 1 && !be.ctx->capturing) {
+        CoReq r;
+        r.level = level; r.bgv = bgv; r.t = bgv ? t : 0; r.alias = alias; r.key = k;
+        r.a0 = a0; r.a1 = a1; r.b0 = b0; r.b1 = b1; r.o0 = out0; r.o1 = out1;
+        return co_submit(*ev, r);
     }
-    HIP_TRY(launch_tensor(be.qp, ident_tab(level + 1), sc_.data(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(),
-                          out1->view(), c2, B, st));
-    return gadget_product_core(*ev, level, &c2, nullptr, *k, o0v, o1v, B, &o0v, &o1v, true);  // c2 from the tensor kernel: canonical
+    Scope sc(be.ctx.get());
+    return mul_relin_core(*ev, level, bgv, t, k.get(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(), out1->view(),
+                          out2 ? out2->view() : View{nullptr, 0}, B, alias);
 }
 int he_ckks_mul_relin(he_handle ev, int level, he_handle a0, he_handle a1, he_handle b0, he_handle b1, he_handle rlk, he_handle o0, he_handle o1, he_handle o2) {
     return mul_relin_common(ev, level, false, 0, a0, a1, b0, b1, rlk, o0, o1, o2, "he_ckks_mul_relin");
@@ -2924,6 +3133,66 @@ int he_probe_modmul(he_handle hctx, int iters, double *out) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *out = (double)n * iters / (ms * 1e-3);
+    return HE_OK;
+}
+
+// concurrent single-ciphertext callers (hering_debug.h): the measurement harness of bench.py's `concurrent_b1`
+namespace {
+struct ConcArg {
+    int idx, iters, sync_each, bgv, level;
+    uint64_t t;
+    he_handle ctx, eval, a0, a1, b0, b1, rlk, o0, o1;
+    pthread_barrier_t *start;
+    double t0, t1;
+    int rc;
+    std::string err;
+};
+double mono_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+void *conc_worker(void *vp) {
+    ConcArg &a = *(ConcArg *)vp;
+    pthread_barrier_wait(a.start);
+    a.t0 = mono_s();
+    for (int i = 0; i < a.iters && a.rc == 0; i++) {
+        a.rc = a.bgv ? he_bgv_mul_relin(a.eval, a.level, a.t, a.a0, a.a1, a.b0, a.b1, a.rlk, a.o0, a.o1, 0)
+                     : he_ckks_mul_relin(a.eval, a.level, a.a0, a.a1, a.b0, a.b1, a.rlk, a.o0, a.o1, 0);
+        if (a.rc == 0 && a.sync_each) a.rc = he_ctx_sync(a.ctx);
+    }
+    if (a.rc == 0) a.rc = he_ctx_sync(a.ctx);
+    if (a.rc != 0) a.err = g_err;
+    a.t1 = mono_s();
+    return nullptr;
+}
+}  // namespace
+int he_debug_concurrent_mul_relin(int n_threads, int iters, int sync_each, int bgv, int level, uint64_t t, const he_handle *ctx,
+                                  const he_handle *eval, const he_handle *a0, const he_handle *a1, const he_handle *b0,
+                                  const he_handle *b1, const he_handle *rlk, const he_handle *o0, const he_handle *o1,
+                                  double *wall_s) {
+    if (n_threads <= 0 || n_threads > 4096 || iters <= 0 || !ctx || !eval || !a0 || !a1 || !b0 || !b1 || !rlk || !o0 || !o1 || !wall_s)
+        return fail(HE_EINVAL, "he_debug_concurrent_mul_relin: bad arguments");
+    std::vector<ConcArg> args(n_threads);
+    std::vector<pthread_t> th(n_threads);
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, nullptr, (unsigned)n_threads);
+    int started = 0;
+    for (int i = 0; i < n_threads; i++) {
+        args[i] = ConcArg{i, iters, sync_each, bgv, level, t, ctx[i], eval[i], a0[i], a1[i], b0[i], b1[i], rlk[i], o0[i], o1[i], &start, 0, 0, 0, {}};
+        if (pthread_create(&th[i], nullptr, conc_worker, &args[i]) != 0) break;
+        started++;
+    }
+    if (started != n_threads) {  // release the threads that wait at the barrier with the missing parties, then give up
+        for (int i = started; i < n_threads; i++) args[i].iters = 0;
+        for (int i = started; i < n_threads; i++) pthread_create(&th[i], nullptr, [](void *p) -> void * { pthread_barrier_wait(((ConcArg *)p)->start); return nullptr; }, &args[i]);
+    }
+    for (int i = 0; i < n_threads; i++) pthread_join(th[i], nullptr);
+    pthread_barrier_destroy(&start);
+    if (started != n_threads) return fail(HE_ENOMEM, "he_debug_concurrent_mul_relin: could not start %d threads", n_threads);
+    double lo = args[0].t0, hi = args[0].t1;
+    for (const ConcArg &a : args) { lo = std::min(lo, a.t0); hi = std::max(hi, a.t1); }
+    *wall_s = hi - lo;
+    for (const ConcArg &a : args)
+        if (a.rc != 0) return fail(a.rc, "thread %d: %s", a.idx, a.err.c_str());
     return HE_OK;
 }
 

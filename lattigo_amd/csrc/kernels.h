@@ -21,10 +21,18 @@ struct LimbTab {
 };
 
 // A device-resident polynomial batch: limb stride N words, batch stride bstride words.
+// tab (optional): an entry table -- batch entry z lives at p + tab[z] words (a device array of word offsets, any allocation;
+// differences wrap modulo 2^64) instead of p + z * bstride.  That is how concurrent single-ciphertext calls are coalesced into
+// one batched launch over the callers' own, unrelated polynomials (he_evaluator_set_coalescing).  Only the launchers that
+// say so accept it (the caller-facing operands of the fused MulRelin pipeline: launch_tensor, the product prologue and the
+// epilogues of launch_ntt_rows / launch_ntt_mac_f64); every other launcher refuses a view that carries one.
 struct View {
     uint64_t *p;
     size_t bstride;
+    const size_t *tab = nullptr;
 };
+// fills a device entry table from host values (kernel arguments: no host buffer has to outlive the call)
+hipError_t launch_tab_fill(size_t *dst, const size_t *vals, int n, hipStream_t s);
 
 struct RingDev {
     int logN;

@@ -129,6 +129,15 @@ __device__ __forceinline__ uint64_t ldc(const uint64_t *p, size_t i) { return ((
 typedef const double __attribute__((address_space(4))) *he_cptrd;
 __device__ __forceinline__ double ldcd(const double *p, size_t i) { return ((he_cptrd)(uintptr_t)p)[i]; }
 __device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }  // v_mad_u64_u32
+// word offset of batch entry z of a view (View::tab): through the entry table when the launch has one (block-uniform z: a scalar
+// load), z * bstride otherwise
+__device__ __forceinline__ size_t voff(const size_t *tab, size_t bs, size_t z) {
+    return tab ? (size_t)ldc(reinterpret_cast<const uint64_t *>(tab), z) : z * bs;
+}
+static inline bool no_tab(std::initializer_list<View> vs) {
+    for (const View &v : vs) if (v.tab) return false;
+    return true;
+}
 
 
 // XCD-aware work order (MI355X: 8 XCDs with private L2s, workgroup b runs on XCD b % 8): workgroup `lin` of a launch takes
@@ -292,6 +301,9 @@ struct NttArgs {
     int nbatch, iters;  // f64 kernel only: a workgroup transforms batch entries blockIdx.x * iters ... (+ iters - 1) of its row
     int nbatch_prof = 0;  // host only: batch entries of the launch when grid.x is not their number (rows_bytes)
     int tprod = 0;  // f64 inverse kernel only (NttProdIn): the input is formed here as T(ta1, tb1) with epi_ts, and also written to out2
+    // entry tables (View::tab) of the caller-facing operands: the epilogue's outputs and addends, the product's inputs
+    const size_t *out_tab = nullptr, *out2_tab = nullptr, *epi_w_tab = nullptr, *epi_w2_tab = nullptr;
+    const size_t *ta0_tab = nullptr, *ta1_tab = nullptr, *tb0_tab = nullptr, *tb1_tab = nullptr;
 };
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
@@ -547,8 +559,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
             const size_t zz = second ? bzi - A.zsplit : bzi;
             const size_t off = (size_t)ol * A.N + (size_t)row * N2;
             const uint64_t *yp = (second ? A.epi_y2 + zz * A.epi_y2_bs : A.epi_y + zz * A.epi_y_bs) + off;
-            const uint64_t *wp = (second ? A.epi_w2 + zz * A.epi_w2_bs : A.epi_w + zz * A.epi_w_bs) + off;
-            uint64_t *op = (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs) + off;
+            const uint64_t *wp = (second ? A.epi_w2 + voff(A.epi_w2_tab, A.epi_w2_bs, zz) : A.epi_w + voff(A.epi_w_tab, A.epi_w_bs, zz)) + off;
+            uint64_t *op = (second ? A.out2 + voff(A.out2_tab, A.out2_bs, zz) : A.out + voff(A.out_tab, A.out_bs, zz)) + off;
             const bool addw = (second ? A.epi2 : A.epi) == 2;
             const uint64_t sy = A.epi_s[y];
             uint64_t yv[16];
@@ -558,8 +570,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
                 // the addend from the product's inputs, eight coefficients at a time (plain loads: the other component's
                 // workgroup reads the same rows from L2)
                 const size_t toff = (size_t)ol * A.N + (size_t)row * N2;
-                const uint64_t *pa0 = A.ta0 + zz * A.ta0_bs + toff, *pa1 = A.ta1 + zz * A.ta1_bs + toff;
-                const uint64_t *pb0 = A.tb0 + zz * A.tb0_bs + toff, *pb1 = A.tb1 + zz * A.tb1_bs + toff;
+                const uint64_t *pa0 = A.ta0 + voff(A.ta0_tab, A.ta0_bs, zz) + toff, *pa1 = A.ta1 + voff(A.ta1_tab, A.ta1_bs, zz) + toff;
+                const uint64_t *pb0 = A.tb0 + voff(A.tb0_tab, A.tb0_bs, zz) + toff, *pb1 = A.tb1 + voff(A.tb1_tab, A.tb1_bs, zz) + toff;
                 const uint64_t ts = A.epi_ts[y];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
@@ -862,8 +874,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             const bool second = A.zsplit && (int)bzi >= A.zsplit;
             const size_t zz = second ? bzi - A.zsplit : bzi;
             const uint64_t *yp = (second ? A.epi_y2 + zz * A.epi_y2_bs : A.epi_y + zz * A.epi_y_bs) + (size_t)ol * A.N + (size_t)row * N2;
-            const uint64_t *wp = (second ? A.epi_w2 + zz * A.epi_w2_bs : A.epi_w + zz * A.epi_w_bs) + (size_t)ol * A.N + (size_t)row * N2;
-            uint64_t *op = (second ? A.out2 + zz * A.out2_bs : A.out + zz * A.out_bs) + (size_t)ol * A.N + (size_t)row * N2;
+            const uint64_t *wp = (second ? A.epi_w2 + voff(A.epi_w2_tab, A.epi_w2_bs, zz) : A.epi_w + voff(A.epi_w_tab, A.epi_w_bs, zz)) + (size_t)ol * A.N + (size_t)row * N2;
+            uint64_t *op = (second ? A.out2 + voff(A.out2_tab, A.out2_bs, zz) : A.out + voff(A.out_tab, A.out_bs, zz)) + (size_t)ol * A.N + (size_t)row * N2;
             const bool addw = (second ? A.epi2 : A.epi) == 2;
             const double sp = (double)imform(A.epi_s[y], mc.q, mc.qinv);
             // all sixteen y (then w) loads are issued before the first use: with the format / addend tests inside the
@@ -883,8 +895,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
                 // addend = x y (ts 2^-128 mod q) from the product's inputs (caller words: reduced first), all in doubles; one
                 // canonical reduction of addend + (transform - y) s gives the reference's word
                 const size_t toff = (size_t)ol * A.N + (size_t)row * N2;
-                const uint64_t *pa0 = A.ta0 + zz * A.ta0_bs + toff, *pa1 = A.ta1 + zz * A.ta1_bs + toff;
-                const uint64_t *pb0 = A.tb0 + zz * A.tb0_bs + toff, *pb1 = A.tb1 + zz * A.tb1_bs + toff;
+                const uint64_t *pa0 = A.ta0 + voff(A.ta0_tab, A.ta0_bs, zz) + toff, *pa1 = A.ta1 + voff(A.ta1_tab, A.ta1_bs, zz) + toff;
+                const uint64_t *pb0 = A.tb0 + voff(A.tb0_tab, A.tb0_bs, zz) + toff, *pb1 = A.tb1 + voff(A.tb1_tab, A.tb1_bs, zz) + toff;
                 const double tsp = (double)imform(imform(A.epi_ts[y], mc.q, mc.qinv), mc.q, mc.qinv);
                 // caller words may be any 64-bit representative (as MRed accepts them); every pipeline of this library hands over
                 // words below 2q, which convert as they are -- the Barrett reduction (a dozen integer instructions per word, up to
@@ -998,7 +1010,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             // read it) -- instead of a separate pass writing it and this one reading it back.  Caller words may be any 64-bit
             // representative; the Barrett reduction runs only for a wave that met one of 2q or above.
             const size_t off = (size_t)il * A.N + (size_t)row * N2;
-            const uint64_t *pa = A.ta1 + (size_t)bzi * A.ta1_bs + off, *pb = A.tb1 + (size_t)bzi * A.tb1_bs + off;
+            const uint64_t *pa = A.ta1 + voff(A.ta1_tab, A.ta1_bs, bzi) + off, *pb = A.tb1 + voff(A.tb1_tab, A.tb1_bs, bzi) + off;
             uint64_t *pc = A.out2 + (size_t)bzi * A.out2_bs + off;
             const double tsp = (double)imform(imform(A.epi_ts[y], mc.q, mc.qinv), mc.q, mc.qinv);
             const uint64_t twoq_u = mc.q << 1;
@@ -1269,6 +1281,8 @@ struct MacEpiK {
     const uint64_t *ta0, *ta1, *tb0, *tb1; size_t ta0_bs, ta1_bs, tb0_bs, tb1_bs;
     int ext_f64, tensor, has_w0, has_w1;
     double sp[kMaxLimbs], tsp[kMaxLimbs];
+    // entry tables (View::tab) of the caller-facing operands
+    const size_t *out0_tab, *out1_tab, *w0_tab, *w1_tab, *ta0_tab, *ta1_tab, *tb0_tab, *tb1_tab;
 };
 struct NttMacDmaArgs {
     NttMacKArgs k;
@@ -1519,7 +1533,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 // needs from memory are requested before / while the transform runs, in the registers the key rows use in a digit.
                 const bool second = c != 0;
                 const size_t off = (size_t)cur.out_limb * A.N + cur.rowoff + tau;
-                uint64_t *op = (second ? AA.e.out1 + cur.bz * AA.e.out1_bs : AA.e.out0 + cur.bz * AA.e.out0_bs) + off;
+                uint64_t *op = (second ? AA.e.out1 + voff(AA.e.out1_tab, AA.e.out1_bs, cur.bz) : AA.e.out0 + voff(AA.e.out0_tab, AA.e.out0_bs, cur.bz)) + off;
                 const double sp = AA.e.sp[cur.l];
                 const uint64_t *mcw = reinterpret_cast<const uint64_t *>(A.mc + cur.mi);
                 const uint64_t qu = ldc(mcw, 0);
@@ -1530,8 +1544,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 MAC_STAMP2(48 + c * 4 + 2);
                 if (tensor) {
                     const double tsp = AA.e.tsp[cur.l];
-                    const uint64_t *pa0 = AA.e.ta0 + cur.bz * AA.e.ta0_bs + off, *pa1 = AA.e.ta1 + cur.bz * AA.e.ta1_bs + off;
-                    const uint64_t *pb0 = AA.e.tb0 + cur.bz * AA.e.tb0_bs + off, *pb1 = AA.e.tb1 + cur.bz * AA.e.tb1_bs + off;
+                    const uint64_t *pa0 = AA.e.ta0 + voff(AA.e.ta0_tab, AA.e.ta0_bs, cur.bz) + off, *pa1 = AA.e.ta1 + voff(AA.e.ta1_tab, AA.e.ta1_bs, cur.bz) + off;
+                    const uint64_t *pb0 = AA.e.tb0 + voff(AA.e.tb0_tab, AA.e.tb0_bs, cur.bz) + off, *pb1 = AA.e.tb1 + voff(AA.e.tb1_tab, AA.e.tb1_bs, cur.bz) + off;
                     const uint64_t twoq_u = qu << 1, brc0 = ldc(mcw, 2);
                     // caller words may be any 64-bit representative (as MRed accepts them); every pipeline of this library hands over
                     // words below 2q, which convert as they are -- the Barrett reduction runs only for a wave that met a larger one
@@ -1603,7 +1617,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                     }
 #undef HE_H
                 } else if (addw) {
-                    const uint64_t *wp = (second ? AA.e.w1 + cur.bz * AA.e.w1_bs : AA.e.w0 + cur.bz * AA.e.w0_bs) + off;
+                    const uint64_t *wp = (second ? AA.e.w1 + voff(AA.e.w1_tab, AA.e.w1_bs, cur.bz) : AA.e.w0 + voff(AA.e.w0_tab, AA.e.w0_bs, cur.bz)) + off;
                     uint64_t wv[16];
 #pragma unroll
                     for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[(unsigned)(k * T)]);
@@ -1673,6 +1687,7 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
                               View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi) {
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     if (!r.twd_fwd || !keyd) return hipErrorInvalidValue;
+    if (!no_tab({dec, own}) || (!epi && !no_tab({out0Q, out0P, out1Q, out1P})) || (epi && epi->ext.tab)) return hipErrorInvalidValue;
     const int b = ntt_row_bits(r.logN), aa = r.logN - b;
     if (epi && !ntt_mac_epilogue_supported(r.logN)) return hipErrorInvalidValue;
     NttMacKArgs A;
@@ -1697,6 +1712,8 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
             D.e.tensor = epi->tensor ? 1 : 0;
             D.e.ta0 = epi->ta0.p; D.e.ta0_bs = epi->ta0.bstride; D.e.ta1 = epi->ta1.p; D.e.ta1_bs = epi->ta1.bstride;
             D.e.tb0 = epi->tb0.p; D.e.tb0_bs = epi->tb0.bstride; D.e.tb1 = epi->tb1.p; D.e.tb1_bs = epi->tb1.bstride;
+            D.e.out0_tab = epi->out0.tab; D.e.out1_tab = epi->out1.tab; D.e.w0_tab = epi->w0.tab; D.e.w1_tab = epi->w1.tab;
+            D.e.ta0_tab = epi->ta0.tab; D.e.ta1_tab = epi->ta1.tab; D.e.tb0_tab = epi->tb0.tab; D.e.tb1_tab = epi->tb1.tab;
             for (int i = 0; i < a.nlimbs; i++) { D.e.sp[i] = epi->sp[i]; D.e.tsp[i] = epi->tsp[i]; }
         }
         D.nbatch = (unsigned)batch;
@@ -1956,19 +1973,20 @@ static void set_epilogue(NttArgs &A, const NttEpilogue &epi, int n) {
     A.epi_y_reduce = epi.y_reduce ? 1 : 0;
     A.epi = epi.has_w ? 2 : 1;
     A.epi_y = epi.y.p; A.epi_y_bs = epi.y.bstride;
-    A.epi_w = epi.w.p; A.epi_w_bs = epi.w.bstride;
+    A.epi_w = epi.w.p; A.epi_w_bs = epi.w.bstride; A.epi_w_tab = epi.w.tab;
     for (int i = 0; i < n; i++) A.epi_s[i] = epi.s[i];
     A.epi_tensor = epi.tensor ? 1 : 0;
     if (epi.tensor) {
         A.ta0 = epi.ta0.p; A.ta1 = epi.ta1.p; A.tb0 = epi.tb0.p; A.tb1 = epi.tb1.p;
         A.ta0_bs = epi.ta0.bstride; A.ta1_bs = epi.ta1.bstride; A.tb0_bs = epi.tb0.bstride; A.tb1_bs = epi.tb1.bstride;
+        A.ta0_tab = epi.ta0.tab; A.ta1_tab = epi.ta1.tab; A.tb0_tab = epi.tb0.tab; A.tb1_tab = epi.tb1.tab;
         for (int i = 0; i < n; i++) A.epi_ts[i] = epi.ts[i];
     }
     if (epi.zsplit > 0) {
         A.zsplit = epi.zsplit; A.epi2 = epi.has_w2 ? 2 : 1;
-        A.out2 = epi.out2.p; A.out2_bs = epi.out2.bstride;
+        A.out2 = epi.out2.p; A.out2_bs = epi.out2.bstride; A.out2_tab = epi.out2.tab;
         A.epi_y2 = epi.y2.p; A.epi_y2_bs = epi.y2.bstride;
-        A.epi_w2 = epi.w2.p; A.epi_w2_bs = epi.w2.bstride;
+        A.epi_w2 = epi.w2.p; A.epi_w2_bs = epi.w2.bstride; A.epi_w2_tab = epi.w2.tab;
     }
 }
 hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
@@ -1977,6 +1995,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     const int n = r.logN;
     if (n < 4 || n > 17) return hipErrorInvalidValue;
     if (epi && (inverse || epi->zsplit > 0)) return hipErrorInvalidValue;
+    if (!no_tab({in, out}) || (epi && !no_tab({epi->y, epi->w, epi->dst}))) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
     NttArgs A;
     A.mc = r.mc;
@@ -2042,6 +2061,8 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     if (n < 4 || n > 17) return hipErrorInvalidValue;
     if (epi && inverse) return hipErrorInvalidValue;
     if (prod && (!inverse || !r.twd_inv || !ntt_prod_in_supported(n))) return hipErrorInvalidValue;
+    // entry tables: only the epilogue's outputs / addends / product inputs and the prologue's inputs take one
+    if (in.tab || (out.tab && !epi) || (epi && !no_tab({epi->y, epi->y2})) || (prod && prod->c.tab)) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
     NttArgs A;
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
@@ -2054,11 +2075,12 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
         if (epi->tensor && (epi->zsplit <= 0 || batch != 2 * epi->zsplit)) return hipErrorInvalidValue;
         set_epilogue(A, *epi, tab.n);
     }
-    A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
+    A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride; A.out_tab = out.tab;
     A.flags = flags;
     if (prod) {
         A.tprod = 1;
         A.ta1 = prod->a.p; A.ta1_bs = prod->a.bstride; A.tb1 = prod->b.p; A.tb1_bs = prod->b.bstride;
+        A.ta1_tab = prod->a.tab; A.tb1_tab = prod->b.tab;
         A.out2 = prod->c.p; A.out2_bs = prod->c.bstride;
         for (int i = 0; i < tab.n; i++) A.epi_ts[i] = prod->ts[i];
     }
@@ -2109,6 +2131,7 @@ __global__ void __launch_bounds__(256) ci_fold_kernel(CiFoldArgs A) {
 }
 hipError_t launch_ci_fold(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, bool reduce_input,
                           hipStream_t s) {
+    if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     CiFoldArgs A;
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N;
@@ -2161,6 +2184,7 @@ __global__ void __launch_bounds__(256) ci_ref_inv_fold_kernel(CiRefArgs A) {
     if (jy != j) p[jy] = mred_lazy(b + twoq - mred_lazy(a, F, q, qinv), ninv, q, qinv);
 }
 hipError_t launch_ci_intt_lazy_ref(const RingDev &r, const ModConst &mc_host, int mod, View in, View out, int batch, hipStream_t s) {
+    if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (batch <= 0) return hipSuccess;
     CiRefArgs A;
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride; A.mc = mc_host;
@@ -2278,6 +2302,7 @@ hipError_t launch_ew_w(const RingDev &r, const LimbTab &tab, int op, View x, Vie
 }
 static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
                                  const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s, int dbl) {
+    if (!no_tab({x, y, w, z})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     EwArgs A;
     A.dbl = dbl;
@@ -2356,6 +2381,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherArgs A) {
 }
 hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const uint32_t *index, View out, int batch,
                          bool then_add, hipStream_t s) {
+    if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     GatherArgs A;
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.index = index; A.N = r.N;
@@ -2422,6 +2448,7 @@ __global__ void __launch_bounds__(256) automorphism_coeff_ci_kernel(AutoCoeffArg
 }
 hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View in, uint64_t gal, View out, int batch,
                                      hipStream_t s, bool conjugate_invariant) {
+    if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     AutoCoeffArgs A;
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.logN = r.logN;
@@ -2502,6 +2529,7 @@ __global__ void __launch_bounds__(64) modup_kernel(ModUpKArgs A) {
 
 hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a, View src, View dstA, View dstB,
                         int batch, hipStream_t s) {
+    if (!no_tab({src, dstA, dstB})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.ndst <= 0 || batch <= 0) return hipSuccess;
     ModUpKArgs A;
     A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
@@ -3123,6 +3151,7 @@ bool modup_f64_raw_ok(int logN, int nsrc, uint64_t max_small_modulus) {
 }
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
                               View dstA, View dstB, int batch, hipStream_t s, bool f64_raw, int total_limbs) {
+    if (!no_tab({src, dstA, dstB})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (ndesc <= 0 || batch <= 0) return hipSuccess;
     if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
     const int a = r.logN - ntt_row_bits(r.logN);
@@ -3174,6 +3203,7 @@ __global__ void __launch_bounds__(256) center_copy_kernel(CenterArgs A) {
 }
 hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, View dstA, View dstB, int batch,
                               hipStream_t s, int strict) {
+    if (!no_tab({src, dstA, dstB})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.ndst <= 0 || batch <= 0) return hipSuccess;
     CenterArgs A;
     A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
@@ -3206,6 +3236,7 @@ __global__ void __launch_bounds__(256) mask_spread_kernel(MaskSpreadKArgs A) {
 }
 hipError_t launch_mask_spread(const RingDev &r, const MaskSpreadArgs &a, View src, uint64_t *dec, size_t dec_bs, size_t dec_ds,
                               int batch, hipStream_t s) {
+    if (!no_tab({src})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.nblk <= 0 || batch <= 0) return hipSuccess;
     MaskSpreadKArgs A;
     A.src = src.p; A.src_bs = src.bstride; A.dec = dec; A.dec_bs = dec_bs; A.dec_ds = dec_ds; A.N = r.N; A.m = a;
@@ -3308,6 +3339,7 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
 
 hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
                            View out0P, View out1Q, View out1P, int batch, hipStream_t s) {
+    if (!no_tab({dec, own, out0Q, out0P, out1Q, out1P})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     KsKArgs A;
     A.own = own.p; A.own_bs = own.bstride;
@@ -3367,6 +3399,7 @@ __global__ void __launch_bounds__(256) shift_kernel(ShiftArgs A) {
 }
 static hipError_t launch_shift_impl(const RingDev &r, const LimbTab &tab, View in, int k, View out, int batch, int monomial,
                                     hipStream_t s) {
+    if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     ShiftArgs A;
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.k = k; A.monomial = monomial;
@@ -3443,6 +3476,7 @@ __global__ void __launch_bounds__(256) diag_mac_kernel(const DiagMacKArgs A) {
 }
 
 hipError_t launch_diag_mac(const RingDev &r, const DiagMacArgs &a, View out0, View out1, int batch, hipStream_t s) {
+    if (!no_tab({out0, out1})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     if (a.n < 0 || a.n > kMaxDiag) return hipErrorInvalidValue;
     DiagMacKArgs A;
@@ -3472,6 +3506,7 @@ struct TensorArgs {
     const uint64_t *a0, *a1, *b0, *b1;
     uint64_t *c0, *c1, *c2;
     size_t a0_bs, a1_bs, b0_bs, b1_bs, c0_bs, c1_bs, c2_bs;
+    const size_t *a0_tab, *a1_tab, *b0_tab, *b1_tab, *c0_tab, *c1_tab;  // entry tables (View::tab); c2 is always a scratch batch
     const ModConst *mc;
     int N;
     uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs], mod[kMaxLimbs];
@@ -3485,17 +3520,17 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
     const uint64_t q = m.q, qinv = m.qinv, sc = A.s[yy];
     const size_t bz = blockIdx.z, io = (size_t)A.in_limb[yy] * A.N + j, oo = (size_t)A.out_limb[yy] * A.N + j;
     if (!A.c0) {  // c2 only (the fused MulRelin forms c0 / c1 in the ModDown epilogue, NttEpilogue::tensor)
-        const ulonglong2 a1 = ldnt2(A.a1 + bz * A.a1_bs + io), b1 = ldnt2(A.b1 + bz * A.b1_bs + io);
+        const ulonglong2 a1 = ldnt2(A.a1 + voff(A.a1_tab, A.a1_bs, bz) + io), b1 = ldnt2(A.b1 + voff(A.b1_tab, A.b1_bs, bz) + io);
         ulonglong2 c2;
         c2.x = mred(mred(a1.x, sc, q, qinv), b1.x, q, qinv);
         c2.y = mred(mred(a1.y, sc, q, qinv), b1.y, q, qinv);
         *reinterpret_cast<ulonglong2 *>(A.c2 + bz * A.c2_bs + oo) = c2;
         return;
     }
-    const ulonglong2 a0 = ldnt2(A.a0 + bz * A.a0_bs + io);
-    const ulonglong2 a1 = ldnt2(A.a1 + bz * A.a1_bs + io);
-    const ulonglong2 b0 = ldnt2(A.b0 + bz * A.b0_bs + io);
-    const ulonglong2 b1 = ldnt2(A.b1 + bz * A.b1_bs + io);
+    const ulonglong2 a0 = ldnt2(A.a0 + voff(A.a0_tab, A.a0_bs, bz) + io);
+    const ulonglong2 a1 = ldnt2(A.a1 + voff(A.a1_tab, A.a1_bs, bz) + io);
+    const ulonglong2 b0 = ldnt2(A.b0 + voff(A.b0_tab, A.b0_bs, bz) + io);
+    const ulonglong2 b1 = ldnt2(A.b1 + voff(A.b1_tab, A.b1_bs, bz) + io);
     ulonglong2 c0, c1, c2;
     {
         const uint64_t t0 = mred(a0.x, sc, q, qinv), t1 = mred(a1.x, sc, q, qinv);
@@ -3509,8 +3544,8 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
         c2.y = mred(t1, b1.y, q, qinv);
         c1.y = cred(mred(t0, b1.y, q, qinv) + mred(t1, b0.y, q, qinv), q);
     }
-    *reinterpret_cast<ulonglong2 *>(A.c0 + bz * A.c0_bs + oo) = c0;
-    *reinterpret_cast<ulonglong2 *>(A.c1 + bz * A.c1_bs + oo) = c1;
+    *reinterpret_cast<ulonglong2 *>(A.c0 + voff(A.c0_tab, A.c0_bs, bz) + oo) = c0;
+    *reinterpret_cast<ulonglong2 *>(A.c1 + voff(A.c1_tab, A.c1_bs, bz) + oo) = c1;
     *reinterpret_cast<ulonglong2 *>(A.c2 + bz * A.c2_bs + oo) = c2;
 }
 hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *scalar, View a0, View a1, View b0, View b1,
@@ -3520,6 +3555,8 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
     A.a0 = a0.p; A.a1 = a1.p; A.b0 = b0.p; A.b1 = b1.p; A.c0 = c0.p; A.c1 = c1.p; A.c2 = c2.p;
     A.a0_bs = a0.bstride; A.a1_bs = a1.bstride; A.b0_bs = b0.bstride; A.b1_bs = b1.bstride;
     A.c0_bs = c0.bstride; A.c1_bs = c1.bstride; A.c2_bs = c2.bstride;
+    A.a0_tab = a0.tab; A.a1_tab = a1.tab; A.b0_tab = b0.tab; A.b1_tab = b1.tab; A.c0_tab = c0.tab; A.c1_tab = c1.tab;
+    if (c2.tab) return hipErrorInvalidValue;
     A.mc = r.mc; A.N = r.N;
     for (int i = 0; i < tab.n; i++) {
         A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; A.s[i] = scalar[i];
@@ -3529,6 +3566,34 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
     ProfScope ps(K_TENSOR, s, (c0.p ? 7.0 : 3.0) * tab.n * batch * (double)r.N * 8.0);
     hipLaunchKernelGGL(tensor_kernel, grid, block, 0, s, A);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// entry tables of coalesced calls (View::tab): the values travel as kernel arguments, so nothing on the host has to outlive the
+// enqueue and the fill is ordered on the stream like every other launch (one table per evaluator is enough: the fill of the
+// next batch runs after the last kernel of the previous one)
+// ------------------------------------------------------------------------------------
+constexpr int kTabFillMax = 448;
+struct TabFillArgs {
+    size_t *dst;
+    int n;
+    size_t v[kTabFillMax];
+};
+__global__ void __launch_bounds__(64) tab_fill_kernel(TabFillArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < A.n) A.dst[i] = A.v[i];
+}
+hipError_t launch_tab_fill(size_t *dst, const size_t *vals, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += kTabFillMax) {
+        TabFillArgs A;
+        A.dst = dst + i0;
+        A.n = n - i0 < kTabFillMax ? n - i0 : kTabFillMax;
+        for (int i = 0; i < A.n; i++) A.v[i] = vals[i0 + i];
+        hipLaunchKernelGGL(tab_fill_kernel, dim3((unsigned)((A.n + 63) / 64)), dim3(64), 0, s, A);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------

@@ -129,6 +129,18 @@ class Evaluator:
     def NewEvaluationKey(self, q, p, BaseTwoDecomposition=0, BaseTwoDecompositionVectorSize=None) -> EvaluationKey:
         return EvaluationKey(self, q, p, BaseTwoDecomposition, BaseTwoDecompositionVectorSize)
 
+    def SetCoalescing(self, max_batch: int = 64, window_us: int = 30):
+        """he_evaluator_set_coalescing (include/hering.h): concurrent single-ciphertext MulRelin calls on this evaluator -- one
+        OS thread per ciphertext, the reference's own parallel mode (b.RunParallel over shallow copies of one evaluator,
+        schemes/ckks/ckks_benchmarks_test.go:116-207, core/rlwe/evaluator.go:200-227) -- are gathered into batched launches
+        over the callers' own polynomials.  max_batch <= 1 switches it off."""
+        check(load().he_evaluator_set_coalescing(self.h, max_batch, window_us))
+
+    def CoalescingStats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        check(load().he_evaluator_coalescing_stats(self.h, out))
+        return {"calls": int(out[0]), "launches": int(out[1]), "largest_batch": int(out[2]), "one_by_one": int(out[3])}
+
     def EvaluationKeyFromBinary(self, data: bytes) -> EvaluationKey:
         """rlwe.EvaluationKey.UnmarshalBinary (core/rlwe/keys.go:443 -> gadgetciphertext.go:134): load a key the
         reference serialised straight into a device handle."""
@@ -463,3 +475,18 @@ class CKKSRotations:
         if l & (l - 1):
             raise ValueError(f"innersum: invalid parameters (n*batchSize={l} does not divide #slots={N})")
         self.ise.PartialTracesSum(level, ctIn, batchSize, n, opOut)
+
+
+def ConcurrentMulRelin(callers, level: int, iters: int, t: int = 0, sync_each: bool = False) -> float:
+    """The reference's parallel benchmark shape for MulRelin (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:116-207) on OS
+    threads inside the library (he_debug_concurrent_mul_relin, include/hering_debug.h): callers = [(ctx, evaluator, op0, op1,
+    rlk, opOut), ...] with batch-1 ciphertexts; caller i makes `iters` calls of BGVMulRelin (t != 0) / CKKSMulRelin on its own
+    handles, synchronising its context after every call (sync_each) or once at the end.  Returns the wall time in seconds."""
+    n = len(callers)
+    arr = lambda f: (H * n)(*[f(c) for c in callers])
+    wall = C.c_double()
+    check(load().he_debug_concurrent_mul_relin(
+        n, iters, int(sync_each), int(t != 0), level, t, arr(lambda c: c[0].h), arr(lambda c: c[1].h), arr(lambda c: c[2][0].h),
+        arr(lambda c: c[2][1].h), arr(lambda c: c[3][0].h), arr(lambda c: c[3][1].h), arr(lambda c: c[4].h), arr(lambda c: c[5][0].h),
+        arr(lambda c: c[5][1].h), C.byref(wall)))
+    return float(wall.value)
