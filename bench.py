@@ -532,6 +532,9 @@ def main():
                          "counter collection does not survive the tens of thousands of events a bootstrap trace records")
     ap.add_argument("--no-b1", action="store_true", help="skip the single-ciphertext (batch 1) rate / latency measurement")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent single-ciphertext callers measurement (c3)")
+    ap.add_argument("--co-window", type=int, default=30, help="concurrent_b1: gathering window of the submission queue, microseconds")
+    ap.add_argument("--co-batch", type=int, default=64, help="concurrent_b1: largest coalesced batch")
+    ap.add_argument("--only-concurrent", action="store_true", help="print only the concurrent_b1 object (window sweeps)")
     ap.add_argument("--replicate-keys", choices=["auto", "none", "rccl", "host"], default="auto",
                     help="N > 1: rank 0's evaluation key is replicated to every rank before the timed region (RCCL broadcast "
                          "into the key's device storage, or gloo through host memory) instead of each rank drawing its own; "
@@ -556,6 +559,10 @@ def main():
     # HERING_FORCE_DEVICE: test hook to exercise the multi-rank path on a box with fewer GPUs than ranks
     dev = int(os.environ.get("HERING_FORCE_DEVICE", local_rank if world > 1 else 0))
     ctx = la.Context(dev)
+    if args.only_concurrent:
+        print(json.dumps(concurrent_b1(la, ctx, window_us=args.co_window, max_batch=args.co_batch)), flush=True)
+        cp.close()
+        return
     setup, default_B = WORKLOADS[args.workload]
     B = args.batch or default_B
     W = setup(la, ctx, rank, B, cp, args)
@@ -711,7 +718,7 @@ def main():
         del W1
     if not args.no_concurrent and world == 1 and args.workload == "c3":
         try:
-            line["concurrent_b1"] = concurrent_b1(la, ctx)
+            line["concurrent_b1"] = concurrent_b1(la, ctx, window_us=args.co_window, max_batch=args.co_batch)
             if line["concurrent_b1"]["verified"] is False:
                 problems.append("concurrent_b1: a caller's output differs from the oracle")
         except la.HeringError as e:

@@ -8,6 +8,7 @@ import "C"
 import (
 	"fmt"
 	"sync"
+	"sync/atomic"
 	"unsafe"
 
 	"github.com/tuneinsight/lattigo/v6/core/rlwe"
@@ -29,7 +30,9 @@ import (
 //   - results exist on the device only: the host words of an output are stale until Download / DownloadCiphertext / Sync;
 //   - Sync() downloads every output twin that has not been downloaded since it was last written (a full barrier: after it the
 //     host view equals the device view for everything this evaluator produced);
-//   - Forget(p) drops a twin; the cache holds at most MaxTwins twins and is emptied (after a Sync) when it would grow beyond.
+//   - Forget(p) drops a twin; the cache is bounded by MaxTwins: when it would grow beyond, the twins that have not been handed
+//     out for the longest time are evicted one by one (downloaded first when they are newer than the host copy) -- never a
+//     twin handed out recently, so the operands of an operation in progress (this goroutine's or another's) stay put.
 type Evaluator struct {
 	params rlwe.Parameters
 	ctx    *Context
@@ -46,17 +49,20 @@ type Evaluator struct {
 	polys  map[*uint64]*Poly                      // twin of a ring.Poly, keyed by the address of its first coefficient
 	hosts  map[*uint64]ring.Poly                  // the host polynomial of each twin (for Sync)
 	dirty  map[*uint64]bool                       // twins written on the device since their last Download
+	used   map[*uint64]uint64                     // tick of the last time a twin was handed out (eviction order)
+	tick   uint64
 	evks   map[*rlwe.GadgetCiphertext]*EvaluationKey // keys are immutable once generated: uploaded once
 	decs   map[*uint64]*Decomposition             // twin of a BuffDecompQP slice, keyed like polys on its first Q row
 	index  map[uint64]*AutomorphismIndex
 	batch  int
+	parent *Evaluator // ShallowCopy: the evaluator that owns the shared maps (evks, index) and whose lock guards them
 }
 
 // NewEvaluator mirrors rlwe.NewEvaluator(params, evk) on GPU `ctx`.
 func NewEvaluator(ctx *Context, params rlwe.ParameterProvider, evk rlwe.EvaluationKeySet) (*Evaluator, error) {
 	p := *params.GetRLWEParameters()
 	e := &Evaluator{params: p, ctx: ctx, keys: evk, batch: 1,
-		polys: map[*uint64]*Poly{}, hosts: map[*uint64]ring.Poly{}, dirty: map[*uint64]bool{},
+		polys: map[*uint64]*Poly{}, hosts: map[*uint64]ring.Poly{}, dirty: map[*uint64]bool{}, used: map[*uint64]uint64{},
 		evks: map[*rlwe.GadgetCiphertext]*EvaluationKey{}, decs: map[*uint64]*Decomposition{},
 		index: map[uint64]*AutomorphismIndex{}}
 	var err error
@@ -73,7 +79,48 @@ func NewEvaluator(ctx *Context, params rlwe.ParameterProvider, evk rlwe.Evaluati
 	if err = lockedCall(func() C.int { return C.he_evaluator_create(e.RingQ.h, hp, &e.h) }); err != nil {
 		return nil, err
 	}
+	// The reference's callers scale by running many single-ciphertext calls at once (b.RunParallel over ShallowCopy'd
+	// evaluators, schemes/ckks/ckks_benchmarks_test.go:116-207): on by default, such calls are gathered into batched launches.
+	if err = e.SetCoalescing(DefaultCoalesceBatch, DefaultCoalesceWindowMicros); err != nil {
+		return nil, err
+	}
 	return e, nil
+}
+
+// Defaults of the submission queue (see SetCoalescing).
+const (
+	DefaultCoalesceBatch        = 64
+	DefaultCoalesceWindowMicros = 30
+)
+
+// SetCoalescing configures the evaluator's submission queue (he_evaluator_set_coalescing, include/hering.h): MulRelin calls made
+// at the same time from different goroutines -- on this Evaluator or on its ShallowCopy's, which share the device evaluator --
+// are executed as one batched launch over the callers' own device twins; every call returns once its batch is enqueued.
+// maxBatch <= 1 switches it off.  A lone caller is not delayed: the gathering window only applies while calls overlap.
+func (e *Evaluator) SetCoalescing(maxBatch, windowMicros int) error {
+	return lockedCall(func() C.int { return C.he_evaluator_set_coalescing(e.h, C.int(maxBatch), C.int(windowMicros)) }, e)
+}
+
+// ShallowCopy mirrors rlwe.Evaluator.ShallowCopy (core/rlwe/evaluator.go:200-214): a copy for another goroutine that shares
+// everything read-only -- here the device evaluator with its tables, plans, uploaded keys and submission queue -- and has its
+// own twin cache (each goroutine works on its own ciphertexts).
+func (e *Evaluator) ShallowCopy() *Evaluator {
+	root := e
+	if e.parent != nil {
+		root = e.parent
+	}
+	c := &Evaluator{params: e.params, ctx: e.ctx, h: e.h, RingQ: e.RingQ, RingP: e.RingP, keys: e.keys, MaxTwins: e.MaxTwins, batch: e.batch,
+		polys: map[*uint64]*Poly{}, hosts: map[*uint64]ring.Poly{}, dirty: map[*uint64]bool{}, used: map[*uint64]uint64{},
+		evks: root.evks, decs: map[*uint64]*Decomposition{}, index: root.index, parent: root}
+	return c
+}
+
+// sharedMu guards the maps a ShallowCopy shares with the evaluator it was copied from (uploaded keys, automorphism indices).
+func (e *Evaluator) sharedMu() *sync.Mutex {
+	if e.parent != nil {
+		return &e.parent.mu
+	}
+	return &e.mu
 }
 
 // GetRLWEParameters: rlwe.ParameterProvider.
@@ -90,28 +137,20 @@ const DefaultMaxTwins = 4096
 // one (an input seen for the first time) or about to be overwritten (an output).
 func (e *Evaluator) twin(r *Ring, p ring.Poly, upload bool) (*Poly, error) {
 	e.mu.Lock()
+	e.tick++
 	d, ok := e.polys[key(p)]
-	if ok && !upload {
-		e.dirty[key(p)] = true // an output: the device copy is about to become newer than the host's
+	if ok {
+		e.used[key(p)] = e.tick
+		if !upload {
+			e.dirty[key(p)] = true // an output: the device copy is about to become newer than the host's
+		}
 	}
 	e.mu.Unlock()
 	if ok && d.limbs >= len(p.Coeffs) {
 		return d, nil
 	}
-	max := e.MaxTwins
-	if max == 0 {
-		max = DefaultMaxTwins
-	}
-	e.mu.Lock()
-	full := len(e.polys) >= max
-	e.mu.Unlock()
-	if full { // bound the cache: bring the host up to date, then start over (twins still referenced by callers stay valid)
-		if err := e.Sync(); err != nil {
-			return nil, err
-		}
-		e.mu.Lock()
-		e.polys, e.hosts, e.dirty = map[*uint64]*Poly{}, map[*uint64]ring.Poly{}, map[*uint64]bool{}
-		e.mu.Unlock()
+	if err := e.evict(); err != nil {
+		return nil, err
 	}
 	d, err := r.AtLevel(len(p.Coeffs) - 1).NewScratch(e.batch)
 	if err != nil {
@@ -125,11 +164,63 @@ func (e *Evaluator) twin(r *Ring, p ring.Poly, upload bool) (*Poly, error) {
 	e.mu.Lock()
 	e.polys[key(p)] = d
 	e.hosts[key(p)] = p
+	e.used[key(p)] = e.tick
 	if !upload {
 		e.dirty[key(p)] = true
 	}
 	e.mu.Unlock()
 	return d, nil
+}
+
+// evict bounds the twin cache.  An operation fetches its twins one after another and then makes ONE library call with all of
+// them, so a twin handed out a moment ago may be an operand of a call that has not been made yet (on this goroutine or another
+// one): only twins that have not been handed out during the last MaxTwins / 2 twin() calls are candidates.  A candidate that
+// is newer than its host polynomial is downloaded before it is dropped, so dropping never loses a result and a later Download
+// of that polynomial has nothing left to do.  When nothing is old enough the cache grows past the bound for the moment.
+func (e *Evaluator) evict() error {
+	max := e.MaxTwins
+	if max == 0 {
+		max = DefaultMaxTwins
+	}
+	e.mu.Lock()
+	if len(e.polys) < max || atomic.LoadInt32(&e.ctx.liveGraphs) > 0 { // (a live graph addresses twins by device pointer)
+		e.mu.Unlock()
+		return nil
+	}
+	horizon := uint64(max / 2)
+	victims := make([]*uint64, 0, len(e.polys)/4+1)
+	for k, t := range e.used {
+		if e.tick-t > horizon {
+			victims = append(victims, k)
+			if len(victims) >= len(e.polys)/4+1 {
+				break
+			}
+		}
+	}
+	e.mu.Unlock()
+	for _, k := range victims {
+		e.mu.Lock()
+		d, host, dirty, t := e.polys[k], e.hosts[k], e.dirty[k], e.used[k]
+		stillOld := d != nil && e.tick-t > horizon
+		e.mu.Unlock()
+		if !stillOld { // handed out again meanwhile
+			continue
+		}
+		if dirty {
+			if err := d.Download(0, host); err != nil {
+				return err
+			}
+		}
+		e.mu.Lock()
+		if e.polys[k] == d && e.tick-e.used[k] > horizon { // (not re-used while it was being downloaded)
+			delete(e.polys, k)
+			delete(e.hosts, k)
+			delete(e.dirty, k)
+			delete(e.used, k)
+		}
+		e.mu.Unlock()
+	}
+	return nil
 }
 
 // Sync downloads every twin that was written on the device since its last Download, so that the host view of everything this
@@ -205,6 +296,7 @@ func (e *Evaluator) Forget(p ring.Poly) {
 	delete(e.polys, key(p))
 	delete(e.hosts, key(p))
 	delete(e.dirty, key(p))
+	delete(e.used, key(p))
 	e.mu.Unlock()
 }
 
@@ -217,9 +309,10 @@ type EvaluationKey struct {
 
 // evk uploads a gadget ciphertext once (always NTT + Montgomery, core/rlwe/keygenerator.go:314).
 func (e *Evaluator) evk(g *rlwe.GadgetCiphertext) (*EvaluationKey, error) {
-	e.mu.Lock()
+	sm := e.sharedMu()
+	sm.Lock()
 	k, ok := e.evks[g]
-	e.mu.Unlock()
+	sm.Unlock()
 	if ok {
 		return k, nil
 	}
@@ -261,9 +354,13 @@ func (e *Evaluator) evk(g *rlwe.GadgetCiphertext) (*EvaluationKey, error) {
 	if err != nil {
 		return nil, err
 	}
-	e.mu.Lock()
+	sm.Lock()
+	if prev, dup := e.evks[g]; dup { // another goroutine uploaded the same key meanwhile: keep one
+		sm.Unlock()
+		return prev, nil
+	}
 	e.evks[g] = k
-	e.mu.Unlock()
+	sm.Unlock()
 	return k, nil
 }
 
@@ -548,9 +645,10 @@ func (e *Evaluator) AutomorphismIndex(galEl uint64) []uint64 {
 }
 
 func (e *Evaluator) autoIndex(galEl uint64) (*AutomorphismIndex, error) {
-	e.mu.Lock()
+	sm := e.sharedMu()
+	sm.Lock()
 	ix, ok := e.index[galEl]
-	e.mu.Unlock()
+	sm.Unlock()
 	if ok {
 		return ix, nil
 	}
@@ -558,9 +656,9 @@ func (e *Evaluator) autoIndex(galEl uint64) (*AutomorphismIndex, error) {
 	if err != nil {
 		return nil, err
 	}
-	e.mu.Lock()
+	sm.Lock()
 	e.index[galEl] = ix
-	e.mu.Unlock()
+	sm.Unlock()
 	return ix, nil
 }
 

@@ -21,6 +21,7 @@ import (
 	"errors"
 	"fmt"
 	"runtime"
+	"sync/atomic"
 	"unsafe"
 
 	"github.com/tuneinsight/lattigo/v6/ring"
@@ -50,7 +51,12 @@ func lockedCall(f func() C.int, keep ...any) error {
 }
 
 // Context owns one HIP stream on one GPU; all work of the objects created from it is enqueued there.
-type Context struct{ h Handle }
+type Context struct {
+	h Handle
+	// graphs captured on this context that are still alive: their nodes address device polynomials by pointer, so the
+	// evaluators of the context do not evict twins meanwhile (Evaluator.evict)
+	liveGraphs int32
+}
 
 // NewContext opens GPU `device`.  There is no CPU fallback: without a HIP device this fails.
 func NewContext(device int) (*Context, error) {
@@ -72,14 +78,29 @@ type Graph struct {
 }
 
 // Capture records the device work f enqueues on c instead of executing it.  f must have run once before (plans and scratch are
-// built on first use) and must not upload, download or Sync.  The replay reads and writes the same device polynomials.
-func (c *Context) Capture(f func() error) (*Graph, error) {
-	if err := lockedCall(func() C.int { return C.he_graph_begin(c.h) }); err != nil {
+// built on first use) and must not upload, download or Sync.  The replay reads and writes the same device polynomials: while a
+// graph of the context is alive, its evaluators keep every device twin (no eviction); a caller that Forgets or frees a
+// polynomial a graph addresses must Close the graph first.  A panic inside f still ends the capture.
+func (c *Context) Capture(f func() error) (g *Graph, err error) {
+	if err = lockedCall(func() C.int { return C.he_graph_begin(c.h) }); err != nil {
 		return nil, err
 	}
+	g = &Graph{ctx: c}
+	ended := false
+	end := func() error {
+		ended = true
+		return lockedCall(func() C.int { return C.he_graph_end(c.h, &g.h) })
+	}
+	defer func() {
+		if r := recover(); r != nil {
+			if !ended && end() == nil { // leave the context usable, drop what was recorded
+				C.he_graph_destroy(g.h)
+			}
+			panic(r)
+		}
+	}()
 	ferr := f()
-	g := &Graph{ctx: c}
-	err := lockedCall(func() C.int { return C.he_graph_end(c.h, &g.h) })
+	err = end()
 	if ferr != nil {
 		if err == nil {
 			C.he_graph_destroy(g.h)
@@ -89,8 +110,18 @@ func (c *Context) Capture(f func() error) (*Graph, error) {
 	if err != nil {
 		return nil, err
 	}
-	runtime.SetFinalizer(g, func(g *Graph) { C.he_graph_destroy(g.h) })
+	atomic.AddInt32(&c.liveGraphs, 1)
+	runtime.SetFinalizer(g, func(g *Graph) { g.Close() })
 	return g, nil
+}
+
+// Close destroys the graph (idempotent); the context's evaluators may evict twins again once no graph is left.
+func (g *Graph) Close() {
+	if g.h != 0 {
+		C.he_graph_destroy(g.h)
+		g.h = 0
+		atomic.AddInt32(&g.ctx.liveGraphs, -1)
+	}
 }
 
 // Launch enqueues the captured sequence on the context's stream.

@@ -72,6 +72,11 @@ struct Ctx : Obj {
     uint64_t *arena = nullptr;
     size_t arena_words = 0, arena_used = 0;
     std::mutex mu;
+    // he_ctx_sync from many threads: one drains the stream, the others wait for a drain that covers their ticket
+    std::mutex sync_mu;
+    std::condition_variable sync_cv;
+    uint64_t sync_tickets = 0, sync_covered = 0;
+    bool syncing = false;
     // Algorithmic HBM bytes of the primitives called on this context, by the per-primitive formulas of SURVEY.md section 8(d)
     // (ideal single pass: every operand read once, every result written once; twiddles / constants / index tables excluded):
     // [0] with an evaluation key charged to every batch entry, [1] with one key read serving the whole batch.  bench.py sums
@@ -394,6 +399,9 @@ struct Coalescer {
     std::deque<hipEvent_t> inflight;  // one event per launched batch, oldest first
     std::vector<hipEvent_t> free_events;
     uint64_t n_calls = 0, n_launches = 0, n_max = 0, n_fallback = 0;  // he_evaluator_coalescing_stats
+    // > 0 while recent traffic showed callers overlapping (a batch of more than one request, or requests left waiting when a
+    // batch was taken): a lone caller -- no one to wait for -- is launched without the gathering window
+    int crowd = 0;
 };
 struct Evaluator : Obj {
     std::shared_ptr<BasisExtender> be;
@@ -590,8 +598,24 @@ int he_ctx_destroy(he_handle h) { return unreg(h, T_CTX); }
 int he_ctx_sync(he_handle h) {
     GET(c, Ctx, h, T_CTX);
     if (c->capturing) return fail(HE_EINVAL, "he_ctx_sync: the context is capturing a graph (he_graph_end first)");
-    HIP_TRY(hipSetDevice(c->dev));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // Many threads may wait on one context at once (the callers of a coalescing evaluator): ONE of them drains the stream, the
+    // others sleep until a drain that STARTED after their call began has finished -- everything a caller enqueued before calling
+    // is covered by such a drain -- instead of every thread spinning on the stream.
+    std::unique_lock<std::mutex> lk(c->sync_mu);
+    const uint64_t ticket = ++c->sync_tickets;
+    while (c->sync_covered < ticket) {
+        if (c->syncing) { c->sync_cv.wait(lk); continue; }
+        c->syncing = true;
+        const uint64_t covers = c->sync_tickets;
+        lk.unlock();
+        hipError_t e = hipSetDevice(c->dev);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        lk.lock();
+        c->syncing = false;
+        if (e == hipSuccess) c->sync_covered = std::max(c->sync_covered, covers);
+        c->sync_cv.notify_all();
+        if (e != hipSuccess) return fail(HE_EDEVICE, "he_ctx_sync: %s", hipGetErrorString(e));
+    }
     return HE_OK;
 }
 int he_timer_start(he_handle h) {
@@ -2573,7 +2597,10 @@ static int cached_auto_index(Evaluator &ev, uint64_t gal, const uint32_t **out) 
     auto it = ev.auto_index.find(gal);
     if (it != ev.auto_index.end()) { *out = it->second; return HE_OK; }
     BasisExtender &be = *ev.be;
-    if (ev.auto_index.size() >= Evaluator::kAutoIndexCap) {  // a bound on the memory a long-running caller can pin
+    // a bound on the memory a long-running caller can pin -- but never while a hipGraph of this context is alive or being
+    // recorded: captured Automorphism launches have these device pointers baked into their kernel nodes (and a stream
+    // synchronisation would invalidate a capture in progress); the cache then grows past the bound until the graphs are gone
+    if (ev.auto_index.size() >= Evaluator::kAutoIndexCap && be.ctx->live_graphs == 0 && !be.ctx->capturing) {
         HIP_TRY(hipStreamSynchronize(be.ctx->stream));
         for (auto &kv : ev.auto_index) (void)hipFree(kv.second);
         ev.auto_index.clear();
@@ -2911,13 +2938,17 @@ void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoRe
     using clock = std::chrono::steady_clock;
     hipSetDevice(ev.be->ctx->dev);
     while (!mine.done) {
-        // gather: up to max_batch requests, for at most window_us after the oldest arrived -- or for as long as the device
-        // still has two batches of this queue ahead of it
+        // gather: up to max_batch requests, until no request has arrived for window_us (callers released by the same event --
+        // the previous batch completing -- trickle in as the OS schedules them) but no longer than 8 window_us after the oldest
+        // arrived -- or for as long as the device still has two batches of this queue ahead of it
         for (;;) {
             if ((int)c.pending.size() >= c.max_batch) break;
             const bool busy = co_inflight(c) >= 2;
-            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - c.pending.front()->arrived).count();
-            if (!busy && waited >= c.window_us) break;
+            const auto now = clock::now();
+            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.front()->arrived).count();
+            const auto quiet = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.back()->arrived).count();
+            const long long win = c.crowd > 0 ? c.window_us : 0;
+            if (!busy && (quiet >= win || waited >= 8 * win)) break;
             if (busy) {
                 c.cv.wait_for(lk, std::chrono::microseconds(100));  // arrivals notify
             } else {  // a few microseconds: a timed futex wait would oversleep by the timer slack
@@ -2932,6 +2963,8 @@ void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoRe
             if ((*it)->same_key(head)) { batch.push_back(*it); it = c.pending.erase(it); }
             else ++it;
         }
+        if (batch.size() > 1 || !c.pending.empty()) c.crowd = 256;
+        else if (c.crowd > 0) c.crowd--;
         hipEvent_t e = nullptr;
         if (!c.free_events.empty()) { e = c.free_events.back(); c.free_events.pop_back(); }
         else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;

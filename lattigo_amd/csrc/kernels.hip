@@ -838,7 +838,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     if constexpr (!INV) {
         constexpr int sh0 = LOGB - 4;
         const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + in_off;
-        if (A.flags & NTT_INPUT_F64) {  // doubles left by the basis extension (|x| < 64 q, see launch_modup_fused)
+        if (A.flags & NTT_INPUT_F64) {  // doubles left by the basis extension (|x| < 2^53 through every stage: modup_f64_raw_ok)
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = __longlong_as_double((long long)ldnt(&src[(k << sh0) + tau]));
         } else {
@@ -2574,7 +2574,7 @@ struct ModUpFusedArgs {
     int nchunk;   // small grids: the destinations of a digit are shared out over nchunk workgroups (blockIdx.y = digit * nchunk + chunk),
                   // each redoing the source stage -- a launch of a few hundred workgroups is the latency of ONE wave walking all
                   // its destinations, and the chip is idle anyway
-    int f64_raw;  // double-precision destinations are stored as the doubles they are (|x| < 64 p, unreduced): the consumer is a
+    int f64_raw;  // double-precision destinations are stored as the doubles they are (unreduced, bounded by modup_f64_raw_ok): the consumer is a
                   // double-precision row kernel told so (NttMacArgs::dec_f64 / NTT_INPUT_F64), six instructions per word saved here
 };
 
@@ -2896,7 +2896,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
 #pragma unroll
                         for (int r = 0; r < R; r++) o[r] += modmul_f64(u52_to_f64(ytake(r, i)), Tl, pd, pid);
                     }
-                }  // |o| < (2 + 5*NSRC) p
+                }  // |o| < (2 + 5*NSRC) p + NSRC 2^32 (the split sources' low parts L are added unreduced; modup_f64_raw_ok counts them)
             }
             if constexpr (LOGA > 0) {
                 const double *tw = A.twd_fwd + (size_t)mi * A.N;
@@ -3145,8 +3145,10 @@ static void launch_modup_fused_variant(int a, int nsrc, dim3 grid, dim3 block, c
 }
 
 bool modup_f64_raw_ok(int logN, int nsrc, uint64_t max_small_modulus) {
-    // |o| < (2 + 5 nsrc) p after the matrix-vector sum, + 2p per forward stage (column and row): everything must stay below 2^53
-    const long double bound = (long double)(2 + 5 * nsrc + 2 * logN) * (long double)max_small_modulus;
+    // |o| < (2 + 5 nsrc) p + nsrc 2^32 after the matrix-vector sum (the second term: the exact low parts L of the split residues'
+    // running sum, two per split source and below 2^31 each, join o unreduced -- HE_MODUP_MAGIC), + 2p per forward stage (column
+    // and row): everything must stay below 2^53
+    const long double bound = (long double)(2 + 5 * nsrc + 2 * logN) * (long double)max_small_modulus + (long double)nsrc * 0x1p32L;
     return bound < 0x1p53L;
 }
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,

@@ -59,9 +59,12 @@ class Graph:
     def __exit__(self, et, ev, tb):
         h = H()
         rc = load().he_graph_end(self.ctx.h, C.byref(h))
-        if et is None:
-            check(rc)
+        if rc == 0 and et is not None:
+            load().he_graph_destroy(h.value)  # the body raised: drop what was recorded (a live graph pins the context's scratch)
+        elif rc == 0:
             self.h = h.value
+        elif et is None:
+            check(rc)
         return False
 
     def launch(self):

@@ -114,7 +114,7 @@ def test_aliasing_levels_and_squaring_are_kept_apart(ctx):
     for i, kind in enumerate(kinds):
         assert np.array_equal(np.stack([o.get() for o in outs[i]]), want[i]), (i, kind)
     st = gev.CoalescingStats()
-    assert st["calls"] == len(kinds) and st["launches"] >= 4  # at least the four keys: plain / aliased at the top level, lower, ...
+    assert st["calls"] == len(kinds) and st["launches"] >= 3  # three keys at least: plain / aliased at the top level, the lower level
 
 
 def test_shapes_without_entry_tables_run_one_by_one(ctx):
