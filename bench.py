@@ -183,6 +183,49 @@ def replicate_key(cp, ev, key, rank, args):
 # -------------------------------------------------------------------------------------------------------------------
 # workloads: each returns step(), the units one step processes, a verifier of the last step's output and report fields
 # -------------------------------------------------------------------------------------------------------------------
+def valu_model_mulrelin(q, p, N):
+    """Modular-multiply equivalents of ONE MulRelin in closed form (NTT (N/2) logN + N per limb, basis
+    extension L_src x L_dst x N, key inner product 2 beta (L + alpha) N, tensor 6 L N, ModDown's last op 2 L N), split by the
+    arithmetic class of the limb they run on: moduli below 2^47 are computed with the exact double-precision product
+    (csrc/kernels.hip modmul_f64), the others with 64-bit Montgomery products.  The two classes have different measured
+    ceilings (he_probe_modmul_f64 / he_probe_modmul), so the ALU-bound time of the operation is
+    n_f64 / rate_f64 + n_int / rate_int -- the binding roofline of this path: its kernels are VALU-issue-bound well before HBM."""
+    L, alpha = len(q), len(p)
+    beta = (L + alpha - 1) // alpha
+    logN = N.bit_length() - 1
+    f64 = lambda m: m < (1 << 47)
+    ntt = (N // 2) * logN + N
+    cnt = {"f64": 0.0, "int": 0.0}
+    parts = {}
+
+    def add(name, modulus, n):
+        k = "f64" if f64(modulus) else "int"
+        cnt[k] += n
+        parts.setdefault(name, {"f64": 0.0, "int": 0.0})[k] += n
+
+    for m in q:                                    # inverse NTT of c2; tensor (6 products); last op of ModDown, both components
+        add("ntt", m, ntt)
+        add("tensor", m, 6 * N)
+        add("moddown_last", m, 2 * N)
+        add("ntt", m, 2 * ntt)                     # forward NTT of the two basis-extended P parts
+    for m in p:
+        add("ntt", m, 2 * ntt)                     # inverse NTT of the P parts of both accumulators
+        add("basis_extension", m, 2 * N)           # y_i of ModDown's sources
+    for m in q:
+        add("basis_extension", m, 2 * alpha * N)   # ModUpPtoQ: alpha sources into every Q limb, both components
+    for d in range(beta):
+        own = range(d * alpha, min((d + 1) * alpha, L))
+        for i in own:
+            add("basis_extension", q[i], N)        # y_i of the digit's sources
+        dsts = [m for i, m in enumerate(q) if i not in own] + list(p)
+        for m in dsts:
+            add("basis_extension", m, len(own) * N)
+            add("ntt", m, ntt)                     # forward NTT of the decomposed digit
+    for m in list(q) + list(p):
+        add("key_mac", m, 2 * beta * N)
+    return cnt, parts
+
+
 def verify_batch(kind, N, q, p, kq, kp, host_in, outs, out_limbs, t=0, gal=0, chunk=64):
     """EVERY batch entry and limb of the timed configuration's last output against the oracle (outside the timed region): the
     oracle runs the entries on the host's cores (oracle.Evaluator.BatchOp), in chunks so that the host copies stay bounded.
@@ -276,6 +319,7 @@ def setup_c3(la, ctx, rank, B, cp, args):
         # serves the B ciphertexts of a step, so the batch-amortised figure is 6L limbs + key / B
         "alg_bytes_per_op": (6 * L + 2 * beta * (L + alpha)) * limb,
         "alg_bytes_per_op_amortised": 6 * L * limb + 2 * beta * (L + alpha) * limb / B,
+        "valu_model": valu_model_mulrelin(q, p, N),
         "cpu": lambda: cpu_baseline("bgv_mulrelin", N, q, p, np.ascontiguousarray(kq), np.ascontiguousarray(kp),
                                     "ctxt-mul+relin ops/s", "BGV MulRelin (logN=15, 12+3 limbs)", t=T),
         "config": {"workload": "BGV logN=15, 12 Q-limbs [55,45x11] + 3 P-limbs [55x3], T=65537: ct x ct MulRelin "
@@ -668,6 +712,31 @@ def main():
         "source": ("closed form of SURVEY.md section 8(d); the library's per-primitive accounting of the timed trace gives "
                    f"{per_op_trace / 2**20:.2f} MiB") if W["alg_bytes_per_op"] else
                   "SURVEY.md section 8(d) per-primitive formulas summed over the timed operation trace (he_alg_bytes)"}
+    if W.get("valu_model") and world == 1:
+        # the binding roofline: modular multiplies per operation against the chip's two measured multiply ceilings
+        cnt, parts = W["valu_model"]
+        rate_int, rate_f64 = ctx.probe_modmul(256), ctx.probe_modmul_f64(256)
+        ideal_s = cnt["int"] / rate_int + cnt["f64"] / rate_f64
+        sq, sq_src = None, None
+        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "sq_counters" in f and f.endswith(".json")), reverse=True):
+            try:
+                sqj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                sq = {k: {kk: v[kk] for kk in ("valu_issue_share_of_wave_time", "valu_insts_per_wave", "wait_any_share",
+                                               "wait_inst_any_share", "lds_bank_conflict_share") if kk in v}
+                      for k, v in (sqj.get("launch_groups") or sqj.get("kernels") or {}).items()}
+                sq_src = f"profiles/{name} (committed rocprofv3 --pmc SQ pass of this command, not this run)"
+                break
+            except Exception:
+                pass
+        roofline["valu"] = {
+            "bound": "valu (integer / double-precision multiply issue)",
+            "modmul_equiv_per_op": cnt["int"] + cnt["f64"], "modmul_equiv_int": cnt["int"], "modmul_equiv_f64": cnt["f64"],
+            "breakdown_per_op": parts,
+            "peak_int_modmul_per_s": rate_int, "peak_f64_modmul_per_s": rate_f64,
+            "peak_source": "he_probe_modmul / he_probe_modmul_f64 run in this process: dependent MRedLazy / modmul_f64 chains, 4 per thread, 4 M threads",
+            "ideal_us_per_op": ideal_s * 1e6, "achieved_us_per_op": 1e6 / per_gpu, "frac": ideal_s * per_gpu,
+            "per_kernel_sq": sq, "per_kernel_sq_source": sq_src,
+            "note": "closed form of SURVEY.md section 8(d)'s multiply counts (valu_model_mulrelin); frac = ALU-bound time / measured time"}
     problems = []
     if over_peak:
         problems.append(f"kernel_GBs above the HBM peak (stale byte model?): {over_peak}")

@@ -28,6 +28,9 @@ const char *he_prof_kernel_name(int id);
 int he_alg_bytes(he_handle ctx, int reset, double out[2]);
 /* dependent-MRedLazy throughput probe: returns modular multiplies per second */
 int he_probe_modmul(he_handle ctx, int iters, double *mults_per_s);
+/* the same for the exact double-precision product the limbs below 2^47 are computed with (error-free product + rounded quotient,
+ * csrc/kernels.hip modmul_f64): the second ceiling of bench.py's `roofline.valu` */
+int he_probe_modmul_f64(he_handle ctx, int iters, double *mults_per_s);
 /* submission queue of an evaluator (he_evaluator_set_coalescing) since its creation: out[0] = single-ciphertext calls served,
  * out[1] = batched launches made for them, out[2] = largest batch, out[3] = calls that ran one by one because their pipeline
  * has launches without entry tables */

@@ -117,7 +117,7 @@ def _declare(L):
         "he_lintrans_mul_sum": [H, i, i, i, HP, HP, HP, HP, HP, HP, HP, i, H, H, H, H],
         "he_ckks_mul_relin": [H, i, H, H, H, H, H, H, H, H],
         "he_bgv_mul_relin": [H, i, C.c_uint64, H, H, H, H, H, H, H, H],
-        "he_probe_modmul": [H, i, C.POINTER(C.c_double)],
+        "he_probe_modmul": [H, i, C.POINTER(C.c_double)], "he_probe_modmul_f64": [H, i, C.POINTER(C.c_double)],
         "he_prof_begin": [H], "he_prof_end": [H, i, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(i)],
         "he_prof_end_bytes": [H, i, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i)],
         "he_alg_bytes": [H, i, C.POINTER(C.c_double)],

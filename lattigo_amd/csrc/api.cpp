@@ -604,7 +604,20 @@ int he_ctx_sync(he_handle h) {
     std::unique_lock<std::mutex> lk(c->sync_mu);
     const uint64_t ticket = ++c->sync_tickets;
     while (c->sync_covered < ticket) {
-        if (c->syncing) { c->sync_cv.wait(lk); continue; }
+        if (c->syncing) {
+            // a short drain is cheaper to wait out on the CPU than through a futex sleep and its wake-up latency (a handful of
+            // callers waiting for a small batch); a long one (dozens of callers, a batch of a millisecond) is slept through
+            const auto t0 = std::chrono::steady_clock::now();
+            bool covered = false;
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(150)) {
+                lk.unlock();
+                sched_yield();
+                lk.lock();
+                if (c->sync_covered >= ticket || !c->syncing) { covered = true; break; }
+            }
+            if (!covered) c->sync_cv.wait(lk);
+            continue;
+        }
         c->syncing = true;
         const uint64_t covers = c->sync_tickets;
         lk.unlock();
@@ -3161,6 +3174,29 @@ int he_probe_modmul(he_handle hctx, int iters, double *out) {
     HIP_TRY(launch_modmul_probe(buf, n, 8, q, inv, c->stream));  // warm-up
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(launch_modmul_probe(buf, n, iters, q, inv, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *out = (double)n * iters / (ms * 1e-3);
+    return HE_OK;
+}
+
+int he_probe_modmul_f64(he_handle hctx, int iters, double *out) {
+    GET(c, Ctx, hctx, T_CTX);
+    if (!out || iters <= 0) return fail(HE_EINVAL, "he_probe_modmul_f64: bad arguments");
+    Scope sc(c.get());
+    const size_t n = (size_t)1 << 24;
+    TRY(c->arena_reserve(n));
+    double *buf = reinterpret_cast<double *>(c->arena_take(n));
+    const double q = 35184372744193.0;  // a 45-bit NTT prime of the headline chain
+    std::vector<double> h(n);
+    for (size_t i = 0; i < n; i++) h[i] = (double)((i * 2654435761ull + 12345ull) % 35184372744193ull);
+    HIP_TRY(hipMemcpyAsync(buf, h.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(launch_modmul_f64_probe(buf, n, 8, q, c->stream));  // warm-up
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_modmul_f64_probe(buf, n, iters, q, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     float ms = 0;

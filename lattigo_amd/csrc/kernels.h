@@ -337,5 +337,6 @@ int prof_end(hipStream_t s, int *counts, float *total_ms, double *total_bytes = 
 
 // throughput probe used by bench.py --microbench (not on the product path)
 hipError_t launch_modmul_probe(uint64_t *buf, size_t n, int iters, uint64_t q, uint64_t qinv, hipStream_t s);
+hipError_t launch_modmul_f64_probe(double *buf, size_t n, int iters, double q, hipStream_t s);
 
 }  // namespace he

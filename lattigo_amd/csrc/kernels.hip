@@ -3613,6 +3613,23 @@ __global__ void __launch_bounds__(256) modmul_probe_kernel(uint64_t *buf, size_t
     }
     buf[i * 4] = a0; buf[i * 4 + 1] = a1; buf[i * 4 + 2] = a2; buf[i * 4 + 3] = a3;
 }
+// the same probe for the double-precision exact product (modmul_f64: the arithmetic of every limb below 2^47)
+__global__ void __launch_bounds__(256) modmul_f64_probe_kernel(double *buf, size_t n, int iters, double q, double qi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i * 4 + 3 >= n) return;
+    double a0 = buf[i * 4], a1 = buf[i * 4 + 1], a2 = buf[i * 4 + 2], a3 = buf[i * 4 + 3];
+    const double w = a0;
+    for (int k = 0; k < iters; k++) {
+        a0 = modmul_f64(a0, w, q, qi); a1 = modmul_f64(a1, w, q, qi);
+        a2 = modmul_f64(a2, w, q, qi); a3 = modmul_f64(a3, w, q, qi);
+    }
+    buf[i * 4] = a0; buf[i * 4 + 1] = a1; buf[i * 4 + 2] = a2; buf[i * 4 + 3] = a3;
+}
+hipError_t launch_modmul_f64_probe(double *buf, size_t n, int iters, double q, hipStream_t s) {
+    const size_t threads = n / 4;
+    hipLaunchKernelGGL(modmul_f64_probe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, buf, n, iters, q, 1.0 / q);
+    return hipGetLastError();
+}
 hipError_t launch_modmul_probe(uint64_t *buf, size_t n, int iters, uint64_t q, uint64_t qinv, hipStream_t s) {
     const size_t threads = n / 4;
     hipLaunchKernelGGL(modmul_probe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, buf, n, iters, q, qinv);

@@ -157,6 +157,11 @@ class Context:
         check(load().he_probe_modmul(self.h, iters, C.byref(out)))
         return float(out.value)
 
+    def probe_modmul_f64(self, iters=256) -> float:
+        out = C.c_double()
+        check(load().he_probe_modmul_f64(self.h, iters, C.byref(out)))
+        return float(out.value)
+
 
 class Poly:
     """Device-resident ring.Poly batch (ring/poly.go:13): [batch][limbs][N] uint64."""
