@@ -445,7 +445,7 @@ def setup_c5(la, ctx, rank, B, cp, args):
     }
 
 
-def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), iters=40, max_batch=64, window_us=30):
+def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), ops_per_run=6000, max_batch=64, window_us=30):
     """What the reference's own interface delivers: its operator API takes ONE ciphertext per call (schemes/schemes.go:14-28) and
     scales by concurrent callers (b.RunParallel over evaluators sharing tables and keys, schemes/ckks/ckks_benchmarks_test.go:
     116-207).  K OS threads (pthreads inside the library, he_debug_concurrent_mul_relin), each repeating MulRelin on its own
@@ -455,7 +455,8 @@ def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), iters=40, max_batch=64, window_us=
       * coalesced: all callers on ONE evaluator with its submission queue on (he_evaluator_set_coalescing): calls waiting at
         the same time become one batched launch over the callers' own polynomials;
       * coalesced_sync_each: the same with every caller waiting for its result (he_ctx_sync) before its next call.
-    Every caller's output is compared with the oracle afterwards."""
+    Every figure is the median of three runs of about ops_per_run calls (the callers share the host's CPU quota with each other:
+    single runs of a few milliseconds scatter by 20 %); every caller's output is compared with the oracle after every run."""
     from lattigo_amd.rlwe import ConcurrentMulRelin
     from oracle import oracle as O
     N = 1 << LOGN
@@ -485,7 +486,16 @@ def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), iters=40, max_batch=64, window_us=
                 return False
         return True
 
-    out = {"K": list(ks), "iters_per_caller": iters, "max_batch": max_batch, "window_us": window_us, "unit": "ctxt-mul+relin ops/s",
+    iters_of = lambda K: max(60, min(600, ops_per_run // K))
+
+    def rate(callers, K, sync_each=False):
+        runs = []
+        for _ in range(3):
+            runs.append(K * iters_of(K) / ConcurrentMulRelin(callers[:K], L - 1, iters_of(K), t=T, sync_each=sync_each))
+        return sorted(runs)[1]
+
+    out = {"K": list(ks), "iters_per_caller": [iters_of(K) for K in ks], "runs": "median of 3", "max_batch": max_batch,
+           "window_us": window_us, "unit": "ctxt-mul+relin ops/s",
            "note": "K OS threads, one batch-1 MulRelin per call (he_debug_concurrent_mul_relin); host wall clock from the common "
                    "start to the last caller's final sync"}
     ok = True
@@ -500,9 +510,8 @@ def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), iters=40, max_batch=64, window_us=
             for cl in shared[:K]:
                 cl[5][0].Zero(); cl[5][1].Zero()
             s0 = ev.CoalescingStats()
-            wall = ConcurrentMulRelin(shared[:K], L - 1, iters, t=T, sync_each=sync_each)
+            rates.append(rate(shared, K, sync_each))
             s1 = ev.CoalescingStats()
-            rates.append(K * iters / wall)
             out.setdefault(name + "_mean_batch", []).append((s1["calls"] - s0["calls"]) / max(1, s1["launches"] - s0["launches"]))
             ok = ok and check(shared[:K])
         out[name] = rates
@@ -511,8 +520,7 @@ def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), iters=40, max_batch=64, window_us=
     rates = []
     for K in ks:
         ConcurrentMulRelin(shared[:K], L - 1, 3, t=T)
-        wall = ConcurrentMulRelin(shared[:K], L - 1, iters, t=T)
-        rates.append(K * iters / wall)
+        rates.append(rate(shared, K))
         ok = ok and check(shared[:K])
     out["one_context_uncoalesced"] = rates
     del shared, cs, ev, rlk
@@ -525,8 +533,7 @@ def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), iters=40, max_batch=64, window_us=
     rates = []
     for K in ks:
         ConcurrentMulRelin(sep[:K], L - 1, 3, t=T)
-        wall = ConcurrentMulRelin(sep[:K], L - 1, iters, t=T)
-        rates.append(K * iters / wall)
+        rates.append(rate(sep, K))
         ok = ok and check(sep[:K])
     out["separate_contexts"] = rates
     out["verified"] = bool(ok)

@@ -77,6 +77,7 @@ struct Ctx : Obj {
     std::condition_variable sync_cv;
     uint64_t sync_tickets = 0, sync_covered = 0;
     bool syncing = false;
+    int sync_waiters = 0;
     // Algorithmic HBM bytes of the primitives called on this context, by the per-primitive formulas of SURVEY.md section 8(d)
     // (ideal single pass: every operand read once, every result written once; twiddles / constants / index tables excluded):
     // [0] with an evaluation key charged to every batch entry, [1] with one key read serving the whole batch.  bench.py sums
@@ -384,16 +385,18 @@ struct CoReq {
     std::shared_ptr<Evk> key;
     std::shared_ptr<Poly> a0, a1, b0, b1, o0, o1;
     std::chrono::steady_clock::time_point arrived;
-    bool done = false;
+    bool done = false, lead = false;  // lead: the leaving leader handed the role to this (still waiting) request
     int rc = 0;
     std::string err;
+    std::condition_variable cv;       // its own: a finished batch wakes exactly its callers, an arrival only the leader
     bool same_key(const CoReq &o) const { return level == o.level && bgv == o.bgv && alias == o.alias && t == o.t && key == o.key; }
 };
 struct Coalescer {
     std::mutex mu;
-    std::condition_variable cv;
+    std::condition_variable cv_leader;  // the gathering leader waits here for arrivals while the device is busy
     std::deque<CoReq *> pending;
     bool leader = false;
+    int recent[4] = {0, 0, 0, 0};     // sizes of the last batches: callers that wait for their results come back together
     int max_batch = 0, window_us = 0;
     size_t *d_tab = nullptr;  // [6][max_batch] entry offsets; one table is enough (stream order, see launch_tab_fill)
     std::deque<hipEvent_t> inflight;  // one event per launched batch, oldest first
@@ -603,7 +606,9 @@ int he_ctx_sync(he_handle h) {
     // is covered by such a drain -- instead of every thread spinning on the stream.
     std::unique_lock<std::mutex> lk(c->sync_mu);
     const uint64_t ticket = ++c->sync_tickets;
+    struct Waiting { int &n; explicit Waiting(int &x) : n(x) { n++; } ~Waiting() { n--; } } waiting(c->sync_waiters);
     while (c->sync_covered < ticket) {
+        if (c->syncing && c->sync_waiters > 8) { c->sync_cv.wait(lk); continue; }  // a crowd sleeps: its spinning would eat the CPUs the callers need
         if (c->syncing) {
             // a short drain is cheaper to wait out on the CPU than through a futex sleep and its wake-up latency (a handful of
             // callers waiting for a small batch); a long one (dozens of callers, a batch of a millisecond) is slept through
@@ -2951,9 +2956,11 @@ void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoRe
     using clock = std::chrono::steady_clock;
     hipSetDevice(ev.be->ctx->dev);
     while (!mine.done) {
-        // gather: up to max_batch requests, until no request has arrived for window_us (callers released by the same event --
-        // the previous batch completing -- trickle in as the OS schedules them) but no longer than 8 window_us after the oldest
-        // arrived -- or for as long as the device still has two batches of this queue ahead of it
+        // gather: up to max_batch requests.  While the device still has two batches of this queue ahead of it, waiting is free.
+        // Otherwise stop once no request has arrived for window_us AND at least half of the recent batches' callers are here
+        // (callers that wait for their result come back together, as fast as the OS schedules them), or 8 window_us after the
+        // oldest request arrived.  No window at all for a lone caller (crowd == 0).
+        const int hint = std::max(std::max(c.recent[0], c.recent[1]), std::max(c.recent[2], c.recent[3]));
         for (;;) {
             if ((int)c.pending.size() >= c.max_batch) break;
             const bool busy = co_inflight(c) >= 2;
@@ -2961,9 +2968,9 @@ void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoRe
             const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.front()->arrived).count();
             const auto quiet = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.back()->arrived).count();
             const long long win = c.crowd > 0 ? c.window_us : 0;
-            if (!busy && (quiet >= win || waited >= 8 * win)) break;
+            if (!busy && ((quiet >= win && 2 * (int)c.pending.size() >= hint) || waited >= 8 * win)) break;
             if (busy) {
-                c.cv.wait_for(lk, std::chrono::microseconds(100));  // arrivals notify
+                c.cv_leader.wait_for(lk, std::chrono::microseconds(100));  // arrivals notify
             } else {  // a few microseconds: a timed futex wait would oversleep by the timer slack
                 lk.unlock();
                 sched_yield();
@@ -2978,17 +2985,24 @@ void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoRe
         }
         if (batch.size() > 1 || !c.pending.empty()) c.crowd = 256;
         else if (c.crowd > 0) c.crowd--;
+        c.recent[c.n_launches & 3] = (int)batch.size();
+        // the completion event feeds the "two batches ahead" test of the gathering loop: not needed for a lone caller, whose
+        // stream drain would otherwise also wait for the event's barrier packet (a third of a single-ciphertext call's latency)
         hipEvent_t e = nullptr;
-        if (!c.free_events.empty()) { e = c.free_events.back(); c.free_events.pop_back(); }
-        else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        if (c.crowd > 0) {
+            if (!c.free_events.empty()) { e = c.free_events.back(); c.free_events.pop_back(); }
+            else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        }
         c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
         lk.unlock();
         const int rc = co_run(ev, c, batch, e);
         const std::string msg = rc ? g_err : std::string();
         lk.lock();
         if (e) { if (rc == HE_OK) c.inflight.push_back(e); else c.free_events.push_back(e); }
-        for (CoReq *r : batch) { r->rc = rc; r->err = msg; r->done = true; }
-        c.cv.notify_all();
+        for (CoReq *r : batch) {
+            r->rc = rc; r->err = msg; r->done = true;
+            if (r != &mine) r->cv.notify_one();
+        }
     }
 }
 int co_submit(Evaluator &ev, CoReq &r) {
@@ -2996,15 +3010,17 @@ int co_submit(Evaluator &ev, CoReq &r) {
     std::unique_lock<std::mutex> lk(c.mu);
     r.arrived = std::chrono::steady_clock::now();
     c.pending.push_back(&r);
-    c.cv.notify_all();  // a gathering leader counts arrivals
+    if (c.leader) c.cv_leader.notify_one();  // a gathering leader counts arrivals
     while (!r.done) {
-        if (!c.leader) {
+        if (!c.leader || r.lead) {
             c.leader = true;
+            r.lead = false;
             co_lead(ev, c, lk, r);
-            c.leader = false;
-            c.cv.notify_all();  // whoever still waits takes over
+            // hand the role to the oldest request still waiting (it is asleep on its own condition variable), if any
+            if (!c.pending.empty()) { c.pending.front()->lead = true; c.pending.front()->cv.notify_one(); }
+            else c.leader = false;
         } else {
-            c.cv.wait(lk);
+            r.cv.wait(lk);
         }
     }
     lk.unlock();
