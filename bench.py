@@ -160,6 +160,12 @@ def cpu_baseline(kind, N, q, p, kq, kp, unit, what, seconds=12.0, t=0, gal=0):
             "note": "scalar C restatement of the reference (oracle/), one pinned thread per CPU with private copies of inputs and key; not the Go code"}
 
 
+def key_digest(key) -> int:
+    """48 bits of the SHA-256 of an evaluation key's device words (exact in a float64: compared across ranks over gloo)"""
+    import hashlib
+    return int(hashlib.sha256(key.download().tobytes()).hexdigest()[:12], 16)
+
+
 def replicate_key(cp, ev, key, rank, args):
     """N > 1: rank 0's key on every rank (one-time setup, before the timed region).  A transport that fails on any rank is
     given up by ALL ranks together (the outcome is agreed over the gloo control plane): rccl -> host -> each rank keeps the
@@ -320,6 +326,7 @@ def setup_c3(la, ctx, rank, B, cp, args):
         "alg_bytes_per_op": (6 * L + 2 * beta * (L + alpha)) * limb,
         "alg_bytes_per_op_amortised": 6 * L * limb + 2 * beta * (L + alpha) * limb / B,
         "valu_model": valu_model_mulrelin(q, p, N),
+        "key_digest": lambda: key_digest(rlk),
         "cpu": lambda: cpu_baseline("bgv_mulrelin", N, q, p, np.ascontiguousarray(kq), np.ascontiguousarray(kp),
                                     "ctxt-mul+relin ops/s", "BGV MulRelin (logN=15, 12+3 limbs)", t=T),
         "config": {"workload": "BGV logN=15, 12 Q-limbs [55,45x11] + 3 P-limbs [55x3], T=65537: ct x ct MulRelin "
@@ -395,6 +402,7 @@ def setup_c4(la, ctx, rank, B, cp, args):
         "kernel_bytes": None,
         "alg_bytes_per_op": (4 * L + 2 * beta * (L + alpha)) * limb,  # 160 MiB
         "alg_bytes_per_op_amortised": 4 * L * limb + 2 * beta * (L + alpha) * limb / B,
+        "key_digest": lambda: key_digest(gk),
         "cpu": lambda: cpu_baseline("rotate", N, q, p, kq, kp, "ctxt-rotate ops/s", "CKKS Rotate (logN=16, 20+4 limbs)", gal=gal),
         "config": {"workload": "CKKS logN=16, 20 Q-limbs [60,45x19] + 4 P-limbs [61x4]: Rotate (automorphism + Galois "
                                "key-switch), inputs resident in HBM, Galois key replicated on every GPU",
@@ -590,23 +598,24 @@ def main():
                     help="N > 1: rank 0's evaluation key is replicated to every rank before the timed region (RCCL broadcast "
                          "into the key's device storage, or gloo through host memory) instead of each rank drawing its own; "
                          "auto = rccl when the node has a GPU per rank, none otherwise")
+    ap.add_argument("--selftest", action="store_true",
+                    help="N > 1: fail (exit 5) unless every rank runs on its own GPU, the RCCL communicator reaches all N ranks and every "
+                         "rank's evaluation key equals rank 0's after the replication")
     ap.add_argument("--microbench", action="store_true", help="also report the modular-multiply probe")
     args = ap.parse_args()
 
     from lattigo_amd.dist import ControlPlane
     cp = ControlPlane()  # gloo control plane only (barrier + MAX of the elapsed time); no data-path collective
     rank, local_rank, world = cp.rank, cp.local_rank, cp.world
-    if world > 1:
-        import torch
-        torch.cuda.set_device(int(os.environ.get("HERING_FORCE_DEVICE", local_rank)))
-    if args.replicate_keys == "auto":
-        args.replicate_keys = "none"
-        if world > 1 and "HERING_FORCE_DEVICE" not in os.environ:
-            import torch
-            if torch.cuda.device_count() >= world:
-                args.replicate_keys = "rccl"
-
     import lattigo_amd as la
+    asked = args.replicate_keys
+    if args.replicate_keys == "auto":
+        # one GPU per rank: the RCCL broadcast (driven by libhering on the context's stream -- torch only carries the gloo control
+        # plane, so neither an import order nor torch.cuda is involved); ranks sharing a GPU (test hook) cannot form a communicator
+        args.replicate_keys = "none"
+        if world > 1 and "HERING_FORCE_DEVICE" not in os.environ and la.device_count() >= world:
+            args.replicate_keys = "rccl"
+
     # HERING_FORCE_DEVICE: test hook to exercise the multi-rank path on a box with fewer GPUs than ranks
     dev = int(os.environ.get("HERING_FORCE_DEVICE", local_rank if world > 1 else 0))
     ctx = la.Context(dev)
@@ -621,9 +630,6 @@ def main():
 
     def barrier():
         ctx.sync()
-        if world > 1:
-            import torch
-            torch.cuda.synchronize()
         cp.barrier()
 
     for _ in range(args.warmup):
@@ -642,6 +648,25 @@ def main():
     alg_trace = ctx.alg_bytes(reset=True)  # SURVEY 8(d) per-primitive bytes of the timed steps (key per entry, key per call)
     # what the control plane and (when keys were replicated over RCCL) the RCCL communicator saw
     ranks_seen = {"control_plane_gloo": int(cp.sum_over_ranks(1.0)), "rccl": cp.rccl_world() if args.replicate_keys == "rccl" else None}
+    # a replication that was asked for (or chosen by `auto` because the node has a GPU per rank) and did not happen is a failure of
+    # the run, not a footnote: the multi-GPU record must not silently be N independent key sets
+    multi_gpu_problems = []
+    if world > 1 and asked != "none" and args.replicate_keys.startswith("none") and (asked != "auto" or la.device_count() >= world):
+        multi_gpu_problems.append(f"key replication failed: asked for {asked!r}, ended with {args.replicate_keys!r}")
+    if world > 1 and args.replicate_keys == "rccl" and ranks_seen["rccl"] != world:
+        multi_gpu_problems.append(f"the RCCL communicator reaches {ranks_seen['rccl']} of {world} ranks")
+    key_digest = W.get("key_digest")
+    if world > 1 and key_digest is not None and not args.replicate_keys.startswith("none"):
+        d = float(key_digest())
+        if cp.max_over_ranks(d) != d or -cp.max_over_ranks(-d) != d:
+            multi_gpu_problems.append("evaluation keys differ between the ranks after the replication")
+    if args.selftest and world > 1:
+        devs = cp.sum_over_ranks(float(1 << (ctx.device_id % 48)))  # one bit per device in use: all distinct iff the sum has `world` bits
+        if bin(int(devs)).count("1") != world:
+            multi_gpu_problems.append("ranks share a GPU")
+        if args.replicate_keys != "rccl":
+            multi_gpu_problems.append(f"selftest wants the RCCL leg, the run used {args.replicate_keys!r}")
+    n_bad = cp.sum_over_ranks(1.0 if multi_gpu_problems else 0.0)
 
     # ---- parity of what was timed: the output of the last timed step against the oracle, on every rank ------------
     verified, vmsg = None, "skipped"
@@ -654,6 +679,9 @@ def main():
         cp.close()
         if verified is False:
             sys.exit(3)
+        if n_bad:
+            sys.stderr.write(f"[rank {rank}] multi-GPU problems: {multi_gpu_problems}\n")
+            sys.exit(5)
         return
 
     ops = world * W["units"] * args.steps
@@ -762,6 +790,7 @@ def main():
         "hip_event_ms_per_step": ev_ms / args.steps,
         "rank_ms_per_step": {"min": elapsed_min / args.steps * 1e3, "max": elapsed / args.steps * 1e3},
         "ranks_seen": ranks_seen, "replicate_keys": args.replicate_keys,
+        "multi_gpu_selftest": (None if world == 1 else ("ok" if not n_bad else f"FAILED on {int(n_bad)} rank(s): {multi_gpu_problems}")),
         "roofline": roofline,
     }
     if not args.no_b1 and world == 1 and args.workload != "c5" and B != 1:
@@ -821,6 +850,8 @@ def main():
     cp.close()
     if verified is False:
         sys.exit(3)
+    if n_bad:
+        sys.exit(5)
     if problems:
         sys.exit(4)
 

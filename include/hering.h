@@ -51,6 +51,7 @@ const char *he_last_error(void);
 const char *he_version(void);
 
 /* ---- context ---------------------------------------------------------------- */
+int he_device_count(int *n);  /* HIP devices visible to the process (0 without a driver or a device) */
 int he_ctx_create(int device_id, he_handle *ctx);
 int he_ctx_destroy(he_handle ctx);
 int he_ctx_sync(he_handle ctx);
@@ -277,6 +278,22 @@ int he_evk_destroy(he_handle evk);
  * follow any external write (it refreshes the derived double-precision copy) once that write has completed. */
 int he_evk_device_buffer(he_handle evk, void **ptr, size_t *bytes);
 int he_evk_commit(he_handle evk);
+/* The same replication with RCCL driven by the library itself, on the context's stream -- no framework in the data path, no
+ * import order to respect (librccl.so.1 is loaded at run time and shares this library's HIP runtime).  One process per GPU:
+ * rank 0 draws an id (he_rccl_unique_id, HE_RCCL_ID_BYTES bytes) and hands it to the other ranks over any control plane; every
+ * rank then calls he_rccl_comm_create(ctx, id, rank, world) -- collective, returns when all ranks have joined -- and
+ * he_evk_broadcast(comm, evk, root) on a key of the same shape (an empty one on the peers): the key words go GPU-to-GPU over
+ * xGMI into the key's device storage and the derived double-precision copy is refreshed.  he_rccl_comm_ranks all-reduces a one
+ * over the communicator: the number of ranks RCCL itself reaches (a self-test for multi-GPU runs).  he_poly_all_reduce_sum adds
+ * a polynomial's words across the ranks in place (mod 2^64; the partial accumulators of a key switch split by digit,
+ * he_gadget_product_hoisted_lazy_digits -- the caller reduces afterwards). */
+#define HE_RCCL_ID_BYTES 128
+int he_rccl_unique_id(uint8_t *id);
+int he_rccl_comm_create(he_handle ctx, const uint8_t *id, int rank, int world, he_handle *comm);
+int he_rccl_comm_destroy(he_handle comm);
+int he_rccl_comm_ranks(he_handle comm, int *ranks);
+int he_evk_broadcast(he_handle comm, he_handle evk, int root);
+int he_poly_all_reduce_sum(he_handle comm, he_handle poly);
 /* the key words back on the host, [beta][2][nQk + nPk][N] (GadgetCiphertext.MarshalBinary's payload order per digit is q then p,
  * core/rlwe/gadgetciphertext.go:110-132) */
 int he_evk_download(he_handle evk, uint64_t *dst, size_t n_words);

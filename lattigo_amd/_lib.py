@@ -59,7 +59,7 @@ def _declare(L):
     L.he_prof_kernel_name.restype = C.c_char_p
     L.he_prof_kernel_name.argtypes = [C.c_int]
     sig = {
-        "he_ctx_create": [i, HP], "he_ctx_destroy": [H], "he_ctx_sync": [H], "he_timer_start": [H],
+        "he_device_count": [C.POINTER(i)], "he_ctx_create": [i, HP], "he_ctx_destroy": [H], "he_ctx_sync": [H], "he_timer_start": [H],
         "he_timer_stop": [H, C.POINTER(C.c_float)], "he_device_info": [H, u64p],
         "he_ring_create": [H, i, u64p, i, HP], "he_ring_create_type": [H, i, i, u64p, i, HP], "he_ring_destroy": [H], "he_ring_constant": [H, i, i, u64p],
         "he_ring_roots": [H, i, i, u64p],
@@ -123,6 +123,9 @@ def _declare(L):
         "he_alg_bytes": [H, i, C.POINTER(C.c_double)],
         "he_graph_begin": [H], "he_graph_end": [H, HP], "he_graph_launch": [H], "he_graph_nodes": [H, C.POINTER(i)],
         "he_graph_destroy": [H],
+        "he_rccl_unique_id": [C.POINTER(C.c_uint8)], "he_rccl_comm_create": [H, C.POINTER(C.c_uint8), i, i, HP],
+        "he_rccl_comm_destroy": [H], "he_rccl_comm_ranks": [H, C.POINTER(i)], "he_evk_broadcast": [H, H, i],
+        "he_poly_all_reduce_sum": [H, H],
         "he_evaluator_set_coalescing": [H, i, i], "he_evaluator_coalescing_stats": [H, u64p],
         "he_debug_concurrent_mul_relin": [i, i, i, i, i, C.c_uint64, HP, HP, HP, HP, HP, HP, HP, HP, HP, C.POINTER(C.c_double)],
     }

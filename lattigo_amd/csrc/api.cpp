@@ -23,6 +23,7 @@
 #include <unordered_map>
 #include <cstdlib>
 #include <vector>
+#include <dlfcn.h>
 #include <pthread.h>
 #include <sched.h>
 
@@ -56,7 +57,7 @@ int fail(int code, const char *fmt, ...) {
         if (_r != HE_OK) return _r; \
     } while (0)
 
-enum ObjType { T_CTX = 1, T_RING, T_POLY, T_INDEX, T_BE, T_EVAL, T_EVK, T_DECOMP, T_GRAPH };
+enum ObjType { T_CTX = 1, T_RING, T_POLY, T_INDEX, T_BE, T_EVAL, T_EVK, T_DECOMP, T_GRAPH, T_COMM };
 
 struct Obj {
     ObjType type;
@@ -598,6 +599,13 @@ int he_ctx_create(int device_id, he_handle *out) {
     return HE_OK;
 }
 int he_ctx_destroy(he_handle h) { return unreg(h, T_CTX); }
+int he_device_count(int *n) {
+    if (!n) return fail(HE_EINVAL, "he_device_count: null output");
+    *n = 0;
+    const hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) { (void)hipGetLastError(); *n = 0; }  // no driver / no device: zero, not an error
+    return HE_OK;
+}
 int he_ctx_sync(he_handle h) {
     GET(c, Ctx, h, T_CTX);
     if (c->capturing) return fail(HE_EINVAL, "he_ctx_sync: the context is capturing a graph (he_graph_end first)");
@@ -3218,6 +3226,141 @@ int he_probe_modmul_f64(he_handle hctx, int iters, double *out) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *out = (double)n * iters / (ms * 1e-3);
+    return HE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// RCCL over xGMI ("RCCL only for key distribution", and the partial accumulators of a key switch split
+// over the GPUs by digit).  librccl is loaded at run time and driven directly on the context's stream: no framework in the
+// data path and no second HIP runtime in the process (librccl.so.1 binds to the libamdhip64 this library already uses).
+// ---------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+typedef struct ncclComm *rccl_comm_t;
+typedef struct { char internal[128]; } rccl_id_t;
+constexpr int kRcclUint64 = 5, kRcclSum = 0;  // ncclDataType_t / ncclRedOp_t of rccl.h
+struct RcclApi {
+    void *so = nullptr;
+    int (*GetUniqueId)(rccl_id_t *) = nullptr;
+    int (*CommInitRank)(rccl_comm_t *, int, rccl_id_t, int) = nullptr;
+    int (*CommDestroy)(rccl_comm_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why, path;
+};
+RcclApi &rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        // first choice: the librccl that sits next to the HIP runtime this process actually loaded (a framework imported before
+        // this library brings its own pair -- torch/lib/libamdhip64.so + librccl.so -- and an RCCL build should meet the runtime
+        // it was built with); then the system's
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                names.push_back(dir + "/librccl.so.1");
+                names.push_back(dir + "/librccl.so");
+            }
+        }
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(n);
+        for (const std::string &name : names) {
+            a.so = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (a.so) { a.path = name; break; }
+        }
+        if (!a.so) { a.why = dlerror() ? dlerror() : "librccl.so.1 not found"; return a; }
+        auto sym = [&](const char *n) { void *p = dlsym(a.so, n); if (!p) a.why = std::string("missing symbol ") + n; return p; };
+        a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
+        a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+        a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+        return a;
+    }();
+    return api;
+}
+int rccl_ready() {
+    RcclApi &a = rccl();
+    if (!a.so || !a.why.empty()) return fail(HE_EDEVICE, "RCCL is not available: %s", a.why.c_str());
+    return HE_OK;
+}
+#define RCCL_TRY(expr)                                                                                                  \
+    do {                                                                                                                \
+        int _r = (expr);                                                                                                \
+        if (_r != 0) return fail(HE_EDEVICE, "%s: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(_r) : "?"); \
+    } while (0)
+struct Comm : Obj {
+    std::shared_ptr<Ctx> ctx;
+    rccl_comm_t comm = nullptr;
+    int rank = 0, world = 0;
+    Comm() : Obj(T_COMM) {}
+    ~Comm() override {
+        hipSetDevice(ctx->dev);
+        hipStreamSynchronize(ctx->stream);
+        if (comm) rccl().CommDestroy(comm);
+    }
+};
+}  // namespace
+}  // extern "C++"
+int he_rccl_unique_id(uint8_t *id) {
+    if (!id) return fail(HE_EINVAL, "he_rccl_unique_id: null output");
+    TRY(rccl_ready());
+    rccl_id_t u;
+    RCCL_TRY(rccl().GetUniqueId(&u));
+    memcpy(id, u.internal, sizeof u.internal);
+    return HE_OK;
+}
+int he_rccl_comm_create(he_handle hctx, const uint8_t *id, int rank, int world, he_handle *out) {
+    GET(c, Ctx, hctx, T_CTX);
+    if (!id || !out || world <= 0 || rank < 0 || rank >= world) return fail(HE_EINVAL, "he_rccl_comm_create: bad arguments");
+    TRY(rccl_ready());
+    auto m = std::make_shared<Comm>();
+    m->ctx = c; m->rank = rank; m->world = world;
+    rccl_id_t u;
+    memcpy(u.internal, id, sizeof u.internal);
+    Scope sc(c.get());  // (selects the context's device: the communicator is bound to it)
+    RCCL_TRY(rccl().CommInitRank(&m->comm, world, u, rank));
+    *out = reg(m);
+    return HE_OK;
+}
+int he_rccl_comm_destroy(he_handle h) { return unreg(h, T_COMM); }
+int he_rccl_comm_ranks(he_handle h, int *ranks) {
+    GET(m, Comm, h, T_COMM);
+    if (!ranks) return fail(HE_EINVAL, "he_rccl_comm_ranks: null output");
+    Ctx *c = m->ctx.get();
+    Scope sc(c);
+    TRY(c->arena_reserve(2));
+    uint64_t *d = c->arena_take(2), one = 1, sum = 0;
+    HIP_TRY(hipMemcpyAsync(d, &one, 8, hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(rccl().AllReduce(d, d, 1, kRcclUint64, kRcclSum, m->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(&sum, d, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *ranks = (int)sum;
+    return HE_OK;
+}
+int he_evk_broadcast(he_handle hcomm, he_handle hk, int root) {
+    GET(m, Comm, hcomm, T_COMM);
+    GET(k, Evk, hk, T_EVK);
+    Ctx *c = m->ctx.get();
+    if (k->ev->be->ctx.get() != c) return fail(HE_EINVAL, "he_evk_broadcast: the key belongs to another context than the communicator");
+    if (root < 0 || root >= m->world) return fail(HE_EINVAL, "he_evk_broadcast: root %d outside [0, %d)", root, m->world);
+    Scope sc(c);
+    const size_t words = (size_t)k->beta * 2 * (size_t)(k->nQk + k->nPk) * k->ev->be->Q->N;
+    RCCL_TRY(rccl().Broadcast(k->d, k->d, words, kRcclUint64, root, m->comm, c->stream));
+    if (m->rank != root) TRY(evk_derive(*k));  // the derived double-precision copy follows the new words (same stream: ordered)
+    return HE_OK;
+}
+int he_poly_all_reduce_sum(he_handle hcomm, he_handle hp) {
+    GET(m, Comm, hcomm, T_COMM);
+    GET(p, Poly, hp, T_POLY);
+    Ctx *c = m->ctx.get();
+    if (p->ctx.get() != c) return fail(HE_EINVAL, "he_poly_all_reduce_sum: the polynomial belongs to another context than the communicator");
+    Scope sc(c);
+    RCCL_TRY(rccl().AllReduce(p->d, p->d, (size_t)p->batch * p->nlimbs * p->N, kRcclUint64, kRcclSum, m->comm, c->stream));
     return HE_OK;
 }
 

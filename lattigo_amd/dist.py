@@ -3,7 +3,9 @@ ciphertexts sharded across ranks, evaluation keys replicated, NO data-path colle
 cross-rank traffic is a barrier around the timed region and a MAX-reduce of the elapsed time; both
 run over gloo on host tensors, so the same code is testable with world_size 2 on CPU.  The one-time
 replication of evaluation keys (ReplicateEvaluationKey) goes GPU-to-GPU as an RCCL broadcast over xGMI
-straight into the key's device storage, or over gloo through host memory."""
+straight into the key's device storage, or over gloo through host memory.  The RCCL leg is driven by libhering
+itself (he_rccl_* / he_evk_broadcast, include/hering.h) on the context's stream: torch is used for the gloo
+control plane only -- CPU tensors -- so no import order has to be respected and no second HIP runtime is touched."""
 from __future__ import annotations
 
 import os
@@ -45,14 +47,15 @@ class ControlPlane:
         return float(t.item())
 
     def rccl_world(self):
-        """Ranks of the RCCL communicator as RCCL itself counts them (an all-reduce of ones on the device), or None when no RCCL
-        group was created in this process (no key replication / split key switch over RCCL took place)."""
-        if self._rccl is None or self._dist is None:
+        """Ranks of the RCCL communicator as RCCL itself counts them (an all-reduce of ones on the device, he_rccl_comm_ranks), or
+        None when no communicator was created in this process (no key replication / split key switch over RCCL took place)."""
+        if self._rccl is None:
             return None
-        import torch
-        t = torch.ones(1, dtype=torch.int64, device=f"cuda:{torch.cuda.current_device()}")
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._rccl)
-        return int(t.item())
+        import ctypes as C
+        from ._lib import check, load
+        n = C.c_int()
+        check(load().he_rccl_comm_ranks(self._rccl[1], C.byref(n)))
+        return int(n.value)
 
     def broadcast_object(self, obj, src: int = 0):
         if self._dist is None:
@@ -72,19 +75,23 @@ class ControlPlane:
         self._dist.broadcast(t, src=src)
         return t.numpy().tobytes()
 
-    def _rccl_group(self, device: int):
+    def _rccl_comm(self, ctx):
+        """The RCCL communicator of this process's context (created on first use; collective: every rank must call it): rank 0
+        draws the id, the gloo control plane hands it round, he_rccl_comm_create joins."""
         if self._rccl is None:
-            import torch
-            # torch ships its own libamdhip64; libhering binds to whichever copy the process loaded first, and two HIP
-            # runtimes in one process cannot both own the GPU.  `import torch` before lattigo_amd makes them share one.
-            with open("/proc/self/maps") as f:
-                copies = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
-            if len(copies) > 1:
-                raise RuntimeError("two HIP runtimes are loaded (%s): import torch before lattigo_amd to use the RCCL transport"
-                                   % ", ".join(sorted(copies)))
-            torch.cuda.set_device(device)
-            self._rccl = self._dist.new_group(backend="nccl")  # "nccl" is RCCL on ROCm
-        return self._rccl
+            import ctypes as C
+            from ._lib import H, check, load
+            ident = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                check(load().he_rccl_unique_id(ident))
+            blob = self.broadcast_bytes(bytes(ident), src=0) if self._dist is not None else bytes(ident)
+            ident = (C.c_uint8 * 128)(*blob)
+            h = H()
+            check(load().he_rccl_comm_create(ctx.h, ident, self.rank, self.world, C.byref(h)))
+            self._rccl = (ctx, h.value)
+        if self._rccl[0] is not ctx:
+            raise RuntimeError("the RCCL communicator of this process belongs to another context")
+        return self._rccl[1]
 
     def ReplicateEvaluationKey(self, evaluator, key=None, src: int = 0, transport: str = "rccl"):
         """Rank src holds `key` (rlwe.EvaluationKey); every rank returns a device-resident copy of it.  transport "rccl":
@@ -96,21 +103,12 @@ class ControlPlane:
         shape = self.broadcast_object(key.Shape() if self.rank == src else None, src)
         beta, nQk, nPk, base_two, nj = shape
         if transport == "rccl":
-            import torch
-            dev = evaluator.ringQ.ctx.device_id
+            from ._lib import check, load
             if self.rank != src:
                 key = EvaluationKey(evaluator, None, None, base_two, nj, shape=(beta, nQk, nPk))
-            ptr, nbytes = key.DeviceBuffer()  # drains the context's stream
-
-            class _DeviceWords:
-                __cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<i8", "data": (ptr, False), "version": 2}
-
-            t = torch.as_tensor(_DeviceWords(), device=f"cuda:{dev}")
-            assert t.data_ptr() == ptr
-            self._dist.broadcast(t, src=src, group=self._rccl_group(dev))
-            torch.cuda.synchronize(dev)
-            if self.rank != src:
-                key.Commit()
+            # on the context's stream: the words land in the key's device storage, the derived copy is refreshed behind them
+            check(load().he_evk_broadcast(self._rccl_comm(evaluator.ringQ.ctx), key.h, src))
+            evaluator.ringQ.ctx.sync()
             return key
         if transport != "host":
             raise ValueError("transport is 'rccl' or 'host'")
@@ -138,20 +136,10 @@ class ControlPlane:
             if self.world * max(int(q) for q in r.moduli) >= 1 << 64:
                 raise ValueError("AllReduceSumPolys: world * q exceeds 64 bits")
         if transport == "rccl":
-            import torch
-            dev = rings[0].ctx.device_id
-            group = self._rccl_group(dev)
-            views = []
-            for p in polys:
-                ptr, nbytes = p.DeviceBuffer()  # drains the context's stream
-
-                class _DeviceWords:
-                    __cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<i8", "data": (ptr, False), "version": 2}
-
-                views.append(torch.as_tensor(_DeviceWords(), device=f"cuda:{dev}"))
-            for t in views:  # two's-complement addition of the 64-bit words = addition mod 2^64
-                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=group)
-            torch.cuda.synchronize(dev)
+            from ._lib import check, load
+            comm = self._rccl_comm(rings[0].ctx)
+            for p in polys:  # addition of the 64-bit words mod 2^64, in place, on the context's stream (he_poly_all_reduce_sum)
+                check(load().he_poly_all_reduce_sum(comm, p.h))
         elif transport == "host":
             import numpy as np
             import torch
@@ -190,6 +178,10 @@ class ControlPlane:
         return range(self.rank, n_items, self.world)
 
     def close(self):
+        if self._rccl is not None:
+            from ._lib import load
+            load().he_rccl_comm_destroy(self._rccl[1])
+            self._rccl = None
         if self._dist is not None:
             self._dist.barrier()
             self._dist.destroy_process_group()

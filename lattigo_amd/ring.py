@@ -87,6 +87,13 @@ class Graph:
             pass
 
 
+def device_count() -> int:
+    """HIP devices visible to this process (he_device_count)."""
+    n = C.c_int()
+    check(load().he_device_count(C.byref(n)))
+    return int(n.value)
+
+
 class Context:
     """One HIP device + stream (one per process/GPU)."""
 

@@ -42,7 +42,6 @@ def test_bench_two_ranks_every_workload(workload, batch):
 
 _RCCL_WORKER = """
 import hashlib, os, sys
-import torch                              # before libhering: one HIP runtime in the process (lattigo_amd/dist.py)
 sys.path.insert(0, %r)
 import numpy as np
 import lattigo_amd as la
@@ -51,8 +50,7 @@ from oracle import oracle as O
 from tests.helpers import rng_for, uniform_poly
 cp = ControlPlane()
 dev = cp.local_rank
-torch.cuda.set_device(dev)
-ctx = la.Context(dev)                     # one rank per GPU
+ctx = la.Context(dev)                     # one rank per GPU; the RCCL leg runs inside libhering on this context's stream
 q, p = O.GenModuli(13, [55, 45, 45, 45], [55, 46])
 N = 1 << 12
 gQ, gP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
@@ -201,9 +199,62 @@ def test_one_key_switch_split_over_gpus_rccl(tmp_path):
     if n < 2:
         pytest.skip("needs at least two GPUs (runs on the driver's multi-GPU node)")
     script = tmp_path / "worker.py"
-    script.write_text("import torch\n" + (_SPLIT_WORKER % (ROOT, "rccl")).replace('os.environ.get("HERING_FORCE_DEVICE", cp.local_rank)', "cp.local_rank"))
+    script.write_text((_SPLIT_WORKER % (ROOT, "rccl")).replace('os.environ.get("HERING_FORCE_DEVICE", cp.local_rank)', "cp.local_rank"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", "29569", str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert out.returncode == 0, out.stderr[-3000:]
     assert f"SPLIT_OK {n}" in out.stdout
+
+
+_RCCL_SOLO_WORKER = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import numpy as np
+import lattigo_amd as la                  # no torch in this process: libhering loads RCCL itself (he_rccl_*)
+from lattigo_amd import rlwe as R
+from lattigo_amd._lib import H, check, load
+from oracle import oracle as O
+from tests.helpers import rng_for, uniform_poly
+assert "torch" not in sys.modules
+ctx = la.Context(0)
+N = 1 << 11
+q, p = O.GenModuli(12, [55, 45, 45, 45], [55, 46])
+gQ, gP = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+gev = la.Evaluator(gQ, gP)
+rng = rng_for(2990)
+kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(2)])
+kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(2)])
+key = gev.NewEvaluationKey(kq, kp)
+ident = (C.c_uint8 * 128)()
+check(load().he_rccl_unique_id(ident))
+comm = H()
+check(load().he_rccl_comm_create(ctx.h, ident, 0, 1, C.byref(comm)))
+n = C.c_int()
+check(load().he_rccl_comm_ranks(comm.value, C.byref(n)))
+assert n.value == 1
+check(load().he_evk_broadcast(comm.value, key.h, 0))          # a one-rank broadcast leaves the root's words as they are
+cx = uniform_poly(rng, q, N)
+ct = [la.Poly(gQ, 4), la.Poly(gQ, 4)]
+gev.GadgetProduct(3, la.Poly(gQ, 4).upload(cx), key, ct)
+want = O.Evaluator(O.Ring(N, q), O.Ring(N, p)).GadgetProduct(3, cx, O.EvaluationKey(kq, kp))
+assert np.array_equal(np.stack([c.get() for c in ct]), want)
+pcx = la.Poly(gQ, 4).upload(cx)
+check(load().he_poly_all_reduce_sum(comm.value, pcx.h))       # the sum over one rank
+assert np.array_equal(pcx.get(), cx)
+assert load().he_evk_broadcast(comm.value, key.h, 3) != 0     # root outside the communicator: refused
+check(load().he_rccl_comm_destroy(comm.value))
+print("RCCL_SOLO_OK")
+"""
+
+
+def test_library_side_rccl_leg_one_rank(tmp_path):
+    """The RCCL leg libhering drives itself (he_rccl_unique_id / he_rccl_comm_create / he_evk_broadcast / he_poly_all_reduce_sum /
+    he_rccl_comm_ranks) on a one-rank communicator, in a process that never imports torch: librccl is loaded at run time next to
+    the HIP runtime in use.  (The multi-rank leg needs a GPU per rank: test_multi_rank_rccl_key_replication.)"""
+    script = tmp_path / "worker.py"
+    script.write_text(_RCCL_SOLO_WORKER % ROOT)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "RCCL_SOLO_OK" in out.stdout
+
