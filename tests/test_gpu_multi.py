@@ -36,8 +36,7 @@ def test_bench_two_ranks_every_workload(workload, batch):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["batch_per_gpu"] == batch
-    if workload != "c5":
-        assert line["verified"] is True, line["verified_detail"]
+    assert line["verified"] is True, line["verified_detail"]  # (c5: every entry against the oracle-backed trace's committed digest)
 
 
 _RCCL_WORKER = """

@@ -43,29 +43,43 @@ def gen_primes(logs, nth, taken):
     return out
 
 
-def build(ctx, B, seed_offset=0):
+def build(ctx, B, seed_offset=0, same_input=False):
     """-> (run, info): run() performs one bootstrap of a batch of B ciphertexts on `ctx` (bench.py --workload c5);
-    info carries the shape facts and the objects main() needs for its phase report."""
+    info carries the shape facts and the objects main() needs for its phase report.
+    ctx = None: the SAME trace (same seed, same synthetic keys / diagonals / input) on the CPU oracle backend (oracle/circuits.py),
+    batch 1 -- the checker: tests/golden/gen_c5_trace_digest.py commits the digest of its output, bench.py compares the device's.
+    same_input: every batch entry carries entry 0's ciphertext, so that one oracle run (about a minute of CPU) checks them all."""
+    device = ctx is not None
     logN = 16
     N, n, nth = 1 << logN, 1 << (logN - 1), 2 << logN
     taken = set()
     q, p = gen_primes(LOGQ, nth, taken), gen_primes(LOGP, nth, taken)
-    rq, rp = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
-    ev = la.Evaluator(rq, rp)
+    if device:
+        rq, rp = la.Ring(ctx, N, q), la.Ring(ctx, N, p)
+        ev = la.Evaluator(rq, rp)
+    else:
+        from oracle import circuits as OC
+        from oracle import oracle as O
+        assert B == 1
+        rq, rp = O.Ring(N, q), O.Ring(N, p)
+        ev = O.Evaluator(rq, rp)
     rng = np.random.Generator(np.random.PCG64(0x1A77160 + 5 + seed_offset))
     top, LP = len(q) - 1, len(p)
     beta = (top + 1 + LP - 1) // LP
     kq, kp = uniform(rng, q, N, (beta, 2)), uniform(rng, p, N, (beta, 2))  # one synthetic key image, uploaded per key
 
     def key():
-        return ev.NewEvaluationKey(kq, kp)
+        return ev.NewEvaluationKey(kq, kp) if device else O.EvaluationKey(kq, kp)
 
     dq, dp = uniform(rng, q, N), uniform(rng, p, N)
 
     def diag(level):
+        if not device:
+            return (dq[: level + 1], dp)
         return (la.Poly(rq, level + 1).upload(dq[: level + 1]), la.Poly(rp, LP).upload(dp))
 
-    gks = R.GaloisKeySet()
+    gks = R.GaloisKeySet() if device else None
+    keys = gks.keys if device else {}
     mats = {"cts": [], "stc": []}
     # CoeffsToSlots: 4 factors at the top levels (4+4+4+3 radix-2 layers); SlotsToCoeffs: 3 factors (5+5+5)
     plan = [("cts", top - i, k, 1 << s) for i, (k, s) in enumerate([(4, 11), (4, 7), (4, 3), (3, 0)])]
@@ -78,28 +92,49 @@ def build(ctx, B, seed_offset=0):
         _, r1, r2 = LT.BSGSIndex(diags, n, N1)
         for r in set(r1) | set(r2):
             g = R.GaloisElement(nth, r)
-            if r and g not in gks.keys:
-                gks.keys[g] = key()
-        mats[which].append(LT.LinearTransformation({d: diag(level) for d in diags}, level, LP - 1, n, N1))
+            if r and g not in keys:
+                keys[g] = key()
+        LTC = LT.LinearTransformation if device else OC.LinearTransformation
+        mats[which].append(LTC({d: diag(level) for d in diags}, level, LP - 1, n, N1))
         ndiag += len(diags)
-    gks.keys[nth - 1] = key()
+    keys[nth - 1] = key()
     rlk, d2s, s2d = key(), key(), key()
-    gce = S.CKKSCiphertextEvaluator(ev, rlk)
-    lte = LT.LinTransEvaluator(ev, gks)
-    be = BS.DeviceBootstrapBackend(gce, lte, R.InnerSumEvaluator(ev, gks), d2s, s2d)
+    if device:
+        gce = S.CKKSCiphertextEvaluator(ev, rlk)
+        lte = LT.LinTransEvaluator(ev, gks)
+        be = BS.DeviceBootstrapBackend(gce, lte, R.InnerSumEvaluator(ev, gks), d2s, s2d)
+    else:
+        gce = OC.CKKSCtEvaluator(ev, rlk)
+        be = OC.OracleBootstrapBackend(gce, OC.LinTransEvaluator(ev, keys), OC.InnerSumEvaluator(ev, keys), d2s, s2d)
     pm = M1.Mod1Parameters(q[0], LevelQ=top - 4, LogScale=60, Mod1Type=M1.CosContinuous, K=16, Mod1Degree=30, DoubleAngle=3)
     scales = lambda ms: [Fraction(q[m.LevelQ]) for m in ms]
     boot = BS.Bootstrapper(be, M1.Mod1Evaluator(gce, pm), mats["cts"], scales(mats["cts"]), mats["stc"], scales(mats["stc"]),
                            modup_scale=256.0)
-    ct0 = [la.Poly(rq, 1, B).upload(uniform(rng, q[:1], N, (B,))) for _ in range(2)]
+    host0 = [uniform(rng, q[:1], N, (1 if same_input or not device else B,)) for _ in range(2)]
+    if device:
+        ct0 = [la.Poly(rq, 1, B).upload(np.repeat(h, B, axis=0) if same_input else h) for h in host0]
+        run = lambda: boot.Bootstrap(S.Ciphertext(ct0, 0, 1), Fraction(1 << 60))
+    else:
+        ct0 = [h[0] for h in host0]
+        run = lambda: boot.Bootstrap(OC.Ct(list(ct0), 1), Fraction(1 << 60))
 
-    def run():
-        return boot.Bootstrap(S.Ciphertext(ct0, 0, 1), Fraction(1 << 60))
+    info = {"logN": logN, "L": len(q), "alpha": LP, "galois_keys": len(keys), "dft_diagonals": ndiag}
+    run_ = lambda: run()
+    run_._parts = (boot, be, ct0, gks, ndiag)  # for main()'s phase report
+    run_._shape = {"N": N, "q": q, "p": p, "kq": kq, "kp": kp, "ev": ev, "rq": rq, "key": rlk, "gal": R.GaloisElement(nth, 1)}  # bench.py's CPU leg
+    return run_, info
 
-    info = {"logN": logN, "L": len(q), "alpha": LP, "galois_keys": len(gks.keys), "dft_diagonals": ndiag}
-    run._parts = (boot, be, ct0, gks, ndiag)  # for main()'s phase report
-    run._shape = {"N": N, "q": q, "p": p, "kq": kq, "kp": kp, "ev": ev, "rq": rq, "key": rlk, "gal": R.GaloisElement(nth, 1)}  # bench.py's CPU leg
-    return run, info
+
+def trace_digest(res, device: bool) -> dict:
+    """SHA-256 of every batch entry's refreshed ciphertext (both polynomials, limbs 0..level) of one run()"""
+    import hashlib
+    if device:
+        words = [v.download()[:, : res.level + 1] for v in res.Value]  # [B][limbs][N] per component
+        B = words[0].shape[0]
+        per = [hashlib.sha256(np.ascontiguousarray(np.stack([w[b] for w in words])).tobytes()).hexdigest() for b in range(B)]
+    else:
+        per = [hashlib.sha256(np.ascontiguousarray(np.stack([np.asarray(v)[: res.level + 1] for v in res.Value]), dtype=np.uint64).tobytes()).hexdigest()]
+    return {"level": int(res.level), "entries": per}
 
 
 def main():
