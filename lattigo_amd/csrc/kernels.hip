@@ -1281,9 +1281,17 @@ struct MacEpiK {
     const uint64_t *ta0, *ta1, *tb0, *tb1; size_t ta0_bs, ta1_bs, tb0_bs, tb1_bs;
     int ext_f64, tensor, has_w0, has_w1;
     double sp[kMaxLimbs], tsp[kMaxLimbs];
-    // entry tables (View::tab) of the caller-facing operands
-    const size_t *out0_tab, *out1_tab, *w0_tab, *w1_tab, *ta0_tab, *ta1_tab, *tb0_tab, *tb1_tab;
+    // entry tables (View::tab) of the caller-facing operands, as ONE base pointer plus a row number per operand (eight separate
+    // pointers cost this kernel seventy more spilled scalar registers): operand i's offsets are etab[row_i * nbatch + z], its
+    // row the i-th nibble of etab_rows in the order out0, out1, w0, w1, ta0, ta1, tb0, tb1 (0xF: no table, z * bstride)
+    const size_t *etab;
+    unsigned etab_rows;
 };
+enum { ME_OUT0 = 0, ME_OUT1, ME_W0, ME_W1, ME_TA0, ME_TA1, ME_TB0, ME_TB1 };
+__device__ __forceinline__ size_t meoff(const MacEpiK &e, int which, size_t bs, size_t z, unsigned nbatch) {
+    const unsigned row = (e.etab_rows >> (4 * which)) & 0xFu;
+    return (e.etab && row != 0xFu) ? (size_t)ldc(reinterpret_cast<const uint64_t *>(e.etab), (size_t)row * nbatch + z) : z * bs;
+}
 struct NttMacDmaArgs {
     NttMacKArgs k;
     MacEpiK e;
@@ -1533,7 +1541,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 // needs from memory are requested before / while the transform runs, in the registers the key rows use in a digit.
                 const bool second = c != 0;
                 const size_t off = (size_t)cur.out_limb * A.N + cur.rowoff + tau;
-                uint64_t *op = (second ? AA.e.out1 + voff(AA.e.out1_tab, AA.e.out1_bs, cur.bz) : AA.e.out0 + voff(AA.e.out0_tab, AA.e.out0_bs, cur.bz)) + off;
+                uint64_t *op = (second ? AA.e.out1 + meoff(AA.e, ME_OUT1, AA.e.out1_bs, cur.bz, AA.nbatch) : AA.e.out0 + meoff(AA.e, ME_OUT0, AA.e.out0_bs, cur.bz, AA.nbatch)) + off;
                 const double sp = AA.e.sp[cur.l];
                 const uint64_t *mcw = reinterpret_cast<const uint64_t *>(A.mc + cur.mi);
                 const uint64_t qu = ldc(mcw, 0);
@@ -1544,8 +1552,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 MAC_STAMP2(48 + c * 4 + 2);
                 if (tensor) {
                     const double tsp = AA.e.tsp[cur.l];
-                    const uint64_t *pa0 = AA.e.ta0 + voff(AA.e.ta0_tab, AA.e.ta0_bs, cur.bz) + off, *pa1 = AA.e.ta1 + voff(AA.e.ta1_tab, AA.e.ta1_bs, cur.bz) + off;
-                    const uint64_t *pb0 = AA.e.tb0 + voff(AA.e.tb0_tab, AA.e.tb0_bs, cur.bz) + off, *pb1 = AA.e.tb1 + voff(AA.e.tb1_tab, AA.e.tb1_bs, cur.bz) + off;
+                    const uint64_t *pa0 = AA.e.ta0 + meoff(AA.e, ME_TA0, AA.e.ta0_bs, cur.bz, AA.nbatch) + off, *pa1 = AA.e.ta1 + meoff(AA.e, ME_TA1, AA.e.ta1_bs, cur.bz, AA.nbatch) + off;
+                    const uint64_t *pb0 = AA.e.tb0 + meoff(AA.e, ME_TB0, AA.e.tb0_bs, cur.bz, AA.nbatch) + off, *pb1 = AA.e.tb1 + meoff(AA.e, ME_TB1, AA.e.tb1_bs, cur.bz, AA.nbatch) + off;
                     const uint64_t twoq_u = qu << 1, brc0 = ldc(mcw, 2);
                     // caller words may be any 64-bit representative (as MRed accepts them); every pipeline of this library hands over
                     // words below 2q, which convert as they are -- the Barrett reduction runs only for a wave that met a larger one
@@ -1617,7 +1625,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                     }
 #undef HE_H
                 } else if (addw) {
-                    const uint64_t *wp = (second ? AA.e.w1 + voff(AA.e.w1_tab, AA.e.w1_bs, cur.bz) : AA.e.w0 + voff(AA.e.w0_tab, AA.e.w0_bs, cur.bz)) + off;
+                    const uint64_t *wp = (second ? AA.e.w1 + meoff(AA.e, ME_W1, AA.e.w1_bs, cur.bz, AA.nbatch) : AA.e.w0 + meoff(AA.e, ME_W0, AA.e.w0_bs, cur.bz, AA.nbatch)) + off;
                     uint64_t wv[16];
 #pragma unroll
                     for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[(unsigned)(k * T)]);
@@ -1712,8 +1720,19 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
             D.e.tensor = epi->tensor ? 1 : 0;
             D.e.ta0 = epi->ta0.p; D.e.ta0_bs = epi->ta0.bstride; D.e.ta1 = epi->ta1.p; D.e.ta1_bs = epi->ta1.bstride;
             D.e.tb0 = epi->tb0.p; D.e.tb0_bs = epi->tb0.bstride; D.e.tb1 = epi->tb1.p; D.e.tb1_bs = epi->tb1.bstride;
-            D.e.out0_tab = epi->out0.tab; D.e.out1_tab = epi->out1.tab; D.e.w0_tab = epi->w0.tab; D.e.w1_tab = epi->w1.tab;
-            D.e.ta0_tab = epi->ta0.tab; D.e.ta1_tab = epi->ta1.tab; D.e.tb0_tab = epi->tb0.tab; D.e.tb1_tab = epi->tb1.tab;
+            {   // the operands' entry tables must be rows of ONE table with `batch` entries per row (api.cpp builds them so)
+                const View *vs[8] = {&epi->out0, &epi->out1, &epi->w0, &epi->w1, &epi->ta0, &epi->ta1, &epi->tb0, &epi->tb1};
+                const size_t *base = nullptr;
+                for (const View *v : vs) if (v->tab && (!base || v->tab < base)) base = v->tab;
+                D.e.etab = base;
+                D.e.etab_rows = 0xFFFFFFFFu;
+                for (int i = 0; i < 8 && base; i++) {
+                    if (!vs[i]->tab) continue;
+                    const size_t d = (size_t)(vs[i]->tab - base);
+                    if (d % (size_t)batch != 0 || d / (size_t)batch >= 15) return hipErrorInvalidValue;
+                    D.e.etab_rows = (D.e.etab_rows & ~(0xFu << (4 * i))) | ((unsigned)(d / (size_t)batch) << (4 * i));
+                }
+            }
             for (int i = 0; i < a.nlimbs; i++) { D.e.sp[i] = epi->sp[i]; D.e.tsp[i] = epi->tsp[i]; }
         }
         D.nbatch = (unsigned)batch;
