@@ -246,14 +246,16 @@ int he_evaluator_destroy(he_handle eval);
  * (schemes/schemes.go:14-28) and scales by running many such calls at once -- one goroutine per ciphertext over evaluators that
  * share their tables and keys (Evaluator.ShallowCopy / WithKey, core/rlwe/evaluator.go:200-227; b.RunParallel in
  * schemes/ckks/ckks_benchmarks_test.go:116-207).  A GPU wants those independent callers in one launch: with max_batch > 1,
- * he_ckks_mul_relin / he_bgv_mul_relin calls on `eval` that carry batch-1 polynomials and a relinearisation key are filed in a
- * submission queue; requests of the same (scheme, level, t, key) waiting at the same time -- from any number of OS threads --
- * are executed as ONE batched launch that addresses each caller's own polynomials through a device table of entry pointers (no
- * staging copies), and every call returns once its batch is enqueued on the context's stream (the usual contract: results
- * are visible after he_ctx_sync or a download).  window_us bounds how long a request waits for companions while the device is
- * idle; while two earlier batches are still in flight, gathering continues for free.  Results are bit-identical to the
- * uncoalesced calls.  max_batch <= 1 switches it off.  Calls with batch > 1, without a key, or made while the context records
- * a graph are launched directly as before. */
+ * the single-ciphertext forms (batch-1 polynomials) of he_ckks_mul_relin / he_bgv_mul_relin (with a relinearisation key),
+ * he_gadget_product, he_relinearize and he_automorphism_ct on `eval` are filed in a submission queue; requests of the same
+ * (operation, level, t / Galois element, key) waiting at the same time -- from any number of OS threads -- are executed as ONE
+ * batched launch that addresses each caller's own polynomials through a device table of entry pointers (no staging copies), and
+ * every call returns once its batch is enqueued on the context's stream (the usual contract: results are visible after
+ * he_ctx_sync or a download).  window_us bounds how long a request waits for companions while the device is idle (a lone caller
+ * does not wait at all); while two earlier batches are still in flight, gathering continues for free.  Results are bit-identical
+ * to the uncoalesced calls.  max_batch <= 1 switches it off.  Calls with batch > 1, a MulRelin without a key, hoisted forms, and
+ * calls made while the context records a graph are launched directly as before; shapes whose pipeline has no fused plans
+ * (base-2 gadgets, conjugate-invariant rings, evaluators without special primes) are queued but served one by one. */
 int he_evaluator_set_coalescing(he_handle eval, int max_batch, int window_us);
 
 /* GadgetCiphertext (core/rlwe/gadgetciphertext.go:19-42), BaseTwoDecomposition = 0.

@@ -37,11 +37,14 @@ int he_probe_modmul_f64(he_handle ctx, int iters, double *mults_per_s);
 int he_evaluator_coalescing_stats(he_handle eval, uint64_t out[4]);
 /* Concurrent single-ciphertext callers, the shape of the reference's parallel benchmarks (b.RunParallel,
  * schemes/ckks/ckks_benchmarks_test.go:116-207): n_threads OS threads (pthreads inside the library: no interpreter in the timed
- * region); thread i makes `iters` calls he_bgv_mul_relin(eval[i], level, t, a0[i], a1[i], b0[i], b1[i], rlk[i], o0[i], o1[i], 0)
- * -- or he_ckks_mul_relin when bgv == 0 -- on its own batch-1 handles; sync_each != 0: every call is followed by
- * he_ctx_sync(ctx[i]) (a caller that needs each result before its next call), otherwise one sync after the last call.  All
- * threads start together; *wall_s = first start to last finish.  Returns the first non-zero status of any call. */
-int he_debug_concurrent_mul_relin(int n_threads, int iters, int sync_each, int bgv, int level, uint64_t t, const he_handle *ctx,
+ * region); thread i makes `iters` calls on its own batch-1 handles -- op 0: he_ckks_mul_relin(eval[i], level, a0[i], a1[i], b0[i],
+ * b1[i], rlk[i], o0[i], o1[i], 0); op 1: he_bgv_mul_relin (t = plaintext modulus); op 2: he_automorphism_ct(eval[i], level, a0[i],
+ * a1[i], t = Galois element, rlk[i] = Galois key, o0[i], o1[i]); op 3: he_relinearize(eval[i], level, a0[i], a1[i], b0[i], rlk[i],
+ * o0[i], o1[i]); op 4: he_gadget_product(eval[i], level, a0[i], rlk[i], o0[i], o1[i]) (unused handle arrays may repeat another).
+ * sync_each != 0: every call is followed by he_ctx_sync(ctx[i]) (a caller that needs each result before its next call),
+ * otherwise one sync after the last call.  All threads start together; *wall_s = first start to last finish.  Returns the
+ * first non-zero status of any call. */
+int he_debug_concurrent_mul_relin(int n_threads, int iters, int sync_each, int op, int level, uint64_t t, const he_handle *ctx,
                                   const he_handle *eval, const he_handle *a0, const he_handle *a1, const he_handle *b0,
                                   const he_handle *b1, const he_handle *rlk, const he_handle *o0, const he_handle *o1,
                                   double *wall_s);

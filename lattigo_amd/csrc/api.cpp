@@ -378,19 +378,25 @@ struct FusedPlan {
 // context's stream (the library's usual contract: results are visible after he_ctx_sync / a download).
 struct Poly;
 struct Evk;
+enum CoOp { CO_MUL_RELIN = 0, CO_GADGET_PRODUCT, CO_RELINEARIZE, CO_AUTOMORPHISM };
 struct CoReq {
     // key: requests are batched together only when all of this matches
+    int op = CO_MUL_RELIN;
     int level = 0;
     bool bgv = false, alias = false;
-    uint64_t t = 0;
+    uint64_t t = 0;  // BGV plaintext modulus (MulRelin) / Galois element (Automorphism)
     std::shared_ptr<Evk> key;
+    // operands by operation: MulRelin a0 a1 b0 b1 -> o0 o1; GadgetProduct a0 (= cx) -> o0 o1; Relinearize a0 a1 b0 (= in0 in1 in2)
+    // -> o0 o1; Automorphism a0 a1 (= in0 in1) -> o0 o1
     std::shared_ptr<Poly> a0, a1, b0, b1, o0, o1;
     std::chrono::steady_clock::time_point arrived;
     bool done = false, lead = false;  // lead: the leaving leader handed the role to this (still waiting) request
     int rc = 0;
     std::string err;
     std::condition_variable cv;       // its own: a finished batch wakes exactly its callers, an arrival only the leader
-    bool same_key(const CoReq &o) const { return level == o.level && bgv == o.bgv && alias == o.alias && t == o.t && key == o.key; }
+    bool same_key(const CoReq &o) const {
+        return op == o.op && level == o.level && bgv == o.bgv && alias == o.alias && t == o.t && key == o.key;
+    }
 };
 struct Coalescer {
     std::mutex mu;
@@ -2424,6 +2430,10 @@ int check_decomp(const Evaluator &ev, const Decomp &dec, int levelQ, int levelP,
 }
 }  // namespace
 
+// a single-ciphertext key switch joins the evaluator's submission queue (defined with the queue, below)
+static int co_submit_keyswitch(const std::shared_ptr<Evaluator> &ev, int op, int level, uint64_t t, const std::shared_ptr<Evk> &k,
+                               std::initializer_list<std::shared_ptr<Poly>> ins, const std::shared_ptr<Poly> &o0,
+                               const std::shared_ptr<Poly> &o1);
 // limbs of an evaluation key's 2 beta rows at (levelQ, levelP): read once per call, shared by the batch
 static double key_limbs(const Evk &k, int levelQ) {
     const int levelP = k.nPk - 1;
@@ -2568,6 +2578,8 @@ int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he
     TRY(check_be_poly(*out0, be, levelQ + 1, "he_gadget_product"));
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product"));
     if (out0->batch != cx->batch || out1->batch != cx->batch) return fail(HE_EINVAL, "he_gadget_product: batch mismatch");
+    if (cx->batch == 1 && ev->co && ev->co->max_batch > 1 && !be.ctx->capturing)
+        return co_submit_keyswitch(ev, CO_GADGET_PRODUCT, levelQ, 0, k, {cx}, out0, out1);
     Scope sc(be.ctx.get());
     be.ctx->acct(3.0 * (levelQ + 1), key_limbs(*k, levelQ), cx->batch, be.Q->N);  // GadgetProduct: 3 L + 2 beta (L + alpha)
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true, k.get())));
@@ -2608,6 +2620,8 @@ int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_
         TRY(check_be_poly(*p, be, level + 1, "he_relinearize"));
         if (p->batch != in0->batch) return fail(HE_EINVAL, "he_relinearize: batch mismatch");
     }
+    if (in0->batch == 1 && ev->co && ev->co->max_batch > 1 && !be.ctx->capturing)
+        return co_submit_keyswitch(ev, CO_RELINEARIZE, level, 0, k, {in0, in1, in2}, out0, out1);
     Scope sc(be.ctx.get());
     const int B = in0->batch, N = be.Q->N;
     be.ctx->acct(5.0 * (std::min(level, k->nQk - 1) + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, N);  // Relinearize: 3 L in, 2 L out, key
@@ -2639,6 +2653,26 @@ static int cached_auto_index(Evaluator &ev, uint64_t gal, const uint32_t **out) 
     *out = d;
     return HE_OK;
 }
+// the launches of Automorphism / AutomorphismHoisted over B entries; the caller holds the context (Scope).  in1: the NTT-domain
+// second component (null when `dec` holds its decomposition).  in0 / in1 / out0 / out1 may carry entry tables (a coalesced batch)
+// when keyswitch_tables_ok() said so.
+static int automorphism_core(Evaluator &ev, int level, View in0, const View *in1, const Decomp *dec, uint64_t gal, const Evk &k, View out0,
+                             View out1, int B) {
+    BasisExtender &be = *ev.be;
+    const int N = be.Q->N;
+    // Rotate: (4 L + 2 beta (L + alpha)); hoisted: the decomposition replaces the second input
+    be.ctx->acct(dec ? 3.0 * (level + 1) + key_limbs(k, level) / 2 : 4.0 * (level + 1), key_limbs(k, level), B, N);
+    const size_t wQ = (size_t)B * (level + 1) * N;
+    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k.nPk - 1, B, !dec, &k) + 2 * wQ + (size_t)N));
+    View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
+    const uint32_t *index = nullptr;
+    TRY(cached_auto_index(ev, gal, &index));
+    hipStream_t st = be.ctx->stream;
+    TRY(gadget_product_core(ev, level, in1, dec, k, t0, t1, B, &in0, nullptr));
+    HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t0, index, out0, B, false, st));
+    HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t1, index, out1, B, false, st));
+    return HE_OK;
+}
 static int automorphism_common(he_handle hev, int level, he_handle hin0, he_handle hin1, he_handle hdec, uint64_t gal, he_handle hk,
                                he_handle hout0, he_handle hout1, const char *who) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -2661,23 +2695,13 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     if (!(gal & 1)) return fail(HE_EINVAL, "%s: Galois element must be odd", who);
     if (dec && k->pw2) return fail(HE_EINVAL, "%s: method is unsupported for BaseTwoDecomposition != 0", who);
     if (dec) TRY(check_decomp(*ev, *dec, level, k->nPk - 1, who));
+    // a single-ciphertext Automorphism on an evaluator with a submission queue joins it (he_evaluator_set_coalescing)
+    if (in1 && B == 1 && ev->co && ev->co->max_batch > 1 && !be.ctx->capturing)
+        return co_submit_keyswitch(ev, CO_AUTOMORPHISM, level, gal, k, {in0, in1}, out0, out1);
     Scope sc(be.ctx.get());
-    const int N = be.Q->N;
-    // Rotate: (4 L + 2 beta (L + alpha)); hoisted: the decomposition replaces the second input
-    be.ctx->acct(dec ? 3.0 * (level + 1) + key_limbs(*k, level) / 2 : 4.0 * (level + 1), key_limbs(*k, level), B, N);
-    const size_t wQ = (size_t)B * (level + 1) * N;
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, !dec, k.get()) + 2 * wQ + (size_t)N));
-    View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
-    const uint32_t *index = nullptr;
-    TRY(cached_auto_index(*ev, gal, &index));
-    hipStream_t st = be.ctx->stream;
     View in1v{nullptr, 0};
     if (in1) in1v = in1->view();
-    const View in0v = in0->view();
-    TRY(gadget_product_core(*ev, level, in1 ? &in1v : nullptr, dec ? dec.get() : nullptr, *k, t0, t1, B, &in0v, nullptr));
-    HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t0, index, out0->view(), B, false, st));
-    HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t1, index, out1->view(), B, false, st));
-    return HE_OK;
+    return automorphism_core(*ev, level, in0->view(), in1 ? &in1v : nullptr, dec ? dec.get() : nullptr, gal, *k, out0->view(), out1->view(), B);
 }
 int he_automorphism_ct(he_handle ev, int level, he_handle in0, he_handle in1, uint64_t gal, he_handle gk, he_handle out0, he_handle out1) {
     return automorphism_common(ev, level, in0, in1, 0, gal, gk, out0, out1, "he_automorphism_ct");
@@ -2914,6 +2938,19 @@ static int mul_relin_tables_ok(Evaluator &ev, int level, const Evk &k, bool *ok)
     return HE_OK;
 }
 
+// The same question for the key switches proper (GadgetProduct, Relinearize, Automorphism): their NTT-domain operand is read by
+// the inverse row pass and as the digits' own limbs, the addends and outputs by the epilogues (Automorphism: the final gathers) --
+// provided both fused plans exist (no base-2 gadget, special primes present, standard ring).
+static int keyswitch_tables_ok(Evaluator &ev, int level, const Evk &k, bool *ok) {
+    *ok = false;
+    if (k.nPk <= 0 || k.pw2) return HE_OK;
+    const FusedPlan *dplan = nullptr, *mdplan = nullptr;
+    TRY(get_dec_plan(ev, level, k.nPk - 1, k.nPk, &dplan));
+    TRY(get_md_plan(ev, level, k.nPk - 1, &mdplan));
+    *ok = dplan->ok && mdplan->ok;
+    return HE_OK;
+}
+
 namespace {
 // ---- coalescing of concurrent single-ciphertext calls (struct Coalescer) ---------------------------------------------
 int co_inflight(Coalescer &c) {  // batches still running or queued on the device (caller holds c.mu)
@@ -2924,38 +2961,62 @@ int co_inflight(Coalescer &c) {  // batches still running or queued on the devic
     (void)hipGetLastError();  // hipErrorNotReady is not an error here
     return (int)c.inflight.size();
 }
+// the launches of one request-shaped call over B entries (strided views of one request, or entry-table views of a batch)
+int co_launch(Evaluator &ev, const CoReq &r, const View (&v)[6], int B) {
+    BasisExtender &be = *ev.be;
+    const int N = be.Q->N;
+    switch (r.op) {
+        case CO_MUL_RELIN:
+            return mul_relin_core(ev, r.level, r.bgv, r.t, r.key.get(), v[0], v[1], v[2], v[3], v[4], v[5], View{nullptr, 0}, B, r.alias);
+        case CO_GADGET_PRODUCT:
+            be.ctx->acct(3.0 * (r.level + 1), key_limbs(*r.key, r.level), B, N);
+            TRY(be.ctx->arena_reserve(ks_scratch_words(be, r.level, r.key->nPk - 1, B, true, r.key.get())));
+            return gadget_product_core(ev, r.level, &v[0], nullptr, *r.key, v[4], v[5], B);
+        case CO_RELINEARIZE:
+            be.ctx->acct(5.0 * (r.level + 1), key_limbs(*r.key, r.level), B, N);
+            TRY(be.ctx->arena_reserve(ks_scratch_words(be, r.level, r.key->nPk - 1, B, true, r.key.get())));
+            return gadget_product_core(ev, r.level, &v[2], nullptr, *r.key, v[4], v[5], B, &v[0], &v[1]);
+        case CO_AUTOMORPHISM:
+            return automorphism_core(ev, r.level, v[0], &v[1], nullptr, r.t, *r.key, v[4], v[5], B);
+    }
+    return fail(HE_EINVAL, "coalescer: unknown operation");
+}
 // one batched launch for `batch` (all of one key); returns the status every request of the batch gets
 int co_run(Evaluator &ev, Coalescer &c, const std::vector<CoReq *> &batch, hipEvent_t done_ev) {
     BasisExtender &be = *ev.be;
     const CoReq &r0 = *batch[0];
-    const int B = (int)batch.size(), N = be.Q->N;
+    const int B = (int)batch.size();
     Scope sc(be.ctx.get());
     bool tables = false;
-    if (B > 1) TRY(mul_relin_tables_ok(ev, r0.level, *r0.key, &tables));
+    if (B > 1) {
+        if (r0.op == CO_MUL_RELIN) TRY(mul_relin_tables_ok(ev, r0.level, *r0.key, &tables));
+        else if (!r0.alias) TRY(keyswitch_tables_ok(ev, r0.level, *r0.key, &tables));  // (flagged key switches: one by one)
+    }
+    const std::shared_ptr<Poly> CoReq::*slot[6] = {&CoReq::a0, &CoReq::a1, &CoReq::b0, &CoReq::b1, &CoReq::o0, &CoReq::o1};
     int rc = HE_OK;
     if (B == 1 || !tables) {
         // one entry, or a shape whose pipeline has launches without entry tables (unfused ModDown): one call per request
         if (B > 1) c.n_fallback += (uint64_t)B;
         for (CoReq *r : batch) {
             be.ctx->arena_reset();
-            rc = mul_relin_core(ev, r->level, r->bgv, r->t, r->key.get(), r->a0->view(), r->a1->view(), r->b0->view(), r->b1->view(),
-                                r->o0->view(), r->o1->view(), View{nullptr, 0}, 1, r->alias);
+            View v[6];
+            for (int sidx = 0; sidx < 6; sidx++) v[sidx] = ((*r).*slot[sidx]) ? ((*r).*slot[sidx])->view() : View{nullptr, 0};
+            rc = co_launch(ev, *r, v, 1);
             if (rc != HE_OK) break;
         }
     } else {
         // entry tables: row s of the table holds, per entry, the word offset of that entry's polynomial from entry 0's
-        std::vector<size_t> vals((size_t)6 * B);
-        const std::shared_ptr<Poly> CoReq::*slot[6] = {&CoReq::a0, &CoReq::a1, &CoReq::b0, &CoReq::b1, &CoReq::o0, &CoReq::o1};
+        std::vector<size_t> vals((size_t)6 * B, 0);
         View v[6];
         for (int sidx = 0; sidx < 6; sidx++) {
+            if (!((*batch[0]).*slot[sidx])) { v[sidx] = View{nullptr, 0}; continue; }
             uint64_t *base = ((*batch[0]).*slot[sidx])->d;
             for (int z = 0; z < B; z++) vals[(size_t)sidx * B + z] = (size_t)((((*batch[z]).*slot[sidx])->d) - base);
             v[sidx] = View{base, 0, c.d_tab + (size_t)sidx * B};
         }
         HIP_TRY(launch_tab_fill(c.d_tab, vals.data(), 6 * B, be.ctx->stream));
-        rc = mul_relin_core(ev, r0.level, r0.bgv, r0.t, r0.key.get(), v[0], v[1], v[2], v[3], v[4], v[5], View{nullptr, 0}, B, r0.alias);
+        rc = co_launch(ev, r0, v, B);
     }
-    (void)N;
     if (rc == HE_OK && done_ev) HIP_TRY(hipEventRecord(done_ev, be.ctx->stream));
     return rc;
 }
@@ -3037,6 +3098,24 @@ int co_submit(Evaluator &ev, CoReq &r) {
 }
 }  // namespace
 
+static int co_submit_keyswitch(const std::shared_ptr<Evaluator> &ev, int op, int level, uint64_t t, const std::shared_ptr<Evk> &k,
+                               std::initializer_list<std::shared_ptr<Poly>> ins, const std::shared_ptr<Poly> &o0,
+                               const std::shared_ptr<Poly> &o1) {
+    CoReq r;
+    r.op = op; r.level = level; r.t = t; r.key = k; r.o0 = o0; r.o1 = o1;
+    std::shared_ptr<Poly> CoReq::*slot[4] = {&CoReq::a0, &CoReq::a1, &CoReq::b0, &CoReq::b1};
+    int i = 0;
+    for (const auto &p : ins) r.*slot[i++] = p;
+    // Aliasing that the batched pipeline cannot take for a whole batch on the word of entry 0's pointers: an output that is the
+    // key switch's NTT-domain operand (its own-digit limbs are still being read while the fused epilogue writes the outputs) or
+    // the OTHER component's addend.  Such requests are flagged, batched apart and served one by one (co_run).  An output equal
+    // to its own component's addend -- Relinearize in place -- is read and written by the same thread and batches normally; an
+    // automorphism's outputs are written by the final gathers, after every input has been consumed.
+    const Poly *cx = op == CO_GADGET_PRODUCT ? r.a0.get() : op == CO_RELINEARIZE ? r.b0.get() : nullptr;
+    if (cx) r.alias = cx->d == o0->d || cx->d == o1->d;
+    if (op == CO_RELINEARIZE) r.alias = r.alias || r.a0->d == o1->d || r.a1->d == o0->d;
+    return co_submit(*ev, r);
+}
 static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_handle ha0, he_handle ha1, he_handle hb0, he_handle hb1,
                             he_handle hk, he_handle hout0, he_handle hout1, he_handle hout2, const char *who) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -3383,8 +3462,13 @@ void *conc_worker(void *vp) {
     pthread_barrier_wait(a.start);
     a.t0 = mono_s();
     for (int i = 0; i < a.iters && a.rc == 0; i++) {
-        a.rc = a.bgv ? he_bgv_mul_relin(a.eval, a.level, a.t, a.a0, a.a1, a.b0, a.b1, a.rlk, a.o0, a.o1, 0)
-                     : he_ckks_mul_relin(a.eval, a.level, a.a0, a.a1, a.b0, a.b1, a.rlk, a.o0, a.o1, 0);
+        switch (a.bgv) {  // (the operation selector of he_debug_concurrent_mul_relin)
+            case 0: a.rc = he_ckks_mul_relin(a.eval, a.level, a.a0, a.a1, a.b0, a.b1, a.rlk, a.o0, a.o1, 0); break;
+            case 1: a.rc = he_bgv_mul_relin(a.eval, a.level, a.t, a.a0, a.a1, a.b0, a.b1, a.rlk, a.o0, a.o1, 0); break;
+            case 2: a.rc = he_automorphism_ct(a.eval, a.level, a.a0, a.a1, a.t, a.rlk, a.o0, a.o1); break;
+            case 3: a.rc = he_relinearize(a.eval, a.level, a.a0, a.a1, a.b0, a.rlk, a.o0, a.o1); break;
+            default: a.rc = he_gadget_product(a.eval, a.level, a.a0, a.rlk, a.o0, a.o1); break;
+        }
         if (a.rc == 0 && a.sync_each) a.rc = he_ctx_sync(a.ctx);
     }
     if (a.rc == 0) a.rc = he_ctx_sync(a.ctx);
@@ -3397,7 +3481,8 @@ int he_debug_concurrent_mul_relin(int n_threads, int iters, int sync_each, int b
                                   const he_handle *eval, const he_handle *a0, const he_handle *a1, const he_handle *b0,
                                   const he_handle *b1, const he_handle *rlk, const he_handle *o0, const he_handle *o1,
                                   double *wall_s) {
-    if (n_threads <= 0 || n_threads > 4096 || iters <= 0 || !ctx || !eval || !a0 || !a1 || !b0 || !b1 || !rlk || !o0 || !o1 || !wall_s)
+    if (n_threads <= 0 || n_threads > 4096 || iters <= 0 || !ctx || !eval || !a0 || !a1 || !b0 || !b1 || !rlk || !o0 || !o1 || !wall_s ||
+        bgv < 0 || bgv > 4)
         return fail(HE_EINVAL, "he_debug_concurrent_mul_relin: bad arguments");
     std::vector<ConcArg> args(n_threads);
     std::vector<pthread_t> th(n_threads);

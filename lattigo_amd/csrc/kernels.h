@@ -24,8 +24,9 @@ struct LimbTab {
 // tab (optional): an entry table -- batch entry z lives at p + tab[z] words (a device array of word offsets, any allocation;
 // differences wrap modulo 2^64) instead of p + z * bstride.  That is how concurrent single-ciphertext calls are coalesced into
 // one batched launch over the callers' own, unrelated polynomials (he_evaluator_set_coalescing).  Only the launchers that
-// say so accept it (the caller-facing operands of the fused MulRelin pipeline: launch_tensor, the product prologue and the
-// epilogues of launch_ntt_rows / launch_ntt_mac_f64); every other launcher refuses a view that carries one.
+// say so accept it -- the caller-facing operands of the fused MulRelin / key-switch pipelines: launch_tensor; the input, the
+// product prologue and the epilogues of launch_ntt_rows; the own-digit operand of launch_ks_inner / launch_ntt_mac_f64 and the
+// latter's epilogue; the output of launch_gather -- every other launcher refuses a view that carries one.
 struct View {
     uint64_t *p;
     size_t bstride;

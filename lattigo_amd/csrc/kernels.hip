@@ -302,6 +302,7 @@ struct NttArgs {
     int nbatch_prof = 0;  // host only: batch entries of the launch when grid.x is not their number (rows_bytes)
     int tprod = 0;  // f64 inverse kernel only (NttProdIn): the input is formed here as T(ta1, tb1) with epi_ts, and also written to out2
     // entry tables (View::tab) of the caller-facing operands: the epilogue's outputs and addends, the product's inputs
+    const size_t *in_tab = nullptr;  // the transform's input (launch_ntt_rows: the operand of a coalesced key switch)
     const size_t *out_tab = nullptr, *out2_tab = nullptr, *epi_w_tab = nullptr, *epi_w2_tab = nullptr;
     const size_t *ta0_tab = nullptr, *ta1_tab = nullptr, *tb0_tab = nullptr, *tb1_tab = nullptr;
 };
@@ -510,7 +511,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
     const ModConst mc = A.mc[mi];
     const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
     const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
-    const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + (size_t)il * A.N + (size_t)row * N2;
+    const uint64_t *__restrict__ src = A.in + voff(A.in_tab, A.in_bs, bzi) + (size_t)il * A.N + (size_t)row * N2;
     uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
     const int rowtw = (1 << A.a) + row;  // 2^a + r
 
@@ -828,7 +829,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     const unsigned b1 = PIPE ? min(b0 + (unsigned)A.iters, (unsigned)A.nbatch) : b0 + 1;  // otherwise iters == 1
     uint64_t nx[16];
     if constexpr (INV && !TP) {
-        const uint64_t *src0 = A.in + (size_t)b0 * A.in_bs + in_off;
+        const uint64_t *src0 = A.in + voff(A.in_tab, A.in_bs, b0) + in_off;
 #pragma unroll
         for (int k = 0; k < 16; k++) nx[k] = ldnt(&src0[nat_e<T>(k, tau)]);
     }
@@ -837,7 +838,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
     double x[16];
     if constexpr (!INV) {
         constexpr int sh0 = LOGB - 4;
-        const uint64_t *__restrict__ src = A.in + (size_t)bzi * A.in_bs + in_off;
+        const uint64_t *__restrict__ src = A.in + voff(A.in_tab, A.in_bs, bzi) + in_off;
         if (A.flags & NTT_INPUT_F64) {  // doubles left by the basis extension (|x| < 2^53 through every stage: modup_f64_raw_ok)
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = __longlong_as_double((long long)ldnt(&src[(k << sh0) + tau]));
@@ -1044,7 +1045,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
         }
         }
         if constexpr (PIPE) if (bzi + 1 < b1) {
-            const uint64_t *srcn = A.in + (size_t)(bzi + 1) * A.in_bs + in_off;
+            const uint64_t *srcn = A.in + voff(A.in_tab, A.in_bs, bzi + 1) + in_off;
 #pragma unroll
             for (int k = 0; k < 16; k++) nx[k] = ldnt(&srcn[nat_e<T>(k, tau)]);
         }
@@ -1108,6 +1109,7 @@ extern "C" int he_debug_mac_stamps(uint64_t *out, int n) {
 struct NttMacKArgs {
     const uint64_t *dec, *own;
     size_t dec_bs, own_bs;
+    const size_t *own_tab;  // entry table of `own` (View::tab): the NTT-domain input of a coalesced key switch
     const double *keyd;
     uint64_t *o0Q, *o0P, *o1Q, *o1P;
     size_t oQ0_bs, oP0_bs, oQ1_bs, oP1_bs;
@@ -1150,7 +1152,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
         return A.m.own_alpha > 0 && A.m.out_view[l] == 0 && ql >= d * A.m.own_alpha && ql < (d + 1) * A.m.own_alpha;
     };
     auto digit_src = [&](int d) -> const uint64_t * {
-        return own_digit(d) ? A.own + bz * A.own_bs + (size_t)ql * A.N + rowoff
+        return own_digit(d) ? A.own + voff(A.own_tab, A.own_bs, bz) + (size_t)ql * A.N + rowoff
                             : A.dec + bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)A.m.dec_limb[l] * A.N + rowoff;
     };
     double t16[15];  // twiddles of the coming radix-16 round
@@ -1368,7 +1370,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
     auto digit_src = [&](const Item &it, int d) -> const uint64_t * {
         if (EPI && d >= A.m.beta)
             return AA.e.ext + ((size_t)(d - A.m.beta) * AA.nbatch + it.bz) * AA.e.ext_bs + (size_t)it.ql * A.N + it.rowoff;
-        return own_digit(it, d) ? A.own + it.bz * A.own_bs + (size_t)it.ql * A.N + it.rowoff
+        return own_digit(it, d) ? A.own + voff(A.own_tab, A.own_bs, it.bz) + (size_t)it.ql * A.N + it.rowoff
                                 : A.dec + it.bz * A.dec_bs + (size_t)d * A.m.dec_dstride + (size_t)it.ql * A.N + it.rowoff;
     };
     // LDS-DMA of one digit row: instruction j moves elements {2j, 2j + 1} x (this wave's 64 columns)
@@ -1695,11 +1697,11 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
                               View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi) {
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     if (!r.twd_fwd || !keyd) return hipErrorInvalidValue;
-    if (!no_tab({dec, own}) || (!epi && !no_tab({out0Q, out0P, out1Q, out1P})) || (epi && epi->ext.tab)) return hipErrorInvalidValue;
+    if (dec.tab || (!epi && !no_tab({out0Q, out0P, out1Q, out1P})) || (epi && epi->ext.tab)) return hipErrorInvalidValue;
     const int b = ntt_row_bits(r.logN), aa = r.logN - b;
     if (epi && !ntt_mac_epilogue_supported(r.logN)) return hipErrorInvalidValue;
     NttMacKArgs A;
-    A.dec = dec.p; A.dec_bs = dec.bstride; A.own = own.p; A.own_bs = own.bstride; A.keyd = keyd;
+    A.dec = dec.p; A.dec_bs = dec.bstride; A.own = own.p; A.own_bs = own.bstride; A.own_tab = own.tab; A.keyd = keyd;
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
     A.mc = r.mc; A.twd = r.twd_fwd; A.N = r.N; A.a = aa; A.m = a;
@@ -2081,7 +2083,8 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     if (epi && inverse) return hipErrorInvalidValue;
     if (prod && (!inverse || !r.twd_inv || !ntt_prod_in_supported(n))) return hipErrorInvalidValue;
     // entry tables: only the epilogue's outputs / addends / product inputs and the prologue's inputs take one
-    if (in.tab || (out.tab && !epi) || (epi && !no_tab({epi->y, epi->y2})) || (prod && prod->c.tab)) return hipErrorInvalidValue;
+    // (forward tensor-mode epilogue: the workgroup -> entry map of that launch shape is not the table's)
+    if ((in.tab && epi && epi->tensor) || (out.tab && !epi) || (epi && !no_tab({epi->y, epi->y2})) || (prod && prod->c.tab)) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
     NttArgs A;
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
@@ -2094,7 +2097,7 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
         if (epi->tensor && (epi->zsplit <= 0 || batch != 2 * epi->zsplit)) return hipErrorInvalidValue;
         set_epilogue(A, *epi, tab.n);
     }
-    A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride; A.out_tab = out.tab;
+    A.in = in.p; A.in_bs = in.bstride; A.in_tab = in.tab; A.out = out.p; A.out_bs = out.bstride; A.out_tab = out.tab;
     A.flags = flags;
     if (prod) {
         A.tprod = 1;
@@ -2383,6 +2386,7 @@ struct GatherArgs {
     const uint64_t *in;
     uint64_t *out;
     size_t in_bs, out_bs;
+    const size_t *out_tab;  // entry table of the output (View::tab)
     const uint32_t *index;
     int N;
     uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs];
@@ -2394,16 +2398,16 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherArgs A) {
     if (j >= A.N) return;
     const uint32_t src = A.index[j];
     const uint64_t *in = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N;
-    uint64_t *out = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N;
+    uint64_t *out = A.out + voff(A.out_tab, A.out_bs, blockIdx.z) + (size_t)A.out_limb[blockIdx.y] * A.N;
     const uint64_t v = ldnt(&in[src]);
     if (ADD) out[j] += v; else out[j] = v;
 }
 hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const uint32_t *index, View out, int batch,
                          bool then_add, hipStream_t s) {
-    if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
+    if (in.tab) return hipErrorInvalidValue;  // entry tables: only the output
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     GatherArgs A;
-    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.index = index; A.N = r.N;
+    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.out_tab = out.tab; A.index = index; A.N = r.N;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
     ProfScope ps(K_GATHER, s, (then_add ? 3.0 : 2.0) * tab.n * batch * (double)r.N * 8.0);
@@ -3277,6 +3281,7 @@ hipError_t launch_mask_spread(const RingDev &r, const MaskSpreadArgs &a, View sr
 struct KsKArgs {
     const uint64_t *own;
     size_t own_bs;
+    const size_t *own_tab;  // entry table of `own` (View::tab)
     const uint64_t *dec;
     const uint64_t *key;
     uint64_t *o0Q, *o0P, *o1Q, *o1P;
@@ -3307,7 +3312,7 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
 #pragma unroll
     for (int b = 0; b < BB; b++) {
         const size_t bb = (size_t)(b0 + b < A.batch ? b0 + b : b0);
-        boff_own[b] = bb * A.own_bs;
+        boff_own[b] = voff(A.own_tab, A.own_bs, bb);
         boff_dec[b] = bb * A.dec_bs;
     }
     auto is_own = [&](int d) -> bool {
@@ -3360,10 +3365,10 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
 
 hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
                            View out0P, View out1Q, View out1P, int batch, hipStream_t s) {
-    if (!no_tab({dec, own, out0Q, out0P, out1Q, out1P})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
+    if (!no_tab({dec, out0Q, out0P, out1Q, out1P})) return hipErrorInvalidValue;  // entry tables: only the own-digit operand
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     KsKArgs A;
-    A.own = own.p; A.own_bs = own.bstride;
+    A.own = own.p; A.own_bs = own.bstride; A.own_tab = own.tab;
     A.dec = dec.p; A.dec_bs = dec.bstride; A.key = key;
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;

@@ -347,11 +347,45 @@ class BGVCiphertextEvaluator:
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# ckks.Evaluator on rlwe.Ciphertext objects.  Scales are exact rationals (fractions.Fraction) where the reference keeps
-# 128-bit floats, and a constant c is encoded as round-half-away(c * scale) computed exactly (the reference rounds a
-# big.Float product, schemes/ckks/scaling.go:10-43): the encoded integer can differ from the reference's by one unit in
-# its last place, far below the noise.  Everything after that point is the same integer arithmetic, bit for bit.
+# ckks.Evaluator on rlwe.Ciphertext objects.  A constant c is encoded exactly as bigComplexToRNSScalar does
+# (schemes/ckks/scaling.go:10-43): c is first held at EncodingPrecision bits (bignum.ToComplex, evaluator.go:77,168,639), the
+# product with the scale is a big.Float of 128 bits (rlwe.ScalePrecision, round to nearest even), +-0.5 is added in the same
+# precision and the result truncated (_big_float_scalar below; round 4 -- rounds 1-3 rounded the exact product).  Scales are
+# carried as exact rationals where the reference re-rounds its 128-bit float after every Mul / Div (core/rlwe/scale.go:77-113);
+# the value used to encode a constant is that rational rounded to 128 bits.
 # ----------------------------------------------------------------------------------------------------------------
+def _round_bits(x, prec: int):
+    """x (a Fraction) rounded to `prec` significant bits, ties to even: the value a big.Float of that precision holds"""
+    from fractions import Fraction
+    x = Fraction(x)
+    if x == 0:
+        return x
+    neg, x = x < 0, abs(x)
+    e = x.numerator.bit_length() - x.denominator.bit_length() + 1  # x < 2^e
+    if x < Fraction(2) ** (e - 1):
+        e -= 1                                                     # now 2^(e-1) <= x < 2^e
+    ulp = Fraction(2) ** (e - prec)
+    m, rem = divmod(x / ulp, 1)
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and int(m) & 1):
+        m += 1
+    x = int(m) * ulp
+    return -x if neg else x
+
+
+def _big_float_scalar(c, scale, enc_prec: int = 53) -> int:
+    """One component of bigComplexToRNSScalar (schemes/ckks/scaling.go:16-26 / :30-40): r = Mul(c, scale) in a fresh big.Float --
+    precision max(prec(c), prec(scale)) = max(EncodingPrecision, 128) --, r +- 0.5 in that precision, r.Int() (toward zero)."""
+    import math
+    from fractions import Fraction
+    c = _round_bits(c, enc_prec)  # bignum.ToComplex(op1, EncodingPrecision)
+    if c == 0:
+        return 0
+    prec = max(enc_prec, 128)
+    r = _round_bits(c * _round_bits(scale, 128), prec)
+    r = _round_bits(r + Fraction(1, 2) if c > 0 else r - Fraction(1, 2), prec)
+    return math.trunc(r)
+
+
 def _round_half_away(x):
     from fractions import Fraction
     x = Fraction(x)
@@ -382,6 +416,8 @@ class CKKSCiphertextEvaluator:
         self.t = None
         # RootsForward[1] of every limb as a plain integer: the square root of -1 that evaluateWithScalar uses (:417)
         self.imag_unit = [int(self.ringQ.roots(i)[1]) * pow(1 << 64, -1, q) % q for i, q in enumerate(self.Q)]
+        # Parameters.EncodingPrecision (schemes/ckks/params.go:185-195): max(53, floor(log2(DefaultScale))); settable
+        self.EncodingPrecision = 53
 
     NewCiphertext = BGVCiphertextEvaluator.NewCiphertext
     _new_result = BGVCiphertextEvaluator._new_result
@@ -391,7 +427,7 @@ class CKKSCiphertextEvaluator:
     def _rns(self, level, scale, c):
         """bigComplexToRNSScalar + the (a + b i, a - b i) pair of evaluateWithScalar (schemes/ckks/scaling.go:10, evaluator.go:410)"""
         re, im = _as_complex_fraction(c)
-        real, imag = _round_half_away(re * scale), _round_half_away(im * scale)
+        real, imag = _big_float_scalar(re, scale, self.EncodingPrecision), _big_float_scalar(im, scale, self.EncodingPrecision)
         s0, s1 = [], []
         for i, q in enumerate(self.Q[: level + 1]):
             r, m = real % q, (imag % q) * self.imag_unit[i] % q
@@ -399,9 +435,10 @@ class CKKSCiphertextEvaluator:
             s1.append((r - m) % q)
         return np.array(s0, dtype=np.uint64), np.array(s1, dtype=np.uint64)
 
-    @staticmethod
-    def _is_int(c):
+    def _is_int(self, c):
+        """bignum.Complex.IsInt of the constant as held at EncodingPrecision (evaluator.go:645)"""
         re, im = _as_complex_fraction(c)
+        re, im = _round_bits(re, self.EncodingPrecision), _round_bits(im, self.EncodingPrecision)
         return re.denominator == 1 and im.denominator == 1
 
     def _addsub_ct(self, op0, op1, opOut, sub):

@@ -477,16 +477,25 @@ class CKKSRotations:
         self.ise.PartialTracesSum(level, ctIn, batchSize, n, opOut)
 
 
-def ConcurrentMulRelin(callers, level: int, iters: int, t: int = 0, sync_each: bool = False) -> float:
-    """The reference's parallel benchmark shape for MulRelin (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:116-207) on OS
-    threads inside the library (he_debug_concurrent_mul_relin, include/hering_debug.h): callers = [(ctx, evaluator, op0, op1,
-    rlk, opOut), ...] with batch-1 ciphertexts; caller i makes `iters` calls of BGVMulRelin (t != 0) / CKKSMulRelin on its own
-    handles, synchronising its context after every call (sync_each) or once at the end.  Returns the wall time in seconds."""
+def ConcurrentCalls(op: str, callers, level: int, iters: int, t: int = 0, sync_each: bool = False) -> float:
+    """The reference's parallel benchmark shape (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:116-207) on OS threads inside
+    the library (he_debug_concurrent_mul_relin, include/hering_debug.h).  op "ckks_mulrelin" / "bgv_mulrelin" (t = plaintext
+    modulus): callers = [(ctx, evaluator, op0, op1, rlk, opOut), ...]; "rotate" (t = Galois element): [(ctx, evaluator, ct, None,
+    galois key, ctOut)]; "relinearize": [(ctx, evaluator, ct3, None, rlk, ctOut)]; "gadget_product": [(ctx, evaluator, [cx], None,
+    key, ctOut)] -- all with batch-1 polynomials.  Caller i makes `iters` calls on its own handles, synchronising its context
+    after every call (sync_each) or once at the end.  Returns the wall time in seconds."""
+    code = {"ckks_mulrelin": 0, "bgv_mulrelin": 1, "rotate": 2, "relinearize": 3, "gadget_product": 4}[op]
     n = len(callers)
     arr = lambda f: (H * n)(*[f(c) for c in callers])
+    pick = lambda c, which, i: (c[which][i].h if c[which] is not None and len(c[which]) > i else c[2][0].h)
     wall = C.c_double()
     check(load().he_debug_concurrent_mul_relin(
-        n, iters, int(sync_each), int(t != 0), level, t, arr(lambda c: c[0].h), arr(lambda c: c[1].h), arr(lambda c: c[2][0].h),
-        arr(lambda c: c[2][1].h), arr(lambda c: c[3][0].h), arr(lambda c: c[3][1].h), arr(lambda c: c[4].h), arr(lambda c: c[5][0].h),
-        arr(lambda c: c[5][1].h), C.byref(wall)))
+        n, iters, int(sync_each), code, level, t, arr(lambda c: c[0].h), arr(lambda c: c[1].h), arr(lambda c: pick(c, 2, 0)),
+        arr(lambda c: pick(c, 2, 1)), arr(lambda c: pick(c, 3, 0) if code < 2 else pick(c, 2, 2)), arr(lambda c: pick(c, 3, 1)),
+        arr(lambda c: c[4].h), arr(lambda c: c[5][0].h), arr(lambda c: c[5][1].h), C.byref(wall)))
     return float(wall.value)
+
+
+def ConcurrentMulRelin(callers, level: int, iters: int, t: int = 0, sync_each: bool = False) -> float:
+    """ConcurrentCalls for BGVMulRelin (t != 0) / CKKSMulRelin"""
+    return ConcurrentCalls("bgv_mulrelin" if t != 0 else "ckks_mulrelin", callers, level, iters, t, sync_each)

@@ -661,8 +661,64 @@ class BGVCtEvaluator:
 
 # ---------------------------------------------------------------------------------------------------------------
 # ckks.Evaluator at the rlwe.Ciphertext level (numpy arrays); scales are exact rationals, constants are encoded as
-# round-half-away(c * scale) (schemes/ckks/scaling.go:10-43 with exact instead of 128-bit float arithmetic)
+# bigComplexToRNSScalar encodes them (schemes/ckks/scaling.go:10-43): with the reference's big.Float roundings restated on
+# integers (_keep / _const_to_int below; written apart from the product driver's lattigo_amd/drivers/schemes.py)
 # ---------------------------------------------------------------------------------------------------------------
+def _keep(num: int, den: int, bits: int):
+    """(m, e): the nearest-even `bits`-bit approximation m 2^e of num / den (num, den > 0) -- a big.Float of that precision"""
+    e = num.bit_length() - den.bit_length() - bits  # num / den in (2^(e+bits-1), 2^(e+bits+1))
+    for _ in range(3):
+        n, d = (num, den << e) if e >= 0 else (num << -e, den)
+        m, r = divmod(n, d)
+        if m >> bits:
+            e += 1
+            continue
+        if not m >> (bits - 1):
+            e -= 1
+            continue
+        if 2 * r > d or (2 * r == d and m & 1):
+            m += 1  # (a carry to bits + 1 bits is still m 2^e exactly)
+        return m, e
+    raise AssertionError("unreachable")
+
+
+def _const_to_int(c, scale, enc_prec=53):
+    """scaling.go:16-26: big.Float(c at enc_prec bits) * big.Float(scale at 128 bits) -> 128 bits; +-0.5 -> 128 bits; Int()"""
+    from fractions import Fraction
+    c, scale = Fraction(c), Fraction(scale)
+    if c == 0:
+        return 0
+    sign = 1 if c > 0 else -1
+    cm, ce = _keep(abs(c.numerator), c.denominator, enc_prec)
+    if cm == 0:
+        return 0
+    sm, se = _keep(scale.numerator, scale.denominator, 128)
+    bits = max(enc_prec, 128)
+    pm, pe = _keep(cm * sm, 1, bits)
+    pe += ce + se                                   # |c| * scale ~ pm 2^pe
+    # + 0.5 in the same precision: align, add, keep
+    if pe >= 0:
+        num, den = (pm << pe) * 2 + 1, 2
+    else:
+        num, den = pm * 2 + (1 << -pe), 2 << -pe
+    rm, re_ = _keep(num, den, bits)
+    mag = rm << re_ if re_ >= 0 else rm >> -re_     # toward zero
+    return sign * mag
+
+
+def _ckks_is_int(c, enc_prec=53):
+    from fractions import Fraction
+    for part in _cfrac(c):
+        part = Fraction(part)
+        if part == 0:
+            continue
+        m, e = _keep(abs(part.numerator), part.denominator, enc_prec)
+        if e < 0 and m & ((1 << -e) - 1):
+            return False
+    return True
+
+
+
 def _rha(x):
     from fractions import Fraction
     x = Fraction(x)
@@ -696,9 +752,11 @@ class CKKSCtEvaluator:
     MulRelinNew = BGVCtEvaluator.MulRelinNew
     Relinearize = BGVCtEvaluator.Relinearize
 
+    EncodingPrecision = 53  # Parameters.EncodingPrecision (schemes/ckks/params.go:185-195)
+
     def _rns(self, level, scale, c):
         re, im = _cfrac(c)
-        real, imag = _rha(re * scale), _rha(im * scale)
+        real, imag = _const_to_int(re, scale, self.EncodingPrecision), _const_to_int(im, scale, self.EncodingPrecision)
         s0, s1 = [], []
         for i, q in enumerate(self.Q[: level + 1]):
             root = int(self.ringQ.roots_forward(i)[1])  # Montgomery form of sqrt(-1) mod q_i (evaluator.go:417)
@@ -707,10 +765,8 @@ class CKKSCtEvaluator:
             s1.append((r + q - m) % q)
         return np.array(s0, dtype=np.uint64), np.array(s1, dtype=np.uint64)
 
-    @staticmethod
-    def _is_int(c):
-        re, im = _cfrac(c)
-        return re.denominator == 1 and im.denominator == 1
+    def _is_int(self, c):
+        return _ckks_is_int(c, self.EncodingPrecision)
 
     def _addsub_ct(self, op0, op1, opOut, sub):
         from fractions import Fraction

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import lattigo_amd as la
-from lattigo_amd.rlwe import ConcurrentMulRelin
+from lattigo_amd.rlwe import ConcurrentCalls, ConcurrentMulRelin
 from oracle import oracle as O
 from tests.gpu_common import Pair, ctx  # noqa: F401
 from tests.helpers import rng_for, uniform_poly
@@ -152,3 +152,49 @@ def test_library_side_thread_harness(ctx, sync_each):
     assert st["calls"] == K * M and st["launches"] < st["calls"], st
     for k in range(K):
         assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.BGVMulRelin(T, ins[k][0], ins[k][1], ok, True)), k
+
+
+@pytest.mark.parametrize("logN", [13, 16])
+def test_key_switches_coalesce_too(ctx, logN):
+    """GadgetProduct, Relinearize (into fresh outputs and in place -- the reference's usual form) and Automorphism (Rotate) from
+    concurrent single-ciphertext callers: the NTT-domain operand is then read through the entry table by the inverse rows and as
+    the digits' own limbs, the addends / outputs by the epilogues and the final gathers.  logN = 16: 8192-coefficient rows."""
+    nq, np_ = (6, 2) if logN == 16 else (5, 2)
+    pr, q, p, N, rng, gev, oev, gk, ok = _setup(ctx, logN, nq, np_)
+    K = 5 if logN == 16 else 8
+    gev.SetCoalescing(64, 3000)
+    gal = 5
+    cts = [np.stack([uniform_poly(rng, q, N) for _ in range(3)]) for _ in range(K)]       # [k][component 0..2]
+    up = lambda k, n: [la.Poly(pr.gQ, nq).upload(c) for c in cts[k][:n]]
+    fresh = lambda: [la.Poly(pr.gQ, nq), la.Poly(pr.gQ, nq)]
+    # GadgetProduct(cx = component 1)
+    cx, outs = [la.Poly(pr.gQ, nq).upload(cts[k][1]) for k in range(K)], [fresh() for _ in range(K)]
+    _run_threads([(lambda k: lambda: gev.GadgetProduct(nq - 1, cx[k], gk, outs[k]))(k) for k in range(K)])
+    for k in range(K):
+        assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.GadgetProduct(nq - 1, cts[k][1], ok)), ("gadget", k)
+    # Relinearize: even callers into fresh outputs, odd callers in place (out = the degree-2 ciphertext's first two components)
+    ct3 = [up(k, 3) for k in range(K)]
+    outs = [fresh() if k % 2 == 0 else ct3[k][:2] for k in range(K)]
+    _run_threads([(lambda k: lambda: gev.Relinearize(nq - 1, ct3[k], gk, outs[k]))(k) for k in range(K)])
+    for k in range(K):
+        assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.Relinearize(cts[k], ok)), ("relinearize", k)
+    # Relinearize with the output on the key switch's own operand (component 2): flagged, served one by one, same words
+    ct3 = [up(k, 3) for k in range(K)]
+    outs = [[ct3[k][2], la.Poly(pr.gQ, nq)] for k in range(K)]
+    _run_threads([(lambda k: lambda: gev.Relinearize(nq - 1, ct3[k], gk, outs[k]))(k) for k in range(K)])
+    for k in range(K):
+        assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.Relinearize(cts[k], ok)), ("relinearize onto c2", k)
+    # Automorphism
+    ct2, outs = [up(k, 2) for k in range(K)], [fresh() for _ in range(K)]
+    _run_threads([(lambda k: lambda: gev.Automorphism(nq - 1, ct2[k], gal, gk, outs[k]))(k) for k in range(K)])
+    for k in range(K):
+        assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.Automorphism(cts[k][:2], gal, ok)), ("automorphism", k)
+    ctx.sync()
+    st = gev.CoalescingStats()
+    assert st["calls"] == 4 * K and st["launches"] < st["calls"] and st["largest_batch"] >= 2, st
+    # the library-side thread harness on rotations
+    outs = [fresh() for _ in range(K)]
+    ConcurrentCalls("rotate", [(ctx, gev, ct2[k], None, gk, outs[k]) for k in range(K)], nq - 1, 4, t=gal, sync_each=True)
+    for k in range(K):
+        assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.Automorphism(cts[k][:2], gal, ok)), ("harness rotate", k)
+
