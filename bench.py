@@ -474,7 +474,7 @@ def setup_c5(la, ctx, rank, B, cp, args):
     }
 
 
-def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), ops_per_run=6000, max_batch=64, window_us=30):
+def concurrent_b1(la, ctx, workload="c3", ks=(1, 4, 16, 64), ops_per_run=6000, max_batch=64, window_us=30):
     """What the reference's own interface delivers: its operator API takes ONE ciphertext per call (schemes/schemes.go:14-28) and
     scales by concurrent callers (b.RunParallel over evaluators sharing tables and keys, schemes/ckks/ckks_benchmarks_test.go:
     116-207).  K OS threads (pthreads inside the library, he_debug_concurrent_mul_relin), each repeating MulRelin on its own
@@ -485,26 +485,30 @@ def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), ops_per_run=6000, max_batch=64, wi
         the same time become one batched launch over the callers' own polynomials;
       * coalesced_sync_each: the same with every caller waiting for its result (he_ctx_sync) before its next call.
     Every figure is the median of three runs of about ops_per_run calls (the callers share the host's CPU quota with each other:
-    single runs of a few milliseconds scatter by 20 %); every caller's output is compared with the oracle after every run."""
-    from lattigo_amd.rlwe import ConcurrentMulRelin
+    single runs of a few milliseconds scatter by 20 %); every caller's output is compared with the oracle after every run.
+    workload "c3": BGV MulRelin at the headline shape; "c4": CKKS Rotate (Automorphism + Galois key switch) at logN = 16, 20 + 4 limbs."""
+    from lattigo_amd.rlwe import ConcurrentCalls
     from oracle import oracle as O
-    N = 1 << LOGN
-    q, p = gen_moduli()
+    rotate = workload == "c4"
+    N, (q, p) = (1 << 16, (C4_Q, C4_P)) if rotate else (1 << LOGN, gen_moduli())
+    op, tt = ("rotate", 5) if rotate else ("bgv_mulrelin", T)
     L, alpha = len(q), len(p)
     beta = (L + alpha - 1) // alpha
     kmax = max(ks)
     rng = np.random.Generator(np.random.PCG64(0x1A77160 + 77))
     kq, kp = uniform(rng, q, N, (beta, 2)), uniform(rng, p, N, (beta, 2))
-    host = [uniform(rng, q, N, (kmax,)) for _ in range(4)]  # a0, a1, b0, b1: [K][L][N]
+    host = [uniform(rng, q, N, (kmax,)) for _ in range(2 if rotate else 4)]  # a0, a1 [, b0, b1]: [K][L][N]
     want = O.Evaluator(O.Ring(N, q), O.Ring(N, p)).BatchOp(
-        "bgv_mulrelin", np.stack([host[0], host[1]], axis=1), np.stack([host[2], host[3]], axis=1), O.EvaluationKey(kq, kp), t=T)
+        op, np.stack([host[0], host[1]], axis=1), None if rotate else np.stack([host[2], host[3]], axis=1), O.EvaluationKey(kq, kp),
+        t=0 if rotate else T, gal=tt if rotate else 0)
+    ConcurrentMulRelin = lambda callers, level, iters, t=0, sync_each=False: ConcurrentCalls(op, callers, level, iters, tt, sync_each)
 
     def callers_on(c, n):
         ringQ, ringP = la.Ring(c, N, q), la.Ring(c, N, p)
         ev = la.Evaluator(ringQ, ringP)
         rlk = ev.NewEvaluationKey(kq, kp)
         mk = lambda k: ([la.Poly(ringQ, L).upload(host[0][k]), la.Poly(ringQ, L).upload(host[1][k])],
-                        [la.Poly(ringQ, L).upload(host[2][k]), la.Poly(ringQ, L).upload(host[3][k])],
+                        None if rotate else [la.Poly(ringQ, L).upload(host[2][k]), la.Poly(ringQ, L).upload(host[3][k])],
                         [la.Poly(ringQ, L, zero=False), la.Poly(ringQ, L, zero=False)])
         return ev, rlk, [mk(k) for k in n]
 
@@ -524,8 +528,8 @@ def concurrent_b1(la, ctx, ks=(1, 4, 16, 64), ops_per_run=6000, max_batch=64, wi
         return sorted(runs)[1]
 
     out = {"K": list(ks), "iters_per_caller": [iters_of(K) for K in ks], "runs": "median of 3", "max_batch": max_batch,
-           "window_us": window_us, "unit": "ctxt-mul+relin ops/s",
-           "note": "K OS threads, one batch-1 MulRelin per call (he_debug_concurrent_mul_relin); host wall clock from the common "
+           "window_us": window_us, "unit": "ctxt-rotate ops/s" if rotate else "ctxt-mul+relin ops/s", "operation": op,
+           "note": "K OS threads, one batch-1 operation per call (he_debug_concurrent_mul_relin); host wall clock from the common "
                    "start to the last caller's final sync"}
     ok = True
     # one shared evaluator, submission queue on
@@ -641,7 +645,7 @@ def main():
     dev = int(os.environ.get("HERING_FORCE_DEVICE", local_rank if world > 1 else 0))
     ctx = la.Context(dev)
     if args.only_concurrent:
-        print(json.dumps(concurrent_b1(la, ctx, window_us=args.co_window, max_batch=args.co_batch)), flush=True)
+        print(json.dumps(concurrent_b1(la, ctx, args.workload, window_us=args.co_window, max_batch=args.co_batch)), flush=True)
         cp.close()
         return
     setup, default_B = WORKLOADS[args.workload]
@@ -842,9 +846,9 @@ def main():
         line["b1"] = {"batch": 1, "ops_per_s": 1.0 / dt1, "latency_ms": dt1 * 1e3, "note": "one ciphertext per bootstrap"}
         line["b1"]["graph"] = graph_replay(la, ctx, W1["step"], 5)
         del W1
-    if not args.no_concurrent and world == 1 and args.workload == "c3":
+    if not args.no_concurrent and world == 1 and args.workload in ("c3", "c4"):
         try:
-            line["concurrent_b1"] = concurrent_b1(la, ctx, window_us=args.co_window, max_batch=args.co_batch)
+            line["concurrent_b1"] = concurrent_b1(la, ctx, args.workload, window_us=args.co_window, max_batch=args.co_batch)
             if line["concurrent_b1"]["verified"] is False:
                 problems.append("concurrent_b1: a caller's output differs from the oracle")
         except la.HeringError as e:
