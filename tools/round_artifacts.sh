@@ -2,7 +2,7 @@
 #   bash tools/round_artifacts.sh          -> bench line, rocprofv3 kernel stats of the same command, PMC traffic (c2, c3, c4, c5) + SQ passes
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_* $R/gpurun_out/prof_final
-BARGS="--no-cpu-baseline --no-verify --no-ntt --no-b1"
+BARGS="--no-cpu-baseline --no-verify --no-ntt --no-b1 --no-concurrent"
 # PMC traffic: separate FETCH_SIZE / WRITE_SIZE passes (kernel trace only, as the guide prescribes); steps of bench.py's step() per
 # run = warmup + steps (no HIP-event leg under the profiler)
 for W in c2 c3 c4 c5; do
