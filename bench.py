@@ -17,7 +17,7 @@ scaling, no data-path collective -- SURVEY.md section 8e); ranks synchronise onl
 and the MAX over ranks of the elapsed time.  After the timed region the output of the LAST step is checked against the CPU
 oracle on EVERY batch entry of every rank ("verified"; a mismatch makes the run fail).  Prints ONE JSON line on rank 0.
 
-Byte accounting: per-kernel algorithmic bytes come from the launchers themselves (he_prof_end_bytes:
+Byte accounting (DESIGN.md sections 4 and 6): per-kernel algorithmic bytes come from the launchers themselves (he_prof_end_bytes:
 every polynomial stream a launch reads or writes, once), per-op algorithmic bytes from the per-primitive formulas of SURVEY.md
 section 8(d) accumulated at the C ABI over the timed operation trace (he_alg_bytes) -- for c3 both are checked against the
 closed forms below, so the model cannot drift from the pipeline again.

@@ -159,7 +159,7 @@ class ControlPlane:
         accumulates digits digit_range(beta, rank, world), the four partial (Q, P) accumulators are summed across the ranks
         (RCCL all-reduce over xGMI, or gloo through the host) and every rank finishes with ModDown.  Bit-identical to the
         unsplit call.  This trades a 2 (L + alpha)-limb all-reduce per ciphertext for 1/world of the key memory and of the
-        inner-product work: the decomposition and the ModDown are not split (DESIGN.md section 6)."""
+        inner-product work: the decomposition and the ModDown are not split (DESIGN.md section 7)."""
         from .ring import Poly
         rQ, rP = evaluator.ringQ, evaluator.ringP
         levelP = evk.LevelP()
