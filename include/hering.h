@@ -290,6 +290,7 @@ int he_evk_commit(he_handle evk);
  * a polynomial's words across the ranks in place (mod 2^64; the partial accumulators of a key switch split by digit,
  * he_gadget_product_hoisted_lazy_digits -- the caller reduces afterwards). */
 #define HE_RCCL_ID_BYTES 128
+int he_rccl_available(int *yes);  /* could librccl be loaded in this process?  (ask every rank BEFORE the first collective call) */
 int he_rccl_unique_id(uint8_t *id);
 int he_rccl_comm_create(he_handle ctx, const uint8_t *id, int rank, int world, he_handle *comm);
 int he_rccl_comm_destroy(he_handle comm);

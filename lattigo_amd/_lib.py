@@ -123,7 +123,7 @@ def _declare(L):
         "he_alg_bytes": [H, i, C.POINTER(C.c_double)],
         "he_graph_begin": [H], "he_graph_end": [H, HP], "he_graph_launch": [H], "he_graph_nodes": [H, C.POINTER(i)],
         "he_graph_destroy": [H],
-        "he_rccl_unique_id": [C.POINTER(C.c_uint8)], "he_rccl_comm_create": [H, C.POINTER(C.c_uint8), i, i, HP],
+        "he_rccl_available": [C.POINTER(i)], "he_rccl_unique_id": [C.POINTER(C.c_uint8)], "he_rccl_comm_create": [H, C.POINTER(C.c_uint8), i, i, HP],
         "he_rccl_comm_destroy": [H], "he_rccl_comm_ranks": [H, C.POINTER(i)], "he_evk_broadcast": [H, H, i],
         "he_poly_all_reduce_sum": [H, H],
         "he_evaluator_set_coalescing": [H, i, i], "he_evaluator_coalescing_stats": [H, u64p],

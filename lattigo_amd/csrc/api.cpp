@@ -3385,6 +3385,12 @@ struct Comm : Obj {
 };
 }  // namespace
 }  // extern "C++"
+int he_rccl_available(int *yes) {
+    if (!yes) return fail(HE_EINVAL, "he_rccl_available: null output");
+    RcclApi &a = rccl();
+    *yes = (a.so && a.why.empty()) ? 1 : 0;
+    return HE_OK;
+}
 int he_rccl_unique_id(uint8_t *id) {
     if (!id) return fail(HE_EINVAL, "he_rccl_unique_id: null output");
     TRY(rccl_ready());

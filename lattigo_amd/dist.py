@@ -80,12 +80,20 @@ class ControlPlane:
         draws the id, the gloo control plane hands it round, he_rccl_comm_create joins."""
         if self._rccl is None:
             import ctypes as C
-            from ._lib import H, check, load
-            ident = (C.c_uint8 * 128)()
-            if self.rank == 0:
-                check(load().he_rccl_unique_id(ident))
-            blob = self.broadcast_bytes(bytes(ident), src=0) if self._dist is not None else bytes(ident)
-            ident = (C.c_uint8 * 128)(*blob)
+            from ._lib import H, HeringError, check, load
+            # every step that can fail on ONE rank is agreed on over the control plane before anybody enters a collective: a rank
+            # that raised while the others wait inside ncclCommInitRank (or inside the id's broadcast) would hang the job
+            yes = C.c_int()
+            check(load().he_rccl_available(C.byref(yes)))
+            if self.sum_over_ranks(float(yes.value)) != self.world:
+                raise HeringError(-3, "RCCL is not available on every rank")
+            ident, ok = (C.c_uint8 * 128)(), 1
+            if self.rank == 0 and load().he_rccl_unique_id(ident) != 0:
+                ok = 0
+            blob = self.broadcast_bytes(bytes([ok]) + bytes(ident), src=0) if self._dist is not None else bytes([ok]) + bytes(ident)
+            if blob[0] == 0:
+                raise HeringError(-3, "rank 0 could not draw an RCCL id")
+            ident = (C.c_uint8 * 128)(*blob[1:])
             h = H()
             check(load().he_rccl_comm_create(ctx.h, ident, self.rank, self.world, C.byref(h)))
             self._rccl = (ctx, h.value)
