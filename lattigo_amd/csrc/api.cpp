@@ -2312,9 +2312,14 @@ int moddown_pair(Evaluator &ev, int levelQ, int levelP, View c0Q, View c0P, View
 }
 // full GadgetProduct: out_k = [add_k +] GadgetProduct(cx)_k.  Both components share every launch
 // (accumulators are laid out [2][B] so ModDown runs once over 2B entries).
+// scatter_ginv (optional, in/out): on entry g^-1 mod 2N of an automorphism the caller wants applied to the outputs; where the
+// fused ModDown epilogues write the result they store it through that automorphism (NttEpilogue::scatter_ginv) and the value is
+// left as it is; a path without such an epilogue sets it to 0 and the caller applies the automorphism itself (launch_gather).
 int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp *hoisted, const Evk &k, View out0, View out1, int B,
                         const View *add0 = nullptr, const View *add1 = nullptr, bool cx_canonical = false,
-                        const TensorIn *tin = nullptr) {
+                        const TensorIn *tin = nullptr, uint32_t *scatter_ginv = nullptr) {
+    const uint32_t want_scatter = scatter_ginv ? *scatter_ginv : 0u;
+    if (scatter_ginv) *scatter_ginv = 0;
     BasisExtender &be = *ev.be;
     const int levelP = k.nPk - 1, N = be.Q->N;
     const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
@@ -2360,6 +2365,8 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
         HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, 2 * B, st, raw, g.total_limbs));
         if (defer.deferred) {
             NttMacEpilogue me;
+            me.scatter_ginv = tin ? 0u : want_scatter;
+            if (scatter_ginv && !tin) *scatter_ginv = want_scatter;
             me.ext = sQ; me.ext_f64 = raw;
             me.out0 = out0; me.out1 = out1;
             me.has_w0 = add0 != nullptr && !tin; me.has_w1 = add1 != nullptr && !tin;
@@ -2369,6 +2376,7 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
             LimbTab ti;  // the Q limbs the integer kernels own: their epilogue stays with the forward rows
             ti.n = 0;
             NttEpilogue epi;
+            epi.scatter_ginv = me.scatter_ginv;
             for (int i = 0; i <= levelQ; i++) {
                 const ModConst &m = be.Q->sub[i].mc;
                 const uint64_t si = be.Q->moduli[i] - be.md_ptoq[levelP][i];
@@ -2395,6 +2403,8 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
             return HE_OK;
         }
         NttEpilogue epi;
+        epi.scatter_ginv = tin ? 0u : want_scatter;
+        if (scatter_ginv && !tin) *scatter_ginv = want_scatter;
         for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
         epi.y = a0Q; epi.has_w = add0 != nullptr; epi.w = add0 ? *add0 : a0Q;
         epi.y_small_f64 = acc_f64;
@@ -2664,10 +2674,33 @@ static int automorphism_core(Evaluator &ev, int level, View in0, const View *in1
     be.ctx->acct(dec ? 3.0 * (level + 1) + key_limbs(k, level) / 2 : 4.0 * (level + 1), key_limbs(k, level), B, N);
     const size_t wQ = (size_t)B * (level + 1) * N;
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k.nPk - 1, B, !dec, &k) + 2 * wQ + (size_t)N));
+    hipStream_t st = be.ctx->stream;
+    // The automorphism is applied where the key switch writes its result: the fused ModDown epilogues store coefficient e at
+    // index_{g^-1}[e] (NttEpilogue::scatter_ginv), so that the intermediate ciphertext and the two gather passes over it disappear.
+    // Standard ring only (NthRoot = 2N), and not when an output is an input of its own entry (a thread would read the addend at e
+    // and overwrite another position some other thread still has to read); paths without a fused epilogue report back and get
+    // the gathers.  HERING_NO_AUTO_SCATTER=1 keeps the gathers (A/B).
+    static const bool no_scatter = getenv("HERING_NO_AUTO_SCATTER") && atoi(getenv("HERING_NO_AUTO_SCATTER")) != 0;
+    uint32_t ginv = 0;
+    // (entry-table views: aliasing requests never reach a table batch, co_submit_keyswitch)
+    const bool alias = out0.p == in0.p || out1.p == in0.p || (in1 && (out0.p == in1->p || out1.p == in1->p));
+    const FusedPlan *mdplan = nullptr;
+    if (k.nPk > 0) TRY(get_md_plan(ev, level, k.nPk - 1, &mdplan));
+    if (!no_scatter && be.type == 0 && !alias && mdplan && mdplan->ok && epilogue_scatter_supported(be.Q->logN)) {  // (a fused ModDown plan: every path below ends in an epilogue)
+        const uint64_t mask = (2ull << be.Q->logN) - 1;
+        uint64_t x = gal & mask;
+        for (int i = 0; i < 6; i++) x = (x * (2 - gal * x)) & mask;  // Newton: g^-1 mod 2N (g odd)
+        ginv = (uint32_t)x;
+    }
+    if (ginv) {
+        uint32_t applied = ginv;
+        TRY(gadget_product_core(ev, level, in1, dec, k, out0, out1, B, &in0, nullptr, false, nullptr, &applied));
+        if (!applied) return fail(HE_EINVAL, "automorphism: internal error, the fused ModDown plan took a path without its epilogue");
+        return HE_OK;
+    }
     View t0{be.ctx->arena_take(wQ), (size_t)(level + 1) * N}, t1{be.ctx->arena_take(wQ), (size_t)(level + 1) * N};
     const uint32_t *index = nullptr;
     TRY(cached_auto_index(ev, gal, &index));
-    hipStream_t st = be.ctx->stream;
     TRY(gadget_product_core(ev, level, in1, dec, k, t0, t1, B, &in0, nullptr));
     HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t0, index, out0, B, false, st));
     HIP_TRY(launch_gather(be.qp, ident_tab(level + 1), t1, index, out1, B, false, st));
@@ -3109,11 +3142,12 @@ static int co_submit_keyswitch(const std::shared_ptr<Evaluator> &ev, int op, int
     // Aliasing that the batched pipeline cannot take for a whole batch on the word of entry 0's pointers: an output that is the
     // key switch's NTT-domain operand (its own-digit limbs are still being read while the fused epilogue writes the outputs) or
     // the OTHER component's addend.  Such requests are flagged, batched apart and served one by one (co_run).  An output equal
-    // to its own component's addend -- Relinearize in place -- is read and written by the same thread and batches normally; an
-    // automorphism's outputs are written by the final gathers, after every input has been consumed.
+    // to its own component's addend -- Relinearize in place -- is read and written by the same thread and batches normally.
     const Poly *cx = op == CO_GADGET_PRODUCT ? r.a0.get() : op == CO_RELINEARIZE ? r.b0.get() : nullptr;
     if (cx) r.alias = cx->d == o0->d || cx->d == o1->d;
     if (op == CO_RELINEARIZE) r.alias = r.alias || r.a0->d == o1->d || r.a1->d == o0->d;
+    // (an automorphism that writes onto its own inputs takes the gather form, which reads them all first: flagged too)
+    if (op == CO_AUTOMORPHISM) r.alias = r.a0->d == o0->d || r.a0->d == o1->d || r.a1->d == o0->d || r.a1->d == o1->d;
     return co_submit(*ev, r);
 }
 static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_handle ha0, he_handle ha1, he_handle hb0, he_handle hb1,

@@ -95,6 +95,10 @@ struct NttEpilogue {
     // intermediate), so that dst may alias y
     bool has_dst = false;
     View dst;
+    // launch_ntt_rows, not with `tensor`: the result is stored through the NTT-domain automorphism of Galois element g (ring/
+    // automorphism.go:50-77: coefficient e of the transform lands where out[j] = in[index_g[j]] reads it); scatter_ginv = g^-1 mod 2N
+    // (standard ring), 0 = plain stores.  Outputs must then not alias the addends (a thread reads w at e and writes elsewhere).
+    uint32_t scatter_ginv = 0;
 };
 // Optional prologue of the INVERSE row pass over the limbs of the double-precision class (production row sizes): the input is
 // formed in the kernel as the degree-2 term of a ciphertext product, c = T(a, b) = MRed(MRed(a, ts[limb]), b), canonical, and
@@ -105,6 +109,7 @@ struct NttProdIn {
     uint64_t ts[kMaxLimbs];
 };
 bool ntt_prod_in_supported(int logN);
+bool epilogue_scatter_supported(int logN);  // NttEpilogue::scatter_ginv / NttMacEpilogue::scatter_ginv: the production row sizes
 hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,
                            hipStream_t s, const NttEpilogue *epi = nullptr, const NttProdIn *prod = nullptr);
 
@@ -311,6 +316,7 @@ struct NttMacEpilogue {
     bool tensor = false;
     View ta0, ta1, tb0, tb1;
     double sp[kMaxLimbs], tsp[kMaxLimbs];
+    uint32_t scatter_ginv = 0;  // as NttEpilogue::scatter_ginv
 };
 bool ntt_mac_epilogue_supported(int logN);
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,

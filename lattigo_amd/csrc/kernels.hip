@@ -134,6 +134,16 @@ __device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { 
 __device__ __forceinline__ size_t voff(const size_t *tab, size_t bs, size_t z) {
     return tab ? (size_t)ldc(reinterpret_cast<const uint64_t *>(tab), z) : z * bs;
 }
+// Automorphism fused into an epilogue's stores (ring/automorphism.go:50-77 applied where the result is written): the NTT-domain
+// automorphism of Galois element g is the gather out[j] = in[index_g[j]], i.e. source coefficient e lands at index_{g^-1}[e] --
+// computed here (two bit reversals and a multiply, AutomorphismNTTIndex :12-34 for NthRoot = 2N) instead of loaded.  The map sends
+// every aligned block of 64 consecutive coefficients onto an aligned block of 64 (the low six index bits are the high exponent
+// bits, which g permutes among themselves), so a wave's store still fills whole cache lines.  ginv = g^-1 mod 2N, 0 = no scatter.
+__device__ __forceinline__ unsigned auto_dest(unsigned e, unsigned ginv, int logN) {
+    const unsigned t1 = 2u * (__brev(e) >> (32 - logN)) + 1u;
+    const unsigned t2 = (((ginv * t1) & ((2u << logN) - 1u)) - 1u) >> 1;
+    return __brev(t2) >> (32 - logN);
+}
 static inline bool no_tab(std::initializer_list<View> vs) {
     for (const View &v : vs) if (v.tab) return false;
     return true;
@@ -302,6 +312,8 @@ struct NttArgs {
     int nbatch_prof = 0;  // host only: batch entries of the launch when grid.x is not their number (rows_bytes)
     int tprod = 0;  // f64 inverse kernel only (NttProdIn): the input is formed here as T(ta1, tb1) with epi_ts, and also written to out2
     // entry tables (View::tab) of the caller-facing operands: the epilogue's outputs and addends, the product's inputs
+    unsigned sc_ginv = 0;            // epilogue stores scattered by the automorphism of inverse Galois element sc_ginv (auto_dest); 0: none
+    int sc_logN = 0;
     const size_t *in_tab = nullptr;  // the transform's input (launch_ntt_rows: the operand of a coalesced key switch)
     const size_t *out_tab = nullptr, *out2_tab = nullptr, *epi_w_tab = nullptr, *epi_w2_tab = nullptr;
     const size_t *ta0_tab = nullptr, *ta1_tab = nullptr, *tb0_tab = nullptr, *tb1_tab = nullptr;
@@ -487,7 +499,9 @@ __device__ __forceinline__ void rows_lds_xfer(uint64_t (&x)[16], uint64_t *lds, 
 // Montgomery sequence -- without the fold's code the kernel keeps its four waves per SIMD with the sequence's fixed scratch
 // registers (the generic inverse spills 27-45 with them).  Round 2 ran this variant on Shoup twiddle pairs (19 instructions per
 // product and twice the twiddle bytes); the 16-instruction sequence on the ordinary table is 4 % faster and needs no second table.
-template <int LOGB, bool INV, bool NC, bool LEAN = false>
+// SCAT (forward, production row sizes): the epilogue's stores go through auto_dest (NttEpilogue::scatter_ginv); its own
+// instantiation, so that the plain kernels keep their registers
+template <int LOGB, bool INV, bool NC, bool LEAN = false, bool SCAT = false>
 __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4) ntt_rows_kernel(NttArgs A) {
     constexpr int N2 = 1 << LOGB;
     constexpr int T = N2 / 16;
@@ -600,13 +614,17 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int e = nat_e<T>(k, tau);
-                    stnt(&op[e], cred(wv[k] + mred(settle(lds[lds_phys(e)]) + twoq - yv[k], sy, q, qinv), q));
+                    uint64_t *dp = &op[e];
+                    if constexpr (SCAT) dp = op - (size_t)row * N2 + auto_dest((unsigned)(row * N2 + e), A.sc_ginv, A.sc_logN);
+                    stnt(dp, cred(wv[k] + mred(settle(lds[lds_phys(e)]) + twoq - yv[k], sy, q, qinv), q));
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int e = nat_e<T>(k, tau);
-                    stnt(&op[e], mred(settle(lds[lds_phys(e)]) + twoq - yv[k], sy, q, qinv));
+                    uint64_t *dp = &op[e];
+                    if constexpr (SCAT) dp = op - (size_t)row * N2 + auto_dest((unsigned)(row * N2 + e), A.sc_ginv, A.sc_logN);
+                    stnt(dp, mred(settle(lds[lds_phys(e)]) + twoq - yv[k], sy, q, qinv));
                 }
             }
         } else {
@@ -797,7 +815,7 @@ __device__ __forceinline__ void rows_lds_xfer_f64(double (&x)[16], double *lds, 
     }
 }
 
-template <int LOGB, bool INV, bool TP = false>
+template <int LOGB, bool INV, bool TP = false, bool SCAT = false>
 __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) ntt_rows_f64_kernel(NttArgs A) {
     static_assert(!TP || INV, "the product prologue belongs to the inverse transform");
     constexpr int N2 = 1 << LOGB;
@@ -988,13 +1006,17 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
                 for (int k = 0; k < 16; k++) {
                     const int e = nat_e<T>(k, tau);
                     const uint64_t v = canon_f64(modmul_f64(lds[lds_phys(e)] - yv[k], sp, q, qi), q, qi);
-                    stnt(&op[e], cred(wv[k] + v, mc.q));
+                    uint64_t *dp = &op[e];
+                    if constexpr (SCAT) dp = op - (size_t)row * N2 + auto_dest((unsigned)(row * N2 + e), A.sc_ginv, A.sc_logN);
+                    stnt(dp, cred(wv[k] + v, mc.q));
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int e = nat_e<T>(k, tau);
-                    stnt(&op[e], canon_f64(modmul_f64(lds[lds_phys(e)] - yv[k], sp, q, qi), q, qi));
+                    uint64_t *dp = &op[e];
+                    if constexpr (SCAT) dp = op - (size_t)row * N2 + auto_dest((unsigned)(row * N2 + e), A.sc_ginv, A.sc_logN);
+                    stnt(dp, canon_f64(modmul_f64(lds[lds_phys(e)] - yv[k], sp, q, qi), q, qi));
                 }
             }
         } else {
@@ -1288,6 +1310,8 @@ struct MacEpiK {
     // row the i-th nibble of etab_rows in the order out0, out1, w0, w1, ta0, ta1, tb0, tb1 (0xF: no table, z * bstride)
     const size_t *etab;
     unsigned etab_rows;
+    unsigned sc_ginv;  // stores scattered by the automorphism of inverse Galois element sc_ginv (auto_dest); 0: none
+    int sc_logN;
 };
 enum { ME_OUT0 = 0, ME_OUT1, ME_W0, ME_W1, ME_TA0, ME_TA1, ME_TB0, ME_TB1 };
 __device__ __forceinline__ size_t meoff(const MacEpiK &e, int which, size_t bs, size_t z, unsigned nbatch) {
@@ -1315,7 +1339,7 @@ struct NttMacDmaArgs {
 // accumulators' P parts arrive through the same prefetch chain as two more "digits", are transformed like them, and
 // out_c = [w_c +] (NTT(ext_c) - acc_c) s is formed against the accumulator still in registers -- the Q accumulators are never
 // written, and the separate forward-row + epilogue launch (HBM-bound, next to this latency-bound kernel) is gone.
-template <int LOGB, bool QF64, bool EPI = false>
+template <int LOGB, bool QF64, bool EPI = false, bool SCAT = false>
 __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(NttMacDmaArgs AA) {
     static_assert(LOGB == 12 || LOGB == 13, "production row sizes only");
     constexpr int N2 = 1 << LOGB;
@@ -1634,12 +1658,17 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         const uint64_t v = canon_f64(modmul_f64(x[k] - reduce_f64(acc0[k], q, qi), sp, q, qi), q, qi);
-                        stnt(&op[(unsigned)(k * T)], cred(wv[k] + v, qu));
+                        uint64_t *dp = &op[(unsigned)(k * T)];
+                        if constexpr (SCAT) dp = op - (cur.rowoff + tau) + auto_dest((unsigned)(cur.rowoff + tau) + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
+                        stnt(dp, cred(wv[k] + v, qu));
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        stnt(&op[(unsigned)(k * T)], canon_f64(modmul_f64(x[k] - reduce_f64(acc0[k], q, qi), sp, q, qi), q, qi));
+                    for (int k = 0; k < 16; k++) {
+                        uint64_t *dp = &op[(unsigned)(k * T)];
+                        if constexpr (SCAT) dp = op - (cur.rowoff + tau) + auto_dest((unsigned)(cur.rowoff + tau) + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
+                        stnt(dp, canon_f64(modmul_f64(x[k] - reduce_f64(acc0[k], q, qi), sp, q, qi), q, qi));
+                    }
                 }
                 MAC_STAMP2(48 + c * 4 + 3);
                 // the second pass works on the other accumulator through the same names (a run-time choice between the two
@@ -1689,6 +1718,10 @@ bool ntt_prod_in_supported(int logN) {
     const int b = ntt_row_bits(logN);
     return b == 12 || b == 13;
 }
+bool epilogue_scatter_supported(int logN) {
+    const int b = ntt_row_bits(logN);
+    return b == 12 || b == 13;
+}
 bool ntt_mac_epilogue_supported(int logN) {
     const int b = ntt_row_bits(logN);
     return b == 12 || b == 13;
@@ -1720,6 +1753,8 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
             D.e.has_w0 = epi->has_w0 ? 1 : 0; D.e.has_w1 = epi->has_w1 ? 1 : 0;
             D.e.w0 = epi->w0.p; D.e.w0_bs = epi->w0.bstride; D.e.w1 = epi->w1.p; D.e.w1_bs = epi->w1.bstride;
             D.e.tensor = epi->tensor ? 1 : 0;
+            if (epi->scatter_ginv && epi->tensor) return hipErrorInvalidValue;
+            D.e.sc_ginv = epi->scatter_ginv; D.e.sc_logN = r.logN;
             D.e.ta0 = epi->ta0.p; D.e.ta0_bs = epi->ta0.bstride; D.e.ta1 = epi->ta1.p; D.e.ta1_bs = epi->ta1.bstride;
             D.e.tb0 = epi->tb0.p; D.e.tb0_bs = epi->tb0.bstride; D.e.tb1 = epi->tb1.p; D.e.tb1_bs = epi->tb1.bstride;
             {   // the operands' entry tables must be rows of ONE table with `batch` entries per row (api.cpp builds them so)
@@ -1751,7 +1786,10 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
             if ((D.nitems & 7u) == 0) G = (G + 7u) & ~7u;
         }
         ProfScope ps(K_NTT_MAC_F64, s, mac_bytes);
-        if (epi) {
+        if (epi && D.e.sc_ginv) {
+            if (b == 12) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false, true, true>), dim3(G), dim3(256), 0, s, D);
+            else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, false, true, true>), dim3(G), dim3(512), 0, s, D);
+        } else if (epi) {
             if (b == 12) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false, true>), dim3(G), dim3(256), 0, s, D);
             else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, false, true>), dim3(G), dim3(512), 0, s, D);
         } else if (b == 12) {
@@ -1901,6 +1939,15 @@ static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStrea
             return hipGetLastError();
         }
     }
+    if constexpr (!INV) {
+        if (A.sc_ginv) {  // scattered epilogue stores (NttEpilogue::scatter_ginv): production row sizes only
+            if ((logb != 12 && logb != 13) || !A.epi) return hipErrorInvalidValue;
+            ProfScope ps(K_NTT_ROWS_FWD, s, rows_bytes(grid, A, logb));
+            if (logb == 12) hipLaunchKernelGGL((ntt_rows_kernel<12, false, NC, false, true>), grid, dim3(256), 0, s, A);
+            else hipLaunchKernelGGL((ntt_rows_kernel<13, false, NC, false, true>), grid, dim3(512), 0, s, A);
+            return hipGetLastError();
+        }
+    }
 #define HE_ROWS_CASE(B)                                                                           \
     case B:                                                                                       \
         { ProfScope ps(INV ? K_NTT_ROWS_INV : K_NTT_ROWS_FWD, s, rows_bytes(grid, A, B));                                 \
@@ -1922,6 +1969,15 @@ static hipError_t launch_rows_f64(int logb, dim3 grid, const NttArgs &A, hipStre
             ProfScope ps(K_NTT_ROWS_INV_F64, s, rows_bytes(grid, A, logb));
             if (logb == 12) hipLaunchKernelGGL((ntt_rows_f64_kernel<12, true, true>), grid, dim3(256), 0, s, A);
             else hipLaunchKernelGGL((ntt_rows_f64_kernel<13, true, true>), grid, dim3(512), 0, s, A);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (!INV) {
+        if (A.sc_ginv) {
+            if ((logb != 12 && logb != 13) || !A.epi) return hipErrorInvalidValue;
+            ProfScope ps(K_NTT_ROWS_FWD_F64, s, rows_bytes(grid, A, logb));
+            if (logb == 12) hipLaunchKernelGGL((ntt_rows_f64_kernel<12, false, false, true>), grid, dim3(256), 0, s, A);
+            else hipLaunchKernelGGL((ntt_rows_f64_kernel<13, false, false, true>), grid, dim3(512), 0, s, A);
             return hipGetLastError();
         }
     }
@@ -1997,6 +2053,9 @@ static void set_epilogue(NttArgs &A, const NttEpilogue &epi, int n) {
     A.epi_w = epi.w.p; A.epi_w_bs = epi.w.bstride; A.epi_w_tab = epi.w.tab;
     for (int i = 0; i < n; i++) A.epi_s[i] = epi.s[i];
     A.epi_tensor = epi.tensor ? 1 : 0;
+    A.sc_ginv = epi.tensor ? 0u : epi.scatter_ginv;
+    A.sc_logN = 0;
+    for (int nn = A.N; nn > 1; nn >>= 1) A.sc_logN++;
     if (epi.tensor) {
         A.ta0 = epi.ta0.p; A.ta1 = epi.ta1.p; A.tb0 = epi.tb0.p; A.tb1 = epi.tb1.p;
         A.ta0_bs = epi.ta0.bstride; A.ta1_bs = epi.ta1.bstride; A.tb0_bs = epi.tb0.bstride; A.tb1_bs = epi.tb1.bstride;
