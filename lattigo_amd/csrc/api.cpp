@@ -1747,7 +1747,7 @@ int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2n
 // limb_filter: 0 = every limb, 1 = only limbs NOT of class 2 (the fused f64 NTT+MAC kernel takes the others)
 int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View o0Q,
              View o0P, View o1Q, View o1P, int batch, const View *own = nullptr, int own_alpha = 0, int limb_filter = 0,
-             int digit_begin = 0, int digit_end = -1) {
+             int digit_begin = 0, int digit_end = -1, const KsScatter *scatter = nullptr) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, N = be.Q->N;
     KsArgs a{};
@@ -1777,6 +1777,12 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
     a.own_alpha = own ? own_alpha : 0;
     a.own_nq = levelQ + 1;
     const View decv{const_cast<uint64_t *>(dec), dec_bs};
+    if (scatter && scatter->ginv) {  // (add_s arrives by Q limb: compact it to the launch limbs)
+        KsScatter sc = *scatter;
+        for (int i = 0; i < n; i++) sc.add_s[i] = a.out_view[i] == 0 ? scatter->add_s[a.out_limb[i]] : 0;
+        HIP_TRY(launch_ks_inner(be.qp, a, decv, own ? *own : decv, keyp, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream, &sc));
+        return HE_OK;
+    }
     HIP_TRY(launch_ks_inner(be.qp, a, decv, own ? *own : decv, keyp, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
     return HE_OK;
 }
@@ -2764,6 +2770,29 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, levelP, B, o, "he_automorphism_hoisted_lazy"));
     Scope sc(be.ctx.get());
     be.ctx->acct(levelQ + 1 + key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + levelP + 2), key_limbs(*k, levelQ), B, N);
+    ScalarTab s{};  // ctTmp[1].Q = ctIn[0] * P   (MulScalarBigint with P = prod p_j at levelP)
+    for (int i = 0; i <= levelQ; i++) {
+        const ModConst &m = be.Q->sub[i].mc;
+        uint64_t pm = 1;
+        for (int j = 0; j <= levelP; j++) pm = mulmod(pm, be.P->moduli[j] % m.q, m.q);
+        s.s[i] = mform(pm, m.q, m.brc0, m.brc1);
+    }
+    // ONE launch: the key inner product adds ctIn[0] * P to component 0 at the source position and stores all four accumulators
+    // through the automorphism (KsScatter) -- instead of inner product, two element-wise passes and four gathers.  Standard
+    // ring, and the outputs must not be the addend (other threads still read it); HERING_NO_AUTO_SCATTER=1: the old sequence.
+    static const bool no_scatter = getenv("HERING_NO_AUTO_SCATTER") && atoi(getenv("HERING_NO_AUTO_SCATTER")) != 0;
+    const bool alias = o.q0->d == in0->d || o.q1->d == in0->d;
+    if (!no_scatter && be.type == 0 && !alias) {
+        KsScatter ks;
+        const uint64_t mask = (2ull << be.Q->logN) - 1;
+        uint64_t x = gal & mask;
+        for (int i = 0; i < 6; i++) x = (x * (2 - gal * x)) & mask;  // Newton: g^-1 mod 2N (g odd)
+        ks.ginv = (uint32_t)x;
+        ks.add0 = in0->view();
+        for (int i = 0; i <= levelQ; i++) ks.add_s[i] = s.s[i];
+        return ks_inner(*ev, levelQ, levelP, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(),
+                        o.p1->view(), B, nullptr, 0, 0, 0, -1, &ks);
+    }
     const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
     TRY(be.ctx->arena_reserve(2 * B * (sQw + sPw) + N + 64));
     View t0Q{be.ctx->arena_take(B * sQw), sQw}, t1Q{be.ctx->arena_take(B * sQw), sQw};
@@ -2775,13 +2804,6 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     const LimbTab tq = ident_tab(levelQ + 1), tp = ident_tab(levelP + 1, 0, 0, be.LQ);
     HIP_TRY(launch_gather(be.qp, tq, t1Q, index, o.q1->view(), B, false, st));
     HIP_TRY(launch_gather(be.qp, tp, t1P, index, o.p1->view(), B, false, st));
-    ScalarTab s{};  // ctTmp[1].Q = ctIn[0] * P   (MulScalarBigint with P = prod p_j at levelP)
-    for (int i = 0; i <= levelQ; i++) {
-        const ModConst &m = be.Q->sub[i].mc;
-        uint64_t pm = 1;
-        for (int j = 0; j <= levelP; j++) pm = mulmod(pm, be.P->moduli[j] % m.q, m.q);
-        s.s[i] = mform(pm, m.q, m.brc0, m.brc1);
-    }
     HIP_TRY(launch_ew(be.qp, tq, EW_MUL_SCALAR_MONT, in0->view(), in0->view(), t1Q, B, &s, nullptr, st));
     HIP_TRY(launch_ew(be.qp, tq, EW_ADD, t0Q, t1Q, t0Q, B, nullptr, nullptr, st));
     HIP_TRY(launch_gather(be.qp, tq, t0Q, index, o.q0->view(), B, false, st));

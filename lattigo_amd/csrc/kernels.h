@@ -268,8 +268,16 @@ struct KsArgs {
     int own_alpha;                    // digit d owns Q limbs [d*alpha, (d+1)*alpha)
     int own_nq;                       // launch limbs < own_nq are Q limbs with limb index == launch index
 };
+// Optional (AutomorphismHoistedLazy as ONE launch, core/rlwe/evaluator_automorphism.go:104-165): the accumulators are stored
+// through the NTT-domain automorphism whose inverse Galois element is ginv (see NttEpilogue::scatter_ginv), and component 0 of
+// the Q limbs is first increased by MRed(add0, add_s[launch limb]) -- the ctIn[0] * P term -- read at the source position.
+struct KsScatter {
+    uint32_t ginv = 0;
+    View add0{nullptr, 0};
+    uint64_t add_s[kMaxLimbs];
+};
 hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
-                           View out0P, View out1Q, View out1P, int batch, hipStream_t s);
+                           View out0P, View out1Q, View out1P, int batch, hipStream_t s, const KsScatter *sc = nullptr);
 
 // Plaintext-diagonal x ciphertext multiply-accumulate (inner loop of lintrans, circuits/common/lintrans/
 // lintrans_evaluator.go:346-394): out_k = Reduce(prev_k + sum_i MulCoeffsMontgomeryLazy(pt_i, ct_i[k])), k = 0,1, for the

@@ -3348,9 +3348,17 @@ struct KsKArgs {
     const ModConst *mc;
     int N, batch;
     KsArgs k;
+    // SCAT (AutomorphismHoistedLazy in one launch, core/rlwe/evaluator_automorphism.go:104-165): the accumulators are stored
+    // through the automorphism (auto_dest), and component 0 of the Q limbs first takes the addend MRed(add0, add_s[limb]) --
+    // ctIn[0] * P -- at the SOURCE position (the permutation is applied to the sum)
+    unsigned sc_ginv;
+    int sc_logN;
+    const uint64_t *add0;
+    size_t add0_bs;
+    uint64_t add_s[kMaxLimbs];
 };
 
-template <int BB>
+template <int BB, bool SCAT = false>
 __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= A.N) return;
@@ -3377,6 +3385,14 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
     auto is_own = [&](int d) -> bool {
         return A.k.own_alpha > 0 && A.k.out_view[l] == 0 && ql >= d * A.k.own_alpha && ql < (d + 1) * A.k.own_alpha;
     };
+    [[maybe_unused]] uint64_t addv[BB];
+    if constexpr (SCAT) {
+        if (A.add0 && A.k.out_view[l] == 0) {  // block-uniform; in flight over the whole digit loop
+#pragma unroll
+            for (int b = 0; b < BB; b++)
+                addv[b] = ldnt(&A.add0[(size_t)(b0 + b < A.batch ? b0 + b : b0) * A.add0_bs + (size_t)A.k.out_limb[l] * A.N + x]);
+        }
+    }
     uint64_t cn[BB], kn0, kn1;
     auto fetch = [&](int d) {
         kn0 = kp[(size_t)d * A.k.key_dstride];
@@ -3412,18 +3428,23 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
 #pragma unroll
     for (int b = 0; b < BB; b++) {
         if (b0 + b < A.batch) {
-            const uint64_t r0 = cred(mred128_lazy(hi0[b], lo0[b], q, m.qinv), q);
+            uint64_t r0 = cred(mred128_lazy(hi0[b], lo0[b], q, m.qinv), q);
             const uint64_t r1 = cred(mred128_lazy(hi1[b], lo1[b], q, m.qinv), q);
             uint64_t *o0 = isP ? A.o0P + (size_t)(b0 + b) * A.oP0_bs : A.o0Q + (size_t)(b0 + b) * A.oQ0_bs;
             uint64_t *o1 = isP ? A.o1P + (size_t)(b0 + b) * A.oP1_bs : A.o1Q + (size_t)(b0 + b) * A.oQ1_bs;
-            stnt(&o0[(size_t)ol * A.N + x], r0);
-            stnt(&o1[(size_t)ol * A.N + x], r1);
+            size_t pos = (size_t)x;
+            if constexpr (SCAT) {
+                if (A.add0 && !isP) r0 = cred(r0 + mred(addv[b], A.add_s[l], q, m.qinv), q);
+                pos = auto_dest((unsigned)x, A.sc_ginv, A.sc_logN);
+            }
+            stnt(&o0[(size_t)ol * A.N + pos], r0);
+            stnt(&o1[(size_t)ol * A.N + pos], r1);
         }
     }
 }
 
 hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
-                           View out0P, View out1Q, View out1P, int batch, hipStream_t s) {
+                           View out0P, View out1Q, View out1P, int batch, hipStream_t s, const KsScatter *sc) {
     if (!no_tab({dec, out0Q, out0P, out1Q, out1P})) return hipErrorInvalidValue;  // entry tables: only the own-digit operand
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     KsKArgs A;
@@ -3432,10 +3453,26 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
     A.mc = r.mc; A.N = r.N; A.batch = batch; A.k = a;
+    A.sc_ginv = 0; A.sc_logN = r.logN; A.add0 = nullptr; A.add0_bs = 0;
     const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
     dim3 grid((unsigned)((r.N + 255) / 256), a.nlimbs, (batch + bb - 1) / bb), block(256);
     // beta digits in, two key rows per digit shared by the batch, two accumulators out
-    ProfScope ps(K_KS_INNER, s, ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0);
+    double ks_bytes = ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0;
+    if (sc && sc->ginv) {
+        if (sc->add0.tab) return hipErrorInvalidValue;
+        A.sc_ginv = sc->ginv;
+        int nadd = 0;
+        if (sc->add0.p) {
+            A.add0 = sc->add0.p; A.add0_bs = sc->add0.bstride;
+            for (int i = 0; i < a.nlimbs; i++) { A.add_s[i] = sc->add_s[i]; nadd += a.out_view[i] == 0; }
+        }
+        ProfScope ps(K_KS_INNER, s, ks_bytes + (double)nadd * batch * (double)r.N * 8.0);
+        if (bb == 4) hipLaunchKernelGGL((ks_inner_kernel<4, true>), grid, block, 0, s, A);
+        else if (bb == 2) hipLaunchKernelGGL((ks_inner_kernel<2, true>), grid, block, 0, s, A);
+        else hipLaunchKernelGGL((ks_inner_kernel<1, true>), grid, block, 0, s, A);
+        return hipGetLastError();
+    }
+    ProfScope ps(K_KS_INNER, s, ks_bytes);
     if (bb == 4) hipLaunchKernelGGL((ks_inner_kernel<4>), grid, block, 0, s, A);
     else if (bb == 2) hipLaunchKernelGGL((ks_inner_kernel<2>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((ks_inner_kernel<1>), grid, block, 0, s, A);
