@@ -77,7 +77,11 @@ int he_graph_nodes(he_handle graph, int *nodes);  /* kernel / memset / copy node
 int he_graph_destroy(he_handle graph);
 
 /* ---- ring: ring.NewRing (ring/ring.go:207), SubRing tables (ring/subring.go:99-159),
- *      RescaleConstants (ring/ring.go:329).  Standard (negacyclic) type, NthRoot = 2N. */
+ *      RescaleConstants (ring/ring.go:329).  Standard (negacyclic) type, NthRoot = 2N.
+ *      logN in [4, 20] (the reference's MaxLogN, core/rlwe/params.go:21); NTT-friendly prime moduli below 2^61 (the range in
+ *      which the reference's own lazy butterflies are exact, ring/ntt.go:169; its GenModuli draws 61-bit primes downstream of
+ *      2^61 only, params.go:838).  The fused key-switch pipelines cover logN <= 17; larger rings run the same operations through
+ *      the generic passes (three-pass NTT from logN = 19, unfused basis extension), bit-identical results. */
 int he_ring_create(he_handle ctx, int logN, const uint64_t *moduli, int n_moduli, he_handle *ring);
 /* ring.NewRingFromType (ring/ring.go:267): ring_type 0 = Standard, 1 = ConjugateInvariant
  * (Z[X+X^-1]/(X^2N+1), NthRoot = 4N; NTT of ring/ntt.go:716-1311).  Conjugate-invariant rings are accepted everywhere a

@@ -686,7 +686,7 @@ int he_ring_create_type(he_handle hctx, int logN, int ring_type, const uint64_t 
     if (ring_type != 0 && ring_type != 1) return fail(HE_EINVAL, "he_ring_create: invalid ring type %d", ring_type);
     if (!moduli || !out || n <= 0) return fail(HE_EINVAL, "he_ring_create: invalid ModuliChain (must be a non-empty []uint64)");
     if (n > 48) return fail(HE_EINVAL, "he_ring_create: at most 48 moduli per ring");
-    if (logN < 4 || logN > 17) return fail(HE_EPARAM, "he_ring_create: logN=%d outside [4,17]", logN);
+    if (logN < 4 || logN > kMaxLogN) return fail(HE_EPARAM, "he_ring_create: logN=%d outside [4,%d]", logN, kMaxLogN);
     for (int i = 0; i < n; i++)
         for (int j = i + 1; j < n; j++)
             if (moduli[i] == moduli[j]) return fail(HE_EPARAM, "he_ring_create: invalid ModuliChain (moduli are not distinct)");

@@ -10,6 +10,7 @@
 namespace he {
 
 constexpr int kMaxLimbs = 64;  // limbs addressed by one launch
+constexpr int kMaxLogN = 20;   // the reference's MaxLogN (core/rlwe/params.go:21); the fused key-switch pipelines cover logN <= 17
 
 // Which limbs a launch touches: entry y of the grid's y-dimension reads limb in_limb[y]
 // of the input view(s), writes limb out_limb[y] and uses modulus record mod[y].

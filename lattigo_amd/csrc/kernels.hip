@@ -5,7 +5,7 @@
 // are the HBM/LDS ones: limb-major coalesced loads, twiddles and butterfly stages
 // staged through LDS / registers, one launch covering every (limb x batch entry).
 //
-// NTT decomposition (N = 2^n, n <= 17):  a = max(0, n-12) "column" stages are done
+// NTT decomposition (N = 2^n, n <= 20; the fused pipelines below stop at n = 17, beyond that the generic passes run):  a = max(0, n-12) "column" stages are done
 // in registers on elements strided by N/2^a (ntt_cols), the remaining b = n-a <= 12
 // stages on contiguous rows of 2^b coefficients held in LDS, in rounds of up to four
 // stages with 16 coefficients per thread in registers (ntt_rows).  The transform is
@@ -315,6 +315,7 @@ struct NttArgs {
     unsigned sc_ginv = 0;            // epilogue stores scattered by the automorphism of inverse Galois element sc_ginv (auto_dest); 0: none
     int sc_logN = 0;
     const size_t *in_tab = nullptr;  // the transform's input (launch_ntt_rows: the operand of a coalesced key switch)
+    int cb = 0;  // column kernel only: stages done by an outer column pass (logN >= 19: the columns take two passes, see ntt_cols_kernel)
     const size_t *out_tab = nullptr, *out2_tab = nullptr, *epi_w_tab = nullptr, *epi_w2_tab = nullptr;
     const size_t *ta0_tab = nullptr, *ta1_tab = nullptr, *tb0_tab = nullptr, *tb1_tab = nullptr;
 };
@@ -1852,22 +1853,28 @@ hipError_t launch_key_to_f64(const RingDev &r, const uint64_t *key, double *keyd
 }
 
 // ------------------------------------------------------------------------------------
-// ntt_cols: the a = LOGA outermost stages, in registers, on elements strided by N/2^a.
-// grid = (N2/256, limbs, batch), block = 256.
+// ntt_cols: LOGA strided stages in registers.  With cb = 0 they are the LOGA outermost stages of the transform, on elements
+// strided by N / 2^LOGA.  With cb > 0 (logN >= 19, where the a = logN - 13 column stages no longer fit one thread's registers)
+// an outer pass has done stages 0 .. cb-1 and this one does stages cb .. cb+LOGA-1: inside each of the 2^cb blocks of N / 2^cb
+// coefficients, block j playing the part of "row" 2^cb + j of the twiddle table exactly as a row does in ntt_rows.
+// grid = (N / 2^LOGA / 256, limbs, batch), block = 256.
 // ------------------------------------------------------------------------------------
 template <int LOGA, bool INV>
 __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
     constexpr int R = 1 << LOGA;
-    const int N2 = A.N >> LOGA;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N2) return;
+    const int N2 = (A.N >> A.cb) >> LOGA;    // stride of a thread's coefficients
+    const int cg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cg >= (A.N >> LOGA)) return;
+    const int blk = cg / N2, c = cg - blk * N2;  // (N2 is a power of two)
+    const int rowtw = (1 << A.cb) + blk;
     const int y = blockIdx.y;
     const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
     const ModConst mc = A.mc[mi];
     const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
     const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
-    const uint64_t *__restrict__ src = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)il * A.N + c;
-    uint64_t *__restrict__ dst = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)ol * A.N + c;
+    const size_t e0 = (size_t)blk * ((size_t)N2 << LOGA) + c;
+    const uint64_t *__restrict__ src = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)il * A.N + e0;
+    uint64_t *__restrict__ dst = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)ol * A.N + e0;
 
     uint64_t x[R];
 #pragma unroll
@@ -1889,8 +1896,8 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if (r & d) continue;
-                if (nc) bfly_fwd_nc(x[r], x[r + d], tw[(1 << s) + (r >> (LOGA - s))], q, qinv);
-                else bfly_fwd(x[r], x[r + d], tw[(1 << s) + (r >> (LOGA - s))], q, twoq, qinv);
+                if (nc) bfly_fwd_nc(x[r], x[r + d], tw[(rowtw << s) + (r >> (LOGA - s))], q, qinv);
+                else bfly_fwd(x[r], x[r + d], tw[(rowtw << s) + (r >> (LOGA - s))], q, twoq, qinv);
             }
         }
     } else {
@@ -1900,7 +1907,7 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if (r & d) continue;
-                const uint64_t wv = tw[(1 << s) + (r >> (LOGA - s))];
+                const uint64_t wv = tw[(rowtw << s) + (r >> (LOGA - s))];
                 if (s == 0 && A.scale) {
                     const uint64_t wn = mred(wv, mc.ninv, q, qinv);
                     bfly_inv_scaled(x[r], x[r + d], wn, mc.ninv, q, twoq, qinv);
@@ -2073,10 +2080,13 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
                       hipStream_t s, const uint64_t *io_scalar, const NttEpilogue *epi) {
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     const int n = r.logN;
-    if (n < 4 || n > 17) return hipErrorInvalidValue;
+    if (n < 4 || n > kMaxLogN) return hipErrorInvalidValue;
     if (epi && (inverse || epi->zsplit > 0)) return hipErrorInvalidValue;
     if (!no_tab({in, out}) || (epi && !no_tab({epi->y, epi->w, epi->dst}))) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
+    // column stages: one pass of up to five (32 coefficients per thread); logN = 19, 20 (a = 6, 7) take an outer pass of a - 4
+    // and an inner pass of 4 inside the 2^(a-4) blocks the outer pass leaves (ntt_cols_kernel, NttArgs::cb)
+    const int a_out = a > 5 ? a - 4 : a, a_in = a - a_out;
     NttArgs A;
     A.mc = r.mc;
     A.N = r.N;
@@ -2088,7 +2098,8 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     const int sflag = io_scalar ? NTT_ADD_SCALAR : 0;
     for (int i = 0; i < tab.n; i++) A.io_s[i] = io_scalar ? io_scalar[i] : 0;
     dim3 grows(batch, tab.n, 1u << a);
-    dim3 gcols((unsigned)(((r.N >> a) + 255) / 256), tab.n, batch);
+    dim3 gcols((unsigned)(((r.N >> a_out) + 255) / 256), tab.n, batch);
+    dim3 gcols_in((unsigned)(((r.N >> (a_in > 0 ? a_in : 1)) + 255) / 256), tab.n, batch);
     hipError_t e;
     if (!inverse) {
         A.tw = r.tw_fwd;
@@ -2097,11 +2108,16 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
         if (a > 0) {
             A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
             A.flags = (flags & NTT_REDUCE_INPUT) | sflag;
-            if ((e = launch_cols<false>(a, gcols, A, s)) != hipSuccess) return e;
+            if ((e = launch_cols<false>(a_out, gcols, A, s)) != hipSuccess) return e;
             // second pass in place on `out`: limbs are now addressed by out_limb
             NttArgs B = A;
             for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
             B.in = out.p; B.in_bs = out.bstride;
+            if (a_in > 0) {
+                B.flags = 0; B.cb = a_out;
+                if ((e = launch_cols<false>(a_in, gcols_in, B, s)) != hipSuccess) return e;
+                B.cb = 0;
+            }
             B.flags = flags & NTT_LAZY_OUT;
             if (epi) {
                 set_epilogue(B, *epi, tab.n);
@@ -2127,9 +2143,14 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
         NttArgs B = A;
         for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
         B.in = out.p; B.in_bs = out.bstride;
+        if (a_in > 0) {
+            B.flags = 0; B.scale = 0; B.cb = a_out;
+            if ((e = launch_cols<true>(a_in, gcols_in, B, s)) != hipSuccess) return e;
+            B.cb = 0;
+        }
         B.flags = sflag;
         B.scale = 1;
-        return launch_cols<true>(a, gcols, B, s);
+        return launch_cols<true>(a_out, gcols, B, s);
     }
     return hipSuccess;
 }

@@ -8,7 +8,7 @@
   host's cores), plus Relinearize(degree-2 result) == MulRelin.
 * Boundary moduli of the two fast arithmetic classes: the largest NTT-friendly primes below 2^47 (double-precision
   kernels, exactness argument "34q + input < 2^53") and below 2^58 (correction-free integer butterflies,
-  "34q / 36q < 2^64") at logN = 16 and 17, on worst-case inputs (all q-1, alternating 0 / q-1, non-canonical words up
+  "34q / 36q < 2^64"; 42q at logN = 20) at logN = 16, 17 and 20, on worst-case inputs (all q-1, alternating 0 / q-1, non-canonical words up
   to 2^64-1, which this library reduces first), through Ring.NTT/INTT and through the whole key-switch pipeline.
 """
 import numpy as np
@@ -212,7 +212,7 @@ def _worst_case_inputs(rng, q, N):
             rng.integers(0, q, size=N, dtype=np.uint64), rng.integers(0, 2 * q, size=N, dtype=np.uint64)]
 
 
-@pytest.mark.parametrize("logN", [15, 16, 17])
+@pytest.mark.parametrize("logN", [15, 16, 17, 20])
 @pytest.mark.parametrize("bits", [47, 58, 61])
 def test_ntt_class_boundary_moduli(ctx, logN, bits):
     """Largest primes of the double-precision (< 2^47) and correction-free (< 2^58) classes, plus the smallest primes

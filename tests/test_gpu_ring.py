@@ -114,6 +114,40 @@ def test_ntt_large_roundtrip_and_linearity(ctx, logN):
     assert np.array_equal(fm.get(), shifted)
 
 
+@pytest.mark.parametrize("logN", [17, 18, 19, 20])
+def test_ntt_up_to_the_reference_max_logn(ctx, logN):
+    """core/rlwe/params.go:21 MaxLogN = 20.  logN = 18 runs five column stages in one pass, 19 and 20 take an outer and an inner
+    column pass before the rows (ntt_cols_kernel, NttArgs::cb).  All three modulus classes (double-precision, correction-free
+    integer, [0, 4q) integer), batch of 2, every limb against the oracle; NTTLazy range; round trip; in place."""
+    q, _ = O.GenModuli(logN + 1, [60, 45, 55, 40], [])
+    pr = Pair(ctx, logN, len(q), qmods=q)
+    rng = rng_for(1700 + logN)
+    x = np.stack([uniform_poly(rng, pr.q, pr.N) for _ in range(2)])
+    px, py = pr.up(pr.gQ, x, 2), la.Poly(pr.gQ, len(q), 2)
+    pr.gQ.NTT(px, py)
+    want = np.stack([pr.oQ.NTT(x[b]) for b in range(2)])
+    assert np.array_equal(py.get(), want)
+    pr.gQ.NTTLazy(px, py)
+    lz = py.get()
+    assert np.all(lz < 2 * np.array(pr.q, dtype=np.uint64)[None, :, None])
+    assert np.array_equal(np.stack([pr.oQ.unop("Reduce", lz[b]) for b in range(2)]), want)
+    pz = la.Poly(pr.gQ, len(q), 2)
+    pr.gQ.INTT(py, pz)
+    assert np.array_equal(pz.get(), x)
+    pr.gQ.INTTLazy(py, pz)
+    assert np.array_equal(pr.oQ.unop("Reduce", pz.get()[1]), x[1])
+    pr.gQ.NTT(px, px)  # in place
+    assert np.array_equal(px.get(), want)
+    # non-canonical input words (the reference's NTT takes any word below overflow)
+    big = x[0] + 3 * np.array(pr.q, dtype=np.uint64)[:, None]
+    pb = pr.up(pr.gQ, big)
+    pr.gQ.NTT(pb, pb)
+    assert np.array_equal(pb.get(), want[0])
+    po = la.Poly(pr.gQ, len(q), 2)
+    pr.gQ.DivRoundByLastModulusNTT(py.upload(want), po)
+    assert np.array_equal(po.get()[1, : len(q) - 1], pr.oQ.DivRoundByLastModulusNTT(want[1]))
+
+
 def test_ntt_edge_inputs(ctx):
     """zeros, q-1 everywhere, and non-canonical inputs (the reference NTT accepts any word below overflow)."""
     pr = Pair(ctx, 10, 2)

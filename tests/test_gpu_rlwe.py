@@ -326,6 +326,13 @@ def test_full_size_config5_shape_logN16(ctx):
     _full_size_check(ctx, 16, [60] + [45] * 10 + [60] * 6 + [40] * 8, [61] * 5, 5, False)
 
 
+@pytest.mark.parametrize("logN", [18, 19])
+def test_key_switch_beyond_the_fused_pipelines(ctx, logN):
+    """logN > 17 (the reference accepts up to MaxLogN = 20): no fused basis extension / NTT + MAC there -- GadgetProduct, Rotate,
+    the hoisted forms, MulRelin and Rescale run through the generic passes and must give the same words as everywhere else."""
+    _full_size_check(ctx, logN, [55, 45, 45, 58], [61, 55], 18, True)
+
+
 @pytest.mark.parametrize("pw2", [12, 20, 31])
 def test_base2_gadget_product(ctx, pw2):
     """gadgetProductSinglePAndBitDecompLazy with BaseTwoDecomposition != 0 (core/rlwe/evaluator_gadget_product.go:203-338)."""
