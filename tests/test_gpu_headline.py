@@ -168,6 +168,9 @@ def test_byte_accounting_matches_the_survey_formulas(ctx):
     assert per_entry == (6 * L + 2 * beta * (L + alpha)) * limb * B
     assert per_call == 6 * L * limb * B + 2 * beta * (L + alpha) * limb
     # launch accounting of the same call: the pipeline of DESIGN.md section 4 (12 + 3 limbs, 11 + 0 of them below 2^47)
+    import os
+    if any(k.startswith("HERING_NO_") and v not in ("", "0") for k, v in os.environ.items()):
+        return  # a run of the suite with one of the fusions switched off: other launches, other bytes
     ctx.prof_begin()
     gev.BGVMulRelin(L - 1, t, a, b, rlk, out)
     prof = ctx.prof_end_bytes()
