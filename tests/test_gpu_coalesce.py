@@ -198,3 +198,84 @@ def test_key_switches_coalesce_too(ctx, logN):
     for k in range(K):
         assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.Automorphism(cts[k][:2], gal, ok)), ("harness rotate", k)
 
+
+
+def test_mixed_dependent_chains_from_many_threads(ctx):
+    """Every caller runs a CHAIN of dependent operations on its own ciphertext -- MulRelin (plain, squaring in place), two
+    rotations (one in place: the flagged one-by-one path), GadgetProduct, and direct ring calls (Add) in between, which do not go
+    through the queue -- while eleven others do the same with the steps in another order.  What a step reads was written by a
+    batch launched by ANOTHER thread (the leader of that moment) or by a direct launch of this one: stream order must hold across
+    both.  Final ciphertexts: identical to the same chains run one after the other with the queue switched off, and caller 0's to
+    the oracle's chain."""
+    logN, nq, np_ = 13, 5, 2
+    pr, q, p, N, rng, gev, oev, rlk, orlk = _setup(ctx, logN, nq, np_)
+    beta, lv = (nq + np_ - 1) // np_, nq - 1
+    g = [pow(5, 3, 2 * N), 2 * N - 1]
+    gk, ogk = [], []
+    for _ in g:
+        kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(beta)])
+        kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(beta)])
+        gk.append(gev.NewEvaluationKey(kq, kp)); ogk.append(O.EvaluationKey(kq, kp))
+    K, STEPS = 12, 9
+    ops = ["mul", "rot0", "add", "square_inplace", "gadget", "rot1_inplace", "mul", "add", "rot0"]
+    x0 = [np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(K)]
+    y0 = [np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(K)]
+
+    def run_chain(k, x, y, out):
+        for s in range(STEPS):
+            op = ops[(5 * k + s) % len(ops)]
+            if op == "mul":
+                gev.CKKSMulRelin(lv, x, y, rlk, out); x, out = out, x
+            elif op == "square_inplace":
+                gev.CKKSMulRelin(lv, x, x, rlk, x)
+            elif op == "rot0":
+                gev.Automorphism(lv, x, g[0], gk[0], out); x, out = out, x
+            elif op == "rot1_inplace":
+                gev.Automorphism(lv, x, g[1], gk[1], x)
+            elif op == "gadget":
+                gev.GadgetProduct(lv, x[1], rlk, out)
+                pr.gQ.Add(out[0], x[0], out[0]); x, out = out, x
+            else:
+                pr.gQ.Add(x[0], y[0], x[0]); pr.gQ.Add(x[1], y[1], x[1])
+        return x
+
+    def fresh(k):
+        return ([la.Poly(pr.gQ, nq).upload(c) for c in x0[k]], [la.Poly(pr.gQ, nq).upload(c) for c in y0[k]],
+                [la.Poly(pr.gQ, nq), la.Poly(pr.gQ, nq)])
+
+    gev.SetCoalescing(0, 0)
+    ref = []
+    for k in range(K):
+        ref.append(np.stack([c.get() for c in run_chain(k, *fresh(k))]))
+    gev.SetCoalescing(16, 500)
+    state, res = [fresh(k) for k in range(K)], [None] * K
+
+    def caller(k):
+        def f():
+            res[k] = run_chain(k, *state[k])
+        return f
+
+    _run_threads([caller(k) for k in range(K)])
+    ctx.sync()
+    for k in range(K):
+        assert np.array_equal(np.stack([c.get() for c in res[k]]), ref[k]), k
+    st = gev.CoalescingStats()
+    assert st["launches"] < st["calls"], st
+    # caller 0's chain in the oracle
+    sub = O.Ring(N, q)
+    x, y = x0[0], y0[0]
+    for s in range(STEPS):
+        op = ops[s % len(ops)]
+        if op == "mul":
+            x = oev.CKKSMulRelin(x, y, orlk, True)
+        elif op == "square_inplace":
+            x = oev.CKKSMulRelin(x, x, orlk, True)
+        elif op in ("rot0", "rot1_inplace"):
+            i = 0 if op == "rot0" else 1
+            x = np.stack(oev.Automorphism(x, g[i], ogk[i]))
+        elif op == "gadget":
+            w = oev.GadgetProduct(lv, x[1], orlk)
+            x = np.stack([sub.binop("Add", w[0], x[0]), w[1]])
+        else:
+            x = np.stack([sub.binop("Add", x[0], y[0]), sub.binop("Add", x[1], y[1])])
+    assert np.array_equal(ref[0], x)
