@@ -306,6 +306,8 @@ def _full_size_check(ctx, logN, logq, logp, seed, do_rotate):
         gev.CKKSMulRelin(level, a, b, gevk, o2)
         wantm = oev.CKKSMulRelin(ct[0], ct2, oevk, True)
         assert np.array_equal(np.stack([o.get() for o in o2]), wantm), ("MulRelin", level)
+        if level == 0:
+            continue  # (nothing to rescale into)
         res = [la.Poly(pr.gQ, level), la.Poly(pr.gQ, level)]
         gev.Rescale(level, 1, o2, res)
         assert np.array_equal(np.stack([r.get() for r in res]), oev.Rescale(wantm, 1)), ("Rescale", level)
