@@ -16,10 +16,80 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lattigo_amd as la  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.gpu_common import Pair  # noqa: E402
+from tests.helpers import rng_for, uniform_poly  # noqa: E402
 from tests.test_gpu_rlwe import _full_size_check  # noqa: E402
 
 QBITS = [36, 40, 45, 45, 45, 46, 50, 55, 55, 58, 60]
 PBITS = [45, 55, 55, 60, 61, 61]
+
+
+def api_case(ctx, rng):
+    """One call of the scheme-level entry points with everything drawn at random: operation, level (below the ring's and the key's
+    top), a key that stops below the ring's top level, batch size, and which outputs alias which inputs (the in-place forms the
+    reference allows: MulRelin(ct0, ct1, ct0 / ct1), squaring, Relinearize and Rotate in place).  Every entry against the oracle."""
+    logN = int(rng.choice([11, 12, 13, 13, 14, 15]))
+    nq, np_ = int(rng.integers(2, 9)), int(rng.integers(1, 5))
+    logq = [int(rng.choice([50, 55, 58, 60]))] + [int(rng.choice(QBITS)) for _ in range(nq - 1)]
+    logp = [int(rng.choice(PBITS)) for _ in range(np_)]
+    q, p = O.GenModuli(logN + 1, logq, logp)
+    pr = Pair(ctx, logN, nq, np_, qmods=q, pmods=p)
+    N = pr.N
+    nqk = int(rng.integers(1, nq + 1))                       # the key's Q limbs
+    level = int(rng.integers(0, nqk))
+    B = int(rng.choice([1, 1, 2, 3, 5]))
+    op = str(rng.choice(["bgv", "ckks", "relin", "rotate", "gadget"]))
+    alias = int(rng.integers(0, 4))
+    seed = int(rng.integers(1, 1 << 30))
+    tag = f"api op={op} logN={logN} logq={logq} logp={logp} nqk={nqk} level={level} B={B} alias={alias} seed={seed}"
+    r = rng_for(seed)
+    gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+    beta = O.BaseRNSDecompositionVectorSize(nqk - 1, np_ - 1)
+    kq = np.stack([np.stack([uniform_poly(r, q[:nqk], N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(r, p, N) for _ in range(2)]) for _ in range(beta)])
+    gk, ok = gev.NewEvaluationKey(kq, kp), O.EvaluationKey(kq, kp)
+    Qm, nl = q[: level + 1], level + 1
+    draw = lambda n: np.stack([np.stack([uniform_poly(r, Qm, N) for _ in range(n)]) for _ in range(B)])  # [B][n][limb][N]
+    up = lambda h, n: [la.Poly(pr.gQ, nl, B).upload(np.ascontiguousarray(h[:, k])) for k in range(n)]
+    fresh = lambda: [la.Poly(pr.gQ, nl, B), la.Poly(pr.gQ, nl, B)]
+    T = 65537
+    if op in ("bgv", "ckks"):
+        ha = draw(2)
+        hb = ha if alias == 3 else draw(2)
+        da = up(ha, 2)
+        db = da if alias == 3 else up(hb, 2)
+        out = {0: fresh(), 1: da, 2: db, 3: da}[alias]
+        if op == "bgv":
+            gev.BGVMulRelin(level, T, da, db, gk, out)
+        else:
+            gev.CKKSMulRelin(level, da, db, gk, out)
+        want = [oev.BGVMulRelin(T, ha[b], hb[b], ok, True) if op == "bgv" else oev.CKKSMulRelin(ha[b], hb[b], ok, True) for b in range(B)]
+    elif op == "relin":
+        h = draw(3)
+        d = up(h, 3)
+        out = [d[0] if alias & 1 else la.Poly(pr.gQ, nl, B), d[1] if alias & 2 else la.Poly(pr.gQ, nl, B)]
+        gev.Relinearize(level, d, gk, out)
+        want = [oev.Relinearize(h[b], ok) for b in range(B)]
+    elif op == "rotate":
+        h = draw(2)
+        d = up(h, 2)
+        gal = int(rng.choice([pow(5, int(rng.integers(1, N // 2)), 2 * N), 2 * N - 1]))
+        out = d if alias & 1 else fresh()
+        gev.Automorphism(level, d, gal, gk, out)
+        want = [oev.Automorphism(h[b], gal, ok) for b in range(B)]
+    else:
+        h = draw(1)
+        d = up(h, 1)
+        out = fresh()
+        gev.GadgetProduct(level, d[0], gk, out)
+        want = [oev.GadgetProduct(level, h[b, 0], ok) for b in range(B)]
+    got = [o.get().reshape(B, nl, N) for o in out]  # (a batch-1 polynomial comes back without the batch axis)
+    for b in range(B):
+        for k in range(2):
+            if not np.array_equal(got[k][b], np.asarray(want[b])[k]):
+                raise AssertionError(f"{tag}: entry {b} component {k}")
+    return tag
 
 
 def main():
@@ -27,11 +97,22 @@ def main():
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="logN 13..16, chains of up to 14 limbs, up to 6 special primes")
+    ap.add_argument("--api", action="store_true", help="single scheme-level calls with random level / key level / batch / aliasing")
     a = ap.parse_args()
     rng = np.random.Generator(np.random.PCG64(a.seed))
     ctx = la.Context(0)
     t0, n, bad = time.time(), 0, []
     while time.time() - t0 < a.seconds:
+        if a.api:
+            st = rng.bit_generator.state
+            try:
+                print("ok  ", api_case(ctx, rng), flush=True)
+            except Exception as e:  # noqa: BLE001
+                bad.append(str(e))
+                print("FAIL", e, flush=True)
+                traceback.print_exc()
+            n += 1
+            continue
         if a.big:
             logN = int(rng.choice([13, 14, 15, 15, 16]))
             nq = int(rng.integers(3, 15))
