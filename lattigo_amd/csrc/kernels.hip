@@ -1859,14 +1859,16 @@ hipError_t launch_key_to_f64(const RingDev &r, const uint64_t *key, double *keyd
 // coefficients, block j playing the part of "row" 2^cb + j of the twiddle table exactly as a row does in ntt_rows.
 // grid = (N / 2^LOGA / 256, limbs, batch), block = 256.
 // ------------------------------------------------------------------------------------
-template <int LOGA, bool INV>
+// INNER = false is the outer (or only) pass: its twiddle indices are compile-time constants, i.e. scalar loads.
+template <int LOGA, bool INV, bool INNER = false>
 __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
     constexpr int R = 1 << LOGA;
-    const int N2 = (A.N >> A.cb) >> LOGA;    // stride of a thread's coefficients
+    const int cbits = INNER ? A.cb : 0;
+    const int N2 = (A.N >> cbits) >> LOGA;    // stride of a thread's coefficients
     const int cg = blockIdx.x * blockDim.x + threadIdx.x;
     if (cg >= (A.N >> LOGA)) return;
-    const int blk = cg / N2, c = cg - blk * N2;  // (N2 is a power of two)
-    const int rowtw = (1 << A.cb) + blk;
+    const int blk = INNER ? cg >> __builtin_ctz((unsigned)N2) : 0, c = INNER ? cg & (N2 - 1) : cg;  // (N2 is a power of two)
+    const int rowtw = INNER ? (1 << cbits) + blk : 1;
     const int y = blockIdx.y;
     const int il = A.tab.in_limb[y], ol = A.tab.out_limb[y], mi = A.tab.mod[y];
     const ModConst mc = A.mc[mi];
@@ -2044,6 +2046,12 @@ static hipError_t launch_cols(int loga, dim3 grid, const NttArgs &A, hipStream_t
         { ProfScope ps(INV ? K_NTT_COLS_INV : K_NTT_COLS_FWD, s, 2.0 * A.tab.n * grid.z * (double)A.N * 8.0);                        \
         hipLaunchKernelGGL((ntt_cols_kernel<Av, INV>), grid, dim3(256), 0, s, A); }       \
         break;
+    if (A.cb > 0) {  // inner pass of a two-pass column stage (logN = 19, 20): always four stages
+        if (loga != 4) return hipErrorInvalidValue;
+        ProfScope ps(INV ? K_NTT_COLS_INV : K_NTT_COLS_FWD, s, 2.0 * A.tab.n * grid.z * (double)A.N * 8.0);
+        hipLaunchKernelGGL((ntt_cols_kernel<4, INV, true>), grid, dim3(256), 0, s, A);
+        return hipGetLastError();
+    }
     switch (loga) {
         HE_COLS_CASE(1) HE_COLS_CASE(2) HE_COLS_CASE(3) HE_COLS_CASE(4) HE_COLS_CASE(5)
         default: return hipErrorInvalidValue;
