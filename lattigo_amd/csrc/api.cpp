@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -404,8 +405,11 @@ struct Coalescer {
     std::deque<CoReq *> pending;
     bool leader = false;
     int recent[4] = {0, 0, 0, 0};     // sizes of the last batches: callers that wait for their results come back together
-    int max_batch = 0, window_us = 0;
-    size_t *d_tab = nullptr;  // [6][max_batch] entry offsets; one table is enough (stream order, see launch_tab_fill)
+    // read without the lock by every single-ciphertext call that asks "is the queue on?": atomic.  0 / 1 = off.
+    std::atomic<int> max_batch{0};
+    int window_us = 0;
+    size_t *d_tab = nullptr;  // [6][tab_cap] entry offsets; one table is enough (stream order, see launch_tab_fill)
+    int tab_cap = 0;          // entries per row of d_tab: a batch gathered under an older, larger max_batch is served one by one
     std::deque<hipEvent_t> inflight;  // one event per launched batch, oldest first
     std::vector<hipEvent_t> free_events;
     uint64_t n_calls = 0, n_launches = 0, n_max = 0, n_fallback = 0;  // he_evaluator_coalescing_stats
@@ -415,7 +419,7 @@ struct Coalescer {
 };
 struct Evaluator : Obj {
     std::shared_ptr<BasisExtender> be;
-    std::unique_ptr<Coalescer> co;
+    const std::unique_ptr<Coalescer> co{new Coalescer()};  // always there (off until he_evaluator_set_coalescing): no pointer to race on
     ConstPool pool;
     // automorphism index tables by Galois element, built on first use and kept (the reference caches them the same way:
     // Evaluator.automorphismIndex, core/rlwe/evaluator.go:81-86,:190-205); N x 4 bytes each
@@ -1539,21 +1543,20 @@ int he_evaluator_set_coalescing(he_handle h, int max_batch, int window_us) {
     if (max_batch < 0 || max_batch > 1024 || window_us < 0 || window_us > 100000)
         return fail(HE_EINVAL, "he_evaluator_set_coalescing: max_batch in [0, 1024], window_us in [0, 100000]");
     Ctx *c = ev->be->ctx.get();
-    Scope sc(c);
-    if (ev->co) {
-        std::lock_guard<std::mutex> lk(ev->co->mu);
-        if (!ev->co->pending.empty() || ev->co->leader) return fail(HE_EINVAL, "he_evaluator_set_coalescing: calls are in flight on this evaluator");
-    }
-    if (max_batch <= 1) {  // off: later calls launch directly (the object stays: another thread may be looking at it)
-        if (ev->co) { std::lock_guard<std::mutex> lk(ev->co->mu); ev->co->max_batch = 0; }
+    Scope sc(c);  // (a leader launches its batch under this lock: none is between gathering and launching while we hold it)
+    std::lock_guard<std::mutex> lk(ev->co->mu);
+    if (!ev->co->pending.empty() || ev->co->leader) return fail(HE_EINVAL, "he_evaluator_set_coalescing: calls are in flight on this evaluator");
+    if (max_batch <= 1) {  // off: later calls launch directly
+        ev->co->max_batch = 0;
         return HE_OK;
     }
-    if (!ev->co) ev->co.reset(new Coalescer());
-    std::lock_guard<std::mutex> lk(ev->co->mu);
-    HIP_TRY(hipStreamSynchronize(c->stream));  // launches that read the old table
-    if (ev->co->d_tab) HIP_TRY(hipFree(ev->co->d_tab));
-    ev->co->d_tab = nullptr;
-    HIP_TRY(hipMalloc((void **)&ev->co->d_tab, (size_t)6 * max_batch * sizeof(size_t)));
+    if (max_batch > ev->co->tab_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));  // launches that read the old table
+        if (ev->co->d_tab) HIP_TRY(hipFree(ev->co->d_tab));
+        ev->co->d_tab = nullptr; ev->co->tab_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ev->co->d_tab, (size_t)6 * max_batch * sizeof(size_t)));
+        ev->co->tab_cap = max_batch;
+    }
     ev->co->max_batch = max_batch;
     ev->co->window_us = window_us;
     return HE_OK;
@@ -1562,7 +1565,6 @@ int he_evaluator_coalescing_stats(he_handle h, uint64_t out[4]) {
     GET(ev, Evaluator, h, T_EVAL);
     if (!out) return fail(HE_EINVAL, "he_evaluator_coalescing_stats: null output");
     out[0] = out[1] = out[2] = out[3] = 0;
-    if (!ev->co) return HE_OK;
     std::lock_guard<std::mutex> lk(ev->co->mu);
     out[0] = ev->co->n_calls; out[1] = ev->co->n_launches; out[2] = ev->co->n_max; out[3] = ev->co->n_fallback;
     return HE_OK;
@@ -2594,7 +2596,7 @@ int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he
     TRY(check_be_poly(*out0, be, levelQ + 1, "he_gadget_product"));
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product"));
     if (out0->batch != cx->batch || out1->batch != cx->batch) return fail(HE_EINVAL, "he_gadget_product: batch mismatch");
-    if (cx->batch == 1 && ev->co && ev->co->max_batch > 1 && !be.ctx->capturing)
+    if (cx->batch == 1 && ev->co->max_batch.load(std::memory_order_relaxed) > 1 && !be.ctx->capturing)
         return co_submit_keyswitch(ev, CO_GADGET_PRODUCT, levelQ, 0, k, {cx}, out0, out1);
     Scope sc(be.ctx.get());
     be.ctx->acct(3.0 * (levelQ + 1), key_limbs(*k, levelQ), cx->batch, be.Q->N);  // GadgetProduct: 3 L + 2 beta (L + alpha)
@@ -2636,7 +2638,7 @@ int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_
         TRY(check_be_poly(*p, be, level + 1, "he_relinearize"));
         if (p->batch != in0->batch) return fail(HE_EINVAL, "he_relinearize: batch mismatch");
     }
-    if (in0->batch == 1 && ev->co && ev->co->max_batch > 1 && !be.ctx->capturing)
+    if (in0->batch == 1 && ev->co->max_batch.load(std::memory_order_relaxed) > 1 && !be.ctx->capturing)
         return co_submit_keyswitch(ev, CO_RELINEARIZE, level, 0, k, {in0, in1, in2}, out0, out1);
     Scope sc(be.ctx.get());
     const int B = in0->batch, N = be.Q->N;
@@ -2735,7 +2737,7 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     if (dec && k->pw2) return fail(HE_EINVAL, "%s: method is unsupported for BaseTwoDecomposition != 0", who);
     if (dec) TRY(check_decomp(*ev, *dec, level, k->nPk - 1, who));
     // a single-ciphertext Automorphism on an evaluator with a submission queue joins it (he_evaluator_set_coalescing)
-    if (in1 && B == 1 && ev->co && ev->co->max_batch > 1 && !be.ctx->capturing)
+    if (in1 && B == 1 && ev->co->max_batch.load(std::memory_order_relaxed) > 1 && !be.ctx->capturing)
         return co_submit_keyswitch(ev, CO_AUTOMORPHISM, level, gal, k, {in0, in1}, out0, out1);
     Scope sc(be.ctx.get());
     View in1v{nullptr, 0};
@@ -3049,6 +3051,7 @@ int co_run(Evaluator &ev, Coalescer &c, const std::vector<CoReq *> &batch, hipEv
     }
     const std::shared_ptr<Poly> CoReq::*slot[6] = {&CoReq::a0, &CoReq::a1, &CoReq::b0, &CoReq::b1, &CoReq::o0, &CoReq::o1};
     int rc = HE_OK;
+    if (B > c.tab_cap) tables = false;  // (gathered under a larger max_batch than the table was sized for)
     if (B == 1 || !tables) {
         // one entry, or a shape whose pipeline has launches without entry tables (unfused ModDown): one call per request
         if (B > 1) c.n_fallback += (uint64_t)B;
@@ -3085,8 +3088,10 @@ void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoRe
         // (callers that wait for their result come back together, as fast as the OS schedules them), or 8 window_us after the
         // oldest request arrived.  No window at all for a lone caller (crowd == 0).
         const int hint = std::max(std::max(c.recent[0], c.recent[1]), std::max(c.recent[2], c.recent[3]));
+        // (at least one: a request that passed the "queue on?" test just before the queue was switched off is still served)
+        const int max_batch = std::max(1, c.max_batch.load(std::memory_order_relaxed));
         for (;;) {
-            if ((int)c.pending.size() >= c.max_batch) break;
+            if ((int)c.pending.size() >= max_batch) break;
             const bool busy = co_inflight(c) >= 2;
             const auto now = clock::now();
             const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.front()->arrived).count();
@@ -3103,7 +3108,7 @@ void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoRe
         }
         std::vector<CoReq *> batch;
         const CoReq &head = *c.pending.front();
-        for (auto it = c.pending.begin(); it != c.pending.end() && (int)batch.size() < c.max_batch;) {
+        for (auto it = c.pending.begin(); it != c.pending.end() && (int)batch.size() < max_batch;) {
             if ((*it)->same_key(head)) { batch.push_back(*it); it = c.pending.erase(it); }
             else ++it;
         }
@@ -3206,7 +3211,7 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
         for (Poly *in : {a0.get(), a1.get(), b0.get(), b1.get()}) alias = alias || o->d == in->d;
     // a single-ciphertext MulRelin on an evaluator with a submission queue joins it (not while the context records a graph:
     // a captured sequence must be this thread's own launches)
-    if (k && B == 1 && ev->co && ev->co->max_batch > 1 && !be.ctx->capturing) {
+    if (k && B == 1 && ev->co->max_batch.load(std::memory_order_relaxed) > 1 && !be.ctx->capturing) {
         CoReq r;
         r.level = level; r.bgv = bgv; r.t = bgv ? t : 0; r.alias = alias; r.key = k;
         r.a0 = a0; r.a1 = a1; r.b0 = b0; r.b1 = b1; r.o0 = out0; r.o1 = out1;
