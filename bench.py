@@ -860,6 +860,21 @@ def main():
         except la.HeringError as e:
             line["concurrent_b1"] = {"error": str(e)}
             problems.append(f"concurrent_b1 failed: {e}")
+        # the same shape from a COMPILED host through the public interface only (include/hering.hpp; tests/cpp/run_parallel.cpp:
+        # std::thread per caller, its own process and context): what a Go caller of the cgo package would see
+        exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "cpp", "run_parallel")
+        if args.workload == "c3" and os.path.exists(exe) and "error" not in line["concurrent_b1"]:
+            import subprocess
+            runs = []
+            for sync_each in (0, 1):
+                try:
+                    r = subprocess.run([exe, "64", "96", str(sync_each), "1"], capture_output=True, text=True, timeout=120)
+                    runs.append(json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]})
+                except Exception as e:  # noqa: BLE001 -- a missing / stale binary must not cost the bench line
+                    runs.append({"error": str(e)})
+            line["concurrent_b1"]["compiled_host"] = runs
+            if any(x.get("verified") is False for x in runs):
+                problems.append("concurrent_b1.compiled_host: a caller's output differs from the oracle")
     if not args.no_ntt:
         line["ntt"] = ntt_rates(la, ctx)
         line["ntt_limb_per_s"] = line["ntt"]["logN15_L12"]["limb_ntt_per_s"]

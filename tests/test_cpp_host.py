@@ -51,3 +51,16 @@ def test_cpp_parity_program():
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_compiled_host_concurrent_callers():
+    """tests/cpp/run_parallel.cpp: std::thread per ciphertext over ONE hering::Evaluator at the headline shape (the reference's
+    b.RunParallel pattern from a compiled host, public interface only); caller 0's result equals the oracle's."""
+    import json
+    _build()
+    for sync_each in ("0", "1"):
+        r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "run_parallel"), "8", "6", sync_each, "1"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["verified"] is True and d["K"] == 8 and d["ops_per_s"] > 0
