@@ -1020,3 +1020,9 @@ def test_random_scheme_level_calls(ctx):
     for _ in range(150):
         seen.add(fz.api_case(ctx, rng).split()[1])
     assert seen == {"op=bgv", "op=ckks", "op=relin", "op=rotate", "op=gadget"}
+    # the ring-level generator of the same tool (every coefficient-wise formula, transforms, rescales, automorphisms; logN 4..16, level
+    # below the top, batch, in place): 400 draws (39 159 on the GPU by the tool itself)
+    ops = set()
+    for _ in range(400):
+        ops.add(fz.ring_case(ctx, rng).split()[1])
+    assert len(ops) >= 30, ops

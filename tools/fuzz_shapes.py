@@ -92,21 +92,106 @@ def api_case(ctx, rng):
     return tag
 
 
+BIN = ["Add", "AddLazy", "Sub", "SubLazy", "MulCoeffsBarrett", "MulCoeffsBarrettLazy", "MulCoeffsBarrettThenAdd",
+       "MulCoeffsBarrettThenAddLazy", "MulCoeffsMontgomery", "MulCoeffsMontgomeryLazy", "MulCoeffsMontgomeryLazyThenNeg",
+       "MulCoeffsMontgomeryThenAdd", "MulCoeffsMontgomeryThenAddLazy", "MulCoeffsMontgomeryLazyThenAddLazy",
+       "MulCoeffsMontgomeryThenSub", "MulCoeffsMontgomeryThenSubLazy", "MulCoeffsMontgomeryLazyThenSubLazy"]
+UN = ["Neg", "Reduce", "ReduceLazy", "MForm", "MFormLazy", "IMForm"]
+SCAL = ["AddScalar", "SubScalar", "MulScalar", "MulScalarThenAdd", "MulScalarThenSub"]
+DIV = ["DivRoundByLastModulusNTT", "DivRoundByLastModulus", "DivFloorByLastModulusNTT", "DivFloorByLastModulus"]
+
+
+def ring_case(ctx, rng):
+    """One ring-level call with everything drawn at random: degree (logN 4..16), chain, level below the ring's top, batch size, the
+    operation (every coefficient-wise formula, the transforms, the rescales, the automorphisms) and whether the output is one of
+    the inputs.  Word for word against the oracle (NTTLazy / INTTLazy after Reduce)."""
+    logN = int(rng.integers(4, 17))
+    nq = int(rng.integers(1, 9 if logN > 13 else 13))
+    logq = [int(rng.choice(QBITS + [61])) for _ in range(nq)]
+    q, _ = O.GenModuli(logN + 1, logq, [])
+    pr = Pair(ctx, logN, nq, qmods=q)
+    N = pr.N
+    level = int(rng.integers(0, nq))
+    B = int(rng.choice([1, 1, 2, 3, 7]))
+    kind = str(rng.choice(["bin", "bin", "un", "scal", "ntt", "div", "auto"]))
+    inplace = int(rng.integers(0, 3))
+    seed = int(rng.integers(1, 1 << 30))
+    r = rng_for(seed)
+    Qm, nl = q[: level + 1], level + 1
+    draw = lambda: np.stack([uniform_poly(r, Qm, N) for _ in range(B)])
+    up = lambda h: la.Poly(pr.gQ, nl, B).upload(h)
+    g, o = pr.gQ.AtLevel(level), O.Ring(N, Qm)
+    a, b, c = draw(), draw(), draw()
+    pa, pb, pc = up(a), up(b), up(c)
+    each = lambda f: np.stack([f(i) for i in range(B)])
+    name = kind
+    if kind == "bin":
+        name = str(rng.choice(BIN))
+        out = {0: pc, 1: pa, 2: pb}[inplace]
+        init = {0: c, 1: a, 2: b}[inplace]
+        g.binop(name, pa, pb, out)
+        want = each(lambda i: o.binop(name, a[i], b[i], init[i]))
+    elif kind == "un":
+        name = str(rng.choice(UN))
+        src = a + (np.uint64(3) * np.array(Qm, dtype=np.uint64)[None, :, None] if "Reduce" in name else np.uint64(0))
+        pa = up(src)
+        out = pa if inplace else pc
+        g.unop(name, pa, out)
+        want = each(lambda i: o.unop(name, src[i]))
+    elif kind == "scal":
+        name = str(rng.choice(SCAL))
+        scalar = int(rng.integers(0, 1 << 62))
+        out = pc
+        g.scalarop(name, pa, scalar, out)
+        want = each(lambda i: o.scalarop(name, a[i], scalar, c[i]))
+    elif kind == "ntt":
+        name = str(rng.choice(["NTT", "INTT", "NTTLazy", "INTTLazy"]))
+        out = pa if inplace else pc
+        getattr(g, name)(pa, out)
+        want = each(lambda i: getattr(o, name.replace("Lazy", ""))(a[i]))
+        got = out.get().reshape(B, nl, N)
+        got = each(lambda i: o.unop("Reduce", got[i]))
+        if not np.array_equal(got, want):
+            raise AssertionError(f"ring op={name} logN={logN} logq={logq} level={level} B={B} inplace={inplace} seed={seed}")
+        return f"ring op={name} logN={logN} nq={nq} level={level} B={B}"
+    elif kind == "div":
+        if level == 0:
+            return "ring op=div(level 0: skipped)"
+        name = str(rng.choice(DIV))
+        out = pa if inplace else la.Poly(pr.gQ, nl, B)
+        getattr(g, name)(pa, out)
+        want = each(lambda i: getattr(o, name)(a[i]))
+        got = out.get().reshape(B, nl, N)[:, :level]
+        if not np.array_equal(got, want):
+            raise AssertionError(f"ring op={name} logN={logN} logq={logq} level={level} B={B} inplace={inplace} seed={seed}")
+        return f"ring op={name} logN={logN} nq={nq} level={level} B={B}"
+    else:
+        gal = int(rng.choice([pow(5, int(rng.integers(1, max(2, N // 2))), 2 * N), 2 * N - 1]))
+        name = str(rng.choice(["AutomorphismNTT", "Automorphism"]))
+        out = pc
+        getattr(g, name)(pa, gal, out)
+        want = each(lambda i: getattr(o, name)(a[i], gal))
+    got = out.get().reshape(B, nl, N)
+    if not np.array_equal(got, want):
+        raise AssertionError(f"ring op={name} logN={logN} logq={logq} level={level} B={B} inplace={inplace} seed={seed}")
+    return f"ring op={name} logN={logN} nq={nq} level={level} B={B}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="logN 13..16, chains of up to 14 limbs, up to 6 special primes")
     ap.add_argument("--api", action="store_true", help="single scheme-level calls with random level / key level / batch / aliasing")
+    ap.add_argument("--ring", action="store_true", help="single ring-level calls (coefficient-wise formulas, transforms, rescales, automorphisms)")
     a = ap.parse_args()
     rng = np.random.Generator(np.random.PCG64(a.seed))
     ctx = la.Context(0)
     t0, n, bad = time.time(), 0, []
     while time.time() - t0 < a.seconds:
-        if a.api:
-            st = rng.bit_generator.state
+        if a.api or a.ring:
             try:
-                print("ok  ", api_case(ctx, rng), flush=True)
+                print("ok  ", (api_case if a.api else ring_case)(ctx, rng), flush=True)
             except Exception as e:  # noqa: BLE001
                 bad.append(str(e))
                 print("FAIL", e, flush=True)
