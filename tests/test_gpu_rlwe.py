@@ -1026,3 +1026,7 @@ def test_random_scheme_level_calls(ctx):
     for _ in range(400):
         ops.add(fz.ring_case(ctx, rng).split()[1])
     assert len(ops) >= 30, ops
+    # basis extension entry points, the evaluator's fused ModDownQPtoQNTT and DecomposeNTT at random (levelQ, levelP): 200 draws
+    # (20 370 by the tool)
+    for _ in range(200):
+        fz.be_case(ctx, rng)

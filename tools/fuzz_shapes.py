@@ -177,21 +177,90 @@ def ring_case(ctx, rng):
     return f"ring op={name} logN={logN} nq={nq} level={level} B={B}"
 
 
+def be_case(ctx, rng):
+    """ring.BasisExtender's five entry points, the evaluator's fused ModDownQPtoQNTT and DecomposeNTT at random (levelQ, levelP),
+    batch and modulus classes: the word-exact ModUp representatives, the float64 step, partial last digits."""
+    logN = int(rng.integers(8, 16))
+    nq, np_ = int(rng.integers(1, 13 if logN < 14 else 9)), int(rng.integers(1, 7))
+    logq = [int(rng.choice([50, 55, 58, 60]))] + [int(rng.choice(QBITS)) for _ in range(nq - 1)]
+    logp = [int(rng.choice(PBITS)) for _ in range(np_)]
+    q, p = O.GenModuli(logN + 1, logq, logp)
+    pr = Pair(ctx, logN, nq, np_, qmods=q, pmods=p)
+    N = pr.N
+    levelQ, levelP = int(rng.integers(0, nq)), int(rng.integers(0, np_))
+    B = int(rng.choice([1, 2, 3, 5]))
+    op = str(rng.choice(["ModUpQtoP", "ModUpPtoQ", "ModDownQPtoQ", "ModDownQPtoQNTT", "ModDownQPtoP", "EvalModDownQPtoQNTT", "DecomposeNTT"]))
+    seed = int(rng.integers(1, 1 << 30))
+    tag = f"be op={op} logN={logN} logq={logq} logp={logp} levelQ={levelQ} levelP={levelP} B={B} seed={seed}"
+    r = rng_for(seed)
+    Qm, Pm = q[: levelQ + 1], p[: levelP + 1]
+    xq = np.stack([uniform_poly(r, Qm, N) for _ in range(B)])
+    xp = np.stack([uniform_poly(r, Pm, N) for _ in range(B)])
+    pq, pp = la.Poly(pr.gQ, levelQ + 1, B).upload(xq), la.Poly(pr.gP, levelP + 1, B).upload(xp)
+    obe = O.BasisExtender(pr.oQ, pr.oP)
+    each = lambda f: np.stack([f(i) for i in range(B)])
+    if op in ("EvalModDownQPtoQNTT", "DecomposeNTT"):
+        gev, oev = la.Evaluator(pr.gQ, pr.gP), O.Evaluator(pr.oQ, pr.oP)
+        if op == "EvalModDownQPtoQNTT":
+            out = la.Poly(pr.gQ, levelQ + 1, B)
+            gev.ModDownQPtoQNTT(levelQ, levelP, pq, pp, out)
+            want, got = each(lambda i: obe.ModDownQPtoQNTT(levelQ, levelP, xq[i], xp[i])), out.get().reshape(B, levelQ + 1, N)
+        else:
+            levelP = np_ - 1  # (the hoisting buffer is filled at the evaluator's top P level, as the reference's callers do)
+            is_ntt = bool(rng.integers(0, 2))
+            dec = la.Decomposition(gev, B)
+            gev.DecomposeNTT(levelQ, levelP, levelP + 1, pq, is_ntt, dec)
+            beta = O.BaseRNSDecompositionVectorSize(levelQ, levelP)
+            for i in range(B):
+                dq, dp = oev.DecomposeNTT(levelQ, levelP, levelP + 1, xq[i], is_ntt)
+                for d in range(beta):
+                    for l in range(levelQ + 1):
+                        if not np.array_equal(dec.limb(i, d, False, l), dq[d, l]):
+                            raise AssertionError(f"{tag} ntt={is_ntt}: entry {i} digit {d} Q limb {l}")
+                    for l in range(levelP + 1):
+                        if not np.array_equal(dec.limb(i, d, True, l), dp[d, l]):
+                            raise AssertionError(f"{tag} ntt={is_ntt}: entry {i} digit {d} P limb {l}")
+            return tag
+    else:
+        gbe = la.BasisExtender(pr.gQ, pr.gP)
+        if op == "ModUpQtoP":
+            out = la.Poly(pr.gP, levelP + 1, B)
+            gbe.ModUpQtoP(levelQ, levelP, pq, out)
+            want, nl = each(lambda i: obe.ModUpQtoP(levelQ, levelP, xq[i])), levelP + 1
+        elif op == "ModUpPtoQ":
+            out = la.Poly(pr.gQ, levelQ + 1, B)
+            gbe.ModUpPtoQ(levelP, levelQ, pp, out)
+            want, nl = each(lambda i: obe.ModUpPtoQ(levelP, levelQ, xp[i])), levelQ + 1
+        elif op == "ModDownQPtoP":
+            out = la.Poly(pr.gP, levelP + 1, B)
+            gbe.ModDownQPtoP(levelQ, levelP, pq, pp, out)
+            want, nl = each(lambda i: obe.ModDownQPtoP(levelQ, levelP, xq[i], xp[i])), levelP + 1
+        else:
+            out = la.Poly(pr.gQ, levelQ + 1, B)
+            getattr(gbe, op)(levelQ, levelP, pq, pp, out)
+            want, nl = each(lambda i: getattr(obe, op)(levelQ, levelP, xq[i], xp[i])), levelQ + 1
+        got = out.get().reshape(B, nl, N)
+    if not np.array_equal(got, want):
+        raise AssertionError(tag)
+    return tag
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="logN 13..16, chains of up to 14 limbs, up to 6 special primes")
     ap.add_argument("--api", action="store_true", help="single scheme-level calls with random level / key level / batch / aliasing")
+    ap.add_argument("--be", action="store_true", help="basis extension entry points and DecomposeNTT at random levels")
     ap.add_argument("--ring", action="store_true", help="single ring-level calls (coefficient-wise formulas, transforms, rescales, automorphisms)")
     a = ap.parse_args()
     rng = np.random.Generator(np.random.PCG64(a.seed))
     ctx = la.Context(0)
     t0, n, bad = time.time(), 0, []
     while time.time() - t0 < a.seconds:
-        if a.api or a.ring:
+        if a.api or a.ring or a.be:
             try:
-                print("ok  ", (api_case if a.api else ring_case)(ctx, rng), flush=True)
+                print("ok  ", (api_case if a.api else ring_case if a.ring else be_case)(ctx, rng), flush=True)
             except Exception as e:  # noqa: BLE001
                 bad.append(str(e))
                 print("FAIL", e, flush=True)
