@@ -16,8 +16,8 @@ import sys
 
 FAMILY = [(r"ntt_mac_f64(_dma)?_kernel", "ntt_mac_f64"), (r"ntt_rows_f64_kernel<\d+, false", "ntt_rows_fwd_f64"),
           (r"ntt_rows_f64_kernel<\d+, true", "ntt_rows_inv_f64"), (r"ntt_rows_kernel<\d+, false", "ntt_rows_fwd"),
-          (r"ntt_rows_kernel<\d+, true", "ntt_rows_inv"), (r"ntt_cols_kernel<\d+, false>", "ntt_cols_fwd"),
-          (r"ntt_cols_kernel<\d+, true>", "ntt_cols_inv"), (r"modup_fused_kernel|modup_kernel", "modup"), (r"center_copy", "center_copy"),
+          (r"ntt_rows_kernel<\d+, true", "ntt_rows_inv"), (r"ntt_cols_kernel<\d+, false\b", "ntt_cols_fwd"),
+          (r"ntt_cols_kernel<\d+, true\b", "ntt_cols_inv"), (r"modup_fused_kernel|modup_kernel", "modup"), (r"center_copy", "center_copy"),
           (r"ks_inner_kernel", "ks_inner"), (r"tensor_kernel", "tensor"), (r"ew_kernel", "ew"), (r"gather_kernel|shift_kernel", "gather"),
           (r"diag_mac_kernel", "diag_mac"), (r"build_index", "build_index"), (r"automorphism_coeff", "automorphism_coeff"),
           (r"mask_spread", "mask_spread"), (r"ci_fold|ci_ref", "ci_fold"), (r"key_to_f64", "key_to_f64")]
