@@ -30,6 +30,9 @@ def fam(name):
     return None
 
 
+UNMATCHED = collections.Counter()  # library kernels (namespace he::) no pattern claims: a renamed kernel must not vanish from the sums
+
+
 def load(path):
     d = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in csv.DictReader(open(path)):
@@ -38,6 +41,8 @@ def load(path):
             d[f][0] += 1
             d[f][1] += float(r["Counter_Value"])
             d[f][2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        elif "he::" in r["Kernel_Name"] and not re.search(r"tab_fill|probe", r["Kernel_Name"]):
+            UNMATCHED[re.sub(r"\(.*$", "", r["Kernel_Name"])] += 1
     return d
 
 
@@ -63,4 +68,7 @@ if steps:
     out["steps_profiled"] = steps
     out["hbm_bytes_per_step"] = total / steps
     out["hbm_MiB_per_unit"] = total / steps / batch / 2**20
+if UNMATCHED:
+    out["unmatched_kernels"] = dict(UNMATCHED)
+    sys.stderr.write(f"pmc_summary: kernels of the library that no family pattern matches (their bytes are NOT in the sums): {dict(UNMATCHED)}\n")
 print(json.dumps(out, indent=1))
