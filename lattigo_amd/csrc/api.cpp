@@ -3468,7 +3468,10 @@ int he_rccl_comm_create(he_handle hctx, const uint8_t *id, int rank, int world, 
     m->ctx = c; m->rank = rank; m->world = world;
     rccl_id_t u;
     memcpy(u.internal, id, sizeof u.internal);
-    Scope sc(c.get());  // (selects the context's device: the communicator is bound to it)
+    // The communicator is bound to the device current at the call; the context's lock is NOT held across the rendezvous: a peer
+    // that never arrives must cost the caller this thread (lattigo_amd/dist.py gives it a deadline), not every later call on the
+    // context.
+    HIP_TRY(hipSetDevice(c->dev));
     RCCL_TRY(rccl().CommInitRank(&m->comm, world, u, rank));
     *out = reg(m);
     return HE_OK;

@@ -94,12 +94,43 @@ class ControlPlane:
             if blob[0] == 0:
                 raise HeringError(-3, "rank 0 could not draw an RCCL id")
             ident = (C.c_uint8 * 128)(*blob[1:])
-            h = H()
-            check(load().he_rccl_comm_create(ctx.h, ident, self.rank, self.world, C.byref(h)))
-            self._rccl = (ctx, h.value)
+            # the rendezvous itself, with a deadline (HERING_RCCL_TIMEOUT seconds, default 120): a peer that never joins -- a rank
+            # on a broken link, an interface RCCL cannot bootstrap over -- would otherwise hang the whole job inside
+            # ncclCommInitRank.  It runs on a helper thread that is abandoned on timeout (the library does not hold the context's
+            # lock across the rendezvous); the outcome is agreed on, so that either every rank has a communicator or none uses one.
+            joined = self._rccl_join(ctx, ident, float(os.environ.get("HERING_RCCL_TIMEOUT", "120")))
+            if self.sum_over_ranks(1.0 if joined is not None else 0.0) != self.world:
+                self._rccl_abandoned = self._rccl_abandoned or self._rccl_thread_stuck
+                if joined is not None:
+                    load().he_rccl_comm_destroy(joined)
+                raise HeringError(-3, "the RCCL rendezvous did not complete on every rank within the deadline")
+            self._rccl = (ctx, joined)
         if self._rccl[0] is not ctx:
             raise RuntimeError("the RCCL communicator of this process belongs to another context")
         return self._rccl[1]
+
+    _rccl_abandoned = False     # a helper thread of this process is still inside ncclCommInitRank: leave with os._exit (close())
+    _rccl_thread_stuck = False  # ... as of the last _rccl_join
+
+    def _rccl_join(self, ctx, ident, timeout_s: float):
+        """he_rccl_comm_create on a helper thread; the communicator handle, or None when the call failed or did not return in time"""
+        import ctypes as C
+        import threading
+        from ._lib import H, load
+        box = {}
+
+        def work():
+            h = H()
+            box["rc"] = load().he_rccl_comm_create(ctx.h, ident, self.rank, self.world, C.byref(h))
+            box["h"] = h.value
+
+        t = threading.Thread(target=work, daemon=True, name="hering-rccl-rendezvous")
+        t.start()
+        t.join(timeout_s)
+        self._rccl_thread_stuck = t.is_alive()
+        if t.is_alive() or box.get("rc") != 0:
+            return None
+        return box["h"]
 
     def ReplicateEvaluationKey(self, evaluator, key=None, src: int = 0, transport: str = "rccl"):
         """Rank src holds `key` (rlwe.EvaluationKey); every rank returns a device-resident copy of it.  transport "rccl":
@@ -194,3 +225,23 @@ class ControlPlane:
             self._dist.barrier()
             self._dist.destroy_process_group()
             self._dist = None
+        if self._rccl_abandoned:
+            # a thread of this process never came back from the RCCL rendezvous: the interpreter's orderly shutdown (and RCCL's own
+            # exit handlers) could wait for it for ever.  Leave through os._exit when the program ends -- with the status it ends with.
+            import atexit
+            import sys
+            status = {"code": 0}
+            orig_exit = sys.exit
+
+            def exit_recording(code=0):
+                status["code"] = code if isinstance(code, int) else (0 if code is None else 1)
+                orig_exit(code)
+
+            sys.exit = exit_recording
+
+            def hard_exit():
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(status["code"])
+
+            atexit.register(hard_exit)

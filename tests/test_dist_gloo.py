@@ -74,3 +74,60 @@ def test_digit_shares_partition_the_decomposition():
             assert [d for s in shares for d in s] == list(range(beta))
             sizes = [len(s) for s in shares]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_rccl_rendezvous_has_a_deadline(monkeypatch):
+    """The RCCL communicator is created on a helper thread with a deadline: a rendezvous that never completes (a peer that does not
+    join) must end as an agreed failure -- the callers then fall back to the host transport -- instead of hanging the job, a fast
+    failure must not be mistaken for a stuck thread, and a normal return hands the communicator over."""
+    import threading
+    import time
+
+    import lattigo_amd._lib as L
+    from lattigo_amd.dist import ControlPlane
+
+    class FakeLib:
+        def __init__(self, mode):
+            self.mode, self.gate = mode, threading.Event()
+
+        def he_rccl_available(self, yes):
+            yes._obj.value = 1
+            return 0
+
+        def he_rccl_unique_id(self, ident):
+            return 0
+
+        def he_rccl_comm_create(self, ctx, ident, rank, world, h):
+            if self.mode == "hang":
+                self.gate.wait(20)
+                return -3
+            if self.mode == "fail":
+                return -3
+            h._obj.value = 4242
+            return 0
+
+        def he_rccl_comm_destroy(self, h):
+            return 0
+
+        def he_last_error(self):
+            return b"fake"
+
+    class Ctx:
+        h = 1
+
+    monkeypatch.setenv("HERING_RCCL_TIMEOUT", "0.3")
+    for mode in ("hang", "fail", "ok"):
+        fake = FakeLib(mode)
+        monkeypatch.setattr(L, "load", lambda fake=fake: fake)
+        cp = ControlPlane()
+        assert cp.world == 1
+        t0 = time.time()
+        if mode == "ok":
+            assert cp._rccl_comm(Ctx) == 4242 and not cp._rccl_abandoned
+        else:
+            with pytest.raises(L.HeringError, match="did not complete on every rank"):
+                cp._rccl_comm(Ctx)
+            assert cp._rccl_abandoned == (mode == "hang")
+            assert cp._rccl is None
+        assert time.time() - t0 < 5
+        fake.gate.set()
