@@ -67,6 +67,47 @@ public:
         check(he_device_count(&n));
         return n;
     }
+    static std::string Version() { return he_version(); }
+    // CU count, LDS bytes per CU, clock kHz, HBM bytes
+    std::array<uint64_t, 4> DeviceInfo() const {
+        std::array<uint64_t, 4> v{};
+        check(he_device_info(h(), v.data()));
+        return v;
+    }
+    // HIP-event stopwatch on the context's stream
+    void TimerStart() const { check(he_timer_start(h())); }
+    float TimerStop() const {
+        float ms = 0;
+        check(he_timer_stop(h(), &ms));
+        return ms;
+    }
+};
+
+// A captured sequence of calls on a Context (he_graph_*): Capture(f) records what f enqueues; Launch replays it as one enqueue.
+// f must have run once before (plans, scratch) and must not upload, download or Sync; the polynomials it touches must outlive the graph.
+class Graph {
+    detail::Ref r_;
+
+public:
+    template <class F>
+    Graph(const Context &ctx, F &&f) {
+        check(he_graph_begin(ctx.h()));
+        he_handle g = 0;
+        try {
+            f();
+        } catch (...) {
+            if (he_graph_end(ctx.h(), &g) == HE_OK) he_graph_destroy(g);  // leave the context usable
+            throw;
+        }
+        check(he_graph_end(ctx.h(), &g));
+        r_ = detail::own(g, he_graph_destroy);
+    }
+    void Launch() const { check(he_graph_launch(r_->h)); }
+    int Nodes() const {
+        int n = 0;
+        check(he_graph_nodes(r_->h, &n));
+        return n;
+    }
 };
 
 class Ring;
@@ -96,6 +137,40 @@ public:
     }
     void CopyLvl(int level, const Poly &src) { check(he_poly_copy(h(), src.h(), level)); }  // ring.Poly.CopyLvl
     void Zero() { check(he_poly_zero(h())); }
+    // one row of Coeffs [][]uint64: limb `limb` of batch entry b (N words)
+    void UploadLimb(int b, int limb, const uint64_t *src) { check(he_poly_upload_limb(h(), b, limb, src)); }
+    void DownloadLimb(int b, int limb, uint64_t *dst) const { check(he_poly_download_limb(h(), b, limb, dst)); }
+    // limbs 0..level of entries [srcB0, srcB0 + nb) of src -> entries [dstB0, dstB0 + nb) of this batch
+    void CopyBatch(int dstB0, const Poly &src, int srcB0, int nb, int level) { check(he_poly_copy_batch(h(), dstB0, src.h(), srcB0, nb, level)); }
+    // what the library itself says about the handle (limbs, batch, N)
+    std::array<int, 3> Shape() const {
+        std::array<int, 3> v{};
+        check(he_poly_shape(h(), &v[0], &v[1], &v[2]));
+        return v;
+    }
+    // device storage for transports that move device memory themselves (drains the context's stream first)
+    std::pair<void *, size_t> DeviceBuffer() const {
+        void *p = nullptr;
+        size_t n = 0;
+        check(he_poly_device_buffer(h(), &p, &n));
+        return {p, n};
+    }
+};
+
+// the table ring.AutomorphismNTTIndex returns (ring/automorphism.go:12-34), on the device
+class AutomorphismIndex {
+    detail::Ref r_;
+    int n_ = 0;
+    friend class Ring;
+
+public:
+    AutomorphismIndex() = default;
+    he_handle h() const { return r_ ? r_->h : 0; }
+    std::vector<uint64_t> Download() const {
+        std::vector<uint64_t> v((size_t)n_);
+        check(he_automorphism_index_download(h(), v.data()));
+        return v;
+    }
 };
 
 enum class RingType { Standard = 0, ConjugateInvariant = 1 };  // ring/ring.go:24-27
@@ -113,7 +188,8 @@ public:
     Ring(const Context &ctx, int logN, std::vector<uint64_t> moduli, RingType type = RingType::Standard)
         : ctx_(ctx), moduli_(std::move(moduli)), logN_(logN), level_((int)moduli_.size() - 1), type_(type) {
         he_handle h = 0;
-        check(he_ring_create_type(ctx.h(), logN, (int)type, moduli_.data(), (int)moduli_.size(), &h));
+        if (type == RingType::Standard) check(he_ring_create(ctx.h(), logN, moduli_.data(), (int)moduli_.size(), &h));  // ring.NewRing
+        else check(he_ring_create_type(ctx.h(), logN, (int)type, moduli_.data(), (int)moduli_.size(), &h));
         r_ = detail::own(h, he_ring_destroy);
     }
     he_handle h() const { return r_->h; }
@@ -153,26 +229,28 @@ public:
     void INTTLazy(const Poly &p1, Poly &p2) const { check(he_intt_lazy(h(), level_, p1.h(), p2.h())); }
 
     // ring/operations.go
-    void Add(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_ADD, p1, p2, p3); }
+    void Add(const Poly &p1, const Poly &p2, Poly &p3) const { check(he_add(h(), level_, p1.h(), p2.h(), p3.h())); }
     void AddLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_ADD_LAZY, p1, p2, p3); }
-    void Sub(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_SUB, p1, p2, p3); }
+    void Sub(const Poly &p1, const Poly &p2, Poly &p3) const { check(he_sub(h(), level_, p1.h(), p2.h(), p3.h())); }
     void SubLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_SUB_LAZY, p1, p2, p3); }
-    void Neg(const Poly &p1, Poly &p2) const { un(HE_NEG, p1, p2); }
-    void Reduce(const Poly &p1, Poly &p2) const { un(HE_REDUCE, p1, p2); }
+    void Neg(const Poly &p1, Poly &p2) const { check(he_neg(h(), level_, p1.h(), p2.h())); }
+    void Reduce(const Poly &p1, Poly &p2) const { check(he_reduce(h(), level_, p1.h(), p2.h())); }
     void ReduceLazy(const Poly &p1, Poly &p2) const { un(HE_REDUCE_LAZY, p1, p2); }
-    void MForm(const Poly &p1, Poly &p2) const { un(HE_MFORM, p1, p2); }
+    void MForm(const Poly &p1, Poly &p2) const { check(he_mform(h(), level_, p1.h(), p2.h())); }
     void MFormLazy(const Poly &p1, Poly &p2) const { un(HE_MFORM_LAZY, p1, p2); }
-    void IMForm(const Poly &p1, Poly &p2) const { un(HE_IMFORM, p1, p2); }
+    void IMForm(const Poly &p1, Poly &p2) const { check(he_imform(h(), level_, p1.h(), p2.h())); }
     void MulCoeffsBarrett(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_BARRETT, p1, p2, p3); }
     void MulCoeffsBarrettLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_BARRETT_LAZY, p1, p2, p3); }
     void MulCoeffsBarrettThenAdd(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_BARRETT_THEN_ADD, p1, p2, p3); }
     void MulCoeffsBarrettThenAddLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_BARRETT_THEN_ADD_LAZY, p1, p2, p3); }
-    void MulCoeffsMontgomery(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY, p1, p2, p3); }
-    void MulCoeffsMontgomeryLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY_LAZY, p1, p2, p3); }
+    void MulCoeffsMontgomery(const Poly &p1, const Poly &p2, Poly &p3) const { check(he_mul_coeffs_montgomery(h(), level_, p1.h(), p2.h(), p3.h())); }
+    void MulCoeffsMontgomeryLazy(const Poly &p1, const Poly &p2, Poly &p3) const { check(he_mul_coeffs_montgomery_lazy(h(), level_, p1.h(), p2.h(), p3.h())); }
     void MulCoeffsMontgomeryLazyThenNeg(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY_LAZY_THEN_NEG, p1, p2, p3); }
-    void MulCoeffsMontgomeryThenAdd(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY_THEN_ADD, p1, p2, p3); }
+    void MulCoeffsMontgomeryThenAdd(const Poly &p1, const Poly &p2, Poly &p3) const { check(he_mul_coeffs_montgomery_then_add(h(), level_, p1.h(), p2.h(), p3.h())); }
     void MulCoeffsMontgomeryThenAddLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY_THEN_ADD_LAZY, p1, p2, p3); }
-    void MulCoeffsMontgomeryLazyThenAddLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY_LAZY_THEN_ADD_LAZY, p1, p2, p3); }
+    void MulCoeffsMontgomeryLazyThenAddLazy(const Poly &p1, const Poly &p2, Poly &p3) const {
+        check(he_mul_coeffs_montgomery_lazy_then_add_lazy(h(), level_, p1.h(), p2.h(), p3.h()));
+    }
     void MulCoeffsMontgomeryThenSub(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY_THEN_SUB, p1, p2, p3); }
     void MulCoeffsMontgomeryThenSubLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY_THEN_SUB_LAZY, p1, p2, p3); }
     void MulCoeffsMontgomeryLazyThenSubLazy(const Poly &p1, const Poly &p2, Poly &p3) const { bin(HE_MUL_COEFFS_MONTGOMERY_LAZY_THEN_SUB_LAZY, p1, p2, p3); }
@@ -214,8 +292,67 @@ public:
         check(he_automorphism_ntt_with_index(h(), level_, pIn.h(), ix, pOut.h()));
     }
     void Automorphism(const Poly &pIn, uint64_t galEl, Poly &pOut) const { check(he_automorphism(h(), level_, pIn.h(), galEl, pOut.h())); }
+    AutomorphismIndex AutomorphismNTTIndex(uint64_t galEl) const {  // :12
+        he_handle ix = 0;
+        check(he_automorphism_index_create(h(), galEl, &ix));
+        AutomorphismIndex a;
+        a.r_ = detail::own(ix, he_automorphism_index_destroy);
+        a.n_ = N();
+        return a;
+    }
+    void AutomorphismNTTWithIndex(const Poly &pIn, const AutomorphismIndex &index, Poly &pOut) const {  // :50
+        check(he_automorphism_ntt_with_index(h(), level_, pIn.h(), index.h(), pOut.h()));
+    }
+    void AutomorphismNTTWithIndexThenAddLazy(const Poly &pIn, const AutomorphismIndex &index, Poly &pOut) const {  // :82
+        check(he_automorphism_ntt_with_index_then_add_lazy(h(), level_, pIn.h(), index.h(), pOut.h()));
+    }
+    // {Add,Sub,Mul}ScalarBigint, MulScalarBigintThenAdd (operations.go:158,193,231,240): little-endian 64-bit words of |scalar|
+    void AddScalarBigint(const Poly &p1, const std::vector<uint64_t> &words, Poly &p2) const {
+        check(he_add_scalar_bigint(h(), level_, p1.h(), words.data(), (int)words.size(), p2.h()));
+    }
+    void SubScalarBigint(const Poly &p1, const std::vector<uint64_t> &words, Poly &p2) const {
+        check(he_sub_scalar_bigint(h(), level_, p1.h(), words.data(), (int)words.size(), p2.h()));
+    }
+    void MulScalarBigint(const Poly &p1, const std::vector<uint64_t> &words, Poly &p2) const {
+        check(he_mul_scalar_bigint(h(), level_, p1.h(), words.data(), (int)words.size(), p2.h()));
+    }
+    void MulScalarBigintThenAdd(const Poly &p1, const std::vector<uint64_t> &words, Poly &p2) const {
+        check(he_mul_scalar_bigint_then_add(h(), level_, p1.h(), words.data(), (int)words.size(), p2.h()));
+    }
+    // {Add,Sub,Mul}DoubleRNSScalar, MulDoubleRNSScalarThenAdd (operations.go:166,176,249,260): scalar0 on coefficients [0, N/2), scalar1 on [N/2, N)
+    void AddDoubleRNSScalar(const Poly &p1, const std::vector<uint64_t> &s0, const std::vector<uint64_t> &s1, Poly &p2) const { drs(0, p1, s0, s1, p2); }
+    void SubDoubleRNSScalar(const Poly &p1, const std::vector<uint64_t> &s0, const std::vector<uint64_t> &s1, Poly &p2) const { drs(1, p1, s0, s1, p2); }
+    void MulDoubleRNSScalar(const Poly &p1, const std::vector<uint64_t> &s0, const std::vector<uint64_t> &s1, Poly &p2) const { drs(2, p1, s0, s1, p2); }
+    void MulDoubleRNSScalarThenAdd(const Poly &p1, const std::vector<uint64_t> &s0, const std::vector<uint64_t> &s1, Poly &p2) const { drs(3, p1, s0, s1, p2); }
+    // MulByVectorMontgomery / ...ThenAddLazy (operations.go:363,370): every limb times limb 0 of the batch-1 polynomial `vector`
+    void MulByVectorMontgomery(const Poly &p1, const Poly &vector, Poly &p2) const { check(he_mul_by_vector_montgomery(h(), level_, p1.h(), vector.h(), 0, p2.h())); }
+    void MulByVectorMontgomeryThenAddLazy(const Poly &p1, const Poly &vector, Poly &p2) const {
+        check(he_mul_by_vector_montgomery(h(), level_, p1.h(), vector.h(), 1, p2.h()));
+    }
+    // SubRing.RootsForward / RootsBackward (ring/subring.go:44-47)
+    std::vector<uint64_t> RootsForward(int limb) const { return roots(limb, 0); }
+    std::vector<uint64_t> RootsBackward(int limb) const { return roots(limb, 1); }
+    // ring.NumberTheoreticTransformer on host slices (ring/ntt.go:17-22): the plug point of ring.NewRingWithCustomNTT
+    void Forward(int limb, const uint64_t *p1, uint64_t *p2) const { check(he_subring_ntt_host(h(), limb, 0, 0, p1, p2)); }
+    void ForwardLazy(int limb, const uint64_t *p1, uint64_t *p2) const { check(he_subring_ntt_host(h(), limb, 0, 1, p1, p2)); }
+    void Backward(int limb, const uint64_t *p1, uint64_t *p2) const { check(he_subring_ntt_host(h(), limb, 1, 0, p1, p2)); }
+    void BackwardLazy(int limb, const uint64_t *p1, uint64_t *p2) const { check(he_subring_ntt_host(h(), limb, 1, 1, p1, p2)); }
+
+    // the selector forms (enum he_binop / he_unop / he_scalarop of hering.h), for table-driven callers
+    void BinOp(int op, const Poly &p1, const Poly &p2, Poly &p3) const { bin(op, p1, p2, p3); }
+    void UnOp(int op, const Poly &p1, Poly &p2) const { un(op, p1, p2); }
+    void ScalarOp(int op, const Poly &p1, uint64_t scalar, Poly &p2) const { sc(op, p1, scalar, p2); }
 
 private:
+    void drs(int op, const Poly &p1, const std::vector<uint64_t> &s0, const std::vector<uint64_t> &s1, Poly &p2) const {
+        if ((int)s0.size() <= level_ || (int)s1.size() <= level_) throw std::invalid_argument("DoubleRNSScalar: one scalar pair per limb");
+        check(he_double_rns_scalarop(h(), level_, op, p1.h(), s0.data(), s1.data(), p2.h()));
+    }
+    std::vector<uint64_t> roots(int limb, int dir) const {
+        std::vector<uint64_t> v((size_t)N());
+        check(he_ring_roots(h(), limb, dir, v.data()));
+        return v;
+    }
     void bin(int op, const Poly &p1, const Poly &p2, Poly &p3) const { check(he_binop(h(), level_, op, p1.h(), p2.h(), p3.h())); }
     void un(int op, const Poly &p1, Poly &p2) const { check(he_unop(h(), level_, op, p1.h(), p2.h())); }
     void sc(int op, const Poly &p1, uint64_t s, Poly &p2) const { check(he_scalarop(h(), level_, op, p1.h(), s, p2.h())); }
@@ -269,6 +406,16 @@ public:
     he_handle h() const { return r_ ? r_->h : 0; }
     int LevelQ() const { return nQk_ - 1; }
     int LevelP() const { return nPk_ - 1; }
+    // the key words back on the host: [beta][2][nQk + nPk][N]
+    void Download(uint64_t *dst, size_t words) const { check(he_evk_download(h(), dst, words)); }
+    // device storage for an external (GPU-to-GPU) fill; Commit() after the write has completed
+    std::pair<void *, size_t> DeviceBuffer() const {
+        void *p = nullptr;
+        size_t n = 0;
+        check(he_evk_device_buffer(h(), &p, &n));
+        return {p, n};
+    }
+    void Commit() const { check(he_evk_commit(h())); }
 };
 
 // BuffDecompQP of Evaluator.DecomposeNTT: an opaque device buffer (beta digits of (Q limbs, P limbs) per batch entry)
@@ -309,6 +456,17 @@ public:
         k.nPk_ = nPk;
         return k;
     }
+    // BaseTwoDecomposition = pw2 != 0 (at most one special prime; nPk = 0 and p empty: a key without P part): nj[i] bit windows of Q-limb i
+    EvaluationKey NewEvaluationKeyBase2(int pw2, const std::vector<int> &nj, int nQk, int nPk, const std::vector<uint64_t> &q,
+                                        const std::vector<uint64_t> &p) const {
+        he_handle h = 0;
+        check(he_evk_create_base2(this->h(), pw2, nj.data(), (int)nj.size(), nQk, nPk, q.data(), nPk > 0 ? p.data() : nullptr, &h));
+        EvaluationKey k;
+        k.r_ = detail::own(h, he_evk_destroy);
+        k.nQk_ = nQk;
+        k.nPk_ = nPk;
+        return k;
+    }
     Decomposition NewDecomposition(int batch = 1) const {
         he_handle h = 0;
         check(he_decomp_create(this->h(), batch, &h));
@@ -336,6 +494,48 @@ public:
         check(he_eval_moddown_qp_to_q_ntt(h(), levelQ, levelP, p1Q.h(), p1P.h(), p2Q.h()));
     }
     // (CheckAndGetGaloisKey / AutomorphismIndex are key-set and table look-ups of the Go side: go/hering/evaluator.go)
+
+    // Decomposer.DecomposeAndSplit (ring/basis_extension.go:381): coefficient-domain p0Q -> digit `digit` extended to (p1Q, p1P)
+    void DecomposeAndSplit(int levelQ, int levelP, int nbPi, int digit, const Poly &p0Q, Poly &p1Q, Poly &p1P) const {
+        check(he_decompose_and_split(h(), levelQ, levelP, nbPi, digit, p0Q.h(), p1Q.h(), p1P.h()));
+    }
+    // the inner product over the digits [digitBegin, digitEnd) only (a key switch split over GPUs by digit)
+    void GadgetProductHoistedLazyDigits(int levelQ, const Decomposition &decompQP, const EvaluationKey &gadgetCt, int digitBegin, int digitEnd,
+                                        std::array<PolyQP, 2> &ct) const {
+        check(he_gadget_product_hoisted_lazy_digits(h(), levelQ, decompQP.h(), gadgetCt.h(), digitBegin, digitEnd, ct[0].Q.h(), ct[0].P.h(),
+                                                    ct[1].Q.h(), ct[1].P.h()));
+    }
+    // one limb of the hoisting buffer back on the host (tests)
+    void DecompositionLimb(const Decomposition &d, int b, int digit, bool isP, int limb, uint64_t *dst) const {
+        check(he_decomp_download_limb(d.h(), b, digit, isP ? 1 : 0, limb, dst));
+    }
+    // pieces of bootstrapping.Evaluator.ModUp (circuits/ckks/bootstrapping/evaluator.go:654-755)
+    void CenteredLift(int strict, const Poly &src, int firstQ, int levelQ, Poly &dstQ, int levelP, Poly &dstP) const {
+        check(he_centered_lift(h(), strict, src.h(), firstQ, levelQ, dstQ.h(), levelP, dstP.h()));
+    }
+    void DecompositionFill(Decomposition &d, int levelQ, int levelP, const Poly &srcQ, const Poly &srcP) const {
+        check(he_decomp_fill(d.h(), levelQ, levelP, srcQ.h(), srcP.h()));
+    }
+    // inner accumulation of lintrans.Evaluator.MultiplyByDiagMatrix[BSGS] (lintrans_evaluator.go:216-241, :346-394): term i =
+    // (plaintext diagonal, ciphertext, optional automorphism index); out_k = Reduce([out_k +] sum_i pt_i * phi_i(ct_i[k])) on Q and P
+    struct DiagTerm {
+        PolyQP pt, c0, c1;             // c0.P / c1.P empty: the term has no P part
+        const AutomorphismIndex *index;  // nullptr: no automorphism
+    };
+    void LinTransMulSum(int levelQ, int levelP, const std::vector<DiagTerm> &terms, bool accumulate, std::array<PolyQP, 2> &out) const {
+        const int n = (int)terms.size();
+        std::vector<he_handle> ptQ(n), ptP(n), c0Q(n), c0P(n), c1Q(n), c1P(n), ix(n);
+        bool any_index = false;
+        for (int i = 0; i < n; i++) {
+            ptQ[i] = terms[i].pt.Q.h(); ptP[i] = terms[i].pt.P.h();
+            c0Q[i] = terms[i].c0.Q.h(); c0P[i] = terms[i].c0.P.h();
+            c1Q[i] = terms[i].c1.Q.h(); c1P[i] = terms[i].c1.P.h();
+            ix[i] = terms[i].index ? terms[i].index->h() : 0;
+            any_index = any_index || ix[i] != 0;
+        }
+        check(he_lintrans_mul_sum(h(), levelQ, levelP, n, ptQ.data(), ptP.data(), c0Q.data(), c0P.data(), c1Q.data(), c1P.data(),
+                                  any_index ? ix.data() : nullptr, accumulate ? 1 : 0, out[0].Q.h(), out[0].P.h(), out[1].Q.h(), out[1].P.h()));
+    }
 
     // ---- rlwe.Evaluator ----
     void ModDown(int levelQ, int levelP, const std::array<PolyQP, 2> &ctQP, Ciphertext &ct) const {
@@ -388,6 +588,36 @@ private:
             check(he_ckks_mul_relin(h(), level, op0.Value[0].h(), op0.Value[1].h(), op1.Value[0].h(), op1.Value[1].h(), k, opOut.Value.at(0).h(),
                                     opOut.Value.at(1).h(), o2));
     }
+};
+
+// One process per GPU: the RCCL communicator of a context, driven by the library on the context's stream (key replication over xGMI;
+// the all-reduce of a key switch split by digit).  Rank 0 draws the id and hands it to the others over any control plane.
+class Communicator {
+    detail::Ref r_;
+
+public:
+    static bool Available() {
+        int yes = 0;
+        check(he_rccl_available(&yes));
+        return yes != 0;
+    }
+    static std::array<uint8_t, HE_RCCL_ID_BYTES> UniqueId() {
+        std::array<uint8_t, HE_RCCL_ID_BYTES> id{};
+        check(he_rccl_unique_id(id.data()));
+        return id;
+    }
+    Communicator(const Context &ctx, const std::array<uint8_t, HE_RCCL_ID_BYTES> &id, int rank, int world) {  // collective
+        he_handle h = 0;
+        check(he_rccl_comm_create(ctx.h(), id.data(), rank, world, &h));
+        r_ = detail::own(h, he_rccl_comm_destroy);
+    }
+    int Ranks() const {  // the ranks RCCL itself reaches (an all-reduce of ones)
+        int n = 0;
+        check(he_rccl_comm_ranks(r_->h, &n));
+        return n;
+    }
+    void Broadcast(const EvaluationKey &evk, int root) const { check(he_evk_broadcast(r_->h, evk.h(), root)); }
+    void AllReduceSum(Poly &p) const { check(he_poly_all_reduce_sum(r_->h, p.h())); }
 };
 
 }  // namespace hering

@@ -117,6 +117,58 @@ static void test_ring(const hering::Context &ctx, int logN) {
     lo_automorphism_ntt_index(N, 2 * (uint64_t)N, galEl, index.data());
     lo_automorphism_ntt_with_index(oQ, level, want.data(), index.data(), wa.data());
     REQUIRE(pa.Download() == wa);
+    // AutomorphismNTTIndex: the table itself and the WithIndex forms
+    hering::AutomorphismIndex ix = ringQ.AutomorphismNTTIndex(galEl);
+    REQUIRE(ix.Download() == index);
+    Poly pa2 = ringQ.NewPoly();
+    ringQ.AutomorphismNTTWithIndex(pz, ix, pa2);
+    REQUIRE(pa2.Download() == wa);
+    ringQ.AutomorphismNTTWithIndexThenAddLazy(pz, ix, pa2);  // pa2 += phi(pz), lazily
+    lo_automorphism_ntt_with_index_then_add_lazy(oQ, level, want.data(), index.data(), wa.data());
+    REQUIRE(pa2.Download() == wa);
+    // the per-limb tables and the host-slice transformer (ring.NumberTheoreticTransformer, BASELINE config 1's plumbing)
+    for (int i = 0; i <= level; i++) {
+        const u64v rf = ringQ.RootsForward(i);
+        REQUIRE(std::equal(rf.begin(), rf.end(), lo_ring_roots_fwd(oQ, i)));
+        REQUIRE(ringQ.Constant(i, 0) == q[i]);
+    }
+    {
+        u64v f(N), bk(N), wf(x.size());
+        ringQ.Forward(1, &x[(size_t)N], f.data());
+        lo_ntt(oQ, level, x.data(), wf.data());
+        REQUIRE(std::equal(f.begin(), f.end(), wf.begin() + N));
+        ringQ.Backward(1, f.data(), bk.data());
+        REQUIRE(std::equal(bk.begin(), bk.end(), x.begin() + N));
+    }
+    // rows of Coeffs one by one, the handle's own shape, AddScalarBigint with a multi-word scalar
+    {
+        Poly pl2 = ringQ.NewPoly();
+        for (int i = 0; i <= level; i++) pl2.UploadLimb(0, i, &x[(size_t)i * N]);
+        REQUIRE(pl2.Download() == x);
+        u64v row(N);
+        pl2.DownloadLimb(0, level, row.data());
+        REQUIRE(std::equal(row.begin(), row.end(), x.begin() + (size_t)level * N));
+        const auto shape = pl2.Shape();
+        REQUIRE(shape[0] == level + 1 && shape[1] == 1 && shape[2] == N);
+        const u64v big = {0x123456789abcdef0ull, 0x0fedcba987654321ull, 0x1ull};
+        ringQ.AddScalarBigint(px, big, pl2);
+        lo_add_scalar_bigint(oQ, level, x.data(), big.data(), (int)big.size(), want2.data());
+        u64v w2(want2.begin(), want2.begin() + x.size());
+        REQUIRE(pl2.Download() == w2);
+    }
+    // a captured sequence replays to the same words
+    {
+        Poly g1 = ringQ.NewPoly(), g2 = ringQ.NewPoly();
+        auto seq = [&] { ringQ.NTT(px, g1); ringQ.MulCoeffsMontgomery(g1, g1, g2); ringQ.INTT(g2, g2); };
+        seq();
+        const u64v first = g2.Download();
+        g2.Zero();
+        hering::Graph graph(ctx, seq);
+        REQUIRE(graph.Nodes() >= 3);
+        graph.Launch();
+        REQUIRE(g2.Download() == first);
+    }
+    lo_ntt(oQ, level, x.data(), want.data());
     // AtLevel: only the first limbs are touched
     Poly pl = ringQ.NewPoly();
     ringQ.AtLevel(1).NTT(px, pl);
