@@ -17,6 +17,8 @@ extern "C" {
 #include "lattigo_oracle.h"
 }
 
+#include "ntt_kat.inc"  // the reference's own known-answer vectors (ring/ntt_test.go:10-89)
+
 using hering::Ciphertext;
 using hering::Poly;
 using u64v = std::vector<uint64_t>;
@@ -316,6 +318,17 @@ int main(int argc, char **argv) {
         threw = e.code == HE_EPARAM && std::string(e.what()).find("moduli are not distinct") != std::string::npos;
     }
     REQUIRE(threw);
+    // TestNTT's known answers (ring/ntt_test.go:95-121): NTT(poly) == polyNTT, then INTT in place gives poly back
+    REQUIRE(kNttKat.size() == 6);
+    for (const NttKat &k : kNttKat) {
+        hering::Ring r(ctx, k.logN, k.Qis);
+        Poly px = r.NewPoly(), pz = r.NewPoly();
+        px.Upload(k.poly);
+        r.NTT(px, pz);
+        REQUIRE(pz.Download() == k.polyNTT);
+        r.INTT(pz, pz);
+        REQUIRE(pz.Download() == k.poly);
+    }
     for (int logN : {10, 13, 15}) test_ring(ctx, logN);
     for (int logN : {11, 13}) test_rlwe(ctx, logN);
     ctx.Sync();
