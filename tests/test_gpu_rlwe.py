@@ -1010,7 +1010,7 @@ def test_gadget_product_output_aliasing_its_input(ctx, logN):
 def test_random_scheme_level_calls(ctx):
     """tools/fuzz_shapes.py's single-call generator, 150 draws of a fixed seed: operation, shape, modulus classes, level, a key
     that ends below the ring's top level, batch size and output / input aliasing all at random, every entry against the oracle
-    (the tool itself ran 9 813 draws and 3 000 full-size shape checks on the GPU without a mismatch)."""
+    (the tool itself ran 17 387 draws and 3 000 full-size shape checks on the GPU without a mismatch)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_shapes", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "fuzz_shapes.py"))
     fz = importlib.util.module_from_spec(spec)
