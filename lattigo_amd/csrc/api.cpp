@@ -713,8 +713,6 @@ int he_ring_create_type(he_handle hctx, int logN, int ring_type, const uint64_t 
     for (uint64_t m : r->moduli) r->small.push_back(modulus_class(m));
     TRY(upload_f64_tables(subs, r->N, &r->d_twdf, &r->d_twdi));
     r->dev = RingDev{logN, r->N, r->d_mc, r->d_twf, r->d_twi, r->small.data(), r->d_twdf, r->d_twdi};
-    if (ring_type == 0) {  // (the conjugate-invariant tables are remapped; the class test below does not apply to its fold twiddles)
-    }
     *out = reg(r);
     return HE_OK;
 }
@@ -763,7 +761,7 @@ static int poly_alloc(he_handle hring, int n_limbs, int batch, bool zero, he_han
     }
     // scratch polynomials: contents unspecified (a recycled buffer); HERING_POISON=1 fills them with a pattern so that a
     // read-before-write shows up as a parity failure instead of depending on what the buffer held
-    static const bool poison = getenv("HERING_POISON") && atoi(getenv("HERING_POISON")) != 0;
+    static const bool poison = env_flag("HERING_POISON");
     if (zero) HIP_TRY(hipMemsetAsync(p->d, 0, bytes, r->ctx->stream));
     else if (poison) HIP_TRY(hipMemsetAsync(p->d, 0x5a, bytes, r->ctx->stream));
     *out = reg(p);
@@ -1793,7 +1791,7 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
 // which destinations of a descriptor take the lean integer path of modup_fused_kernel (see there): moduli below 2^58 that are
 // not on the double-precision path, column sums that cannot overflow, and a sum that one Montgomery reduction brings below 2p
 void mark_fast_destinations(const BasisExtender &be, ModUpDesc &D, const std::vector<uint64_t> &basis) {
-    static const bool off = getenv("HERING_NO_FAST_MODUP") && atoi(getenv("HERING_NO_FAST_MODUP")) != 0;
+    static const bool off = env_flag("HERING_NO_FAST_MODUP");
     uint64_t mx = 0;
     for (uint64_t m : basis) mx = std::max(mx, m);
     for (int j = 0; j < D.ndst; j++) {
@@ -2106,7 +2104,7 @@ int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP
 // class-2 limbs of the gadget product: forward row NTT + key MAC in one kernel (dec holds the post-column state)
 // May the basis extension hand unreduced doubles to the double-precision row kernels (launch_modup_fused f64_raw)?
 static bool f64_raw_ok(const BasisExtender &be, int levelQ, int levelP, int nsrc) {
-    static const bool off = getenv("HERING_NO_F64_RAW") && atoi(getenv("HERING_NO_F64_RAW")) != 0;
+    static const bool off = env_flag("HERING_NO_F64_RAW");
     if (off) return false;
     uint64_t mx = 0;
     for (int j = 0; j <= levelQ; j++) if (be.small[j] == 2) mx = std::max(mx, be.Q->moduli[j]);
@@ -2205,7 +2203,7 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
     const FusedPlan *plan = nullptr;
     if (!k.pw2) TRY(get_dec_plan(ev, levelQ, levelP, levelP + 1, &plan));
     const bool make_c2 = tin && tin->make_c2;
-    static const bool no_prod_in = getenv("HERING_NO_PROD_PROLOGUE") && atoi(getenv("HERING_NO_PROD_PROLOGUE")) != 0;
+    static const bool no_prod_in = env_flag("HERING_NO_PROD_PROLOGUE");
     const bool prod_in = make_c2 && plan && plan->ok && be.d_twdi != nullptr && ntt_prod_in_supported(be.Q->logN) && !no_prod_in;
     if (make_c2) {
         // cx = T(a1, b1): everywhere by the tensor kernel, or -- prod_in -- only on the integer-class limbs, the others being formed
@@ -2350,7 +2348,7 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
     // ModDown inside the NTT + MAC kernel: possible when the P part does not depend on that kernel (no P limb of the
     // double-precision class) -- then the P accumulators come from ks_inner alone, are extended first, and the kernel over the
     // double-precision Q limbs forms the final outputs against its accumulators in registers (NttMacEpilogue)
-    static const bool no_mac_epi = getenv("HERING_NO_MAC_EPILOGUE") && atoi(getenv("HERING_NO_MAC_EPILOGUE")) != 0;
+    static const bool no_mac_epi = env_flag("HERING_NO_MAC_EPILOGUE");
     MacDefer defer;
     if (cx && plan->ok && k.keyd && !k.pw2 && !no_mac_epi && ntt_mac_epilogue_supported(be.Q->logN)) {
         // (the kernel writes the outputs while other workgroups still read cx -- the digits' own limbs: not when they alias)
@@ -2688,7 +2686,7 @@ static int automorphism_core(Evaluator &ev, int level, View in0, const View *in1
     // Standard ring only (NthRoot = 2N), and not when an output is an input of its own entry (a thread would read the addend at e
     // and overwrite another position some other thread still has to read); paths without a fused epilogue report back and get
     // the gathers.  HERING_NO_AUTO_SCATTER=1 keeps the gathers (A/B).
-    static const bool no_scatter = getenv("HERING_NO_AUTO_SCATTER") && atoi(getenv("HERING_NO_AUTO_SCATTER")) != 0;
+    static const bool no_scatter = env_flag("HERING_NO_AUTO_SCATTER");
     uint32_t ginv = 0;
     // (entry-table views: aliasing requests never reach a table batch, co_submit_keyswitch)
     const bool alias = out0.p == in0.p || out1.p == in0.p || (in1 && (out0.p == in1->p || out1.p == in1->p));
@@ -2782,7 +2780,7 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     // ONE launch: the key inner product adds ctIn[0] * P to component 0 at the source position and stores all four accumulators
     // through the automorphism (KsScatter) -- instead of inner product, two element-wise passes and four gathers.  Standard
     // ring, and the outputs must not be the addend (other threads still read it); HERING_NO_AUTO_SCATTER=1: the old sequence.
-    static const bool no_scatter = getenv("HERING_NO_AUTO_SCATTER") && atoi(getenv("HERING_NO_AUTO_SCATTER")) != 0;
+    static const bool no_scatter = env_flag("HERING_NO_AUTO_SCATTER");
     const bool alias = o.q0->d == in0->d || o.q1->d == in0->d;
     if (!no_scatter && be.type == 0 && !alias) {
         KsScatter ks;
@@ -2971,7 +2969,7 @@ static int mul_relin_core(Evaluator &ev, int level, bool bgv, uint64_t t, Evk *k
     // With a fused ModDown the tensor kernel forms c2 only: c0 / c1 are computed from the inputs where they are added, in the
     // ModDown epilogue (24 limbs of writes and 24 of reads fewer; the inputs' second read comes from L2).  Not when an output
     // aliases an input: the epilogue of one component would overwrite words the other still reads.
-    static const bool no_fuse = getenv("HERING_NO_TENSOR_EPILOGUE") && atoi(getenv("HERING_NO_TENSOR_EPILOGUE")) != 0;
+    static const bool no_fuse = env_flag("HERING_NO_TENSOR_EPILOGUE");
     const FusedPlan *mdplan = nullptr;
     const bool may_fuse = k->nPk > 0 && !alias && !no_fuse;  // a P-less (base-2) key has no ModDown to fuse into
     if (may_fuse) TRY(get_md_plan(ev, level, k->nPk - 1, &mdplan));

@@ -4,11 +4,17 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "modarith.h"
 
 namespace he {
 
+// run-time switch HERING_* (DESIGN.md section 9): set and non-zero
+inline bool env_flag(const char *name) {
+    const char *v = std::getenv(name);
+    return v != nullptr && std::atoi(v) != 0;
+}
 constexpr int kMaxLimbs = 64;  // limbs addressed by one launch
 constexpr int kMaxLogN = 20;   // the reference's MaxLogN (core/rlwe/params.go:21); the fused key-switch pipelines cover logN <= 17
 

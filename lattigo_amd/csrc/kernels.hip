@@ -1734,7 +1734,7 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
     if (dec.tab || (!epi && !no_tab({out0Q, out0P, out1Q, out1P})) || (epi && epi->ext.tab)) return hipErrorInvalidValue;
     const int b = ntt_row_bits(r.logN), aa = r.logN - b;
     if (epi && !ntt_mac_epilogue_supported(r.logN)) return hipErrorInvalidValue;
-    NttMacKArgs A;
+    NttMacKArgs A{};
     A.dec = dec.p; A.dec_bs = dec.bstride; A.own = own.p; A.own_bs = own.bstride; A.own_tab = own.tab; A.keyd = keyd;
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
@@ -1743,7 +1743,7 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
     double mac_bytes = ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0;
     // with the epilogue: + the two extension rows, + the addends (w0 / w1) or the four inputs of the product, per entry and limb
     if (epi) mac_bytes += (2.0 + (epi->tensor ? 4.0 : (epi->has_w0 ? 1.0 : 0.0) + (epi->has_w1 ? 1.0 : 0.0))) * batch * a.nlimbs * (double)r.N * 8.0;
-    static const bool plain_only = getenv("HERING_MAC_PLAIN") && atoi(getenv("HERING_MAC_PLAIN")) != 0;
+    static const bool plain_only = env_flag("HERING_MAC_PLAIN");
     if (epi || b == 13 || (b == 12 && !plain_only)) {  // (the plain kernel has no 8192-row instantiation: it would spill)
         NttMacDmaArgs D;
         D.k = A;
@@ -1844,7 +1844,7 @@ __global__ void __launch_bounds__(256) key_to_f64_kernel(KeyF64Args A) {
 }
 hipError_t launch_key_to_f64(const RingDev &r, const uint64_t *key, double *keyd, int nblocks, const uint8_t *limb_mod_host,
                              int nlimbs, hipStream_t s) {
-    KeyF64Args A;
+    KeyF64Args A{};
     A.key = key; A.keyd = keyd; A.mc = r.mc; A.N = r.N; A.nlimbs = nlimbs;
     for (int i = 0; i < nlimbs; i++) A.mod[i] = limb_mod_host[i];
     dim3 grid((unsigned)((r.N + 255) / 256), nlimbs, nblocks), block(256);
@@ -1938,7 +1938,7 @@ static double rows_bytes(dim3 grid, const NttArgs &A, int logb) {
 }
 template <bool INV, bool NC>
 static hipError_t launch_rows_nc(int logb, dim3 grid, const NttArgs &A, hipStream_t s) {
-    static const bool no_lean = getenv("HERING_NO_LEAN_INV_ROWS") && atoi(getenv("HERING_NO_LEAN_INV_ROWS")) != 0;
+    static const bool no_lean = env_flag("HERING_NO_LEAN_INV_ROWS");
     // the production row sizes without the N^-1 fold: the lean inverse variant (see ntt_rows_kernel)
     if constexpr (INV) {
         if (!no_lean && (logb == 12 || logb == 13) && !A.scale) {
@@ -2095,7 +2095,7 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     // column stages: one pass of up to five (32 coefficients per thread); logN = 19, 20 (a = 6, 7) take an outer pass of a - 4
     // and an inner pass of 4 inside the 2^(a-4) blocks the outer pass leaves (ntt_cols_kernel, NttArgs::cb)
     const int a_out = a > 5 ? a - 4 : a, a_in = a - a_out;
-    NttArgs A;
+    NttArgs A{};  // (zero-filled: the per-limb arrays are copied by launch_rows whether or not an epilogue set them)
     A.mc = r.mc;
     A.N = r.N;
     A.a = a;
@@ -2174,7 +2174,7 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     // (forward tensor-mode epilogue: the workgroup -> entry map of that launch shape is not the table's)
     if ((in.tab && epi && epi->tensor) || (out.tab && !epi) || (epi && !no_tab({epi->y, epi->y2})) || (prod && prod->c.tab)) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
-    NttArgs A;
+    NttArgs A{};
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
     A.epi = 0; A.epi_y = A.epi_w = nullptr; A.epi_y_bs = A.epi_w_bs = 0;
     A.zsplit = 0; A.epi2 = 0; A.out2 = nullptr; A.out2_bs = 0; A.epi_y2 = A.epi_w2 = nullptr; A.epi_y2_bs = A.epi_w2_bs = 0;
@@ -2243,7 +2243,7 @@ hipError_t launch_ci_fold(const RingDev &r, const LimbTab &tab, View in, View ou
                           hipStream_t s) {
     if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
-    CiFoldArgs A;
+    CiFoldArgs A{};
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N;
     A.inverse = inverse; A.reduce_input = reduce_input;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
@@ -2296,7 +2296,7 @@ __global__ void __launch_bounds__(256) ci_ref_inv_fold_kernel(CiRefArgs A) {
 hipError_t launch_ci_intt_lazy_ref(const RingDev &r, const ModConst &mc_host, int mod, View in, View out, int batch, hipStream_t s) {
     if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (batch <= 0) return hipSuccess;
-    CiRefArgs A;
+    CiRefArgs A{};
     A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride; A.mc = mc_host;
     A.tw = r.tw_inv + (size_t)mod * r.N; A.N = r.N;
     ProfScope ps(K_CI_FOLD, s, 2.0 * (r.logN + 1) * batch * (double)r.N * 8.0);  // one pass per stage (off the hot path)
@@ -2414,7 +2414,7 @@ static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, V
                                  const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s, int dbl) {
     if (!no_tab({x, y, w, z})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
-    EwArgs A;
+    EwArgs A{};
     A.dbl = dbl;
     A.x = x.p; A.y = y.p; A.z = z.p; A.w = w.p;
     A.x_bs = x.bstride; A.y_bs = y.bstride; A.z_bs = z.bstride; A.w_bs = w.bstride;
@@ -2429,7 +2429,7 @@ static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, V
     }
     dim3 grid((unsigned)((r.N / 2 + 255) / 256), tab.n, batch), block(256);
     {   // HERING_EW_STATS=1: launches and limb-units per element-wise op, printed at exit (diagnosis of driver-level traces)
-        static const bool stats = getenv("HERING_EW_STATS") && atoi(getenv("HERING_EW_STATS")) != 0;
+        static const bool stats = env_flag("HERING_EW_STATS");
         if (stats) {
             static std::mutex mu;
             static std::unordered_map<int, std::pair<long, double>> cnt;
@@ -2494,7 +2494,7 @@ hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const ui
                          bool then_add, hipStream_t s) {
     if (in.tab) return hipErrorInvalidValue;  // entry tables: only the output
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
-    GatherArgs A;
+    GatherArgs A{};
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.out_tab = out.tab; A.index = index; A.N = r.N;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
@@ -2561,7 +2561,7 @@ hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View 
                                      hipStream_t s, bool conjugate_invariant) {
     if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
-    AutoCoeffArgs A;
+    AutoCoeffArgs A{};
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.logN = r.logN;
     A.gal = gal; A.ginv = 0;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
@@ -2642,7 +2642,7 @@ hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a,
                         int batch, hipStream_t s) {
     if (!no_tab({src, dstA, dstB})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.ndst <= 0 || batch <= 0) return hipSuccess;
-    ModUpKArgs A;
+    ModUpKArgs A{};
     A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
     A.mc = r.mc; A.a = c.a; A.T = c.T; A.vt = c.vt; A.N = r.N; A.m = a;
@@ -3268,7 +3268,7 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
     if (ndesc <= 0 || batch <= 0) return hipSuccess;
     if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
     const int a = r.logN - ntt_row_bits(r.logN);
-    ModUpFusedArgs A;
+    ModUpFusedArgs A{};
     A.f64_raw = f64_raw ? 1 : 0;
     A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
@@ -3318,7 +3318,7 @@ hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, Vi
                               hipStream_t s, int strict) {
     if (!no_tab({src, dstA, dstB})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.ndst <= 0 || batch <= 0) return hipSuccess;
-    CenterArgs A;
+    CenterArgs A{};
     A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
     A.mc = r.mc; A.N = r.N; A.m = a; A.strict = strict;
@@ -3351,7 +3351,7 @@ hipError_t launch_mask_spread(const RingDev &r, const MaskSpreadArgs &a, View sr
                               int batch, hipStream_t s) {
     if (!no_tab({src})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.nblk <= 0 || batch <= 0) return hipSuccess;
-    MaskSpreadKArgs A;
+    MaskSpreadKArgs A{};
     A.src = src.p; A.src_bs = src.bstride; A.dec = dec; A.dec_bs = dec_bs; A.dec_ds = dec_ds; A.N = r.N; A.m = a;
     dim3 grid((unsigned)((r.N + 255) / 256), a.nblk, batch), block(256);
     ProfScope ps(K_MASK_SPREAD, s, ((double)a.nblk * a.ndst + a.ndst) * batch * (double)r.N * 8.0);
@@ -3476,7 +3476,7 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own
                            View out0P, View out1Q, View out1P, int batch, hipStream_t s, const KsScatter *sc) {
     if (!no_tab({dec, out0Q, out0P, out1Q, out1P})) return hipErrorInvalidValue;  // entry tables: only the own-digit operand
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
-    KsKArgs A;
+    KsKArgs A{};
     A.own = own.p; A.own_bs = own.bstride; A.own_tab = own.tab;
     A.dec = dec.p; A.dec_bs = dec.bstride; A.key = key;
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
@@ -3552,7 +3552,7 @@ static hipError_t launch_shift_impl(const RingDev &r, const LimbTab &tab, View i
                                     hipStream_t s) {
     if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
-    ShiftArgs A;
+    ShiftArgs A{};
     A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.k = k; A.monomial = monomial;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
@@ -3630,7 +3630,7 @@ hipError_t launch_diag_mac(const RingDev &r, const DiagMacArgs &a, View out0, Vi
     if (!no_tab({out0, out1})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     if (a.n < 0 || a.n > kMaxDiag) return hipErrorInvalidValue;
-    DiagMacKArgs A;
+    DiagMacKArgs A{};
     A.a = a;
     A.o0 = out0.p; A.o1 = out1.p; A.o0_bs = out0.bstride; A.o1_bs = out1.bstride;
     A.mc = r.mc; A.N = r.N; A.batch = batch;
@@ -3702,7 +3702,7 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
 hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *scalar, View a0, View a1, View b0, View b1,
                          View c0, View c1, View c2, int batch, hipStream_t s) {
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
-    TensorArgs A;
+    TensorArgs A{};
     A.a0 = a0.p; A.a1 = a1.p; A.b0 = b0.p; A.b1 = b1.p; A.c0 = c0.p; A.c1 = c1.p; A.c2 = c2.p;
     A.a0_bs = a0.bstride; A.a1_bs = a1.bstride; A.b0_bs = b0.bstride; A.b1_bs = b1.bstride;
     A.c0_bs = c0.bstride; A.c1_bs = c1.bstride; A.c2_bs = c2.bstride;
@@ -3736,7 +3736,7 @@ __global__ void __launch_bounds__(64) tab_fill_kernel(TabFillArgs A) {
 }
 hipError_t launch_tab_fill(size_t *dst, const size_t *vals, int n, hipStream_t s) {
     for (int i0 = 0; i0 < n; i0 += kTabFillMax) {
-        TabFillArgs A;
+        TabFillArgs A{};
         A.dst = dst + i0;
         A.n = n - i0 < kTabFillMax ? n - i0 : kTabFillMax;
         for (int i = 0; i < A.n; i++) A.v[i] = vals[i0 + i];
