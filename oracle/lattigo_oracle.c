@@ -1666,9 +1666,10 @@ void lo_batch_op(const lo_evaluator *e, int kind, int level, uint64_t t, uint64_
     if (nthreads > nb) nthreads = nb;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
     batch_arg *args = (batch_arg *)calloc(nthreads, sizeof(batch_arg));
+    if (!th || !args) { fprintf(stderr, "lo_batch_op: out of memory\n"); abort(); }
     for (int i = 0; i < nthreads; i++) {
         args[i] = (batch_arg){kind, i, nthreads, nb, e, level, t, gal, op0, op1, key, out};
-        pthread_create(&th[i], NULL, batch_worker, &args[i]);
+        if (pthread_create(&th[i], NULL, batch_worker, &args[i]) != 0) { fprintf(stderr, "lo_batch_op: pthread_create failed\n"); abort(); }
     }
     for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
     free(th); free(args);
