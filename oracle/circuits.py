@@ -662,7 +662,7 @@ class BGVCtEvaluator:
 # ---------------------------------------------------------------------------------------------------------------
 # ckks.Evaluator at the rlwe.Ciphertext level (numpy arrays); scales are exact rationals, constants are encoded as
 # bigComplexToRNSScalar encodes them (schemes/ckks/scaling.go:10-43): with the reference's big.Float roundings restated on
-# integers (_keep / _const_to_int below; written apart from the product driver's lattigo_amd/drivers/schemes.py)
+# integers (_keep / _const_to_int below; written apart from the product driver's tests/drivers/schemes.py)
 # ---------------------------------------------------------------------------------------------------------------
 def _keep(num: int, den: int, bits: int):
     """(m, e): the nearest-even `bits`-bit approximation m 2^e of num / den (num, den > 0) -- a big.Float of that precision"""
@@ -877,7 +877,7 @@ class CKKSCtEvaluator:
 
 
 class OracleBootstrapBackend:
-    """adapters for lattigo_amd.drivers.bootstrapping.Bootstrapper over the oracle (test infrastructure)"""
+    """adapters for drivers.bootstrapping.Bootstrapper over the oracle (test infrastructure)"""
 
     def __init__(self, ckks: CKKSCtEvaluator, lte: LinTransEvaluator, ise: InnerSumEvaluator, EvkDenseToSparse=None,
                  EvkSparseToDense=None):

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (never imported by lattigo_amd/).  A second, independently organised restatement of the reference's
-polynomial evaluation on ciphertexts, written from the Go sources and not from lattigo_amd/drivers/polyeval.py, so that the
+polynomial evaluation on ciphertexts, written from the Go sources and not from tests/drivers/polyeval.py, so that the
 GPU tests stop comparing that driver with itself:
 
   circuits/common/polynomial/polynomial_evaluator.go:33-359   Evaluate, baby / giant steps, monomial combination

@@ -72,7 +72,7 @@ class ToyBootstrap:
 
     def __init__(self, rng, logN=9, K=12, deg=30, r=3, h=16):
         from fractions import Fraction
-        from lattigo_amd.drivers import mod1 as M1
+        from drivers import mod1 as M1
         self.N = N = 1 << logN
         self.q, self.p = O.GenModuli(logN + 1, [55] * 14, [55, 55])
         self.ringQ, self.ringP = O.Ring(N, self.q), O.Ring(N, self.p)
@@ -125,7 +125,7 @@ class ToyBootstrap:
         return ckks_encrypt(rng, r0, self.sk, z, self.Delta)
 
     def oracle_bootstrapper(self):
-        from lattigo_amd.drivers import bootstrapping as BS
+        from drivers import bootstrapping as BS
         from oracle import polyeval_ref as PR
         ce = OC.CKKSCtEvaluator(self.oev, self.rlk)
         be = OC.OracleBootstrapBackend(ce, OC.LinTransEvaluator(self.oev, self.gks), OC.InnerSumEvaluator(self.oev, self.gks))
@@ -139,7 +139,7 @@ class ToyBootstrap:
         return ckks_decrypt(sub, np.stack(res.Value), self.sk, res.Scale) * (2.0 ** 55 / self.Delta)
 
 
-from lattigo_amd.drivers.dft import (bitrev_indices, diag_matmul, fast_encode_rns, layer_diagonals, special_fft,  # noqa: E402,F401
+from drivers.dft import (bitrev_indices, diag_matmul, fast_encode_rns, layer_diagonals, special_fft,  # noqa: E402,F401
                              special_ifft)
 
 
@@ -149,16 +149,16 @@ def run_functional_bootstrap(logN, logq_res, n_stc, evalmod_bits, n_cts, cts_bit
     lattigo_amd.Context on the device.  Returns a dict with the precision and timings."""
     import time
     from fractions import Fraction
-    from lattigo_amd.drivers import bootstrapping as BS
-    from lattigo_amd.drivers import lintrans as LT
-    from lattigo_amd.drivers import mod1 as M1
+    from drivers import bootstrapping as BS
+    from drivers import lintrans as LT
+    from drivers import mod1 as M1
     from tests.helpers import prod, rng_for
     from tests.rlwe_fixtures import phase
     device = ctx is not None
     if device:
         import lattigo_amd as la
         from lattigo_amd import rlwe as R
-        from lattigo_amd.drivers import schemes as S
+        from drivers import schemes as S
     t_start = time.time()
     N, n, nth = 1 << logN, 1 << (logN - 1), 2 << logN
     depth = deg.bit_length() + r
@@ -205,8 +205,8 @@ def run_functional_bootstrap(logN, logq_res, n_stc, evalmod_bits, n_cts, cts_bit
         lt = OC.LinearTransformation(vec, level, LP - 1, n, N1)
         return lt, scale, set(r1) | set(r2)
 
-    if device:  # product path: lattigo_amd.drivers.dft encodes the factors with the device's NTT / MForm
-        from lattigo_amd.drivers import dft as DFT
+    if device:  # product path: drivers.dft encodes the factors with the device's NTT / MForm
+        from drivers import dft as DFT
         enc = DFT.Encoder(gQ, gP)
         cts, cts_sc, r_a = DFT.NewMatrices(enc, DFT.HomomorphicEncode, cts_groups, top, gain)
         stc, stc_sc, r_b = DFT.NewMatrices(enc, DFT.HomomorphicDecode, stc_groups, stc_top)

@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+_TESTS = os.path.join(ROOT, "tests")  # drivers/ lives here: test scaffolding, not part of the shipped package
+if _TESTS not in sys.path:
+    sys.path.insert(0, _TESTS)
 
 
 def pytest_configure(config):

@@ -1,4 +1,5 @@
-"""Host-side DRIVERS above the operator boundary -- not MI355X-native work.
+"""TEST SCAFFOLDING (tests/drivers, outside the shipped package lattigo_amd/ since round 5): host-side DRIVERS above the
+operator boundary -- not MI355X-native work.
 
 These modules restate, function by function, the control flow of the reference's own Go drivers that sit on
 `rlwe.EvaluatorProvider` / `schemes.Evaluator` (circuits/common/lintrans, circuits/common/polynomial, circuits/ckks/mod1,

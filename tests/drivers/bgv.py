@@ -4,8 +4,8 @@ over the device-resident ring and basis-extension operators.  The standard BGV t
 ``Evaluator.BGVMulRelin`` (rlwe.py)."""
 from __future__ import annotations
 
-from ..ring import BasisExtender, Poly, Ring
-from ..rlwe import EvaluationKey, Evaluator
+from lattigo_amd.ring import BasisExtender, Poly, Ring
+from lattigo_amd.rlwe import EvaluationKey, Evaluator
 
 
 class ScaleInvariantEvaluator:

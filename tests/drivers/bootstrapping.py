@@ -5,9 +5,9 @@ device-resident operators; the homomorphic DFTs sit on lintrans.py, the modular 
 host-driven circuit that is not part of this package."""
 from __future__ import annotations
 
-from .._lib import check, load
-from ..ring import Poly
-from ..rlwe import Decomposition, EvaluationKey, Evaluator, InnerSumEvaluator
+from lattigo_amd._lib import check, load
+from lattigo_amd.ring import Poly
+from lattigo_amd.rlwe import Decomposition, EvaluationKey, Evaluator, InnerSumEvaluator
 
 
 def ApplyEvaluationKey(ev: Evaluator, level: int, ctIn, evk: EvaluationKey, opOut):

@@ -147,7 +147,7 @@ class Encoder:
         self.N = ringQ.N
 
     def _up(self, ring, nl, values, scale, montgomery):
-        from ..ring import Poly
+        from lattigo_amd.ring import Poly
         p = Poly(ring, nl).upload(fast_encode_rns(values, self.N, scale, ring.ModuliChain()[:nl]))
         r = ring.AtLevel(nl - 1)
         r.NTT(p, p)
@@ -168,7 +168,7 @@ class Encoder:
     def Decode(self, pt, scale, is_ntt=True):
         """pt: a device Poly (batch 1) -> N/2 complex slots.  CRT reconstruction in Python big integers (host)."""
         from fractions import Fraction
-        from ..ring import Poly
+        from lattigo_amd.ring import Poly
         nl = pt.n_limbs
         r = self.ringQ.AtLevel(nl - 1)
         t = pt

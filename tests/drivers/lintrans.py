@@ -8,9 +8,9 @@ from __future__ import annotations
 
 import ctypes as C
 
-from .._lib import H, check, load
-from ..ring import BasisExtender, Poly
-from ..rlwe import Decomposition, Evaluator, GaloisElement, GaloisKeySet
+from lattigo_amd._lib import H, check, load
+from lattigo_amd.ring import BasisExtender, Poly
+from lattigo_amd.rlwe import Decomposition, Evaluator, GaloisElement, GaloisKeySet
 
 MAX_TERMS = 64  # terms per he_lintrans_mul_sum call
 

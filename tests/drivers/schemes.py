@@ -8,8 +8,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..ring import Poly
-from ..rlwe import EvaluationKey, Evaluator
+from lattigo_amd.ring import Poly
+from lattigo_amd.rlwe import EvaluationKey, Evaluator
 
 
 class _Base:

@@ -13,6 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from tests.bootstrap_fixtures import run_functional_bootstrap  # noqa: E402
 from tests.test_gpu_c5_bootstrap import C5  # noqa: E402
 

@@ -1,11 +1,11 @@
-"""lattigo_amd.drivers.dft host logic (numpy only): the special FFT, its factorisation into sparse diagonal-form factors, and the
+"""drivers.dft host logic (numpy only): the special FFT, its factorisation into sparse diagonal-form factors, and the
 double-precision slot encoder's rounding (circuits/ckks/dft/dft.go:368-470; schemes/ckks/encoder.go:160-330)."""
 from fractions import Fraction
 
 import numpy as np
 import pytest
 
-from lattigo_amd.drivers import dft as DFT
+from drivers import dft as DFT
 from oracle import oracle as O
 
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import lattigo_amd as la
-from lattigo_amd.drivers import lintrans as LT
+from drivers import lintrans as LT
 from lattigo_amd import rlwe as R
 from oracle import circuits as OC
 from oracle import oracle as O
@@ -202,7 +202,7 @@ def test_lintrans_mul_sum_kernel(ctx):
 def test_scale_invariant_multiplication(ctx, logN, logq, logp):
     """BFV-style MulRelinScaleInvariant (schemes/bgv/evaluator.go:898-1071) on the device vs the oracle: with and without
     relinearisation, the squaring branch, a lower level, a batch."""
-    from lattigo_amd.drivers import bgv as BGV
+    from drivers import bgv as BGV
     from tests.rlwe_fixtures import downstream_primes
     rg = Rig(ctx, logN, logq, logp, 4600 + logN)
     N, t = rg.N, 65537
@@ -238,7 +238,7 @@ def test_bootstrapping_modup(ctx, sparse, scale, logSlots, levelIn):
     """bootstrapping.Evaluator.ModUp (circuits/ckks/bootstrapping/evaluator.go:612-769): centred lifts with both sign
     conventions, the hoisting buffer filled with the lifted polynomial, message rescaling, Trace; bit-exact, batch 2.
     The first two coefficients are forced to q/2 and q/2 + 1 (where `>=` and `>` differ)."""
-    from lattigo_amd.drivers import bootstrapping as BS
+    from drivers import bootstrapping as BS
     rg = Rig(ctx, 10, [55, 45, 45, 50], [55, 46], 4700 + logSlots)
     nth, top = 2 * rg.N, len(rg.q) - 1
     rg.keys(R.GaloisElementsForTrace(nth, 10, logSlots) + [3, 7])
@@ -308,7 +308,7 @@ def test_ckks_rotation_call_sites(ctx):
 def test_scheme_evaluator_call_sites(ctx):
     """schemes.Evaluator ring-level call sites for CKKS and BGV (MulRelinThenAdd with and without relinearisation, the
     BGV scale-matching branch, ct x pt products, Add/Sub of unequal degrees) on the device vs the oracle, batch 2."""
-    from lattigo_amd.drivers import schemes as S
+    from drivers import schemes as S
     rg = Rig(ctx, 11, [55, 45, 45, 50], [55, 46], 4900)
     rg.keys([1])
     grlk, orlk = rg.ggks.keys[1], rg.ogks[1]
@@ -390,8 +390,8 @@ def test_bgv_polynomial_evaluation(ctx, deg):
     """circuits/bgv/polynomial Evaluator.Evaluate: the product driver on the device-resident bgv.Evaluator mirror vs the
     oracle's own restatement of the evaluator (oracle/polyeval_ref.py, written from the Go sources) on the oracle backend:
     the same primitive sequence with the same (level, scale, degree) after every call, and the same words; batch 2."""
-    from lattigo_amd.drivers import polyeval as PE
-    from lattigo_amd.drivers import schemes as S
+    from drivers import polyeval as PE
+    from drivers import schemes as S
     from oracle import polyeval_ref as PR
     rg = Rig(ctx, 10, [55, 45, 45, 45, 45, 45, 45, 45], [55, 55], 5100 + deg)
     rg.keys([1])
@@ -420,8 +420,8 @@ def test_ckks_polynomial_evaluation(ctx, deg, basis):
     scale planning): the product driver on the device-resident ckks.Evaluator mirror vs oracle/polyeval_ref.py on the oracle
     backend: the same primitive sequence and level / scale schedule, bit-exact words, batch 2."""
     from fractions import Fraction
-    from lattigo_amd.drivers import polyeval as PE
-    from lattigo_amd.drivers import schemes as S
+    from drivers import polyeval as PE
+    from drivers import schemes as S
     from oracle import polyeval_ref as PR
     rg = Rig(ctx, 10, [55] + [45] * 7, [55, 55], 5200 + deg)
     rg.keys([1])
@@ -451,8 +451,8 @@ def test_mod1(ctx, kind, K, deg, r):
     (oracle/polyeval_ref.py evaluate_mod1, fed the same approximation coefficients) on the oracle backend: the same primitive
     sequence and level / scale schedule, bit-exact words, batch 2."""
     from fractions import Fraction
-    from lattigo_amd.drivers import mod1 as M1
-    from lattigo_amd.drivers import schemes as S
+    from drivers import mod1 as M1
+    from drivers import schemes as S
     from oracle import polyeval_ref as PR
     rg = Rig(ctx, 10, [55] + [45] * 10, [55, 55], 5300 + K)
     rg.keys([1])
@@ -483,9 +483,9 @@ def test_toy_bootstrapping_end_to_end(ctx):
     evaluator.go:518-560) fully device-resident on the toy instance of tests/bootstrap_fixtures.py: every polynomial of the
     refreshed ciphertext equals the oracle-backed run bit for bit, and it decrypts to the input slots (BASELINE config 5's
     pipeline at toy size; batch 2)."""
-    from lattigo_amd.drivers import bootstrapping as BS
-    from lattigo_amd.drivers import mod1 as M1
-    from lattigo_amd.drivers import schemes as S
+    from drivers import bootstrapping as BS
+    from drivers import mod1 as M1
+    from drivers import schemes as S
     from tests.bootstrap_fixtures import ToyBootstrap
     rng = rng_for(5400)
     tb = ToyBootstrap(rng)
@@ -518,10 +518,10 @@ def test_toy_bootstrapping_end_to_end(ctx):
 
 @pytest.mark.gpu
 def test_ckks_encoder_and_dft_factors(ctx):
-    """lattigo_amd.drivers.dft: Encode is bit-identical to the oracle's NTT of the same rounded coefficients, Decode inverts it, and the
+    """drivers.dft: Encode is bit-identical to the oracle's NTT of the same rounded coefficients, Decode inverts it, and the
     factor lists multiply back to the special FFT (without its bit-reversal) and its inverse."""
     from fractions import Fraction
-    from lattigo_amd.drivers import dft as DFT
+    from drivers import dft as DFT
     logN = 9
     N, n = 1 << logN, 1 << (logN - 1)
     q, p = O.GenModuli(logN + 1, [55, 45, 45], [56])

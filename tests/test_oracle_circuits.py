@@ -146,7 +146,7 @@ def test_evaluate_many_shares_the_decomposition_and_levels():
 
 
 def test_host_helpers_of_the_product_match_the_oracle():
-    from lattigo_amd.drivers import lintrans as LT
+    from drivers import lintrans as LT
     from lattigo_amd import rlwe as R
 
     for diags, slots, N1 in (([0, 1, 2, 3, 9, 200, 511], 256, 8), ([5, 6, 7], 512, 4), (list(range(40)), 64, 16)):
@@ -286,7 +286,7 @@ def _ring_poly_eval(coeffs, m, t):
 def test_bgv_polynomial_evaluation_decrypts(deg):
     """circuits/bgv/polynomial Evaluator.Evaluate (Paterson-Stockmeyer over the power basis, level / scale planning by the
     simulated evaluator) with the oracle as the bgv.Evaluator backend: Dec(p(ct)) = p(m) in R_t, output scale = target."""
-    from lattigo_amd.drivers import polyeval as PE
+    from drivers import polyeval as PE
     from tests.rlwe_fixtures import bgv_decrypt, bgv_encrypt
     t = 65537
     q, p = O.GenModuli(10, [55, 45, 45, 45, 45, 45, 45], [55, 55])
@@ -316,7 +316,7 @@ def test_ckks_polynomial_evaluation_decrypts(deg, basis):
     """circuits/ckks/polynomial Evaluator.Evaluate (monomial and Chebyshev bases, complex coefficients) with the oracle as
     the ckks.Evaluator backend: the slots of Dec(p(ct)) equal p(slots of ct) to ~1e-7, output scale = target exactly."""
     from fractions import Fraction
-    from lattigo_amd.drivers import polyeval as PE
+    from drivers import polyeval as PE
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     q, p = O.GenModuli(10, [55] + [45] * 7, [55, 55])
     rng = rng_for(4000 + deg)
@@ -348,7 +348,7 @@ def test_mod1_evaluates_the_scaled_sine(kind, K, deg, r):
     """circuits/ckks/mod1 Evaluator.EvaluateNew (bootstrapping's EvalMod) with the oracle as the ckks.Evaluator backend:
     slots x / K in, QDiff / (2 pi) * sin(2 pi x) out (= QDiff * (x mod 1) for x close to an integer)."""
     from fractions import Fraction
-    from lattigo_amd.drivers import mod1 as M1
+    from drivers import mod1 as M1
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     q, p = O.GenModuli(10, [55] + [45] * 10, [55, 55])
     rng = rng_for(4100 + K)
@@ -391,7 +391,7 @@ def test_mod1_with_arcsine_is_linear_in_the_message():
     """Mod1InvDegree > 0 (mod1_parameters.go:117-137, mod1_evaluator.go:121-138): composing the scaled sine with the arcsine
     series removes the cubic term, so the result is QDiff * (x mod 1) even for a large message ratio 2^-3."""
     from fractions import Fraction
-    from lattigo_amd.drivers import mod1 as M1
+    from drivers import mod1 as M1
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     q, p = O.GenModuli(10, [55] + [45] * 12, [55, 55])
     rng = rng_for(4300)
@@ -421,7 +421,7 @@ def test_scale_down_brings_the_message_below_q0():
     ciphertext multiplied by an integer so that Q[0] / scale = MessageRatio; the slots are unchanged."""
     from fractions import Fraction
     from types import SimpleNamespace
-    from lattigo_amd.drivers import bootstrapping as BS
+    from drivers import bootstrapping as BS
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     q, p = O.GenModuli(10, [55, 45, 45], [55])
     rng = rng_for(4400)
@@ -441,7 +441,7 @@ def test_scale_down_brings_the_message_below_q0():
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# oracle/polyeval_ref.py (the independent restatement of the polynomial evaluator) against lattigo_amd/drivers/polyeval.py:
+# oracle/polyeval_ref.py (the independent restatement of the polynomial evaluator) against tests/drivers/polyeval.py:
 # same backend, same inputs -> the same sequence of primitive calls with the same (level, scale, degree) after each, and the
 # same words.  The restatement also decrypts to p(m) on its own.
 # ---------------------------------------------------------------------------------------------------------------
@@ -458,7 +458,7 @@ def _poly_rig(seed, logq, t=None):
 
 @pytest.mark.parametrize("deg", [1, 2, 3, 6, 7, 8, 15, 17, 33, 63])
 def test_polyeval_restatement_matches_the_driver_bgv(deg):
-    from lattigo_amd.drivers import polyeval as PE
+    from drivers import polyeval as PE
     from oracle import polyeval_ref as PR
     from tests.rlwe_fixtures import bgv_decrypt, bgv_encrypt
     t = 65537
@@ -483,7 +483,7 @@ def test_polyeval_restatement_matches_the_driver_bgv(deg):
                                                    (31, "Chebyshev", "odd", False), (63, "Chebyshev", "odd", False)])
 def test_polyeval_restatement_matches_the_driver_ckks(deg, basis, parity, lazy):
     from fractions import Fraction
-    from lattigo_amd.drivers import polyeval as PE
+    from drivers import polyeval as PE
     from oracle import polyeval_ref as PR
     from tests.rlwe_fixtures import ckks_decrypt, ckks_encrypt
     rng, q, ringQ, sk, ce = _poly_rig(6200 + deg, [55] + [45] * 8)
@@ -514,10 +514,10 @@ def test_polyeval_restatement_matches_the_driver_ckks(deg, basis, parity, lazy):
 
 @pytest.mark.parametrize("kind,K,deg,r,inv", [("cos", 8, 30, 2, 0), ("sin", 3, 31, 0, 0), ("hanki", 16, 30, 3, 0), ("cos", 8, 30, 1, 7)])
 def test_mod1_restatement_matches_the_driver(kind, K, deg, r, inv):
-    """oracle/polyeval_ref.py evaluate_mod1 against lattigo_amd/drivers/mod1.py on the same backend: the same primitive
+    """oracle/polyeval_ref.py evaluate_mod1 against tests/drivers/mod1.py on the same backend: the same primitive
     sequence with the same (level, scale, degree) after each call, the same words"""
     from fractions import Fraction
-    from lattigo_amd.drivers import mod1 as M1
+    from drivers import mod1 as M1
     from oracle import polyeval_ref as PR
     rng, q, ringQ, sk, ce = _poly_rig(6300 + K, [55] + [45] * 10)
     typ = {"cos": M1.CosContinuous, "sin": M1.SinContinuous, "hanki": M1.CosDiscrete}[kind]
@@ -540,7 +540,7 @@ def test_scale_rounding_helpers_agree_and_are_correctly_rounded():
     import decimal
     import random
     from fractions import Fraction
-    from lattigo_amd.drivers.mod1 import _bigfloat_round, _bigfloat_sqrt
+    from drivers.mod1 import _bigfloat_round, _bigfloat_sqrt
     from oracle.polyeval_ref import _keep_bits, _sqrt_bits
     rnd = random.Random(7)
     decimal.getcontext().prec = 120

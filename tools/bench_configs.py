@@ -14,6 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # drivers/ (test scaffolding)
 import lattigo_amd as la  # noqa: E402
 from bench import uniform  # noqa: E402
 
@@ -103,7 +104,7 @@ def main():
     out.append({"config": "c4", "what": "CKKS logN=16: hoisted Rotate (decomposition shared)", "batch": B, "ms": ms,
                 "ops_per_s": B / (ms * 1e-3)})
     # ---- lintrans / inner sum on the config-4 chain: host drivers over the device operators
-    from lattigo_amd.drivers import lintrans as LT
+    from drivers import lintrans as LT
     from lattigo_amd import rlwe as R
     B = 4
     nth, slots = 2 * N, N // 2

@@ -14,14 +14,16 @@ from fractions import Fraction
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))  # drivers/: the reference's host drivers restated (test scaffolding)
 import lattigo_amd as la  # noqa: E402
 from bench import uniform  # noqa: E402
-from lattigo_amd.drivers import bootstrapping as BS  # noqa: E402
-from lattigo_amd.drivers import lintrans as LT  # noqa: E402
-from lattigo_amd.drivers import mod1 as M1  # noqa: E402
+from drivers import bootstrapping as BS  # noqa: E402
+from drivers import lintrans as LT  # noqa: E402
+from drivers import mod1 as M1  # noqa: E402
 from lattigo_amd import rlwe as R  # noqa: E402
-from lattigo_amd.drivers import schemes as S  # noqa: E402
+from drivers import schemes as S  # noqa: E402
 
 # moduli of the right sizes, = 1 mod 2^17 (generated once with the reference's prime search; values only set the sizes)
 LOGQ = [60] + [40] * 9 + [39] * 3 + [60] * 8 + [56] * 4
