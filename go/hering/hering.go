@@ -71,6 +71,13 @@ func NewContext(device int) (*Context, error) {
 // Sync waits for everything enqueued on the context.
 func (c *Context) Sync() error { return lockedCall(func() C.int { return C.he_ctx_sync(c.h) }) }
 
+// SetCoalescing configures the context's submission queue (he_ctx_set_coalescing, include/hering.h): single-ciphertext calls of
+// ANY operator made at the same time from different goroutines -- ring methods, Rescale, the rlwe.EvaluatorProvider methods,
+// MulRelin -- are executed as batched launches over the callers' own device twins.  maxBatch <= 1 switches it off.
+func (c *Context) SetCoalescing(maxBatch, windowMicros int) error {
+	return lockedCall(func() C.int { return C.he_ctx_set_coalescing(c.h, C.int(maxBatch), C.int(windowMicros)) })
+}
+
 // Graph is a captured sequence of calls on a Context (he_graph_*, include/hering.h): one enqueue replays them all.
 type Graph struct {
 	ctx *Context

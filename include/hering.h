@@ -250,17 +250,24 @@ int he_evaluator_destroy(he_handle eval);
  * (schemes/schemes.go:14-28) and scales by running many such calls at once -- one goroutine per ciphertext over evaluators that
  * share their tables and keys (Evaluator.ShallowCopy / WithKey, core/rlwe/evaluator.go:200-227; b.RunParallel in
  * schemes/ckks/ckks_benchmarks_test.go:116-207).  A GPU wants those independent callers in one launch: with max_batch > 1,
- * the single-ciphertext forms (batch-1 polynomials) of he_ckks_mul_relin / he_bgv_mul_relin (with a relinearisation key),
- * he_gadget_product, he_relinearize and he_automorphism_ct on `eval` are filed in a submission queue; requests of the same
- * (operation, level, t / Galois element, key) waiting at the same time -- from any number of OS threads -- are executed as ONE
- * batched launch that addresses each caller's own polynomials through a device table of entry pointers (no staging copies), and
- * every call returns once its batch is enqueued on the context's stream (the usual contract: results are visible after
- * he_ctx_sync or a download).  window_us bounds how long a request waits for companions while the device is idle (a lone caller
- * does not wait at all); while two earlier batches are still in flight, gathering continues for free.  Results are bit-identical
- * to the uncoalesced calls.  max_batch <= 1 switches it off.  Calls with batch > 1, a MulRelin without a key, hoisted forms, and
- * calls made while the context records a graph are launched directly as before; shapes whose pipeline has no fused plans
- * (base-2 gadgets, conjugate-invariant rings, evaluators without special primes) are queued but served one by one. */
+ * the single-ciphertext forms (batch-1 polynomials) of EVERY operator entry point of this header -- the ring-level methods
+ * (he_ntt / he_intt, he_binop / he_unop / the scalar forms, he_shift, the automorphisms, the eight rescale variants), the basis
+ * extender's ModUp / ModDown, all seven rlwe.EvaluatorProvider methods (core/rlwe/rlwe.go:10-18: he_decompose_ntt,
+ * he_gadget_product[_lazy / _hoisted / _hoisted_lazy], he_moddown, he_eval_moddown_qp_to_q_ntt, he_relinearize,
+ * he_automorphism_ct / _hoisted / _hoisted_lazy), he_ckks_mul_relin / he_bgv_mul_relin with or without a key, he_centered_lift,
+ * he_decomp_fill and he_lintrans_mul_sum -- on the context of `eval` are filed in that context's submission queue; requests of the
+ * same (operation, object, scalar arguments, key, aliasing pattern of the operands) waiting at the same time -- from any number of
+ * OS threads -- are executed as ONE batched launch that addresses each caller's own polynomials and hoisting buffers through a
+ * device table of entry offsets (no staging copies), and every call returns once its batch is enqueued on the context's stream
+ * (the usual contract: results are visible after he_ctx_sync or a download).  A thread's own calls keep their order.  window_us
+ * bounds how long a request waits for companions while the device is idle (a lone caller does not wait at all); while two earlier
+ * batches are still in flight, gathering continues for free.  Results are bit-identical to the uncoalesced calls.  max_batch <= 1
+ * switches it off.  Calls with batch > 1 and calls made while the context records a graph are launched directly as before; shapes
+ * whose launches take no entry tables (base-2 gadgets, conjugate-invariant rings, evaluators without special primes, key switches
+ * that write onto their own operand) are queued but served one by one.  The queue belongs to the CONTEXT (all objects of a context
+ * share one stream): he_ctx_set_coalescing is the same switch addressed through the context handle. */
 int he_evaluator_set_coalescing(he_handle eval, int max_batch, int window_us);
+int he_ctx_set_coalescing(he_handle ctx, int max_batch, int window_us);
 
 /* GadgetCiphertext (core/rlwe/gadgetciphertext.go:19-42), BaseTwoDecomposition = 0.
  * Host image: q[beta][2][nQk][N], p[beta][2][nPk][N], NTT + Montgomery form.     */

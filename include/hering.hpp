@@ -62,6 +62,9 @@ public:
     }
     he_handle h() const { return r_->h; }
     void Sync() const { check(he_ctx_sync(h())); }
+    // the submission queue of the context (hering.h, he_ctx_set_coalescing): concurrent single-ciphertext calls of any operator --
+    // one thread per ciphertext, the reference's b.RunParallel shape -- become batched launches over the callers' own polynomials
+    void SetCoalescing(int maxBatch = 64, int windowMicros = 30) const { check(he_ctx_set_coalescing(h(), maxBatch, windowMicros)); }
     static int DeviceCount() {
         int n = 0;
         check(he_device_count(&n));
@@ -574,6 +577,7 @@ public:
         for (size_t i = 0; i < op0.Value.size(); i++) r.DivRoundByLastModulusManyNTT(nbRescales, op0.Value[i], opOut.Value.at(i));
     }
     // the reference's parallel mode (many goroutines, one ciphertext per call) gathered into batched launches: hering.h
+    // (the queue belongs to the evaluator's context and serves every operator of that context: Context::SetCoalescing is the same switch)
     void SetCoalescing(int maxBatch = 64, int windowMicros = 30) const { check(he_evaluator_set_coalescing(h(), maxBatch, windowMicros)); }
 
 private:

@@ -35,6 +35,7 @@ int he_probe_modmul_f64(he_handle ctx, int iters, double *mults_per_s);
  * out[1] = batched launches made for them, out[2] = largest batch, out[3] = calls that ran one by one because their pipeline
  * has launches without entry tables */
 int he_evaluator_coalescing_stats(he_handle eval, uint64_t out[4]);
+int he_ctx_coalescing_stats(he_handle ctx, uint64_t out[4]);  /* the same counters through the context handle */
 /* Concurrent single-ciphertext callers, the shape of the reference's parallel benchmarks (b.RunParallel,
  * schemes/ckks/ckks_benchmarks_test.go:116-207): n_threads OS threads (pthreads inside the library: no interpreter in the timed
  * region); thread i makes `iters` calls on its own batch-1 handles -- op 0: he_ckks_mul_relin(eval[i], level, a0[i], a1[i], b0[i],

@@ -127,9 +127,24 @@ def _declare(L):
         "he_rccl_comm_destroy": [H], "he_rccl_comm_ranks": [H, C.POINTER(i)], "he_evk_broadcast": [H, H, i],
         "he_poly_all_reduce_sum": [H, H],
         "he_evaluator_set_coalescing": [H, i, i], "he_evaluator_coalescing_stats": [H, u64p],
+        "he_ctx_set_coalescing": [H, i, i], "he_ctx_coalescing_stats": [H, u64p],
         "he_debug_concurrent_mul_relin": [i, i, i, i, i, C.c_uint64, HP, HP, HP, HP, HP, HP, HP, HP, HP, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    if os.environ.get("HERING_CALL_STATS"):  # diagnosis: histogram of the ABI calls of a run, written at exit (tools/)
+        import atexit
+        import collections
+        import json
+        counts = collections.Counter()
+
+        def wrap(name, fn):
+            def call(*a):
+                counts[name] += 1
+                return fn(*a)
+            return call
+        for name in sig:
+            setattr(L, name, wrap(name, getattr(L, name)))
+        atexit.register(lambda: json.dump(dict(counts.most_common()), open(os.environ["HERING_CALL_STATS"], "w"), indent=1))

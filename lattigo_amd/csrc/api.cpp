@@ -13,6 +13,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -66,6 +67,84 @@ struct Obj {
     virtual ~Obj() {}
 };
 
+// Submission queue of a context (he_ctx_set_coalescing / he_evaluator_set_coalescing): concurrent single-ciphertext calls of one
+// operation are gathered into ONE batched launch over an entry table of the callers' own polynomials (View::tab).  The reference's
+// unit of parallelism is a goroutine per ciphertext on CPU cores (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:116-207, over
+// evaluators that share their tables, core/rlwe/evaluator.go:200-227; the bootstrapping benchmark runs whole circuits that way,
+// circuits/ckks/bootstrapping/evaluator_benchmarks_test.go:14-42); a GPU wants those callers in one grid.  Flat combining:
+// a caller files its request; whoever finds no leader becomes the leader, gathers for at most `window_us` (no limit while two
+// earlier batches are still in flight on the device -- waiting is free then), launches every pending request of the oldest
+// request's key as one batch, marks them done and hands the role over.  A call returns once its batch is ENQUEUED on the
+// context's stream (the library's usual contract: results are visible after he_ctx_sync / a download).
+//
+// Round 5: the queue belongs to the CONTEXT and a request is generic -- (operation, the object it addresses, its scalar
+// arguments) is the key, the operands are a list of device views, and the launches are a closure over everything in the key that
+// is handed the operands as views (one request: its own; a batch: entry 0's base pointers + entry tables).  Every entry point of
+// the one-ciphertext interface files such a request (the ring-level methods, Rescale, the seven rlwe.EvaluatorProvider methods,
+// the lintrans inner loop), not only the four key switches of round 4.
+enum CoOp {
+    CO_MUL_RELIN = 0, CO_GADGET_PRODUCT, CO_RELINEARIZE, CO_AUTOMORPHISM,
+    CO_NTT, CO_EW, CO_EW_DOUBLE, CO_SHIFT, CO_RESCALE, CO_GATHER, CO_AUTO_COEFF, CO_MODUP, CO_MODDOWN_BE,
+    CO_DECOMPOSE_SPLIT, CO_DECOMPOSE_NTT, CO_GP_LAZY, CO_GP_HOISTED_LAZY, CO_GP_HOISTED, CO_MODDOWN, CO_EVAL_MODDOWN,
+    CO_AUTO_HOISTED, CO_AUTO_HOISTED_LAZY, CO_CENTERED_LIFT, CO_DECOMP_FILL, CO_LINTRANS, CO_MUL, CO_COPY
+};
+struct CoReq {
+    // ---- key: requests are batched together only when all of this matches
+    int op = 0;
+    const void *obj = nullptr;      // the ring / basis extender / evaluator the call addresses
+    const void *key = nullptr;      // evaluation key (or index table) identity
+    int64_t par[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the call's scalar arguments; par[7] = aliasing pattern of the operands
+    std::vector<uint64_t> blob;     // scalar arguments of variable size (per-limb scalars, ...), compared by value
+    // ---- operands: device views of this request's own polynomials (null pointer: operand absent)
+    std::vector<View> ops;
+    std::vector<std::shared_ptr<Obj>> keep;  // what the launches address stays alive until they are enqueued
+    // the launches over B entries, v[s] = operand s (this request's views, or entry 0's pointer + an entry table).  It must
+    // capture nothing that is not covered by the key: a batch runs the closure of its FIRST request for everyone.
+    std::function<int(const View *v, int B)> run;
+    // optional: may this shape be addressed through entry tables (false: the batch is served one by one)?
+    std::function<int(bool *ok)> tables_ok;
+    // ---- queue state
+    std::chrono::steady_clock::time_point arrived;
+    bool done = false, lead = false;  // lead: the leaving leader handed the role to this (still waiting) request
+    int rc = 0;
+    std::string err;
+    std::condition_variable cv;       // its own: a finished batch wakes exactly its callers, an arrival only the leader
+    bool same_key(const CoReq &o) const {
+        return op == o.op && obj == o.obj && key == o.key && memcmp(par, o.par, sizeof par) == 0 && ops.size() == o.ops.size() &&
+               blob == o.blob;
+    }
+    // par[7]: which operands are the same polynomial (bit i * n + j for i < j): the launches decide in-place forms on entry 0's
+    // pointers, so every entry of a batch must alias the same way
+    void set_alias_pattern() {
+        uint64_t m = 0;
+        int bit = 0;
+        const size_t n = ops.size() < 11 ? ops.size() : 11;
+        for (size_t i = 0; i < n; i++)
+            for (size_t j = i + 1; j < n; j++, bit++)
+                if (ops[i].p && ops[i].p == ops[j].p) m |= 1ull << bit;
+        par[7] = (int64_t)m;
+    }
+};
+struct Coalescer {
+    std::mutex mu;
+    std::condition_variable cv_leader;  // the gathering leader waits here for arrivals while the device is busy
+    std::deque<CoReq *> pending;
+    bool leader = false;
+    int recent[4] = {0, 0, 0, 0};     // sizes of the last batches: callers that wait for their results come back together
+    // read without the lock by every single-ciphertext call that asks "is the queue on?": atomic.  0 / 1 = off.
+    std::atomic<int> max_batch{0};
+    int window_us = 0;
+    size_t *d_tab = nullptr;  // [rows][B] entry offsets; one table is enough (stream order, see launch_tab_fill)
+    size_t tab_words = 0;     // capacity of d_tab: a batch whose table does not fit is served one by one
+    std::deque<hipEvent_t> inflight;  // one event per launched batch, oldest first
+    std::vector<hipEvent_t> free_events;
+    uint64_t n_calls = 0, n_launches = 0, n_max = 0, n_fallback = 0;  // he_ctx_coalescing_stats
+    // > 0 while recent traffic showed callers overlapping (a batch of more than one request, or requests left waiting when a
+    // batch was taken): a lone caller -- no one to wait for -- is launched without the gathering window
+    int crowd = 0;
+};
+
+
 struct Ctx : Obj {
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -74,6 +153,7 @@ struct Ctx : Obj {
     uint64_t *arena = nullptr;
     size_t arena_words = 0, arena_used = 0;
     std::mutex mu;
+    const std::unique_ptr<Coalescer> co{new Coalescer()};  // always there (off until he_ctx_set_coalescing): no pointer to race on
     // he_ctx_sync from many threads: one drains the stream, the others wait for a drain that covers their ticket
     std::mutex sync_mu;
     std::condition_variable sync_cv;
@@ -155,6 +235,9 @@ struct Ctx : Obj {
         hipSetDevice(dev);
         if (stream) hipStreamSynchronize(stream);
         pool_release_all();
+        if (co->d_tab) hipFree(co->d_tab);
+        for (hipEvent_t e : co->inflight) hipEventDestroy(e);
+        for (hipEvent_t e : co->free_events) hipEventDestroy(e);
         if (arena) hipFree(arena);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
@@ -369,57 +452,10 @@ struct FusedPlan {
     bool ok = false;
     std::vector<FusedGroup> groups;
 };
-// Submission queue of an evaluator (he_evaluator_set_coalescing): concurrent single-ciphertext calls of one operation are
-// gathered into ONE batched launch over an entry table of the callers' own polynomials (View::tab).  The reference's unit of
-// parallelism is a goroutine per ciphertext on CPU cores (b.RunParallel, schemes/ckks/ckks_benchmarks_test.go:116-207, over
-// evaluators that share their tables, core/rlwe/evaluator.go:200-227); a GPU wants those callers in one grid.  Flat combining:
-// a caller files its request; whoever finds no leader becomes the leader, gathers for at most `window_us` (no limit while two
-// earlier batches are still in flight on the device -- waiting is free then), launches every pending request of the oldest
-// request's key as one batch, marks them done and hands the role over.  A call returns once its batch is ENQUEUED on the
-// context's stream (the library's usual contract: results are visible after he_ctx_sync / a download).
 struct Poly;
 struct Evk;
-enum CoOp { CO_MUL_RELIN = 0, CO_GADGET_PRODUCT, CO_RELINEARIZE, CO_AUTOMORPHISM };
-struct CoReq {
-    // key: requests are batched together only when all of this matches
-    int op = CO_MUL_RELIN;
-    int level = 0;
-    bool bgv = false, alias = false;
-    uint64_t t = 0;  // BGV plaintext modulus (MulRelin) / Galois element (Automorphism)
-    std::shared_ptr<Evk> key;
-    // operands by operation: MulRelin a0 a1 b0 b1 -> o0 o1; GadgetProduct a0 (= cx) -> o0 o1; Relinearize a0 a1 b0 (= in0 in1 in2)
-    // -> o0 o1; Automorphism a0 a1 (= in0 in1) -> o0 o1
-    std::shared_ptr<Poly> a0, a1, b0, b1, o0, o1;
-    std::chrono::steady_clock::time_point arrived;
-    bool done = false, lead = false;  // lead: the leaving leader handed the role to this (still waiting) request
-    int rc = 0;
-    std::string err;
-    std::condition_variable cv;       // its own: a finished batch wakes exactly its callers, an arrival only the leader
-    bool same_key(const CoReq &o) const {
-        return op == o.op && level == o.level && bgv == o.bgv && alias == o.alias && t == o.t && key == o.key;
-    }
-};
-struct Coalescer {
-    std::mutex mu;
-    std::condition_variable cv_leader;  // the gathering leader waits here for arrivals while the device is busy
-    std::deque<CoReq *> pending;
-    bool leader = false;
-    int recent[4] = {0, 0, 0, 0};     // sizes of the last batches: callers that wait for their results come back together
-    // read without the lock by every single-ciphertext call that asks "is the queue on?": atomic.  0 / 1 = off.
-    std::atomic<int> max_batch{0};
-    int window_us = 0;
-    size_t *d_tab = nullptr;  // [6][tab_cap] entry offsets; one table is enough (stream order, see launch_tab_fill)
-    int tab_cap = 0;          // entries per row of d_tab: a batch gathered under an older, larger max_batch is served one by one
-    std::deque<hipEvent_t> inflight;  // one event per launched batch, oldest first
-    std::vector<hipEvent_t> free_events;
-    uint64_t n_calls = 0, n_launches = 0, n_max = 0, n_fallback = 0;  // he_evaluator_coalescing_stats
-    // > 0 while recent traffic showed callers overlapping (a batch of more than one request, or requests left waiting when a
-    // batch was taken): a lone caller -- no one to wait for -- is launched without the gathering window
-    int crowd = 0;
-};
 struct Evaluator : Obj {
     std::shared_ptr<BasisExtender> be;
-    const std::unique_ptr<Coalescer> co{new Coalescer()};  // always there (off until he_evaluator_set_coalescing): no pointer to race on
     ConstPool pool;
     // automorphism index tables by Galois element, built on first use and kept (the reference caches them the same way:
     // Evaluator.automorphismIndex, core/rlwe/evaluator.go:81-86,:190-205); N x 4 bytes each
@@ -436,11 +472,6 @@ struct Evaluator : Obj {
         hipStreamSynchronize(be->ctx->stream);
         for (ModUpDesc *p : plan_mem) hipFree(p);
         for (auto &kv : auto_index) hipFree(kv.second);
-        if (co) {
-            if (co->d_tab) hipFree(co->d_tab);
-            for (hipEvent_t e : co->inflight) hipEventDestroy(e);
-            for (hipEvent_t e : co->free_events) hipEventDestroy(e);
-        }
         pool.release();
     }
 };
@@ -475,6 +506,7 @@ struct Decomp : Obj {
         if (d) ev->be->ctx->pool_give((size_t)batch * bstride() * 8, d);
     }
     size_t bstride() const { return (size_t)beta_max * width * ev->be->Q->N; }
+    View view() const { return View{d, bstride()}; }
     size_t dstride() const { return (size_t)width * ev->be->Q->N; }
 };
 
@@ -520,6 +552,152 @@ struct Scope {  // per-call: select device, lock the context, reset the scratch 
     }
     ~Scope() { c->mu.unlock(); }
 };
+
+// ---- the context's submission queue (struct Coalescer): coalescing of concurrent single-ciphertext calls ---------------------
+constexpr size_t kTabRowsMin = 16;  // rows of the entry table reserved per batch entry (he_ctx_set_coalescing sizes it)
+int co_inflight(Coalescer &c) {  // batches still running or queued on the device (caller holds c.mu)
+    while (!c.inflight.empty() && hipEventQuery(c.inflight.front()) == hipSuccess) {
+        c.free_events.push_back(c.inflight.front());
+        c.inflight.pop_front();
+    }
+    (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    return (int)c.inflight.size();
+}
+// the launches of `batch` (all of one key): one batched launch sequence over entry tables where the shape allows, one call per
+// request otherwise.  Fills every request's own status / message; returns the number of requests served one by one.
+int co_run(Ctx &ctx, Coalescer &c, const std::vector<CoReq *> &batch, hipEvent_t done_ev) {
+    CoReq &r0 = *batch[0];
+    const int B = (int)batch.size();
+    const size_t ns = r0.ops.size();
+    Scope sc(&ctx);
+    bool tables = B > 1;
+    int rc = HE_OK;
+    if (tables && r0.tables_ok) rc = r0.tables_ok(&tables);
+    if (rc == HE_OK && tables && ns * (size_t)B > c.tab_words) tables = false;  // (gathered under a larger max_batch than the table was sized for)
+    // an operand present in one request and absent in another cannot share a table row (the key fixes the count, not the nulls)
+    for (int z = 1; tables && z < B; z++)
+        for (size_t s = 0; s < ns; s++) tables = tables && (batch[z]->ops[s].p == nullptr) == (r0.ops[s].p == nullptr);
+    int fallback = 0;
+    if (rc != HE_OK) {
+        const std::string msg = g_err;
+        for (CoReq *r : batch) { r->rc = rc; r->err = msg; }
+    } else if (B == 1 || !tables) {
+        // one entry, or a shape whose pipeline has launches without entry tables (unfused ModDown, conjugate-invariant rings,
+        // base-2 gadgets): one call per request, each with its own status
+        if (B > 1) fallback = B;
+        for (CoReq *r : batch) {
+            ctx.arena_reset();
+            r->rc = r->run(r->ops.data(), 1);
+            if (r->rc != HE_OK) r->err = g_err;
+        }
+    } else {
+        // entry tables: row s of the table holds, per entry, the word offset of that entry's operand s from entry 0's
+        std::vector<size_t> vals(ns * (size_t)B, 0);
+        std::vector<View> v(ns);
+        for (size_t s = 0; s < ns; s++) {
+            uint64_t *base = r0.ops[s].p;
+            if (!base) { v[s] = View{nullptr, 0}; continue; }
+            for (int z = 0; z < B; z++) vals[s * B + z] = (size_t)(batch[z]->ops[s].p - base);
+            v[s] = View{base, 0, c.d_tab + s * B};
+        }
+        hipError_t e = launch_tab_fill(c.d_tab, vals.data(), (int)vals.size(), ctx.stream);
+        if (e != hipSuccess) rc = fail(HE_EDEVICE, "launch_tab_fill: %s", hipGetErrorString(e));
+        else rc = r0.run(v.data(), B);
+        const std::string msg = rc ? g_err : std::string();
+        for (CoReq *r : batch) { r->rc = rc; r->err = msg; }
+    }
+    if (done_ev && hipEventRecord(done_ev, ctx.stream) != hipSuccess) (void)hipGetLastError();
+    return fallback;
+}
+// the calling thread is the leader: serve batches until its own request is done (caller holds lk on c.mu)
+void co_lead(Ctx &ctx, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mine) {
+    using clock = std::chrono::steady_clock;
+    hipSetDevice(ctx.dev);
+    while (!mine.done) {
+        // gather: up to max_batch requests.  While the device still has two batches of this queue ahead of it, waiting is free.
+        // Otherwise stop once no request has arrived for window_us AND at least half of the recent batches' callers are here
+        // (callers that wait for their result come back together, as fast as the OS schedules them), or 8 window_us after the
+        // oldest request arrived.  No window at all for a lone caller (crowd == 0).
+        const int hint = std::max(std::max(c.recent[0], c.recent[1]), std::max(c.recent[2], c.recent[3]));
+        // (at least one: a request that passed the "queue on?" test just before the queue was switched off is still served)
+        const int max_batch = std::max(1, c.max_batch.load(std::memory_order_relaxed));
+        for (;;) {
+            if ((int)c.pending.size() >= max_batch) break;
+            const bool busy = co_inflight(c) >= 2;
+            const auto now = clock::now();
+            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.front()->arrived).count();
+            const auto quiet = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.back()->arrived).count();
+            const long long win = c.crowd > 0 ? c.window_us : 0;
+            if (!busy && ((quiet >= win && 2 * (int)c.pending.size() >= hint) || waited >= 8 * win)) break;
+            if (busy) {
+                c.cv_leader.wait_for(lk, std::chrono::microseconds(100));  // arrivals notify
+            } else {  // a few microseconds: a timed futex wait would oversleep by the timer slack
+                lk.unlock();
+                sched_yield();
+                lk.lock();
+            }
+        }
+        std::vector<CoReq *> batch;
+        const CoReq &head = *c.pending.front();
+        for (auto it = c.pending.begin(); it != c.pending.end() && (int)batch.size() < max_batch;) {
+            if ((*it)->same_key(head)) { batch.push_back(*it); it = c.pending.erase(it); }
+            else ++it;
+        }
+        if (batch.size() > 1 || !c.pending.empty()) c.crowd = 256;
+        else if (c.crowd > 0) c.crowd--;
+        c.recent[c.n_launches & 3] = (int)batch.size();
+        // the completion event feeds the "two batches ahead" test of the gathering loop: not needed for a lone caller, whose
+        // stream drain would otherwise also wait for the event's barrier packet (a third of a single-ciphertext call's latency)
+        hipEvent_t e = nullptr;
+        if (c.crowd > 0) {
+            if (!c.free_events.empty()) { e = c.free_events.back(); c.free_events.pop_back(); }
+            else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        }
+        c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
+        lk.unlock();
+        const int fallback = co_run(ctx, c, batch, e);
+        lk.lock();
+        c.n_fallback += (uint64_t)fallback;
+        if (e) c.inflight.push_back(e);
+        for (CoReq *r : batch) {
+            r->done = true;
+            if (r != &mine) r->cv.notify_one();
+        }
+    }
+}
+int co_submit(Ctx &ctx, CoReq &r) {
+    Coalescer &c = *ctx.co;
+    std::unique_lock<std::mutex> lk(c.mu);
+    r.arrived = std::chrono::steady_clock::now();
+    c.pending.push_back(&r);
+    if (c.leader) c.cv_leader.notify_one();  // a gathering leader counts arrivals
+    while (!r.done) {
+        if (!c.leader || r.lead) {
+            c.leader = true;
+            r.lead = false;
+            co_lead(ctx, c, lk, r);
+            // hand the role to the oldest request still waiting (it is asleep on its own condition variable), if any
+            if (!c.pending.empty()) { c.pending.front()->lead = true; c.pending.front()->cv.notify_one(); }
+            else c.leader = false;
+        } else {
+            r.cv.wait(lk);
+        }
+    }
+    lk.unlock();
+    if (r.rc != HE_OK) return fail(r.rc, "%s", r.err.c_str());
+    return HE_OK;
+}
+// Every entry point of the one-ciphertext interface ends here: a call over one batch entry on a context whose queue is on (and
+// that is not recording a graph: a captured sequence must be this thread's own launches) joins the queue; everything else runs
+// its launches at once under the context's lock.
+int co_dispatch(Ctx &ctx, int B, CoReq &r) {
+    if (B == 1 && ctx.co->max_batch.load(std::memory_order_relaxed) > 1 && !ctx.capturing) {
+        r.set_alias_pattern();
+        return co_submit(ctx, r);
+    }
+    Scope sc(&ctx);
+    return r.run(r.ops.data(), B);
+}
 
 LimbTab ident_tab(int n, int in0 = 0, int out0 = 0, int mod0 = 0) {
     LimbTab t;
@@ -889,10 +1067,17 @@ static int ntt_api(he_handle hring, int level, he_handle h1, he_handle h2, bool 
     TRY(check_poly(*p1, *r, level, who));
     TRY(check_poly(*p2, *r, level, who));
     if (p1->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
-    Scope sc(r->ctx.get());
-    r->ctx->acct(2.0 * (level + 1), 0, p1->batch, r->N);  // NTT / INTT: 2 L limbs
-    HIP_TRY(ring_ntt(*r, ident_tab(level + 1), p1->view(), p2->view(), p1->batch, inverse, flags | NTT_REDUCE_INPUT));
-    return HE_OK;
+    CoReq q;
+    q.op = CO_NTT; q.obj = r.get(); q.par[0] = level; q.par[1] = inverse; q.par[2] = flags;
+    q.ops = {p1->view(), p2->view()};
+    q.keep = {r, p1, p2};
+    q.run = [r, level, inverse, flags](const View *v, int B) -> int {
+        r->ctx->acct(2.0 * (level + 1), 0, B, r->N);  // NTT / INTT: 2 L limbs
+        HIP_TRY(ring_ntt(*r, ident_tab(level + 1), v[0], v[1], B, inverse, flags | NTT_REDUCE_INPUT));
+        return HE_OK;
+    };
+    q.tables_ok = [r](bool *ok) -> int { *ok = r->type == 0; return HE_OK; };  // (the conjugate-invariant fold takes no entry tables)
+    return co_dispatch(*r->ctx, p1->batch, q);
 }
 int he_ntt(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, false, 0, "he_ntt"); }
 int he_ntt_lazy(he_handle r, int level, he_handle p1, he_handle p2) { return ntt_api(r, level, p1, p2, false, NTT_LAZY_OUT, "he_ntt_lazy"); }
@@ -934,14 +1119,19 @@ int he_binop(he_handle hring, int level, int op, he_handle h1, he_handle h2, he_
     View v1 = p1->view(), v2 = p2->view();
     if (p1->batch != p3->batch) v1.bstride = 0;
     if (p2->batch != p3->batch) v2.bstride = 0;
-    Scope sc(r->ctx.get());
-    {   // binary 3 L, ...ThenAdd / ...ThenSub 4 L; a batch-1 operand is read once for the whole batch
+    CoReq q;
+    q.op = CO_EW; q.obj = r.get(); q.par[0] = level; q.par[1] = op;
+    q.ops = {v1, v2, p3->view()};
+    q.keep = {r, p1, p2, p3};
+    q.run = [r, level, op](const View *v, int B) -> int {
+        // binary 3 L, ...ThenAdd / ...ThenSub 4 L; a batch-1 operand is read once for the whole batch
         const bool then = op == EW_MUL_BARRETT_THEN_ADD || op == EW_MUL_BARRETT_THEN_ADD_LAZY || (op >= EW_MUL_MONT_THEN_ADD && op <= EW_MUL_MONT_LAZY_THEN_SUB_LAZY);
-        const double sh = (double)(v1.bstride == 0 && p3->batch > 1) + (double)(v2.bstride == 0 && p3->batch > 1);
-        r->ctx->acct(((then ? 4.0 : 3.0) - sh) * (level + 1), sh * (level + 1), p3->batch, r->N);
-    }
-    HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), op, v1, v2, p3->view(), p3->batch, nullptr, nullptr, r->ctx->stream));
-    return HE_OK;
+        const double sh = (double)(v[0].bstride == 0 && !v[0].tab && B > 1) + (double)(v[1].bstride == 0 && !v[1].tab && B > 1);
+        r->ctx->acct(((then ? 4.0 : 3.0) - sh) * (level + 1), sh * (level + 1), B, r->N);
+        HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), op, v[0], v[1], v[2], B, nullptr, nullptr, r->ctx->stream));
+        return HE_OK;
+    };
+    return co_dispatch(*r->ctx, p3->batch, q);
 }
 int he_unop(he_handle hring, int level, int op, he_handle h1, he_handle h2) {
     GET(r, Ring, hring, T_RING);
@@ -951,16 +1141,33 @@ int he_unop(he_handle hring, int level, int op, he_handle h1, he_handle h2) {
     TRY(check_poly(*p1, *r, level, "he_unop"));
     TRY(check_poly(*p2, *r, level, "he_unop"));
     if (p1->batch != p2->batch) return fail(HE_EINVAL, "he_unop: batch mismatch");
-    Scope sc(r->ctx.get());
-    r->ctx->acct(2.0 * (level + 1), 0, p2->batch, r->N);  // unary: 2 L
-    HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), EW_NEG + op, p1->view(), p1->view(), p2->view(), p2->batch, nullptr, nullptr, r->ctx->stream));
-    return HE_OK;
+    CoReq q;
+    q.op = CO_EW; q.obj = r.get(); q.par[0] = level; q.par[1] = EW_NEG + op;
+    q.ops = {p1->view(), p2->view()};
+    q.keep = {r, p1, p2};
+    q.run = [r, level, op](const View *v, int B) -> int {
+        r->ctx->acct(2.0 * (level + 1), 0, B, r->N);  // unary: 2 L
+        HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), EW_NEG + op, v[0], v[0], v[1], B, nullptr, nullptr, r->ctx->stream));
+        return HE_OK;
+    };
+    return co_dispatch(*r->ctx, p2->batch, q);
 }
 // scalar given per limb (already what the kernel consumes)
-static int scalar_launch(Ring &r, int level, int ewop, Poly &p1, Poly &p2, const ScalarTab &st) {
-    r.ctx->acct((ewop == EW_MUL_SCALAR_MONT_THEN_ADD ? 3.0 : 2.0) * (level + 1), 0, p2.batch, r.N);  // unary (3 L with the addend)
-    HIP_TRY(launch_ew(r.dev, ident_tab(level + 1), ewop, p1.view(), p1.view(), p2.view(), p2.batch, &st, nullptr, r.ctx->stream));
-    return HE_OK;
+static int scalar_launch(const std::shared_ptr<Ring> &r, int level, int ewop, const std::shared_ptr<Poly> &p1,
+                         const std::shared_ptr<Poly> &p2, const ScalarTab &st, bool dbl = false) {
+    CoReq q;
+    q.op = dbl ? CO_EW_DOUBLE : CO_EW; q.obj = r.get(); q.par[0] = level; q.par[1] = ewop; q.par[2] = 1;  // (par[2]: a scalar form)
+    q.blob.assign(st.s, st.s + level + 1);
+    if (dbl) q.blob.insert(q.blob.end(), st.s2, st.s2 + level + 1);
+    q.ops = {p1->view(), p2->view()};
+    q.keep = {r, p1, p2};
+    q.run = [r, level, ewop, st, dbl](const View *v, int B) -> int {
+        r->ctx->acct((ewop == EW_MUL_SCALAR_MONT_THEN_ADD ? 3.0 : 2.0) * (level + 1), 0, B, r->N);  // unary (3 L with the addend)
+        if (dbl) HIP_TRY(launch_ew_double(r->dev, ident_tab(level + 1), ewop, v[0], v[1], B, &st, r->ctx->stream));
+        else HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), ewop, v[0], v[0], v[1], B, &st, nullptr, r->ctx->stream));
+        return HE_OK;
+    };
+    return co_dispatch(*r->ctx, p2->batch, q);
 }
 int he_scalarop(he_handle hring, int level, int op, he_handle h1, uint64_t scalar, he_handle h2) {
     GET(r, Ring, hring, T_RING);
@@ -990,8 +1197,7 @@ int he_scalarop(he_handle hring, int level, int op, he_handle h1, uint64_t scala
         case HE_MUL_SCALAR: ewop = EW_MUL_SCALAR_MONT; break;
         default: ewop = EW_MUL_SCALAR_MONT_THEN_ADD; break;
     }
-    Scope sc(r->ctx.get());
-    return scalar_launch(*r, level, ewop, *p1, *p2, st);
+    return scalar_launch(r, level, ewop, p1, p2, st);
 }
 int he_mul_rns_scalar_montgomery(he_handle hring, int level, he_handle h1, const uint64_t *scalar, he_handle h2) {
     GET(r, Ring, hring, T_RING);
@@ -1002,8 +1208,7 @@ int he_mul_rns_scalar_montgomery(he_handle hring, int level, he_handle h1, const
     if (!scalar || p1->batch != p2->batch) return fail(HE_EINVAL, "he_mul_rns_scalar_montgomery: bad arguments");
     ScalarTab st{};
     for (int i = 0; i <= level; i++) st.s[i] = scalar[i];
-    Scope sc(r->ctx.get());
-    return scalar_launch(*r, level, EW_MUL_SCALAR_MONT, *p1, *p2, st);
+    return scalar_launch(r, level, EW_MUL_SCALAR_MONT, p1, p2, st);
 }
 static int bigint_api(he_handle hring, int level, he_handle h1, const uint64_t *words, int nw, he_handle h2, int kind) {
     GET(r, Ring, hring, T_RING);
@@ -1018,8 +1223,7 @@ static int bigint_api(he_handle hring, int level, he_handle h1, const uint64_t *
         const uint64_t v = words_mod(words, nw, m.q);
         st.s[i] = kind >= 2 ? mform(v, m.q, m.brc0, m.brc1) : v;
     }
-    Scope sc(r->ctx.get());
-    return scalar_launch(*r, level, kind == 0 ? EW_ADD_SCALAR : (kind == 1 ? EW_SUB_SCALAR : (kind == 2 ? EW_MUL_SCALAR_MONT : EW_MUL_SCALAR_MONT_THEN_ADD)), *p1, *p2, st);
+    return scalar_launch(r, level, kind == 0 ? EW_ADD_SCALAR : (kind == 1 ? EW_SUB_SCALAR : (kind == 2 ? EW_MUL_SCALAR_MONT : EW_MUL_SCALAR_MONT_THEN_ADD)), p1, p2, st);
 }
 int he_mul_scalar_bigint_then_add(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 3); }
 int he_double_rns_scalarop(he_handle hring, int level, int op, he_handle h1, const uint64_t *s0, const uint64_t *s1, he_handle h2) {
@@ -1037,10 +1241,7 @@ int he_double_rns_scalarop(he_handle hring, int level, int op, he_handle h1, con
         st.s2[i] = op >= 2 ? mform(s1[i], m.q, m.brc0, m.brc1) : s1[i];
     }
     static const int ops[4] = {EW_ADD_SCALAR, EW_SUB_SCALAR, EW_MUL_SCALAR_MONT, EW_MUL_SCALAR_MONT_THEN_ADD};
-    Scope sc(r->ctx.get());
-    r->ctx->acct((op == 3 ? 3.0 : 2.0) * (level + 1), 0, p2->batch, r->N);
-    HIP_TRY(launch_ew_double(r->dev, ident_tab(level + 1), ops[op], p1->view(), p2->view(), p2->batch, &st, r->ctx->stream));
-    return HE_OK;
+    return scalar_launch(r, level, ops[op], p1, p2, st, true);
 }
 static int shift_api(he_handle hring, int level, he_handle h1, int k, he_handle h2, bool monomial, const char *who) {
     GET(r, Ring, hring, T_RING);
@@ -1053,20 +1254,28 @@ static int shift_api(he_handle hring, int level, he_handle h1, int k, he_handle 
     const int period = monomial ? 2 * N : N;
     int kk = k % period;
     if (kk < 0) kk += period;
-    Scope sc(r->ctx.get());
-    r->ctx->acct(2.0 * (level + 1), 0, B, N);
-    View in = p1->view();
-    const LimbTab tab = ident_tab(level + 1);
-    if (p1->d == p2->d) {  // in place: stage the input (the reference rotates in place / through a temporary)
-        const size_t w = (size_t)(level + 1) * N;
-        TRY(r->ctx->arena_reserve(B * w + 64));
-        View tmp{r->ctx->arena_take(B * w), w};
-        HIP_TRY(hipMemcpy2DAsync(tmp.p, w * 8, p1->d, p1->view().bstride * 8, w * 8, B, hipMemcpyDeviceToDevice, r->ctx->stream));
-        in = tmp;
-    }
-    if (monomial) HIP_TRY(launch_mult_by_monomial(r->dev, tab, in, kk, p2->view(), B, r->ctx->stream));
-    else HIP_TRY(launch_shift(r->dev, tab, in, kk, p2->view(), B, r->ctx->stream));
-    return HE_OK;
+    const bool inplace = p1->d == p2->d;
+    CoReq q;
+    q.op = CO_SHIFT; q.obj = r.get(); q.par[0] = level; q.par[1] = kk; q.par[2] = monomial;
+    q.ops = {p1->view(), p2->view()};
+    q.keep = {r, p1, p2};
+    q.run = [r, level, kk, monomial, inplace, N](const View *v, int B) -> int {
+        r->ctx->acct(2.0 * (level + 1), 0, B, N);
+        View in = v[0];
+        const LimbTab tab = ident_tab(level + 1);
+        if (inplace) {  // in place: stage the input (the reference rotates in place / through a temporary)
+            const size_t w = (size_t)(level + 1) * N;
+            TRY(r->ctx->arena_reserve(B * w + 64));
+            View tmp{r->ctx->arena_take(B * w), w};
+            HIP_TRY(launch_ew(r->dev, tab, EW_COPY, v[0], v[0], tmp, B, nullptr, nullptr, r->ctx->stream));
+            in = tmp;
+        }
+        if (monomial) HIP_TRY(launch_mult_by_monomial(r->dev, tab, in, kk, v[1], B, r->ctx->stream));
+        else HIP_TRY(launch_shift(r->dev, tab, in, kk, v[1], B, r->ctx->stream));
+        return HE_OK;
+    };
+    (void)B;
+    return co_dispatch(*r->ctx, p1->batch, q);
 }
 int he_shift(he_handle r, int l, he_handle p1, int k, he_handle p2) { return shift_api(r, l, p1, k, p2, false, "he_shift"); }
 int he_mult_by_monomial(he_handle r, int l, he_handle p1, int k, he_handle p2) { return shift_api(r, l, p1, k, p2, true, "he_mult_by_monomial"); }
@@ -1079,14 +1288,20 @@ int he_mul_by_vector_montgomery(he_handle hring, int level, he_handle h1, he_han
     TRY(check_poly(*p1, *r, level, who));
     TRY(check_poly(*p2, *r, level, who));
     if (v->N != r->N || v->batch != 1 || p1->batch != p2->batch) return fail(HE_EINVAL, "%s: the vector is one batch-1 limb of degree N", who);
-    uint8_t zeros[kMaxLimbs] = {0};
     View vv = v->view();
     vv.bstride = 0;  // the same vector for every batch entry and (through the limb override) every limb
-    Scope sc(r->ctx.get());
-    r->ctx->acct((then_add_lazy ? 3.0 : 2.0) * (level + 1), 1.0, p2->batch, r->N);
-    HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), then_add_lazy ? EW_MUL_MONT_THEN_ADD_LAZY : EW_MUL_MONT, vv, p1->view(), p2->view(),
-                      p2->batch, nullptr, zeros, r->ctx->stream));
-    return HE_OK;
+    CoReq q;
+    q.op = CO_EW; q.obj = r.get(); q.par[0] = level; q.par[1] = then_add_lazy ? EW_MUL_MONT_THEN_ADD_LAZY : EW_MUL_MONT; q.par[2] = 2;  // (a vector form)
+    q.ops = {vv, p1->view(), p2->view()};
+    q.keep = {r, v, p1, p2};
+    q.run = [r, level, then_add_lazy](const View *w, int B) -> int {
+        const uint8_t zeros[kMaxLimbs] = {0};
+        r->ctx->acct((then_add_lazy ? 3.0 : 2.0) * (level + 1), 1.0, B, r->N);
+        HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), then_add_lazy ? EW_MUL_MONT_THEN_ADD_LAZY : EW_MUL_MONT, w[0], w[1], w[2], B, nullptr,
+                          zeros, r->ctx->stream));
+        return HE_OK;
+    };
+    return co_dispatch(*r->ctx, p2->batch, q);
 }
 int he_add_scalar_bigint(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 0); }
 int he_sub_scalar_bigint(he_handle r, int l, he_handle p1, const uint64_t *w, int n, he_handle p2) { return bigint_api(r, l, p1, w, n, p2, 1); }
@@ -1141,7 +1356,7 @@ int div_by_last_modulus_ntt(Ring &r, int level, View p0, View p1, int batch, boo
         return HE_OK;
     }
     // conjugate-invariant ring: the lazy representative of INTTConjugateInvariantLazy is observable in the other moduli -- exact words
-    HIP_TRY(launch_ci_intt_lazy_ref(r.dev, r.sub[level].mc, level, View{p0.p + (size_t)level * r.N, p0.bstride}, sc.s0, batch, st));
+    HIP_TRY(launch_ci_intt_lazy_ref(r.dev, r.sub[level].mc, level, View{p0.p + (size_t)level * r.N, p0.bstride, p0.tab}, sc.s0, batch, st));
     ScalarTab s{};
     if (round) {  // b0 += pHalf mod q_L                                          scaling.go:114
         LimbTab t0; t0.n = 1; t0.in_limb[0] = 0; t0.out_limb[0] = 0; t0.mod[0] = (uint8_t)level;
@@ -1205,37 +1420,44 @@ int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, boo
     TRY(check_poly(*p0, *r, level, who));
     if (nb < 0 || nb > level) return fail(HE_EINVAL, "%s: cannot divide %d times at level %d", who, nb, level);
     if (p1->N != r->N || p1->nlimbs < level + 1 - nb || p0->batch != p1->batch) return fail(HE_EINVAL, "%s: output shape mismatch", who);
-    Scope sc(r->ctx.get());
-    for (int i = 0; i < nb; i++) r->ctx->acct(2.0 * (level - i + 1) - 1.0, 0, p0->batch, r->N);  // rescale: (2 L - 1) per polynomial and step
-    hipStream_t st = r->ctx->stream;
-    const int B = p0->batch, N = r->N;
-    if (nb == 0) {
-        if (p0->d != p1->d)
-            HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), EW_COPY, p0->view(), p0->view(), p1->view(), B, nullptr, nullptr, st));
+    const bool same = p0->d == p1->d;
+    CoReq q;
+    q.op = CO_RESCALE; q.obj = r.get(); q.par[0] = level; q.par[1] = nb; q.par[2] = round; q.par[3] = ntt; q.par[4] = many;
+    q.ops = {p0->view(), p1->view()};
+    q.keep = {r, p0, p1};
+    q.run = [r, level, nb, round, ntt, many, same](const View *v, int B) -> int {
+        for (int i = 0; i < nb; i++) r->ctx->acct(2.0 * (level - i + 1) - 1.0, 0, B, r->N);  // rescale: (2 L - 1) per polynomial and step
+        hipStream_t st = r->ctx->stream;
+        const int N = r->N;
+        if (nb == 0) {
+            if (!same) HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), EW_COPY, v[0], v[0], v[1], B, nullptr, nullptr, st));
+            return HE_OK;
+        }
+        const size_t w0 = (size_t)B * N, w1 = (size_t)B * (level + 1) * N;
+        TRY(r->ctx->arena_reserve(w0 + 2 * w1));
+        RescaleScratch rs;
+        rs.s0 = View{r->ctx->arena_take(w0), (size_t)N};
+        rs.s1 = View{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
+        if (ntt && nb == 1 && !(many && !round && r->type == 1)) return div_by_last_modulus_ntt(*r, level, v[0], v[1], B, round, rs);
+        View buf{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
+        View cur = v[0];
+        int lv = level;
+        if (ntt) {  // INTT, nb coefficient-domain steps, NTT          scaling.go:37-62, :148-174
+            HIP_TRY(ring_ntt(*r, ident_tab(level + 1), v[0], buf, B, true, NTT_REDUCE_INPUT));
+            cur = buf;
+        }
+        for (int i = 0; i < nb; i++) {
+            const bool last = (i == nb - 1);
+            View dst = (last && !ntt) ? v[1] : buf;
+            TRY(div_by_last_modulus_coeff(*r, lv, cur, dst, B, round, rs));
+            cur = dst;
+            lv--;
+        }
+        if (ntt) HIP_TRY(ring_ntt(*r, ident_tab(lv + 1), buf, v[1], B, false, NTT_REDUCE_INPUT));
         return HE_OK;
-    }
-    const size_t w0 = (size_t)B * N, w1 = (size_t)B * (level + 1) * N;
-    TRY(r->ctx->arena_reserve(w0 + 2 * w1));
-    RescaleScratch rs;
-    rs.s0 = View{r->ctx->arena_take(w0), (size_t)N};
-    rs.s1 = View{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
-    if (ntt && nb == 1 && !(many && !round && r->type == 1)) return div_by_last_modulus_ntt(*r, level, p0->view(), p1->view(), B, round, rs);
-    View buf{r->ctx->arena_take(w1), (size_t)(level + 1) * N};
-    View cur = p0->view();
-    int lv = level;
-    if (ntt) {  // INTT, nb coefficient-domain steps, NTT          scaling.go:37-62, :148-174
-        HIP_TRY(ring_ntt(*r, ident_tab(level + 1), p0->view(), buf, B, true, NTT_REDUCE_INPUT));
-        cur = buf;
-    }
-    for (int i = 0; i < nb; i++) {
-        const bool last = (i == nb - 1);
-        View dst = (last && !ntt) ? p1->view() : buf;
-        TRY(div_by_last_modulus_coeff(*r, lv, cur, dst, B, round, rs));
-        cur = dst;
-        lv--;
-    }
-    if (ntt) HIP_TRY(ring_ntt(*r, ident_tab(lv + 1), buf, p1->view(), B, false, NTT_REDUCE_INPUT));
-    return HE_OK;
+    };
+    q.tables_ok = [r](bool *ok) -> int { *ok = r->type == 0; return HE_OK; };  // (conjugate-invariant rings: launches without entry tables)
+    return co_dispatch(*r->ctx, p0->batch, q);
 }
 }  // namespace
 
@@ -1284,10 +1506,16 @@ static int gather_api(he_handle hring, int level, he_handle hin, he_handle hidx,
     TRY(check_poly(*pout, *r, level, who));
     if (ix->N != r->N || pin->batch != pout->batch) return fail(HE_EINVAL, "%s: shape mismatch", who);
     if (pin->d == pout->d) return fail(HE_EINVAL, "%s: the automorphism cannot be evaluated in place", who);
-    Scope sc(r->ctx.get());
-    r->ctx->acct((add ? 3.0 : 2.0) * (level + 1), 0, pin->batch, r->N);  // automorphism: 2 L (+ L for ...ThenAddLazy)
-    HIP_TRY(launch_gather(r->dev, ident_tab(level + 1), pin->view(), ix->d, pout->view(), pin->batch, add, r->ctx->stream));
-    return HE_OK;
+    CoReq q;
+    q.op = CO_GATHER; q.obj = r.get(); q.key = ix.get(); q.par[0] = level; q.par[1] = add;
+    q.ops = {pin->view(), pout->view()};
+    q.keep = {r, pin, pout, ix};
+    q.run = [r, ix, level, add](const View *v, int B) -> int {
+        r->ctx->acct((add ? 3.0 : 2.0) * (level + 1), 0, B, r->N);  // automorphism: 2 L (+ L for ...ThenAddLazy)
+        HIP_TRY(launch_gather(r->dev, ident_tab(level + 1), v[0], ix->d, v[1], B, add, r->ctx->stream));
+        return HE_OK;
+    };
+    return co_dispatch(*r->ctx, pin->batch, q);
 }
 int he_automorphism_ntt_with_index(he_handle r, int l, he_handle in, he_handle idx, he_handle out) { return gather_api(r, l, in, idx, out, false, "he_automorphism_ntt_with_index"); }
 int he_automorphism_ntt_with_index_then_add_lazy(he_handle r, int l, he_handle in, he_handle idx, he_handle out) { return gather_api(r, l, in, idx, out, true, "he_automorphism_ntt_with_index_then_add_lazy"); }
@@ -1299,10 +1527,16 @@ int he_automorphism(he_handle hring, int level, he_handle hin, uint64_t gal, he_
     TRY(check_poly(*pout, *r, level, "he_automorphism"));
     if (pin->batch != pout->batch) return fail(HE_EINVAL, "he_automorphism: batch mismatch");
     if (pin->d == pout->d) return fail(HE_EINVAL, "he_automorphism: the automorphism cannot be evaluated in place");
-    Scope sc(r->ctx.get());
-    r->ctx->acct(2.0 * (level + 1), 0, pin->batch, r->N);
-    HIP_TRY(launch_automorphism_coeff(r->dev, ident_tab(level + 1), pin->view(), gal, pout->view(), pin->batch, r->ctx->stream, r->type == 1));
-    return HE_OK;
+    CoReq q;
+    q.op = CO_AUTO_COEFF; q.obj = r.get(); q.par[0] = level; q.par[1] = (int64_t)gal;
+    q.ops = {pin->view(), pout->view()};
+    q.keep = {r, pin, pout};
+    q.run = [r, level, gal](const View *v, int B) -> int {
+        r->ctx->acct(2.0 * (level + 1), 0, B, r->N);
+        HIP_TRY(launch_automorphism_coeff(r->dev, ident_tab(level + 1), v[0], gal, v[1], B, r->ctx->stream, r->type == 1));
+        return HE_OK;
+    };
+    return co_dispatch(*r->ctx, pin->batch, q);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1435,9 +1669,15 @@ int he_modup_q_to_p(he_handle hbe, int levelQ, int levelP, he_handle hq, he_hand
     TRY(check_be_poly(*pq, *be, levelQ + 1, "he_modup_q_to_p"));
     TRY(check_be_poly(*pp, *be, levelP + 1, "he_modup_q_to_p"));
     if (pq->batch != pp->batch) return fail(HE_EINVAL, "he_modup_q_to_p: batch mismatch");
-    Scope sc(be->ctx.get());
-    be->ctx->acct(levelQ + 1 + levelP + 1, 0, pq->batch, be->Q->N);  // ModUp: L_src + L_dst
-    return modup_between(*be, true, levelQ, levelP, pq->view(), pp->view(), 0, pq->batch);
+    CoReq q;
+    q.op = CO_MODUP; q.obj = be.get(); q.par[0] = levelQ; q.par[1] = levelP; q.par[2] = 1;
+    q.ops = {pq->view(), pp->view()};
+    q.keep = {be, pq, pp};
+    q.run = [be, levelQ, levelP](const View *v, int B) -> int {
+        be->ctx->acct(levelQ + 1 + levelP + 1, 0, B, be->Q->N);  // ModUp: L_src + L_dst
+        return modup_between(*be, true, levelQ, levelP, v[0], v[1], 0, B);
+    };
+    return co_dispatch(*be->ctx, pq->batch, q);
 }
 int he_modup_p_to_q(he_handle hbe, int levelP, int levelQ, he_handle hp, he_handle hq) {
     GET(be, BasisExtender, hbe, T_BE);
@@ -1447,9 +1687,15 @@ int he_modup_p_to_q(he_handle hbe, int levelP, int levelQ, he_handle hp, he_hand
     TRY(check_be_poly(*pq, *be, levelQ + 1, "he_modup_p_to_q"));
     TRY(check_be_poly(*pp, *be, levelP + 1, "he_modup_p_to_q"));
     if (pq->batch != pp->batch) return fail(HE_EINVAL, "he_modup_p_to_q: batch mismatch");
-    Scope sc(be->ctx.get());
-    be->ctx->acct(levelQ + 1 + levelP + 1, 0, pq->batch, be->Q->N);
-    return modup_between(*be, false, levelP, levelQ, pp->view(), pq->view(), 0, pq->batch);
+    CoReq q;
+    q.op = CO_MODUP; q.obj = be.get(); q.par[0] = levelQ; q.par[1] = levelP; q.par[2] = 0;
+    q.ops = {pp->view(), pq->view()};
+    q.keep = {be, pq, pp};
+    q.run = [be, levelQ, levelP](const View *v, int B) -> int {
+        be->ctx->acct(levelQ + 1 + levelP + 1, 0, B, be->Q->N);
+        return modup_between(*be, false, levelP, levelQ, v[0], v[1], 0, B);
+    };
+    return co_dispatch(*be->ctx, pq->batch, q);
 }
 static int moddown_api(he_handle hbe, int levelQ, int levelP, he_handle h1q, he_handle h1p, he_handle h2, int kind, const char *who) {
     GET(be, BasisExtender, hbe, T_BE);
@@ -1461,27 +1707,34 @@ static int moddown_api(he_handle hbe, int levelQ, int levelP, he_handle h1q, he_
     TRY(check_be_poly(*p1p, *be, levelP + 1, who));
     TRY(check_be_poly(*p2, *be, (kind == 2 ? levelP : levelQ) + 1, who));
     if (p1q->batch != p1p->batch || p1q->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
-    Scope sc(be->ctx.get());
-    const int B = p1q->batch, N = be->Q->N;
-    be->ctx->acct(kind == 2 ? levelQ + 1 + 2.0 * (levelP + 1) : 2.0 * (levelQ + 1) + levelP + 1, 0, B, N);  // ModDown: 2 L + alpha
-    const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
-    TRY(be->ctx->arena_reserve(wP + wQ));
-    View sP{be->ctx->arena_take(wP), (size_t)(levelP + 1) * N};
-    View sQ{be->ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
-    hipStream_t st = be->ctx->stream;
-    ScalarTab s{};
-    if (kind == 1) return moddown_q_ntt(*be, levelQ, levelP, p1q->view(), p1p->view(), p2->view(), B, sP, sQ);
-    if (kind == 0) {  // ModDownQPtoQ, basis_extension.go:215-230
-        TRY(modup_between(*be, false, levelP, levelQ, p1p->view(), sQ, 0, B));
-        for (int i = 0; i <= levelQ; i++) s.s[i] = be->Q->moduli[i] - be->md_ptoq[levelP][i];
-        HIP_TRY(launch_ew(be->qp, ident_tab(levelQ + 1), EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sQ, p1q->view(), p2->view(), B, &s, nullptr, st));
+    CoReq q;
+    q.op = CO_MODDOWN_BE; q.obj = be.get(); q.par[0] = levelQ; q.par[1] = levelP; q.par[2] = kind;
+    q.ops = {p1q->view(), p1p->view(), p2->view()};
+    q.keep = {be, p1q, p1p, p2};
+    q.run = [be, levelQ, levelP, kind](const View *v, int B) -> int {
+        const int N = be->Q->N;
+        be->ctx->acct(kind == 2 ? levelQ + 1 + 2.0 * (levelP + 1) : 2.0 * (levelQ + 1) + levelP + 1, 0, B, N);  // ModDown: 2 L + alpha
+        const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
+        TRY(be->ctx->arena_reserve(wP + wQ));
+        View sP{be->ctx->arena_take(wP), (size_t)(levelP + 1) * N};
+        View sQ{be->ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
+        hipStream_t st = be->ctx->stream;
+        ScalarTab s{};
+        if (kind == 1) return moddown_q_ntt(*be, levelQ, levelP, v[0], v[1], v[2], B, sP, sQ);
+        if (kind == 0) {  // ModDownQPtoQ, basis_extension.go:215-230
+            TRY(modup_between(*be, false, levelP, levelQ, v[1], sQ, 0, B));
+            for (int i = 0; i <= levelQ; i++) s.s[i] = be->Q->moduli[i] - be->md_ptoq[levelP][i];
+            HIP_TRY(launch_ew(be->qp, ident_tab(levelQ + 1), EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sQ, v[0], v[2], B, &s, nullptr, st));
+            return HE_OK;
+        }
+        // ModDownQPtoP, basis_extension.go:262-277
+        TRY(modup_between(*be, true, levelQ, levelP, v[0], sP, 0, B));
+        for (int i = 0; i <= levelP; i++) s.s[i] = be->P->moduli[i] - be->md_qtop[levelQ][i];
+        HIP_TRY(launch_ew(be->qp, ident_tab(levelP + 1, 0, 0, be->LQ), EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sP, v[1], v[2], B, &s, nullptr, st));
         return HE_OK;
-    }
-    // ModDownQPtoP, basis_extension.go:262-277
-    TRY(modup_between(*be, true, levelQ, levelP, p1q->view(), sP, 0, B));
-    for (int i = 0; i <= levelP; i++) s.s[i] = be->P->moduli[i] - be->md_qtop[levelQ][i];
-    HIP_TRY(launch_ew(be->qp, ident_tab(levelP + 1, 0, 0, be->LQ), EW_SUB_THEN_MUL_SCALAR_MONT_2Q, sP, p1p->view(), p2->view(), B, &s, nullptr, st));
-    return HE_OK;
+    };
+    q.tables_ok = [be](bool *ok) -> int { *ok = be->type == 0; return HE_OK; };
+    return co_dispatch(*be->ctx, p1q->batch, q);
 }
 int he_moddown_qp_to_q(he_handle be, int lq, int lp, he_handle a, he_handle b, he_handle c) { return moddown_api(be, lq, lp, a, b, c, 0, "he_moddown_qp_to_q"); }
 int he_moddown_qp_to_q_ntt(he_handle be, int lq, int lp, he_handle a, he_handle b, he_handle c) { return moddown_api(be, lq, lp, a, b, c, 1, "he_moddown_qp_to_q_ntt"); }
@@ -1536,40 +1789,54 @@ int he_evaluator_create(he_handle hq, he_handle hp, he_handle *out) {
     return HE_OK;
 }
 int he_evaluator_destroy(he_handle h) { return unreg(h, T_EVAL); }
-int he_evaluator_set_coalescing(he_handle h, int max_batch, int window_us) {
-    GET(ev, Evaluator, h, T_EVAL);
+static int ctx_set_coalescing(const std::shared_ptr<Ctx> &c, int max_batch, int window_us, const char *who) {
     if (max_batch < 0 || max_batch > 1024 || window_us < 0 || window_us > 100000)
-        return fail(HE_EINVAL, "he_evaluator_set_coalescing: max_batch in [0, 1024], window_us in [0, 100000]");
-    Ctx *c = ev->be->ctx.get();
-    Scope sc(c);  // (a leader launches its batch under this lock: none is between gathering and launching while we hold it)
-    std::lock_guard<std::mutex> lk(ev->co->mu);
-    if (!ev->co->pending.empty() || ev->co->leader) return fail(HE_EINVAL, "he_evaluator_set_coalescing: calls are in flight on this evaluator");
+        return fail(HE_EINVAL, "%s: max_batch in [0, 1024], window_us in [0, 100000]", who);
+    Scope sc(c.get());  // (a leader launches its batch under this lock: none is between gathering and launching while we hold it)
+    Coalescer &co = *c->co;
+    std::lock_guard<std::mutex> lk(co.mu);
+    if (!co.pending.empty() || co.leader) return fail(HE_EINVAL, "%s: calls are in flight on this context", who);
     if (max_batch <= 1) {  // off: later calls launch directly
-        ev->co->max_batch = 0;
+        co.max_batch = 0;
         return HE_OK;
     }
-    if (max_batch > ev->co->tab_cap) {
+    // rows for the operands of any call but the longest lintrans term lists (those are served one by one when they do not fit)
+    const size_t words = (size_t)std::max<size_t>(kTabRowsMin, 128) * (size_t)max_batch;
+    if (words > co.tab_words) {
         HIP_TRY(hipStreamSynchronize(c->stream));  // launches that read the old table
-        if (ev->co->d_tab) HIP_TRY(hipFree(ev->co->d_tab));
-        ev->co->d_tab = nullptr; ev->co->tab_cap = 0;
-        HIP_TRY(hipMalloc((void **)&ev->co->d_tab, (size_t)6 * max_batch * sizeof(size_t)));
-        ev->co->tab_cap = max_batch;
+        if (co.d_tab) HIP_TRY(hipFree(co.d_tab));
+        co.d_tab = nullptr; co.tab_words = 0;
+        HIP_TRY(hipMalloc((void **)&co.d_tab, words * sizeof(size_t)));
+        co.tab_words = words;
     }
-    ev->co->max_batch = max_batch;
-    ev->co->window_us = window_us;
+    co.max_batch = max_batch;
+    co.window_us = window_us;
     return HE_OK;
+}
+static int ctx_coalescing_stats(Ctx &c, uint64_t out[4], const char *who) {
+    if (!out) return fail(HE_EINVAL, "%s: null output", who);
+    std::lock_guard<std::mutex> lk(c.co->mu);
+    out[0] = c.co->n_calls; out[1] = c.co->n_launches; out[2] = c.co->n_max; out[3] = c.co->n_fallback;
+    return HE_OK;
+}
+// the queue belongs to the context (round 5): the evaluator-level entry points of round 4 address their context's queue
+int he_evaluator_set_coalescing(he_handle h, int max_batch, int window_us) {
+    GET(ev, Evaluator, h, T_EVAL);
+    return ctx_set_coalescing(ev->be->ctx, max_batch, window_us, "he_evaluator_set_coalescing");
 }
 int he_evaluator_coalescing_stats(he_handle h, uint64_t out[4]) {
     GET(ev, Evaluator, h, T_EVAL);
-    if (!out) return fail(HE_EINVAL, "he_evaluator_coalescing_stats: null output");
-    out[0] = out[1] = out[2] = out[3] = 0;
-    std::lock_guard<std::mutex> lk(ev->co->mu);
-    out[0] = ev->co->n_calls; out[1] = ev->co->n_launches; out[2] = ev->co->n_max; out[3] = ev->co->n_fallback;
-    return HE_OK;
+    return ctx_coalescing_stats(*ev->be->ctx, out, "he_evaluator_coalescing_stats");
+}
+int he_ctx_set_coalescing(he_handle h, int max_batch, int window_us) {
+    GET(c, Ctx, h, T_CTX);
+    return ctx_set_coalescing(c, max_batch, window_us, "he_ctx_set_coalescing");
+}
+int he_ctx_coalescing_stats(he_handle h, uint64_t out[4]) {
+    GET(c, Ctx, h, T_CTX);
+    return ctx_coalescing_stats(*c, out, "he_ctx_coalescing_stats");
 }
 
-// double-precision copy of the key for the fused NTT+MAC kernel, when some key limb is below 2^47 (re-run after the key
-// words change: he_evk_commit)
 static int evk_derive(Evk &k) {
     BasisExtender &be = *k.ev->be;
     const int nQk = k.nQk, nPk = k.nPk;
@@ -1713,15 +1980,14 @@ int decompose_digit(Evaluator &ev, int levelQ, int levelP, int nbPi, int digit, 
 
 // DecomposeNTT (core/rlwe/evaluator_gadget_product.go:459-510) into a Decomp buffer.
 // c2ntt / c2inv: NTT-domain and coefficient-domain views of the input (levelQ+1 limbs).
-int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2ntt, View c2inv, uint64_t *dec, size_t dec_bs,
-                       size_t dec_ds, int batch) {
+int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2ntt, View c2inv, View dec, size_t dec_ds, int batch) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ;
     const int beta = base_rns_size(levelQ, levelP);
     hipStream_t st = be.ctx->stream;
     if (dec_ds != (size_t)(be.LQ + be.LP) * be.Q->N) return fail(HE_EINVAL, "decompose: unexpected digit stride");
     for (int d = 0; d < beta; d++) {
-        View blk{dec + (size_t)d * dec_ds, dec_bs};
+        View blk{dec.p + (size_t)d * dec_ds, dec.bstride, dec.tab};
         TRY(decompose_digit(ev, levelQ, levelP, nbPi, d, c2inv, blk, 0, blk, LQ, batch));
         const int s0 = d * nbPi, e0 = std::min(s0 + nbPi, levelQ + 1);
         LimbTab t;  // NTT of every limb except the digit's own
@@ -1745,7 +2011,7 @@ int decompose_ntt_into(Evaluator &ev, int levelQ, int levelP, int nbPi, View c2n
 
 // inner product of a decomposition with a key (gadgetProductMultiplePLazyHoisted :401-453)
 // limb_filter: 0 = every limb, 1 = only limbs NOT of class 2 (the fused f64 NTT+MAC kernel takes the others)
-int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View o0Q,
+int ks_inner(Evaluator &ev, int levelQ, int levelP, View dec, size_t dec_ds, const Evk &k, View o0Q,
              View o0P, View o1Q, View o1P, int batch, const View *own = nullptr, int own_alpha = 0, int limb_filter = 0,
              int digit_begin = 0, int digit_end = -1, const KsScatter *scatter = nullptr) {
     BasisExtender &be = *ev.be;
@@ -1756,7 +2022,7 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
     const uint64_t *keyp = k.d;
     if (digit_end >= 0) {  // a sub-range of the digits (he_gadget_product_hoisted_lazy_digits): shift both operands
         if (own || digit_begin < 0 || digit_end > a.beta || digit_begin >= digit_end) return fail(HE_EINVAL, "gadget product: bad digit range");
-        dec += (size_t)digit_begin * dec_ds;
+        dec.p += (size_t)digit_begin * dec_ds;
         keyp += (size_t)digit_begin * 2 * (size_t)(k.nQk + k.nPk) * N;
         a.beta = digit_end - digit_begin;
     }
@@ -1776,7 +2042,7 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t 
     a.key_dstride = 2 * a.key_kstride;
     a.own_alpha = own ? own_alpha : 0;
     a.own_nq = levelQ + 1;
-    const View decv{const_cast<uint64_t *>(dec), dec_bs};
+    const View decv = dec;
     if (scatter && scatter->ginv) {  // (add_s arrives by Q limb: compact it to the launch limbs)
         KsScatter sc = *scatter;
         for (int i = 0; i < n; i++) sc.add_s[i] = a.out_view[i] == 0 ? scatter->add_s[a.out_limb[i]] : 0;
@@ -1929,7 +2195,7 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
 }
 // forward ROWS pass over every non-own limb of every digit block of a decomposition
 // limb_filter 1: skip the class-2 limbs (their transform is fused into launch_ntt_mac_f64)
-int dec_rows_ntt(Evaluator &ev, int levelQ, int levelP, int nbPi, uint64_t *dec, size_t dec_bs, int batch, int limb_filter = 0) {
+int dec_rows_ntt(Evaluator &ev, int levelQ, int levelP, int nbPi, View dec, int batch, int limb_filter = 0) {
     BasisExtender &be = *ev.be;
     const int LQ = be.LQ, width = be.LQ + be.LP;
     const int beta = base_rns_size(levelQ, levelP);
@@ -1937,7 +2203,7 @@ int dec_rows_ntt(Evaluator &ev, int levelQ, int levelP, int nbPi, uint64_t *dec,
     t.n = 0;
     auto flush = [&]() -> int {
         if (t.n == 0) return HE_OK;
-        HIP_TRY(launch_ntt_rows(be.qp, t, View{dec, dec_bs}, View{dec, dec_bs}, batch, false, 0, be.ctx->stream));
+        HIP_TRY(launch_ntt_rows(be.qp, t, dec, dec, batch, false, 0, be.ctx->stream));
         t.n = 0;
         return HE_OK;
     };
@@ -1974,8 +2240,8 @@ size_t ks_scratch_words(const BasisExtender &be, int levelQ, int levelP, int bat
 }  // namespace
 
 namespace {
-int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, uint64_t *dec,
-                    size_t dec_bs, int batch, int ntt_filter = 0, bool f64_raw = false);
+int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, View dec, int batch,
+                    int ntt_filter = 0, bool f64_raw = false);
 }
 int he_decompose_and_split(he_handle hev, int levelQ, int levelP, int nbPi, int digit, he_handle h0, he_handle h1q, he_handle h1p) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -1989,9 +2255,16 @@ int he_decompose_and_split(he_handle hev, int levelQ, int levelP, int nbPi, int 
     TRY(check_be_poly(*p1q, be, levelQ + 1, "he_decompose_and_split"));
     TRY(check_be_poly(*p1p, be, levelP + 1, "he_decompose_and_split"));
     if (p0->batch != p1q->batch || p0->batch != p1p->batch) return fail(HE_EINVAL, "he_decompose_and_split: batch mismatch");
-    Scope sc(be.ctx.get());
-    be.ctx->acct(std::min(nbPi, levelQ + 1 - digit * nbPi) + levelQ + 1 + levelP + 1, 0, p0->batch, be.Q->N);  // ModUp of one digit
-    return decompose_digit(*ev, levelQ, levelP, nbPi, digit, p0->view(), p1q->view(), 0, p1p->view(), 0, p0->batch);
+    CoReq q;
+    q.op = CO_DECOMPOSE_SPLIT; q.obj = ev.get(); q.par[0] = levelQ; q.par[1] = levelP; q.par[2] = nbPi; q.par[3] = digit;
+    q.ops = {p0->view(), p1q->view(), p1p->view()};
+    q.keep = {ev, p0, p1q, p1p};
+    q.run = [ev, levelQ, levelP, nbPi, digit](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(std::min(nbPi, levelQ + 1 - digit * nbPi) + levelQ + 1 + levelP + 1, 0, B, be.Q->N);  // ModUp of one digit
+        return decompose_digit(*ev, levelQ, levelP, nbPi, digit, v[0], v[1], 0, v[2], 0, B);
+    };
+    return co_dispatch(*be.ctx, p0->batch, q);
 }
 
 int he_decomp_create(he_handle hev, int batch, he_handle *out) {
@@ -2037,36 +2310,45 @@ int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle 
     TRY(check_be_poly(*c2, be, levelQ + 1, "he_decompose_ntt"));
     if (c2->batch != dec->batch) return fail(HE_EINVAL, "he_decompose_ntt: batch mismatch");
     if (base_rns_size(levelQ, levelP) > dec->beta_max) return fail(HE_EINVAL, "he_decompose_ntt: too many digits");
-    Scope sc(be.ctx.get());
-    be.ctx->acct(levelQ + 1 + (double)base_rns_size(levelQ, levelP) * (levelQ + levelP + 2), 0, c2->batch, be.Q->N);  // DecomposeNTT: L in, beta (L + alpha) out
     dec->fillQ = -1;  // not filled until every launch below has been enqueued (check_decomp refuses a partial buffer)
-    auto filled = [&]() { dec->fillQ = levelQ; dec->fillP = levelP; dec->fill_beta = base_rns_size(levelQ, levelP); return HE_OK; };
-    const int B = c2->batch, N = be.Q->N;
-    const size_t w = (size_t)B * (levelQ + 1) * N;
-    TRY(be.ctx->arena_reserve(w));
-    View other{be.ctx->arena_take(w), (size_t)(levelQ + 1) * N};
-    View ntt = c2->view(), inv = other;
-    if (c2_is_ntt) {
-        const FusedPlan *plan = nullptr;
-        TRY(get_dec_plan(*ev, levelQ, levelP, nbPi, &plan));
-        if (plan->ok) {
-            HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), c2->view(), other, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
-            TRY(decompose_fused(*ev, *plan, levelQ, levelP, nbPi, other, dec->d, dec->bstride(), B));
-            const int beta = base_rns_size(levelQ, levelP);
-            for (int d = 0; d < beta; d++) {  // own limbs: copy of the NTT-domain input (evaluator_gadget_product.go:498-503)
-                const int s0 = d * nbPi, e0 = std::min(s0 + nbPi, levelQ + 1);
-                View blk{dec->d + (size_t)d * dec->dstride(), dec->bstride()};
-                HIP_TRY(launch_ew(be.qp, ident_tab(e0 - s0, s0, s0, s0), EW_COPY, c2->view(), c2->view(), blk, B, nullptr, nullptr, be.ctx->stream));
+    const size_t dec_ds = dec->dstride();
+    CoReq q;
+    q.op = CO_DECOMPOSE_NTT; q.obj = ev.get(); q.par[0] = levelQ; q.par[1] = levelP; q.par[2] = nbPi; q.par[3] = c2_is_ntt;
+    q.ops = {c2->view(), dec->view()};
+    q.keep = {ev, c2, dec};
+    q.run = [ev, levelQ, levelP, nbPi, c2_is_ntt, dec_ds](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        const int N = be.Q->N;
+        be.ctx->acct(levelQ + 1 + (double)base_rns_size(levelQ, levelP) * (levelQ + levelP + 2), 0, B, N);  // DecomposeNTT: L in, beta (L + alpha) out
+        const size_t w = (size_t)B * (levelQ + 1) * N;
+        TRY(be.ctx->arena_reserve(w));
+        View other{be.ctx->arena_take(w), (size_t)(levelQ + 1) * N};
+        View ntt = v[0], inv = other;
+        if (c2_is_ntt) {
+            const FusedPlan *plan = nullptr;
+            TRY(get_dec_plan(*ev, levelQ, levelP, nbPi, &plan));
+            if (plan->ok) {
+                HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), v[0], other, B, true, NTT_REDUCE_INPUT, be.ctx->stream));
+                TRY(decompose_fused(*ev, *plan, levelQ, levelP, nbPi, other, v[1], B));
+                const int beta = base_rns_size(levelQ, levelP);
+                for (int d = 0; d < beta; d++) {  // own limbs: copy of the NTT-domain input (evaluator_gadget_product.go:498-503)
+                    const int s0 = d * nbPi, e0 = std::min(s0 + nbPi, levelQ + 1);
+                    View blk{v[1].p + (size_t)d * dec_ds, v[1].bstride, v[1].tab};
+                    HIP_TRY(launch_ew(be.qp, ident_tab(e0 - s0, s0, s0, s0), EW_COPY, v[0], v[0], blk, B, nullptr, nullptr, be.ctx->stream));
+                }
+                return HE_OK;
             }
-            return filled();
+            HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), v[0], other, B, true, NTT_REDUCE_INPUT));
+        } else {
+            HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), v[0], other, B, false, NTT_REDUCE_INPUT));
+            ntt = other; inv = v[0];
         }
-        HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), c2->view(), other, B, true, NTT_REDUCE_INPUT));
-    } else {
-        HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), c2->view(), other, B, false, NTT_REDUCE_INPUT));
-        ntt = other; inv = c2->view();
-    }
-    TRY(decompose_ntt_into(*ev, levelQ, levelP, nbPi, ntt, inv, dec->d, dec->bstride(), dec->dstride(), B));
-    return filled();
+        return decompose_ntt_into(*ev, levelQ, levelP, nbPi, ntt, inv, v[1], dec_ds, B);
+    };
+    q.tables_ok = [ev](bool *ok) -> int { *ok = ev->be->type == 0; return HE_OK; };
+    TRY(co_dispatch(*be.ctx, c2->batch, q));
+    dec->fillQ = levelQ; dec->fillP = levelP; dec->fill_beta = base_rns_size(levelQ, levelP);
+    return HE_OK;
 }
 
 namespace {
@@ -2093,13 +2375,13 @@ int get_qp_out(he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, const
 
 // DecomposeNTT through the fused kernels: `rows_inv` = inverse ROWS pass of the NTT-domain input.
 // Own limbs are NOT written (ks_inner reads them from the input; he_decompose_ntt copies them).
-int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, uint64_t *dec,
-                    size_t dec_bs, int batch, int ntt_filter, bool f64_raw) {
+int decompose_fused(Evaluator &ev, const FusedPlan &plan, int levelQ, int levelP, int nbPi, View rows_inv, View dec, int batch,
+                    int ntt_filter, bool f64_raw) {
     BasisExtender &be = *ev.be;
-    const View dv{dec, dec_bs};
+    const View dv = dec;
     for (const FusedGroup &g : plan.groups)
         HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, g.dst_classes, rows_inv, dv, dv, batch, be.ctx->stream, f64_raw, g.total_limbs));
-    return dec_rows_ntt(ev, levelQ, levelP, nbPi, dec, dec_bs, batch, ntt_filter);
+    return dec_rows_ntt(ev, levelQ, levelP, nbPi, dec, batch, ntt_filter);
 }
 // class-2 limbs of the gadget product: forward row NTT + key MAC in one kernel (dec holds the post-column state)
 // May the basis extension hand unreduced doubles to the double-precision row kernels (launch_modup_fused f64_raw)?
@@ -2241,7 +2523,7 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
             View blk{dec + (size_t)d * ds, bs};
             HIP_TRY(be_ntt(be, t, blk, blk, B, false, 0));
         }
-        return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
+        return ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B);
     }
     if (plan->ok) {
         if (prod_in) {
@@ -2257,8 +2539,8 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
             int max_nsrc = 1;
             for (const FusedGroup &g : plan->groups) max_nsrc = std::max(max_nsrc, g.nsrc);
             const bool raw = f64_raw_ok(be, levelQ, levelP, max_nsrc);
-            TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B, 1, raw));
-            TRY(ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
+            TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, View{dec, bs}, B, 1, raw));
+            TRY(ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
             if (defer && defer->want) {
                 defer->deferred = true; defer->dec = dec; defer->bs = bs; defer->ds = ds; defer->raw = raw; defer->own_reduce = !cx_canonical;
                 return HE_OK;
@@ -2266,12 +2548,12 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
             if (acc_q_f64) *acc_q_f64 = want_f64;
             return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64, !cx_canonical, raw);
         }
-        TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, dec, bs, B));
-        return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
+        TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, View{dec, bs}, B));
+        return ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
     }
     HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT));
-    TRY(decompose_ntt_into(ev, levelQ, levelP, levelP + 1, cx, inv, dec, bs, ds, B));
-    return ks_inner(ev, levelQ, levelP, dec, bs, ds, k, o0Q, o0P, o1Q, o1P, B);
+    TRY(decompose_ntt_into(ev, levelQ, levelP, levelP + 1, cx, inv, View{dec, bs}, ds, B));
+    return ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B);
 }
 // ModDownQPtoQNTT up to (not including) its last fused op: sQ = NTTLazy(ModUpPtoQ(INTTLazy(accP))) for nb entries
 int moddown_front(Evaluator &ev, int levelQ, int levelP, View accP, View sP, View sQ, int nb, bool canonical = false) {
@@ -2321,7 +2603,7 @@ int moddown_pair(Evaluator &ev, int levelQ, int levelP, View c0Q, View c0P, View
 // scatter_ginv (optional, in/out): on entry g^-1 mod 2N of an automorphism the caller wants applied to the outputs; where the
 // fused ModDown epilogues write the result they store it through that automorphism (NttEpilogue::scatter_ginv) and the value is
 // left as it is; a path without such an epilogue sets it to 0 and the caller applies the automorphism itself (launch_gather).
-int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp *hoisted, const Evk &k, View out0, View out1, int B,
+int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const View *hoisted, const Evk &k, View out0, View out1, int B,
                         const View *add0 = nullptr, const View *add1 = nullptr, bool cx_canonical = false,
                         const TensorIn *tin = nullptr, uint32_t *scatter_ginv = nullptr) {
     const uint32_t want_scatter = scatter_ginv ? *scatter_ginv : 0u;
@@ -2358,7 +2640,7 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const Decomp 
     if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical, &acc_f64, &defer, tin));
     else {
         acc_f64 = false;
-        TRY(ks_inner(ev, levelQ, levelP, hoisted->d, hoisted->bstride(), hoisted->dstride(), k, a0Q, a0P, a1Q, a1P, B));
+        TRY(ks_inner(ev, levelQ, levelP, *hoisted, (size_t)(be.LQ + be.LP) * N, k, a0Q, a0P, a1Q, a1P, B));
     }
     View sP{be.ctx->arena_take(2 * B * sPw), sPw}, sQ{be.ctx->arena_take(2 * B * sQw), sQw};
     if (plan->ok) {
@@ -2446,10 +2728,8 @@ int check_decomp(const Evaluator &ev, const Decomp &dec, int levelQ, int levelP,
 }
 }  // namespace
 
-// a single-ciphertext key switch joins the evaluator's submission queue (defined with the queue, below)
-static int co_submit_keyswitch(const std::shared_ptr<Evaluator> &ev, int op, int level, uint64_t t, const std::shared_ptr<Evk> &k,
-                               std::initializer_list<std::shared_ptr<Poly>> ins, const std::shared_ptr<Poly> &o0,
-                               const std::shared_ptr<Poly> &o1);
+static int keyswitch_tables_ok(Evaluator &ev, int level, const Evk &k, bool *ok);
+static int mul_relin_tables_ok(Evaluator &ev, int level, const Evk &k, bool *ok);
 // limbs of an evaluation key's 2 beta rows at (levelQ, levelP): read once per call, shared by the batch
 static double key_limbs(const Evk &k, int levelQ) {
     const int levelP = k.nPk - 1;
@@ -2465,10 +2745,26 @@ int he_gadget_product_lazy(he_handle hev, int levelQ, he_handle hcx, he_handle h
     TRY(check_be_poly(*cx, be, levelQ + 1, "he_gadget_product_lazy"));
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, cx->batch, o, "he_gadget_product_lazy"));
-    Scope sc(be.ctx.get());
-    be.ctx->acct(levelQ + 1 + 2.0 * (levelQ + k->nPk + 1), key_limbs(*k, levelQ), cx->batch, be.Q->N);  // cx in, two QP accumulators out, key
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true, k.get())));
-    return gadget_product_lazy_core(*ev, levelQ, cx->view(), cx->batch, *k, o.q0->view(), o.vp0(), o.q1->view(), o.vp1());
+    CoReq q;
+    q.op = CO_GP_LAZY; q.obj = ev.get(); q.key = k.get(); q.par[0] = levelQ;
+    q.ops = {cx->view(), o.q0->view(), o.vp0(), o.q1->view(), o.vp1()};
+    q.keep = {ev, k, cx, o.q0, o.p0, o.q1, o.p1};
+    q.run = [ev, k, levelQ](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(levelQ + 1 + 2.0 * (levelQ + k->nPk + 1), key_limbs(*k, levelQ), B, be.Q->N);  // cx in, two QP accumulators out, key
+        TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, B, true, k.get())));
+        return gadget_product_lazy_core(*ev, levelQ, v[0], B, *k, v[1], v[2], v[3], v[4]);
+    };
+    // entry tables: the fused decomposition (the unfused / base-2 launches write the digits through pointers of their own)
+    q.tables_ok = [ev, k, levelQ](bool *ok) -> int {
+        *ok = false;
+        if (k->pw2 || k->nPk <= 0) return HE_OK;
+        const FusedPlan *plan = nullptr;
+        TRY(get_dec_plan(*ev, levelQ, k->nPk - 1, k->nPk, &plan));
+        *ok = plan->ok;
+        return HE_OK;
+    };
+    return co_dispatch(*be.ctx, cx->batch, q);
 }
 int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he_handle hk, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -2480,9 +2776,17 @@ int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he
     TRY(check_decomp(*ev, *dec, levelQ, k->nPk - 1, "he_gadget_product_hoisted_lazy"));
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, k->nPk - 1, dec->batch, o, "he_gadget_product_hoisted_lazy"));
-    Scope sc(be.ctx.get());
-    be.ctx->acct(key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + k->nPk + 1), key_limbs(*k, levelQ), dec->batch, be.Q->N);  // decomposition in, accumulators out, key
-    return ks_inner(*ev, levelQ, k->nPk - 1, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), dec->batch);
+    const size_t dec_ds = dec->dstride();
+    CoReq q;
+    q.op = CO_GP_HOISTED_LAZY; q.obj = ev.get(); q.key = k.get(); q.par[0] = levelQ;
+    q.ops = {dec->view(), o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view()};
+    q.keep = {ev, k, dec, o.q0, o.p0, o.q1, o.p1};
+    q.run = [ev, k, levelQ, dec_ds](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + k->nPk + 1), key_limbs(*k, levelQ), B, be.Q->N);  // decomposition in, accumulators out, key
+        return ks_inner(*ev, levelQ, k->nPk - 1, v[0], dec_ds, *k, v[1], v[2], v[3], v[4], B);
+    };
+    return co_dispatch(*be.ctx, dec->batch, q);
 }
 int he_gadget_product_hoisted_lazy_digits(he_handle hev, int levelQ, he_handle hdec, he_handle hk, int digit_begin, int digit_end,
                                           he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P) {
@@ -2510,7 +2814,7 @@ int he_gadget_product_hoisted_lazy_digits(he_handle hev, int levelQ, he_handle h
         }
         return HE_OK;
     }
-    return ks_inner(*ev, levelQ, k->nPk - 1, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(),
+    return ks_inner(*ev, levelQ, k->nPk - 1, dec->view(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(),
                     dec->batch, nullptr, 0, 0, digit_begin, digit_end);
 }
 int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, he_handle hout0, he_handle hout1) {
@@ -2526,22 +2830,37 @@ int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c
             TRY(check_be_poly(*pp, be, levelQ + 1, "he_moddown"));
             if (pp->batch != out0->batch) return fail(HE_EINVAL, "he_moddown: batch mismatch");
         }
-        Scope sc(be.ctx.get());
-        be.ctx->acct(4.0 * (levelQ + 1), 0, out0->batch, be.Q->N);
-        const LimbTab tq = ident_tab(levelQ + 1);
-        HIP_TRY(launch_ew(be.qp, tq, EW_COPY, q0->view(), q0->view(), out0->view(), out0->batch, nullptr, nullptr, be.ctx->stream));
-        HIP_TRY(launch_ew(be.qp, tq, EW_COPY, q1->view(), q1->view(), out1->view(), out1->batch, nullptr, nullptr, be.ctx->stream));
-        return HE_OK;
+        CoReq q;
+        q.op = CO_MODDOWN; q.obj = ev.get(); q.par[0] = levelQ; q.par[1] = -1;
+        q.ops = {q0->view(), q1->view(), out0->view(), out1->view()};
+        q.keep = {ev, q0, q1, out0, out1};
+        q.run = [ev, levelQ](const View *v, int B) -> int {
+            BasisExtender &be = *ev->be;
+            be.ctx->acct(4.0 * (levelQ + 1), 0, B, be.Q->N);
+            const LimbTab tq = ident_tab(levelQ + 1);
+            HIP_TRY(launch_ew(be.qp, tq, EW_COPY, v[0], v[0], v[2], B, nullptr, nullptr, be.ctx->stream));
+            HIP_TRY(launch_ew(be.qp, tq, EW_COPY, v[1], v[1], v[3], B, nullptr, nullptr, be.ctx->stream));
+            return HE_OK;
+        };
+        return co_dispatch(*be.ctx, out0->batch, q);
     }
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, levelP, out0->batch, o, "he_moddown"));
     TRY(check_be_poly(*out0, be, levelQ + 1, "he_moddown"));
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_moddown"));
     if (out1->batch != out0->batch) return fail(HE_EINVAL, "he_moddown: batch mismatch");
-    Scope sc(be.ctx.get());
-    be.ctx->acct(2.0 * (2.0 * (levelQ + 1) + levelP + 1), 0, out0->batch, be.Q->N);  // ModDown of both components: 2 (2 L + alpha)
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, levelP, out0->batch, false)));
-    return moddown_pair(*ev, levelQ, levelP, o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), out0->view(), out1->view(), out0->batch);
+    CoReq q;
+    q.op = CO_MODDOWN; q.obj = ev.get(); q.par[0] = levelQ; q.par[1] = levelP;
+    q.ops = {o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view(), out0->view(), out1->view()};
+    q.keep = {ev, o.q0, o.p0, o.q1, o.p1, out0, out1};
+    q.run = [ev, levelQ, levelP](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(2.0 * (2.0 * (levelQ + 1) + levelP + 1), 0, B, be.Q->N);  // ModDown of both components: 2 (2 L + alpha)
+        TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, levelP, B, false)));
+        return moddown_pair(*ev, levelQ, levelP, v[0], v[1], v[2], v[3], v[4], v[5], B);
+    };
+    q.tables_ok = [ev](bool *ok) -> int { *ok = ev->be->type == 0; return HE_OK; };
+    return co_dispatch(*be.ctx, out0->batch, q);
 }
 int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle h1q, he_handle h1p, he_handle h2) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -2555,32 +2874,40 @@ int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle
     TRY(check_be_poly(*p1p, be, levelP + 1, who));
     TRY(check_be_poly(*p2, be, levelQ + 1, who));
     if (p1q->batch != p1p->batch || p1q->batch != p2->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
-    Scope sc(be.ctx.get());
-    const int B = p1q->batch, N = be.Q->N;
-    be.ctx->acct(2.0 * (levelQ + 1) + levelP + 1, 0, B, N);  // ModDownQPtoQNTT: 2 L + alpha
-    const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
-    TRY(be.ctx->arena_reserve(wP + wQ));
-    View sP{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
-    View sQ{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
-    const FusedPlan *plan = nullptr;
-    TRY(get_md_plan(*ev, levelQ, levelP, &plan));
-    // the fused basis extension runs one 128-thread workgroup per 1024 coefficients and batch entry over ALL destination
-    // limbs: below one workgroup per CU the six-launch path, which also spreads the limbs over the grid, has the lower latency
-    const int rowbits = be.Q->logN <= 12 ? be.Q->logN : (be.Q->logN <= 15 ? 12 : 13);  // ntt_row_bits (kernels.hip)
-    const bool wide = (size_t)B * ((size_t)1 << rowbits) / 128 >= 256;
-    if (!plan->ok || !wide) return moddown_q_ntt(be, levelQ, levelP, p1q->view(), p1p->view(), p2->view(), B, sP, sQ);
-    // three launches: INTT rows (P) -> [cols + ModUpPtoQ + cols] -> NTT rows whose epilogue is the last op of the ModDown
-    hipStream_t st = be.ctx->stream;
-    HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), p1p->view(), sP, B, true, NTT_REDUCE_INPUT, st));
-    const FusedGroup &g = plan->groups[0];
-    const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);
-    HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, B, st, raw, g.total_limbs));
-    NttEpilogue epi;
-    for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
-    epi.y = p1q->view(); epi.has_w = false; epi.w = p1q->view();
-    epi.y_reduce = true;  // p1Q is the caller's: any 64-bit word
-    HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, p2->view(), B, false, raw ? NTT_INPUT_F64 : 0, st, &epi));
-    return HE_OK;
+    CoReq q;
+    q.op = CO_EVAL_MODDOWN; q.obj = ev.get(); q.par[0] = levelQ; q.par[1] = levelP;
+    q.ops = {p1q->view(), p1p->view(), p2->view()};
+    q.keep = {ev, p1q, p1p, p2};
+    q.run = [ev, levelQ, levelP](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        const int N = be.Q->N;
+        be.ctx->acct(2.0 * (levelQ + 1) + levelP + 1, 0, B, N);  // ModDownQPtoQNTT: 2 L + alpha
+        const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
+        TRY(be.ctx->arena_reserve(wP + wQ));
+        View sP{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
+        View sQ{be.ctx->arena_take(wQ), (size_t)(levelQ + 1) * N};
+        const FusedPlan *plan = nullptr;
+        TRY(get_md_plan(*ev, levelQ, levelP, &plan));
+        // the fused basis extension runs one 128-thread workgroup per 1024 coefficients and batch entry over ALL destination
+        // limbs: below one workgroup per CU the six-launch path, which also spreads the limbs over the grid, has the lower latency
+        const int rowbits = be.Q->logN <= 12 ? be.Q->logN : (be.Q->logN <= 15 ? 12 : 13);  // ntt_row_bits (kernels.hip)
+        const bool wide = (size_t)B * ((size_t)1 << rowbits) / 128 >= 256;
+        if (!plan->ok || !wide) return moddown_q_ntt(be, levelQ, levelP, v[0], v[1], v[2], B, sP, sQ);
+        // three launches: INTT rows (P) -> [cols + ModUpPtoQ + cols] -> NTT rows whose epilogue is the last op of the ModDown
+        hipStream_t st = be.ctx->stream;
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelP + 1, 0, 0, be.LQ), v[1], sP, B, true, NTT_REDUCE_INPUT, st));
+        const FusedGroup &g = plan->groups[0];
+        const bool raw = f64_raw_ok(be, levelQ, -1, g.nsrc);
+        HIP_TRY(launch_modup_fused(be.qp, g.dev, 1, g.nsrc, g.dst_classes, sP, sQ, sQ, B, st, raw, g.total_limbs));
+        NttEpilogue epi;
+        for (int i = 0; i <= levelQ; i++) epi.s[i] = be.Q->moduli[i] - be.md_ptoq[levelP][i];
+        epi.y = v[0]; epi.has_w = false; epi.w = v[0];
+        epi.y_reduce = true;  // p1Q is the caller's: any 64-bit word
+        HIP_TRY(launch_ntt_rows(be.qp, ident_tab(levelQ + 1), sQ, v[2], B, false, raw ? NTT_INPUT_F64 : 0, st, &epi));
+        return HE_OK;
+    };
+    q.tables_ok = [ev](bool *ok) -> int { *ok = ev->be->type == 0; return HE_OK; };
+    return co_dispatch(*be.ctx, p1q->batch, q);
 }
 int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he_handle hout0, he_handle hout1) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -2594,13 +2921,24 @@ int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he
     TRY(check_be_poly(*out0, be, levelQ + 1, "he_gadget_product"));
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product"));
     if (out0->batch != cx->batch || out1->batch != cx->batch) return fail(HE_EINVAL, "he_gadget_product: batch mismatch");
-    if (cx->batch == 1 && ev->co->max_batch.load(std::memory_order_relaxed) > 1 && !be.ctx->capturing)
-        return co_submit_keyswitch(ev, CO_GADGET_PRODUCT, levelQ, 0, k, {cx}, out0, out1);
-    Scope sc(be.ctx.get());
-    be.ctx->acct(3.0 * (levelQ + 1), key_limbs(*k, levelQ), cx->batch, be.Q->N);  // GadgetProduct: 3 L + 2 beta (L + alpha)
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, cx->batch, true, k.get())));
-    const View cxv = cx->view();
-    return gadget_product_core(*ev, levelQ, &cxv, nullptr, *k, out0->view(), out1->view(), cx->batch);
+    // an output that is the key switch's NTT-domain operand: its own-digit limbs are still being read while the fused epilogue
+    // writes the outputs of OTHER entries' workgroups -- such requests (their own key: the aliasing pattern) are served one by one
+    const bool alias = cx->d == out0->d || cx->d == out1->d;
+    CoReq q;
+    q.op = CO_GADGET_PRODUCT; q.obj = ev.get(); q.key = k.get(); q.par[0] = levelQ;
+    q.ops = {cx->view(), out0->view(), out1->view()};
+    q.keep = {ev, k, cx, out0, out1};
+    q.run = [ev, k, levelQ](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(3.0 * (levelQ + 1), key_limbs(*k, levelQ), B, be.Q->N);  // GadgetProduct: 3 L + 2 beta (L + alpha)
+        TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, B, true, k.get())));
+        return gadget_product_core(*ev, levelQ, &v[0], nullptr, *k, v[1], v[2], B);
+    };
+    q.tables_ok = [ev, k, levelQ, alias](bool *ok) -> int {
+        *ok = false;
+        return alias ? HE_OK : keyswitch_tables_ok(*ev, levelQ, *k, ok);
+    };
+    return co_dispatch(*be.ctx, cx->batch, q);
 }
 int he_gadget_product_hoisted(he_handle hev, int levelQ, he_handle hdec, he_handle hk, he_handle hout0, he_handle hout1) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -2615,10 +2953,18 @@ int he_gadget_product_hoisted(he_handle hev, int levelQ, he_handle hdec, he_hand
     TRY(check_be_poly(*out0, be, levelQ + 1, "he_gadget_product_hoisted"));
     TRY(check_be_poly(*out1, be, levelQ + 1, "he_gadget_product_hoisted"));
     if (out0->batch != dec->batch || out1->batch != dec->batch) return fail(HE_EINVAL, "he_gadget_product_hoisted: batch mismatch");
-    Scope sc(be.ctx.get());
-    be.ctx->acct(key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + 1), key_limbs(*k, levelQ), dec->batch, be.Q->N);  // hoisted: decomposition in, 2 L out, key
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, dec->batch, false)));
-    return gadget_product_core(*ev, levelQ, nullptr, dec.get(), *k, out0->view(), out1->view(), dec->batch);
+    CoReq q;
+    q.op = CO_GP_HOISTED; q.obj = ev.get(); q.key = k.get(); q.par[0] = levelQ;
+    q.ops = {dec->view(), out0->view(), out1->view()};
+    q.keep = {ev, k, dec, out0, out1};
+    q.run = [ev, k, levelQ](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + 1), key_limbs(*k, levelQ), B, be.Q->N);  // hoisted: decomposition in, 2 L out, key
+        TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, B, false)));
+        return gadget_product_core(*ev, levelQ, nullptr, &v[0], *k, v[1], v[2], B);
+    };
+    q.tables_ok = [ev](bool *ok) -> int { *ok = ev->be->type == 0; return HE_OK; };
+    return co_dispatch(*be.ctx, dec->batch, q);
 }
 
 // Relinearize (core/rlwe/evaluator_evaluationkey.go:117-148)
@@ -2636,15 +2982,25 @@ int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_
         TRY(check_be_poly(*p, be, level + 1, "he_relinearize"));
         if (p->batch != in0->batch) return fail(HE_EINVAL, "he_relinearize: batch mismatch");
     }
-    if (in0->batch == 1 && ev->co->max_batch.load(std::memory_order_relaxed) > 1 && !be.ctx->capturing)
-        return co_submit_keyswitch(ev, CO_RELINEARIZE, level, 0, k, {in0, in1, in2}, out0, out1);
-    Scope sc(be.ctx.get());
-    const int B = in0->batch, N = be.Q->N;
-    be.ctx->acct(5.0 * (std::min(level, k->nQk - 1) + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, N);  // Relinearize: 3 L in, 2 L out, key
-    (void)N;
-    TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k.get())));
-    const View in2v = in2->view(), in0v = in0->view(), in1v = in1->view();
-    return gadget_product_core(*ev, level, &in2v, nullptr, *k, out0->view(), out1->view(), B, &in0v, &in1v);
+    // Aliasing that the batched pipeline cannot take for a whole batch: an output that is the key switch's NTT-domain operand
+    // (in2) or the OTHER component's addend.  An output equal to its own component's addend -- Relinearize in place -- is read and
+    // written by the same thread and batches normally.
+    const bool alias = in2->d == out0->d || in2->d == out1->d || in0->d == out1->d || in1->d == out0->d;
+    CoReq q;
+    q.op = CO_RELINEARIZE; q.obj = ev.get(); q.key = k.get(); q.par[0] = level;
+    q.ops = {in0->view(), in1->view(), in2->view(), out0->view(), out1->view()};
+    q.keep = {ev, k, in0, in1, in2, out0, out1};
+    q.run = [ev, k, level](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(5.0 * (std::min(level, k->nQk - 1) + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, be.Q->N);  // Relinearize: 3 L in, 2 L out, key
+        TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k.get())));
+        return gadget_product_core(*ev, level, &v[2], nullptr, *k, v[3], v[4], B, &v[0], &v[1]);
+    };
+    q.tables_ok = [ev, k, level, alias](bool *ok) -> int {
+        *ok = false;
+        return alias ? HE_OK : keyswitch_tables_ok(*ev, level, *k, ok);
+    };
+    return co_dispatch(*be.ctx, in0->batch, q);
 }
 
 // Automorphism / AutomorphismHoisted (core/rlwe/evaluator_automorphism.go:13-100), NTT domain
@@ -2672,7 +3028,7 @@ static int cached_auto_index(Evaluator &ev, uint64_t gal, const uint32_t **out) 
 // the launches of Automorphism / AutomorphismHoisted over B entries; the caller holds the context (Scope).  in1: the NTT-domain
 // second component (null when `dec` holds its decomposition).  in0 / in1 / out0 / out1 may carry entry tables (a coalesced batch)
 // when keyswitch_tables_ok() said so.
-static int automorphism_core(Evaluator &ev, int level, View in0, const View *in1, const Decomp *dec, uint64_t gal, const Evk &k, View out0,
+static int automorphism_core(Evaluator &ev, int level, View in0, const View *in1, const View *dec, uint64_t gal, const Evk &k, View out0,
                              View out1, int B) {
     BasisExtender &be = *ev.be;
     const int N = be.Q->N;
@@ -2734,13 +3090,21 @@ static int automorphism_common(he_handle hev, int level, he_handle hin0, he_hand
     if (!(gal & 1)) return fail(HE_EINVAL, "%s: Galois element must be odd", who);
     if (dec && k->pw2) return fail(HE_EINVAL, "%s: method is unsupported for BaseTwoDecomposition != 0", who);
     if (dec) TRY(check_decomp(*ev, *dec, level, k->nPk - 1, who));
-    // a single-ciphertext Automorphism on an evaluator with a submission queue joins it (he_evaluator_set_coalescing)
-    if (in1 && B == 1 && ev->co->max_batch.load(std::memory_order_relaxed) > 1 && !be.ctx->capturing)
-        return co_submit_keyswitch(ev, CO_AUTOMORPHISM, level, gal, k, {in0, in1}, out0, out1);
-    Scope sc(be.ctx.get());
-    View in1v{nullptr, 0};
-    if (in1) in1v = in1->view();
-    return automorphism_core(*ev, level, in0->view(), in1 ? &in1v : nullptr, dec ? dec.get() : nullptr, gal, *k, out0->view(), out1->view(), B);
+    // (an automorphism that writes onto its own inputs takes the gather form, which reads them all first: no entry tables then)
+    const bool alias = in0->d == out0->d || in0->d == out1->d || (in1 && (in1->d == out0->d || in1->d == out1->d));
+    const bool hoisted = dec != nullptr;
+    CoReq q;
+    q.op = hoisted ? CO_AUTO_HOISTED : CO_AUTOMORPHISM; q.obj = ev.get(); q.key = k.get(); q.par[0] = level; q.par[1] = (int64_t)gal;
+    q.ops = {in0->view(), hoisted ? dec->view() : in1->view(), out0->view(), out1->view()};
+    q.keep = {ev, k, in0, in1, dec, out0, out1};
+    q.run = [ev, k, level, gal, hoisted](const View *v, int B) -> int {
+        return automorphism_core(*ev, level, v[0], hoisted ? nullptr : &v[1], hoisted ? &v[1] : nullptr, gal, *k, v[2], v[3], B);
+    };
+    q.tables_ok = [ev, k, level, alias](bool *ok) -> int {
+        *ok = false;
+        return alias ? HE_OK : keyswitch_tables_ok(*ev, level, *k, ok);
+    };
+    return co_dispatch(*be.ctx, B, q);
 }
 int he_automorphism_ct(he_handle ev, int level, he_handle in0, he_handle in1, uint64_t gal, he_handle gk, he_handle out0, he_handle out1) {
     return automorphism_common(ev, level, in0, in1, 0, gal, gk, out0, out1, "he_automorphism_ct");
@@ -2759,7 +3123,7 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     GET(k, Evk, hk, T_EVK);
     BasisExtender &be = *ev->be;
     if (levelQ < 0 || levelQ > k->nQk - 1) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: levelQ out of range");
-    const int levelP = k->nPk - 1, B = dec->batch, N = be.Q->N;
+    const int levelP = k->nPk - 1, B = dec->batch;
     if (k->ev.get() != ev.get()) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: key belongs to another evaluator");
     if (k->pw2) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: method is unsupported for BaseTwoDecomposition != 0");
     if (!(gal & 1)) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: Galois element must be odd");
@@ -2768,47 +3132,55 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     if (in0->batch != B) return fail(HE_EINVAL, "he_automorphism_hoisted_lazy: batch mismatch");
     QPOut o;
     TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, levelP, B, o, "he_automorphism_hoisted_lazy"));
-    Scope sc(be.ctx.get());
-    be.ctx->acct(levelQ + 1 + key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + levelP + 2), key_limbs(*k, levelQ), B, N);
-    ScalarTab s{};  // ctTmp[1].Q = ctIn[0] * P   (MulScalarBigint with P = prod p_j at levelP)
-    for (int i = 0; i <= levelQ; i++) {
-        const ModConst &m = be.Q->sub[i].mc;
-        uint64_t pm = 1;
-        for (int j = 0; j <= levelP; j++) pm = mulmod(pm, be.P->moduli[j] % m.q, m.q);
-        s.s[i] = mform(pm, m.q, m.brc0, m.brc1);
-    }
-    // ONE launch: the key inner product adds ctIn[0] * P to component 0 at the source position and stores all four accumulators
-    // through the automorphism (KsScatter) -- instead of inner product, two element-wise passes and four gathers.  Standard
-    // ring, and the outputs must not be the addend (other threads still read it); HERING_NO_AUTO_SCATTER=1: the old sequence.
-    static const bool no_scatter = env_flag("HERING_NO_AUTO_SCATTER");
     const bool alias = o.q0->d == in0->d || o.q1->d == in0->d;
-    if (!no_scatter && be.type == 0 && !alias) {
-        KsScatter ks;
-        const uint64_t mask = (2ull << be.Q->logN) - 1;
-        uint64_t x = gal & mask;
-        for (int i = 0; i < 6; i++) x = (x * (2 - gal * x)) & mask;  // Newton: g^-1 mod 2N (g odd)
-        ks.ginv = (uint32_t)x;
-        ks.add0 = in0->view();
-        for (int i = 0; i <= levelQ; i++) ks.add_s[i] = s.s[i];
-        return ks_inner(*ev, levelQ, levelP, dec->d, dec->bstride(), dec->dstride(), *k, o.q0->view(), o.p0->view(), o.q1->view(),
-                        o.p1->view(), B, nullptr, 0, 0, 0, -1, &ks);
-    }
-    const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
-    TRY(be.ctx->arena_reserve(2 * B * (sQw + sPw) + N + 64));
-    View t0Q{be.ctx->arena_take(B * sQw), sQw}, t1Q{be.ctx->arena_take(B * sQw), sQw};
-    View t0P{be.ctx->arena_take(B * sPw), sPw}, t1P{be.ctx->arena_take(B * sPw), sPw};
-    const uint32_t *index = nullptr;
-    TRY(cached_auto_index(*ev, gal, &index));
-    hipStream_t st = be.ctx->stream;
-    TRY(ks_inner(*ev, levelQ, levelP, dec->d, dec->bstride(), dec->dstride(), *k, t0Q, t0P, t1Q, t1P, B));
-    const LimbTab tq = ident_tab(levelQ + 1), tp = ident_tab(levelP + 1, 0, 0, be.LQ);
-    HIP_TRY(launch_gather(be.qp, tq, t1Q, index, o.q1->view(), B, false, st));
-    HIP_TRY(launch_gather(be.qp, tp, t1P, index, o.p1->view(), B, false, st));
-    HIP_TRY(launch_ew(be.qp, tq, EW_MUL_SCALAR_MONT, in0->view(), in0->view(), t1Q, B, &s, nullptr, st));
-    HIP_TRY(launch_ew(be.qp, tq, EW_ADD, t0Q, t1Q, t0Q, B, nullptr, nullptr, st));
-    HIP_TRY(launch_gather(be.qp, tq, t0Q, index, o.q0->view(), B, false, st));
-    HIP_TRY(launch_gather(be.qp, tp, t0P, index, o.p0->view(), B, false, st));
-    return HE_OK;
+    const size_t dec_ds = dec->dstride();
+    CoReq q;
+    q.op = CO_AUTO_HOISTED_LAZY; q.obj = ev.get(); q.key = k.get(); q.par[0] = levelQ; q.par[1] = (int64_t)gal;
+    q.ops = {in0->view(), dec->view(), o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view()};
+    q.keep = {ev, k, in0, dec, o.q0, o.p0, o.q1, o.p1};
+    q.run = [ev, k, levelQ, levelP, gal, alias, dec_ds](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        const int N = be.Q->N;
+        be.ctx->acct(levelQ + 1 + key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + levelP + 2), key_limbs(*k, levelQ), B, N);
+        ScalarTab s{};  // ctTmp[1].Q = ctIn[0] * P   (MulScalarBigint with P = prod p_j at levelP)
+        for (int i = 0; i <= levelQ; i++) {
+            const ModConst &m = be.Q->sub[i].mc;
+            uint64_t pm = 1;
+            for (int j = 0; j <= levelP; j++) pm = mulmod(pm, be.P->moduli[j] % m.q, m.q);
+            s.s[i] = mform(pm, m.q, m.brc0, m.brc1);
+        }
+        // ONE launch: the key inner product adds ctIn[0] * P to component 0 at the source position and stores all four accumulators
+        // through the automorphism (KsScatter) -- instead of inner product, two element-wise passes and four gathers.  Standard
+        // ring, and the outputs must not be the addend (other threads still read it); HERING_NO_AUTO_SCATTER=1: the old sequence.
+        static const bool no_scatter = env_flag("HERING_NO_AUTO_SCATTER");
+        if (!no_scatter && be.type == 0 && !alias) {
+            KsScatter ks;
+            const uint64_t mask = (2ull << be.Q->logN) - 1;
+            uint64_t x = gal & mask;
+            for (int i = 0; i < 6; i++) x = (x * (2 - gal * x)) & mask;  // Newton: g^-1 mod 2N (g odd)
+            ks.ginv = (uint32_t)x;
+            ks.add0 = v[0];
+            for (int i = 0; i <= levelQ; i++) ks.add_s[i] = s.s[i];
+            return ks_inner(*ev, levelQ, levelP, v[1], dec_ds, *k, v[2], v[3], v[4], v[5], B, nullptr, 0, 0, 0, -1, &ks);
+        }
+        const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
+        TRY(be.ctx->arena_reserve(2 * B * (sQw + sPw) + N + 64));
+        View t0Q{be.ctx->arena_take(B * sQw), sQw}, t1Q{be.ctx->arena_take(B * sQw), sQw};
+        View t0P{be.ctx->arena_take(B * sPw), sPw}, t1P{be.ctx->arena_take(B * sPw), sPw};
+        const uint32_t *index = nullptr;
+        TRY(cached_auto_index(*ev, gal, &index));
+        hipStream_t st = be.ctx->stream;
+        TRY(ks_inner(*ev, levelQ, levelP, v[1], dec_ds, *k, t0Q, t0P, t1Q, t1P, B));
+        const LimbTab tq = ident_tab(levelQ + 1), tp = ident_tab(levelP + 1, 0, 0, be.LQ);
+        HIP_TRY(launch_gather(be.qp, tq, t1Q, index, v[4], B, false, st));
+        HIP_TRY(launch_gather(be.qp, tp, t1P, index, v[5], B, false, st));
+        HIP_TRY(launch_ew(be.qp, tq, EW_MUL_SCALAR_MONT, v[0], v[0], t1Q, B, &s, nullptr, st));
+        HIP_TRY(launch_ew(be.qp, tq, EW_ADD, t0Q, t1Q, t0Q, B, nullptr, nullptr, st));
+        HIP_TRY(launch_gather(be.qp, tq, t0Q, index, v[2], B, false, st));
+        HIP_TRY(launch_gather(be.qp, tp, t0P, index, v[3], B, false, st));
+        return HE_OK;
+    };
+    return co_dispatch(*be.ctx, B, q);
 }
 
 // centred lifts / hoisting-buffer fill of bootstrapping.Evaluator.ModUp (see hering.h)
@@ -2838,10 +3210,17 @@ int he_centered_lift(he_handle hev, int strict, he_handle hsrc, int first_q, int
     for (int j = 0; j <= levelP; j++, n++) { a.dst_limb[n] = (uint8_t)j; a.dst_mod[n] = (uint8_t)(be.LQ + j); a.dst_view[n] = 1; }
     a.ndst = n;
     if (n > kMaxLimbs) return fail(HE_EINVAL, "%s: too many destination limbs", who);
-    Scope sc(be.ctx.get());
-    be.ctx->acct(1.0 + n, 0, src->batch, be.Q->N);
-    HIP_TRY(launch_center_copy(be.qp, a, src->view(), dq->view(), dp ? dp->view() : dq->view(), src->batch, be.ctx->stream, strict & 3));
-    return HE_OK;
+    CoReq q;
+    q.op = CO_CENTERED_LIFT; q.obj = ev.get(); q.par[0] = strict & 3; q.par[1] = first_q; q.par[2] = levelQ; q.par[3] = levelP;
+    q.ops = {src->view(), dq->view(), dp ? dp->view() : dq->view()};
+    q.keep = {ev, src, dq, dp};
+    q.run = [ev, a, n, strict](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(1.0 + n, 0, B, be.Q->N);
+        HIP_TRY(launch_center_copy(be.qp, a, v[0], v[1], v[2], B, be.ctx->stream, strict & 3));
+        return HE_OK;
+    };
+    return co_dispatch(*be.ctx, src->batch, q);
 }
 int he_decomp_fill(he_handle hdec, int levelQ, int levelP, he_handle hq, he_handle hp) {
     GET(d, Decomp, hdec, T_DECOMP);
@@ -2853,17 +3232,25 @@ int he_decomp_fill(he_handle hdec, int levelQ, int levelP, he_handle hq, he_hand
     TRY(check_be_poly(*sq, be, levelQ + 1, who));
     TRY(check_be_poly(*sp, be, levelP + 1, who));
     if (sq->batch != d->batch || sp->batch != d->batch) return fail(HE_EINVAL, "%s: batch mismatch", who);
-    Scope sc(be.ctx.get());
-    be.ctx->acct(levelQ + levelP + 2 + (double)d->beta_max * (levelQ + levelP + 2), 0, d->batch, be.Q->N);
     d->fillQ = -1;  // see he_decompose_ntt
-    const size_t N = be.Q->N;
-    for (int dg = 0; dg < d->beta_max; dg++) {
-        uint64_t *base = d->d + (size_t)dg * d->dstride();
-        HIP_TRY(hipMemcpy2DAsync(base, d->bstride() * 8, sq->d, sq->view().bstride * 8, (size_t)(levelQ + 1) * N * 8, d->batch,
-                                 hipMemcpyDeviceToDevice, be.ctx->stream));
-        HIP_TRY(hipMemcpy2DAsync(base + (size_t)be.LQ * N, d->bstride() * 8, sp->d, sp->view().bstride * 8,
-                                 (size_t)(levelP + 1) * N * 8, d->batch, hipMemcpyDeviceToDevice, be.ctx->stream));
-    }
+    const std::shared_ptr<Evaluator> ev = d->ev;
+    const int beta_max = d->beta_max;
+    const size_t dec_ds = d->dstride();
+    CoReq q;
+    q.op = CO_DECOMP_FILL; q.obj = ev.get(); q.par[0] = levelQ; q.par[1] = levelP;
+    q.ops = {sq->view(), sp->view(), d->view()};
+    q.keep = {ev, sq, sp, d};
+    q.run = [ev, levelQ, levelP, beta_max, dec_ds](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        be.ctx->acct(levelQ + levelP + 2 + (double)beta_max * (levelQ + levelP + 2), 0, B, be.Q->N);
+        for (int dg = 0; dg < beta_max; dg++) {  // every digit block takes a copy of the Q part and of the P part
+            View blk{v[2].p + (size_t)dg * dec_ds, v[2].bstride, v[2].tab};
+            HIP_TRY(launch_ew(be.qp, ident_tab(levelQ + 1), EW_COPY, v[0], v[0], blk, B, nullptr, nullptr, be.ctx->stream));
+            HIP_TRY(launch_ew(be.qp, ident_tab(levelP + 1, 0, be.LQ, be.LQ), EW_COPY, v[1], v[1], blk, B, nullptr, nullptr, be.ctx->stream));
+        }
+        return HE_OK;
+    };
+    TRY(co_dispatch(*be.ctx, d->batch, q));
     d->fillQ = levelQ; d->fillP = levelP; d->fill_beta = d->beta_max;
     return HE_OK;
 }
@@ -2885,12 +3272,13 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
     const int B = q0->batch;
     QPOut o;
     TRY(get_qp_out(o0Q, o0P, o1Q, o1P, be, levelQ, levelP, B, o, who));
-    DiagMacArgs aq{}, ap{};
-    aq.n = ap.n = n;
-    aq.nlimbs = levelQ + 1; ap.nlimbs = levelP + 1;
-    aq.accumulate = ap.accumulate = accumulate ? 1 : 0;
-    aq.mod0 = 0; ap.mod0 = be.LQ;
-    std::vector<std::shared_ptr<Obj>> keep;  // inputs stay alive until the launches are enqueued
+    // operands of the request: [0..3] the outputs, then per term i: 6 i + 4 + {0: ptQ, 1: c0Q, 2: c1Q, 3: ptP, 4: c0P, 5: c1P}
+    // (null views for the P part of a term without one)
+    CoReq q;
+    q.op = CO_LINTRANS; q.obj = ev.get(); q.par[0] = levelQ; q.par[1] = levelP; q.par[2] = n; q.par[3] = accumulate ? 1 : 0;
+    q.ops = {o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view()};
+    q.keep = {ev, o.q0, o.p0, o.q1, o.p1};
+    std::vector<const uint32_t *> idx(n, nullptr);
     for (int i = 0; i < n; i++) {
         GET(tq, Poly, ptQ[i], T_POLY);
         GET(c0q, Poly, ct0Q[i], T_POLY);
@@ -2900,20 +3288,22 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
         TRY(check_be_poly(*c1q, be, levelQ + 1, who));
         if ((tq->batch != 1 && tq->batch != B) || c0q->batch != B || c1q->batch != B) return fail(HE_EINVAL, "%s: batch mismatch (term %d)", who, i);
         if (c0q->d == q0->d || c0q->d == q1->d || c1q->d == q0->d || c1q->d == q1->d) return fail(HE_EINVAL, "%s: an input aliases the output", who);
-        const uint32_t *ix = nullptr;
         if (index && index[i]) {
             GET(ixo, AutoIndex, index[i], T_INDEX);
             if (ixo->N != be.Q->N) return fail(HE_EINVAL, "%s: automorphism index of another degree", who);
-            ix = ixo->d;
-            keep.push_back(ixo);
+            idx[i] = ixo->d;
+            q.keep.push_back(ixo);
         }
-        aq.pt[i] = tq->d; aq.pt_bs[i] = tq->batch == 1 ? 0 : tq->view().bstride;
-        aq.c0[i] = c0q->d; aq.c0_bs[i] = c0q->view().bstride;
-        aq.c1[i] = c1q->d; aq.c1_bs[i] = c1q->view().bstride;
-        aq.index[i] = ap.index[i] = ix;
-        keep.push_back(tq); keep.push_back(c0q); keep.push_back(c1q);
+        q.blob.push_back((uint64_t)(uintptr_t)idx[i]);  // (the index table is part of the key: the same rotation for every entry)
+        View vt = tq->view();
+        if (tq->batch == 1) vt.bstride = 0;  // one plaintext diagonal for the whole batch
+        q.ops.push_back(vt); q.ops.push_back(c0q->view()); q.ops.push_back(c1q->view());
+        q.keep.push_back(tq); q.keep.push_back(c0q); q.keep.push_back(c1q);
         if ((ct0P[i] == 0) != (ct1P[i] == 0)) return fail(HE_EINVAL, "%s: term %d has only one P part", who, i);
-        if (ct0P[i] == 0) { ap.pt[i] = nullptr; ap.c0[i] = ap.c1[i] = nullptr; continue; }
+        if (ct0P[i] == 0) {
+            q.ops.push_back(View{nullptr, 0}); q.ops.push_back(View{nullptr, 0}); q.ops.push_back(View{nullptr, 0});
+            continue;
+        }
         GET(tp, Poly, ptP[i], T_POLY);
         GET(c0p, Poly, ct0P[i], T_POLY);
         GET(c1p, Poly, ct1P[i], T_POLY);
@@ -2922,21 +3312,47 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
         TRY(check_be_poly(*c1p, be, levelP + 1, who));
         if ((tp->batch != 1 && tp->batch != B) || c0p->batch != B || c1p->batch != B) return fail(HE_EINVAL, "%s: batch mismatch (term %d)", who, i);
         if (c0p->d == p0->d || c0p->d == p1->d || c1p->d == p0->d || c1p->d == p1->d) return fail(HE_EINVAL, "%s: an input aliases the output", who);
-        ap.pt[i] = tp->d; ap.pt_bs[i] = tp->batch == 1 ? 0 : tp->view().bstride;
-        ap.c0[i] = c0p->d; ap.c0_bs[i] = c0p->view().bstride;
-        ap.c1[i] = c1p->d; ap.c1_bs[i] = c1p->view().bstride;
-        keep.push_back(tp); keep.push_back(c0p); keep.push_back(c1p);
+        View vp = tp->view();
+        if (tp->batch == 1) vp.bstride = 0;
+        q.ops.push_back(vp); q.ops.push_back(c0p->view()); q.ops.push_back(c1p->view());
+        q.keep.push_back(tp); q.keep.push_back(c0p); q.keep.push_back(c1p);
     }
-    Scope sc(be.ctx.get());
-    {   // per term: the plaintext diagonal (shared by the batch when it has batch 1) and both ciphertext components; two outputs
+    q.run = [ev, levelQ, levelP, n, accumulate, idx](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        DiagMacArgs aq{}, ap{};
+        aq.n = ap.n = n;
+        aq.nlimbs = levelQ + 1; ap.nlimbs = levelP + 1;
+        aq.accumulate = ap.accumulate = accumulate ? 1 : 0;
+        aq.mod0 = 0; ap.mod0 = be.LQ;
+        const bool tabs = v[0].tab != nullptr;  // a coalesced batch: the terms' operands are rows 4 + 6 i ... of the entry table
         double per = 2.0, shared = 0.0;
-        for (int i = 0; i < n; i++) { per += 2.0; if (ap.pt_bs[i]) per += 1.0; else shared += 1.0; }
+        for (int i = 0; i < n; i++) {
+            const View *t = v + 4 + 6 * i;
+            aq.pt[i] = t[0].p; aq.pt_bs[i] = t[0].bstride;
+            aq.c0[i] = t[1].p; aq.c0_bs[i] = t[1].bstride;
+            aq.c1[i] = t[2].p; aq.c1_bs[i] = t[2].bstride;
+            ap.pt[i] = t[3].p; ap.pt_bs[i] = t[3].bstride;
+            ap.c0[i] = t[4].p; ap.c0_bs[i] = t[4].bstride;
+            ap.c1[i] = t[5].p; ap.c1_bs[i] = t[5].bstride;
+            aq.index[i] = ap.index[i] = idx[i];
+            // per term: the plaintext diagonal (shared by the batch when it has batch 1) and both ciphertext components
+            per += 2.0;
+            if (t[0].bstride || tabs) per += 1.0; else shared += 1.0;
+        }
+        if (tabs) {
+            // rows 4 + 6 i + {0, 1, 2} are the Q part's (pt, c0, c1) of term i, + {3, 4, 5} the P part's: DiagMacArgs::term_tab wants
+            // [3 i + j][B] -- a table with a stride of six rows per term, so the Q launch starts at row 4, the P launch at row 7,
+            // and both skip the other part's three rows (term_tab_rows = 6)
+            aq.term_tab = v[4].tab; ap.term_tab = v[4].tab + (size_t)3 * B;
+            aq.term_rows = ap.term_rows = 6;
+        }
         be.ctx->acct(per * (levelQ + levelP + 2), shared * (levelQ + levelP + 2), B, be.Q->N);
-    }
-    hipStream_t st = be.ctx->stream;
-    HIP_TRY(launch_diag_mac(be.qp, aq, o.q0->view(), o.q1->view(), B, st));
-    HIP_TRY(launch_diag_mac(be.qp, ap, o.p0->view(), o.p1->view(), B, st));
-    return HE_OK;
+        hipStream_t st = be.ctx->stream;
+        HIP_TRY(launch_diag_mac(be.qp, aq, v[0], v[2], B, st));
+        HIP_TRY(launch_diag_mac(be.qp, ap, v[1], v[3], B, st));
+        return HE_OK;
+    };
+    return co_dispatch(*be.ctx, B, q);
 }
 
 // CKKS mulRelin / BGV tensorStandard (schemes/ckks/evaluator.go:764-872, schemes/bgv/evaluator.go:592-685)
@@ -3006,175 +3422,6 @@ static int keyswitch_tables_ok(Evaluator &ev, int level, const Evk &k, bool *ok)
     return HE_OK;
 }
 
-namespace {
-// ---- coalescing of concurrent single-ciphertext calls (struct Coalescer) ---------------------------------------------
-int co_inflight(Coalescer &c) {  // batches still running or queued on the device (caller holds c.mu)
-    while (!c.inflight.empty() && hipEventQuery(c.inflight.front()) == hipSuccess) {
-        c.free_events.push_back(c.inflight.front());
-        c.inflight.pop_front();
-    }
-    (void)hipGetLastError();  // hipErrorNotReady is not an error here
-    return (int)c.inflight.size();
-}
-// the launches of one request-shaped call over B entries (strided views of one request, or entry-table views of a batch)
-int co_launch(Evaluator &ev, const CoReq &r, const View (&v)[6], int B) {
-    BasisExtender &be = *ev.be;
-    const int N = be.Q->N;
-    switch (r.op) {
-        case CO_MUL_RELIN:
-            return mul_relin_core(ev, r.level, r.bgv, r.t, r.key.get(), v[0], v[1], v[2], v[3], v[4], v[5], View{nullptr, 0}, B, r.alias);
-        case CO_GADGET_PRODUCT:
-            be.ctx->acct(3.0 * (r.level + 1), key_limbs(*r.key, r.level), B, N);
-            TRY(be.ctx->arena_reserve(ks_scratch_words(be, r.level, r.key->nPk - 1, B, true, r.key.get())));
-            return gadget_product_core(ev, r.level, &v[0], nullptr, *r.key, v[4], v[5], B);
-        case CO_RELINEARIZE:
-            be.ctx->acct(5.0 * (r.level + 1), key_limbs(*r.key, r.level), B, N);
-            TRY(be.ctx->arena_reserve(ks_scratch_words(be, r.level, r.key->nPk - 1, B, true, r.key.get())));
-            return gadget_product_core(ev, r.level, &v[2], nullptr, *r.key, v[4], v[5], B, &v[0], &v[1]);
-        case CO_AUTOMORPHISM:
-            return automorphism_core(ev, r.level, v[0], &v[1], nullptr, r.t, *r.key, v[4], v[5], B);
-    }
-    return fail(HE_EINVAL, "coalescer: unknown operation");
-}
-// one batched launch for `batch` (all of one key); returns the status every request of the batch gets
-int co_run(Evaluator &ev, Coalescer &c, const std::vector<CoReq *> &batch, hipEvent_t done_ev) {
-    BasisExtender &be = *ev.be;
-    const CoReq &r0 = *batch[0];
-    const int B = (int)batch.size();
-    Scope sc(be.ctx.get());
-    bool tables = false;
-    if (B > 1) {
-        if (r0.op == CO_MUL_RELIN) TRY(mul_relin_tables_ok(ev, r0.level, *r0.key, &tables));
-        else if (!r0.alias) TRY(keyswitch_tables_ok(ev, r0.level, *r0.key, &tables));  // (flagged key switches: one by one)
-    }
-    const std::shared_ptr<Poly> CoReq::*slot[6] = {&CoReq::a0, &CoReq::a1, &CoReq::b0, &CoReq::b1, &CoReq::o0, &CoReq::o1};
-    int rc = HE_OK;
-    if (B > c.tab_cap) tables = false;  // (gathered under a larger max_batch than the table was sized for)
-    if (B == 1 || !tables) {
-        // one entry, or a shape whose pipeline has launches without entry tables (unfused ModDown): one call per request
-        if (B > 1) c.n_fallback += (uint64_t)B;
-        for (CoReq *r : batch) {
-            be.ctx->arena_reset();
-            View v[6];
-            for (int sidx = 0; sidx < 6; sidx++) v[sidx] = ((*r).*slot[sidx]) ? ((*r).*slot[sidx])->view() : View{nullptr, 0};
-            rc = co_launch(ev, *r, v, 1);
-            if (rc != HE_OK) break;
-        }
-    } else {
-        // entry tables: row s of the table holds, per entry, the word offset of that entry's polynomial from entry 0's
-        std::vector<size_t> vals((size_t)6 * B, 0);
-        View v[6];
-        for (int sidx = 0; sidx < 6; sidx++) {
-            if (!((*batch[0]).*slot[sidx])) { v[sidx] = View{nullptr, 0}; continue; }
-            uint64_t *base = ((*batch[0]).*slot[sidx])->d;
-            for (int z = 0; z < B; z++) vals[(size_t)sidx * B + z] = (size_t)((((*batch[z]).*slot[sidx])->d) - base);
-            v[sidx] = View{base, 0, c.d_tab + (size_t)sidx * B};
-        }
-        HIP_TRY(launch_tab_fill(c.d_tab, vals.data(), 6 * B, be.ctx->stream));
-        rc = co_launch(ev, r0, v, B);
-    }
-    if (rc == HE_OK && done_ev) HIP_TRY(hipEventRecord(done_ev, be.ctx->stream));
-    return rc;
-}
-// the calling thread is the leader: serve batches until its own request is done (caller holds lk on c.mu)
-void co_lead(Evaluator &ev, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mine) {
-    using clock = std::chrono::steady_clock;
-    hipSetDevice(ev.be->ctx->dev);
-    while (!mine.done) {
-        // gather: up to max_batch requests.  While the device still has two batches of this queue ahead of it, waiting is free.
-        // Otherwise stop once no request has arrived for window_us AND at least half of the recent batches' callers are here
-        // (callers that wait for their result come back together, as fast as the OS schedules them), or 8 window_us after the
-        // oldest request arrived.  No window at all for a lone caller (crowd == 0).
-        const int hint = std::max(std::max(c.recent[0], c.recent[1]), std::max(c.recent[2], c.recent[3]));
-        // (at least one: a request that passed the "queue on?" test just before the queue was switched off is still served)
-        const int max_batch = std::max(1, c.max_batch.load(std::memory_order_relaxed));
-        for (;;) {
-            if ((int)c.pending.size() >= max_batch) break;
-            const bool busy = co_inflight(c) >= 2;
-            const auto now = clock::now();
-            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.front()->arrived).count();
-            const auto quiet = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.back()->arrived).count();
-            const long long win = c.crowd > 0 ? c.window_us : 0;
-            if (!busy && ((quiet >= win && 2 * (int)c.pending.size() >= hint) || waited >= 8 * win)) break;
-            if (busy) {
-                c.cv_leader.wait_for(lk, std::chrono::microseconds(100));  // arrivals notify
-            } else {  // a few microseconds: a timed futex wait would oversleep by the timer slack
-                lk.unlock();
-                sched_yield();
-                lk.lock();
-            }
-        }
-        std::vector<CoReq *> batch;
-        const CoReq &head = *c.pending.front();
-        for (auto it = c.pending.begin(); it != c.pending.end() && (int)batch.size() < max_batch;) {
-            if ((*it)->same_key(head)) { batch.push_back(*it); it = c.pending.erase(it); }
-            else ++it;
-        }
-        if (batch.size() > 1 || !c.pending.empty()) c.crowd = 256;
-        else if (c.crowd > 0) c.crowd--;
-        c.recent[c.n_launches & 3] = (int)batch.size();
-        // the completion event feeds the "two batches ahead" test of the gathering loop: not needed for a lone caller, whose
-        // stream drain would otherwise also wait for the event's barrier packet (a third of a single-ciphertext call's latency)
-        hipEvent_t e = nullptr;
-        if (c.crowd > 0) {
-            if (!c.free_events.empty()) { e = c.free_events.back(); c.free_events.pop_back(); }
-            else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-        }
-        c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
-        lk.unlock();
-        const int rc = co_run(ev, c, batch, e);
-        const std::string msg = rc ? g_err : std::string();
-        lk.lock();
-        if (e) { if (rc == HE_OK) c.inflight.push_back(e); else c.free_events.push_back(e); }
-        for (CoReq *r : batch) {
-            r->rc = rc; r->err = msg; r->done = true;
-            if (r != &mine) r->cv.notify_one();
-        }
-    }
-}
-int co_submit(Evaluator &ev, CoReq &r) {
-    Coalescer &c = *ev.co;
-    std::unique_lock<std::mutex> lk(c.mu);
-    r.arrived = std::chrono::steady_clock::now();
-    c.pending.push_back(&r);
-    if (c.leader) c.cv_leader.notify_one();  // a gathering leader counts arrivals
-    while (!r.done) {
-        if (!c.leader || r.lead) {
-            c.leader = true;
-            r.lead = false;
-            co_lead(ev, c, lk, r);
-            // hand the role to the oldest request still waiting (it is asleep on its own condition variable), if any
-            if (!c.pending.empty()) { c.pending.front()->lead = true; c.pending.front()->cv.notify_one(); }
-            else c.leader = false;
-        } else {
-            r.cv.wait(lk);
-        }
-    }
-    lk.unlock();
-    if (r.rc != HE_OK) return fail(r.rc, "%s", r.err.c_str());
-    return HE_OK;
-}
-}  // namespace
-
-static int co_submit_keyswitch(const std::shared_ptr<Evaluator> &ev, int op, int level, uint64_t t, const std::shared_ptr<Evk> &k,
-                               std::initializer_list<std::shared_ptr<Poly>> ins, const std::shared_ptr<Poly> &o0,
-                               const std::shared_ptr<Poly> &o1) {
-    CoReq r;
-    r.op = op; r.level = level; r.t = t; r.key = k; r.o0 = o0; r.o1 = o1;
-    std::shared_ptr<Poly> CoReq::*slot[4] = {&CoReq::a0, &CoReq::a1, &CoReq::b0, &CoReq::b1};
-    int i = 0;
-    for (const auto &p : ins) r.*slot[i++] = p;
-    // Aliasing that the batched pipeline cannot take for a whole batch on the word of entry 0's pointers: an output that is the
-    // key switch's NTT-domain operand (its own-digit limbs are still being read while the fused epilogue writes the outputs) or
-    // the OTHER component's addend.  Such requests are flagged, batched apart and served one by one (co_run).  An output equal
-    // to its own component's addend -- Relinearize in place -- is read and written by the same thread and batches normally.
-    const Poly *cx = op == CO_GADGET_PRODUCT ? r.a0.get() : op == CO_RELINEARIZE ? r.b0.get() : nullptr;
-    if (cx) r.alias = cx->d == o0->d || cx->d == o1->d;
-    if (op == CO_RELINEARIZE) r.alias = r.alias || r.a0->d == o1->d || r.a1->d == o0->d;
-    // (an automorphism that writes onto its own inputs takes the gather form, which reads them all first: flagged too)
-    if (op == CO_AUTOMORPHISM) r.alias = r.a0->d == o0->d || r.a0->d == o1->d || r.a1->d == o0->d || r.a1->d == o1->d;
-    return co_submit(*ev, r);
-}
 static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_handle ha0, he_handle ha1, he_handle hb0, he_handle hb1,
                             he_handle hk, he_handle hout0, he_handle hout1, he_handle hout2, const char *who) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -3207,17 +3454,16 @@ static int mul_relin_common(he_handle hev, int level, bool bgv, uint64_t t, he_h
     bool alias = false;
     for (Poly *o : {out0.get(), out1.get()})
         for (Poly *in : {a0.get(), a1.get(), b0.get(), b1.get()}) alias = alias || o->d == in->d;
-    // a single-ciphertext MulRelin on an evaluator with a submission queue joins it (not while the context records a graph:
-    // a captured sequence must be this thread's own launches)
-    if (k && B == 1 && ev->co->max_batch.load(std::memory_order_relaxed) > 1 && !be.ctx->capturing) {
-        CoReq r;
-        r.level = level; r.bgv = bgv; r.t = bgv ? t : 0; r.alias = alias; r.key = k;
-        r.a0 = a0; r.a1 = a1; r.b0 = b0; r.b1 = b1; r.o0 = out0; r.o1 = out1;
-        return co_submit(*ev, r);
-    }
-    Scope sc(be.ctx.get());
-    return mul_relin_core(*ev, level, bgv, t, k.get(), a0->view(), a1->view(), b0->view(), b1->view(), out0->view(), out1->view(),
-                          out2 ? out2->view() : View{nullptr, 0}, B, alias);
+    // (a degree-2 output that is one of the inputs: the tensor kernel reads all four inputs of a coefficient before it writes)
+    CoReq q;
+    q.op = k ? CO_MUL_RELIN : CO_MUL; q.obj = ev.get(); q.key = k.get(); q.par[0] = level; q.par[1] = bgv; q.par[2] = (int64_t)(bgv ? t : 0);
+    q.ops = {a0->view(), a1->view(), b0->view(), b1->view(), out0->view(), out1->view(), out2 ? out2->view() : View{nullptr, 0}};
+    q.keep = {ev, k, a0, a1, b0, b1, out0, out1, out2};
+    q.run = [ev, k, level, bgv, t, alias](const View *v, int B) -> int {
+        return mul_relin_core(*ev, level, bgv, t, k.get(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], B, alias);
+    };
+    if (k) q.tables_ok = [ev, k, level](bool *ok) -> int { return mul_relin_tables_ok(*ev, level, *k, ok); };
+    return co_dispatch(*be.ctx, B, q);
 }
 int he_ckks_mul_relin(he_handle ev, int level, he_handle a0, he_handle a1, he_handle b0, he_handle b1, he_handle rlk, he_handle o0, he_handle o1, he_handle o2) {
     return mul_relin_common(ev, level, false, 0, a0, a1, b0, b1, rlk, o0, o1, o2, "he_ckks_mul_relin");

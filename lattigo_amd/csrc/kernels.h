@@ -298,6 +298,10 @@ struct DiagMacArgs {
     const uint64_t *pt[kMaxDiag], *c0[kMaxDiag], *c1[kMaxDiag];  // c0/c1 null: the term is skipped on this ring
     const uint32_t *index[kMaxDiag];                             // null: identity
     size_t pt_bs[kMaxDiag], c0_bs[kMaxDiag], c1_bs[kMaxDiag];
+    // optional entry tables of the terms' operands (View::tab for a term list): row term_rows * i + {0: pt, 1: c0, 2: c1} of
+    // term_tab holds, per batch entry, the word offsets from the term's base pointers; replaces the batch strides
+    const size_t *term_tab = nullptr;
+    int term_rows = 3;
 };
 hipError_t launch_diag_mac(const RingDev &r, const DiagMacArgs &a, View out0, View out1, int batch, hipStream_t s);
 

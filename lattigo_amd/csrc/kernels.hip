@@ -318,6 +318,7 @@ struct NttArgs {
     int cb = 0;  // column kernel only: stages done by an outer column pass (logN >= 19: the columns take two passes, see ntt_cols_kernel)
     const size_t *out_tab = nullptr, *out2_tab = nullptr, *epi_w_tab = nullptr, *epi_w2_tab = nullptr;
     const size_t *ta0_tab = nullptr, *ta1_tab = nullptr, *tb0_tab = nullptr, *tb1_tab = nullptr;
+    const size_t *epi_y_tab = nullptr, *epi_y2_tab = nullptr;  // the epilogue's subtrahend (the rescale's own input)
 };
 
 __device__ __forceinline__ int lds_phys(int e) { return e + (e >> 4); }
@@ -527,7 +528,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
     const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
     const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
     const uint64_t *__restrict__ src = A.in + voff(A.in_tab, A.in_bs, bzi) + (size_t)il * A.N + (size_t)row * N2;
-    uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
+    // (with an epilogue the stores go through `op` below: entries of the second output set have no row in the entry table)
+    uint64_t *__restrict__ dst = A.out + ((!INV && A.epi) ? (size_t)0 : voff(A.out_tab, A.out_bs, bzi)) + (size_t)ol * A.N + (size_t)row * N2;
     const int rowtw = (1 << A.a) + row;  // 2^a + r
 
     uint64_t x[16];
@@ -574,7 +576,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
             const bool second = A.zsplit && (int)bzi >= A.zsplit;
             const size_t zz = second ? bzi - A.zsplit : bzi;
             const size_t off = (size_t)ol * A.N + (size_t)row * N2;
-            const uint64_t *yp = (second ? A.epi_y2 + zz * A.epi_y2_bs : A.epi_y + zz * A.epi_y_bs) + off;
+            const uint64_t *yp = (second ? A.epi_y2 + voff(A.epi_y2_tab, A.epi_y2_bs, zz) : A.epi_y + voff(A.epi_y_tab, A.epi_y_bs, zz)) + off;
             const uint64_t *wp = (second ? A.epi_w2 + voff(A.epi_w2_tab, A.epi_w2_bs, zz) : A.epi_w + voff(A.epi_w_tab, A.epi_w_bs, zz)) + off;
             uint64_t *op = (second ? A.out2 + voff(A.out2_tab, A.out2_bs, zz) : A.out + voff(A.out_tab, A.out_bs, zz)) + off;
             const bool addw = (second ? A.epi2 : A.epi) == 2;
@@ -853,7 +855,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
         for (int k = 0; k < 16; k++) nx[k] = ldnt(&src0[nat_e<T>(k, tau)]);
     }
     for (unsigned bzi = b0; bzi < b1; bzi++) {
-    uint64_t *__restrict__ dst = A.out + (size_t)bzi * A.out_bs + (size_t)ol * A.N + (size_t)row * N2;
+    uint64_t *__restrict__ dst = A.out + ((!INV && A.epi) ? (size_t)0 : voff(A.out_tab, A.out_bs, bzi)) + (size_t)ol * A.N + (size_t)row * N2;
     double x[16];
     if constexpr (!INV) {
         constexpr int sh0 = LOGB - 4;
@@ -893,7 +895,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
             // that a lazy addend w gives the reference's word.  y (a key-switch accumulator) is canonical and below 2^47.
             const bool second = A.zsplit && (int)bzi >= A.zsplit;
             const size_t zz = second ? bzi - A.zsplit : bzi;
-            const uint64_t *yp = (second ? A.epi_y2 + zz * A.epi_y2_bs : A.epi_y + zz * A.epi_y_bs) + (size_t)ol * A.N + (size_t)row * N2;
+            const uint64_t *yp = (second ? A.epi_y2 + voff(A.epi_y2_tab, A.epi_y2_bs, zz) : A.epi_y + voff(A.epi_y_tab, A.epi_y_bs, zz)) + (size_t)ol * A.N + (size_t)row * N2;
             const uint64_t *wp = (second ? A.epi_w2 + voff(A.epi_w2_tab, A.epi_w2_bs, zz) : A.epi_w + voff(A.epi_w_tab, A.epi_w_bs, zz)) + (size_t)ol * A.N + (size_t)row * N2;
             uint64_t *op = (second ? A.out2 + voff(A.out2_tab, A.out2_bs, zz) : A.out + voff(A.out_tab, A.out_bs, zz)) + (size_t)ol * A.N + (size_t)row * N2;
             const bool addw = (second ? A.epi2 : A.epi) == 2;
@@ -1140,6 +1142,8 @@ struct NttMacKArgs {
     const double *twd;
     int N, a;
     NttMacArgs m;
+    // entry tables (View::tab) of the four accumulator outputs when they are the caller's (GadgetProductLazy of a coalesced batch)
+    const size_t *oQ0_tab = nullptr, *oP0_tab = nullptr, *oQ1_tab = nullptr, *oP1_tab = nullptr;
 };
 // QF64: every limb of the launch is a Q limb whose accumulators are written as doubles (NttMacArgs::q_out_f64)
 template <int LOGB, bool QF64>
@@ -1248,8 +1252,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
     }
     const int ol = A.m.out_limb[l];
     const bool isP = A.m.out_view[l] != 0;
-    uint64_t *o0 = (isP ? A.o0P + bz * A.oP0_bs : A.o0Q + bz * A.oQ0_bs) + (size_t)ol * A.N + rowoff;
-    uint64_t *o1 = (isP ? A.o1P + bz * A.oP1_bs : A.o1Q + bz * A.oQ1_bs) + (size_t)ol * A.N + rowoff;
+    uint64_t *o0 = (isP ? A.o0P + voff(A.oP0_tab, A.oP0_bs, bz) : A.o0Q + voff(A.oQ0_tab, A.oQ0_bs, bz)) + (size_t)ol * A.N + rowoff;
+    uint64_t *o1 = (isP ? A.o1P + voff(A.oP1_tab, A.oP1_bs, bz) : A.o1Q + voff(A.oQ1_tab, A.oQ1_bs, bz)) + (size_t)ol * A.N + rowoff;
     if constexpr (QF64) {  // the f64 ModDown epilogue reads these as doubles
         double *d0 = reinterpret_cast<double *>(o0), *d1 = reinterpret_cast<double *>(o1);
 #pragma unroll
@@ -1679,10 +1683,13 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
             }
         }
         const int ol = cur.out_limb;
-        uint64_t *o0 = (cur.isP ? A.o0P + cur.bz * A.oP0_bs : A.o0Q + cur.bz * A.oQ0_bs) + (size_t)ol * A.N + cur.rowoff + tau;
-        uint64_t *o1 = (cur.isP ? A.o1P + cur.bz * A.oP1_bs : A.o1Q + cur.bz * A.oQ1_bs) + (size_t)ol * A.N + cur.rowoff + tau;
+        uint64_t *o0 = nullptr, *o1 = nullptr;
+        if constexpr (!EPI) {
+            o0 = (cur.isP ? A.o0P + voff(A.oP0_tab, A.oP0_bs, cur.bz) : A.o0Q + voff(A.oQ0_tab, A.oQ0_bs, cur.bz)) + (size_t)ol * A.N + cur.rowoff + tau;
+            o1 = (cur.isP ? A.o1P + voff(A.oP1_tab, A.oP1_bs, cur.bz) : A.o1Q + voff(A.oQ1_tab, A.oQ1_bs, cur.bz)) + (size_t)ol * A.N + cur.rowoff + tau;
+        }
         if constexpr (EPI) {
-            (void)o0; (void)o1;  // the epilogue wrote the final outputs
+            (void)o0; (void)o1; (void)ol;  // the epilogue wrote the final outputs
         } else if constexpr (QF64) {  // the f64 ModDown epilogue reads these as doubles
             double *d0 = reinterpret_cast<double *>(o0), *d1 = reinterpret_cast<double *>(o1);
 #pragma unroll
@@ -1731,13 +1738,14 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
                               View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi) {
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     if (!r.twd_fwd || !keyd) return hipErrorInvalidValue;
-    if (dec.tab || (!epi && !no_tab({out0Q, out0P, out1Q, out1P})) || (epi && epi->ext.tab)) return hipErrorInvalidValue;
+    if (dec.tab || (epi && epi->ext.tab) || (a.q_out_f64 && !no_tab({out0Q, out1Q}))) return hipErrorInvalidValue;
     const int b = ntt_row_bits(r.logN), aa = r.logN - b;
     if (epi && !ntt_mac_epilogue_supported(r.logN)) return hipErrorInvalidValue;
     NttMacKArgs A{};
     A.dec = dec.p; A.dec_bs = dec.bstride; A.own = own.p; A.own_bs = own.bstride; A.own_tab = own.tab; A.keyd = keyd;
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
+    A.oQ0_tab = out0Q.tab; A.oP0_tab = out0P.tab; A.oQ1_tab = out1Q.tab; A.oP1_tab = out1P.tab;
     A.mc = r.mc; A.twd = r.twd_fwd; A.N = r.N; A.a = aa; A.m = a;
     // beta digits in (an own digit is the input limb itself), two key rows per digit shared by the batch, two accumulators out
     double mac_bytes = ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0;
@@ -1875,8 +1883,8 @@ __global__ void __launch_bounds__(256) ntt_cols_kernel(NttArgs A) {
     const uint64_t q = mc.q, qinv = mc.qinv, twoq = mc.q << 1;
     const uint64_t *__restrict__ tw = A.tw + (size_t)mi * A.N;
     const size_t e0 = (size_t)blk * ((size_t)N2 << LOGA) + c;
-    const uint64_t *__restrict__ src = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)il * A.N + e0;
-    uint64_t *__restrict__ dst = A.out + (size_t)blockIdx.z * A.out_bs + (size_t)ol * A.N + e0;
+    const uint64_t *__restrict__ src = A.in + voff(A.in_tab, A.in_bs, blockIdx.z) + (size_t)il * A.N + e0;
+    uint64_t *__restrict__ dst = A.out + voff(A.out_tab, A.out_bs, blockIdx.z) + (size_t)ol * A.N + e0;
 
     uint64_t x[R];
 #pragma unroll
@@ -2064,7 +2072,7 @@ static void set_epilogue(NttArgs &A, const NttEpilogue &epi, int n) {
     A.epi_y_f64 = epi.y_small_f64 ? 1 : 0;
     A.epi_y_reduce = epi.y_reduce ? 1 : 0;
     A.epi = epi.has_w ? 2 : 1;
-    A.epi_y = epi.y.p; A.epi_y_bs = epi.y.bstride;
+    A.epi_y = epi.y.p; A.epi_y_bs = epi.y.bstride; A.epi_y_tab = epi.y.tab;
     A.epi_w = epi.w.p; A.epi_w_bs = epi.w.bstride; A.epi_w_tab = epi.w.tab;
     for (int i = 0; i < n; i++) A.epi_s[i] = epi.s[i];
     A.epi_tensor = epi.tensor ? 1 : 0;
@@ -2080,7 +2088,7 @@ static void set_epilogue(NttArgs &A, const NttEpilogue &epi, int n) {
     if (epi.zsplit > 0) {
         A.zsplit = epi.zsplit; A.epi2 = epi.has_w2 ? 2 : 1;
         A.out2 = epi.out2.p; A.out2_bs = epi.out2.bstride; A.out2_tab = epi.out2.tab;
-        A.epi_y2 = epi.y2.p; A.epi_y2_bs = epi.y2.bstride;
+        A.epi_y2 = epi.y2.p; A.epi_y2_bs = epi.y2.bstride; A.epi_y2_tab = epi.y2.tab;
         A.epi_w2 = epi.w2.p; A.epi_w2_bs = epi.w2.bstride; A.epi_w2_tab = epi.w2.tab;
     }
 }
@@ -2090,7 +2098,6 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
     const int n = r.logN;
     if (n < 4 || n > kMaxLogN) return hipErrorInvalidValue;
     if (epi && (inverse || epi->zsplit > 0)) return hipErrorInvalidValue;
-    if (!no_tab({in, out}) || (epi && !no_tab({epi->y, epi->w, epi->dst}))) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
     // column stages: one pass of up to five (32 coefficients per thread); logN = 19, 20 (a = 6, 7) take an outer pass of a - 4
     // and an inner pass of 4 inside the 2^(a-4) blocks the outer pass leaves (ntt_cols_kernel, NttArgs::cb)
@@ -2114,13 +2121,13 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
         A.twd = r.twd_fwd;
         A.scale = 0;
         if (a > 0) {
-            A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
+            A.in = in.p; A.in_bs = in.bstride; A.in_tab = in.tab; A.out = out.p; A.out_bs = out.bstride; A.out_tab = out.tab;
             A.flags = (flags & NTT_REDUCE_INPUT) | sflag;
             if ((e = launch_cols<false>(a_out, gcols, A, s)) != hipSuccess) return e;
             // second pass in place on `out`: limbs are now addressed by out_limb
             NttArgs B = A;
             for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
-            B.in = out.p; B.in_bs = out.bstride;
+            B.in = out.p; B.in_bs = out.bstride; B.in_tab = out.tab;
             if (a_in > 0) {
                 B.flags = 0; B.cb = a_out;
                 if ((e = launch_cols<false>(a_in, gcols_in, B, s)) != hipSuccess) return e;
@@ -2129,28 +2136,28 @@ hipError_t launch_ntt(const RingDev &r, const LimbTab &tab, View in, View out, i
             B.flags = flags & NTT_LAZY_OUT;
             if (epi) {
                 set_epilogue(B, *epi, tab.n);
-                if (epi->has_dst) { B.out = epi->dst.p; B.out_bs = epi->dst.bstride; }
+                if (epi->has_dst) { B.out = epi->dst.p; B.out_bs = epi->dst.bstride; B.out_tab = epi->dst.tab; }
             }
             return launch_rows<false>(b, grows, B, r.host_small, s);
         }
-        A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
+        A.in = in.p; A.in_bs = in.bstride; A.in_tab = in.tab; A.out = out.p; A.out_bs = out.bstride; A.out_tab = out.tab;
         A.flags = flags | sflag;
         if (epi) {
             set_epilogue(A, *epi, tab.n);
-            if (epi->has_dst) { A.out = epi->dst.p; A.out_bs = epi->dst.bstride; }
+            if (epi->has_dst) { A.out = epi->dst.p; A.out_bs = epi->dst.bstride; A.out_tab = epi->dst.tab; }
         }
         return launch_rows<false>(b, grows, A, r.host_small, s);
     }
     A.tw = r.tw_inv;
     A.twd = r.twd_inv;
-    A.in = in.p; A.in_bs = in.bstride; A.out = out.p; A.out_bs = out.bstride;
+    A.in = in.p; A.in_bs = in.bstride; A.in_tab = in.tab; A.out = out.p; A.out_bs = out.bstride; A.out_tab = out.tab;
     A.flags = (flags & NTT_REDUCE_INPUT) | (a == 0 ? sflag : 0);
     A.scale = (a == 0);
     if ((e = launch_rows<true>(b, grows, A, r.host_small, s)) != hipSuccess) return e;
     if (a > 0) {
         NttArgs B = A;
         for (int i = 0; i < tab.n; i++) B.tab.in_limb[i] = tab.out_limb[i];
-        B.in = out.p; B.in_bs = out.bstride;
+        B.in = out.p; B.in_bs = out.bstride; B.in_tab = out.tab;
         if (a_in > 0) {
             B.flags = 0; B.scale = 0; B.cb = a_out;
             if ((e = launch_cols<true>(a_in, gcols_in, B, s)) != hipSuccess) return e;
@@ -2170,9 +2177,9 @@ hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View o
     if (n < 4 || n > 17) return hipErrorInvalidValue;
     if (epi && inverse) return hipErrorInvalidValue;
     if (prod && (!inverse || !r.twd_inv || !ntt_prod_in_supported(n))) return hipErrorInvalidValue;
-    // entry tables: only the epilogue's outputs / addends / product inputs and the prologue's inputs take one
-    // (forward tensor-mode epilogue: the workgroup -> entry map of that launch shape is not the table's)
-    if ((in.tab && epi && epi->tensor) || (out.tab && !epi) || (epi && !no_tab({epi->y, epi->y2})) || (prod && prod->c.tab)) return hipErrorInvalidValue;
+    // entry tables: every operand but the product prologue's copy of c2 (always a scratch batch) takes one
+    // (forward tensor-mode epilogue: the workgroup -> entry map of that launch shape is not the input table's)
+    if ((in.tab && epi && epi->tensor) || (prod && prod->c.tab)) return hipErrorInvalidValue;
     const int b = ntt_row_bits(n), a = n - b;
     NttArgs A{};
     A.mc = r.mc; A.N = r.N; A.a = a; A.tab = tab;
@@ -2317,6 +2324,7 @@ struct EwArgs {
     const uint64_t *x, *y, *w;
     uint64_t *z;
     size_t x_bs, y_bs, z_bs, w_bs;
+    const size_t *x_tab, *y_tab, *z_tab, *w_tab;  // entry tables (View::tab)
     const ModConst *mc;
     int N;
     int n;
@@ -2382,13 +2390,13 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
     const ModConst m = A.mc[A.mod[yy]];
     const uint64_t s2 = A.s2[yy], s = (A.dbl && j >= (A.N >> 1)) ? s2 : A.s[yy];
     const size_t bz = blockIdx.z;
-    const ulonglong2 xv = ldnt2(A.x + bz * A.x_bs + (size_t)A.x_limb[yy] * A.N + j);
+    const ulonglong2 xv = ldnt2(A.x + voff(A.x_tab, A.x_bs, bz) + (size_t)A.x_limb[yy] * A.N + j);
     ulonglong2 yv = make_ulonglong2(0, 0), zv = make_ulonglong2(0, 0);
     if constexpr (ew_reads_y<OP>())
-        yv = ldnt2(A.y + bz * A.y_bs + (size_t)A.y_limb[yy] * A.N + j);
-    uint64_t *zp = A.z + bz * A.z_bs + (size_t)A.z_limb[yy] * A.N + j;
+        yv = ldnt2(A.y + voff(A.y_tab, A.y_bs, bz) + (size_t)A.y_limb[yy] * A.N + j);
+    uint64_t *zp = A.z + voff(A.z_tab, A.z_bs, bz) + (size_t)A.z_limb[yy] * A.N + j;
     if constexpr (ew_reads_z<OP>())
-        zv = ldnt2(A.w + bz * A.w_bs + (size_t)A.z_limb[yy] * A.N + j);
+        zv = ldnt2(A.w + voff(A.w_tab, A.w_bs, bz) + (size_t)A.z_limb[yy] * A.N + j);
     ulonglong2 o;
     o.x = ew_apply<OP>(xv.x, yv.x, zv.x, m, s, s2);
     o.y = ew_apply<OP>(xv.y, yv.y, zv.y, m, s, s2);
@@ -2412,12 +2420,12 @@ hipError_t launch_ew_w(const RingDev &r, const LimbTab &tab, int op, View x, Vie
 }
 static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, View x, View y, View w, View z, int batch,
                                  const ScalarTab *sc, const uint8_t *x_limb_override, hipStream_t s, int dbl) {
-    if (!no_tab({x, y, w, z})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     EwArgs A{};
     A.dbl = dbl;
     A.x = x.p; A.y = y.p; A.z = z.p; A.w = w.p;
     A.x_bs = x.bstride; A.y_bs = y.bstride; A.z_bs = z.bstride; A.w_bs = w.bstride;
+    A.x_tab = x.tab; A.y_tab = y.tab; A.z_tab = z.tab; A.w_tab = w.tab;
     A.mc = r.mc; A.N = r.N; A.n = tab.n;
     for (int i = 0; i < tab.n; i++) {
         A.x_limb[i] = x_limb_override ? x_limb_override[i] : tab.in_limb[i];
@@ -2474,7 +2482,7 @@ struct GatherArgs {
     const uint64_t *in;
     uint64_t *out;
     size_t in_bs, out_bs;
-    const size_t *out_tab;  // entry table of the output (View::tab)
+    const size_t *in_tab, *out_tab;  // entry tables (View::tab)
     const uint32_t *index;
     int N;
     uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs];
@@ -2485,17 +2493,16 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherArgs A) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= A.N) return;
     const uint32_t src = A.index[j];
-    const uint64_t *in = A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N;
+    const uint64_t *in = A.in + voff(A.in_tab, A.in_bs, blockIdx.z) + (size_t)A.in_limb[blockIdx.y] * A.N;
     uint64_t *out = A.out + voff(A.out_tab, A.out_bs, blockIdx.z) + (size_t)A.out_limb[blockIdx.y] * A.N;
     const uint64_t v = ldnt(&in[src]);
     if (ADD) out[j] += v; else out[j] = v;
 }
 hipError_t launch_gather(const RingDev &r, const LimbTab &tab, View in, const uint32_t *index, View out, int batch,
                          bool then_add, hipStream_t s) {
-    if (in.tab) return hipErrorInvalidValue;  // entry tables: only the output
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     GatherArgs A{};
-    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.out_tab = out.tab; A.index = index; A.N = r.N;
+    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.in_tab = in.tab; A.out_tab = out.tab; A.index = index; A.N = r.N;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
     ProfScope ps(K_GATHER, s, (then_add ? 3.0 : 2.0) * tab.n * batch * (double)r.N * 8.0);
@@ -2527,6 +2534,7 @@ struct AutoCoeffArgs {
     const uint64_t *in;
     uint64_t *out;
     size_t in_bs, out_bs;
+    const size_t *in_tab, *out_tab;  // entry tables (View::tab)
     const ModConst *mc;
     int N, logN;
     uint64_t gal, ginv;  // ginv = gal^-1 mod 2N (conjugate-invariant form only)
@@ -2539,8 +2547,8 @@ __global__ void __launch_bounds__(256) automorphism_coeff_kernel(AutoCoeffArgs A
     if (i >= (uint64_t)A.N) return;
     const uint64_t raw = i * A.gal, idx = raw & (uint64_t)(A.N - 1), neg = (raw >> A.logN) & 1;
     const uint64_t q = A.mc[A.mod[blockIdx.y]].q;
-    const uint64_t c = (A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N)[i];
-    (A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N)[idx] = neg ? q - c : c;
+    const uint64_t c = (A.in + voff(A.in_tab, A.in_bs, blockIdx.z) + (size_t)A.in_limb[blockIdx.y] * A.N)[i];
+    (A.out + voff(A.out_tab, A.out_bs, blockIdx.z) + (size_t)A.out_limb[blockIdx.y] * A.N)[idx] = neg ? q - c : c;
 }
 // Conjugate-invariant ring Z[X + X^-1]/(X^2N + 1) (ring/automorphism.go:122-151): the reference walks i over [0, 2N) and keeps
 // the images i * gal mod 2N that fall below N, reading coefficient i (or 2N - i, negated, for i >= N).  gal is odd, so every
@@ -2554,15 +2562,14 @@ __global__ void __launch_bounds__(256) automorphism_coeff_ci_kernel(AutoCoeffArg
     uint64_t idx = i;
     if (i >= N) { idx = 2 * N - i; neg ^= 1; }
     const uint64_t q = A.mc[A.mod[blockIdx.y]].q;
-    const uint64_t c = (A.in + (size_t)blockIdx.z * A.in_bs + (size_t)A.in_limb[blockIdx.y] * A.N)[idx];
-    (A.out + (size_t)blockIdx.z * A.out_bs + (size_t)A.out_limb[blockIdx.y] * A.N)[x] = neg ? q - c : c;
+    const uint64_t c = (A.in + voff(A.in_tab, A.in_bs, blockIdx.z) + (size_t)A.in_limb[blockIdx.y] * A.N)[idx];
+    (A.out + voff(A.out_tab, A.out_bs, blockIdx.z) + (size_t)A.out_limb[blockIdx.y] * A.N)[x] = neg ? q - c : c;
 }
 hipError_t launch_automorphism_coeff(const RingDev &r, const LimbTab &tab, View in, uint64_t gal, View out, int batch,
                                      hipStream_t s, bool conjugate_invariant) {
-    if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     AutoCoeffArgs A{};
-    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.logN = r.logN;
+    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.in_tab = in.tab; A.out_tab = out.tab; A.mc = r.mc; A.N = r.N; A.logN = r.logN;
     A.gal = gal; A.ginv = 0;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
@@ -2592,6 +2599,7 @@ struct ModUpKArgs {
     const uint64_t *src;
     uint64_t *dstA, *dstB;
     size_t src_bs, dstA_bs, dstB_bs;
+    const size_t *src_tab, *dstA_tab, *dstB_tab;  // entry tables (View::tab)
     const ModConst *mc;
     const uint64_t *a, *T, *vt;
     int N, nchunk;
@@ -2606,7 +2614,7 @@ __global__ void __launch_bounds__(64) modup_kernel(ModUpKArgs A) {
     const int nsrc = NSRC > 0 ? NSRC : A.m.nsrc;
     uint64_t yv[NSRC > 0 ? NSRC : 32];
     double vi = 0.0;
-    const uint64_t *src = A.src + bz * A.src_bs + x;
+    const uint64_t *src = A.src + voff(A.src_tab, A.src_bs, bz) + x;
 #pragma unroll
     for (int i = 0; i < (NSRC > 0 ? NSRC : 32); i++) {
         if (i < nsrc) {
@@ -2633,18 +2641,18 @@ __global__ void __launch_bounds__(64) modup_kernel(ModUpKArgs A) {
         const uint64_t rlo = (uint64_t)acc, rhi = (uint64_t)(acc >> 64);
         uint64_t res = rhi - mulhi64(rlo * mp.qinv, mp.q) + mp.q + A.vt[(size_t)row * (nsrc + 1) + v];
         res = cred(res + mp.q - A.m.dst_half[j], mp.q);   // SubScalar, vec_ops.go:653
-        uint64_t *dst = A.m.dst_view[j] ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs);
+        uint64_t *dst = A.m.dst_view[j] ? (A.dstB + voff(A.dstB_tab, A.dstB_bs, bz)) : (A.dstA + voff(A.dstA_tab, A.dstA_bs, bz));
         dst[(size_t)A.m.dst_limb[j] * A.N + x] = res;
     }
 }
 
 hipError_t launch_modup(const RingDev &r, const ModUpDev &c, const ModUpArgs &a, View src, View dstA, View dstB,
                         int batch, hipStream_t s) {
-    if (!no_tab({src, dstA, dstB})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.ndst <= 0 || batch <= 0) return hipSuccess;
     ModUpKArgs A{};
     A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
+    A.src_tab = src.tab; A.dstA_tab = dstA.tab; A.dstB_tab = dstB.tab;
     A.mc = r.mc; A.a = c.a; A.T = c.T; A.vt = c.vt; A.N = r.N; A.m = a;
     const int bx = (r.N + 63) / 64;
     int nchunk = 2048 / (bx * batch);
@@ -2677,6 +2685,7 @@ struct ModUpFusedArgs {
     const uint64_t *src;
     uint64_t *dstA, *dstB;
     size_t src_bs, dstA_bs, dstB_bs;
+    const size_t *src_tab, *dstA_tab, *dstB_tab;  // entry tables (View::tab)
     const ModConst *mc;
     const uint64_t *tw_fwd, *tw_inv;
     const double *twd_fwd, *twd_inv;
@@ -2734,7 +2743,8 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
     for (int i = 0; i < NSRC; i++) splitmask |= (D.src_split[i] != 0 ? 1u : 0u) << i;
     splitmask = single ? 0u : U(splitmask);
     const size_t bz = blockIdx.z;
-    const uint64_t *src = A.src + bz * A.src_bs + c;
+    const uint64_t *src = A.src + voff(A.src_tab, A.src_bs, bz) + c;
+    const size_t dstA_off = voff(A.dstA_tab, A.dstA_bs, bz), dstB_off = voff(A.dstB_tab, A.dstB_bs, bz);
 
     // mixed variant: the integer residues live in LDS (read back only for the few large destination moduli)
     // Long digits (NSRC > 3 with three column stages: 8 residues per source and thread) keep the first KREG sources' residues in
@@ -2911,7 +2921,7 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
         const ModConst mp = A.mc[mi];
         const uint64_t p = mp.q, pinv = mp.qinv, twop = mp.q << 1;
         const bool small = (p >> kF64Bits) == 0;  // block-uniform
-        uint64_t *dst = (U(D.dst_view[j]) ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs)) + dst_off +
+        uint64_t *dst = (U(D.dst_view[j]) ? (A.dstB + dstB_off) : (A.dstA + dstA_off)) + dst_off +
                         (size_t)U(D.dst_limb[j]) * A.N + c;
         // residue y_i of coefficient r as an integer (the mixed variant keeps them as doubles)
         auto Y = [&](int r, int i) -> uint64_t {
@@ -3264,7 +3274,6 @@ bool modup_f64_raw_ok(int logN, int nsrc, uint64_t max_small_modulus) {
 }
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
                               View dstA, View dstB, int batch, hipStream_t s, bool f64_raw, int total_limbs) {
-    if (!no_tab({src, dstA, dstB})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (ndesc <= 0 || batch <= 0) return hipSuccess;
     if (!modup_fused_supported(r.logN, nsrc)) return hipErrorInvalidValue;
     const int a = r.logN - ntt_row_bits(r.logN);
@@ -3272,6 +3281,7 @@ hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int 
     A.f64_raw = f64_raw ? 1 : 0;
     A.desc = descs_dev; A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
+    A.src_tab = src.tab; A.dstA_tab = dstA.tab; A.dstB_tab = dstB.tab;
     A.mc = r.mc; A.tw_fwd = r.tw_fwd; A.tw_inv = r.tw_inv; A.twd_fwd = r.twd_fwd; A.twd_inv = r.twd_inv; A.N = r.N;
     A.tws_fwd = r.tws_fwd;
     const bool use_f64 = ((dst_classes & 2) && r.twd_fwd != nullptr) || !modup_int_light(nsrc, a);
@@ -3295,6 +3305,7 @@ struct CenterArgs {
     const uint64_t *src;
     uint64_t *dstA, *dstB;
     size_t src_bs, dstA_bs, dstB_bs;
+    const size_t *src_tab, *dstA_tab, *dstB_tab;  // entry tables (View::tab)
     const ModConst *mc;
     int N, strict;
     ModUpArgs m;
@@ -3304,23 +3315,23 @@ __global__ void __launch_bounds__(256) center_copy_kernel(CenterArgs A) {
     if (x >= A.N) return;
     const size_t bz = blockIdx.z;
     const uint64_t qs = A.mc[A.m.src_mod[0]].q;
-    uint64_t c = (A.src + bz * A.src_bs)[(size_t)A.m.src_limb[0] * A.N + x];
+    uint64_t c = (A.src + voff(A.src_tab, A.src_bs, bz))[(size_t)A.m.src_limb[0] * A.N + x];
     const bool neg = (A.strict & 1) ? c > (qs >> 1) : c >= (qs >> 1);
     if (neg) c = qs - c;
     const int j = blockIdx.y;
     const ModConst mp = A.mc[A.m.dst_mod[j]];
     // bit 1: small-norm form, no reduction of |c| (ring/ringqp/operations.go:325-349)
     const uint64_t t = (A.strict & 2) ? c : bred_add(c, mp.q, mp.brc0);
-    uint64_t *dst = A.m.dst_view[j] ? (A.dstB + bz * A.dstB_bs) : (A.dstA + bz * A.dstA_bs);
+    uint64_t *dst = A.m.dst_view[j] ? (A.dstB + voff(A.dstB_tab, A.dstB_bs, bz)) : (A.dstA + voff(A.dstA_tab, A.dstA_bs, bz));
     dst[(size_t)A.m.dst_limb[j] * A.N + x] = neg ? mp.q - t : t;
 }
 hipError_t launch_center_copy(const RingDev &r, const ModUpArgs &a, View src, View dstA, View dstB, int batch,
                               hipStream_t s, int strict) {
-    if (!no_tab({src, dstA, dstB})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.ndst <= 0 || batch <= 0) return hipSuccess;
     CenterArgs A{};
     A.src = src.p; A.dstA = dstA.p; A.dstB = dstB.p;
     A.src_bs = src.bstride; A.dstA_bs = dstA.bstride; A.dstB_bs = dstB.bstride;
+    A.src_tab = src.tab; A.dstA_tab = dstA.tab; A.dstB_tab = dstB.tab;
     A.mc = r.mc; A.N = r.N; A.m = a; A.strict = strict;
     dim3 grid((unsigned)((r.N + 255) / 256), a.ndst, batch), block(256);
     ProfScope ps(K_CENTER, s, (double)(1 + a.ndst) * batch * (double)r.N * 8.0);
@@ -3374,6 +3385,7 @@ struct KsKArgs {
     const uint64_t *key;
     uint64_t *o0Q, *o0P, *o1Q, *o1P;
     size_t dec_bs, oQ0_bs, oP0_bs, oQ1_bs, oP1_bs;
+    const size_t *dec_tab, *oQ0_tab, *oP0_tab, *oQ1_tab, *oP1_tab, *add0_tab;  // entry tables (View::tab)
     const ModConst *mc;
     int N, batch;
     KsArgs k;
@@ -3409,7 +3421,7 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
     for (int b = 0; b < BB; b++) {
         const size_t bb = (size_t)(b0 + b < A.batch ? b0 + b : b0);
         boff_own[b] = voff(A.own_tab, A.own_bs, bb);
-        boff_dec[b] = bb * A.dec_bs;
+        boff_dec[b] = voff(A.dec_tab, A.dec_bs, bb);
     }
     auto is_own = [&](int d) -> bool {
         return A.k.own_alpha > 0 && A.k.out_view[l] == 0 && ql >= d * A.k.own_alpha && ql < (d + 1) * A.k.own_alpha;
@@ -3419,7 +3431,7 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
         if (A.add0 && A.k.out_view[l] == 0) {  // block-uniform; in flight over the whole digit loop
 #pragma unroll
             for (int b = 0; b < BB; b++)
-                addv[b] = ldnt(&A.add0[(size_t)(b0 + b < A.batch ? b0 + b : b0) * A.add0_bs + (size_t)A.k.out_limb[l] * A.N + x]);
+                addv[b] = ldnt(&A.add0[voff(A.add0_tab, A.add0_bs, (size_t)(b0 + b < A.batch ? b0 + b : b0)) + (size_t)A.k.out_limb[l] * A.N + x]);
         }
     }
     uint64_t cn[BB], kn0, kn1;
@@ -3459,8 +3471,8 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
         if (b0 + b < A.batch) {
             uint64_t r0 = cred(mred128_lazy(hi0[b], lo0[b], q, m.qinv), q);
             const uint64_t r1 = cred(mred128_lazy(hi1[b], lo1[b], q, m.qinv), q);
-            uint64_t *o0 = isP ? A.o0P + (size_t)(b0 + b) * A.oP0_bs : A.o0Q + (size_t)(b0 + b) * A.oQ0_bs;
-            uint64_t *o1 = isP ? A.o1P + (size_t)(b0 + b) * A.oP1_bs : A.o1Q + (size_t)(b0 + b) * A.oQ1_bs;
+            uint64_t *o0 = isP ? A.o0P + voff(A.oP0_tab, A.oP0_bs, (size_t)(b0 + b)) : A.o0Q + voff(A.oQ0_tab, A.oQ0_bs, (size_t)(b0 + b));
+            uint64_t *o1 = isP ? A.o1P + voff(A.oP1_tab, A.oP1_bs, (size_t)(b0 + b)) : A.o1Q + voff(A.oQ1_tab, A.oQ1_bs, (size_t)(b0 + b));
             size_t pos = (size_t)x;
             if constexpr (SCAT) {
                 if (A.add0 && !isP) r0 = cred(r0 + mred(addv[b], A.add_s[l], q, m.qinv), q);
@@ -3474,13 +3486,13 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
 
 hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
                            View out0P, View out1Q, View out1P, int batch, hipStream_t s, const KsScatter *sc) {
-    if (!no_tab({dec, out0Q, out0P, out1Q, out1P})) return hipErrorInvalidValue;  // entry tables: only the own-digit operand
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     KsKArgs A{};
     A.own = own.p; A.own_bs = own.bstride; A.own_tab = own.tab;
     A.dec = dec.p; A.dec_bs = dec.bstride; A.key = key;
     A.o0Q = out0Q.p; A.o0P = out0P.p; A.o1Q = out1Q.p; A.o1P = out1P.p;
     A.oQ0_bs = out0Q.bstride; A.oP0_bs = out0P.bstride; A.oQ1_bs = out1Q.bstride; A.oP1_bs = out1P.bstride;
+    A.dec_tab = dec.tab; A.oQ0_tab = out0Q.tab; A.oP0_tab = out0P.tab; A.oQ1_tab = out1Q.tab; A.oP1_tab = out1P.tab; A.add0_tab = nullptr;
     A.mc = r.mc; A.N = r.N; A.batch = batch; A.k = a;
     A.sc_ginv = 0; A.sc_logN = r.logN; A.add0 = nullptr; A.add0_bs = 0;
     const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
@@ -3488,11 +3500,10 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own
     // beta digits in, two key rows per digit shared by the batch, two accumulators out
     double ks_bytes = ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0;
     if (sc && sc->ginv) {
-        if (sc->add0.tab) return hipErrorInvalidValue;
         A.sc_ginv = sc->ginv;
         int nadd = 0;
         if (sc->add0.p) {
-            A.add0 = sc->add0.p; A.add0_bs = sc->add0.bstride;
+            A.add0 = sc->add0.p; A.add0_bs = sc->add0.bstride; A.add0_tab = sc->add0.tab;
             for (int i = 0; i < a.nlimbs; i++) { A.add_s[i] = sc->add_s[i]; nadd += a.out_view[i] == 0; }
         }
         ProfScope ps(K_KS_INNER, s, ks_bytes + (double)nadd * batch * (double)r.N * 8.0);
@@ -3515,6 +3526,7 @@ struct ShiftArgs {
     const uint64_t *in;
     uint64_t *out;
     size_t in_bs, out_bs;
+    const size_t *in_tab, *out_tab;  // entry tables (View::tab)
     const ModConst *mc;
     int N, k, monomial;
     uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs], mod[kMaxLimbs];
@@ -3523,8 +3535,8 @@ __global__ void __launch_bounds__(256) shift_kernel(ShiftArgs A) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= A.N) return;
     const int l = blockIdx.y;
-    const uint64_t *in = A.in + blockIdx.z * A.in_bs + (size_t)A.in_limb[l] * A.N;
-    uint64_t *out = A.out + blockIdx.z * A.out_bs + (size_t)A.out_limb[l] * A.N;
+    const uint64_t *in = A.in + voff(A.in_tab, A.in_bs, blockIdx.z) + (size_t)A.in_limb[l] * A.N;
+    uint64_t *out = A.out + voff(A.out_tab, A.out_bs, blockIdx.z) + (size_t)A.out_limb[l] * A.N;
     if (!A.monomial) {
         int src = j + A.k;
         if (src >= A.N) src -= A.N;
@@ -3550,10 +3562,9 @@ __global__ void __launch_bounds__(256) shift_kernel(ShiftArgs A) {
 }
 static hipError_t launch_shift_impl(const RingDev &r, const LimbTab &tab, View in, int k, View out, int batch, int monomial,
                                     hipStream_t s) {
-    if (!no_tab({in, out})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (tab.n <= 0 || batch <= 0) return hipSuccess;
     ShiftArgs A{};
-    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.mc = r.mc; A.N = r.N; A.k = k; A.monomial = monomial;
+    A.in = in.p; A.out = out.p; A.in_bs = in.bstride; A.out_bs = out.bstride; A.in_tab = in.tab; A.out_tab = out.tab; A.mc = r.mc; A.N = r.N; A.k = k; A.monomial = monomial;
     for (int i = 0; i < tab.n; i++) { A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; }
     dim3 grid((unsigned)((r.N + 255) / 256), tab.n, batch), block(256);
     ProfScope ps(K_GATHER, s, 2.0 * tab.n * batch * (double)r.N * 8.0);
@@ -3574,6 +3585,7 @@ struct DiagMacKArgs {
     DiagMacArgs a;
     uint64_t *o0, *o1;
     size_t o0_bs, o1_bs;
+    const size_t *o0_tab, *o1_tab;  // entry tables (View::tab) of the outputs; the terms' are in DiagMacArgs
     const ModConst *mc;
     int N, batch;
 };
@@ -3595,16 +3607,21 @@ __global__ void __launch_bounds__(256) diag_mac_kernel(const DiagMacKArgs A) {
         const uint64_t *pp = A.a.pt[i] + lo + x;
         const uint64_t *p0 = A.a.c0[i] + lo + xi, *p1 = A.a.c1[i] + lo + xi;
         const size_t pbs = A.a.pt_bs[i], bs0 = A.a.c0_bs[i], bs1 = A.a.c1_bs[i];
+        // entry tables of the terms (a coalesced batch of single-ciphertext callers): rows term_rows * i + {0, 1, 2} of term_tab hold
+        // the word offsets of term i's plaintext, c0 and c1 per entry, `batch` entries per row
+        const size_t *tt = A.a.term_tab ? A.a.term_tab + (size_t)A.a.term_rows * i * A.batch : nullptr;
         uint64_t w = pp[0];
 #pragma unroll
         for (int b = 0; b < BB; b++) {
             if (b0 + b < A.batch) {
-                if (pbs != 0) w = pp[(size_t)(b0 + b) * pbs];
+                const size_t zb = (size_t)(b0 + b);
+                if (tt) w = pp[ldc(reinterpret_cast<const uint64_t *>(tt), zb)];
+                else if (pbs != 0) w = pp[zb * pbs];
                 uint64_t ph, pl;
-                mul64wide(ldnt(&p0[(size_t)(b0 + b) * bs0]), w, ph, pl);
+                mul64wide(ldnt(&p0[tt ? (size_t)ldc(reinterpret_cast<const uint64_t *>(tt), (size_t)A.batch + zb) : zb * bs0]), w, ph, pl);
                 lo0[b] += pl; hi0[b] += ph + (lo0[b] < pl);
                 hi0[b] = hi0[b] >= q ? hi0[b] - q : hi0[b];
-                mul64wide(ldnt(&p1[(size_t)(b0 + b) * bs1]), w, ph, pl);
+                mul64wide(ldnt(&p1[tt ? (size_t)ldc(reinterpret_cast<const uint64_t *>(tt), (size_t)2 * A.batch + zb) : zb * bs1]), w, ph, pl);
                 lo1[b] += pl; hi1[b] += ph + (lo1[b] < pl);
                 hi1[b] = hi1[b] >= q ? hi1[b] - q : hi1[b];
             }
@@ -3615,7 +3632,7 @@ __global__ void __launch_bounds__(256) diag_mac_kernel(const DiagMacKArgs A) {
         if (b0 + b < A.batch) {
             uint64_t r0 = cred(mred128_lazy(hi0[b], lo0[b], q, m.qinv), q);
             uint64_t r1 = cred(mred128_lazy(hi1[b], lo1[b], q, m.qinv), q);
-            uint64_t *o0 = A.o0 + (size_t)(b0 + b) * A.o0_bs + lo + x, *o1 = A.o1 + (size_t)(b0 + b) * A.o1_bs + lo + x;
+            uint64_t *o0 = A.o0 + voff(A.o0_tab, A.o0_bs, (size_t)(b0 + b)) + lo + x, *o1 = A.o1 + voff(A.o1_tab, A.o1_bs, (size_t)(b0 + b)) + lo + x;
             if (A.a.accumulate) {
                 r0 = cred(r0 + bred_add(*o0, q, m.brc0), q);
                 r1 = cred(r1 + bred_add(*o1, q, m.brc0), q);
@@ -3627,12 +3644,11 @@ __global__ void __launch_bounds__(256) diag_mac_kernel(const DiagMacKArgs A) {
 }
 
 hipError_t launch_diag_mac(const RingDev &r, const DiagMacArgs &a, View out0, View out1, int batch, hipStream_t s) {
-    if (!no_tab({out0, out1})) return hipErrorInvalidValue;  // no entry tables here (View::tab)
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     if (a.n < 0 || a.n > kMaxDiag) return hipErrorInvalidValue;
     DiagMacKArgs A{};
     A.a = a;
-    A.o0 = out0.p; A.o1 = out1.p; A.o0_bs = out0.bstride; A.o1_bs = out1.bstride;
+    A.o0 = out0.p; A.o1 = out1.p; A.o0_bs = out0.bstride; A.o1_bs = out1.bstride; A.o0_tab = out0.tab; A.o1_tab = out1.tab;
     A.mc = r.mc; A.N = r.N; A.batch = batch;
     const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
     dim3 grid((unsigned)((r.N + 255) / 256), a.nlimbs, (batch + bb - 1) / bb), block(256);
@@ -3641,7 +3657,7 @@ hipError_t launch_diag_mac(const RingDev &r, const DiagMacArgs &a, View out0, Vi
     double dm_limbs = (a.accumulate ? 4.0 : 2.0) * batch;
     for (int i = 0; i < a.n; i++) {
         if (!a.c0[i] && !a.c1[i]) continue;
-        dm_limbs += (a.pt_bs[i] ? (double)batch : 1.0) + (a.c0[i] ? batch : 0) + (a.c1[i] ? batch : 0);
+        dm_limbs += ((a.pt_bs[i] || a.term_tab) ? (double)batch : 1.0) + (a.c0[i] ? batch : 0) + (a.c1[i] ? batch : 0);
     }
     ProfScope ps(K_DIAG_MAC, s, dm_limbs * a.nlimbs * (double)r.N * 8.0);
     if (bb == 4) hipLaunchKernelGGL((diag_mac_kernel<4>), grid, block, 0, s, A);
@@ -3657,7 +3673,7 @@ struct TensorArgs {
     const uint64_t *a0, *a1, *b0, *b1;
     uint64_t *c0, *c1, *c2;
     size_t a0_bs, a1_bs, b0_bs, b1_bs, c0_bs, c1_bs, c2_bs;
-    const size_t *a0_tab, *a1_tab, *b0_tab, *b1_tab, *c0_tab, *c1_tab;  // entry tables (View::tab); c2 is always a scratch batch
+    const size_t *a0_tab, *a1_tab, *b0_tab, *b1_tab, *c0_tab, *c1_tab, *c2_tab;  // entry tables (View::tab)
     const ModConst *mc;
     int N;
     uint8_t in_limb[kMaxLimbs], out_limb[kMaxLimbs], mod[kMaxLimbs];
@@ -3675,7 +3691,7 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
         ulonglong2 c2;
         c2.x = mred(mred(a1.x, sc, q, qinv), b1.x, q, qinv);
         c2.y = mred(mred(a1.y, sc, q, qinv), b1.y, q, qinv);
-        *reinterpret_cast<ulonglong2 *>(A.c2 + bz * A.c2_bs + oo) = c2;
+        *reinterpret_cast<ulonglong2 *>(A.c2 + voff(A.c2_tab, A.c2_bs, bz) + oo) = c2;
         return;
     }
     const ulonglong2 a0 = ldnt2(A.a0 + voff(A.a0_tab, A.a0_bs, bz) + io);
@@ -3697,7 +3713,7 @@ __global__ void __launch_bounds__(256) tensor_kernel(TensorArgs A) {
     }
     *reinterpret_cast<ulonglong2 *>(A.c0 + voff(A.c0_tab, A.c0_bs, bz) + oo) = c0;
     *reinterpret_cast<ulonglong2 *>(A.c1 + voff(A.c1_tab, A.c1_bs, bz) + oo) = c1;
-    *reinterpret_cast<ulonglong2 *>(A.c2 + bz * A.c2_bs + oo) = c2;
+    *reinterpret_cast<ulonglong2 *>(A.c2 + voff(A.c2_tab, A.c2_bs, bz) + oo) = c2;
 }
 hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *scalar, View a0, View a1, View b0, View b1,
                          View c0, View c1, View c2, int batch, hipStream_t s) {
@@ -3706,8 +3722,7 @@ hipError_t launch_tensor(const RingDev &r, const LimbTab &tab, const uint64_t *s
     A.a0 = a0.p; A.a1 = a1.p; A.b0 = b0.p; A.b1 = b1.p; A.c0 = c0.p; A.c1 = c1.p; A.c2 = c2.p;
     A.a0_bs = a0.bstride; A.a1_bs = a1.bstride; A.b0_bs = b0.bstride; A.b1_bs = b1.bstride;
     A.c0_bs = c0.bstride; A.c1_bs = c1.bstride; A.c2_bs = c2.bstride;
-    A.a0_tab = a0.tab; A.a1_tab = a1.tab; A.b0_tab = b0.tab; A.b1_tab = b1.tab; A.c0_tab = c0.tab; A.c1_tab = c1.tab;
-    if (c2.tab) return hipErrorInvalidValue;
+    A.a0_tab = a0.tab; A.a1_tab = a1.tab; A.b0_tab = b0.tab; A.b1_tab = b1.tab; A.c0_tab = c0.tab; A.c1_tab = c1.tab; A.c2_tab = c2.tab;
     A.mc = r.mc; A.N = r.N;
     for (int i = 0; i < tab.n; i++) {
         A.in_limb[i] = tab.in_limb[i]; A.out_limb[i] = tab.out_limb[i]; A.mod[i] = tab.mod[i]; A.s[i] = scalar[i];

@@ -117,6 +117,17 @@ class Context:
     def sync(self):
         check(load().he_ctx_sync(self.h))
 
+    def SetCoalescing(self, max_batch: int = 64, window_us: int = 30):
+        """he_ctx_set_coalescing (include/hering.h): concurrent single-ciphertext calls of ANY operator on this context -- one OS
+        thread per ciphertext, the reference's own parallel mode (b.RunParallel) -- are gathered into batched launches over the
+        callers' own polynomials.  max_batch <= 1 switches it off."""
+        check(load().he_ctx_set_coalescing(self.h, max_batch, window_us))
+
+    def CoalescingStats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        check(load().he_ctx_coalescing_stats(self.h, out))
+        return {"calls": int(out[0]), "launches": int(out[1]), "largest_batch": int(out[2]), "one_by_one": int(out[3])}
+
     def capture(self):
         """`with ctx.capture() as g: <calls>` records the calls made on this context into a replayable hipGraph
         (he_graph_begin / he_graph_end, include/hering.h); `g.launch()` enqueues the whole sequence at once."""

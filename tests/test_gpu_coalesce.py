@@ -22,6 +22,14 @@ pytestmark = pytest.mark.gpu
 T = 65537
 
 
+@pytest.fixture(autouse=True)
+def _queue_off_afterwards(ctx):
+    """the queue belongs to the context, which the session shares: every test leaves it switched off"""
+    yield
+    ctx.sync()
+    ctx.SetCoalescing(0, 0)
+
+
 def _chain(logN, nq, np_):
     """a chain mixing the double-precision class (45-bit) with the integer class (55-bit q0 and special primes), as the headline's"""
     q, p = O.GenModuli(logN + 1, [55] + [45] * (nq - 1), [55] * np_)
@@ -37,6 +45,14 @@ def _setup(ctx, logN, nq, np_, ci=False):
     kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(beta)])
     kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(beta)])
     return pr, q, p, N, rng, gev, oev, gev.NewEvaluationKey(kq, kp), O.EvaluationKey(kq, kp)
+
+
+def _stats(ctx_or_ev, before=None):
+    """queue counters (they belong to the context, which the whole test session shares: tests look at differences)"""
+    st = ctx_or_ev.CoalescingStats()
+    if before is not None:
+        st = {k: (st[k] - before[k] if k != "largest_batch" else st[k]) for k in st}
+    return st
 
 
 def _run_threads(fns):
@@ -66,6 +82,7 @@ def test_concurrent_callers_get_the_uncoalesced_words(ctx, logN, scheme):
     pr, q, p, N, rng, gev, oev, gk, ok = _setup(ctx, logN, nq, np_)
     K, M = (6, 2) if logN == 15 else (9, 3)
     gev.SetCoalescing(64, 3000)  # a wide window: Python threads arrive milliseconds apart
+    st0 = _stats(gev)
     ins = [[np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(2)] for _ in range(K)]  # [k][op][comp]
     dev = [[[la.Poly(pr.gQ, nq).upload(c) for c in op] for op in ins[k]] for k in range(K)]
     outs = [[[la.Poly(pr.gQ, nq), la.Poly(pr.gQ, nq)] for _ in range(M)] for _ in range(K)]
@@ -79,7 +96,7 @@ def test_concurrent_callers_get_the_uncoalesced_words(ctx, logN, scheme):
 
     _run_threads([caller(k) for k in range(K)])
     ctx.sync()
-    st = gev.CoalescingStats()
+    st = _stats(gev, st0)
     assert st["calls"] == K * M and st["one_by_one"] == 0
     assert st["launches"] < st["calls"] and st["largest_batch"] >= 2, st
     for k in range(K):
@@ -98,6 +115,7 @@ def test_aliasing_levels_and_squaring_are_kept_apart(ctx):
     logN, nq, np_ = 13, 5, 2
     pr, q, p, N, rng, gev, oev, gk, ok = _setup(ctx, logN, nq, np_)
     gev.SetCoalescing(16, 3000)
+    st0 = _stats(gev)
     kinds = ["plain", "inplace0", "inplace1", "square", "lower", "plain", "inplace0", "lower", "square_inplace", "plain"]
     ins, dev, outs, want = [], [], [], []
     for kind in kinds:
@@ -113,7 +131,7 @@ def test_aliasing_levels_and_squaring_are_kept_apart(ctx):
     ctx.sync()
     for i, kind in enumerate(kinds):
         assert np.array_equal(np.stack([o.get() for o in outs[i]]), want[i]), (i, kind)
-    st = gev.CoalescingStats()
+    st = _stats(gev, st0)
     assert st["calls"] == len(kinds) and st["launches"] >= 3  # three keys at least: plain / aliased at the top level, the lower level
 
 
@@ -123,6 +141,7 @@ def test_shapes_without_entry_tables_run_one_by_one(ctx):
     logN, nq, np_ = 11, 4, 2
     pr, q, p, N, rng, gev, oev, gk, ok = _setup(ctx, logN, nq, np_, ci=True)
     gev.SetCoalescing(8, 3000)
+    st0 = _stats(gev)
     K = 4
     ins = [[np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(2)] for _ in range(K)]
     dev = [[[la.Poly(pr.gQ, nq).upload(c) for c in op] for op in ins[k]] for k in range(K)]
@@ -131,8 +150,8 @@ def test_shapes_without_entry_tables_run_one_by_one(ctx):
     ctx.sync()
     for k in range(K):
         assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.CKKSMulRelin(ins[k][0], ins[k][1], ok, True)), k
-    st = gev.CoalescingStats()
-    assert st["calls"] == K and (st["largest_batch"] == 1 or st["one_by_one"] >= 2), st
+    st = _stats(gev, st0)
+    assert st["calls"] == K and st["one_by_one"] >= 2 * (st["launches"] < K), st
 
 
 @pytest.mark.parametrize("sync_each", [False, True])
@@ -143,12 +162,13 @@ def test_library_side_thread_harness(ctx, sync_each):
     pr, q, p, N, rng, gev, oev, gk, ok = _setup(ctx, logN, nq, np_)
     K, M = 24, 5
     gev.SetCoalescing(64, 50)
+    st0 = _stats(gev)
     ins = [[np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(2)] for _ in range(K)]
     dev = [[[la.Poly(pr.gQ, nq).upload(c) for c in op] for op in ins[k]] for k in range(K)]
     outs = [[la.Poly(pr.gQ, nq), la.Poly(pr.gQ, nq)] for _ in range(K)]
     wall = ConcurrentMulRelin([(ctx, gev, dev[k][0], dev[k][1], gk, outs[k]) for k in range(K)], nq - 1, M, t=T, sync_each=sync_each)
     assert wall > 0
-    st = gev.CoalescingStats()
+    st = _stats(gev, st0)
     assert st["calls"] == K * M and st["launches"] < st["calls"], st
     for k in range(K):
         assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.BGVMulRelin(T, ins[k][0], ins[k][1], ok, True)), k
@@ -163,6 +183,7 @@ def test_key_switches_coalesce_too(ctx, logN):
     pr, q, p, N, rng, gev, oev, gk, ok = _setup(ctx, logN, nq, np_)
     K = 5 if logN == 16 else 8
     gev.SetCoalescing(64, 3000)
+    st0 = _stats(gev)
     gal = 5
     cts = [np.stack([uniform_poly(rng, q, N) for _ in range(3)]) for _ in range(K)]       # [k][component 0..2]
     up = lambda k, n: [la.Poly(pr.gQ, nq).upload(c) for c in cts[k][:n]]
@@ -190,7 +211,7 @@ def test_key_switches_coalesce_too(ctx, logN):
     for k in range(K):
         assert np.array_equal(np.stack([o.get() for o in outs[k]]), oev.Automorphism(cts[k][:2], gal, ok)), ("automorphism", k)
     ctx.sync()
-    st = gev.CoalescingStats()
+    st = _stats(gev, st0)
     assert st["calls"] == 4 * K and st["launches"] < st["calls"] and st["largest_batch"] >= 2, st
     # the library-side thread harness on rotations
     outs = [fresh() for _ in range(K)]
@@ -202,8 +223,8 @@ def test_key_switches_coalesce_too(ctx, logN):
 
 def test_mixed_dependent_chains_from_many_threads(ctx):
     """Every caller runs a CHAIN of dependent operations on its own ciphertext -- MulRelin (plain, squaring in place), two
-    rotations (one in place: the flagged one-by-one path), GadgetProduct, and direct ring calls (Add) in between, which do not go
-    through the queue -- while eleven others do the same with the steps in another order.  What a step reads was written by a
+    rotations (one in place: the flagged one-by-one path), GadgetProduct, and ring calls (Add) in between (queued as well since
+    round 5) -- while eleven others do the same with the steps in another order.  What a step reads was written by a
     batch launched by ANOTHER thread (the leader of that moment) or by a direct launch of this one: stream order must hold across
     both.  Final ciphertexts: identical to the same chains run one after the other with the queue switched off, and caller 0's to
     the oracle's chain."""
@@ -248,6 +269,7 @@ def test_mixed_dependent_chains_from_many_threads(ctx):
     for k in range(K):
         ref.append(np.stack([c.get() for c in run_chain(k, *fresh(k))]))
     gev.SetCoalescing(16, 500)
+    st0 = _stats(gev)
     state, res = [fresh(k) for k in range(K)], [None] * K
 
     def caller(k):
@@ -259,8 +281,9 @@ def test_mixed_dependent_chains_from_many_threads(ctx):
     ctx.sync()
     for k in range(K):
         assert np.array_equal(np.stack([c.get() for c in res[k]]), ref[k]), k
-    st = gev.CoalescingStats()
+    st = _stats(gev, st0)
     assert st["launches"] < st["calls"], st
+    gev.SetCoalescing(0, 0)
     # caller 0's chain in the oracle
     sub = O.Ring(N, q)
     x, y = x0[0], y0[0]
@@ -279,3 +302,153 @@ def test_mixed_dependent_chains_from_many_threads(ctx):
         else:
             x = np.stack([sub.binop("Add", x[0], y[0]), sub.binop("Add", x[1], y[1])])
     assert np.array_equal(ref[0], x)
+
+
+# ---- round 5: the queue serves the WHOLE one-ciphertext interface ------------------------------------------------------------
+def _program(pr, ctx, gev, be, keys, nq, np_, seed, N):
+    """One caller's program: every operator entry point of include/hering.h on its own batch-1 polynomials, each result kept.
+    Returns the list of result arrays (downloaded after the final sync by the caller of this function)."""
+    rng = rng_for(seed)
+    q, p = pr.q, pr.p
+    lvQ, lvP = nq - 1, np_ - 1
+    rQ, rP = pr.gQ, pr.gP
+    rlk, gk, gal = keys
+    keep = []
+
+    def newq(nl=nq, arr=None):
+        x = la.Poly(rQ, nl)
+        if arr is not None:
+            x.upload(arr)
+        keep.append(x)
+        return x
+
+    def newp(arr=None):
+        x = la.Poly(rP, np_)
+        if arr is not None:
+            x.upload(arr)
+        keep.append(x)
+        return x
+
+    uq = lambda: uniform_poly(rng, q, N)
+    up_ = lambda: uniform_poly(rng, p, N)
+    a, b, c = newq(arr=uq()), newq(arr=uq()), newq(arr=uq())
+    res = []
+    # ring level
+    t = newq(); rQ.NTT(a, t); res.append(t)
+    t = newq(); rQ.INTT(a, t); res.append(t)
+    t = newq(); rQ.NTTLazy(b, t); rQ.Reduce(t, t); res.append(t)
+    t = newq(); rQ.Add(a, b, t); res.append(t)
+    t = newq(); rQ.Sub(a, b, t); res.append(t)
+    t = newq(); rQ.MulCoeffsMontgomery(a, b, t); rQ.MulCoeffsMontgomeryThenAdd(b, c, t); res.append(t)
+    t = newq(); rQ.Neg(a, t); rQ.MForm(t, t); res.append(t)
+    t = newq(); rQ.MulScalar(a, 0x1234567, t); rQ.AddScalar(t, 77, t); res.append(t)
+    t = newq(); rQ.MulScalarBigint(a, (1 << 90) + 12345, t); res.append(t)
+    t = newq(); rQ.MulDoubleRNSScalar(a, [3 + i for i in range(nq)], [5 + i for i in range(nq)], t); res.append(t)
+    t = newq(); rQ.Shift(a, 37, t); rQ.Shift(t, 5, t); res.append(t)          # (out of place, then in place)
+    t = newq(); rQ.MultByMonomial(a, N + 3, t); res.append(t)
+    idx = rQ.AutomorphismNTTIndex(gal)
+    t = newq(); rQ.AutomorphismNTTWithIndex(a, idx, t); rQ.AutomorphismNTTWithIndexThenAddLazy(b, idx, t); rQ.Reduce(t, t); res.append(t)
+    t = newq(); rQ.Automorphism(a, gal, t); res.append(t)
+    t = newq(nq - 1); rQ.DivRoundByLastModulusNTT(a, t); res.append(t)
+    t = newq(nq - 2); rQ.DivRoundByLastModulusManyNTT(2, a, t); res.append(t)
+    t = newq(nq - 1); rQ.DivFloorByLastModulus(a, t); res.append(t)
+    t = newq(nq - 2); rQ.DivFloorByLastModulusManyNTT(2, b, t); res.append(t)
+    t = newq(nq - 1); rQ.DivRoundByLastModulusNTT(c, c); res.append(c)          # in place (the schemes' Rescale form)
+    c = newq(arr=uq())
+    # basis extender
+    pp = newp(arr=up_())
+    t = newp(); be.ModUpQtoP(lvQ, lvP, a, t); res.append(t)
+    t = newq(); be.ModUpPtoQ(lvP, lvQ, pp, t); res.append(t)
+    t = newq(); be.ModDownQPtoQ(lvQ, lvP, a, pp, t); res.append(t)
+    t = newq(); be.ModDownQPtoQNTT(lvQ, lvP, a, pp, t); res.append(t)
+    t = newp(); be.ModDownQPtoP(lvQ, lvP, a, pp, t); res.append(t)
+    # rlwe.EvaluatorProvider
+    qp = lambda: [(newq(), newp()), (newq(), newp())]
+    two = lambda: [newq(), newq()]
+    t0, t1 = newq(), newp(); gev.DecomposeAndSplit(lvQ, lvP, np_, 1, a, t0, t1); res += [t0, t1]
+    dec = la.Decomposition(gev); keep.append(dec)
+    gev.DecomposeNTT(lvQ, lvP, np_, a, True, dec)
+    acc = qp(); gev.GadgetProductHoistedLazy(lvQ, dec, gk, acc); res += [acc[0][0], acc[0][1], acc[1][0], acc[1][1]]
+    o = two(); gev.ModDown(lvQ, lvP, acc, o); res += o
+    o = two(); gev.GadgetProductHoisted(lvQ, dec, gk, o); res += o
+    o = two(); gev.AutomorphismHoisted(lvQ, [b, a], dec, gal, gk, o); res += o
+    acc2 = qp(); gev.AutomorphismHoistedLazy(lvQ, [b, a], dec, gal, gk, acc2); res += [acc2[0][0], acc2[0][1], acc2[1][0], acc2[1][1]]
+    acc3 = qp(); gev.GadgetProductLazy(lvQ, b, rlk, acc3); res += [acc3[0][0], acc3[0][1], acc3[1][0], acc3[1][1]]
+    t = newq(); gev.ModDownQPtoQNTT(lvQ, lvP, acc3[0][0], acc3[0][1], t); res.append(t)
+    o = two(); gev.GadgetProduct(lvQ, c, rlk, o); res += o
+    o = two(); gev.Relinearize(lvQ, [a, b, c], rlk, o); res += o
+    o = two(); gev.Automorphism(lvQ, [a, b], gal, gk, o); res += o
+    o = two(); gev.CKKSMulRelin(lvQ, [a, b], [b, c], rlk, o); res += o
+    o = [newq(), newq(), newq()]; gev.BGVMulRelin(lvQ, T, [a, b], [b, c], None, o); res += o  # Mul without a key: degree 2
+    o2 = two(); gev.Rescale(lvQ, 1, o[:2], o2); res += o2
+    # the lintrans inner loop and the bootstrapping helpers
+    import ctypes as C
+
+    from lattigo_amd._lib import H, check, load
+    out = qp()
+    terms = [((a, pp), acc[0], acc[1], None), ((b, pp), acc2[0], acc2[1], idx), ((c, pp), acc3[0], acc3[1], None)]
+    arr = lambda f: (H * len(terms))(*[f(t_) for t_ in terms])
+    for accumulate in (0, 1):
+        check(load().he_lintrans_mul_sum(gev.h, lvQ, lvP, len(terms), arr(lambda t_: t_[0][0].h), arr(lambda t_: t_[0][1].h),
+                                         arr(lambda t_: t_[1][0].h), arr(lambda t_: t_[1][1].h), arr(lambda t_: t_[2][0].h),
+                                         arr(lambda t_: t_[2][1].h), arr(lambda t_: t_[3].h if t_[3] is not None else 0), accumulate,
+                                         out[0][0].h, out[0][1].h, out[1][0].h, out[1][1].h))
+    res += [out[0][0], out[0][1], out[1][0], out[1][1]]
+    lq, lp_ = newq(), newp()
+    check(load().he_centered_lift(gev.h, 1, a.h, 0, lvQ, lq.h, lvP, lp_.h)); res += [lq, lp_]
+    dec2 = la.Decomposition(gev); keep.append(dec2)
+    check(load().he_decomp_fill(dec2.h, lvQ, lvP, lq.h, lp_.h))
+    o = two(); gev.GadgetProductHoisted(lvQ, dec2, gk, o); res += o
+    keep.append(idx)
+    return res, keep
+
+
+@pytest.mark.parametrize("logN", [13, 16])
+def test_every_operator_entry_point_coalesces(ctx, logN):
+    """Round 5: the queue belongs to the context and serves every entry point of the one-ciphertext interface.  K threads run the
+    same program -- ring methods, all rescale variants, ModUp / ModDown, the seven rlwe.EvaluatorProvider methods, Mul with and
+    without a key, Rescale, the lintrans inner loop, the bootstrapping helpers -- each on its own polynomials and hoisting
+    buffers; every result must equal, word for word, the same program run alone with the queue off (whose words the rest of the
+    suite pins on the oracle), the batches must really form (fewer launches than calls), and no request of this standard-ring
+    shape may have been served one by one.  logN = 16: the 8192-row kernels."""
+    nq, np_ = (6, 2) if logN == 16 else (5, 2)
+    pr, q, p, N, rng, gev, oev, rlk, orlk = _setup(ctx, logN, nq, np_)
+    beta = (nq + np_ - 1) // np_
+    gal = pow(5, 7, 2 * N)
+    kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(beta)])
+    gk = gev.NewEvaluationKey(kq, kp)
+    be = la.BasisExtender(pr.gQ, pr.gP)
+    K = 6 if logN == 16 else 8
+    ctx.SetCoalescing(0, 0)
+    ref = []
+    for k in range(K):
+        res, keep = _program(pr, ctx, gev, be, (rlk, gk, gal), nq, np_, 7000 + k, N)
+        ctx.sync()
+        ref.append([r.get() for r in res])
+        del res, keep
+    ctx.SetCoalescing(64, 3000)
+    before = ctx.CoalescingStats()
+    got = [None] * K
+
+    def caller(k):
+        def f():
+            got[k] = _program(pr, ctx, gev, be, (rlk, gk, gal), nq, np_, 7000 + k, N)
+        return f
+
+    _run_threads([caller(k) for k in range(K)])
+    ctx.sync()
+    st = ctx.CoalescingStats()
+    for k in range(K):
+        res = [r.get() for r in got[k][0]]
+        assert len(res) == len(ref[k])
+        for i, (x, y) in enumerate(zip(res, ref[k])):
+            assert np.array_equal(x, y), (k, i)
+    calls, launches = st["calls"] - before["calls"], st["launches"] - before["launches"]
+    assert calls >= K * 45 and launches < calls // 2, st
+    assert st["one_by_one"] == before["one_by_one"], st
+    ctx.SetCoalescing(0, 0)
+    # and the oracle on two of the new paths directly (Rescale, the lazy gadget product + ModDown), caller 0's operands
+    r0 = rng_for(7000)
+    a, b, c = (uniform_poly(r0, q, N) for _ in range(3))
+    assert np.array_equal(ref[0][14], pr.oQ.DivRoundByLastModulusNTT(a))
