@@ -573,6 +573,98 @@ def concurrent_b1(la, ctx, workload="c3", ks=(1, 4, 16, 64), ops_per_run=6000, m
     return out
 
 
+def concurrent_c5(la, ctx, ks=(4, 16, 32), window_us=100, max_batch=64, rounds=3):
+    """BASELINE config 5 in the shape of the reference's own benchmark: BenchmarkConcurrentBootstrap runs b.RunParallel over
+    bootstrappers (circuits/ckks/bootstrapping/evaluator_benchmarks_test.go:14-42) -- K callers, ONE ciphertext each, every call of
+    the circuit a single-ciphertext call on shared keys and matrices.  The drivers above the operator interface exist here only as
+    Python restatements (tests/drivers), and K interpreter threads would serialise on the interpreter's lock (measured: 19
+    bootstraps/s at K = 16, below one lone caller's 33).  So ONE run of the driver on a batch-1 ciphertext is RECORDED (every he_*
+    call with its arguments: ModUp, CoeffsToSlots, EvalMod x2, SlotsToCoeffs -- about 1 900 calls of the public entry points,
+    allocations included) and replayed by K pthreads inside the library (he_debug_replay, include/hering_debug.h): the same calls
+    through the same entry points, each thread on its own ciphertext, temporaries and hoisting buffers, all threads on ONE evaluator
+    whose context's submission queue is on -- what K goroutines over the cgo package would do.  Every caller's refreshed ciphertext
+    must hash to the committed digest of the oracle-backed trace."""
+    import gc
+    import hashlib
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bootstrap_c5_shape as C5
+    from fractions import Fraction
+    from drivers import schemes as S
+    from lattigo_amd import _lib
+    L = _lib.load()
+    kmax = max(ks)
+    run, _ = C5.build(ctx, 1, seed_offset=0, same_input=True)
+    boot, _, ct0, _, _ = run._parts
+    run()  # warm-up with the queue off: index tables, plans, lazily built helpers -- shared objects exist before the recording
+    ctx.sync()
+    gc.collect()
+    _lib.trace_begin()
+    res = boot.Bootstrap(S.Ciphertext(ct0, 0, 1), Fraction(1 << 60))
+    program = _lib.trace_end()
+    ctx.sync()
+    rq = run._shape["rq"]
+    host = ct0[0].download(), ct0[1].download()
+    ins = [[la.Poly(rq, 1, 1).upload(h) for h in host] for _ in range(kmax)]
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "c5_trace_digest.json")))
+    level = int(res.level)
+    ok = level == golden["level"] and C5.trace_digest(res, device=True)["entries"][0] == golden["entries"][0]
+    out = {"K": list(ks), "unit": "ctxt-bootstraps/s", "max_batch": max_batch, "window_us": window_us, "rounds_per_caller": rounds,
+           "calls_per_bootstrap": int(sum(1 for _ in _program_calls(program))),
+           "host": "K pthreads replaying the recorded call sequence of one driver run (he_debug_replay): public entry points only",
+           "coalesced": [], "mean_batch": [], "served_one_by_one": []}
+
+    def fetch(h):
+        nl, b, n = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(L.he_poly_shape(int(h), C.byref(nl), C.byref(b), C.byref(n)))
+        a = np.empty((b.value, nl.value, n.value), dtype=np.uint64)
+        _lib.check(L.he_poly_download(int(h), a.ctypes.data_as(_lib.u64p), a.size))
+        _lib.check(L.he_poly_free(int(h)))
+        return a
+
+    def go(K, coalesce, n_rounds):
+        nonlocal ok
+        ctx.SetCoalescing(max_batch if coalesce else 0, window_us)
+        s0 = ctx.CoalescingStats()
+        wall, outs = _lib.replay(ctx.h, program, K, n_rounds, [ct0[0].h, ct0[1].h], [[p.h for p in ins[k]] for k in range(K)],
+                                 [v.h for v in res.Value])
+        s1 = ctx.CoalescingStats()
+        ctx.SetCoalescing(0, 0)
+        dbg = (C.c_uint64 * 8)()
+        _lib.check(L.he_debug_queue_counters(ctx.h, dbg))
+        out.setdefault("queue_counters", []).append({"K": K, "coalesce": coalesce, "wall_s": round(wall, 4), "cumulative": [int(x) for x in dbg]})
+        for k in range(K):
+            words = [fetch(h)[:, : level + 1] for h in outs[k]]
+            d = hashlib.sha256(np.ascontiguousarray(np.stack([w[0] for w in words])).tobytes()).hexdigest()
+            ok = ok and d == golden["entries"][0]
+        return K * n_rounds / wall, (s1["calls"] - s0["calls"]) / max(1, s1["launches"] - s0["launches"]), s1["one_by_one"] - s0["one_by_one"]
+
+    go(min(4, kmax), True, 1)  # arena, pools, the queue's history
+    for K in ks:
+        go(K, True, 1)  # the buffer pool grows to K callers' temporaries (hipMalloc synchronises the device)
+        r, mb, obo = go(K, True, rounds)
+        out["coalesced"].append(r); out["mean_batch"].append(mb); out["served_one_by_one"].append(obo)
+    out["uncoalesced_K%d" % ks[0]] = go(ks[0], False, rounds)[0]
+    out["lone_caller"] = go(1, False, rounds)[0]
+    out["verified"] = bool(ok)
+    return out
+
+
+def _program_calls(program):
+    """the calls of a recorded program (lattigo_amd/_lib.py trace_end; encoding: csrc/replay.cpp)"""
+    i, n = 0, len(program)
+    while i < n:
+        fn, na = int(program[i]), int(program[i + 1])
+        i += 2
+        for _ in range(na):
+            kind = int(program[i]); i += 1
+            if kind in (3, 4):
+                i += 1 + int(program[i])
+            elif kind != 5:
+                i += 1
+        yield fn
+
+
 # default batches from sweeps on MI355X (round 3): c2 128 / 256 / 512 / 1024 / 2048: 204k / 223k / 243k / 257k / 263k (a logN = 14, 8-limb
 # ciphertext is small: the launches need the larger batch to fill the chip); c3 64 / 128 / 192 / 256 / 512: 33.9k / 36.6k / 37.5k /
 # 37.8k / 38.0k on one box (the persistent NTT+MAC kernel's tail shrinks with more items per workgroup; flat beyond 256);
@@ -868,13 +960,42 @@ def main():
             runs = []
             for sync_each in (0, 1):
                 try:
-                    r = subprocess.run([exe, "64", "96", str(sync_each), "1"], capture_output=True, text=True, timeout=120)
+                    r = subprocess.run([exe, "64", "96", str(sync_each), "1", "c3"], capture_output=True, text=True, timeout=120)
                     runs.append(json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]})
                 except Exception as e:  # noqa: BLE001 -- a missing / stale binary must not cost the bench line
                     runs.append({"error": str(e)})
             line["concurrent_b1"]["compiled_host"] = runs
             if any(x.get("verified") is False for x in runs):
                 problems.append("concurrent_b1.compiled_host: a caller's output differs from the oracle")
+    if not args.no_concurrent and world == 1 and args.workload == "c2":
+        # config 2 through the one-ciphertext interface (round 5: the queue serves Mul without a key and Rescale as well): a COMPILED
+        # host, std::thread per ciphertext, four interface calls per operation, every caller's result checked against the oracle
+        exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "cpp", "run_parallel")
+        if os.path.exists(exe):
+            import subprocess
+            runs = []
+            for K, mb, sync_each, co in ((16, 16, 0, 1), (32, 32, 0, 1), (64, 64, 0, 1), (64, 64, 1, 1), (64, 64, 0, 0)):
+                try:
+                    r = subprocess.run([exe, str(K), str(max(24, 6144 // K)), str(sync_each), str(co), "c2", str(mb), str(max(args.co_window, 100))],
+                                       capture_output=True, text=True, timeout=180)
+                    runs.append(json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]})
+                except Exception as e:  # noqa: BLE001
+                    runs.append({"error": str(e)})
+            line["concurrent_b1"] = {"unit": "ctxt-mul+rescale ops/s", "compiled_host": runs,
+                                     "note": "tests/cpp/run_parallel.cpp c2: K threads, one ciphertext per call (Mul, then Rescale: "
+                                             "he_rescale_polys, the three polynomials in one call) on one evaluator; the last run: the "
+                                             "same callers with the queue off.  More callers than the host's CPU quota (16 here) lose "
+                                             "to the scheduler, not to the GPU"}
+            if any(x.get("verified") is False for x in runs):
+                problems.append("concurrent_b1.compiled_host: a caller's output differs from the oracle")
+    if not args.no_concurrent and world == 1 and args.workload == "c5":
+        try:
+            line["concurrent_b1"] = concurrent_c5(la, ctx, window_us=max(args.co_window, 100))
+            if line["concurrent_b1"].get("verified") is False:
+                problems.append("concurrent_b1: a caller's refreshed ciphertext differs from the committed digest")
+        except la.HeringError as e:
+            line["concurrent_b1"] = {"error": str(e)}
+            problems.append(f"concurrent_b1 failed: {e}")
     if not args.no_ntt:
         line["ntt"] = ntt_rates(la, ctx)
         line["ntt_limb_per_s"] = line["ntt"]["logN15_L12"]["limb_ntt_per_s"]

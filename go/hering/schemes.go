@@ -247,6 +247,11 @@ func (s *SchemeEvaluator) Rescale(op0, op1 *rlwe.Ciphertext) error {
 	}
 	r := s.RingQ.AtLevel(op0.Level())
 	op1.Resize(op0.Degree(), op0.Level()-nb)
+	// the loop over the components as ONE call (he_rescale_polys): with the context's submission queue on, the polynomials of this
+	// ciphertext share a batch with the other goroutines'
+	in := make([]Handle, len(op0.Value))
+	out := make([]Handle, len(op0.Value))
+	keep := make([]any, 0, 2*len(op0.Value))
 	for i := range op0.Value {
 		a, err := s.twin(s.RingQ, op0.Value[i], true)
 		if err != nil {
@@ -256,9 +261,10 @@ func (s *SchemeEvaluator) Rescale(op0, op1 *rlwe.Ciphertext) error {
 		if err != nil {
 			return err
 		}
-		if err = r.DivRoundByLastModulusManyNTT(nb, a, o); err != nil {
-			return err
-		}
+		in[i], out[i] = a.h, o.h
+		keep = append(keep, a, o)
 	}
-	return nil
+	return lockedCall(func() C.int {
+		return C.he_rescale_polys(r.h, C.int(r.level), C.int(nb), C.int(len(in)), &in[0], &out[0])
+	}, keep...)
 }

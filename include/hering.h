@@ -215,6 +215,11 @@ int he_div_round_by_last_modulus_many_ntt(he_handle ring, int level, int nb, he_
 int he_div_round_by_last_modulus_many(he_handle ring, int level, int nb, he_handle p0, he_handle p1);     /* :177 */
 int he_div_floor_by_last_modulus_many_ntt(he_handle ring, int level, int nb, he_handle p0, he_handle p1); /* :37  */
 int he_div_floor_by_last_modulus_many(he_handle ring, int level, int nb, he_handle p0, he_handle p1);     /* :65  */
+/* Evaluator.Rescale's loop over the polynomials of ONE ciphertext (schemes/ckks/evaluator.go:503-507, schemes/bgv/evaluator.go:
+ * 1385-1389: DivRoundByLastModulusManyNTT(level, nb, ctIn.Value[i], opOut.Value[i]) for every component) as one call: p0[i] ->
+ * p1[i], i < n <= 16.  The same words as n calls of he_div_round_by_last_modulus_many_ntt; on a context whose submission queue is on
+ * the n polynomials are filed together and ride in one batch with the other callers' (one round of the queue per Rescale). */
+int he_rescale_polys(he_handle ring, int level, int nb, int n, const he_handle *p0, const he_handle *p1);
 
 /* ---- automorphism: ring/automorphism.go ------------------------------------------ */
 /* AutomorphismNTTIndex (:12): builds and keeps the index table on the device */

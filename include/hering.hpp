@@ -573,8 +573,9 @@ public:
     }
     // Evaluator.Rescale: DivRoundByLastModulusManyNTT per component (schemes/ckks/evaluator.go:477, schemes/bgv/evaluator.go:1363)
     void Rescale(int nbRescales, const Ciphertext &op0, Ciphertext &opOut) const {
-        const Ring r = ringQ_.AtLevel(op0.Level());
-        for (size_t i = 0; i < op0.Value.size(); i++) r.DivRoundByLastModulusManyNTT(nbRescales, op0.Value[i], opOut.Value.at(i));
+        std::vector<he_handle> in, out;
+        for (size_t i = 0; i < op0.Value.size(); i++) { in.push_back(op0.Value[i].h()); out.push_back(opOut.Value.at(i).h()); }
+        check(he_rescale_polys(ringQ_.h(), op0.Level(), nbRescales, (int)in.size(), in.data(), out.data()));  // the loop as one call
     }
     // the reference's parallel mode (many goroutines, one ciphertext per call) gathered into batched launches: hering.h
     // (the queue belongs to the evaluator's context and serves every operator of that context: Context::SetCoalescing is the same switch)

@@ -36,6 +36,10 @@ int he_probe_modmul_f64(he_handle ctx, int iters, double *mults_per_s);
  * has launches without entry tables */
 int he_evaluator_coalescing_stats(he_handle eval, uint64_t out[4]);
 int he_ctx_coalescing_stats(he_handle ctx, uint64_t out[4]);  /* the same counters through the context handle */
+/* diagnosis of the queue's gathering rule since the context was created: out[0..2] = batches launched because every recently
+ * active caller was waiting / because the oldest request had waited 8 windows / because max_batch requests were pending; out[3],
+ * out[4] = microseconds the leaders spent gathering and launching; out[5] / out[6] = sums of callers present / expected at launch */
+int he_debug_queue_counters(he_handle ctx, uint64_t out[8]);
 /* Concurrent single-ciphertext callers, the shape of the reference's parallel benchmarks (b.RunParallel,
  * schemes/ckks/ckks_benchmarks_test.go:116-207): n_threads OS threads (pthreads inside the library: no interpreter in the timed
  * region); thread i makes `iters` calls on its own batch-1 handles -- op 0: he_ckks_mul_relin(eval[i], level, a0[i], a1[i], b0[i],
@@ -49,6 +53,18 @@ int he_debug_concurrent_mul_relin(int n_threads, int iters, int sync_each, int o
                                   const he_handle *eval, const he_handle *a0, const he_handle *a1, const he_handle *b0,
                                   const he_handle *b1, const he_handle *rlk, const he_handle *o0, const he_handle *o1,
                                   double *wall_s);
+
+/* A whole circuit under the reference's concurrency shape (BenchmarkConcurrentBootstrap: b.RunParallel over bootstrappers,
+ * circuits/ckks/bootstrapping/evaluator_benchmarks_test.go:14-42): n_threads OS threads (pthreads inside the library) each replay
+ * `rounds` times a RECORDED sequence of calls of the public entry points of hering.h (lattigo_amd/_lib.py trace_begin / trace_end
+ * records one run of a driver; encoding: csrc/replay.cpp).  Handles the recorded run created are replaced by the replaying
+ * thread's own; the n_subst handles subst_from[] (the run's inputs) are replaced per thread by subst_to[thread * n_subst + i];
+ * every other handle (rings, evaluator, keys, plaintexts) is shared.  watch[]: recorded handles whose per-thread counterparts of
+ * the LAST round are returned in watch_out[thread * n_watch + i] and left alive (the caller downloads and frees them).  *wall_s:
+ * common start to the last thread's final he_ctx_sync.  Returns the first non-zero status; err (optional) receives its message. */
+int he_debug_replay(he_handle ctx, const uint64_t *program, size_t n_words, int n_threads, int rounds, const uint64_t *subst_from,
+                    int n_subst, const uint64_t *subst_to, const uint64_t *watch, int n_watch, uint64_t *watch_out, double *wall_s,
+                    char *err, size_t err_len);
 
 #ifdef __cplusplus
 }

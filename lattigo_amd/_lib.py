@@ -85,6 +85,7 @@ def _declare(L):
         "he_div_floor_by_last_modulus_ntt": [H, i, H, H], "he_div_floor_by_last_modulus": [H, i, H, H],
         "he_div_round_by_last_modulus_many_ntt": [H, i, i, H, H], "he_div_round_by_last_modulus_many": [H, i, i, H, H],
         "he_div_floor_by_last_modulus_many_ntt": [H, i, i, H, H], "he_div_floor_by_last_modulus_many": [H, i, i, H, H],
+        "he_rescale_polys": [H, i, i, i, HP, HP],
         "he_automorphism_index_create": [H, C.c_uint64, HP], "he_automorphism_index_destroy": [H],
         "he_automorphism_index_download": [H, u64p],
         "he_automorphism_ntt_with_index": [H, i, H, H, H],
@@ -128,6 +129,7 @@ def _declare(L):
         "he_poly_all_reduce_sum": [H, H],
         "he_evaluator_set_coalescing": [H, i, i], "he_evaluator_coalescing_stats": [H, u64p],
         "he_ctx_set_coalescing": [H, i, i], "he_ctx_coalescing_stats": [H, u64p],
+        "he_debug_queue_counters": [H, u64p],
         "he_debug_concurrent_mul_relin": [i, i, i, i, i, C.c_uint64, HP, HP, HP, HP, HP, HP, HP, HP, HP, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
@@ -148,3 +150,131 @@ def _declare(L):
         for name in sig:
             setattr(L, name, wrap(name, getattr(L, name)))
         atexit.register(lambda: json.dump(dict(counts.most_common()), open(os.environ["HERING_CALL_STATS"], "w"), indent=1))
+
+
+# ---- recording of the ABI calls of a run (diagnostics: the program of he_debug_replay, include/hering_debug.h) ----------------
+# name -> (function number of csrc/replay.cpp, argument kinds): h handle, i immediate, O created handle (byref), A u64 array,
+# H handle array; "+n" appends the immediate n (a variant selector the replayer's entry takes)
+_TRACE_FNS = {
+    "he_poly_alloc": (0, "hiiO"), "he_poly_alloc_scratch": (1, "hiiO"), "he_poly_free": (2, "h"), "he_poly_copy": (3, "hhi"),
+    "he_poly_copy_batch": (4, "hihiii"), "he_poly_zero": (5, "h"),
+    "he_ntt": (6, "hihh"), "he_ntt_lazy": (7, "hihh"), "he_intt": (8, "hihh"), "he_intt_lazy": (9, "hihh"),
+    "he_binop": (10, "hiihhh"), "he_unop": (11, "hiihh"), "he_scalarop": (12, "hiihih"),
+    "he_mul_rns_scalar_montgomery": (13, "hihAh"), "he_add_scalar_bigint": (14, "hihAih"), "he_sub_scalar_bigint": (15, "hihAih"),
+    "he_mul_scalar_bigint": (16, "hihAih"), "he_mul_scalar_bigint_then_add": (17, "hihAih"), "he_double_rns_scalarop": (18, "hiihAAh"),
+    "he_shift": (19, "hihih"), "he_mult_by_monomial": (20, "hihih"), "he_mul_by_vector_montgomery": (21, "hihhih"),
+    "he_div_round_by_last_modulus_many_ntt": (22, "hiihh+3"), "he_div_round_by_last_modulus_many": (22, "hiihh+1"),
+    "he_div_floor_by_last_modulus_many_ntt": (22, "hiihh+2"), "he_div_floor_by_last_modulus_many": (22, "hiihh+0"),
+    "he_rescale_polys": (23, "hiiiHH"), "he_automorphism_index_create": (24, "hiO"), "he_automorphism_index_destroy": (25, "h"),
+    "he_automorphism_ntt_with_index": (26, "hihhh"), "he_automorphism_ntt_with_index_then_add_lazy": (27, "hihhh"),
+    "he_automorphism": (28, "hihih"), "he_modup_q_to_p": (29, "hiihh"), "he_modup_p_to_q": (30, "hiihh"),
+    "he_moddown_qp_to_q": (31, "hiihhh+0"), "he_moddown_qp_to_q_ntt": (31, "hiihhh+1"), "he_moddown_qp_to_p": (31, "hiihhh+2"),
+    "he_eval_moddown_qp_to_q_ntt": (32, "hiihhh"), "he_decomp_create": (33, "hiO"), "he_decomp_destroy": (34, "h"),
+    "he_decompose_ntt": (35, "hiiihih"), "he_gadget_product_lazy": (36, "hihhhhhh"), "he_gadget_product_hoisted_lazy": (37, "hihhhhhh"),
+    "he_moddown": (38, "hiihhhhhh"), "he_gadget_product": (39, "hihhhh"), "he_gadget_product_hoisted": (40, "hihhhh"),
+    "he_relinearize": (41, "hihhhhhh"), "he_automorphism_ct": (42, "hihhihhh"), "he_automorphism_hoisted": (43, "hihhihhh"),
+    "he_automorphism_hoisted_lazy": (44, "hihhihhhhh"), "he_centered_lift": (45, "hihiihih"), "he_decomp_fill": (46, "hiihh"),
+    "he_lintrans_mul_sum": (47, "hiiiHHHHHHHihhhh"), "he_ckks_mul_relin": (48, "hihhhhhhhh"), "he_bgv_mul_relin": (49, "hiihhhhhhhh"),
+}
+# length of the arrays of a call: (function, argument index) -> index of the argument holding it (+1 for "level" arguments)
+_TRACE_LEN = {("he_mul_rns_scalar_montgomery", 3): (1, 1), ("he_add_scalar_bigint", 3): (4, 0), ("he_sub_scalar_bigint", 3): (4, 0),
+              ("he_mul_scalar_bigint", 3): (4, 0), ("he_mul_scalar_bigint_then_add", 3): (4, 0), ("he_double_rns_scalarop", 4): (1, 1),
+              ("he_double_rns_scalarop", 5): (1, 1), ("he_rescale_polys", 4): (3, 0), ("he_rescale_polys", 5): (3, 0)}
+_TRACE_LEN.update({("he_lintrans_mul_sum", k): (3, 0) for k in range(4, 11)})
+# calls a replay has no use for: they read, wait or account, and do not change what the replayed calls see
+_TRACE_IGNORE = {"he_ctx_sync", "he_last_error", "he_alg_bytes", "he_timer_start", "he_timer_stop", "he_poly_download", "he_poly_shape",
+                 "he_poly_download_limb", "he_prof_begin", "he_prof_end", "he_prof_end_bytes", "he_ctx_coalescing_stats",
+                 "he_evaluator_coalescing_stats", "he_version", "he_device_info", "he_ring_constant", "he_ring_roots", "he_decomp_download_limb"}
+_trace = None
+
+
+def _val(x):
+    v = getattr(x, "value", x)
+    return int(v) & 0xFFFFFFFFFFFFFFFF
+
+
+def trace_begin():
+    """Start recording every ABI call this process makes (the single-threaded run of a driver) as a program for he_debug_replay.
+    Calls outside the replayer's table (uploads, object creation other than polynomials / hoisting buffers / index tables) make
+    trace_end fail: the recorded window must be the steady-state part of a run."""
+    global _trace
+    L = load()
+    if _trace is not None:
+        raise RuntimeError("a trace is already being recorded")
+    _trace = {"words": [], "bad": [], "orig": {}}
+    import inspect  # noqa: F401
+
+    def wrap(name, fn):
+        spec = _TRACE_FNS.get(name)
+
+        def call(*a):
+            rc = fn(*a)
+            if spec is None:
+                if name not in _TRACE_IGNORE:
+                    _trace["bad"].append(name)
+                return rc
+            fid, kinds = spec
+            extra = None
+            if "+" in kinds:
+                kinds, extra = kinds.split("+")
+            w = [fid, len(kinds) + (1 if extra is not None else 0)]
+            for k, (kind, x) in enumerate(zip(kinds, a)):
+                if kind == "h":
+                    v = _val(x)
+                    w += [1, v] if v else [5]
+                elif kind == "i":
+                    w += [0, _val(x)]
+                elif kind == "O":
+                    w += [2, int(x._obj.value)]
+                else:
+                    src, plus = _TRACE_LEN[(name, k)]
+                    n = int(_val(a[src])) + plus
+                    if x is None or n <= 0:
+                        w += [5] if x is None else [3 if kind == "A" else 4, 0]
+                    else:
+                        w += [3 if kind == "A" else 4, n] + [int(x[j]) & 0xFFFFFFFFFFFFFFFF for j in range(n)]
+            if extra is not None:
+                w += [0, int(extra)]
+            _trace["words"] += w
+            return rc
+        return call
+
+    for name in declared_symbols():
+        if hasattr(L, name) and name not in ("he_last_error", "he_version", "he_prof_kernel_name", "he_debug_replay"):
+            _trace["orig"][name] = getattr(L, name)
+            setattr(L, name, wrap(name, _trace["orig"][name]))
+
+
+def trace_end():
+    """Stop recording; returns the program (numpy uint64 words) of the calls made since trace_begin."""
+    global _trace
+    import numpy as np
+    L = load()
+    t, _trace = _trace, None
+    for name, fn in t["orig"].items():
+        setattr(L, name, fn)
+    if t["bad"]:
+        raise RuntimeError(f"calls the replayer does not know were made while recording: {sorted(set(t['bad']))}")
+    return np.array(t["words"], dtype=np.uint64)
+
+
+def replay(ctx_handle, program, n_threads: int, rounds: int, subst_from, subst_to, watch):
+    """he_debug_replay: returns (wall seconds, [n_threads][len(watch)] handles of the watched results of the last round)."""
+    import numpy as np
+    L = load()
+    L.he_debug_replay.argtypes = [H, u64p, C.c_size_t, C.c_int, C.c_int, u64p, C.c_int, u64p, u64p, C.c_int, u64p, C.POINTER(C.c_double),
+                                  C.c_char_p, C.c_size_t]
+    L.he_debug_replay.restype = C.c_int
+    program = np.ascontiguousarray(program, dtype=np.uint64)
+    sf = np.ascontiguousarray(subst_from, dtype=np.uint64)
+    st = np.ascontiguousarray(subst_to, dtype=np.uint64).reshape(n_threads, len(sf))
+    wt = np.ascontiguousarray(watch, dtype=np.uint64)
+    out = np.zeros((n_threads, max(len(wt), 1)), dtype=np.uint64)
+    wall = C.c_double()
+    err = C.create_string_buffer(512)
+    p = lambda a: a.ctypes.data_as(u64p)
+    rc = L.he_debug_replay(ctx_handle, p(program), program.size, n_threads, rounds, p(sf), len(sf), p(st), p(wt), len(wt), p(out),
+                           C.byref(wall), err, 512)
+    if rc != 0:
+        raise HeringError(rc, err.value.decode() or "he_debug_replay failed")
+    return float(wall.value), out[:, : len(wt)]

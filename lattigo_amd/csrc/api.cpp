@@ -28,6 +28,10 @@
 #include <dlfcn.h>
 #include <pthread.h>
 #include <sched.h>
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "../../include/hering.h"
 #include "../../include/hering_debug.h"
@@ -105,10 +109,14 @@ struct CoReq {
     std::function<int(bool *ok)> tables_ok;
     // ---- queue state
     std::chrono::steady_clock::time_point arrived;
-    bool done = false, lead = false;  // lead: the leaving leader handed the role to this (still waiting) request
+    uint64_t caller = 0;  // the submitting thread (several requests of one call share it)
+    uint64_t seq = 0;     // how many queued calls that thread had made before this one
+    // done: status and message are final (the LAST thing a leader writes: the submitter may return, and the request die, at once);
+    // lead: the leaving leader handed the role to this (still waiting) request.  Both are read without the queue's lock by the
+    // sleeping submitter, which waits on the queue's generation word (Coalescer::gen).
+    std::atomic<bool> done{false}, lead{false};
     int rc = 0;
     std::string err;
-    std::condition_variable cv;       // its own: a finished batch wakes exactly its callers, an arrival only the leader
     bool same_key(const CoReq &o) const {
         return op == o.op && obj == o.obj && key == o.key && memcmp(par, o.par, sizeof par) == 0 && ops.size() == o.ops.size() &&
                blob == o.blob;
@@ -128,6 +136,11 @@ struct CoReq {
 struct Coalescer {
     std::mutex mu;
     std::condition_variable cv_leader;  // the gathering leader waits here for arrivals while the device is busy
+    // Submitters sleep on this word (futex): a finished batch or a hand-over of the leader's role bumps it and wakes them ALL with
+    // one system call; each looks at its own request's flags and goes back to sleep if it is not concerned.  (Round 4 had one
+    // condition variable per request: a batch of 64 cost its leader 64 wake-up calls under the queue's lock, and every woken
+    // caller queued for that lock first -- 0.3 ms per batch once the batches themselves took less.)
+    std::atomic<uint32_t> gen{0};
     std::deque<CoReq *> pending;
     bool leader = false;
     int recent[4] = {0, 0, 0, 0};     // sizes of the last batches: callers that wait for their results come back together
@@ -142,6 +155,11 @@ struct Coalescer {
     // > 0 while recent traffic showed callers overlapping (a batch of more than one request, or requests left waiting when a
     // batch was taken): a lone caller -- no one to wait for -- is launched without the gathering window
     int crowd = 0;
+    // the threads that filed a request lately (id, time of their last request): the gathering rule waits for them
+    std::vector<std::pair<uint64_t, std::chrono::steady_clock::time_point>> seen;
+    // diagnosis (he_debug_queue_counters): why gathering ended -- [0] everyone here, [1] timeout, [2] full -- and where the
+    // leaders' time went: [3] microseconds gathering, [4] microseconds launching, [5] sum of callers present, [6] sum of callers expected
+    uint64_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 
@@ -266,8 +284,25 @@ struct Ctx : Obj {
     }
 };
 
+// a device-resident automorphism index table (N x 4 bytes), shared by every AutoIndex handle of its (ring, Galois element)
+struct IndexTable {
+    std::shared_ptr<Ctx> ctx;
+    uint32_t *d = nullptr;
+    ~IndexTable() {
+        if (!d) return;
+        hipSetDevice(ctx->dev);
+        hipStreamSynchronize(ctx->stream);
+        hipFree(d);
+    }
+};
 struct Ring : Obj {
     std::shared_ptr<Ctx> ctx;
+    // he_automorphism_index_create: tables by Galois element, built once and kept (the reference caches them the same way,
+    // Evaluator.automorphismIndex, core/rlwe/evaluator.go:81-86): the drivers above the ABI create and drop index handles per use,
+    // and a hipMalloc / hipFree pair per handle synchronises the device each time
+    std::mutex index_mu;
+    std::unordered_map<uint64_t, std::shared_ptr<IndexTable>> index_cache;
+    static constexpr size_t kIndexCacheCap = 4096;
     int logN = 0, N = 0;
     int type = 0;  // 0 Standard, 1 ConjugateInvariant
     std::vector<uint64_t> moduli;
@@ -328,13 +363,9 @@ struct AutoIndex : Obj {
     std::shared_ptr<Ctx> ctx;
     int N = 0;
     uint64_t gal = 0;
-    uint32_t *d = nullptr;
+    std::shared_ptr<IndexTable> tab;  // owns the device memory (shared through the ring's cache)
+    uint32_t *d = nullptr;            // = tab->d
     AutoIndex() : Obj(T_INDEX) {}
-    ~AutoIndex() override {
-        hipSetDevice(ctx->dev);
-        hipStreamSynchronize(ctx->stream);
-        if (d) hipFree(d);
-    }
 };
 
 // constant pool: host vectors concatenated into one device buffer
@@ -610,25 +641,54 @@ int co_run(Ctx &ctx, Coalescer &c, const std::vector<CoReq *> &batch, hipEvent_t
     return fallback;
 }
 // the calling thread is the leader: serve batches until its own request is done (caller holds lk on c.mu)
-void co_lead(Ctx &ctx, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mine) {
+void co_wake_all(Coalescer &c) {
+    c.gen.fetch_add(1, std::memory_order_release);
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+// `extra` (optional): the other requests of the calling thread (co_submit_many): it leads until ALL of its requests are done
+void co_lead(Ctx &ctx, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mine, const std::vector<CoReq *> *extra = nullptr) {
     using clock = std::chrono::steady_clock;
     hipSetDevice(ctx.dev);
-    while (!mine.done) {
+    auto all_done = [&]() -> bool {
+        if (!mine.done.load(std::memory_order_acquire)) return false;
+        if (extra) for (CoReq *r : *extra) if (!r->done.load(std::memory_order_acquire)) return false;
+        return true;
+    };
+    while (!all_done()) {
         // gather: up to max_batch requests.  While the device still has two batches of this queue ahead of it, waiting is free.
         // Otherwise stop once no request has arrived for window_us AND at least half of the recent batches' callers are here
         // (callers that wait for their result come back together, as fast as the OS schedules them), or 8 window_us after the
         // oldest request arrived.  No window at all for a lone caller (crowd == 0).
-        const int hint = std::max(std::max(c.recent[0], c.recent[1]), std::max(c.recent[2], c.recent[3]));
         // (at least one: a request that passed the "queue on?" test just before the queue was switched off is still served)
         const int max_batch = std::max(1, c.max_batch.load(std::memory_order_relaxed));
+        const auto g0 = clock::now();
         for (;;) {
-            if ((int)c.pending.size() >= max_batch) break;
+            if ((int)c.pending.size() >= max_batch) { c.dbg[2]++; break; }
             const bool busy = co_inflight(c) >= 2;
             const auto now = clock::now();
             const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.front()->arrived).count();
-            const auto quiet = std::chrono::duration_cast<std::chrono::microseconds>(now - c.pending.back()->arrived).count();
             const long long win = c.crowd > 0 ? c.window_us : 0;
-            if (!busy && ((quiet >= win && 2 * (int)c.pending.size() >= hint) || waited >= 8 * win)) break;
+            // Round 5: the rule counts CALLERS.  Every thread that filed a request in the last few milliseconds is expected back
+            // (callers of the one-ciphertext interface run the same circuit: they arrive at the same operation one after the
+            // other); once all of them are waiting here -- for this operation or another -- nobody else can arrive and waiting
+            // is pointless; until then the leader waits, at most 8 windows from the oldest request's arrival.
+            int active = 0, here = 0;
+            {
+                uint64_t ids[256];
+                for (auto it = c.seen.begin(); it != c.seen.end();) {
+                    if (std::chrono::duration_cast<std::chrono::microseconds>(now - it->second).count() > 3000 + 8 * win) it = c.seen.erase(it);
+                    else { ++active; ++it; }
+                }
+                for (const CoReq *r : c.pending) {
+                    bool dup = false;
+                    for (int i = 0; i < here && i < 256; i++) dup = dup || ids[i] == r->caller;
+                    if (!dup) { if (here < 256) ids[here] = r->caller; here++; }
+                }
+            }
+            if (!busy && (here >= active || waited >= 8 * win)) {
+                c.dbg[here >= active ? 0 : 1]++; c.dbg[5] += (uint64_t)here; c.dbg[6] += (uint64_t)active;
+                break;
+            }
             if (busy) {
                 c.cv_leader.wait_for(lk, std::chrono::microseconds(100));  // arrivals notify
             } else {  // a few microseconds: a timed futex wait would oversleep by the timer slack
@@ -638,7 +698,16 @@ void co_lead(Ctx &ctx, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mi
             }
         }
         std::vector<CoReq *> batch;
-        const CoReq &head = *c.pending.front();
+        // Which operation goes first: the oldest request's -- unless a caller of the same cohort is BEHIND it.  Callers of the
+        // one-ciphertext interface that run the same circuit (b.RunParallel) make the same sequence of calls, so a thread's call
+        // count is its position in the circuit; once two groups of callers have drifted apart (a timeout, a slow wake-up) they
+        // would stay apart for ever, each group's batches a fraction of what they could be.  Serving the group that is behind
+        // (fewer calls made, within 64 calls of the oldest request's thread: unrelated threads keep arrival order) lets it catch
+        // up with the group that waits here, and the two merge.
+        const CoReq *hp = c.pending.front();
+        for (const CoReq *r : c.pending)
+            if (r->seq < hp->seq && c.pending.front()->seq - r->seq <= 64) hp = r;
+        const CoReq &head = *hp;
         for (auto it = c.pending.begin(); it != c.pending.end() && (int)batch.size() < max_batch;) {
             if ((*it)->same_key(head)) { batch.push_back(*it); it = c.pending.erase(it); }
             else ++it;
@@ -654,39 +723,83 @@ void co_lead(Ctx &ctx, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mi
             else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
         }
         c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
+        const auto g1 = clock::now();
+        c.dbg[3] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(g1 - g0).count();
         lk.unlock();
         const int fallback = co_run(ctx, c, batch, e);
+        const uint64_t run_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - g1).count();
+        // (status and message were written by co_run; `done` is the last touch: the owner may leave at once)
+        bool mine_in_batch = false;
+        for (CoReq *r : batch) {
+            if (r == &mine || (extra && std::find(extra->begin(), extra->end(), r) != extra->end())) { mine_in_batch = true; continue; }
+            r->done.store(true, std::memory_order_release);
+        }
+        co_wake_all(c);
         lk.lock();
+        c.dbg[4] += run_us;
         c.n_fallback += (uint64_t)fallback;
         if (e) c.inflight.push_back(e);
-        for (CoReq *r : batch) {
-            r->done = true;
-            if (r != &mine) r->cv.notify_one();
-        }
+        if (mine_in_batch)
+            for (CoReq *r : batch)
+                if (r == &mine || (extra && std::find(extra->begin(), extra->end(), r) != extra->end())) r->done.store(true, std::memory_order_release);
     }
 }
-int co_submit(Ctx &ctx, CoReq &r) {
+// files the requests of ONE call (most calls: one; the polynomials of a ciphertext in he_rescale_ct: several, which then share
+// a batch) and returns when all of them have been enqueued on the stream
+int co_submit_many(Ctx &ctx, const std::vector<CoReq *> &rs) {
     Coalescer &c = *ctx.co;
-    std::unique_lock<std::mutex> lk(c.mu);
-    r.arrived = std::chrono::steady_clock::now();
-    c.pending.push_back(&r);
-    if (c.leader) c.cv_leader.notify_one();  // a gathering leader counts arrivals
-    while (!r.done) {
-        if (!c.leader || r.lead) {
-            c.leader = true;
-            r.lead = false;
-            co_lead(ctx, c, lk, r);
-            // hand the role to the oldest request still waiting (it is asleep on its own condition variable), if any
-            if (!c.pending.empty()) { c.pending.front()->lead = true; c.pending.front()->cv.notify_one(); }
-            else c.leader = false;
-        } else {
-            r.cv.wait(lk);
+    CoReq &r = *rs[0];
+    auto all_done = [&]() -> bool {
+        for (CoReq *q : rs) if (!q->done.load(std::memory_order_acquire)) return false;
+        return true;
+    };
+    auto take_lead = [&]() -> bool {  // the role may have been handed to any of this call's requests
+        bool l = false;
+        for (CoReq *q : rs) l = q->lead.exchange(false, std::memory_order_acq_rel) || l;
+        return l;
+    };
+    {
+        std::unique_lock<std::mutex> lk(c.mu);
+        const auto now = std::chrono::steady_clock::now();
+        static std::atomic<uint64_t> next_caller{1};
+        thread_local uint64_t me = next_caller.fetch_add(1, std::memory_order_relaxed);
+        thread_local uint64_t my_calls = 0;
+        for (CoReq *q : rs) { q->arrived = now; q->caller = me; q->seq = my_calls; c.pending.push_back(q); }
+        my_calls++;
+        {
+            bool found = false;
+            for (auto &sv : c.seen) if (sv.first == me) { sv.second = now; found = true; break; }
+            if (!found) c.seen.emplace_back(me, now);
+        }
+        bool lead = false;
+        if (!c.leader) { c.leader = true; lead = true; }
+        else c.cv_leader.notify_one();  // a gathering leader counts arrivals
+        for (;;) {
+            if (lead) {
+                co_lead(ctx, c, lk, r, rs.size() > 1 ? &rs : nullptr);
+                // hand the role to the oldest request still waiting (its owner sleeps on the generation word), if any
+                if (!c.pending.empty()) { c.pending.front()->lead.store(true, std::memory_order_release); lk.unlock(); co_wake_all(c); }
+                else { c.leader = false; lk.unlock(); }
+                break;
+            }
+            lk.unlock();
+            // wait for a batch to finish or for the role: read the generation first, then the flags (a bump in between makes the
+            // futex wait return at once)
+            for (;;) {
+                const uint32_t g = c.gen.load(std::memory_order_acquire);
+                if (all_done()) break;
+                if (take_lead()) { lead = true; break; }
+                syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.gen), FUTEX_WAIT_PRIVATE, g, nullptr, nullptr, 0);
+            }
+            if (!lead) break;
+            lk.lock();
         }
     }
-    lk.unlock();
-    if (r.rc != HE_OK) return fail(r.rc, "%s", r.err.c_str());
+    for (CoReq *q : rs)
+        if (q->rc != HE_OK) return fail(q->rc, "%s", q->err.c_str());
     return HE_OK;
 }
+int co_submit(Ctx &ctx, CoReq &r) { return co_submit_many(ctx, std::vector<CoReq *>{&r}); }
 // Every entry point of the one-ciphertext interface ends here: a call over one batch entry on a context whose queue is on (and
 // that is not recording a graph: a captured sequence must be this thread's own launches) joins the queue; everything else runs
 // its launches at once under the context's lock.
@@ -1413,15 +1526,16 @@ int div_by_last_modulus_coeff(Ring &r, int level, View p0, View p1, int batch, b
 // many: the *Many* entry points.  DivFloorByLastModulusManyNTT always goes INTT -> coefficient-domain steps -> NTT, even for one
 // step (scaling.go:37-62), whereas DivRoundByLastModulusManyNTT(1) is DivRoundByLastModulusNTT (:169-171); on a standard ring
 // the two routes give the same words, on a conjugate-invariant ring the single-step NTT form sees the lazy INTT words.
-int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, bool round, bool ntt, const char *who, bool many = false) {
-    GET(r, Ring, hring, T_RING);
+// the request of one DivRound / DivFloor call (validation + launches); div_many files it, he_rescale_polys files several at once
+int div_fill(CoReq &q, const std::shared_ptr<Ring> &r, int level, int nb, he_handle h0, he_handle h1, bool round, bool ntt, const char *who,
+             bool many, int *batch) {
     GET(p0, Poly, h0, T_POLY);
     GET(p1, Poly, h1, T_POLY);
     TRY(check_poly(*p0, *r, level, who));
     if (nb < 0 || nb > level) return fail(HE_EINVAL, "%s: cannot divide %d times at level %d", who, nb, level);
     if (p1->N != r->N || p1->nlimbs < level + 1 - nb || p0->batch != p1->batch) return fail(HE_EINVAL, "%s: output shape mismatch", who);
     const bool same = p0->d == p1->d;
-    CoReq q;
+    *batch = p0->batch;
     q.op = CO_RESCALE; q.obj = r.get(); q.par[0] = level; q.par[1] = nb; q.par[2] = round; q.par[3] = ntt; q.par[4] = many;
     q.ops = {p0->view(), p1->view()};
     q.keep = {r, p0, p1};
@@ -1457,7 +1571,14 @@ int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, boo
         return HE_OK;
     };
     q.tables_ok = [r](bool *ok) -> int { *ok = r->type == 0; return HE_OK; };  // (conjugate-invariant rings: launches without entry tables)
-    return co_dispatch(*r->ctx, p0->batch, q);
+    return HE_OK;
+}
+int div_many(he_handle hring, int level, int nb, he_handle h0, he_handle h1, bool round, bool ntt, const char *who, bool many = false) {
+    GET(r, Ring, hring, T_RING);
+    CoReq q;
+    int B = 0;
+    TRY(div_fill(q, r, level, nb, h0, h1, round, ntt, who, many, &B));
+    return co_dispatch(*r->ctx, B, q);
 }
 }  // namespace
 
@@ -1469,6 +1590,35 @@ int he_div_round_by_last_modulus_many_ntt(he_handle r, int l, int nb, he_handle 
 int he_div_round_by_last_modulus_many(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, true, false, "he_div_round_by_last_modulus_many"); }
 int he_div_floor_by_last_modulus_many_ntt(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, false, true, "he_div_floor_by_last_modulus_many_ntt", true); }
 int he_div_floor_by_last_modulus_many(he_handle r, int l, int nb, he_handle a, he_handle b) { return div_many(r, l, nb, a, b, false, false, "he_div_floor_by_last_modulus_many"); }
+// Evaluator.Rescale's loop over the polynomials of a ciphertext (schemes/ckks/evaluator.go:503-507, schemes/bgv/evaluator.go:
+// 1385-1389: DivRoundByLastModulusManyNTT per component) as ONE call: on a context whose queue is on, the n requests are filed
+// together and share a batch with the other callers' -- a degree-2 ciphertext's Rescale is one round of the queue, not three.
+int he_rescale_polys(he_handle hring, int level, int nb, int n, const he_handle *p0, const he_handle *p1) {
+    GET(r, Ring, hring, T_RING);
+    if (n < 0 || n > 16 || (n > 0 && (!p0 || !p1))) return fail(HE_EINVAL, "he_rescale_polys: n in [0, 16] and both handle arrays");
+    std::deque<CoReq> qs((size_t)n);
+    std::vector<CoReq *> ptrs;
+    bool queue = r->ctx->co->max_batch.load(std::memory_order_relaxed) > 1 && !r->ctx->capturing;
+    for (int i = 0; i < n; i++) {
+        int B = 0;
+        TRY(div_fill(qs[i], r, level, nb, p0[i], p1[i], true, true, "he_rescale_polys", false, &B));
+        queue = queue && B == 1;
+        ptrs.push_back(&qs[i]);
+    }
+    if (n == 0) return HE_OK;
+    if (queue) {
+        for (CoReq &q : qs) q.set_alias_pattern();
+        return co_submit_many(*r->ctx, ptrs);
+    }
+    for (int i = 0; i < n; i++) {
+        int B = 0;
+        GET(pp, Poly, p0[i], T_POLY);
+        B = pp->batch;
+        Scope sc(r->ctx.get());
+        TRY(qs[i].run(qs[i].ops.data(), B));
+    }
+    return HE_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // automorphism (ring/automorphism.go)
@@ -1480,9 +1630,26 @@ int he_automorphism_index_create(he_handle hring, uint64_t gal, he_handle *out) 
     ix->ctx = r->ctx;
     ix->N = r->N;
     ix->gal = gal;
-    Scope sc(r->ctx.get());
-    HIP_TRY(hipMalloc((void **)&ix->d, (size_t)r->N * sizeof(uint32_t)));
-    HIP_TRY(launch_build_automorphism_index(r->logN, r->logN + r->type, gal, ix->d, r->ctx->stream));
+    {
+        std::lock_guard<std::mutex> lk(r->index_mu);
+        auto it = r->index_cache.find(gal);
+        if (it != r->index_cache.end()) ix->tab = it->second;
+    }
+    if (!ix->tab) {
+        auto tab = std::make_shared<IndexTable>();
+        tab->ctx = r->ctx;
+        {
+            Scope sc(r->ctx.get());
+            HIP_TRY(hipMalloc((void **)&tab->d, (size_t)r->N * sizeof(uint32_t)));
+            HIP_TRY(launch_build_automorphism_index(r->logN, r->logN + r->type, gal, tab->d, r->ctx->stream));
+        }
+        std::lock_guard<std::mutex> lk(r->index_mu);
+        auto it = r->index_cache.find(gal);
+        if (it != r->index_cache.end()) tab = it->second;  // (another thread built it meanwhile: one table per element)
+        else if (r->index_cache.size() < Ring::kIndexCacheCap) r->index_cache.emplace(gal, tab);
+        ix->tab = tab;
+    }
+    ix->d = ix->tab->d;
     *out = reg(ix);
     return HE_OK;
 }
@@ -1507,7 +1674,9 @@ static int gather_api(he_handle hring, int level, he_handle hin, he_handle hidx,
     if (ix->N != r->N || pin->batch != pout->batch) return fail(HE_EINVAL, "%s: shape mismatch", who);
     if (pin->d == pout->d) return fail(HE_EINVAL, "%s: the automorphism cannot be evaluated in place", who);
     CoReq q;
-    q.op = CO_GATHER; q.obj = r.get(); q.key = ix.get(); q.par[0] = level; q.par[1] = add;
+    // (the index table is identified by its Galois element, not by its handle: callers that each built their own table of the same
+    // automorphism share a batch -- entry 0's table serves them all)
+    q.op = CO_GATHER; q.obj = r.get(); q.par[0] = level; q.par[1] = add; q.par[2] = (int64_t)ix->gal;
     q.ops = {pin->view(), pout->view()};
     q.keep = {r, pin, pout, ix};
     q.run = [r, ix, level, add](const View *v, int B) -> int {
@@ -1831,6 +2000,13 @@ int he_evaluator_coalescing_stats(he_handle h, uint64_t out[4]) {
 int he_ctx_set_coalescing(he_handle h, int max_batch, int window_us) {
     GET(c, Ctx, h, T_CTX);
     return ctx_set_coalescing(c, max_batch, window_us, "he_ctx_set_coalescing");
+}
+int he_debug_queue_counters(he_handle h, uint64_t out[8]) {
+    GET(c, Ctx, h, T_CTX);
+    if (!out) return fail(HE_EINVAL, "he_debug_queue_counters: null output");
+    std::lock_guard<std::mutex> lk(c->co->mu);
+    for (int i = 0; i < 8; i++) out[i] = c->co->dbg[i];
+    return HE_OK;
 }
 int he_ctx_coalescing_stats(he_handle h, uint64_t out[4]) {
     GET(c, Ctx, h, T_CTX);
@@ -3279,6 +3455,7 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
     q.ops = {o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view()};
     q.keep = {ev, o.q0, o.p0, o.q1, o.p1};
     std::vector<const uint32_t *> idx(n, nullptr);
+    std::vector<uint64_t> idx_gal(n, 0);
     for (int i = 0; i < n; i++) {
         GET(tq, Poly, ptQ[i], T_POLY);
         GET(c0q, Poly, ct0Q[i], T_POLY);
@@ -3292,9 +3469,10 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
             GET(ixo, AutoIndex, index[i], T_INDEX);
             if (ixo->N != be.Q->N) return fail(HE_EINVAL, "%s: automorphism index of another degree", who);
             idx[i] = ixo->d;
+            idx_gal[i] = ixo->gal;
             q.keep.push_back(ixo);
         }
-        q.blob.push_back((uint64_t)(uintptr_t)idx[i]);  // (the index table is part of the key: the same rotation for every entry)
+        q.blob.push_back(idx_gal[i]);  // (the rotation of the term is part of the key -- by Galois element, see gather_api)
         View vt = tq->view();
         if (tq->batch == 1) vt.bstride = 0;  // one plaintext diagonal for the whole batch
         q.ops.push_back(vt); q.ops.push_back(c0q->view()); q.ops.push_back(c1q->view());
@@ -3763,7 +3941,7 @@ struct ConcArg {
     int idx, iters, sync_each, bgv, level;
     uint64_t t;
     he_handle ctx, eval, a0, a1, b0, b1, rlk, o0, o1;
-    pthread_barrier_t *start;
+    std::atomic<int> *go;  // 0: wait, 1: run, -1: give up (a thread could not be started)
     double t0, t1;
     int rc;
     std::string err;
@@ -3773,7 +3951,9 @@ double mono_s() {
 }
 void *conc_worker(void *vp) {
     ConcArg &a = *(ConcArg *)vp;
-    pthread_barrier_wait(a.start);
+    int g;
+    while ((g = a.go->load(std::memory_order_acquire)) == 0) sched_yield();
+    if (g < 0) return nullptr;
     a.t0 = mono_s();
     for (int i = 0; i < a.iters && a.rc == 0; i++) {
         switch (a.bgv) {  // (the operation selector of he_debug_concurrent_mul_relin)
@@ -3800,20 +3980,17 @@ int he_debug_concurrent_mul_relin(int n_threads, int iters, int sync_each, int b
         return fail(HE_EINVAL, "he_debug_concurrent_mul_relin: bad arguments");
     std::vector<ConcArg> args(n_threads);
     std::vector<pthread_t> th(n_threads);
-    pthread_barrier_t start;
-    pthread_barrier_init(&start, nullptr, (unsigned)n_threads);
+    // all threads or none: they wait for `go`, which says "run" only once every one of them exists (a barrier sized for threads
+    // that were never created would not open, and joining handles that were never filled is undefined)
+    std::atomic<int> go{0};
     int started = 0;
     for (int i = 0; i < n_threads; i++) {
-        args[i] = ConcArg{i, iters, sync_each, bgv, level, t, ctx[i], eval[i], a0[i], a1[i], b0[i], b1[i], rlk[i], o0[i], o1[i], &start, 0, 0, 0, {}};
+        args[i] = ConcArg{i, iters, sync_each, bgv, level, t, ctx[i], eval[i], a0[i], a1[i], b0[i], b1[i], rlk[i], o0[i], o1[i], &go, 0, 0, 0, {}};
         if (pthread_create(&th[i], nullptr, conc_worker, &args[i]) != 0) break;
         started++;
     }
-    if (started != n_threads) {  // release the threads that wait at the barrier with the missing parties, then give up
-        for (int i = started; i < n_threads; i++) args[i].iters = 0;
-        for (int i = started; i < n_threads; i++) pthread_create(&th[i], nullptr, [](void *p) -> void * { pthread_barrier_wait(((ConcArg *)p)->start); return nullptr; }, &args[i]);
-    }
-    for (int i = 0; i < n_threads; i++) pthread_join(th[i], nullptr);
-    pthread_barrier_destroy(&start);
+    go.store(started == n_threads ? 1 : -1, std::memory_order_release);
+    for (int i = 0; i < started; i++) pthread_join(th[i], nullptr);
     if (started != n_threads) return fail(HE_ENOMEM, "he_debug_concurrent_mul_relin: could not start %d threads", n_threads);
     double lo = args[0].t0, hi = args[0].t1;
     for (const ConcArg &a : args) { lo = std::min(lo, a.t0); hi = std::max(hi, a.t1); }

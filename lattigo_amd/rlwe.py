@@ -270,9 +270,9 @@ class Evaluator:
 
     # schemes/{ckks,bgv} Evaluator.Rescale (ckks :477, bgv :1363)
     def Rescale(self, level, nbRescales, op0, opOut):
-        r = self.ringQ.AtLevel(level)
-        for a, b in zip(op0, opOut):
-            r.DivRoundByLastModulusManyNTT(nbRescales, a, b)
+        n = min(len(op0), len(opOut))
+        hs = lambda ps: (H * n)(*[p.h for p in ps[:n]])
+        check(load().he_rescale_polys(self.ringQ.h, level, nbRescales, n, hs(op0), hs(opOut)))
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -1,19 +1,26 @@
 // run_parallel.cpp -- the reference's parallel benchmark shape (b.RunParallel over shallow copies of one evaluator,
 // schemes/ckks/ckks_benchmarks_test.go:116-207; schemes/bgv's MulRelin at the BASELINE config-3 shape) from a COMPILED host
 // through the public interface only (include/hering.hpp): K OS threads, one ciphertext per call, one shared evaluator whose
-// submission queue turns the concurrent calls into batched launches.  Prints one JSON line; bench.py embeds it.
+// context's submission queue turns the concurrent calls into batched launches.  Prints one JSON line; bench.py embeds it.
 //
-//   run_parallel [K=64] [calls per thread=96] [sync_each=0|1] [coalesce=1|0]
+//   run_parallel [K=64] [calls per thread=96] [sync_each=0|1] [coalesce=1|0] [workload=c3|c2] [max_batch=64] [window_us=30]
+//
+// workload c3: BGV MulRelin, logN = 15, 12 + 3 limbs (BASELINE config 3).
+// workload c2: CKKS Mul (degree 2, no relinearisation) + Rescale of the three polynomials, logN = 14, 8 + 1 limbs (BASELINE
+//              config 2; schemes/ckks/evaluator.go:764-872, :477-515) -- two calls of the interface per operation (Mul, Rescale).
+// EVERY caller's last result is compared with the oracle (on the host's threads), not a sample.
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
 #include "hering.hpp"
+#include "hering_debug.h"
 extern "C" {
 #include "lattigo_oracle.h"
 }
@@ -33,10 +40,14 @@ static u64v uniform(std::mt19937_64 &rng, const u64v &moduli, int N, int entries
 int main(int argc, char **argv) {
     const int K = argc > 1 ? std::atoi(argv[1]) : 64, iters = argc > 2 ? std::atoi(argv[2]) : 96;
     const bool sync_each = argc > 3 && std::atoi(argv[3]) != 0, coalesce = !(argc > 4 && std::atoi(argv[4]) == 0);
-    const int logN = 15, N = 1 << logN;
+    const std::string workload = argc > 5 ? argv[5] : "c3";
+    const int max_batch = argc > 6 ? std::atoi(argv[6]) : 64, window_us = argc > 7 ? std::atoi(argv[7]) : 30;
+    const bool c2 = workload == "c2";
+    if (!c2 && workload != "c3") { std::fprintf(stderr, "run_parallel: workload c3 or c2\n"); return 2; }
+    const int logN = c2 ? 14 : 15, N = 1 << logN;
     const uint64_t T = 65537;
-    std::vector<int> logq(12, 45), logp(3, 55);
-    logq[0] = 55;
+    std::vector<int> logq(c2 ? 8 : 12, c2 ? 40 : 45), logp(c2 ? 1 : 3, c2 ? 60 : 55);
+    logq[0] = c2 ? 50 : 55;
     u64v q(logq.size()), p(logp.size());
     if (lo_gen_moduli(logN + 1, logq.data(), (int)logq.size(), logp.data(), (int)logp.size(), q.data(), p.data()) != 0) return 2;
     const int nq = (int)q.size(), np = (int)p.size(), level = nq - 1;
@@ -48,21 +59,23 @@ int main(int argc, char **argv) {
         const int beta = lo_base_rns_decomposition_vector_size(level, np - 1);
         const u64v kq = uniform(rng, q, N, beta * 2), kp = uniform(rng, p, N, beta * 2);
         hering::EvaluationKey rlk = eval.NewEvaluationKey(beta, nq, np, kq, kp);
-        if (coalesce) eval.SetCoalescing(64, 30); else eval.SetCoalescing(0, 0);
+        if (coalesce) ctx.SetCoalescing(max_batch, window_us); else ctx.SetCoalescing(0, 0);
         const size_t words = (size_t)nq * N;
-        struct Caller { hering::Ciphertext a, b, out; };
+        struct Caller { hering::Ciphertext a, b, out, res; };
         std::vector<Caller> callers(K);
-        u64v in0, in1;  // caller 0's operands, for the check
+        std::vector<u64v> in0(K), in1(K);  // every caller's operands, for the check
         for (int k = 0; k < K; k++) {
-            const u64v a = uniform(rng, q, N, 2), b = uniform(rng, q, N, 2);
-            if (k == 0) { in0 = a; in1 = b; }
+            in0[k] = uniform(rng, q, N, 2); in1[k] = uniform(rng, q, N, 2);
             for (int c = 0; c < 2; c++) {
                 hering::Poly pa = ringQ.NewScratch(), pb = ringQ.NewScratch();
-                pa.Upload(a.data() + c * words, words);
-                pb.Upload(b.data() + c * words, words);
+                pa.Upload(in0[k].data() + c * words, words);
+                pb.Upload(in1[k].data() + c * words, words);
                 callers[k].a.Value.push_back(pa);
                 callers[k].b.Value.push_back(pb);
+            }
+            for (int c = 0; c < (c2 ? 3 : 2); c++) {
                 callers[k].out.Value.push_back(ringQ.NewPoly());
+                if (c2) callers[k].res.Value.push_back(ringQ.AtLevel(level - 1).NewPoly());
             }
         }
         auto run = [&](int n) {
@@ -73,8 +86,13 @@ int main(int argc, char **argv) {
                 th.emplace_back([&, k] {
                     ready++;
                     while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
-                    for (int i = 0; i < n; i++) {
-                        eval.MulRelinBGV(T, callers[k].a, callers[k].b, &rlk, callers[k].out);  // one ciphertext per call
+                    for (int i = 0; i < n; i++) {  // one ciphertext per call
+                        if (c2) {
+                            eval.MulRelinCKKS(callers[k].a, callers[k].b, nullptr, callers[k].out);
+                            eval.Rescale(1, callers[k].out, callers[k].res);
+                        } else {
+                            eval.MulRelinBGV(T, callers[k].a, callers[k].b, &rlk, callers[k].out);
+                        }
                         if (sync_each) ctx.Sync();
                     }
                 });
@@ -86,21 +104,43 @@ int main(int argc, char **argv) {
             return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         };
         run(8);  // warm-up: plans, scratch arena, the queue's batch-size history
+        uint64_t st0[4] = {0, 0, 0, 0}, st1[4] = {0, 0, 0, 0};
+        he_ctx_coalescing_stats(ctx.h(), st0);
         const double dt = run(iters);
-        // parity of what was timed: caller 0's last result against the oracle
+        he_ctx_coalescing_stats(ctx.h(), st1);
+        const double mean_batch = st1[1] > st0[1] ? (double)(st1[0] - st0[0]) / (double)(st1[1] - st0[1]) : 0.0;
+        // parity of what was timed: EVERY caller's last result against the oracle, on the host's threads
         lo_ring *oQ = lo_ring_new(N, q.data(), nq), *oP = lo_ring_new(N, p.data(), np);
         lo_evaluator *oev = lo_evaluator_new(oQ, oP);
         lo_evk oevk{};
         oevk.beta = beta; oevk.nQk = nq; oevk.nPk = np; oevk.q = kq.data(); oevk.p = kp.data();
         for (int &v : oevk.nj) v = 1;
-        u64v want(2 * words);
-        lo_bgv_mul_relin(oev, level, T, in0.data(), in1.data(), &oevk, 1, want.data());
-        const u64v g0 = callers[0].out.Value[0].Download(), g1 = callers[0].out.Value[1].Download();
-        const bool ok = std::equal(g0.begin(), g0.end(), want.begin()) && std::equal(g1.begin(), g1.end(), want.begin() + words);
-        std::printf("{\"host\": \"C++ (include/hering.hpp), std::thread per caller, public interface only\", \"K\": %d, \"calls_per_caller\": %d, "
-                    "\"sync_each\": %s, \"coalescing\": %s, \"ops_per_s\": %.1f, \"verified\": %s}\n",
-                    K, iters, sync_each ? "true" : "false", coalesce ? "true" : "false", (double)K * iters / dt, ok ? "true" : "false");
-        return ok ? 0 : 1;
+        u64v op0((size_t)K * 2 * words), op1((size_t)K * 2 * words);
+        for (int k = 0; k < K; k++) {
+            std::memcpy(op0.data() + (size_t)k * 2 * words, in0[k].data(), 2 * words * 8);
+            std::memcpy(op1.data() + (size_t)k * 2 * words, in1[k].data(), 2 * words * 8);
+        }
+        const size_t per = c2 ? (size_t)3 * (nq - 1) * N : 2 * words;  // lo_batch_op: [nb][3][level][N] (kind 2) / [nb][2][level+1][N]
+        u64v want((size_t)K * per);
+        const int host_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        lo_batch_op(oev, c2 ? 2 : 0, level, c2 ? 0 : T, 0, op0.data(), op1.data(), c2 ? nullptr : &oevk, K, host_threads, want.data());
+        int bad = 0;
+        for (int k = 0; k < K; k++) {
+            const hering::Ciphertext &r = c2 ? callers[k].res : callers[k].out;
+            const size_t w = c2 ? (size_t)(nq - 1) * N : words;
+            bool ok = true;
+            for (size_t c = 0; c < r.Value.size(); c++) {
+                const u64v g = r.Value[c].Download();
+                ok = ok && g.size() >= w && std::equal(g.begin(), g.begin() + w, want.begin() + (size_t)k * per + c * w);
+            }
+            bad += ok ? 0 : 1;
+        }
+        std::printf("{\"host\": \"C++ (include/hering.hpp), std::thread per caller, public interface only\", \"workload\": \"%s\", \"K\": %d, "
+                    "\"calls_per_caller\": %d, \"interface_calls_per_op\": %d, \"sync_each\": %s, \"coalescing\": %s, \"max_batch\": %d, "
+                    "\"window_us\": %d, \"mean_batch\": %.1f, \"ops_per_s\": %.1f, \"verified\": %s, \"verified_callers\": \"%d/%d\"}\n",
+                    workload.c_str(), K, iters, c2 ? 2 : 1, sync_each ? "true" : "false", coalesce ? "true" : "false", max_batch, window_us,
+                    mean_batch, (double)K * iters / dt, bad == 0 ? "true" : "false", K - bad, K);
+        return bad == 0 ? 0 : 1;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "run_parallel: %s\n", e.what());
         return 3;

@@ -61,13 +61,16 @@ def test_cpp_parity_program():
 
 
 @pytest.mark.gpu
-def test_compiled_host_concurrent_callers():
-    """tests/cpp/run_parallel.cpp: std::thread per ciphertext over ONE hering::Evaluator at the headline shape (the reference's
-    b.RunParallel pattern from a compiled host, public interface only); caller 0's result equals the oracle's."""
+@pytest.mark.parametrize("workload", ["c3", "c2"])
+def test_compiled_host_concurrent_callers(workload):
+    """tests/cpp/run_parallel.cpp: std::thread per ciphertext over ONE hering::Evaluator (the reference's b.RunParallel pattern from
+    a compiled host, public interface only) -- c3: BGV MulRelin at the headline shape; c2: CKKS Mul + Rescale, four interface calls
+    per operation, all of them through the context's submission queue.  EVERY caller's last result equals the oracle's."""
     import json
     _build()
     for sync_each in ("0", "1"):
-        r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "run_parallel"), "8", "6", sync_each, "1"], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "run_parallel"), "8", "6", sync_each, "1", workload], capture_output=True,
+                           text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         d = json.loads(r.stdout.strip().splitlines()[-1])
-        assert d["verified"] is True and d["K"] == 8 and d["ops_per_s"] > 0
+        assert d["verified"] is True and d["K"] == 8 and d["ops_per_s"] > 0 and d["verified_callers"] == "8/8" and d["workload"] == workload
