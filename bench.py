@@ -630,9 +630,12 @@ def concurrent_c5(la, ctx, ks=(4, 16, 32), window_us=100, max_batch=64, rounds=3
                                  [v.h for v in res.Value])
         s1 = ctx.CoalescingStats()
         ctx.SetCoalescing(0, 0)
-        dbg = (C.c_uint64 * 8)()
-        _lib.check(L.he_debug_queue_counters(ctx.h, dbg))
-        out.setdefault("queue_counters", []).append({"K": K, "coalesce": coalesce, "wall_s": round(wall, 4), "cumulative": [int(x) for x in dbg]})
+        if os.environ.get("HERING_REPLAY_PROFILE"):
+            prof = (C.c_uint64 * 192)()
+            L.he_debug_replay_profile(prof, 64, 1)
+            names = {v[0]: k for k, v in _lib._TRACE_FNS.items()}
+            rows = sorted(((prof[3 * f], prof[3 * f + 1], prof[3 * f + 2], names.get(f, str(f))) for f in range(64) if prof[3 * f + 1]), reverse=True)
+            print(f"replay profile K={K} coalesce={coalesce} wall={wall:.3f}s:", [(n, int(us), int(c), int(mx)) for us, c, mx, n in rows[:12]], file=sys.stderr)
         for k in range(K):
             words = [fetch(h)[:, : level + 1] for h in outs[k]]
             d = hashlib.sha256(np.ascontiguousarray(np.stack([w[0] for w in words])).tobytes()).hexdigest()

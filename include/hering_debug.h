@@ -66,6 +66,10 @@ int he_debug_replay(he_handle ctx, const uint64_t *program, size_t n_words, int 
                     int n_subst, const uint64_t *subst_to, const uint64_t *watch, int n_watch, uint64_t *watch_out, double *wall_s,
                     char *err, size_t err_len);
 
+/* where the replaying threads spent their time, per function number of the program encoding (csrc/replay.cpp): out[3 f] =
+ * microseconds inside the calls of function f summed over the threads, out[3 f + 1] = calls, out[3 f + 2] = longest call */
+int he_debug_replay_profile(uint64_t *out, int n_fn, int reset);
+
 #ifdef __cplusplus
 }
 #endif

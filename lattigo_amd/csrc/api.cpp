@@ -208,7 +208,9 @@ struct Ctx : Obj {
         retired_arenas.clear();
     }
     size_t pool_bytes = 0;
-    static constexpr size_t kPoolCap = (size_t)48 << 30;
+    // bound of the cache: half of the device's memory (set by he_ctx_create; 288 GB of HBM3E per MI355X).  A release beyond it has
+    // to drain the stream before hipFree -- with K callers' temporaries in flight that is tens of milliseconds per call
+    size_t kPoolCap = (size_t)48 << 30;
     hipError_t pool_take(size_t bytes, void **out) {
         {
             std::lock_guard<std::mutex> lk(pool_mu);
@@ -896,6 +898,11 @@ int he_ctx_create(int device_id, he_handle *out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) c->kPoolCap = std::max<size_t>(c->kPoolCap, total_b / 2);
+        else (void)hipGetLastError();
+    }
     *out = reg(c);
     return HE_OK;
 }
@@ -1043,18 +1050,22 @@ static int poly_alloc(he_handle hring, int n_limbs, int batch, bool zero, he_han
     p->N = r->N;
     p->nlimbs = n_limbs;
     p->batch = batch;
-    Scope sc(r->ctx.get());
     const size_t bytes = (size_t)batch * n_limbs * r->N * 8;
+    // scratch polynomials: contents unspecified (a recycled buffer); HERING_POISON=1 fills them with a pattern so that a
+    // read-before-write shows up as a parity failure instead of depending on what the buffer held
+    static const bool poison = env_flag("HERING_POISON");
+    // (the buffer cache has its own lock: only a fill is stream work that needs the context -- a scratch allocation of one caller
+    // does not wait for the launches of another's batch)
+    HIP_TRY(hipSetDevice(r->ctx->dev));
     hipError_t e = r->ctx->pool_take(bytes, (void **)&p->d);
     if (e != hipSuccess) {
         p->d = nullptr;
         return fail(HE_ENOMEM, "he_poly_alloc: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
-    // scratch polynomials: contents unspecified (a recycled buffer); HERING_POISON=1 fills them with a pattern so that a
-    // read-before-write shows up as a parity failure instead of depending on what the buffer held
-    static const bool poison = env_flag("HERING_POISON");
-    if (zero) HIP_TRY(hipMemsetAsync(p->d, 0, bytes, r->ctx->stream));
-    else if (poison) HIP_TRY(hipMemsetAsync(p->d, 0x5a, bytes, r->ctx->stream));
+    if (zero || poison) {
+        Scope sc(r->ctx.get());
+        HIP_TRY(hipMemsetAsync(p->d, zero ? 0 : 0x5a, bytes, r->ctx->stream));
+    }
     *out = reg(p);
     return HE_OK;
 }
@@ -1111,11 +1122,27 @@ int he_poly_copy(he_handle hdst, he_handle hsrc, int level) {
     GET(s, Poly, hsrc, T_POLY);
     if (d->N != s->N || d->batch != s->batch || level < 0 || d->nlimbs < level + 1 || s->nlimbs < level + 1 || d->ctx != s->ctx)
         return fail(HE_EINVAL, "he_poly_copy: shape or context mismatch");
-    Scope sc(d->ctx.get());
-    d->ctx->acct(2.0 * (level + 1), 0, d->batch, d->N);
-    HIP_TRY(hipMemcpy2DAsync(d->d, (size_t)d->nlimbs * d->N * 8, s->d, (size_t)s->nlimbs * s->N * 8, (size_t)(level + 1) * d->N * 8,
-                             d->batch, hipMemcpyDeviceToDevice, d->ctx->stream));
-    return HE_OK;
+    // (the copies of concurrent single-ciphertext callers ride in the queue like every other operation: one EW_COPY launch over an
+    // entry table; a lone copy is a device-to-device memcpy as before)
+    const std::shared_ptr<Ctx> ctx = d->ctx;
+    const int N = d->N;
+    CoReq q;
+    q.op = CO_COPY; q.obj = ctx.get(); q.par[0] = level; q.par[1] = N;
+    q.ops = {s->view(), d->view()};
+    q.keep = {s, d};
+    q.run = [ctx, level, N](const View *v, int B) -> int {
+        ctx->acct(2.0 * (level + 1), 0, B, N);
+        if (!v[0].tab && !v[1].tab) {
+            HIP_TRY(hipMemcpy2DAsync(v[1].p, v[1].bstride * 8, v[0].p, v[0].bstride * 8, (size_t)(level + 1) * N * 8, B, hipMemcpyDeviceToDevice,
+                                     ctx->stream));
+            return HE_OK;
+        }
+        RingDev dev{};  // EW_COPY reads no modulus record and no table: degree and strides are all it needs
+        dev.N = N;
+        HIP_TRY(launch_ew(dev, ident_tab(level + 1), EW_COPY, v[0], v[0], v[1], B, nullptr, nullptr, ctx->stream));
+        return HE_OK;
+    };
+    return co_dispatch(*ctx, d->batch, q);
 }
 int he_poly_copy_batch(he_handle hdst, int dst_b0, he_handle hsrc, int src_b0, int nb, int level) {
     GET(d, Poly, hdst, T_POLY);

@@ -2387,7 +2387,8 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
     const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (j >= A.N) return;
     const int yy = blockIdx.y;
-    const ModConst m = A.mc[A.mod[yy]];
+    ModConst m{};
+    if constexpr (OP != EW_COPY) m = A.mc[A.mod[yy]];  // (a copy needs no modulus: he_poly_copy launches it without a ring)
     const uint64_t s2 = A.s2[yy], s = (A.dbl && j >= (A.N >> 1)) ? s2 : A.s[yy];
     const size_t bz = blockIdx.z;
     const ulonglong2 xv = ldnt2(A.x + voff(A.x_tab, A.x_bs, bz) + (size_t)A.x_limb[yy] * A.N + j);

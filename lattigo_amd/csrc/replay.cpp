@@ -55,6 +55,7 @@ struct Worker {
     double t0 = 0, t1 = 0;
     std::string err;
 };
+std::atomic<uint64_t> g_fn_us[64], g_fn_n[64], g_fn_max[64];  // per function: microseconds inside the calls, calls, longest call (he_debug_replay_profile)
 double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int run_call(const Call &c, std::unordered_map<uint64_t, uint64_t> &map, std::vector<std::pair<uint64_t, uint64_t>> &made) {
@@ -170,7 +171,13 @@ void *worker(void *vp) {
         std::unordered_map<uint64_t, uint64_t> map = w.base;
         std::vector<std::pair<uint64_t, uint64_t>> made;  // (handle, kind) of the objects this round created and has not destroyed
         for (const Call &c : *w.prog) {
+            const double c0 = mono_s();
             w.rc = run_call(c, map, made);
+            const uint64_t us = (uint64_t)((mono_s() - c0) * 1e6);
+            g_fn_us[c.fn].fetch_add(us, std::memory_order_relaxed);
+            g_fn_n[c.fn].fetch_add(1, std::memory_order_relaxed);
+            uint64_t mx = g_fn_max[c.fn].load(std::memory_order_relaxed);
+            while (us > mx && !g_fn_max[c.fn].compare_exchange_weak(mx, us, std::memory_order_relaxed)) {}
             if (w.rc != 0) { w.err = std::string("call of function ") + std::to_string(c.fn) + ": " + he_last_error(); break; }
         }
         const bool last = round + 1 == w.rounds;
@@ -190,6 +197,15 @@ void *worker(void *vp) {
 }
 }  // namespace
 
+// per function number of the program encoding: [3 f + 0] microseconds spent inside its calls (all threads), [3 f + 1] calls,
+// [3 f + 2] the longest single call, since the last reset
+extern "C" int he_debug_replay_profile(uint64_t *out, int n_fn, int reset) {
+    for (int f = 0; f < n_fn && f < 64; f++) {
+        if (out) { out[3 * f] = g_fn_us[f].load(); out[3 * f + 1] = g_fn_n[f].load(); out[3 * f + 2] = g_fn_max[f].load(); }
+        if (reset) { g_fn_us[f] = 0; g_fn_n[f] = 0; g_fn_max[f] = 0; }
+    }
+    return HE_OK;
+}
 extern "C" int he_debug_replay(he_handle ctx, const uint64_t *program, size_t n_words, int n_threads, int rounds, const uint64_t *subst_from,
                                int n_subst, const uint64_t *subst_to, const uint64_t *watch, int n_watch, uint64_t *watch_out, double *wall_s,
                                char *err, size_t err_len) {
