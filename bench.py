@@ -421,6 +421,7 @@ def c5_cpu_baseline(la, ctx, shape, trace_bytes_per_bootstrap):
     ct = [la.Poly(rq, len(q)), la.Poly(rq, len(q))]
     out = [la.Poly(rq, len(q)), la.Poly(rq, len(q))]
     ctx.alg_bytes(reset=True)
+    ctx.alg_valu(reset=True)
     ev.Automorphism(len(q) - 1, ct, shape["gal"], shape["key"], out)
     ctx.sync()
     rot_bytes = ctx.alg_bytes(reset=True)[0]
@@ -762,6 +763,7 @@ def main():
         step()
     barrier()
     ctx.alg_bytes(reset=True)
+    ctx.alg_valu(reset=True)
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
@@ -772,6 +774,7 @@ def main():
     elapsed = cp.max_over_ranks(elapsed_rank)
     elapsed_min = -cp.max_over_ranks(-elapsed_rank)
     alg_trace = ctx.alg_bytes(reset=True)  # SURVEY 8(d) per-primitive bytes of the timed steps (key per entry, key per call)
+    valu_trace = ctx.alg_valu(reset=True)  # SURVEY 8(d) multiply counts of the timed steps, by arithmetic class
     # what the control plane and (when keys were replicated over RCCL) the RCCL communicator saw
     ranks_seen = {"control_plane_gloo": int(cp.sum_over_ranks(1.0)), "rccl": cp.rccl_world() if args.replicate_keys == "rccl" else None}
     # a replication that was asked for (or chosen by `auto` because the node has a GPU per rank) and did not happen is a failure of
@@ -873,15 +876,29 @@ def main():
         "source": ("closed form of SURVEY.md section 8(d); the library's per-primitive accounting of the timed trace gives "
                    f"{per_op_trace / 2**20:.2f} MiB") if W["alg_bytes_per_op"] else
                   "SURVEY.md section 8(d) per-primitive formulas summed over the timed operation trace (he_alg_bytes)"}
-    if W.get("valu_model") and world == 1:
-        # the binding roofline: modular multiplies per operation against the chip's two measured multiply ceilings
-        cnt, parts = W["valu_model"]
+    valu_problem = None
+    if world == 1:
+        # The VALU roofline, for every workload: modular multiplies per operation -- counted by the library per primitive call of the
+        # timed steps (he_alg_valu: the closed forms of SURVEY.md section 8(d), by the arithmetic class of each limb) -- against the
+        # chip's two measured multiply ceilings (he_probe_modmul: the production 16-instruction Montgomery sequence;
+        # he_probe_modmul_f64: the 6-instruction exact double-precision product).  `frac` prices multiplies only; `instr.frac` prices
+        # the instructions an implementation cannot avoid: a butterfly is a product PLUS an add, a subtract and the range handling
+        # (22 instructions on the integer path, 16 of them the product; 10 double-precision operations, 6 of them the product -- the
+        # kernels' own sequences, csrc/kernels.hip bfly_fwd / rows_round16_f64), issued at the rate the probes measure for the
+        # product's instructions.  What is left between instr.frac and 1 is stall (dependent chains, LDS exchanges, waits).
+        ops_timed = W["units"] * args.steps
+        mul_int, mul_f64, bf_int, bf_f64 = (x / ops_timed for x in valu_trace)
         rate_int, rate_f64 = ctx.probe_modmul(256), ctx.probe_modmul_f64(256)
-        ideal_s = cnt["int"] / rate_int + cnt["f64"] / rate_f64
+        ideal_s = mul_int / rate_int + mul_f64 / rate_f64
+        instr_int = bf_int * 22 + (mul_int - bf_int) * 16
+        instr_f64 = bf_f64 * 10 + (mul_f64 - bf_f64) * 6
+        ideal_instr_s = instr_int / (16 * rate_int) + instr_f64 / (6 * rate_f64)
         sq, sq_src = None, None
         for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "sq_counters" in f and f.endswith(".json")), reverse=True):
             try:
                 sqj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if sqj.get("workload", "c3") != args.workload:
+                    continue
                 sq = {k: {kk: v[kk] for kk in ("valu_issue_share_of_wave_time", "valu_insts_per_wave", "wait_any_share",
                                                "wait_inst_any_share", "lds_bank_conflict_share") if kk in v}
                       for k, v in (sqj.get("launch_groups") or sqj.get("kernels") or {}).items()}
@@ -891,14 +908,35 @@ def main():
                 pass
         roofline["valu"] = {
             "bound": "valu (integer / double-precision multiply issue)",
-            "modmul_equiv_per_op": cnt["int"] + cnt["f64"], "modmul_equiv_int": cnt["int"], "modmul_equiv_f64": cnt["f64"],
-            "breakdown_per_op": parts,
+            "modmul_equiv_per_op": mul_int + mul_f64, "modmul_equiv_int": mul_int, "modmul_equiv_f64": mul_f64,
+            "butterflies_int": bf_int, "butterflies_f64": bf_f64,
+            "count_source": "he_alg_valu: closed forms per primitive call of the timed steps (csrc/api.cpp struct Valu)",
             "peak_int_modmul_per_s": rate_int, "peak_f64_modmul_per_s": rate_f64,
             "peak_source": "he_probe_modmul / he_probe_modmul_f64 run in this process: dependent MRedLazy / modmul_f64 chains, 4 per thread, 4 M threads",
             "ideal_us_per_op": ideal_s * 1e6, "achieved_us_per_op": 1e6 / per_gpu, "frac": ideal_s * per_gpu,
+            "instr": {"int_instr_per_op": instr_int, "f64_instr_per_op": instr_f64,
+                      "model": "butterfly = 22 integer instructions (16 the Montgomery product) / 10 double-precision operations (6 the "
+                               "exact product); other products 16 / 6; issue rate = 16 x / 6 x the measured product rates",
+                      "ideal_us_per_op": ideal_instr_s * 1e6, "frac": ideal_instr_s * per_gpu},
             "per_kernel_sq": sq, "per_kernel_sq_source": sq_src,
-            "note": "closed form of SURVEY.md section 8(d)'s multiply counts (valu_model_mulrelin); frac = ALU-bound time / measured time"}
+            "note": "frac = ALU-bound time / measured time, multiplies only; instr.frac counts a butterfly's unavoidable companions too"}
+        if W.get("valu_model"):
+            cnt, parts = W["valu_model"]
+            roofline["valu"]["breakdown_per_op"] = parts
+            roofline["valu"]["closed_form_check"] = "library's per-primitive counts == valu_model_mulrelin (bench.py)"
+            if abs(cnt["int"] - mul_int) > 1e-6 * cnt["int"] or abs(cnt["f64"] - mul_f64) > 1e-6 * max(cnt["f64"], 1.0):
+                valu_problem = f"multiply counts: library {mul_int, mul_f64} != closed form {cnt['int'], cnt['f64']}"
+                roofline["valu"]["closed_form_check"] = "MISMATCH: " + valu_problem
+        # which roofline binds: the larger of the two ideal times per operation
+        hbm_ideal_s = alg_op_am / (HBM_PEAK_GBS * 1e9)
+        roofline["bound"] = "valu" if ideal_instr_s > hbm_ideal_s else "hbm"
+        roofline["bound_detail"] = {"hbm_ideal_us_per_op": hbm_ideal_s * 1e6, "valu_ideal_us_per_op": ideal_instr_s * 1e6,
+                                    "note": "`bound` = the larger ideal time per operation (algorithmic bytes at 8 TB/s vs unavoidable "
+                                            "instructions at the measured issue rates); achieved / peak / frac above stay the dominant "
+                                            "kernel's HBM figures, as the bench contract defines them"}
     problems = []
+    if valu_problem:
+        problems.append(valu_problem)
     if over_peak:
         problems.append(f"kernel_GBs above the HBM peak (stale byte model?): {over_peak}")
     if kb_check and kb_check.startswith("MISMATCH"):

@@ -26,6 +26,11 @@ const char *he_prof_kernel_name(int id);
  * SURVEY.md section 8(d) (NTT 2L, binary 3L, GadgetProduct 3L + 2 beta (L + alpha), ... limbs of N * 8 bytes, times the batch):
  * out[0] charges an evaluation key to every batch entry (the section's convention), out[1] reads it once per call */
 int he_alg_bytes(he_handle ctx, int reset, double out[2]);
+/* modular-multiply work of the primitives called on the context since the last reset, in closed form per primitive (SURVEY.md
+ * section 8(d): NTT (N/2) logN + N per limb, basis extension L_src x L_dst x N, key inner product 2 beta (L + alpha) N, tensor 6 L N,
+ * ...) and by the arithmetic class of the limb: out[0] multiply-equivalents on integer-class limbs (64-bit Montgomery products),
+ * out[1] on limbs below 2^47 (exact double-precision products), out[2] / out[3] how many of these are NTT butterflies */
+int he_alg_valu(he_handle ctx, int reset, double out[4]);
 /* dependent-MRedLazy throughput probe: returns modular multiplies per second */
 int he_probe_modmul(he_handle ctx, int iters, double *mults_per_s);
 /* the same for the exact double-precision product the limbs below 2^47 are computed with (error-free product + rounded quotient,

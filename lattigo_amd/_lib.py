@@ -121,7 +121,7 @@ def _declare(L):
         "he_probe_modmul": [H, i, C.POINTER(C.c_double)], "he_probe_modmul_f64": [H, i, C.POINTER(C.c_double)],
         "he_prof_begin": [H], "he_prof_end": [H, i, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(i)],
         "he_prof_end_bytes": [H, i, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i)],
-        "he_alg_bytes": [H, i, C.POINTER(C.c_double)],
+        "he_alg_bytes": [H, i, C.POINTER(C.c_double)], "he_alg_valu": [H, i, C.POINTER(C.c_double)],
         "he_graph_begin": [H], "he_graph_end": [H, HP], "he_graph_launch": [H], "he_graph_nodes": [H, C.POINTER(i)],
         "he_graph_destroy": [H],
         "he_rccl_available": [C.POINTER(i)], "he_rccl_unique_id": [C.POINTER(C.c_uint8)], "he_rccl_comm_create": [H, C.POINTER(C.c_uint8), i, i, HP],

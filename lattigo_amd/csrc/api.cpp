@@ -183,6 +183,12 @@ struct Ctx : Obj {
     // [0] with an evaluation key charged to every batch entry, [1] with one key read serving the whole batch.  bench.py sums
     // them over a workload's operation trace (he_alg_bytes, hering_debug.h); accounted where a call takes the context lock.
     double alg_bytes[2] = {0.0, 0.0};
+    // Modular-multiply work of the primitives called on this context, in closed form per primitive (NTT
+    // (N/2) logN + N per limb, basis extension L_src x L_dst x N, key inner product 2 beta (L + alpha) N, tensor 6 L N, ...), by
+    // the arithmetic class of the limb it runs on: [0] multiply-equivalents on integer-class limbs (64-bit Montgomery products),
+    // [1] on limbs below 2^47 (exact double-precision products), [2] / [3] how many of those are NTT butterflies (a product plus
+    // an add, a subtract and the range handling) -- he_alg_valu (hering_debug.h): bench.py's `roofline.valu` for every workload
+    double alg_valu[4] = {0.0, 0.0, 0.0, 0.0};
     void acct(double per_entry_limbs, double shared_limbs, int batch, int N) {
         alg_bytes[0] += (per_entry_limbs + shared_limbs) * batch * (double)N * 8.0;
         alg_bytes[1] += (per_entry_limbs * batch + shared_limbs) * (double)N * 8.0;
@@ -472,6 +478,57 @@ struct BasisExtender : Obj {
     }
     uint64_t modulus(int idx) const { return idx < LQ ? Q->moduli[idx] : P->moduli[idx - LQ]; }
 };
+
+// closed-form multiply counts of one primitive call (per batch entry), see Ctx::alg_valu
+struct Valu {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    int logN, N;
+    explicit Valu(int logN_) : logN(logN_), N(1 << logN_) {}
+    void mul(bool f64, double per_coeff) { v[f64 ? 1 : 0] += per_coeff * N; }
+    void ntt(bool f64, double n = 1.0) {  // (N/2) logN butterflies + N (N^-1 / the final reduction), SURVEY.md section 8(d)
+        v[f64 ? 1 : 0] += n * (0.5 * logN + 1.0) * N;
+        v[f64 ? 3 : 2] += n * 0.5 * logN * N;
+    }
+    void into(Ctx &c, int batch) const { for (int i = 0; i < 4; i++) c.alg_valu[i] += v[i] * batch; }
+};
+inline bool cls_f64(const std::vector<uint8_t> &small, int idx) { return small[(size_t)idx] == 2; }
+// ModUp source -> destination: y_i per source limb, |src| products per destination limb
+inline void valu_modup(Valu &V, const std::vector<uint8_t> &small, int s0, int ns, const std::vector<int> &dst) {
+    for (int i = 0; i < ns; i++) V.mul(cls_f64(small, s0 + i), 1.0);
+    for (int j : dst) V.mul(cls_f64(small, j), (double)ns);
+}
+// ModDownQPtoQNTT of one polynomial: INTT of the P part, ModUpPtoQ, NTT of the extension, the last product per Q limb
+inline void valu_moddown(Valu &V, const BasisExtender &be, int levelQ, int levelP, bool ntt_domain = true) {
+    std::vector<int> dq;
+    for (int i = 0; i <= levelQ; i++) dq.push_back(i);
+    if (ntt_domain) for (int j = 0; j <= levelP; j++) V.ntt(cls_f64(be.small, be.LQ + j));
+    valu_modup(V, be.small, be.LQ, levelP + 1, dq);
+    for (int i = 0; i <= levelQ; i++) { if (ntt_domain) V.ntt(cls_f64(be.small, i)); V.mul(cls_f64(be.small, i), 1.0); }
+}
+// DecomposeNTT (with_intt: the inverse transform of the input) and / or the key inner product over beta digits
+inline void valu_keyswitch(Valu &V, const BasisExtender &be, int levelQ, int levelP, int beta, bool decompose, bool inner) {
+    const int alpha = levelP + 1;
+    if (decompose) {
+        for (int i = 0; i <= levelQ; i++) V.ntt(cls_f64(be.small, i));
+        for (int d = 0; d < beta; d++) {
+            const int s0 = d * alpha, e0 = std::min(s0 + alpha, levelQ + 1);
+            std::vector<int> dst;
+            for (int i = 0; i <= levelQ; i++) if (i < s0 || i >= e0) dst.push_back(i);
+            for (int j = 0; j <= levelP; j++) dst.push_back(be.LQ + j);
+            valu_modup(V, be.small, s0, e0 - s0, dst);
+            for (int j : dst) V.ntt(cls_f64(be.small, j));
+        }
+    }
+    if (inner) {
+        for (int i = 0; i <= levelQ; i++) V.mul(cls_f64(be.small, i), 2.0 * beta);
+        for (int j = 0; j <= levelP; j++) V.mul(cls_f64(be.small, be.LQ + j), 2.0 * beta);
+    }
+}
+// GadgetProduct = DecomposeNTT + inner product + ModDown of both components
+inline void valu_gadget_product(Valu &V, const BasisExtender &be, int levelQ, int levelP, int beta, bool decompose) {
+    valu_keyswitch(V, be, levelQ, levelP, beta, decompose, true);
+    if (levelP >= 0) { valu_moddown(V, be, levelQ, levelP); valu_moddown(V, be, levelQ, levelP); }
+}
 
 // rlwe.Evaluator hot path: BasisExtender + ring.Decomposer constants (ring/basis_extension.go:320-377)
 // descriptors of the fused basis-extension kernel, grouped by source-limb count
@@ -1213,6 +1270,7 @@ static int ntt_api(he_handle hring, int level, he_handle h1, he_handle h2, bool 
     q.keep = {r, p1, p2};
     q.run = [r, level, inverse, flags](const View *v, int B) -> int {
         r->ctx->acct(2.0 * (level + 1), 0, B, r->N);  // NTT / INTT: 2 L limbs
+        { Valu V(r->logN); for (int i = 0; i <= level; i++) V.ntt(cls_f64(r->small, i)); V.into(*r->ctx, B); }
         HIP_TRY(ring_ntt(*r, ident_tab(level + 1), v[0], v[1], B, inverse, flags | NTT_REDUCE_INPUT));
         return HE_OK;
     };
@@ -1268,6 +1326,7 @@ int he_binop(he_handle hring, int level, int op, he_handle h1, he_handle h2, he_
         const bool then = op == EW_MUL_BARRETT_THEN_ADD || op == EW_MUL_BARRETT_THEN_ADD_LAZY || (op >= EW_MUL_MONT_THEN_ADD && op <= EW_MUL_MONT_LAZY_THEN_SUB_LAZY);
         const double sh = (double)(v[0].bstride == 0 && !v[0].tab && B > 1) + (double)(v[1].bstride == 0 && !v[1].tab && B > 1);
         r->ctx->acct(((then ? 4.0 : 3.0) - sh) * (level + 1), sh * (level + 1), B, r->N);
+        if (op >= EW_MUL_BARRETT) { Valu V(r->logN); for (int i = 0; i <= level; i++) V.mul(cls_f64(r->small, i), 1.0); V.into(*r->ctx, B); }
         HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), op, v[0], v[1], v[2], B, nullptr, nullptr, r->ctx->stream));
         return HE_OK;
     };
@@ -1287,6 +1346,7 @@ int he_unop(he_handle hring, int level, int op, he_handle h1, he_handle h2) {
     q.keep = {r, p1, p2};
     q.run = [r, level, op](const View *v, int B) -> int {
         r->ctx->acct(2.0 * (level + 1), 0, B, r->N);  // unary: 2 L
+        if (EW_NEG + op >= EW_MFORM && EW_NEG + op <= EW_IMFORM) { Valu V(r->logN); for (int i = 0; i <= level; i++) V.mul(cls_f64(r->small, i), 1.0); V.into(*r->ctx, B); }
         HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), EW_NEG + op, v[0], v[0], v[1], B, nullptr, nullptr, r->ctx->stream));
         return HE_OK;
     };
@@ -1303,6 +1363,7 @@ static int scalar_launch(const std::shared_ptr<Ring> &r, int level, int ewop, co
     q.keep = {r, p1, p2};
     q.run = [r, level, ewop, st, dbl](const View *v, int B) -> int {
         r->ctx->acct((ewop == EW_MUL_SCALAR_MONT_THEN_ADD ? 3.0 : 2.0) * (level + 1), 0, B, r->N);  // unary (3 L with the addend)
+        if (ewop == EW_MUL_SCALAR_MONT || ewop == EW_MUL_SCALAR_MONT_THEN_ADD) { Valu V(r->logN); for (int i = 0; i <= level; i++) V.mul(cls_f64(r->small, i), 1.0); V.into(*r->ctx, B); }
         if (dbl) HIP_TRY(launch_ew_double(r->dev, ident_tab(level + 1), ewop, v[0], v[1], B, &st, r->ctx->stream));
         else HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), ewop, v[0], v[0], v[1], B, &st, nullptr, r->ctx->stream));
         return HE_OK;
@@ -1437,6 +1498,7 @@ int he_mul_by_vector_montgomery(he_handle hring, int level, he_handle h1, he_han
     q.run = [r, level, then_add_lazy](const View *w, int B) -> int {
         const uint8_t zeros[kMaxLimbs] = {0};
         r->ctx->acct((then_add_lazy ? 3.0 : 2.0) * (level + 1), 1.0, B, r->N);
+        { Valu V(r->logN); for (int i = 0; i <= level; i++) V.mul(cls_f64(r->small, i), 1.0); V.into(*r->ctx, B); }
         HIP_TRY(launch_ew(r->dev, ident_tab(level + 1), then_add_lazy ? EW_MUL_MONT_THEN_ADD_LAZY : EW_MUL_MONT, w[0], w[1], w[2], B, nullptr,
                           zeros, r->ctx->stream));
         return HE_OK;
@@ -1568,6 +1630,17 @@ int div_fill(CoReq &q, const std::shared_ptr<Ring> &r, int level, int nb, he_han
     q.keep = {r, p0, p1};
     q.run = [r, level, nb, round, ntt, many, same](const View *v, int B) -> int {
         for (int i = 0; i < nb; i++) r->ctx->acct(2.0 * (level - i + 1) - 1.0, 0, B, r->N);  // rescale: (2 L - 1) per polynomial and step
+        {   // NTT form, one step: INTT of the top limb, one NTT and one product per remaining limb; otherwise: [INTT] + a product per
+            // remaining limb and step + [NTT]
+            Valu V(r->logN);
+            if (ntt && nb == 1) { V.ntt(cls_f64(r->small, level)); for (int i = 0; i < level; i++) { V.ntt(cls_f64(r->small, i)); V.mul(cls_f64(r->small, i), 1.0); } }
+            else {
+                if (ntt) for (int i = 0; i <= level; i++) V.ntt(cls_f64(r->small, i));
+                for (int st = 0; st < nb; st++) for (int i = 0; i < level - st; i++) V.mul(cls_f64(r->small, i), 1.0);
+                if (ntt) for (int i = 0; i <= level - nb; i++) V.ntt(cls_f64(r->small, i));
+            }
+            V.into(*r->ctx, B);
+        }
         hipStream_t st = r->ctx->stream;
         const int N = r->N;
         if (nb == 0) {
@@ -1871,6 +1944,7 @@ int he_modup_q_to_p(he_handle hbe, int levelQ, int levelP, he_handle hq, he_hand
     q.keep = {be, pq, pp};
     q.run = [be, levelQ, levelP](const View *v, int B) -> int {
         be->ctx->acct(levelQ + 1 + levelP + 1, 0, B, be->Q->N);  // ModUp: L_src + L_dst
+        { Valu V(be->Q->logN); std::vector<int> d; for (int j = 0; j <= levelP; j++) d.push_back(be->LQ + j); valu_modup(V, be->small, 0, levelQ + 1, d); V.into(*be->ctx, B); }
         return modup_between(*be, true, levelQ, levelP, v[0], v[1], 0, B);
     };
     return co_dispatch(*be->ctx, pq->batch, q);
@@ -1889,6 +1963,7 @@ int he_modup_p_to_q(he_handle hbe, int levelP, int levelQ, he_handle hp, he_hand
     q.keep = {be, pq, pp};
     q.run = [be, levelQ, levelP](const View *v, int B) -> int {
         be->ctx->acct(levelQ + 1 + levelP + 1, 0, B, be->Q->N);
+        { Valu V(be->Q->logN); std::vector<int> d; for (int i = 0; i <= levelQ; i++) d.push_back(i); valu_modup(V, be->small, be->LQ, levelP + 1, d); V.into(*be->ctx, B); }
         return modup_between(*be, false, levelP, levelQ, v[0], v[1], 0, B);
     };
     return co_dispatch(*be->ctx, pq->batch, q);
@@ -1910,6 +1985,12 @@ static int moddown_api(he_handle hbe, int levelQ, int levelP, he_handle h1q, he_
     q.run = [be, levelQ, levelP, kind](const View *v, int B) -> int {
         const int N = be->Q->N;
         be->ctx->acct(kind == 2 ? levelQ + 1 + 2.0 * (levelP + 1) : 2.0 * (levelQ + 1) + levelP + 1, 0, B, N);  // ModDown: 2 L + alpha
+        {
+            Valu V(be->Q->logN);
+            if (kind != 2) valu_moddown(V, *be, levelQ, levelP, kind == 1);
+            else { std::vector<int> d; for (int j = 0; j <= levelP; j++) { d.push_back(be->LQ + j); V.mul(cls_f64(be->small, be->LQ + j), 1.0); } valu_modup(V, be->small, 0, levelQ + 1, d); }
+            V.into(*be->ctx, B);
+        }
         const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
         TRY(be->ctx->arena_reserve(wP + wQ));
         View sP{be->ctx->arena_take(wP), (size_t)(levelP + 1) * N};
@@ -2465,6 +2546,15 @@ int he_decompose_and_split(he_handle hev, int levelQ, int levelP, int nbPi, int 
     q.run = [ev, levelQ, levelP, nbPi, digit](const View *v, int B) -> int {
         BasisExtender &be = *ev->be;
         be.ctx->acct(std::min(nbPi, levelQ + 1 - digit * nbPi) + levelQ + 1 + levelP + 1, 0, B, be.Q->N);  // ModUp of one digit
+        {
+            Valu V(be.Q->logN);
+            const int s0 = digit * nbPi, e0 = std::min(s0 + nbPi, levelQ + 1);
+            std::vector<int> d;
+            for (int i = 0; i <= levelQ; i++) if (i < s0 || i >= e0) d.push_back(i);
+            for (int j = 0; j <= levelP; j++) d.push_back(be.LQ + j);
+            valu_modup(V, be.small, s0, e0 - s0, d);
+            V.into(*be.ctx, B);
+        }
         return decompose_digit(*ev, levelQ, levelP, nbPi, digit, v[0], v[1], 0, v[2], 0, B);
     };
     return co_dispatch(*be.ctx, p0->batch, q);
@@ -2523,6 +2613,7 @@ int he_decompose_ntt(he_handle hev, int levelQ, int levelP, int nbPi, he_handle 
         BasisExtender &be = *ev->be;
         const int N = be.Q->N;
         be.ctx->acct(levelQ + 1 + (double)base_rns_size(levelQ, levelP) * (levelQ + levelP + 2), 0, B, N);  // DecomposeNTT: L in, beta (L + alpha) out
+        { Valu V(be.Q->logN); valu_keyswitch(V, be, levelQ, levelP, base_rns_size(levelQ, levelP), true, false); V.into(*be.ctx, B); }
         const size_t w = (size_t)B * (levelQ + 1) * N;
         TRY(be.ctx->arena_reserve(w));
         View other{be.ctx->arena_take(w), (size_t)(levelQ + 1) * N};
@@ -2955,6 +3046,7 @@ int he_gadget_product_lazy(he_handle hev, int levelQ, he_handle hcx, he_handle h
     q.run = [ev, k, levelQ](const View *v, int B) -> int {
         BasisExtender &be = *ev->be;
         be.ctx->acct(levelQ + 1 + 2.0 * (levelQ + k->nPk + 1), key_limbs(*k, levelQ), B, be.Q->N);  // cx in, two QP accumulators out, key
+        { Valu V(be.Q->logN); valu_keyswitch(V, be, levelQ, k->nPk - 1, k->pw2 ? k->prefix[levelQ + 1] : base_rns_size(levelQ, k->nPk - 1), true, true); V.into(*be.ctx, B); }
         TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, B, true, k.get())));
         return gadget_product_lazy_core(*ev, levelQ, v[0], B, *k, v[1], v[2], v[3], v[4]);
     };
@@ -2987,6 +3079,7 @@ int he_gadget_product_hoisted_lazy(he_handle hev, int levelQ, he_handle hdec, he
     q.run = [ev, k, levelQ, dec_ds](const View *v, int B) -> int {
         BasisExtender &be = *ev->be;
         be.ctx->acct(key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + k->nPk + 1), key_limbs(*k, levelQ), B, be.Q->N);  // decomposition in, accumulators out, key
+        { Valu V(be.Q->logN); valu_keyswitch(V, be, levelQ, k->nPk - 1, base_rns_size(levelQ, k->nPk - 1), false, true); V.into(*be.ctx, B); }
         return ks_inner(*ev, levelQ, k->nPk - 1, v[0], dec_ds, *k, v[1], v[2], v[3], v[4], B);
     };
     return co_dispatch(*be.ctx, dec->batch, q);
@@ -3059,6 +3152,7 @@ int he_moddown(he_handle hev, int levelQ, int levelP, he_handle c0Q, he_handle c
     q.run = [ev, levelQ, levelP](const View *v, int B) -> int {
         BasisExtender &be = *ev->be;
         be.ctx->acct(2.0 * (2.0 * (levelQ + 1) + levelP + 1), 0, B, be.Q->N);  // ModDown of both components: 2 (2 L + alpha)
+        { Valu V(be.Q->logN); valu_moddown(V, be, levelQ, levelP); valu_moddown(V, be, levelQ, levelP); V.into(*be.ctx, B); }
         TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, levelP, B, false)));
         return moddown_pair(*ev, levelQ, levelP, v[0], v[1], v[2], v[3], v[4], v[5], B);
     };
@@ -3085,6 +3179,7 @@ int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle
         BasisExtender &be = *ev->be;
         const int N = be.Q->N;
         be.ctx->acct(2.0 * (levelQ + 1) + levelP + 1, 0, B, N);  // ModDownQPtoQNTT: 2 L + alpha
+        { Valu V(be.Q->logN); valu_moddown(V, be, levelQ, levelP); V.into(*be.ctx, B); }
         const size_t wP = (size_t)B * (levelP + 1) * N, wQ = (size_t)B * (levelQ + 1) * N;
         TRY(be.ctx->arena_reserve(wP + wQ));
         View sP{be.ctx->arena_take(wP), (size_t)(levelP + 1) * N};
@@ -3134,6 +3229,7 @@ int he_gadget_product(he_handle hev, int levelQ, he_handle hcx, he_handle hk, he
     q.run = [ev, k, levelQ](const View *v, int B) -> int {
         BasisExtender &be = *ev->be;
         be.ctx->acct(3.0 * (levelQ + 1), key_limbs(*k, levelQ), B, be.Q->N);  // GadgetProduct: 3 L + 2 beta (L + alpha)
+        { Valu V(be.Q->logN); valu_gadget_product(V, be, levelQ, k->nPk - 1, k->pw2 ? k->prefix[levelQ + 1] : base_rns_size(levelQ, k->nPk - 1), true); V.into(*be.ctx, B); }
         TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, B, true, k.get())));
         return gadget_product_core(*ev, levelQ, &v[0], nullptr, *k, v[1], v[2], B);
     };
@@ -3163,6 +3259,7 @@ int he_gadget_product_hoisted(he_handle hev, int levelQ, he_handle hdec, he_hand
     q.run = [ev, k, levelQ](const View *v, int B) -> int {
         BasisExtender &be = *ev->be;
         be.ctx->acct(key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + 1), key_limbs(*k, levelQ), B, be.Q->N);  // hoisted: decomposition in, 2 L out, key
+        { Valu V(be.Q->logN); valu_gadget_product(V, be, levelQ, k->nPk - 1, base_rns_size(levelQ, k->nPk - 1), false); V.into(*be.ctx, B); }
         TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, k->nPk - 1, B, false)));
         return gadget_product_core(*ev, levelQ, nullptr, &v[0], *k, v[1], v[2], B);
     };
@@ -3196,6 +3293,7 @@ int he_relinearize(he_handle hev, int level, he_handle hin0, he_handle hin1, he_
     q.run = [ev, k, level](const View *v, int B) -> int {
         BasisExtender &be = *ev->be;
         be.ctx->acct(5.0 * (std::min(level, k->nQk - 1) + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, be.Q->N);  // Relinearize: 3 L in, 2 L out, key
+        { Valu V(be.Q->logN); const int lv = std::min(level, k->nQk - 1); valu_gadget_product(V, be, lv, k->nPk - 1, k->pw2 ? k->prefix[lv + 1] : base_rns_size(lv, k->nPk - 1), true); V.into(*be.ctx, B); }
         TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k->nPk - 1, B, true, k.get())));
         return gadget_product_core(*ev, level, &v[2], nullptr, *k, v[3], v[4], B, &v[0], &v[1]);
     };
@@ -3237,6 +3335,7 @@ static int automorphism_core(Evaluator &ev, int level, View in0, const View *in1
     const int N = be.Q->N;
     // Rotate: (4 L + 2 beta (L + alpha)); hoisted: the decomposition replaces the second input
     be.ctx->acct(dec ? 3.0 * (level + 1) + key_limbs(k, level) / 2 : 4.0 * (level + 1), key_limbs(k, level), B, N);
+    { Valu V(be.Q->logN); valu_gadget_product(V, be, level, k.nPk - 1, k.pw2 ? k.prefix[level + 1] : base_rns_size(level, k.nPk - 1), !dec); V.into(*be.ctx, B); }
     const size_t wQ = (size_t)B * (level + 1) * N;
     TRY(be.ctx->arena_reserve(ks_scratch_words(be, level, k.nPk - 1, B, !dec, &k) + 2 * wQ + (size_t)N));
     hipStream_t st = be.ctx->stream;
@@ -3345,6 +3444,7 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
         BasisExtender &be = *ev->be;
         const int N = be.Q->N;
         be.ctx->acct(levelQ + 1 + key_limbs(*k, levelQ) / 2 + 2.0 * (levelQ + levelP + 2), key_limbs(*k, levelQ), B, N);
+        { Valu V(be.Q->logN); valu_keyswitch(V, be, levelQ, levelP, base_rns_size(levelQ, levelP), false, true); for (int i = 0; i <= levelQ; i++) V.mul(cls_f64(be.small, i), 1.0); V.into(*be.ctx, B); }
         ScalarTab s{};  // ctTmp[1].Q = ctIn[0] * P   (MulScalarBigint with P = prod p_j at levelP)
         for (int i = 0; i <= levelQ; i++) {
             const ModConst &m = be.Q->sub[i].mc;
@@ -3552,6 +3652,7 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
             aq.term_rows = ap.term_rows = 6;
         }
         be.ctx->acct(per * (levelQ + levelP + 2), shared * (levelQ + levelP + 2), B, be.Q->N);
+        { Valu V(be.Q->logN); for (int i = 0; i <= levelQ; i++) V.mul(cls_f64(be.small, i), 2.0 * n + 2.0); for (int j = 0; j <= levelP; j++) V.mul(cls_f64(be.small, be.LQ + j), 2.0 * n + 2.0); V.into(*be.ctx, B); }
         hipStream_t st = be.ctx->stream;
         HIP_TRY(launch_diag_mac(be.qp, aq, v[0], v[2], B, st));
         HIP_TRY(launch_diag_mac(be.qp, ap, v[1], v[3], B, st));
@@ -3577,6 +3678,12 @@ static int mul_relin_core(Evaluator &ev, int level, bool bgv, uint64_t t, Evk *k
         }
     }
     const int N = be.Q->N;
+    {
+        Valu V(be.Q->logN);
+        for (int i = 0; i <= level; i++) V.mul(cls_f64(be.small, i), 6.0);  // the tensor
+        if (k) valu_gadget_product(V, be, level, k->nPk - 1, k->pw2 ? k->prefix[level + 1] : base_rns_size(level, k->nPk - 1), true);
+        V.into(*be.ctx, B);
+    }
     if (k) be.ctx->acct(6.0 * (level + 1), key_limbs(*k, std::min(level, k->nQk - 1)), B, N);  // MulRelin: 6 L + 2 beta (L + alpha)
     else be.ctx->acct(7.0 * (level + 1), 0, B, N);                                                // Mul: 4 L in, 3 L out
     const size_t wQ = (size_t)B * (level + 1) * N;
@@ -3769,6 +3876,13 @@ int he_alg_bytes(he_handle hctx, int reset, double out[2]) {
     std::lock_guard<std::mutex> lk(c->mu);
     if (out) { out[0] = c->alg_bytes[0]; out[1] = c->alg_bytes[1]; }
     if (reset) c->alg_bytes[0] = c->alg_bytes[1] = 0.0;
+    return HE_OK;
+}
+int he_alg_valu(he_handle hctx, int reset, double out[4]) {
+    GET(c, Ctx, hctx, T_CTX);
+    Scope sc(c.get());
+    if (out) for (int i = 0; i < 4; i++) out[i] = c->alg_valu[i];
+    if (reset) for (int i = 0; i < 4; i++) c->alg_valu[i] = 0.0;
     return HE_OK;
 }
 const char *he_prof_kernel_name(int id) { return kernel_name(id); }

@@ -170,6 +170,12 @@ class Context:
         check(load().he_alg_bytes(self.h, int(reset), out))
         return float(out[0]), float(out[1])
 
+    def alg_valu(self, reset: bool = False):
+        """he_alg_valu (hering_debug.h): [integer-class multiplies, double-precision-class multiplies, butterflies among each]"""
+        out = (C.c_double * 4)()
+        check(load().he_alg_valu(self.h, int(reset), out))
+        return [float(x) for x in out]
+
     def probe_modmul(self, iters=256) -> float:
         out = C.c_double()
         check(load().he_probe_modmul(self.h, iters, C.byref(out)))
