@@ -167,6 +167,12 @@ struct Ctx : Obj {
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Small batches (a lone caller, a few callers through the queue): the key switch's double-precision NTT + MAC launch runs on
+    // this side stream beside the integer chain (forward rows -> inner product -> ModDown's inverse rows -> basis extension) and
+    // is joined before the final forward rows; side_pending: a fork of the current call has not been joined yet
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_pending = false;
     // stream-ordered scratch arena (temporaries of one API call)
     uint64_t *arena = nullptr;
     size_t arena_words = 0, arena_used = 0;
@@ -267,6 +273,9 @@ struct Ctx : Obj {
         if (arena) hipFree(arena);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
+        if (side) { hipStreamSynchronize(side); hipStreamDestroy(side); }
+        if (ev_fork) hipEventDestroy(ev_fork);
+        if (ev_join) hipEventDestroy(ev_join);
         if (stream) hipStreamDestroy(stream);
     }
     void arena_reset() { arena_used = 0; }
@@ -955,6 +964,9 @@ int he_ctx_create(int device_id, he_handle *out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) c->kPoolCap = std::max<size_t>(c->kPoolCap, total_b / 2);
@@ -2691,8 +2703,9 @@ static bool f64_raw_ok(const BasisExtender &be, int levelQ, int levelP, int nsrc
 // the caller guarantees that no P limb is of the double-precision class
 int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View cx,
                int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch, bool q_out_f64 = false, bool own_reduce = true,
-               bool dec_f64 = false, const NttMacEpilogue *epi = nullptr) {
+               bool dec_f64 = false, const NttMacEpilogue *epi = nullptr, hipStream_t on = nullptr) {
     BasisExtender &be = *ev.be;
+    const hipStream_t st = on ? on : be.ctx->stream;
     const int LQ = be.LQ, N = be.Q->N;
     NttMacArgs a{};
     a.beta = base_rns_size(levelQ, levelP);
@@ -2722,11 +2735,11 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
             if (a.out_view[i]) return fail(HE_EINVAL, "ks_mac_f64: epilogue with a double-precision P limb");
             e.sp[i] = epi->sp[a.out_limb[i]]; e.tsp[i] = epi->tsp[a.out_limb[i]];
         }
-        HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream, &e));
+        HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, st, &e));
         return HE_OK;
     }
     if (!q_out_f64) {
-        HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
+        HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, st));
         return HE_OK;
     }
     // double-format Q accumulators: the Q limbs and the P limbs go to separate launches (different store code)
@@ -2739,8 +2752,8 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
         d.out_view[m] = a.out_view[i]; d.mod[m] = a.mod[i];
     }
     aq.q_out_f64 = 1;
-    HIP_TRY(launch_ntt_mac_f64(be.qp, aq, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
-    HIP_TRY(launch_ntt_mac_f64(be.qp, ap, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream));
+    HIP_TRY(launch_ntt_mac_f64(be.qp, aq, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, st));
+    HIP_TRY(launch_ntt_mac_f64(be.qp, ap, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, st));
     return HE_OK;
 }
 
@@ -2761,6 +2774,7 @@ struct TensorIn {
 // the P part with the ModDown epilogue inside (gadget_product_core)
 struct MacDefer {
     bool want = false, deferred = false;
+    bool side = false;  // in: run the NTT + MAC launch on the context's side stream (the caller joins: Ctx::side_pending)
     const uint64_t *dec = nullptr;
     size_t bs = 0, ds = 0;
     bool raw = false, own_reduce = true;
@@ -2833,6 +2847,21 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
             int max_nsrc = 1;
             for (const FusedGroup &g : plan->groups) max_nsrc = std::max(max_nsrc, g.nsrc);
             const bool raw = f64_raw_ok(be, levelQ, levelP, max_nsrc);
+            if (defer && defer->side) {
+                // small batch: every launch is one workgroup chain's latency, not throughput.  The NTT + MAC launch over the
+                // double-precision limbs needs only the basis extension's output; it runs on the side stream while this one does
+                // the integer limbs' forward rows and inner product (and, in the caller, the P part's way back to Q)
+                for (const FusedGroup &g : plan->groups)
+                    HIP_TRY(launch_modup_fused(be.qp, g.dev, g.n, g.nsrc, g.dst_classes, inv, View{dec, bs}, View{dec, bs}, B, be.ctx->stream, raw, g.total_limbs));
+                HIP_TRY(hipEventRecord(be.ctx->ev_fork, be.ctx->stream));
+                HIP_TRY(hipStreamWaitEvent(be.ctx->side, be.ctx->ev_fork, 0));
+                if (acc_q_f64) *acc_q_f64 = want_f64;
+                TRY(ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64, !cx_canonical, raw, nullptr, be.ctx->side));
+                HIP_TRY(hipEventRecord(be.ctx->ev_join, be.ctx->side));
+                be.ctx->side_pending = true;
+                TRY(dec_rows_ntt(ev, levelQ, levelP, levelP + 1, View{dec, bs}, B, 1));
+                return ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1);
+            }
             TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, View{dec, bs}, B, 1, raw));
             TRY(ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
             if (defer && defer->want) {
@@ -2931,6 +2960,17 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const View *h
         defer.want = out0.p != cx->p && out1.p != cx->p;
         for (int j = 0; j <= levelP; j++) defer.want = defer.want && be.small[be.LQ + j] != 2;
     }
+    // HERING_SIDE_MAX_BATCH=n (default 0: never): up to n entries take the fork instead of the fused epilogue -- two launches
+    // more, but the longest of the step (NTT + MAC over the digits) leaves the critical path.  Built and measured in round 5
+    // (VERDICT r4 item 7): SLOWER -- 0.184 ms against 0.159 ms for a lone MulRelin, 16.8 k against 18.7 k ops/s from four callers;
+    // the two cross-stream dependencies cost more than the overlap gains (NOTES.md).  Kept as an A/B switch.  Not while a graph
+    // is recorded, not under the kernel profiler, and only when the P accumulators do not depend on that launch.
+    static const int side_max = getenv("HERING_SIDE_MAX_BATCH") ? atoi(getenv("HERING_SIDE_MAX_BATCH")) : 0;
+    if (cx && plan->ok && k.keyd && !k.pw2 && B <= side_max && !be.ctx->capturing && !prof_active(be.ctx->stream)) {
+        bool p_int = true;
+        for (int j = 0; j <= levelP; j++) p_int = p_int && be.small[be.LQ + j] != 2;
+        if (p_int) { defer.want = false; defer.side = true; }
+    }
     if (cx) TRY(gadget_product_lazy_core(ev, levelQ, *cx, B, k, a0Q, a0P, a1Q, a1P, cx_canonical, &acc_f64, &defer, tin));
     else {
         acc_f64 = false;
@@ -2983,6 +3023,10 @@ int gadget_product_core(Evaluator &ev, int levelQ, const View *cx, const View *h
                 HIP_TRY(launch_ntt_rows(be.qp, ti, sQ, out0, 2 * B, false, 0, st, &epi));
             }
             return HE_OK;
+        }
+        if (be.ctx->side_pending) {  // the Q accumulators of the double-precision limbs come from the side stream
+            HIP_TRY(hipStreamWaitEvent(st, be.ctx->ev_join, 0));
+            be.ctx->side_pending = false;
         }
         NttEpilogue epi;
         epi.scatter_ginv = tin ? 0u : want_scatter;
