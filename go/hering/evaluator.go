@@ -42,7 +42,10 @@ type Evaluator struct {
 	keys   rlwe.EvaluationKeySet
 
 	// MaxTwins bounds the twin cache (0: DefaultMaxTwins): the key pointers keep every host polynomial alive and every twin
-	// resident in HBM, so a long circuit without Forget would otherwise grow without limit
+	// resident in HBM, so a long circuit without Forget would otherwise grow without limit.  It is a SOFT bound: twins handed out
+	// during the last MaxTwins / 2 twin() calls are never evicted (they may be operands of a call in progress), and nothing is
+	// evicted while a Graph captured on the context is alive (its nodes address twins by device pointer) -- Close graphs
+	// explicitly (Graph.Close) in long-running services instead of leaving them to the finalizer, and watch TwinCount().
 	MaxTwins int
 
 	mu     sync.Mutex
@@ -129,6 +132,13 @@ func (e *Evaluator) GetRLWEParameters() *rlwe.Parameters { return &e.params }
 // ---- device twins ------------------------------------------------------------------------------------------------------
 
 func key(p ring.Poly) *uint64 { return &p.Coeffs[0][0] }
+
+// TwinCount returns how many device twins the evaluator holds at the moment (MaxTwins is a soft bound, see there).
+func (e *Evaluator) TwinCount() int {
+	e.mu.Lock()
+	defer e.mu.Unlock()
+	return len(e.polys)
+}
 
 // DefaultMaxTwins is the twin-cache bound when Evaluator.MaxTwins is 0.
 const DefaultMaxTwins = 4096

@@ -231,13 +231,19 @@ class ControlPlane:
             import atexit
             import sys
             status = {"code": 0}
-            orig_exit = sys.exit
+            orig_exit, orig_hook = sys.exit, sys.excepthook
 
             def exit_recording(code=0):
                 status["code"] = code if isinstance(code, int) else (0 if code is None else 1)
                 orig_exit(code)
 
+            def hook_recording(et, ev, tb):
+                # a run that dies on an uncaught exception (a failed verification assert, ...) must not leave with status 0
+                status["code"] = ev.code if isinstance(ev, SystemExit) and isinstance(ev.code, int) else 1
+                orig_hook(et, ev, tb)
+
             sys.exit = exit_recording
+            sys.excepthook = hook_recording
 
             def hard_exit():
                 sys.stdout.flush()
