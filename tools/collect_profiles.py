@@ -31,6 +31,53 @@ for w, steps in (("c2", 5), ("c3", 5), ("c4", 5), ("c5", 2)):
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f, wr, str(batch), w, str(1 + steps)], text=True)
     d = json.loads(out)
     json.dump(d, open(os.path.join(P, f"{tag}_pmc_traffic.json" if w == "c3" else f"{tag}_pmc_traffic_{w}.json"), "w"), indent=1)
+for w in ("c2", "c4", "c5"):
+    d = os.path.join(G, f"stats_{w}")
+    if os.path.isdir(d):
+        st = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("kernel_stats.csv")]
+        if st:
+            shutil.copy(st[0], os.path.join(P, f"{tag}_kernel_stats_{w}.csv"))
+if os.path.exists(os.path.join(G, "r05_ntt_pmc.txt")):
+    shutil.copy(os.path.join(G, "r05_ntt_pmc.txt"), os.path.join(P, f"{tag}_ntt_pmc_traffic.txt"))
+
+
+def sq_summary(passes, workload, out_name):
+    groups = {}
+    for t in passes:
+        f = [os.path.join(dp, x) for dp, _, fs in os.walk(os.path.join(G, f"pmc_{t}")) for x in fs if x.endswith("counter_collection.csv")]
+        if not f:
+            return
+        rows = collections.defaultdict(dict)
+        for r in csv.DictReader(open(f[0])):
+            key = (r["Kernel_Name"].split("(")[0].replace("void he::", ""), r["Grid_Size"], r["Dispatch_Id"])
+            rows[key][r["Counter_Name"]] = float(r["Counter_Value"])
+        agg = collections.defaultdict(list)
+        for (name, grid, _), c in rows.items():
+            agg[(name, grid) if workload == "c3" else (name, "")].append(c)
+        for (name, grid), cs in agg.items():
+            m = {k: sum(c.get(k, 0.0) for c in cs) / len(cs) for k in cs[0]}
+            m["_launches"] = len(cs)
+            groups.setdefault(f"{name} grid={grid}" if grid else name, {}).update(m)
+    summary = {"workload": workload, "source": "rocprofv3 --pmc (tools/round_artifacts.sh) on bench.py; per-launch means, summed over the shader engines"
+               + ("" if workload == "c3" else "; launches of one kernel instantiation pooled over the grids of the trace"),
+               "notes": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles per wave; valu_issue_share = VALU instructions per wave / wave-quad-cycles per wave",
+               "launch_groups": {}}
+    for k, m in sorted(groups.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0) * kv[1].get("_launches", 1)):
+        if m.get("SQ_WAVES", 0) < 1000:
+            continue
+        w = m["SQ_WAVES"]
+        e = {"launches": m.get("_launches"), "waves": round(w), "valu_insts_per_wave": round(m.get("SQ_INSTS_VALU", 0) / w, 1),
+             "wave_quad_cycles_per_wave": round(m.get("SQ_WAVE_CYCLES", 0) / w),
+             "valu_issue_share_of_wave_time": round(m.get("SQ_INSTS_VALU", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), 3),
+             "wait_any_share": round(m.get("SQ_WAIT_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), 3),
+             "wait_inst_any_share": round(m.get("SQ_WAIT_INST_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), 3)}
+        summary["launch_groups"][k] = e
+    json.dump(summary, open(os.path.join(P, out_name), "w"), indent=1)
+
+
+for w in ("c2", "c4", "c5"):
+    sq_summary((f"sq1_{w}",), w, f"{tag}_sq_counters_{w}.json")
+
 # SQ passes: per (kernel, grid) launch group
 groups = {}
 for t in ("sq1", "sq2"):
