@@ -632,6 +632,9 @@ def concurrent_c5(la, ctx, ks=(4, 16, 32), window_us=100, max_batch=64, rounds=3
         s1 = ctx.CoalescingStats()
         ctx.SetCoalescing(0, 0)
         if os.environ.get("HERING_REPLAY_PROFILE"):
+            dbg = (C.c_uint64 * 8)()
+            L.he_debug_queue_counters(ctx.h, dbg)
+            print("queue counters (cumulative):", [int(x) for x in dbg], file=sys.stderr)
             prof = (C.c_uint64 * 192)()
             L.he_debug_replay_profile(prof, 64, 1)
             names = {v[0]: k for k, v in _lib._TRACE_FNS.items()}

@@ -43,7 +43,8 @@ int he_evaluator_coalescing_stats(he_handle eval, uint64_t out[4]);
 int he_ctx_coalescing_stats(he_handle ctx, uint64_t out[4]);  /* the same counters through the context handle */
 /* diagnosis of the queue's gathering rule since the context was created: out[0..2] = batches launched because every recently
  * active caller was waiting / because the oldest request had waited 8 windows / because max_batch requests were pending; out[3],
- * out[4] = microseconds the leaders spent gathering and launching; out[5] / out[6] = sums of callers present / expected at launch */
+ * out[4] = microseconds the leaders spent gathering and launching; out[5] / out[6] = sums of callers present / expected at launch;
+ * out[7] = allocations the context's buffer cache could not serve (hipMalloc calls) */
 int he_debug_queue_counters(he_handle ctx, uint64_t out[8]);
 /* Concurrent single-ciphertext callers, the shape of the reference's parallel benchmarks (b.RunParallel,
  * schemes/ckks/ckks_benchmarks_test.go:116-207): n_threads OS threads (pthreads inside the library: no interpreter in the timed

@@ -220,6 +220,7 @@ struct Ctx : Obj {
         retired_arenas.clear();
     }
     size_t pool_bytes = 0;
+    std::atomic<uint64_t> pool_misses{0};  // allocations the cache could not serve (he_debug_queue_counters)
     // bound of the cache: half of the device's memory (set by he_ctx_create; 288 GB of HBM3E per MI355X).  A release beyond it has
     // to drain the stream before hipFree -- with K callers' temporaries in flight that is tens of milliseconds per call
     size_t kPoolCap = (size_t)48 << 30;
@@ -234,6 +235,7 @@ struct Ctx : Obj {
                 return hipSuccess;
             }
         }
+        pool_misses.fetch_add(1, std::memory_order_relaxed);
         hipError_t e = hipMalloc(out, bytes);
         if (e != hipSuccess) {  // give the cache back to the driver and retry once
             (void)hipGetLastError();
@@ -2126,6 +2128,7 @@ int he_debug_queue_counters(he_handle h, uint64_t out[8]) {
     if (!out) return fail(HE_EINVAL, "he_debug_queue_counters: null output");
     std::lock_guard<std::mutex> lk(c->co->mu);
     for (int i = 0; i < 8; i++) out[i] = c->co->dbg[i];
+    out[7] = c->pool_misses.load(std::memory_order_relaxed);
     return HE_OK;
 }
 int he_ctx_coalescing_stats(he_handle h, uint64_t out[4]) {
