@@ -1030,3 +1030,27 @@ def test_random_scheme_level_calls(ctx):
     # (42 092 by the tool)
     for _ in range(200):
         fz.be_case(ctx, rng)
+
+
+def test_random_calls_with_the_queue_on(ctx):
+    """The same three generators (another seed) with the context's submission queue switched on: every batch-1 draw is filed as a
+    request and served as a lone caller's batch (closure over its own views, no entry table), every larger batch launches directly
+    -- the dispatch every entry point takes since round 5 must not change a word."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_shapes", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "fuzz_shapes.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.Generator(np.random.PCG64(20260925))
+    ctx.SetCoalescing(8, 50)
+    try:
+        s0 = ctx.CoalescingStats()
+        for _ in range(100):
+            fz.api_case(ctx, rng)
+        for _ in range(300):
+            fz.ring_case(ctx, rng)
+        for _ in range(150):
+            fz.be_case(ctx, rng)
+        ctx.sync()
+        assert ctx.CoalescingStats()["calls"] - s0["calls"] > 50  # the batch-1 draws did go through the queue
+    finally:
+        ctx.SetCoalescing(0, 0)
