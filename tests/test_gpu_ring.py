@@ -237,7 +237,7 @@ def test_rescale_all_variants(ctx, mods):
     assert np.array_equal(pin.get()[:3], sub.DivRoundByLastModulusNTT(x[:4]))
 
 
-@pytest.mark.parametrize("logN", [13, 15, 16])
+@pytest.mark.parametrize("logN", [13, 14, 15, 16])
 def test_rescale_two_pass_rings_batched_in_place(ctx, logN):
     """DivRound/DivFloorByLastModulusNTT where the transform is column pass + row pass (logN > 12): the step is two fused
     transforms (scalar prologue, MRed epilogue through a scratch intermediate), on a chain that mixes the three modulus classes,
