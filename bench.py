@@ -574,7 +574,7 @@ def concurrent_b1(la, ctx, workload="c3", ks=(1, 4, 16, 64), ops_per_run=6000, m
     return out
 
 
-def concurrent_c5(la, ctx, ks=(4, 16, 32), window_us=100, max_batch=64, rounds=3):
+def concurrent_c5(la, ctx, ks=(4, 16, 32), window_us=100, max_batch=64, rounds=3, depth=8):
     """BASELINE config 5 in the shape of the reference's own benchmark: BenchmarkConcurrentBootstrap runs b.RunParallel over
     bootstrappers (circuits/ckks/bootstrapping/evaluator_benchmarks_test.go:14-42) -- K callers, ONE ciphertext each, every call of
     the circuit a single-ciphertext call on shared keys and matrices.  The drivers above the operator interface exist here only as
@@ -613,7 +613,9 @@ def concurrent_c5(la, ctx, ks=(4, 16, 32), window_us=100, max_batch=64, rounds=3
     out = {"K": list(ks), "unit": "ctxt-bootstraps/s", "max_batch": max_batch, "window_us": window_us, "rounds_per_caller": rounds,
            "calls_per_bootstrap": int(sum(1 for _ in _program_calls(program))),
            "host": "K pthreads replaying the recorded call sequence of one driver run (he_debug_replay): public entry points only",
-           "coalesced": [], "mean_batch": [], "served_one_by_one": []}
+           "coalesced": [], "mean_batch": [], "served_one_by_one": [],
+           "deferred": {"depth": depth, "coalesced": [], "mean_batch": [],
+                        "note": "he_ctx_set_deferred: calls return once filed, the context's dispatcher thread launches them"}}
 
     def fetch(h):
         nl, b, n = C.c_int(), C.c_int(), C.c_int()
@@ -623,18 +625,28 @@ def concurrent_c5(la, ctx, ks=(4, 16, 32), window_us=100, max_batch=64, rounds=3
         _lib.check(L.he_poly_free(int(h)))
         return a
 
-    def go(K, coalesce, n_rounds):
+    def go(K, coalesce, n_rounds, deferred=0):
         nonlocal ok
         ctx.SetCoalescing(max_batch if coalesce else 0, window_us)
+        if coalesce:
+            ctx.SetDeferred(deferred)
         s0 = ctx.CoalescingStats()
         wall, outs = _lib.replay(ctx.h, program, K, n_rounds, [ct0[0].h, ct0[1].h], [[p.h for p in ins[k]] for k in range(K)],
                                  [v.h for v in res.Value])
         s1 = ctx.CoalescingStats()
         ctx.SetCoalescing(0, 0)
         if os.environ.get("HERING_REPLAY_PROFILE"):
-            dbg = (C.c_uint64 * 8)()
+            dbg = (C.c_uint64 * 16)()
             L.he_debug_queue_counters(ctx.h, dbg)
             print("queue counters (cumulative):", [int(x) for x in dbg], file=sys.stderr)
+            ops = (C.c_uint64 * 64)()
+            L.he_debug_queue_op_stats(ctx.h, ops)
+            cur = [int(x) for x in ops]
+            prev = getattr(go, "_ops", [0] * 64)
+            go._ops = cur
+            print("queue batches by operation (op: launches, mean batch):",
+                  {i: (cur[2 * i] - prev[2 * i], round((cur[2 * i + 1] - prev[2 * i + 1]) / (cur[2 * i] - prev[2 * i]), 1))
+                   for i in range(32) if cur[2 * i] > prev[2 * i]}, file=sys.stderr)
             prof = (C.c_uint64 * 192)()
             L.he_debug_replay_profile(prof, 64, 1)
             names = {v[0]: k for k, v in _lib._TRACE_FNS.items()}
@@ -647,12 +659,23 @@ def concurrent_c5(la, ctx, ks=(4, 16, 32), window_us=100, max_batch=64, rounds=3
         return K * n_rounds / wall, (s1["calls"] - s0["calls"]) / max(1, s1["launches"] - s0["launches"]), s1["one_by_one"] - s0["one_by_one"]
 
     go(min(4, kmax), True, 1)  # arena, pools, the queue's history
+    if os.environ.get("HERING_C5_ONLY"):  # diagnosis (tools/c5_gap_analysis.py): one mode, the timed run last in the process
+        dd = depth if os.environ["HERING_C5_ONLY"] == "deferred" else 0
+        go(kmax, True, 1, dd)
+        r, mb, _ = go(kmax, True, rounds, dd)
+        return {"only": os.environ["HERING_C5_ONLY"], "K": kmax, "rate": r, "mean_batch": mb, "wall_s": kmax * rounds / r, "verified": bool(ok)}
     for K in ks:
         go(K, True, 1)  # the buffer pool grows to K callers' temporaries (hipMalloc synchronises the device)
         r, mb, obo = go(K, True, rounds)
         out["coalesced"].append(r); out["mean_batch"].append(mb); out["served_one_by_one"].append(obo)
+        if depth > 0:
+            go(K, True, 1, depth)
+            r, mb, obo = go(K, True, rounds, depth)
+            out["deferred"]["coalesced"].append(r); out["deferred"]["mean_batch"].append(mb)
     out["uncoalesced_K%d" % ks[0]] = go(ks[0], False, rounds)[0]
     out["lone_caller"] = go(1, False, rounds)[0]
+    if depth > 0:
+        out["deferred"]["lone_caller"] = go(1, True, rounds, depth)[0]
     out["verified"] = bool(ok)
     return out
 

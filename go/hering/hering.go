@@ -78,6 +78,15 @@ func (c *Context) SetCoalescing(maxBatch, windowMicros int) error {
 	return lockedCall(func() C.int { return C.he_ctx_set_coalescing(c.h, C.int(maxBatch), C.int(windowMicros)) })
 }
 
+// SetDeferred switches the queue to deferred submission (he_ctx_set_deferred, include/hering.h): a queued call returns once it is
+// filed and the context's dispatcher thread launches it; a failed launch is reported by the next Sync.  The library orders a
+// caller's requests by OS thread, so a goroutine that issues calls in this mode must stay on its thread: call
+// runtime.LockOSThread() at its start (a goroutine that migrated between two calls could see them launched out of order).
+// depth = 0 switches back to calls that return once launched.
+func (c *Context) SetDeferred(depth int) error {
+	return lockedCall(func() C.int { return C.he_ctx_set_deferred(c.h, C.int(depth)) })
+}
+
 // Graph is a captured sequence of calls on a Context (he_graph_*, include/hering.h): one enqueue replays them all.
 type Graph struct {
 	ctx *Context

@@ -273,6 +273,22 @@ int he_evaluator_destroy(he_handle eval);
  * share one stream): he_ctx_set_coalescing is the same switch addressed through the context handle. */
 int he_evaluator_set_coalescing(he_handle eval, int max_batch, int window_us);
 int he_ctx_set_coalescing(he_handle ctx, int max_batch, int window_us);
+/* Deferred submission (an option of the queue above; depth > 0 switches it on, 0 off).  In the default mode a queued call returns
+ * when its batch has been launched: two thread hand-overs per call (caller -> launching thread -> caller) that the device waits out
+ * when the launches are short.  Deferred, a queued call checks its arguments, files its request and returns HE_OK at once; a
+ * dispatcher thread owned by the context gathers the FIRST pending call of every calling thread, batches the ones that match and
+ * launches them, so callers run ahead of the device by up to `depth` requests per thread (a goroutine that issues the calls of a
+ * circuit never waits for a launch, as a goroutine of the reference never waits for anything but its own arithmetic).  Contract:
+ *  - a thread's calls are launched in the order it made them; anything the same thread launches directly afterwards (handles of
+ *    batch > 1, uploads / downloads, key creation, graph capture) first waits for that thread's pending requests;
+ *  - he_ctx_sync launches everything filed before it, drains the stream and returns the first failure of a deferred launch, if any
+ *    (a failure AFTER the arguments were accepted -- a device error -- can no longer be returned by the call that caused it);
+ *  - polynomials may be freed right after the call that uses them (the request holds them);
+ *  - data handed from one thread to another needs a he_ctx_sync in between (in the default mode a returned call is already in
+ *    stream order; deferred, it may still be waiting behind the other thread's earlier calls).
+ * Results are bit-identical to the direct calls.  Requires the queue to be on; he_ctx_set_coalescing(ctx, 0, 0) and he_ctx_destroy
+ * end it (pending requests are launched first). */
+int he_ctx_set_deferred(he_handle ctx, int depth);
 
 /* GadgetCiphertext (core/rlwe/gadgetciphertext.go:19-42), BaseTwoDecomposition = 0.
  * Host image: q[beta][2][nQk][N], p[beta][2][nPk][N], NTT + Montgomery form.     */

@@ -65,6 +65,9 @@ public:
     // the submission queue of the context (hering.h, he_ctx_set_coalescing): concurrent single-ciphertext calls of any operator --
     // one thread per ciphertext, the reference's b.RunParallel shape -- become batched launches over the callers' own polynomials
     void SetCoalescing(int maxBatch = 64, int windowMicros = 30) const { check(he_ctx_set_coalescing(h(), maxBatch, windowMicros)); }
+    // deferred submission (hering.h, he_ctx_set_deferred): queued calls return once filed, the context's dispatcher thread launches
+    // them; a failed launch is reported by the next Sync().  depth = 0: back to calls that return once launched
+    void SetDeferred(int depth = 8) const { check(he_ctx_set_deferred(h(), depth)); }
     static int DeviceCount() {
         int n = 0;
         check(he_device_count(&n));

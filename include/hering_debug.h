@@ -44,8 +44,13 @@ int he_ctx_coalescing_stats(he_handle ctx, uint64_t out[4]);  /* the same counte
 /* diagnosis of the queue's gathering rule since the context was created: out[0..2] = batches launched because every recently
  * active caller was waiting / because the oldest request had waited 8 windows / because max_batch requests were pending; out[3],
  * out[4] = microseconds the leaders spent gathering and launching; out[5] / out[6] = sums of callers present / expected at launch;
- * out[7] = allocations the context's buffer cache could not serve (hipMalloc calls) */
-int he_debug_queue_counters(he_handle ctx, uint64_t out[8]);
+ * out[7] = allocations the context's buffer cache could not serve (hipMalloc calls); deferred submission (he_ctx_set_deferred):
+ * out[8] = microseconds the dispatcher paused because it was four batches ahead of the device, out[9] / out[10] = microseconds it
+ * waited for callers while the device had at least two batches queued (free) / while the device was running dry, out[11] = batches;
+ * out[12] (HERING_QUEUE_TIMING=1 only) = device microseconds spent inside the dispatcher's batches; out[13..15] reserved */
+int he_debug_queue_counters(he_handle ctx, uint64_t out[16]);
+/* per operation of the queue (the CoOp numbering of csrc/api.cpp): out[2 i] = batches launched, out[2 i + 1] = requests served */
+int he_debug_queue_op_stats(he_handle ctx, uint64_t out[64]);
 /* Concurrent single-ciphertext callers, the shape of the reference's parallel benchmarks (b.RunParallel,
  * schemes/ckks/ckks_benchmarks_test.go:116-207): n_threads OS threads (pthreads inside the library: no interpreter in the timed
  * region); thread i makes `iters` calls on its own batch-1 handles -- op 0: he_ckks_mul_relin(eval[i], level, a0[i], a1[i], b0[i],

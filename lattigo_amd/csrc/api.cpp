@@ -22,6 +22,7 @@
 #include <tuple>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <cstdlib>
 #include <vector>
@@ -101,6 +102,7 @@ struct CoReq {
     std::vector<uint64_t> blob;     // scalar arguments of variable size (per-limb scalars, ...), compared by value
     // ---- operands: device views of this request's own polynomials (null pointer: operand absent)
     std::vector<View> ops;
+    int nb = 1;  // batch entries of this request's handles (entry i of operand s: ops[s].p + i * ops[s].bstride)
     std::vector<std::shared_ptr<Obj>> keep;  // what the launches address stays alive until they are enqueued
     // the launches over B entries, v[s] = operand s (this request's views, or entry 0's pointer + an entry table).  It must
     // capture nothing that is not covered by the key: a batch runs the closure of its FIRST request for everyone.
@@ -111,6 +113,7 @@ struct CoReq {
     std::chrono::steady_clock::time_point arrived;
     uint64_t caller = 0;  // the submitting thread (several requests of one call share it)
     uint64_t seq = 0;     // how many queued calls that thread had made before this one
+    uint64_t ticket = 0;  // deferred submission: filing order over all threads of the context (he_ctx_sync waits by ticket)
     // done: status and message are final (the LAST thing a leader writes: the submitter may return, and the request die, at once);
     // lead: the leaving leader handed the role to this (still waiting) request.  Both are read without the queue's lock by the
     // sleeping submitter, which waits on the queue's generation word (Coalescer::gen).
@@ -159,8 +162,43 @@ struct Coalescer {
     std::vector<std::pair<uint64_t, std::chrono::steady_clock::time_point>> seen;
     // diagnosis (he_debug_queue_counters): why gathering ended -- [0] everyone here, [1] timeout, [2] full -- and where the
     // leaders' time went: [3] microseconds gathering, [4] microseconds launching, [5] sum of callers present, [6] sum of callers expected
-    uint64_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // deferred mode: [8] us the dispatcher paused because it was four batches ahead of the device, [9] us it waited for callers
+    // while the device had two or more batches queued (free), [10] us it waited for callers with the device running dry, [11] batches
+    // [12] (HERING_QUEUE_TIMING=1 only) device microseconds between the first and the last launch of the batches, as the stream ran them
+    uint64_t dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t op_launches[32] = {0}, op_calls[32] = {0};  // per operation (CoOp): batches launched, requests served (he_debug_queue_op_stats)
+    std::deque<hipEvent_t> inflight_begin;  // HERING_QUEUE_TIMING=1: the event recorded before each batch of `inflight`
+    // ---- deferred submission (he_ctx_set_deferred): a call files its request and RETURNS; a dispatcher thread of the context
+    // gathers and launches.  depth: requests one thread may have pending before its next call waits (0: off -- calls wait for
+    // their launch as above).  A thread's requests are launched in the order it made them; only the first pending call of each
+    // thread is a candidate for a batch.
+    std::atomic<int> depth{0};
+    std::thread dispatcher;
+    bool stop = false;
+    uint64_t next_ticket = 1;
+    uint64_t launching_min = UINT64_MAX;              // smallest ticket of the batch being launched right now
+    // one record per calling thread (stable address: the thread keeps a pointer while it sleeps): its requests in the order it
+    // made them, how many of them are not launched yet, and whether it sleeps until that count falls to half of `depth`
+    struct Caller {
+        uint64_t id = 0;
+        std::deque<CoReq *> q;
+        std::atomic<int> pending{0};
+        std::atomic<bool> wait_low{false};
+    };
+    std::vector<std::unique_ptr<Caller>> callers;
+    int n_deferred = 0;                               // requests in the callers' queues
+    std::atomic<int> sleepers{0};                     // threads asleep on `gen`
+    std::atomic<int> flushers{0};                     // threads that wait for launches (a flush): woken after every batch
+    int def_rc = 0;                                   // first failure of a deferred launch: reported by the next he_ctx_sync
+    std::string def_err;
+    Caller &caller_of(uint64_t id) {
+        for (auto &m : callers) if (m->id == id) return *m;
+        callers.emplace_back(new Caller());
+        callers.back()->id = id;
+        return *callers.back();
+    }
 };
+thread_local bool g_dispatcher_thread = false;  // the dispatcher's own launches do not wait for the queue
 
 
 struct Ctx : Obj {
@@ -266,6 +304,12 @@ struct Ctx : Obj {
     }
     Ctx() : Obj(T_CTX) {}
     ~Ctx() override {
+        if (co->dispatcher.joinable()) {  // (he_ctx_destroy stops it; this is the context dying with its last object)
+            { std::lock_guard<std::mutex> lk(co->mu); co->stop = true; }
+            co->cv_leader.notify_all();
+            if (co->dispatcher.get_id() == std::this_thread::get_id()) co->dispatcher.detach();
+            else co->dispatcher.join();
+        }
         hipSetDevice(dev);
         if (stream) hipStreamSynchronize(stream);
         pool_release_all();
@@ -644,9 +688,20 @@ int unreg(uint64_t h, ObjType t) {
     auto var = get<T>(h, tag);                                                                       \
     if (!var) return fail(HE_EHANDLE, "%s: bad %s handle %llu", __func__, #T, (unsigned long long)(h))
 
+void co_flush_mine(Ctx &ctx);
+struct NoFlush {};
 struct Scope {  // per-call: select device, lock the context, reset the scratch arena
     Ctx *c;
+    // Deferred submission: launches made directly (batched handles, transfers, key uploads ...) must come after the calling
+    // thread's own pending requests -- wait for those first (BEFORE the context's lock: the dispatcher launches under it).
     explicit Scope(Ctx *ctx) : c(ctx) {
+        if (c->co->depth.load(std::memory_order_relaxed) > 0 && !g_dispatcher_thread) co_flush_mine(*c);
+        c->mu.lock();
+        hipSetDevice(c->dev);
+        c->arena_reset();
+    }
+    // (a launch that touches nothing a pending request can address: the zero fill of a buffer fresh from the pool)
+    Scope(Ctx *ctx, NoFlush) : c(ctx) {
         c->mu.lock();
         hipSetDevice(c->dev);
         c->arena_reset();
@@ -658,6 +713,12 @@ struct Scope {  // per-call: select device, lock the context, reset the scratch 
 constexpr size_t kTabRowsMin = 16;  // rows of the entry table reserved per batch entry (he_ctx_set_coalescing sizes it)
 int co_inflight(Coalescer &c) {  // batches still running or queued on the device (caller holds c.mu)
     while (!c.inflight.empty() && hipEventQuery(c.inflight.front()) == hipSuccess) {
+        if (!c.inflight_begin.empty()) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c.inflight_begin.front(), c.inflight.front()) == hipSuccess) c.dbg[12] += (uint64_t)(ms * 1000.f);
+            c.free_events.push_back(c.inflight_begin.front());
+            c.inflight_begin.pop_front();
+        }
         c.free_events.push_back(c.inflight.front());
         c.inflight.pop_front();
     }
@@ -668,27 +729,30 @@ int co_inflight(Coalescer &c) {  // batches still running or queued on the devic
 // request otherwise.  Fills every request's own status / message; returns the number of requests served one by one.
 int co_run(Ctx &ctx, Coalescer &c, const std::vector<CoReq *> &batch, hipEvent_t done_ev) {
     CoReq &r0 = *batch[0];
-    const int B = (int)batch.size();
+    const int R = (int)batch.size();
+    int B = 0;  // entries: a request over handles of batch nb contributes nb of them
+    for (const CoReq *r : batch) B += r->nb;
     const size_t ns = r0.ops.size();
     Scope sc(&ctx);
-    bool tables = B > 1;
+    if (r0.op >= 0 && r0.op < 32) { c.op_launches[r0.op]++; c.op_calls[r0.op] += (uint64_t)R; }  // (under the context's lock, as its reader)
+    bool tables = R > 1;
     int rc = HE_OK;
     if (tables && r0.tables_ok) rc = r0.tables_ok(&tables);
     if (rc == HE_OK && tables && ns * (size_t)B > c.tab_words) tables = false;  // (gathered under a larger max_batch than the table was sized for)
     // an operand present in one request and absent in another cannot share a table row (the key fixes the count, not the nulls)
-    for (int z = 1; tables && z < B; z++)
+    for (int z = 1; tables && z < R; z++)
         for (size_t s = 0; s < ns; s++) tables = tables && (batch[z]->ops[s].p == nullptr) == (r0.ops[s].p == nullptr);
     int fallback = 0;
     if (rc != HE_OK) {
         const std::string msg = g_err;
         for (CoReq *r : batch) { r->rc = rc; r->err = msg; }
-    } else if (B == 1 || !tables) {
-        // one entry, or a shape whose pipeline has launches without entry tables (unfused ModDown, conjugate-invariant rings,
+    } else if (R == 1 || !tables) {
+        // one request, or a shape whose pipeline has launches without entry tables (unfused ModDown, conjugate-invariant rings,
         // base-2 gadgets): one call per request, each with its own status
-        if (B > 1) fallback = B;
+        if (R > 1) fallback = R;
         for (CoReq *r : batch) {
             ctx.arena_reset();
-            r->rc = r->run(r->ops.data(), 1);
+            r->rc = r->run(r->ops.data(), r->nb);
             if (r->rc != HE_OK) r->err = g_err;
         }
     } else {
@@ -698,7 +762,9 @@ int co_run(Ctx &ctx, Coalescer &c, const std::vector<CoReq *> &batch, hipEvent_t
         for (size_t s = 0; s < ns; s++) {
             uint64_t *base = r0.ops[s].p;
             if (!base) { v[s] = View{nullptr, 0}; continue; }
-            for (int z = 0; z < B; z++) vals[s * B + z] = (size_t)(batch[z]->ops[s].p - base);
+            int e = 0;
+            for (const CoReq *r : batch)
+                for (int i = 0; i < r->nb; i++, e++) vals[s * B + e] = (size_t)(r->ops[s].p + (size_t)i * r->ops[s].bstride - base);
             v[s] = View{base, 0, c.d_tab + s * B};
         }
         hipError_t e = launch_tab_fill(c.d_tab, vals.data(), (int)vals.size(), ctx.stream);
@@ -778,8 +844,9 @@ void co_lead(Ctx &ctx, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mi
         for (const CoReq *r : c.pending)
             if (r->seq < hp->seq && c.pending.front()->seq - r->seq <= 64) hp = r;
         const CoReq &head = *hp;
-        for (auto it = c.pending.begin(); it != c.pending.end() && (int)batch.size() < max_batch;) {
-            if ((*it)->same_key(head)) { batch.push_back(*it); it = c.pending.erase(it); }
+        int entries = 0;
+        for (auto it = c.pending.begin(); it != c.pending.end();) {
+            if ((*it)->same_key(head) && (batch.empty() || entries + (*it)->nb <= max_batch)) { entries += (*it)->nb; batch.push_back(*it); it = c.pending.erase(it); }
             else ++it;
         }
         if (batch.size() > 1 || !c.pending.empty()) c.crowd = 256;
@@ -816,6 +883,260 @@ void co_lead(Ctx &ctx, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mi
 }
 // files the requests of ONE call (most calls: one; the polynomials of a ciphertext in he_rescale_ct: several, which then share
 // a batch) and returns when all of them have been enqueued on the stream
+uint64_t co_me() {
+    static std::atomic<uint64_t> next_caller{1};
+    thread_local uint64_t me = next_caller.fetch_add(1, std::memory_order_relaxed);
+    return me;
+}
+thread_local uint64_t g_my_calls = 0;  // queued calls this thread has made: its position in the circuit (see co_lead)
+void co_note_caller(Coalescer &c, uint64_t me, std::chrono::steady_clock::time_point now) {
+    for (auto &sv : c.seen) if (sv.first == me) { sv.second = now; return; }
+    c.seen.emplace_back(me, now);
+}
+void co_sleep(Coalescer &c, uint32_t g) {  // until the generation word moves on from g
+    c.sleepers.fetch_add(1, std::memory_order_seq_cst);
+    if (c.gen.load(std::memory_order_seq_cst) == g)
+        syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.gen), FUTEX_WAIT_PRIVATE, g, nullptr, nullptr, 0);
+    c.sleepers.fetch_sub(1, std::memory_order_acq_rel);
+}
+
+// ---- deferred submission -------------------------------------------------------------------------------------------------------
+// The blocking queue above costs every call two thread hand-overs (caller -> leader -> caller) that the device waits out: with 16
+// callers replaying a bootstrapping circuit a queue round took ~400 us of host time for ~260 us of kernels.  Deferred: the call
+// files a heap copy of its request and returns HE_OK; the context's dispatcher thread gathers the FIRST pending call of every
+// thread (a thread's calls launch in the order it made them), batches the ones that share a key and launches.  Callers run ahead
+// of the device by at most `depth` requests.  What a deferred call can no longer report -- a launch that fails after the
+// arguments were accepted -- is kept and returned by the next he_ctx_sync.  Everything that launches directly (batched handles,
+// transfers, graph capture) first waits for the calling thread's pending requests (Scope); he_ctx_sync waits for every request
+// filed before it.  Data handed from one thread to another needs a he_ctx_sync in between (in the blocking mode a returned call
+// was already in stream order).
+CoReq *co_heap_copy(CoReq &q) {
+    CoReq *h = new CoReq();
+    h->op = q.op; h->obj = q.obj; h->key = q.key; h->nb = q.nb;
+    memcpy(h->par, q.par, sizeof h->par);
+    h->blob = std::move(q.blob); h->ops = std::move(q.ops); h->keep = std::move(q.keep);
+    h->run = std::move(q.run); h->tables_ok = std::move(q.tables_ok);
+    return h;
+}
+int co_defer(Ctx &ctx, const std::vector<CoReq *> &rs) {
+    Coalescer &c = *ctx.co;
+    const uint64_t me = co_me();
+    std::vector<CoReq *> heap;
+    heap.reserve(rs.size());
+    for (CoReq *q : rs) heap.push_back(co_heap_copy(*q));
+    auto give_back = [&]() {  // the blocking path takes the originals back
+        for (size_t i = 0; i < rs.size(); i++) {
+            CoReq *h = heap[i];
+            rs[i]->blob = std::move(h->blob); rs[i]->ops = std::move(h->ops); rs[i]->keep = std::move(h->keep);
+            rs[i]->run = std::move(h->run); rs[i]->tables_ok = std::move(h->tables_ok);
+            delete h;
+        }
+        return -1;
+    };
+    std::unique_lock<std::mutex> lk(c.mu);
+    Coalescer::Caller &st = c.caller_of(me);
+    int depth = c.depth.load(std::memory_order_relaxed);
+    if (depth > 0 && st.pending.load(std::memory_order_relaxed) >= depth) {
+        // a full pipeline: sleep until HALF of it has been launched (one wake-up per depth / 2 calls, not one per call), without
+        // the queue's lock -- the dispatcher wakes the sleepers whose count reached the mark
+        lk.unlock();
+        st.wait_low.store(true, std::memory_order_seq_cst);
+        for (;;) {
+            const uint32_t g = c.gen.load(std::memory_order_seq_cst);
+            depth = c.depth.load(std::memory_order_relaxed);
+            if (depth <= 0 || st.pending.load(std::memory_order_seq_cst) <= depth / 2) break;
+            co_sleep(c, g);
+        }
+        st.wait_low.store(false, std::memory_order_seq_cst);
+        lk.lock();
+    }
+    if (c.depth.load(std::memory_order_relaxed) <= 0 || c.stop) { lk.unlock(); return give_back(); }  // switched off meanwhile
+    const auto now = std::chrono::steady_clock::now();
+    for (CoReq *h : heap) {
+        h->arrived = now; h->caller = me; h->seq = g_my_calls; h->ticket = c.next_ticket++;
+        st.q.push_back(h);
+    }
+    g_my_calls++;
+    st.pending.fetch_add((int)heap.size(), std::memory_order_seq_cst);
+    c.n_deferred += (int)heap.size();
+    co_note_caller(c, me, now);
+    lk.unlock();
+    c.cv_leader.notify_one();
+    return HE_OK;
+}
+// wait until the calling thread has nothing pending
+void co_flush_mine(Ctx &ctx) {
+    Coalescer &c = *ctx.co;
+    const uint64_t me = co_me();
+    Coalescer::Caller *st;
+    { std::lock_guard<std::mutex> lk(c.mu); st = &c.caller_of(me); }
+    if (st->pending.load(std::memory_order_seq_cst) <= 0) return;
+    c.flushers.fetch_add(1, std::memory_order_seq_cst);
+    c.cv_leader.notify_one();
+    for (;;) {
+        const uint32_t g = c.gen.load(std::memory_order_seq_cst);
+        if (st->pending.load(std::memory_order_seq_cst) <= 0) break;
+        co_sleep(c, g);
+    }
+    c.flushers.fetch_sub(1, std::memory_order_seq_cst);
+}
+// wait until every request filed before this call has been launched; returns (and clears) the first deferred failure
+int co_flush_filed(Ctx &ctx) {
+    Coalescer &c = *ctx.co;
+    std::unique_lock<std::mutex> lk(c.mu);
+    const uint64_t upto = c.next_ticket;  // tickets below this were filed
+    auto behind = [&]() -> bool {
+        if (c.launching_min < upto) return true;
+        for (auto &m : c.callers) if (!m->q.empty() && m->q.front()->ticket < upto) return true;
+        return false;
+    };
+    if (behind()) {
+        c.flushers.fetch_add(1, std::memory_order_seq_cst);
+        while (behind()) {
+            const uint32_t g = c.gen.load(std::memory_order_seq_cst);
+            lk.unlock();
+            c.cv_leader.notify_one();
+            co_sleep(c, g);
+            lk.lock();
+        }
+        c.flushers.fetch_sub(1, std::memory_order_seq_cst);
+    }
+    if (c.def_rc != HE_OK) {
+        const int rc = c.def_rc;
+        const std::string msg = c.def_err;
+        c.def_rc = HE_OK; c.def_err.clear();
+        lk.unlock();
+        return fail(rc, "%s (reported by a deferred call)", msg.c_str());
+    }
+    return HE_OK;
+}
+// the dispatcher thread of a context in deferred mode
+void co_dispatcher_main(Ctx *ctx) {
+    using clock = std::chrono::steady_clock;
+    Coalescer &c = *ctx->co;
+    g_dispatcher_thread = true;
+    hipSetDevice(ctx->dev);
+    static const bool timing = env_flag("HERING_QUEUE_TIMING");  // diagnosis: how long the device spent inside the batches
+    static const int ahead_cap = std::max(2, getenv("HERING_QUEUE_AHEAD") ? atoi(getenv("HERING_QUEUE_AHEAD")) : 16);
+    std::unique_lock<std::mutex> lk(c.mu);
+    std::vector<CoReq *> heads, batch;
+    std::vector<Coalescer::Caller *> owners;
+    for (;;) {
+        c.cv_leader.wait(lk, [&] { return c.stop || c.n_deferred > 0; });
+        if (c.n_deferred <= 0) break;  // (stop, and nothing left to launch)
+        const int max_batch = std::max(1, c.max_batch.load(std::memory_order_relaxed));
+        const auto g0 = clock::now();
+        const CoReq *hp = nullptr;
+        for (;;) {
+            // the candidates: every thread's first pending call (all requests of it); `oldest`: the one filed first
+            heads.clear();
+            int here = 0;
+            const CoReq *oldest = nullptr;
+            for (auto &m : c.callers) {
+                if (m->q.empty()) continue;
+                here++;
+                const uint64_t seq = m->q.front()->seq;
+                for (CoReq *r : m->q) { if (r->seq != seq) break; heads.push_back(r); }
+                if (!oldest || m->q.front()->ticket < oldest->ticket) oldest = m->q.front();
+            }
+            // which operation: the oldest call's -- unless a thread of the same cohort is behind it (see co_lead)
+            hp = oldest;
+            for (const CoReq *r : heads)
+                if (r->seq < hp->seq && oldest->seq - r->seq <= 64) hp = r;
+            int same = 0;  // (in batch entries)
+            for (const CoReq *r : heads) same += r->same_key(*hp) ? r->nb : 0;
+            const auto now = clock::now();
+            int active = 0;
+            const long long win = c.window_us;
+            for (auto it = c.seen.begin(); it != c.seen.end();) {
+                if (std::chrono::duration_cast<std::chrono::microseconds>(now - it->second).count() > 3000 + 8 * win) it = c.seen.erase(it);
+                else { ++active; ++it; }
+            }
+            const int ahead = co_inflight(c);
+            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - oldest->arrived).count();
+            if (c.stop) break;
+            auto spent = [&](int slot) { c.dbg[slot] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - now).count(); };
+            if (ahead >= ahead_cap) { c.cv_leader.wait_for(lk, std::chrono::microseconds(100)); spent(8); continue; }  // far enough ahead of the device
+            if (same >= max_batch) { c.dbg[2]++; break; }
+            if (here >= active) { c.dbg[0]++; c.dbg[5] += (uint64_t)here; c.dbg[6] += (uint64_t)active; break; }
+            if (ahead < 2 && waited >= 8 * win) { c.dbg[1]++; c.dbg[5] += (uint64_t)here; c.dbg[6] += (uint64_t)active; break; }
+            if (ahead >= 2) { c.cv_leader.wait_for(lk, std::chrono::microseconds(100)); spent(9); }  // the device is busy: waiting is free; arrivals notify
+            else { lk.unlock(); sched_yield(); lk.lock(); spent(10); }
+        }
+        batch.clear(); owners.clear();
+        int entries = 0;
+        for (CoReq *r : heads)
+            if (r->same_key(*hp) && (batch.empty() || entries + r->nb <= max_batch)) { entries += r->nb; batch.push_back(r); }
+        uint64_t lo = UINT64_MAX;
+        for (CoReq *r : batch) {
+            lo = std::min(lo, r->ticket);
+            Coalescer::Caller &m = c.caller_of(r->caller);
+            m.q.erase(std::find(m.q.begin(), m.q.end(), r));  // (one of the first few: the requests of the thread's first call)
+            owners.push_back(&m);
+        }
+        c.n_deferred -= (int)batch.size();
+        c.launching_min = lo;
+        auto take_event = [&]() -> hipEvent_t {
+            hipEvent_t ev = nullptr;
+            if (!c.free_events.empty()) { ev = c.free_events.back(); c.free_events.pop_back(); }
+            else if (hipEventCreateWithFlags(&ev, timing ? hipEventDefault : hipEventDisableTiming) != hipSuccess) ev = nullptr;
+            return ev;
+        };
+        hipEvent_t e = take_event(), e_begin = timing ? take_event() : nullptr;
+        if (e_begin && hipEventRecord(e_begin, ctx->stream) != hipSuccess) (void)hipGetLastError();
+        c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
+        c.dbg[11]++;
+        const auto g1 = clock::now();
+        c.dbg[3] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(g1 - g0).count();
+        lk.unlock();
+        const int fallback = co_run(*ctx, c, batch, e);
+        const uint64_t run_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - g1).count();
+        lk.lock();
+        c.dbg[4] += run_us;
+        c.n_fallback += (uint64_t)fallback;
+        if (e) { c.inflight.push_back(e); if (e_begin) c.inflight_begin.push_back(e_begin); }
+        for (CoReq *r : batch)
+            if (r->rc != HE_OK && c.def_rc == HE_OK) { c.def_rc = r->rc; c.def_err = r->err; }
+        c.launching_min = UINT64_MAX;
+        // who has to hear about it: a thread asleep on a full pipeline whose count reached the low mark, anybody flushing.
+        // (sleepers raise their flag BEFORE they read their count, this lowers the count BEFORE it reads the flag: one of the two
+        // sees the other)
+        const int low = c.depth.load(std::memory_order_relaxed) / 2;
+        bool wake = false;
+        for (Coalescer::Caller *m : owners) {
+            const int left = m->pending.fetch_sub(1, std::memory_order_seq_cst) - 1;
+            wake = wake || (left <= low && m->wait_low.load(std::memory_order_seq_cst));
+        }
+        wake = wake || c.flushers.load(std::memory_order_seq_cst) > 0;
+        if (wake) c.gen.fetch_add(1, std::memory_order_seq_cst);
+        lk.unlock();
+        if (wake) syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+        for (CoReq *r : batch) delete r;  // (drops the operands' references: a released polynomial goes back to the buffer cache now)
+        lk.lock();
+    }
+}
+// stop the dispatcher (everything pending is launched first); the queue is in blocking mode afterwards
+void co_stop_dispatcher(Ctx &ctx) {
+    Coalescer &c = *ctx.co;
+    std::thread t;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (!c.dispatcher.joinable()) { c.depth = 0; return; }
+        c.depth = 0;
+        c.stop = true;
+        t = std::move(c.dispatcher);
+    }
+    c.cv_leader.notify_all();
+    if (t.get_id() == std::this_thread::get_id()) t.detach();  // (cannot happen: the dispatcher never calls this)
+    else t.join();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.stop = false;
+    }
+    c.gen.fetch_add(1, std::memory_order_release);
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+
 int co_submit_many(Ctx &ctx, const std::vector<CoReq *> &rs) {
     Coalescer &c = *ctx.co;
     CoReq &r = *rs[0];
@@ -829,18 +1150,27 @@ int co_submit_many(Ctx &ctx, const std::vector<CoReq *> &rs) {
         return l;
     };
     {
-        std::unique_lock<std::mutex> lk(c.mu);
-        const auto now = std::chrono::steady_clock::now();
-        static std::atomic<uint64_t> next_caller{1};
-        thread_local uint64_t me = next_caller.fetch_add(1, std::memory_order_relaxed);
-        thread_local uint64_t my_calls = 0;
-        for (CoReq *q : rs) { q->arrived = now; q->caller = me; q->seq = my_calls; c.pending.push_back(q); }
-        my_calls++;
-        {
-            bool found = false;
-            for (auto &sv : c.seen) if (sv.first == me) { sv.second = now; found = true; break; }
-            if (!found) c.seen.emplace_back(me, now);
+        std::unique_lock<std::mutex> lk(c.mu, std::defer_lock);
+        for (;;) {
+            if (c.depth.load(std::memory_order_relaxed) > 0) {
+                const int rc = co_defer(ctx, rs);
+                if (rc >= 0) return rc;  // (-1: deferred mode was switched off while this call waited: it goes the blocking way)
+            }
+            lk.lock();
+            while (c.stop) {  // a dispatcher that is being stopped still launches what it holds: stay out of its way
+                const uint32_t g = c.gen.load(std::memory_order_acquire);
+                lk.unlock();
+                co_sleep(c, g);
+                lk.lock();
+            }
+            if (c.depth.load(std::memory_order_relaxed) <= 0) break;
+            lk.unlock();  // (deferred mode was switched on meanwhile)
         }
+        const auto now = std::chrono::steady_clock::now();
+        const uint64_t me = co_me();
+        for (CoReq *q : rs) { q->arrived = now; q->caller = me; q->seq = g_my_calls; c.pending.push_back(q); }
+        g_my_calls++;
+        co_note_caller(c, me, now);
         bool lead = false;
         if (!c.leader) { c.leader = true; lead = true; }
         else c.cv_leader.notify_one();  // a gathering leader counts arrivals
@@ -874,7 +1204,10 @@ int co_submit(Ctx &ctx, CoReq &r) { return co_submit_many(ctx, std::vector<CoReq
 // that is not recording a graph: a captured sequence must be this thread's own launches) joins the queue; everything else runs
 // its launches at once under the context's lock.
 int co_dispatch(Ctx &ctx, int B, CoReq &r) {
-    if (B == 1 && ctx.co->max_batch.load(std::memory_order_relaxed) > 1 && !ctx.capturing) {
+    // (handles of a few entries join the queue like single ciphertexts: the drivers stack independent ciphertexts -- the real and
+    // imaginary halves of a bootstrap's EvalMod -- into one handle; a request of nb entries takes nb rows of the entry table)
+    if (B >= 1 && B < ctx.co->max_batch.load(std::memory_order_relaxed) && !ctx.capturing) {
+        r.nb = B;
         r.set_alias_pattern();
         return co_submit(ctx, r);
     }
@@ -977,7 +1310,13 @@ int he_ctx_create(int device_id, he_handle *out) {
     *out = reg(c);
     return HE_OK;
 }
-int he_ctx_destroy(he_handle h) { return unreg(h, T_CTX); }
+int he_ctx_destroy(he_handle h) {
+    {
+        GET(c, Ctx, h, T_CTX);
+        co_stop_dispatcher(*c);  // (deferred submission: everything pending is launched; objects that outlive the handle call directly)
+    }
+    return unreg(h, T_CTX);
+}
 int he_device_count(int *n) {
     if (!n) return fail(HE_EINVAL, "he_device_count: null output");
     *n = 0;
@@ -988,6 +1327,9 @@ int he_device_count(int *n) {
 int he_ctx_sync(he_handle h) {
     GET(c, Ctx, h, T_CTX);
     if (c->capturing) return fail(HE_EINVAL, "he_ctx_sync: the context is capturing a graph (he_graph_end first)");
+    // deferred submission: everything filed before this call is launched first; a launch that failed after its call had returned
+    // is reported here
+    if (c->co->depth.load(std::memory_order_relaxed) > 0) TRY(co_flush_filed(*c));
     // Many threads may wait on one context at once (the callers of a coalescing evaluator): ONE of them drains the stream, the
     // others sleep until a drain that STARTED after their call began has finished -- everything a caller enqueued before calling
     // is covered by such a drain -- instead of every thread spinning on the stream.
@@ -1025,12 +1367,14 @@ int he_ctx_sync(he_handle h) {
 }
 int he_timer_start(he_handle h) {
     GET(c, Ctx, h, T_CTX);
+    if (c->co->depth.load(std::memory_order_relaxed) > 0) TRY(co_flush_filed(*c));  // (the timed region covers what was filed)
     HIP_TRY(hipSetDevice(c->dev));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return HE_OK;
 }
 int he_timer_stop(he_handle h, float *ms) {
     GET(c, Ctx, h, T_CTX);
+    if (c->co->depth.load(std::memory_order_relaxed) > 0) TRY(co_flush_filed(*c));  // (the timed region covers what was filed)
     HIP_TRY(hipSetDevice(c->dev));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
@@ -1134,7 +1478,7 @@ static int poly_alloc(he_handle hring, int n_limbs, int batch, bool zero, he_han
         return fail(HE_ENOMEM, "he_poly_alloc: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
     if (zero || poison) {
-        Scope sc(r->ctx.get());
+        Scope sc(r->ctx.get(), NoFlush{});  // (no pending request can address a buffer that was in the cache)
         HIP_TRY(hipMemsetAsync(p->d, zero ? 0 : 0x5a, bytes, r->ctx->stream));
     }
     *out = reg(p);
@@ -1221,12 +1565,28 @@ int he_poly_copy_batch(he_handle hdst, int dst_b0, he_handle hsrc, int src_b0, i
     if (d->N != s->N || level < 0 || d->nlimbs < level + 1 || s->nlimbs < level + 1 || nb <= 0 || dst_b0 < 0 || src_b0 < 0 ||
         dst_b0 + nb > d->batch || src_b0 + nb > s->batch || d->ctx != s->ctx)
         return fail(HE_EINVAL, "he_poly_copy_batch: shape mismatch");
-    Scope sc(d->ctx.get());
-    d->ctx->acct(2.0 * (level + 1), 0, nb, d->N);
-    const size_t dpitch = (size_t)d->nlimbs * d->N * 8, spitch = (size_t)s->nlimbs * s->N * 8;
-    HIP_TRY(hipMemcpy2DAsync((char *)d->d + dst_b0 * dpitch, dpitch, (const char *)s->d + src_b0 * spitch, spitch,
-                             (size_t)(level + 1) * d->N * 8, nb, hipMemcpyDeviceToDevice, d->ctx->stream));
-    return HE_OK;
+    // (a copy between entry ranges of two handles: the request of he_poly_copy over shifted views)
+    const std::shared_ptr<Ctx> ctx = d->ctx;
+    const int N = d->N;
+    CoReq q;
+    q.op = CO_COPY; q.obj = ctx.get(); q.par[0] = level; q.par[1] = N;
+    View vs = s->view(), vd = d->view();
+    vs.p += (size_t)src_b0 * vs.bstride; vd.p += (size_t)dst_b0 * vd.bstride;
+    q.ops = {vs, vd};
+    q.keep = {s, d};
+    q.run = [ctx, level, N](const View *v, int B) -> int {
+        ctx->acct(2.0 * (level + 1), 0, B, N);
+        if (!v[0].tab && !v[1].tab) {
+            HIP_TRY(hipMemcpy2DAsync(v[1].p, v[1].bstride * 8, v[0].p, v[0].bstride * 8, (size_t)(level + 1) * N * 8, B, hipMemcpyDeviceToDevice,
+                                     ctx->stream));
+            return HE_OK;
+        }
+        RingDev dev{};
+        dev.N = N;
+        HIP_TRY(launch_ew(dev, ident_tab(level + 1), EW_COPY, v[0], v[0], v[1], B, nullptr, nullptr, ctx->stream));
+        return HE_OK;
+    };
+    return co_dispatch(*ctx, nb, q);
 }
 int he_poly_device_buffer(he_handle h, void **ptr, size_t *bytes) {
     GET(p, Poly, h, T_POLY);
@@ -1712,11 +2072,13 @@ int he_rescale_polys(he_handle hring, int level, int nb, int n, const he_handle 
     if (n < 0 || n > 16 || (n > 0 && (!p0 || !p1))) return fail(HE_EINVAL, "he_rescale_polys: n in [0, 16] and both handle arrays");
     std::deque<CoReq> qs((size_t)n);
     std::vector<CoReq *> ptrs;
-    bool queue = r->ctx->co->max_batch.load(std::memory_order_relaxed) > 1 && !r->ctx->capturing;
+    const int max_batch = r->ctx->co->max_batch.load(std::memory_order_relaxed);
+    bool queue = max_batch > 1 && !r->ctx->capturing;
     for (int i = 0; i < n; i++) {
         int B = 0;
         TRY(div_fill(qs[i], r, level, nb, p0[i], p1[i], true, true, "he_rescale_polys", false, &B));
-        queue = queue && B == 1;
+        queue = queue && B >= 1 && B < max_batch;
+        qs[i].nb = B;
         ptrs.push_back(&qs[i]);
     }
     if (n == 0) return HE_OK;
@@ -2083,10 +2445,12 @@ int he_evaluator_destroy(he_handle h) { return unreg(h, T_EVAL); }
 static int ctx_set_coalescing(const std::shared_ptr<Ctx> &c, int max_batch, int window_us, const char *who) {
     if (max_batch < 0 || max_batch > 1024 || window_us < 0 || window_us > 100000)
         return fail(HE_EINVAL, "%s: max_batch in [0, 1024], window_us in [0, 100000]", who);
+    if (max_batch <= 1) co_stop_dispatcher(*c);  // (deferred submission ends with the queue: what is pending is launched first)
+    else if (c->co->depth.load(std::memory_order_relaxed) > 0) TRY(co_flush_filed(*c));
     Scope sc(c.get());  // (a leader launches its batch under this lock: none is between gathering and launching while we hold it)
     Coalescer &co = *c->co;
     std::lock_guard<std::mutex> lk(co.mu);
-    if (!co.pending.empty() || co.leader) return fail(HE_EINVAL, "%s: calls are in flight on this context", who);
+    if (!co.pending.empty() || co.leader || co.n_deferred > 0) return fail(HE_EINVAL, "%s: calls are in flight on this context", who);
     if (max_batch <= 1) {  // off: later calls launch directly
         co.max_batch = 0;
         return HE_OK;
@@ -2123,11 +2487,34 @@ int he_ctx_set_coalescing(he_handle h, int max_batch, int window_us) {
     GET(c, Ctx, h, T_CTX);
     return ctx_set_coalescing(c, max_batch, window_us, "he_ctx_set_coalescing");
 }
-int he_debug_queue_counters(he_handle h, uint64_t out[8]) {
+int he_ctx_set_deferred(he_handle h, int depth) {
+    GET(c, Ctx, h, T_CTX);
+    if (depth < 0 || depth > 256) return fail(HE_EINVAL, "he_ctx_set_deferred: depth in [0, 256]");
+    if (depth == 0) { co_stop_dispatcher(*c); return HE_OK; }
+    Coalescer &co = *c->co;
+    std::lock_guard<std::mutex> lk(co.mu);
+    if (co.max_batch.load(std::memory_order_relaxed) <= 1)
+        return fail(HE_EINVAL, "he_ctx_set_deferred: the submission queue is off (he_ctx_set_coalescing first)");
+    if (co.stop) return fail(HE_EINVAL, "he_ctx_set_deferred: the dispatcher is being stopped");
+    if (!co.dispatcher.joinable()) {
+        if (!co.pending.empty() || co.leader) return fail(HE_EINVAL, "he_ctx_set_deferred: calls are in flight on this context");
+        co.dispatcher = std::thread(co_dispatcher_main, c.get());
+    }
+    co.depth = depth;
+    return HE_OK;
+}
+int he_debug_queue_op_stats(he_handle h, uint64_t out[64]) {
+    GET(c, Ctx, h, T_CTX);
+    if (!out) return fail(HE_EINVAL, "he_debug_queue_op_stats: null output");
+    Scope sc(c.get());
+    for (int i = 0; i < 32; i++) { out[2 * i] = c->co->op_launches[i]; out[2 * i + 1] = c->co->op_calls[i]; }
+    return HE_OK;
+}
+int he_debug_queue_counters(he_handle h, uint64_t out[16]) {
     GET(c, Ctx, h, T_CTX);
     if (!out) return fail(HE_EINVAL, "he_debug_queue_counters: null output");
     std::lock_guard<std::mutex> lk(c->co->mu);
-    for (int i = 0; i < 8; i++) out[i] = c->co->dbg[i];
+    for (int i = 0; i < 16; i++) out[i] = c->co->dbg[i];
     out[7] = c->pool_misses.load(std::memory_order_relaxed);
     return HE_OK;
 }
@@ -2585,7 +2972,9 @@ int he_decomp_create(he_handle hev, int batch, he_handle *out) {
     d->batch = batch;
     d->beta_max = base_rns_size(be.LQ - 1, be.LP - 1);  // digits at (max levelQ, max levelP)
     d->width = be.LQ + be.LP;
-    Scope sc(be.ctx.get());
+    // (no stream work here: the buffer cache has its own lock -- a caller that creates a hoisting buffer neither waits for the
+    // context nor, in deferred mode, for its own pending requests)
+    HIP_TRY(hipSetDevice(be.ctx->dev));
     const size_t bytes = (size_t)batch * d->bstride() * 8;
     hipError_t e = be.ctx->pool_take(bytes, (void **)&d->d);
     if (e != hipSuccess) {

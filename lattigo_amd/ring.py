@@ -123,6 +123,12 @@ class Context:
         callers' own polynomials.  max_batch <= 1 switches it off."""
         check(load().he_ctx_set_coalescing(self.h, max_batch, window_us))
 
+    def SetDeferred(self, depth: int = 8):
+        """he_ctx_set_deferred (include/hering.h): queued calls return as soon as they are filed; the context's dispatcher thread
+        launches them (a thread's calls in order, up to `depth` pending per thread).  Failures of a deferred launch surface at the
+        next Sync().  depth = 0 switches back to calls that return once launched."""
+        check(load().he_ctx_set_deferred(self.h, depth))
+
     def CoalescingStats(self) -> dict:
         out = (C.c_uint64 * 4)()
         check(load().he_ctx_coalescing_stats(self.h, out))

@@ -3,7 +3,7 @@
 // through the public interface only (include/hering.hpp): K OS threads, one ciphertext per call, one shared evaluator whose
 // context's submission queue turns the concurrent calls into batched launches.  Prints one JSON line; bench.py embeds it.
 //
-//   run_parallel [K=64] [calls per thread=96] [sync_each=0|1] [coalesce=1|0] [workload=c3|c2] [max_batch=64] [window_us=30]
+//   run_parallel [K=64] [calls per thread=96] [sync_each=0|1] [coalesce=1|0] [workload=c3|c2] [max_batch=64] [window_us=30] [deferred depth=0]
 //
 // workload c3: BGV MulRelin, logN = 15, 12 + 3 limbs (BASELINE config 3).
 // workload c2: CKKS Mul (degree 2, no relinearisation) + Rescale of the three polynomials, logN = 14, 8 + 1 limbs (BASELINE
@@ -42,6 +42,7 @@ int main(int argc, char **argv) {
     const bool sync_each = argc > 3 && std::atoi(argv[3]) != 0, coalesce = !(argc > 4 && std::atoi(argv[4]) == 0);
     const std::string workload = argc > 5 ? argv[5] : "c3";
     const int max_batch = argc > 6 ? std::atoi(argv[6]) : 64, window_us = argc > 7 ? std::atoi(argv[7]) : 30;
+    const int deferred = argc > 8 ? std::atoi(argv[8]) : 0;  // he_ctx_set_deferred: calls return once filed
     const bool c2 = workload == "c2";
     if (!c2 && workload != "c3") { std::fprintf(stderr, "run_parallel: workload c3 or c2\n"); return 2; }
     const int logN = c2 ? 14 : 15, N = 1 << logN;
@@ -59,7 +60,7 @@ int main(int argc, char **argv) {
         const int beta = lo_base_rns_decomposition_vector_size(level, np - 1);
         const u64v kq = uniform(rng, q, N, beta * 2), kp = uniform(rng, p, N, beta * 2);
         hering::EvaluationKey rlk = eval.NewEvaluationKey(beta, nq, np, kq, kp);
-        if (coalesce) ctx.SetCoalescing(max_batch, window_us); else ctx.SetCoalescing(0, 0);
+        if (coalesce) { ctx.SetCoalescing(max_batch, window_us); ctx.SetDeferred(deferred); } else ctx.SetCoalescing(0, 0);
         const size_t words = (size_t)nq * N;
         struct Caller { hering::Ciphertext a, b, out, res; };
         std::vector<Caller> callers(K);
@@ -137,8 +138,8 @@ int main(int argc, char **argv) {
         }
         std::printf("{\"host\": \"C++ (include/hering.hpp), std::thread per caller, public interface only\", \"workload\": \"%s\", \"K\": %d, "
                     "\"calls_per_caller\": %d, \"interface_calls_per_op\": %d, \"sync_each\": %s, \"coalescing\": %s, \"max_batch\": %d, "
-                    "\"window_us\": %d, \"mean_batch\": %.1f, \"ops_per_s\": %.1f, \"verified\": %s, \"verified_callers\": \"%d/%d\"}\n",
-                    workload.c_str(), K, iters, c2 ? 2 : 1, sync_each ? "true" : "false", coalesce ? "true" : "false", max_batch, window_us,
+                    "\"window_us\": %d, \"deferred_depth\": %d, \"mean_batch\": %.1f, \"ops_per_s\": %.1f, \"verified\": %s, \"verified_callers\": \"%d/%d\"}\n",
+                    workload.c_str(), K, iters, c2 ? 2 : 1, sync_each ? "true" : "false", coalesce ? "true" : "false", max_batch, window_us, coalesce ? deferred : 0,
                     mean_batch, (double)K * iters / dt, bad == 0 ? "true" : "false", K - bad, K);
         return bad == 0 ? 0 : 1;
     } catch (const std::exception &e) {

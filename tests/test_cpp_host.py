@@ -68,9 +68,11 @@ def test_compiled_host_concurrent_callers(workload):
     per operation, all of them through the context's submission queue.  EVERY caller's last result equals the oracle's."""
     import json
     _build()
-    for sync_each in ("0", "1"):
-        r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "run_parallel"), "8", "6", sync_each, "1", workload], capture_output=True,
-                           text=True, timeout=300)
+    # (sync_each, deferred depth): deferred = he_ctx_set_deferred, the calls return once filed
+    for sync_each, deferred in (("0", "0"), ("1", "0"), ("0", "4"), ("1", "4")):
+        r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "run_parallel"), "8", "6", sync_each, "1", workload, "64", "30", deferred],
+                           capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert d["verified"] is True and d["K"] == 8 and d["ops_per_s"] > 0 and d["verified_callers"] == "8/8" and d["workload"] == workload
+        assert d["deferred_depth"] == int(deferred)

@@ -154,14 +154,15 @@ def test_shapes_without_entry_tables_run_one_by_one(ctx):
     assert st["calls"] == K and st["one_by_one"] >= 2 * (st["launches"] < K), st
 
 
-@pytest.mark.parametrize("sync_each", [False, True])
-def test_library_side_thread_harness(ctx, sync_each):
+@pytest.mark.parametrize("sync_each,deferred", [(False, 0), (True, 0), (False, 4), (True, 4)])
+def test_library_side_thread_harness(ctx, sync_each, deferred):
     """he_debug_concurrent_mul_relin (bench.py's `concurrent_b1`): pthreads inside the library, every caller on its own handles;
     callers that wait for each result (sync_each) and callers that only enqueue."""
     logN, nq, np_ = 13, 5, 2
     pr, q, p, N, rng, gev, oev, gk, ok = _setup(ctx, logN, nq, np_)
     K, M = 24, 5
     gev.SetCoalescing(64, 50)
+    ctx.SetDeferred(deferred)
     st0 = _stats(gev)
     ins = [[np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(2)] for _ in range(K)]
     dev = [[[la.Poly(pr.gQ, nq).upload(c) for c in op] for op in ins[k]] for k in range(K)]
@@ -221,8 +222,11 @@ def test_key_switches_coalesce_too(ctx, logN):
 
 
 
-def test_mixed_dependent_chains_from_many_threads(ctx):
-    """Every caller runs a CHAIN of dependent operations on its own ciphertext -- MulRelin (plain, squaring in place), two
+@pytest.mark.parametrize("deferred", [0, 3])
+def test_mixed_dependent_chains_from_many_threads(ctx, deferred):
+    """deferred > 0: he_ctx_set_deferred -- the calls return once filed and the context's dispatcher thread launches them; each
+    thread's chain must still run in its own order.
+    Every caller runs a CHAIN of dependent operations on its own ciphertext -- MulRelin (plain, squaring in place), two
     rotations (one in place: the flagged one-by-one path), GadgetProduct, and ring calls (Add) in between (queued as well since
     round 5) -- while eleven others do the same with the steps in another order.  What a step reads was written by a
     batch launched by ANOTHER thread (the leader of that moment) or by a direct launch of this one: stream order must hold across
@@ -269,6 +273,7 @@ def test_mixed_dependent_chains_from_many_threads(ctx):
     for k in range(K):
         ref.append(np.stack([c.get() for c in run_chain(k, *fresh(k))]))
     gev.SetCoalescing(16, 500)
+    ctx.SetDeferred(deferred)
     st0 = _stats(gev)
     state, res = [fresh(k) for k in range(K)], [None] * K
 
@@ -403,9 +408,11 @@ def _program(pr, ctx, gev, be, keys, nq, np_, seed, N):
     return res, keep
 
 
-@pytest.mark.parametrize("logN", [13, 16])
-def test_every_operator_entry_point_coalesces(ctx, logN):
-    """Round 5: the queue belongs to the context and serves every entry point of the one-ciphertext interface.  K threads run the
+@pytest.mark.parametrize("logN,deferred", [(13, 0), (16, 0), (13, 8), (16, 2)])
+def test_every_operator_entry_point_coalesces(ctx, logN, deferred):
+    """deferred > 0: the same through deferred submission (he_ctx_set_deferred: calls return once filed, temporaries are freed
+    while their requests are still pending, uploads of the same thread wait for its pending requests).
+    Round 5: the queue belongs to the context and serves every entry point of the one-ciphertext interface.  K threads run the
     same program -- ring methods, all rescale variants, ModUp / ModDown, the seven rlwe.EvaluatorProvider methods, Mul with and
     without a key, Rescale, the lintrans inner loop, the bootstrapping helpers -- each on its own polynomials and hoisting
     buffers; every result must equal, word for word, the same program run alone with the queue off (whose words the rest of the
@@ -428,6 +435,7 @@ def test_every_operator_entry_point_coalesces(ctx, logN):
         ref.append([r.get() for r in res])
         del res, keep
     ctx.SetCoalescing(64, 3000)
+    ctx.SetDeferred(deferred)
     before = ctx.CoalescingStats()
     got = [None] * K
 
@@ -452,3 +460,73 @@ def test_every_operator_entry_point_coalesces(ctx, logN):
     r0 = rng_for(7000)
     a, b, c = (uniform_poly(r0, q, N) for _ in range(3))
     assert np.array_equal(ref[0][14], pr.oQ.DivRoundByLastModulusNTT(a))
+
+
+@pytest.mark.parametrize("deferred", [0, 4])
+def test_handles_of_a_few_entries_join_the_queue(ctx, deferred):
+    """The drivers stack independent ciphertexts into one handle (the real and imaginary halves of a bootstrap's EvalMod run as a
+    batch-2 ciphertext): requests over handles of 1, 2 or 3 entries share batches -- a request of nb entries takes nb rows of the
+    entry table -- and CopyBatch (stack / unstack) rides in the queue like CopyLvl.  Word for word the same program with the
+    queue off."""
+    logN, nq, np_ = 13, 5, 2
+    pr, q, p, N, rng, gev, oev, rlk, orlk = _setup(ctx, logN, nq, np_)
+    beta, lv = (nq + np_ - 1) // np_, nq - 1
+    gal = pow(5, 5, 2 * N)
+    kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(beta)])
+    gk = gev.NewEvaluationKey(kq, kp)
+    K = 9
+    nbs = [1 + k % 3 for k in range(K)]
+    ins = [[np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(nbs[k])]) for _ in range(2)]) for _ in range(2)] for k in range(K)]
+
+    def program(k):
+        nb = nbs[k]
+        a, b = ([la.Poly(pr.gQ, nq, nb).upload(c) for c in ins[k][i]] for i in range(2))
+        new = lambda nl=nq, n=nb: la.Poly(pr.gQ, nl, n)  # noqa: E731
+        m = [new(), new()]
+        gev.CKKSMulRelin(lv, a, b, rlk, m)                       # key switch over nb entries
+        pr.gQ.Add(m[0], b[0], m[0]); pr.gQ.Add(m[1], b[1], m[1])  # ring calls
+        r = [new(), new()]
+        gev.Automorphism(lv, m, gal, gk, r)
+        s = [new(nq - 1), new(nq - 1)]
+        gev.Rescale(lv, 1, r, s)                                 # he_rescale_polys: two requests of nb entries in one call
+        # stack two copies of the result into one handle of 2 nb entries, square it, unstack the second half
+        st2 = [new(nq - 1, 2 * nb), new(nq - 1, 2 * nb)]
+        for o, v in zip(st2, s):
+            o.CopyBatch(lv - 1, 0, v, 0, nb); o.CopyBatch(lv - 1, nb, v, 0, nb)
+        sq = [new(nq - 1, 2 * nb), new(nq - 1, 2 * nb)]
+        gev.CKKSMulRelin(lv - 1, st2, st2, rlk, sq)
+        half = [new(nq - 1), new(nq - 1)]
+        for o, v in zip(half, sq):
+            o.CopyBatch(lv - 1, 0, v, nb, nb)
+        return [m, r, s, half]
+
+    ctx.SetCoalescing(0, 0)
+    ref = []
+    for k in range(K):
+        ref.append([[c.download() for c in ct] for ct in program(k)])
+    ctx.SetCoalescing(32, 3000)
+    ctx.SetDeferred(deferred)
+    before = ctx.CoalescingStats()
+    got = [None] * K
+
+    def caller(k):
+        def f():
+            got[k] = program(k)
+        return f
+
+    _run_threads([caller(k) for k in range(K)])
+    ctx.sync()
+    st = ctx.CoalescingStats()
+    for k in range(K):
+        for i, (ct, want) in enumerate(zip(got[k], ref[k])):
+            for c, w in zip(ct, want):
+                assert np.array_equal(c.download(), w), (k, i)
+    calls, launches = st["calls"] - before["calls"], st["launches"] - before["launches"]
+    assert calls == K * 13 and launches < calls, (calls, launches)
+    assert st["one_by_one"] == before["one_by_one"], st
+    # the oracle on caller 1's first entry (nb = 2): MulRelin + Add
+    x = [ins[1][0][c][0] for c in range(2)], [ins[1][1][c][0] for c in range(2)]
+    w = oev.CKKSMulRelin(np.stack(x[0]), np.stack(x[1]), orlk, True)
+    sub = O.Ring(N, q)
+    assert np.array_equal(ref[1][0][0][0], sub.binop("Add", w[0], x[1][0]))
