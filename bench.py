@@ -1025,9 +1025,10 @@ def main():
         if args.workload == "c3" and os.path.exists(exe) and "error" not in line["concurrent_b1"]:
             import subprocess
             runs = []
-            for sync_each in (0, 1):
+            for sync_each, deferred in ((0, 0), (1, 0), (0, 8), (1, 8)):  # deferred: he_ctx_set_deferred, the calls return once filed
                 try:
-                    r = subprocess.run([exe, "64", "96", str(sync_each), "1", "c3"], capture_output=True, text=True, timeout=120)
+                    r = subprocess.run([exe, "64", "96", str(sync_each), "1", "c3", str(args.co_batch), str(args.co_window), str(deferred)],
+                                       capture_output=True, text=True, timeout=120)
                     runs.append(json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]})
                 except Exception as e:  # noqa: BLE001 -- a missing / stale binary must not cost the bench line
                     runs.append({"error": str(e)})
@@ -1041,16 +1042,18 @@ def main():
         if os.path.exists(exe):
             import subprocess
             runs = []
-            for K, mb, sync_each, co in ((16, 16, 0, 1), (32, 32, 0, 1), (64, 64, 0, 1), (64, 64, 1, 1), (64, 64, 0, 0)):
+            for K, mb, sync_each, co, deferred in ((16, 16, 0, 1, 0), (32, 32, 0, 1, 0), (64, 64, 0, 1, 0), (64, 64, 1, 1, 0), (16, 16, 0, 1, 8),
+                                                   (32, 32, 0, 1, 8), (64, 64, 0, 1, 8), (64, 64, 1, 1, 8), (64, 64, 0, 0, 0)):
                 try:
-                    r = subprocess.run([exe, str(K), str(max(24, 6144 // K)), str(sync_each), str(co), "c2", str(mb), str(max(args.co_window, 100))],
-                                       capture_output=True, text=True, timeout=180)
+                    r = subprocess.run([exe, str(K), str(max(24, 6144 // K)), str(sync_each), str(co), "c2", str(mb), str(max(args.co_window, 100)),
+                                        str(deferred)], capture_output=True, text=True, timeout=180)
                     runs.append(json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]})
                 except Exception as e:  # noqa: BLE001
                     runs.append({"error": str(e)})
             line["concurrent_b1"] = {"unit": "ctxt-mul+rescale ops/s", "compiled_host": runs,
                                      "note": "tests/cpp/run_parallel.cpp c2: K threads, one ciphertext per call (Mul, then Rescale: "
-                                             "he_rescale_polys, the three polynomials in one call) on one evaluator; the last run: the "
+                                             "he_rescale_polys, the three polynomials in one call) on one evaluator; deferred_depth > 0: "
+                                             "he_ctx_set_deferred (the calls return once filed, the context's dispatcher launches); the last run: the "
                                              "same callers with the queue off.  More callers than the host's CPU quota (16 here) lose "
                                              "to the scheduler, not to the GPU"}
             if any(x.get("verified") is False for x in runs):

@@ -267,7 +267,9 @@ int he_evaluator_destroy(he_handle eval);
  * (the usual contract: results are visible after he_ctx_sync or a download).  A thread's own calls keep their order.  window_us
  * bounds how long a request waits for companions while the device is idle (a lone caller does not wait at all); while two earlier
  * batches are still in flight, gathering continues for free.  Results are bit-identical to the uncoalesced calls.  max_batch <= 1
- * switches it off.  Calls with batch > 1 and calls made while the context records a graph are launched directly as before; shapes
+ * switches it off.  Handles of a few entries (batch < max_batch: the drivers stack independent ciphertexts -- the two halves of a
+ * bootstrap's EvalMod -- into one handle) are queued the same way, a request of nb entries taking nb rows of the entry table; calls on
+ * larger handles and calls made while the context records a graph are launched directly as before; shapes
  * whose launches take no entry tables (base-2 gadgets, conjugate-invariant rings, evaluators without special primes, key switches
  * that write onto their own operand) are queued but served one by one.  The queue belongs to the CONTEXT (all objects of a context
  * share one stream): he_ctx_set_coalescing is the same switch addressed through the context handle. */

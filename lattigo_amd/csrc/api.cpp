@@ -21,6 +21,7 @@
 #include <memory>
 #include <tuple>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -174,29 +175,36 @@ struct Coalescer {
     // thread is a candidate for a batch.
     std::atomic<int> depth{0};
     std::thread dispatcher;
-    bool stop = false;
-    uint64_t next_ticket = 1;
-    uint64_t launching_min = UINT64_MAX;              // smallest ticket of the batch being launched right now
-    // one record per calling thread (stable address: the thread keeps a pointer while it sleeps): its requests in the order it
-    // made them, how many of them are not launched yet, and whether it sleeps until that count falls to half of `depth`
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> next_ticket{1};
+    std::atomic<uint64_t> launching_min{UINT64_MAX};  // smallest ticket of the batch being launched right now
+    // one record per calling thread (never freed while the context lives: the thread keeps the pointer): its requests in the
+    // order it made them -- under ITS OWN lock, so that filing a request contends with nobody but the dispatcher's glance at this
+    // queue (64 callers filing through the queue's one mutex spent two thirds of their CPU time in futex calls) -- how many of
+    // them are not launched yet, whether it sleeps until that count falls to half of `depth`, and when it last filed
     struct Caller {
         uint64_t id = 0;
+        std::mutex mu;
         std::deque<CoReq *> q;
         std::atomic<int> pending{0};
         std::atomic<bool> wait_low{false};
+        std::atomic<int64_t> last_us{0};
     };
-    std::vector<std::unique_ptr<Caller>> callers;
-    int n_deferred = 0;                               // requests in the callers' queues
+    static constexpr int kMaxCallers = 2048;          // threads beyond that go the blocking way
+    std::atomic<Caller *> callers[kMaxCallers];
+    std::atomic<int> n_callers{0};
+    const uint64_t uid;                               // identity for the threads' caches of their record (an address can be reused)
+    std::atomic<int> n_deferred{0};                   // requests in the callers' queues
+    std::atomic<uint32_t> work{0};                    // bumped by every filed call: the dispatcher sleeps on it
+    std::atomic<bool> disp_idle{false};
+    std::shared_mutex life;                           // filing holds it shared; switching deferred mode off takes it exclusively
     std::atomic<int> sleepers{0};                     // threads asleep on `gen`
     std::atomic<int> flushers{0};                     // threads that wait for launches (a flush): woken after every batch
     int def_rc = 0;                                   // first failure of a deferred launch: reported by the next he_ctx_sync
     std::string def_err;
-    Caller &caller_of(uint64_t id) {
-        for (auto &m : callers) if (m->id == id) return *m;
-        callers.emplace_back(new Caller());
-        callers.back()->id = id;
-        return *callers.back();
-    }
+    static uint64_t new_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1, std::memory_order_relaxed); }
+    Coalescer() : uid(new_uid()) { for (auto &c : callers) c.store(nullptr, std::memory_order_relaxed); }
+    ~Coalescer() { for (int i = 0; i < n_callers.load(); i++) delete callers[i].load(); }
 };
 thread_local bool g_dispatcher_thread = false;  // the dispatcher's own launches do not wait for the queue
 
@@ -305,8 +313,9 @@ struct Ctx : Obj {
     Ctx() : Obj(T_CTX) {}
     ~Ctx() override {
         if (co->dispatcher.joinable()) {  // (he_ctx_destroy stops it; this is the context dying with its last object)
-            { std::lock_guard<std::mutex> lk(co->mu); co->stop = true; }
-            co->cv_leader.notify_all();
+            co->stop = true;
+            co->work.fetch_add(1, std::memory_order_seq_cst);
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&co->work), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
             if (co->dispatcher.get_id() == std::this_thread::get_id()) co->dispatcher.detach();
             else co->dispatcher.join();
         }
@@ -655,31 +664,46 @@ struct Decomp : Obj {
     size_t dstride() const { return (size_t)width * ev->be->Q->N; }
 };
 
-std::mutex g_mu;
-std::unordered_map<uint64_t, std::shared_ptr<Obj>> g_objs;
-uint64_t g_next = 0x1000;
+// The handle registry: every entry point looks its handles up (six to ten per call), from as many threads as there are callers.
+// One mutex made those look-ups queue behind each other (64 callers: the queue's dispatcher sat idle while the callers fought for
+// this lock); 64 shards by handle, readers share a shard's lock.
+struct RegShard {
+    std::shared_mutex mu;
+    std::unordered_map<uint64_t, std::shared_ptr<Obj>> m;
+};
+RegShard g_reg[64];
+std::atomic<uint64_t> g_next{0x1000};
+inline RegShard &reg_shard(uint64_t h) { return g_reg[h & 63]; }
 
 uint64_t reg(std::shared_ptr<Obj> o) {
-    std::lock_guard<std::mutex> l(g_mu);
-    uint64_t h = g_next++;
-    g_objs[h] = std::move(o);
+    const uint64_t h = g_next.fetch_add(1, std::memory_order_relaxed);
+    RegShard &sh = reg_shard(h);
+    std::unique_lock<std::shared_mutex> l(sh.mu);
+    sh.m[h] = std::move(o);
     return h;
 }
 template <class T>
 std::shared_ptr<T> get(uint64_t h, ObjType t) {
-    std::lock_guard<std::mutex> l(g_mu);
-    auto it = g_objs.find(h);
-    if (it == g_objs.end() || it->second->type != t) return nullptr;
+    RegShard &sh = reg_shard(h);
+    std::shared_lock<std::shared_mutex> l(sh.mu);
+    auto it = sh.m.find(h);
+    if (it == sh.m.end() || it->second->type != t) return nullptr;
     return std::static_pointer_cast<T>(it->second);
+}
+void reg_drop(uint64_t h) {  // forget a handle whatever it names (an object that changes owner)
+    RegShard &sh = reg_shard(h);
+    std::unique_lock<std::shared_mutex> l(sh.mu);
+    sh.m.erase(h);
 }
 int unreg(uint64_t h, ObjType t) {
     std::shared_ptr<Obj> keep;
     {
-        std::lock_guard<std::mutex> l(g_mu);
-        auto it = g_objs.find(h);
-        if (it == g_objs.end() || it->second->type != t) return fail(HE_EHANDLE, "unknown handle %llu", (unsigned long long)h);
+        RegShard &sh = reg_shard(h);
+        std::unique_lock<std::shared_mutex> l(sh.mu);
+        auto it = sh.m.find(h);
+        if (it == sh.m.end() || it->second->type != t) return fail(HE_EHANDLE, "unknown handle %llu", (unsigned long long)h);
         keep = it->second;
-        g_objs.erase(it);
+        sh.m.erase(it);
     }
     keep.reset();
     return HE_OK;
@@ -918,28 +942,45 @@ CoReq *co_heap_copy(CoReq &q) {
     h->run = std::move(q.run); h->tables_ok = std::move(q.tables_ok);
     return h;
 }
+int64_t co_now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// the calling thread's record in this queue (create: register it on first use; nullptr when there is none / no room)
+Coalescer::Caller *co_my_caller(Coalescer &c, bool create) {
+    struct Slot { uint64_t uid; Coalescer::Caller *st; };
+    thread_local Slot cache[4] = {{0, nullptr}, {0, nullptr}, {0, nullptr}, {0, nullptr}};
+    thread_local int next = 0;
+    for (const Slot &sl : cache) if (sl.uid == c.uid) return sl.st;
+    const uint64_t me = co_me();
+    Coalescer::Caller *st = nullptr;
+    const int n = c.n_callers.load(std::memory_order_acquire);
+    for (int i = 0; i < n && !st; i++) { Coalescer::Caller *m = c.callers[i].load(std::memory_order_acquire); if (m && m->id == me) st = m; }
+    if (!st) {
+        if (!create) return nullptr;
+        std::lock_guard<std::mutex> lk(c.mu);  // (registration: once per thread)
+        const int k = c.n_callers.load(std::memory_order_relaxed);
+        if (k >= Coalescer::kMaxCallers) return nullptr;
+        st = new Coalescer::Caller();
+        st->id = me;
+        c.callers[k].store(st, std::memory_order_release);
+        c.n_callers.store(k + 1, std::memory_order_release);
+    }
+    cache[next] = Slot{c.uid, st};
+    next = (next + 1) & 3;
+    return st;
+}
+void co_kick_dispatcher(Coalescer &c) {
+    c.work.fetch_add(1, std::memory_order_seq_cst);
+    if (c.disp_idle.load(std::memory_order_seq_cst))
+        syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.work), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+}
 int co_defer(Ctx &ctx, const std::vector<CoReq *> &rs) {
     Coalescer &c = *ctx.co;
-    const uint64_t me = co_me();
-    std::vector<CoReq *> heap;
-    heap.reserve(rs.size());
-    for (CoReq *q : rs) heap.push_back(co_heap_copy(*q));
-    auto give_back = [&]() {  // the blocking path takes the originals back
-        for (size_t i = 0; i < rs.size(); i++) {
-            CoReq *h = heap[i];
-            rs[i]->blob = std::move(h->blob); rs[i]->ops = std::move(h->ops); rs[i]->keep = std::move(h->keep);
-            rs[i]->run = std::move(h->run); rs[i]->tables_ok = std::move(h->tables_ok);
-            delete h;
-        }
-        return -1;
-    };
-    std::unique_lock<std::mutex> lk(c.mu);
-    Coalescer::Caller &st = c.caller_of(me);
+    Coalescer::Caller *stp = co_my_caller(c, true);
+    if (!stp) return -1;  // (more threads than records: the blocking way)
+    Coalescer::Caller &st = *stp;
     int depth = c.depth.load(std::memory_order_relaxed);
     if (depth > 0 && st.pending.load(std::memory_order_relaxed) >= depth) {
-        // a full pipeline: sleep until HALF of it has been launched (one wake-up per depth / 2 calls, not one per call), without
-        // the queue's lock -- the dispatcher wakes the sleepers whose count reached the mark
-        lk.unlock();
+        // a full pipeline: sleep until HALF of it has been launched (one wake-up per depth / 2 requests, not one per call); the
+        // dispatcher wakes the sleepers whose count reached the mark
         st.wait_low.store(true, std::memory_order_seq_cst);
         for (;;) {
             const uint32_t g = c.gen.load(std::memory_order_seq_cst);
@@ -948,31 +989,40 @@ int co_defer(Ctx &ctx, const std::vector<CoReq *> &rs) {
             co_sleep(c, g);
         }
         st.wait_low.store(false, std::memory_order_seq_cst);
-        lk.lock();
     }
-    if (c.depth.load(std::memory_order_relaxed) <= 0 || c.stop) { lk.unlock(); return give_back(); }  // switched off meanwhile
+    std::shared_lock<std::shared_mutex> alive(c.life);  // (deferred mode cannot end between this test and the push)
+    if (c.depth.load(std::memory_order_relaxed) <= 0 || c.stop.load(std::memory_order_relaxed)) return -1;
     const auto now = std::chrono::steady_clock::now();
-    for (CoReq *h : heap) {
-        h->arrived = now; h->caller = me; h->seq = g_my_calls; h->ticket = c.next_ticket++;
-        st.q.push_back(h);
+    const int n = (int)rs.size();
+    CoReq *heap[16];
+    std::vector<CoReq *> more;
+    if (n > 16) more.resize((size_t)n);
+    CoReq **hp = n > 16 ? more.data() : heap;
+    for (int i = 0; i < n; i++) {
+        hp[i] = co_heap_copy(*rs[i]);
+        hp[i]->arrived = now; hp[i]->caller = st.id; hp[i]->seq = g_my_calls;
     }
     g_my_calls++;
-    st.pending.fetch_add((int)heap.size(), std::memory_order_seq_cst);
-    c.n_deferred += (int)heap.size();
-    co_note_caller(c, me, now);
-    lk.unlock();
-    c.cv_leader.notify_one();
+    st.pending.fetch_add(n, std::memory_order_seq_cst);
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        for (int i = 0; i < n; i++) {
+            hp[i]->ticket = c.next_ticket.fetch_add(1, std::memory_order_relaxed);  // (under the record's lock: increasing along its queue)
+            st.q.push_back(hp[i]);
+        }
+    }
+    st.last_us.store(co_now_us(), std::memory_order_relaxed);
+    c.n_deferred.fetch_add(n, std::memory_order_seq_cst);
+    co_kick_dispatcher(c);
     return HE_OK;
 }
 // wait until the calling thread has nothing pending
 void co_flush_mine(Ctx &ctx) {
     Coalescer &c = *ctx.co;
-    const uint64_t me = co_me();
-    Coalescer::Caller *st;
-    { std::lock_guard<std::mutex> lk(c.mu); st = &c.caller_of(me); }
-    if (st->pending.load(std::memory_order_seq_cst) <= 0) return;
+    Coalescer::Caller *st = co_my_caller(c, false);
+    if (!st || st->pending.load(std::memory_order_seq_cst) <= 0) return;
     c.flushers.fetch_add(1, std::memory_order_seq_cst);
-    c.cv_leader.notify_one();
+    co_kick_dispatcher(c);
     for (;;) {
         const uint32_t g = c.gen.load(std::memory_order_seq_cst);
         if (st->pending.load(std::memory_order_seq_cst) <= 0) break;
@@ -983,24 +1033,29 @@ void co_flush_mine(Ctx &ctx) {
 // wait until every request filed before this call has been launched; returns (and clears) the first deferred failure
 int co_flush_filed(Ctx &ctx) {
     Coalescer &c = *ctx.co;
-    std::unique_lock<std::mutex> lk(c.mu);
-    const uint64_t upto = c.next_ticket;  // tickets below this were filed
+    const uint64_t upto = c.next_ticket.load(std::memory_order_seq_cst);  // tickets below this were filed
     auto behind = [&]() -> bool {
-        if (c.launching_min < upto) return true;
-        for (auto &m : c.callers) if (!m->q.empty() && m->q.front()->ticket < upto) return true;
-        return false;
+        if (c.launching_min.load(std::memory_order_seq_cst) < upto) return true;
+        const int n = c.n_callers.load(std::memory_order_acquire);
+        for (int i = 0; i < n; i++) {
+            Coalescer::Caller *m = c.callers[i].load(std::memory_order_acquire);
+            std::lock_guard<std::mutex> lk(m->mu);
+            if (!m->q.empty() && m->q.front()->ticket < upto) return true;
+        }
+        // (a batch moves from the queues to `launching_min` under the records' locks, lowest ticket published first: see the dispatcher)
+        return c.launching_min.load(std::memory_order_seq_cst) < upto;
     };
     if (behind()) {
         c.flushers.fetch_add(1, std::memory_order_seq_cst);
-        while (behind()) {
+        for (;;) {
             const uint32_t g = c.gen.load(std::memory_order_seq_cst);
-            lk.unlock();
-            c.cv_leader.notify_one();
+            if (!behind()) break;
+            co_kick_dispatcher(c);
             co_sleep(c, g);
-            lk.lock();
         }
         c.flushers.fetch_sub(1, std::memory_order_seq_cst);
     }
+    std::unique_lock<std::mutex> lk(c.mu);
     if (c.def_rc != HE_OK) {
         const int rc = c.def_rc;
         const std::string msg = c.def_err;
@@ -1018,27 +1073,51 @@ void co_dispatcher_main(Ctx *ctx) {
     hipSetDevice(ctx->dev);
     static const bool timing = env_flag("HERING_QUEUE_TIMING");  // diagnosis: how long the device spent inside the batches
     static const int ahead_cap = std::max(2, getenv("HERING_QUEUE_AHEAD") ? atoi(getenv("HERING_QUEUE_AHEAD")) : 16);
-    std::unique_lock<std::mutex> lk(c.mu);
     std::vector<CoReq *> heads, batch;
     std::vector<Coalescer::Caller *> owners;
+    auto nap = [&](uint32_t seen_work, long us) {  // until a call is filed, at most `us`
+        timespec ts{0, us * 1000};
+        c.disp_idle.store(true, std::memory_order_seq_cst);
+        if (c.work.load(std::memory_order_seq_cst) == seen_work && !c.stop.load(std::memory_order_seq_cst))
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.work), FUTEX_WAIT_PRIVATE, seen_work, &ts, nullptr, 0);
+        c.disp_idle.store(false, std::memory_order_seq_cst);
+    };
     for (;;) {
-        c.cv_leader.wait(lk, [&] { return c.stop || c.n_deferred > 0; });
-        if (c.n_deferred <= 0) break;  // (stop, and nothing left to launch)
+        uint32_t w = c.work.load(std::memory_order_seq_cst);
+        if (c.n_deferred.load(std::memory_order_seq_cst) <= 0) {
+            if (c.stop.load(std::memory_order_seq_cst)) break;  // (nothing left to launch)
+            nap(w, 2000);
+            continue;
+        }
         const int max_batch = std::max(1, c.max_batch.load(std::memory_order_relaxed));
+        const long long win = c.window_us;
         const auto g0 = clock::now();
         const CoReq *hp = nullptr;
         for (;;) {
+            w = c.work.load(std::memory_order_seq_cst);
             // the candidates: every thread's first pending call (all requests of it); `oldest`: the one filed first
             heads.clear();
-            int here = 0;
+            int here = 0, active = 0;
             const CoReq *oldest = nullptr;
-            for (auto &m : c.callers) {
-                if (m->q.empty()) continue;
-                here++;
-                const uint64_t seq = m->q.front()->seq;
-                for (CoReq *r : m->q) { if (r->seq != seq) break; heads.push_back(r); }
-                if (!oldest || m->q.front()->ticket < oldest->ticket) oldest = m->q.front();
+            const int64_t now_us = co_now_us();
+            const int n = c.n_callers.load(std::memory_order_acquire);
+            for (int i = 0; i < n; i++) {
+                Coalescer::Caller *m = c.callers[i].load(std::memory_order_acquire);
+                bool has = false;
+                {
+                    std::lock_guard<std::mutex> lk(m->mu);
+                    if (!m->q.empty()) {
+                        has = true;
+                        const uint64_t seq = m->q.front()->seq;
+                        for (CoReq *r : m->q) { if (r->seq != seq) break; heads.push_back(r); }
+                        if (!oldest || m->q.front()->ticket < oldest->ticket) oldest = m->q.front();
+                    }
+                }
+                here += has ? 1 : 0;
+                // expected back: every thread that filed in the last few milliseconds (the caller-counting rule of co_lead)
+                active += (has || now_us - m->last_us.load(std::memory_order_relaxed) <= 3000 + 8 * win) ? 1 : 0;
             }
+            if (!oldest) break;  // (cannot happen: n_deferred > 0 and only this thread removes requests)
             // which operation: the oldest call's -- unless a thread of the same cohort is behind it (see co_lead)
             hp = oldest;
             for (const CoReq *r : heads)
@@ -1046,58 +1125,63 @@ void co_dispatcher_main(Ctx *ctx) {
             int same = 0;  // (in batch entries)
             for (const CoReq *r : heads) same += r->same_key(*hp) ? r->nb : 0;
             const auto now = clock::now();
-            int active = 0;
-            const long long win = c.window_us;
-            for (auto it = c.seen.begin(); it != c.seen.end();) {
-                if (std::chrono::duration_cast<std::chrono::microseconds>(now - it->second).count() > 3000 + 8 * win) it = c.seen.erase(it);
-                else { ++active; ++it; }
-            }
-            const int ahead = co_inflight(c);
+            int ahead;
+            { std::lock_guard<std::mutex> lk(c.mu); ahead = co_inflight(c); }
             const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - oldest->arrived).count();
-            if (c.stop) break;
+            if (c.stop.load(std::memory_order_relaxed)) break;
             auto spent = [&](int slot) { c.dbg[slot] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - now).count(); };
-            if (ahead >= ahead_cap) { c.cv_leader.wait_for(lk, std::chrono::microseconds(100)); spent(8); continue; }  // far enough ahead of the device
+            if (ahead >= ahead_cap) { nap(w, 100); spent(8); continue; }  // far enough ahead of the device
             if (same >= max_batch) { c.dbg[2]++; break; }
             if (here >= active) { c.dbg[0]++; c.dbg[5] += (uint64_t)here; c.dbg[6] += (uint64_t)active; break; }
             if (ahead < 2 && waited >= 8 * win) { c.dbg[1]++; c.dbg[5] += (uint64_t)here; c.dbg[6] += (uint64_t)active; break; }
-            if (ahead >= 2) { c.cv_leader.wait_for(lk, std::chrono::microseconds(100)); spent(9); }  // the device is busy: waiting is free; arrivals notify
-            else { lk.unlock(); sched_yield(); lk.lock(); spent(10); }
+            if (ahead >= 2) { nap(w, 100); spent(9); }  // the device is busy: waiting is free; a filed call ends the nap
+            else { sched_yield(); spent(10); }
         }
+        if (!hp) continue;
         batch.clear(); owners.clear();
         int entries = 0;
         for (CoReq *r : heads)
             if (r->same_key(*hp) && (batch.empty() || entries + r->nb <= max_batch)) { entries += r->nb; batch.push_back(r); }
         uint64_t lo = UINT64_MAX;
+        for (CoReq *r : batch) lo = std::min(lo, r->ticket);
+        c.launching_min.store(lo, std::memory_order_seq_cst);  // (published BEFORE the requests leave their queues: he_ctx_sync never sees them nowhere)
+        const int nc = c.n_callers.load(std::memory_order_acquire);
         for (CoReq *r : batch) {
-            lo = std::min(lo, r->ticket);
-            Coalescer::Caller &m = c.caller_of(r->caller);
-            m.q.erase(std::find(m.q.begin(), m.q.end(), r));  // (one of the first few: the requests of the thread's first call)
-            owners.push_back(&m);
+            Coalescer::Caller *m = nullptr;
+            for (int i = 0; i < nc && !m; i++) { Coalescer::Caller *x = c.callers[i].load(std::memory_order_acquire); if (x->id == r->caller) m = x; }
+            std::lock_guard<std::mutex> lk(m->mu);
+            m->q.erase(std::find(m->q.begin(), m->q.end(), r));  // (one of the first few: the requests of the thread's first call)
+            owners.push_back(m);
         }
-        c.n_deferred -= (int)batch.size();
-        c.launching_min = lo;
-        auto take_event = [&]() -> hipEvent_t {
-            hipEvent_t ev = nullptr;
-            if (!c.free_events.empty()) { ev = c.free_events.back(); c.free_events.pop_back(); }
-            else if (hipEventCreateWithFlags(&ev, timing ? hipEventDefault : hipEventDisableTiming) != hipSuccess) ev = nullptr;
-            return ev;
-        };
-        hipEvent_t e = take_event(), e_begin = timing ? take_event() : nullptr;
+        c.n_deferred.fetch_sub((int)batch.size(), std::memory_order_seq_cst);
+        hipEvent_t e = nullptr, e_begin = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            auto take_event = [&]() -> hipEvent_t {
+                hipEvent_t ev = nullptr;
+                if (!c.free_events.empty()) { ev = c.free_events.back(); c.free_events.pop_back(); }
+                else if (hipEventCreateWithFlags(&ev, timing ? hipEventDefault : hipEventDisableTiming) != hipSuccess) ev = nullptr;
+                return ev;
+            };
+            e = take_event();
+            e_begin = timing ? take_event() : nullptr;
+            c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
+            c.dbg[11]++;
+        }
         if (e_begin && hipEventRecord(e_begin, ctx->stream) != hipSuccess) (void)hipGetLastError();
-        c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
-        c.dbg[11]++;
         const auto g1 = clock::now();
         c.dbg[3] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(g1 - g0).count();
-        lk.unlock();
         const int fallback = co_run(*ctx, c, batch, e);
         const uint64_t run_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - g1).count();
-        lk.lock();
-        c.dbg[4] += run_us;
-        c.n_fallback += (uint64_t)fallback;
-        if (e) { c.inflight.push_back(e); if (e_begin) c.inflight_begin.push_back(e_begin); }
-        for (CoReq *r : batch)
-            if (r->rc != HE_OK && c.def_rc == HE_OK) { c.def_rc = r->rc; c.def_err = r->err; }
-        c.launching_min = UINT64_MAX;
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            c.dbg[4] += run_us;
+            c.n_fallback += (uint64_t)fallback;
+            if (e) { c.inflight.push_back(e); if (e_begin) c.inflight_begin.push_back(e_begin); }
+            for (CoReq *r : batch)
+                if (r->rc != HE_OK && c.def_rc == HE_OK) { c.def_rc = r->rc; c.def_err = r->err; }
+        }
+        c.launching_min.store(UINT64_MAX, std::memory_order_seq_cst);
         // who has to hear about it: a thread asleep on a full pipeline whose count reached the low mark, anybody flushing.
         // (sleepers raise their flag BEFORE they read their count, this lowers the count BEFORE it reads the flag: one of the two
         // sees the other)
@@ -1108,11 +1192,11 @@ void co_dispatcher_main(Ctx *ctx) {
             wake = wake || (left <= low && m->wait_low.load(std::memory_order_seq_cst));
         }
         wake = wake || c.flushers.load(std::memory_order_seq_cst) > 0;
-        if (wake) c.gen.fetch_add(1, std::memory_order_seq_cst);
-        lk.unlock();
-        if (wake) syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+        if (wake) {
+            c.gen.fetch_add(1, std::memory_order_seq_cst);
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+        }
         for (CoReq *r : batch) delete r;  // (drops the operands' references: a released polynomial goes back to the buffer cache now)
-        lk.lock();
     }
 }
 // stop the dispatcher (everything pending is launched first); the queue is in blocking mode afterwards
@@ -1121,18 +1205,17 @@ void co_stop_dispatcher(Ctx &ctx) {
     std::thread t;
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        if (!c.dispatcher.joinable()) { c.depth = 0; return; }
+        std::unique_lock<std::shared_mutex> nobody_files(c.life);  // (no call is between its "deferred?" test and its push)
         c.depth = 0;
+        if (!c.dispatcher.joinable()) return;
         c.stop = true;
         t = std::move(c.dispatcher);
     }
-    c.cv_leader.notify_all();
+    co_kick_dispatcher(c);
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.work), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
     if (t.get_id() == std::this_thread::get_id()) t.detach();  // (cannot happen: the dispatcher never calls this)
     else t.join();
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        c.stop = false;
-    }
+    c.stop = false;
     c.gen.fetch_add(1, std::memory_order_release);
     syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
 }
@@ -2411,10 +2494,7 @@ int he_evaluator_create(he_handle hq, he_handle hp, he_handle *out) {
         TRY(he_basis_extender_create(hq, hp, &hbe));
     }
     auto be = get<BasisExtender>(hbe, T_BE);
-    {  // the evaluator owns its extender; drop the public handle
-        std::lock_guard<std::mutex> l(g_mu);
-        g_objs.erase(hbe);
-    }
+    reg_drop(hbe);  // the evaluator owns its extender; drop the public handle
     auto ev = std::make_shared<Evaluator>();
     ev->be = be;
     const int LQ = be->LQ, LP = be->LP;

@@ -18,6 +18,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sys/resource.h>
+#include <time.h>
 
 #include "hering.hpp"
 #include "hering_debug.h"
@@ -79,6 +81,8 @@ int main(int argc, char **argv) {
                 if (c2) callers[k].res.Value.push_back(ringQ.AtLevel(level - 1).NewPoly());
             }
         }
+        std::atomic<long long> caller_cpu_ns{0};  // CPU time the callers spent inside their loops (asleep does not count)
+        auto thread_cpu_ns = [] { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; };
         auto run = [&](int n) {
             std::atomic<int> ready{0};
             std::atomic<bool> go{false};
@@ -87,6 +91,8 @@ int main(int argc, char **argv) {
                 th.emplace_back([&, k] {
                     ready++;
                     while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+                    const long long c0 = thread_cpu_ns();
+                    struct Acc { std::atomic<long long> &a; long long c0; decltype(thread_cpu_ns) &f; ~Acc() { a += f() - c0; } } acc{caller_cpu_ns, c0, thread_cpu_ns};
                     for (int i = 0; i < n; i++) {  // one ciphertext per call
                         if (c2) {
                             eval.MulRelinCKKS(callers[k].a, callers[k].b, nullptr, callers[k].out);
@@ -107,9 +113,25 @@ int main(int argc, char **argv) {
         run(8);  // warm-up: plans, scratch arena, the queue's batch-size history
         uint64_t st0[4] = {0, 0, 0, 0}, st1[4] = {0, 0, 0, 0};
         he_ctx_coalescing_stats(ctx.h(), st0);
+        caller_cpu_ns = 0;
+        rusage ru0{}, ru1{};
+        getrusage(RUSAGE_SELF, &ru0);
         const double dt = run(iters);
+        getrusage(RUSAGE_SELF, &ru1);
+        const double proc_cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6 +
+                                  (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
+        const double sys_s = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
         he_ctx_coalescing_stats(ctx.h(), st1);
         const double mean_batch = st1[1] > st0[1] ? (double)(st1[0] - st0[0]) / (double)(st1[1] - st0[1]) : 0.0;
+        if (std::getenv("HERING_QUEUE_DEBUG")) {  // where the queue's launching thread spent the run (hering_debug.h)
+            uint64_t dbg[16] = {0};
+            he_debug_queue_counters(ctx.h(), dbg);
+            std::fprintf(stderr, "queue counters: everyone %llu timeout %llu full %llu | gather %llu us launch %llu us | ahead-cap %llu us, "
+                                 "waiting (device busy) %llu us, waiting (device dry) %llu us, batches %llu | wall %.0f us\n",
+                         (unsigned long long)dbg[0], (unsigned long long)dbg[1], (unsigned long long)dbg[2], (unsigned long long)dbg[3],
+                         (unsigned long long)dbg[4], (unsigned long long)dbg[8], (unsigned long long)dbg[9], (unsigned long long)dbg[10],
+                         (unsigned long long)dbg[11], dt * 1e6);
+        }
         // parity of what was timed: EVERY caller's last result against the oracle, on the host's threads
         lo_ring *oQ = lo_ring_new(N, q.data(), nq), *oP = lo_ring_new(N, p.data(), np);
         lo_evaluator *oev = lo_evaluator_new(oQ, oP);
@@ -138,9 +160,10 @@ int main(int argc, char **argv) {
         }
         std::printf("{\"host\": \"C++ (include/hering.hpp), std::thread per caller, public interface only\", \"workload\": \"%s\", \"K\": %d, "
                     "\"calls_per_caller\": %d, \"interface_calls_per_op\": %d, \"sync_each\": %s, \"coalescing\": %s, \"max_batch\": %d, "
-                    "\"window_us\": %d, \"deferred_depth\": %d, \"mean_batch\": %.1f, \"ops_per_s\": %.1f, \"verified\": %s, \"verified_callers\": \"%d/%d\"}\n",
+                    "\"window_us\": %d, \"deferred_depth\": %d, \"mean_batch\": %.1f, \"ops_per_s\": %.1f, \"caller_cpu_us_per_interface_call\": %.2f, "
+                    "\"process_cpu_cores_used\": %.1f, \"process_sys_share\": %.2f, \"verified\": %s, \"verified_callers\": \"%d/%d\"}\n",
                     workload.c_str(), K, iters, c2 ? 2 : 1, sync_each ? "true" : "false", coalesce ? "true" : "false", max_batch, window_us, coalesce ? deferred : 0,
-                    mean_batch, (double)K * iters / dt, bad == 0 ? "true" : "false", K - bad, K);
+                    mean_batch, (double)K * iters / dt, caller_cpu_ns.load() * 1e-3 / ((double)K * iters * (c2 ? 2 : 1)), proc_cpu_s / dt, sys_s / std::max(proc_cpu_s, 1e-9), bad == 0 ? "true" : "false", K - bad, K);
         return bad == 0 ? 0 : 1;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "run_parallel: %s\n", e.what());
