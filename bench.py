@@ -537,7 +537,9 @@ def concurrent_b1(la, ctx, workload="c3", ks=(1, 4, 16, 64), ops_per_run=6000, m
     ev, rlk, cs = callers_on(ctx, range(kmax))
     shared = [(ctx, ev, a, b, rlk, o) for a, b, o in cs]
     ev.SetCoalescing(max_batch, window_us)
-    for name, sync_each in (("coalesced", False), ("coalesced_sync_each", True)):
+    # deferred: he_ctx_set_deferred -- the calls return once filed, the context's dispatcher thread launches them
+    for name, sync_each, depth in (("coalesced", False, 0), ("coalesced_sync_each", True, 0), ("deferred", False, 8), ("deferred_sync_each", True, 8)):
+        ctx.SetDeferred(depth)
         rates = []
         for K in ks:
             ConcurrentMulRelin(shared[:K], L - 1, 3, t=T, sync_each=sync_each)
@@ -1042,10 +1044,13 @@ def main():
         if os.path.exists(exe):
             import subprocess
             runs = []
-            for K, mb, sync_each, co, deferred in ((16, 16, 0, 1, 0), (32, 32, 0, 1, 0), (64, 64, 0, 1, 0), (64, 64, 1, 1, 0), (16, 16, 0, 1, 8),
-                                                   (32, 32, 0, 1, 8), (64, 64, 0, 1, 8), (64, 64, 1, 1, 8), (64, 64, 0, 0, 0)):
+            # (K, max_batch in entries: a Rescale files one request per polynomial, so 4 K lets every caller's three share a launch,
+            #  wait for each result, queue on, deferred depth in requests per caller, calls per caller)
+            for K, mb, sync_each, co, deferred, iters in ((16, 64, 0, 1, 0, 1000), (32, 128, 0, 1, 0, 500), (64, 256, 0, 1, 0, 400), (64, 256, 1, 1, 0, 200),
+                                                          (16, 64, 0, 1, 128, 2000), (32, 128, 0, 1, 128, 2000), (64, 256, 0, 1, 128, 1000),
+                                                          (64, 256, 1, 1, 128, 200), (64, 256, 0, 0, 0, 100)):
                 try:
-                    r = subprocess.run([exe, str(K), str(max(24, 6144 // K)), str(sync_each), str(co), "c2", str(mb), str(max(args.co_window, 100)),
+                    r = subprocess.run([exe, str(K), str(iters), str(sync_each), str(co), "c2", str(mb), str(max(args.co_window, 100)),
                                         str(deferred)], capture_output=True, text=True, timeout=180)
                     runs.append(json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]})
                 except Exception as e:  # noqa: BLE001

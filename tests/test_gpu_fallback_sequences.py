@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 PAIRS = [("HERING_NO_AUTO_SCATTER", "HERING_NO_TENSOR_EPILOGUE"), ("HERING_NO_MAC_EPILOGUE", "HERING_NO_PROD_PROLOGUE"),
          ("HERING_NO_FAST_MODUP", "HERING_NO_LEAN_INV_ROWS")]
 TESTS = ["tests/test_gpu_headline.py::test_full_size_config3_bgv_mulrelin_logN15[256]", "tests/test_gpu_rlwe.py::test_rotate",
-         "tests/test_gpu_coalesce.py::test_every_operator_entry_point_coalesces[13]",
+         "tests/test_gpu_coalesce.py::test_every_operator_entry_point_coalesces[13-0]",
+         "tests/test_gpu_coalesce.py::test_every_operator_entry_point_coalesces[13-8]",
          "tests/test_gpu_coalesce.py::test_key_switches_coalesce_too[16]"]
 
 
