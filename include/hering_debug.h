@@ -51,6 +51,9 @@ int he_ctx_coalescing_stats(he_handle ctx, uint64_t out[4]);  /* the same counte
 int he_debug_queue_counters(he_handle ctx, uint64_t out[16]);
 /* per operation of the queue (the CoOp numbering of csrc/api.cpp): out[2 i] = batches launched, out[2 i + 1] = requests served */
 int he_debug_queue_op_stats(he_handle ctx, uint64_t out[64]);
+/* files a request whose launch fails (HE_EDEVICE) after the call was accepted: in the default mode of the queue the call itself returns
+ * the failure; under he_ctx_set_deferred the call returns HE_OK and the next he_ctx_sync reports it (tests) */
+int he_debug_queue_inject_failure(he_handle ctx);
 /* Concurrent single-ciphertext callers, the shape of the reference's parallel benchmarks (b.RunParallel,
  * schemes/ckks/ckks_benchmarks_test.go:116-207): n_threads OS threads (pthreads inside the library: no interpreter in the timed
  * region); thread i makes `iters` calls on its own batch-1 handles -- op 0: he_ckks_mul_relin(eval[i], level, a0[i], a1[i], b0[i],

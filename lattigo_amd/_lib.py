@@ -129,7 +129,7 @@ def _declare(L):
         "he_poly_all_reduce_sum": [H, H],
         "he_evaluator_set_coalescing": [H, i, i], "he_evaluator_coalescing_stats": [H, u64p],
         "he_ctx_set_coalescing": [H, i, i], "he_ctx_set_deferred": [H, i], "he_ctx_coalescing_stats": [H, u64p],
-        "he_debug_queue_counters": [H, u64p], "he_debug_queue_op_stats": [H, u64p],
+        "he_debug_queue_counters": [H, u64p], "he_debug_queue_op_stats": [H, u64p], "he_debug_queue_inject_failure": [H],
         "he_debug_concurrent_mul_relin": [i, i, i, i, i, C.c_uint64, HP, HP, HP, HP, HP, HP, HP, HP, HP, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():

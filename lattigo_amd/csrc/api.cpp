@@ -183,7 +183,7 @@ struct Coalescer {
     // queue (64 callers filing through the queue's one mutex spent two thirds of their CPU time in futex calls) -- how many of
     // them are not launched yet, whether it sleeps until that count falls to half of `depth`, and when it last filed
     struct Caller {
-        uint64_t id = 0;
+        std::atomic<uint64_t> id{0};  // the thread it belongs to; 0: free (its thread ended with nothing pending), may be claimed
         std::mutex mu;
         std::deque<CoReq *> q;
         std::atomic<int> pending{0};
@@ -203,8 +203,18 @@ struct Coalescer {
     int def_rc = 0;                                   // first failure of a deferred launch: reported by the next he_ctx_sync
     std::string def_err;
     static uint64_t new_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1, std::memory_order_relaxed); }
-    Coalescer() : uid(new_uid()) { for (auto &c : callers) c.store(nullptr, std::memory_order_relaxed); }
-    ~Coalescer() { for (int i = 0; i < n_callers.load(); i++) delete callers[i].load(); }
+    // the queues alive in this process, by uid: a thread that ends gives its records back (co_thread_exit)
+    static std::mutex &live_mu() { static std::mutex m; return m; }
+    static std::unordered_map<uint64_t, Coalescer *> &live() { static std::unordered_map<uint64_t, Coalescer *> m; return m; }
+    Coalescer() : uid(new_uid()) {
+        for (auto &c : callers) c.store(nullptr, std::memory_order_relaxed);
+        std::lock_guard<std::mutex> lk(live_mu());
+        live()[uid] = this;
+    }
+    ~Coalescer() {
+        { std::lock_guard<std::mutex> lk(live_mu()); live().erase(uid); }
+        for (int i = 0; i < n_callers.load(); i++) delete callers[i].load();
+    }
 };
 thread_local bool g_dispatcher_thread = false;  // the dispatcher's own launches do not wait for the queue
 
@@ -943,28 +953,48 @@ CoReq *co_heap_copy(CoReq &q) {
     return h;
 }
 int64_t co_now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-// the calling thread's record in this queue (create: register it on first use; nullptr when there is none / no room)
-Coalescer::Caller *co_my_caller(Coalescer &c, bool create) {
+// the calling thread's record in this queue (create: register it on first use; nullptr when there is none / no room).
+// Threads cache the pointer; a thread that ends frees its records (unless requests are still pending) for the next new thread.
+struct CallerCache {
     struct Slot { uint64_t uid; Coalescer::Caller *st; };
-    thread_local Slot cache[4] = {{0, nullptr}, {0, nullptr}, {0, nullptr}, {0, nullptr}};
-    thread_local int next = 0;
-    for (const Slot &sl : cache) if (sl.uid == c.uid) return sl.st;
+    Slot slot[4] = {{0, nullptr}, {0, nullptr}, {0, nullptr}, {0, nullptr}};
+    std::vector<Slot> all;  // every record this thread owns
+    int next = 0;
+    ~CallerCache() {
+        std::lock_guard<std::mutex> lk(Coalescer::live_mu());  // (a queue cannot be destroyed while its record is being released)
+        for (const Slot &sl : all) {
+            if (!Coalescer::live().count(sl.uid)) continue;
+            std::lock_guard<std::mutex> q(sl.st->mu);
+            if (sl.st->pending.load(std::memory_order_seq_cst) == 0 && sl.st->q.empty()) sl.st->id.store(0, std::memory_order_release);
+        }
+    }
+};
+thread_local CallerCache g_caller_cache;
+Coalescer::Caller *co_my_caller(Coalescer &c, bool create) {
+    CallerCache &cc = g_caller_cache;
+    for (const CallerCache::Slot &sl : cc.slot) if (sl.uid == c.uid) return sl.st;
+    for (const CallerCache::Slot &sl : cc.all) if (sl.uid == c.uid) return sl.st;
+    if (!create) return nullptr;
     const uint64_t me = co_me();
     Coalescer::Caller *st = nullptr;
     const int n = c.n_callers.load(std::memory_order_acquire);
-    for (int i = 0; i < n && !st; i++) { Coalescer::Caller *m = c.callers[i].load(std::memory_order_acquire); if (m && m->id == me) st = m; }
+    for (int i = 0; i < n && !st; i++) {  // a record a thread that ended left behind
+        Coalescer::Caller *m = c.callers[i].load(std::memory_order_acquire);
+        uint64_t free_id = 0;
+        if (m && m->id.load(std::memory_order_relaxed) == 0 && m->id.compare_exchange_strong(free_id, me, std::memory_order_acq_rel)) st = m;
+    }
     if (!st) {
-        if (!create) return nullptr;
         std::lock_guard<std::mutex> lk(c.mu);  // (registration: once per thread)
         const int k = c.n_callers.load(std::memory_order_relaxed);
         if (k >= Coalescer::kMaxCallers) return nullptr;
         st = new Coalescer::Caller();
-        st->id = me;
+        st->id.store(me, std::memory_order_relaxed);
         c.callers[k].store(st, std::memory_order_release);
         c.n_callers.store(k + 1, std::memory_order_release);
     }
-    cache[next] = Slot{c.uid, st};
-    next = (next + 1) & 3;
+    cc.slot[cc.next] = CallerCache::Slot{c.uid, st};
+    cc.next = (cc.next + 1) & 3;
+    cc.all.push_back(CallerCache::Slot{c.uid, st});
     return st;
 }
 void co_kick_dispatcher(Coalescer &c) {
@@ -975,7 +1005,7 @@ void co_kick_dispatcher(Coalescer &c) {
 int co_defer(Ctx &ctx, const std::vector<CoReq *> &rs) {
     Coalescer &c = *ctx.co;
     Coalescer::Caller *stp = co_my_caller(c, true);
-    if (!stp) return -1;  // (more threads than records: the blocking way)
+    if (!stp) return -2;  // (more live threads than records: launched directly)
     Coalescer::Caller &st = *stp;
     int depth = c.depth.load(std::memory_order_relaxed);
     if (depth > 0 && st.pending.load(std::memory_order_relaxed) >= depth) {
@@ -1000,7 +1030,7 @@ int co_defer(Ctx &ctx, const std::vector<CoReq *> &rs) {
     CoReq **hp = n > 16 ? more.data() : heap;
     for (int i = 0; i < n; i++) {
         hp[i] = co_heap_copy(*rs[i]);
-        hp[i]->arrived = now; hp[i]->caller = st.id; hp[i]->seq = g_my_calls;
+        hp[i]->arrived = now; hp[i]->caller = st.id.load(std::memory_order_relaxed); hp[i]->seq = g_my_calls;
     }
     g_my_calls++;
     st.pending.fetch_add(n, std::memory_order_seq_cst);
@@ -1148,7 +1178,7 @@ void co_dispatcher_main(Ctx *ctx) {
         const int nc = c.n_callers.load(std::memory_order_acquire);
         for (CoReq *r : batch) {
             Coalescer::Caller *m = nullptr;
-            for (int i = 0; i < nc && !m; i++) { Coalescer::Caller *x = c.callers[i].load(std::memory_order_acquire); if (x->id == r->caller) m = x; }
+            for (int i = 0; i < nc && !m; i++) { Coalescer::Caller *x = c.callers[i].load(std::memory_order_acquire); if (x->id.load(std::memory_order_relaxed) == r->caller) m = x; }
             std::lock_guard<std::mutex> lk(m->mu);
             m->q.erase(std::find(m->q.begin(), m->q.end(), r));  // (one of the first few: the requests of the thread's first call)
             owners.push_back(m);
@@ -1238,6 +1268,14 @@ int co_submit_many(Ctx &ctx, const std::vector<CoReq *> &rs) {
             if (c.depth.load(std::memory_order_relaxed) > 0) {
                 const int rc = co_defer(ctx, rs);
                 if (rc >= 0) return rc;  // (-1: deferred mode was switched off while this call waited: it goes the blocking way)
+                if (rc == -2) {          // no record for this thread: its launches go out directly, one request at a time
+                    Scope sc(&ctx);
+                    for (CoReq *q : rs) {
+                        ctx.arena_reset();
+                        TRY(q->run(q->ops.data(), q->nb));
+                    }
+                    return HE_OK;
+                }
             }
             lk.lock();
             while (c.stop) {  // a dispatcher that is being stopped still launches what it holds: stay out of its way
@@ -2582,6 +2620,15 @@ int he_ctx_set_deferred(he_handle h, int depth) {
     }
     co.depth = depth;
     return HE_OK;
+}
+// a request whose launch fails after it was accepted (tests: where does the failure surface in each mode of the queue?)
+int he_debug_queue_inject_failure(he_handle h) {
+    GET(c, Ctx, h, T_CTX);
+    CoReq q;
+    q.op = 31; q.obj = c.get();
+    q.keep = {c};
+    q.run = [](const View *, int) -> int { return fail(HE_EDEVICE, "injected launch failure"); };
+    return co_dispatch(*c, 1, q);
 }
 int he_debug_queue_op_stats(he_handle h, uint64_t out[64]) {
     GET(c, Ctx, h, T_CTX);

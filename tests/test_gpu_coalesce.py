@@ -530,3 +530,63 @@ def test_handles_of_a_few_entries_join_the_queue(ctx, deferred):
     w = oev.CKKSMulRelin(np.stack(x[0]), np.stack(x[1]), orlk, True)
     sub = O.Ring(N, q)
     assert np.array_equal(ref[1][0][0][0], sub.binop("Add", w[0], x[1][0]))
+
+
+def test_where_a_failed_launch_surfaces(ctx):
+    """The contract of include/hering.h: a launch that fails after its call was accepted is returned by the call itself in the queue's
+    default mode, and by the next Sync() under deferred submission (the call has returned by then); the failure is reported once."""
+    from lattigo_amd._lib import load, check, HeringError
+    L = load()
+    ctx.SetCoalescing(8, 100)
+    with pytest.raises(HeringError, match="injected launch failure"):
+        check(L.he_debug_queue_inject_failure(ctx.h))
+    ctx.sync()
+    ctx.SetDeferred(4)
+    check(L.he_debug_queue_inject_failure(ctx.h))  # accepted: HE_OK
+    with pytest.raises(HeringError, match="injected launch failure.*deferred"):
+        ctx.sync()
+    ctx.sync()  # reported once
+    ctx.SetDeferred(0)
+    ctx.sync()
+
+
+def test_deferred_calls_survive_teardown_and_thread_churn():
+    """A context of its own: deferred calls from short-lived threads (each leaves its record to the next new thread), polynomials
+    freed while their requests are pending, and the context destroyed with requests still in the queue -- everything filed is
+    launched first, nothing hangs, results are the direct calls' words."""
+    import gc
+    c2 = la.Context(0)
+    logN, nq, np_ = 12, 4, 1
+    q, p = _chain(logN, nq, np_)
+    pr = Pair(c2, logN, nq, np_, qmods=q, pmods=p)
+    N, rng = 1 << logN, rng_for(4242)
+    c2.SetCoalescing(16, 200)
+    c2.SetDeferred(4)
+    a = [np.stack([uniform_poly(rng, q, N)]) for _ in range(6)]
+    want = [pr.oQ.binop("Add", x[0], x[0]) for x in a]
+    got = [None] * 6
+    for wave in range(5):  # 30 threads over the context's life, six at a time
+        def caller(k):
+            def f():
+                x = la.Poly(pr.gQ, nq).upload(a[k])
+                y = la.Poly(pr.gQ, nq)
+                for _ in range(12):
+                    t = la.Poly(pr.gQ, nq)   # a temporary freed while its request may still be pending
+                    pr.gQ.Add(x, x, t)
+                    pr.gQ.Add(x, x, y)
+                    del t
+                got[k] = y
+            return f
+        _run_threads([caller(k) for k in range(6)])
+        c2.sync()
+        for k in range(6):
+            assert np.array_equal(got[k].get(), want[k]), (wave, k)
+    st = c2.CoalescingStats()
+    assert st["calls"] == 5 * 6 * 24 and st["launches"] < st["calls"], st
+    # file more and tear everything down without a sync
+    x = la.Poly(pr.gQ, nq).upload(a[0])
+    outs = [la.Poly(pr.gQ, nq) for _ in range(8)]
+    for o in outs:
+        pr.gQ.Add(x, x, o)
+    del outs, x, got, pr, c2
+    gc.collect()
