@@ -590,3 +590,62 @@ def test_deferred_calls_survive_teardown_and_thread_churn():
         pr.gQ.Add(x, x, o)
     del outs, x, got, pr, c2
     gc.collect()
+
+
+def test_switching_modes_under_load(ctx):
+    """Callers keep issuing dependent chains while the main thread switches deferred submission off and on: a call caught by the switch
+    goes the other way (the dispatcher launches what it holds before it stops; calls made meanwhile wait for that), order per thread
+    is kept, nothing hangs.  Every chain's result equals the direct calls' words."""
+    import time
+    from lattigo_amd._lib import HeringError
+    logN, nq, np_ = 12, 4, 1
+    q, p = _chain(logN, nq, np_)
+    pr = Pair(ctx, logN, nq, np_, qmods=q, pmods=p)
+    N, rng = 1 << logN, rng_for(777)
+    K, M = 6, 150
+    a = [uniform_poly(rng, q, N) for _ in range(K)]
+    sub = O.Ring(N, q)
+
+    def chain(k, x, y):
+        # y <- x; then M times y <- y + x (in place: each call depends on the one before), a Neg in between every 10 calls
+        y.CopyLvl(nq - 1, x)
+        for i in range(M):
+            pr.gQ.Add(y, x, y)
+            if i % 10 == 9:
+                pr.gQ.unop("Neg", y, y)
+        return y
+
+    want = []
+    for k in range(K):
+        w = a[k].copy()
+        for i in range(M):
+            w = sub.binop("Add", w, a[k])
+            if i % 10 == 9:
+                w = sub.unop("Neg", w)
+        want.append(w)
+    ctx.SetCoalescing(16, 100)
+    xs = [la.Poly(pr.gQ, nq).upload(a[k]) for k in range(K)]
+    ys = [la.Poly(pr.gQ, nq) for _ in range(K)]
+    done = threading.Event()
+
+    def toggler():
+        d = 0
+        while not done.is_set():
+            d = 0 if d else 4
+            try:
+                ctx.SetDeferred(d)
+            except HeringError:
+                pass  # "calls are in flight": a leader of the default mode is launching right now -- try again next time
+            time.sleep(0.002)
+
+    t = threading.Thread(target=toggler)
+    t.start()
+    try:
+        for rep in range(3):
+            _run_threads([(lambda k=k: chain(k, xs[k], ys[k])) for k in range(K)])
+            ctx.sync()
+            for k in range(K):
+                assert np.array_equal(ys[k].get(), want[k]), (rep, k)
+    finally:
+        done.set()
+        t.join()
