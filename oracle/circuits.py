@@ -741,9 +741,16 @@ def _cfrac(c):
 class CKKSCtEvaluator:
     """schemes/ckks/evaluator.go:42-135, 221-424, 477-515, 570-760, 875-940 on numpy ciphertexts"""
 
-    def __init__(self, ev: O.Evaluator, rlk=None):
+    def __init__(self, ev: O.Evaluator, rlk=None, default_scale=None):
         self.ev, self.rlk, self.ringQ, self.t = ev, rlk, ev.ringQ, None
         self.Q = [int(q) for q in ev.ringQ.moduli]
+        # Parameters.EncodingPrecision (schemes/ckks/params.go:185-195): log2scale := math.Log2(DefaultScale().Float64());
+        # 53 when log2scale <= 53, else uint(log2scale)
+        self.EncodingPrecision = 53
+        if default_scale is not None:
+            import math
+            l2 = math.log2(float(default_scale))
+            self.EncodingPrecision = 53 if l2 <= 53 else int(l2)
 
     NewCiphertext = BGVCtEvaluator.NewCiphertext
     CopyNew = BGVCtEvaluator.CopyNew
@@ -751,8 +758,6 @@ class CKKSCtEvaluator:
     MulNew = BGVCtEvaluator.MulNew
     MulRelinNew = BGVCtEvaluator.MulRelinNew
     Relinearize = BGVCtEvaluator.Relinearize
-
-    EncodingPrecision = 53  # Parameters.EncodingPrecision (schemes/ckks/params.go:185-195)
 
     def _rns(self, level, scale, c):
         re, im = _cfrac(c)

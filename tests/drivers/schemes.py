@@ -405,19 +405,29 @@ def _as_complex_fraction(c):
     return Fraction(c), Fraction(0)
 
 
+def encoding_precision(default_scale) -> int:
+    """Parameters.EncodingPrecision (schemes/ckks/params.go:185-195): `log2scale := math.Log2(DefaultScale().Float64())`; 53 when
+    that is <= 53, else uint(log2scale) (truncation).  default_scale None: parameters whose scale is at most 2^53."""
+    import math
+    if default_scale is None:
+        return 53
+    l2 = math.log2(float(default_scale))
+    return 53 if l2 <= 53 else int(l2)
+
+
 class CKKSCiphertextEvaluator:
     """schemes/ckks Evaluator at the rlwe.Ciphertext level (one level per rescaling): Add / Sub (ciphertext or constant),
     Mul / MulRelin (ciphertext or constant), MulThenAdd (constant), Relinearize, Rescale
     (schemes/ckks/evaluator.go:42-135, 221-424, 477-515, 570-760, 875-940)."""
 
-    def __init__(self, evaluator: Evaluator, rlk: EvaluationKey | None = None):
+    def __init__(self, evaluator: Evaluator, rlk: EvaluationKey | None = None, default_scale=None):
         self.eval, self.rlk, self.ringQ = evaluator, rlk, evaluator.ringQ
         self.Q = [int(q) for q in self.ringQ.ModuliChain()]
         self.t = None
         # RootsForward[1] of every limb as a plain integer: the square root of -1 that evaluateWithScalar uses (:417)
         self.imag_unit = [int(self.ringQ.roots(i)[1]) * pow(1 << 64, -1, q) % q for i, q in enumerate(self.Q)]
-        # Parameters.EncodingPrecision (schemes/ckks/params.go:185-195): max(53, floor(log2(DefaultScale))); settable
-        self.EncodingPrecision = 53
+        # Parameters.EncodingPrecision (schemes/ckks/params.go:185-195): 53, or floor(log2(DefaultScale)) when that is larger
+        self.EncodingPrecision = encoding_precision(default_scale)
 
     NewCiphertext = BGVCiphertextEvaluator.NewCiphertext
     _new_result = BGVCiphertextEvaluator._new_result

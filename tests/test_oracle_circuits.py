@@ -556,3 +556,31 @@ def test_scale_rounding_helpers_agree_and_are_correctly_rounded():
         assert abs(decimal.Decimal(s.numerator) / decimal.Decimal(s.denominator) / d - 1) < decimal.Decimal(2) ** -127
     for v in (Fraction(4), Fraction(9, 4), Fraction(1 << 200), Fraction(1, 1 << 78), Fraction(((1 << 128) - 1) ** 2)):
         assert _bigfloat_sqrt(v) ** 2 == v == _sqrt_bits(v) ** 2  # exact roots stay exact
+
+
+def test_encoding_precision_follows_the_default_scale():
+    """Parameters.EncodingPrecision (schemes/ckks/params.go:185-195): 53 bits, or floor(log2(DefaultScale)) when the scale is above
+    2^53 -- a constant that is not a float64 (1/3, an integer above 2^53) is then held at more bits before it meets the scale
+    (bigComplexToRNSScalar, schemes/ckks/scaling.go:10-43).  The oracle's evaluator and the product driver's helper derive the same
+    precision and encode the same integers."""
+    from fractions import Fraction
+    import importlib
+    q, p = O.GenModuli(10, [55, 45], [55])
+    ev = O.Evaluator(O.Ring(N, q), O.Ring(N, p))
+    assert OC.CKKSCtEvaluator(ev, None).EncodingPrecision == 53
+    assert OC.CKKSCtEvaluator(ev, None, default_scale=Fraction(1 << 45)).EncodingPrecision == 53
+    assert OC.CKKSCtEvaluator(ev, None, default_scale=Fraction(1 << 53)).EncodingPrecision == 53
+    assert OC.CKKSCtEvaluator(ev, None, default_scale=Fraction((1 << 60) + 12345)).EncodingPrecision == 60
+    assert OC.CKKSCtEvaluator(ev, None, default_scale=Fraction(3 << 59)).EncodingPrecision == 60  # uint(60.58) truncates
+    third, scale = Fraction(1, 3), Fraction(1 << 90)
+    lo, hi = OC._const_to_int(third, scale, 53), OC._const_to_int(third, scale, 60)
+    assert lo != hi and abs(hi - scale / 3) < abs(lo - scale / 3)
+    assert abs(Fraction(hi) / scale - third) < Fraction(1, 1 << 60) and abs(Fraction(lo) / scale - third) > Fraction(1, 1 << 58)
+    big = (1 << 57) + 1  # not a float64: lost at 53 bits, exact at 60
+    assert OC._const_to_int(big, Fraction(1 << 10), 60) == big << 10 and OC._const_to_int(big, Fraction(1 << 10), 53) != big << 10
+    S = importlib.import_module("drivers.schemes")  # (the product driver's restatement: pure host code in this function)
+    for sc in (None, Fraction(1 << 45), Fraction((1 << 60) + 12345), Fraction(3 << 59)):
+        want = OC.CKKSCtEvaluator(ev, None, default_scale=sc).EncodingPrecision
+        assert S.encoding_precision(sc) == want
+        for c in (third, Fraction(big), Fraction(-7, 5)):
+            assert S._big_float_scalar(c, scale, want) == OC._const_to_int(c, scale, want)
