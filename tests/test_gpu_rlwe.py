@@ -1032,16 +1032,20 @@ def test_random_scheme_level_calls(ctx):
         fz.be_case(ctx, rng)
 
 
-def test_random_calls_with_the_queue_on(ctx):
-    """The same three generators (another seed) with the context's submission queue switched on: every batch-1 draw is filed as a
-    request and served as a lone caller's batch (closure over its own views, no entry table), every larger batch launches directly
-    -- the dispatch every entry point takes since round 5 must not change a word."""
+@pytest.mark.parametrize("deferred", [0, 6])
+def test_random_calls_with_the_queue_on(ctx, deferred):
+    """The same three generators (another seed) with the context's submission queue switched on: every draw over handles of fewer
+    than max_batch entries is filed as a request and served as a lone caller's batch (closure over its own views, no entry table),
+    every larger batch launches directly -- the dispatch every entry point takes since round 5 must not change a word.  deferred:
+    the calls return once filed and the context's dispatcher thread launches them in the order this thread made them; the
+    generators' downloads wait for the thread's pending requests."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_shapes", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "fuzz_shapes.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     rng = np.random.Generator(np.random.PCG64(20260925))
     ctx.SetCoalescing(8, 50)
+    ctx.SetDeferred(deferred)
     try:
         s0 = ctx.CoalescingStats()
         for _ in range(100):
