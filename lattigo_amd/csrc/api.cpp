@@ -1398,6 +1398,8 @@ int upload_tables(const std::vector<const SubRingHost *> &subs, int N, ModConst 
 
 }  // namespace
 
+static int ctx_set_coalescing(const std::shared_ptr<Ctx> &c, int max_batch, int window_us, const char *who);
+
 extern "C" {
 
 const char *he_last_error(void) { return g_err.c_str(); }
@@ -1429,6 +1431,16 @@ int he_ctx_create(int device_id, he_handle *out) {
         else (void)hipGetLastError();
     }
     *out = reg(c);
+    // HERING_QUEUE_DEFAULT="max_batch,window_us[,depth]" (soak runs): every context starts with its submission queue on (and, with a
+    // depth, in deferred mode) -- the whole test suite then exercises the queued paths with single-threaded callers
+    if (const char *qd = getenv("HERING_QUEUE_DEFAULT")) {
+        int mb = 0, win = 0, depth = 0;
+        const int n = sscanf(qd, "%d,%d,%d", &mb, &win, &depth);
+        if (n >= 2 && mb > 1) {
+            TRY(ctx_set_coalescing(c, mb, win, "HERING_QUEUE_DEFAULT"));
+            if (n >= 3 && depth > 0) TRY(he_ctx_set_deferred(*out, depth));
+        }
+    }
     return HE_OK;
 }
 int he_ctx_destroy(he_handle h) {
@@ -4436,7 +4448,7 @@ int he_prof_end_bytes(he_handle hctx, int max_kernels, int *counts, float *total
 }
 int he_alg_bytes(he_handle hctx, int reset, double out[2]) {
     GET(c, Ctx, hctx, T_CTX);
-    std::lock_guard<std::mutex> lk(c->mu);
+    Scope sc(c.get());  // (deferred submission: the calling thread's pending requests are launched -- and accounted -- first)
     if (out) { out[0] = c->alg_bytes[0]; out[1] = c->alg_bytes[1]; }
     if (reset) c->alg_bytes[0] = c->alg_bytes[1] = 0.0;
     return HE_OK;
