@@ -332,6 +332,19 @@ int main(int argc, char **argv) {
     for (int logN : {10, 13, 15}) test_ring(ctx, logN);
     for (int logN : {11, 13}) test_rlwe(ctx, logN);
     ctx.Sync();
+    // the same checks through the context's submission queue, in its default mode and with deferred submission (every call of
+    // the mirror is then filed and launched by the context's dispatcher thread; downloads wait for the caller's pending requests)
+    const int direct = g_checks;
+    ctx.SetCoalescing(16, 30);
+    test_ring(ctx, 13);
+    test_rlwe(ctx, 13);
+    ctx.SetDeferred(8);
+    test_ring(ctx, 13);
+    test_rlwe(ctx, 11);
+    ctx.Sync();
+    ctx.SetDeferred(0);
+    ctx.SetCoalescing(0, 0);
+    std::printf("(%d of the checks through the submission queue)\n", g_checks - direct);
     std::printf("PASS: %d checks\n", g_checks);
     return 0;
 }
