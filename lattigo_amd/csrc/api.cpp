@@ -92,7 +92,7 @@ enum CoOp {
     CO_MUL_RELIN = 0, CO_GADGET_PRODUCT, CO_RELINEARIZE, CO_AUTOMORPHISM,
     CO_NTT, CO_EW, CO_EW_DOUBLE, CO_SHIFT, CO_RESCALE, CO_GATHER, CO_AUTO_COEFF, CO_MODUP, CO_MODDOWN_BE,
     CO_DECOMPOSE_SPLIT, CO_DECOMPOSE_NTT, CO_GP_LAZY, CO_GP_HOISTED_LAZY, CO_GP_HOISTED, CO_MODDOWN, CO_EVAL_MODDOWN,
-    CO_AUTO_HOISTED, CO_AUTO_HOISTED_LAZY, CO_CENTERED_LIFT, CO_DECOMP_FILL, CO_LINTRANS, CO_MUL, CO_COPY
+    CO_AUTO_HOISTED, CO_AUTO_HOISTED_LAZY, CO_CENTERED_LIFT, CO_DECOMP_FILL, CO_LINTRANS, CO_MUL, CO_COPY, CO_ZERO
 };
 struct CoReq {
     // ---- key: requests are batched together only when all of this matches
@@ -893,7 +893,7 @@ void co_lead(Ctx &ctx, Coalescer &c, std::unique_lock<std::mutex> &lk, CoReq &mi
             if (!c.free_events.empty()) { e = c.free_events.back(); c.free_events.pop_back(); }
             else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
         }
-        c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
+        if (batch[0]->op != CO_ZERO) { c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size()); }  // (operator calls: not the zero fills of allocations)
         const auto g1 = clock::now();
         c.dbg[3] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(g1 - g0).count();
         lk.unlock();
@@ -1195,7 +1195,7 @@ void co_dispatcher_main(Ctx *ctx) {
             };
             e = take_event();
             e_begin = timing ? take_event() : nullptr;
-            c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size());
+            if (batch[0]->op != CO_ZERO) { c.n_calls += batch.size(); c.n_launches++; c.n_max = std::max<uint64_t>(c.n_max, batch.size()); }  // (operator calls: not the zero fills of allocations)
             c.dbg[11]++;
         }
         if (e_begin && hipEventRecord(e_begin, ctx->stream) != hipSuccess) (void)hipGetLastError();
@@ -1610,7 +1610,28 @@ static int poly_alloc(he_handle hring, int n_limbs, int batch, bool zero, he_han
         p->d = nullptr;
         return fail(HE_ENOMEM, "he_poly_alloc: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
-    if (zero || poison) {
+    Ctx &cx = *r->ctx;
+    if (zero && !poison && n_limbs <= kMaxLimbs && batch < cx.co->max_batch.load(std::memory_order_relaxed) && !cx.capturing) {
+        // queue on: the zero fills of concurrent callers' fresh polynomials are one launch over an entry table like any other
+        // request (16 callers replaying a bootstrap issued 44 memsets each per bootstrap, every one under the context's lock)
+        const std::shared_ptr<Ctx> ctx = r->ctx;
+        const int N = r->N;
+        CoReq q;
+        q.op = CO_ZERO; q.obj = ctx.get(); q.par[0] = n_limbs; q.par[1] = N;
+        q.ops = {p->view()};
+        q.keep = {p};
+        q.run = [ctx, n_limbs, N](const View *v, int B) -> int {
+            if (!v[0].tab) {  // one request: its entries are contiguous
+                HIP_TRY(hipMemsetAsync(v[0].p, 0, (size_t)B * n_limbs * N * 8, ctx->stream));
+                return HE_OK;
+            }
+            RingDev dev{};
+            dev.N = N;
+            HIP_TRY(launch_ew(dev, ident_tab(n_limbs), EW_ZERO, v[0], v[0], v[0], B, nullptr, nullptr, ctx->stream));
+            return HE_OK;
+        };
+        TRY(co_dispatch(cx, batch, q));
+    } else if (zero || poison) {
         Scope sc(r->ctx.get(), NoFlush{});  // (no pending request can address a buffer that was in the cache)
         HIP_TRY(hipMemsetAsync(p->d, zero ? 0 : 0x5a, bytes, r->ctx->stream));
     }

@@ -139,6 +139,7 @@ enum EwOp {
     EW_MUL_MONT_THEN_ADD, EW_MUL_MONT_THEN_ADD_LAZY, EW_MUL_MONT_LAZY_THEN_ADD_LAZY,
     EW_MUL_MONT_THEN_SUB, EW_MUL_MONT_THEN_SUB_LAZY, EW_MUL_MONT_LAZY_THEN_SUB_LAZY,
     EW_NEG = 100, EW_REDUCE, EW_REDUCE_LAZY, EW_MFORM, EW_MFORM_LAZY, EW_IMFORM, EW_COPY,
+    EW_ZERO,                       // 0 (no input read: the zero fill of a batch of fresh polynomials through an entry table)
     EW_ADD_SCALAR = 200,           // CRed(x + s)
     EW_SUB_SCALAR,                 // CRed(x + q - s)
     EW_MUL_SCALAR_MONT,            // MRed(x, s)

@@ -2360,6 +2360,7 @@ __device__ __forceinline__ uint64_t ew_apply(uint64_t x, uint64_t y, uint64_t z,
     else if constexpr (OP == EW_MFORM_LAZY) return mform_lazy(x, q, m.brc0, m.brc1);
     else if constexpr (OP == EW_IMFORM) return imform(x, q, qinv);
     else if constexpr (OP == EW_COPY) return x;
+    else if constexpr (OP == EW_ZERO) return 0;
     else if constexpr (OP == EW_ADD_SCALAR) return cred(x + s, q);
     else if constexpr (OP == EW_SUB_SCALAR) return cred(x + q - s, q);
     else if constexpr (OP == EW_MUL_SCALAR_MONT) return mred(x, s, q, qinv);
@@ -2388,10 +2389,11 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
     if (j >= A.N) return;
     const int yy = blockIdx.y;
     ModConst m{};
-    if constexpr (OP != EW_COPY) m = A.mc[A.mod[yy]];  // (a copy needs no modulus: he_poly_copy launches it without a ring)
+    if constexpr (OP != EW_COPY && OP != EW_ZERO) m = A.mc[A.mod[yy]];  // (a copy needs no modulus: he_poly_copy launches it without a ring)
     const uint64_t s2 = A.s2[yy], s = (A.dbl && j >= (A.N >> 1)) ? s2 : A.s[yy];
     const size_t bz = blockIdx.z;
-    const ulonglong2 xv = ldnt2(A.x + voff(A.x_tab, A.x_bs, bz) + (size_t)A.x_limb[yy] * A.N + j);
+    ulonglong2 xv = make_ulonglong2(0, 0);
+    if constexpr (OP != EW_ZERO) xv = ldnt2(A.x + voff(A.x_tab, A.x_bs, bz) + (size_t)A.x_limb[yy] * A.N + j);
     ulonglong2 yv = make_ulonglong2(0, 0), zv = make_ulonglong2(0, 0);
     if constexpr (ew_reads_y<OP>())
         yv = ldnt2(A.y + voff(A.y_tab, A.y_bs, bz) + (size_t)A.y_limb[yy] * A.N + j);
@@ -2455,7 +2457,7 @@ static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, V
                       op == EW_MUL_MONT_THEN_ADD_LAZY || op == EW_MUL_MONT_LAZY_THEN_ADD_LAZY || op == EW_MUL_MONT_THEN_SUB ||
                       op == EW_MUL_MONT_THEN_SUB_LAZY || op == EW_MUL_MONT_LAZY_THEN_SUB_LAZY || op == EW_MUL_SCALAR_MONT_THEN_ADD ||
                       op == EW_SUBMUL2Q_THEN_ADD;
-    ProfScope ps(K_EW, s, (2.0 + ew_y + ew_z) * tab.n * batch * (double)r.N * 8.0);
+    ProfScope ps(K_EW, s, ((op == EW_ZERO ? 1.0 : 2.0) + ew_y + ew_z) * tab.n * batch * (double)r.N * 8.0);
 #define HE_EW_CASE(O) \
     case O: hipLaunchKernelGGL((ew_kernel<O>), grid, block, 0, s, A); break;
     switch (op) {
@@ -2466,7 +2468,7 @@ static hipError_t launch_ew_impl(const RingDev &r, const LimbTab &tab, int op, V
         HE_EW_CASE(EW_MUL_MONT_LAZY_THEN_ADD_LAZY) HE_EW_CASE(EW_MUL_MONT_THEN_SUB)
         HE_EW_CASE(EW_MUL_MONT_THEN_SUB_LAZY) HE_EW_CASE(EW_MUL_MONT_LAZY_THEN_SUB_LAZY)
         HE_EW_CASE(EW_NEG) HE_EW_CASE(EW_REDUCE) HE_EW_CASE(EW_REDUCE_LAZY) HE_EW_CASE(EW_MFORM)
-        HE_EW_CASE(EW_MFORM_LAZY) HE_EW_CASE(EW_IMFORM) HE_EW_CASE(EW_COPY)
+        HE_EW_CASE(EW_MFORM_LAZY) HE_EW_CASE(EW_IMFORM) HE_EW_CASE(EW_COPY) HE_EW_CASE(EW_ZERO)
         HE_EW_CASE(EW_ADD_SCALAR) HE_EW_CASE(EW_SUB_SCALAR) HE_EW_CASE(EW_MUL_SCALAR_MONT)
         HE_EW_CASE(EW_MUL_SCALAR_MONT_THEN_ADD) HE_EW_CASE(EW_ADD_SCALAR_LAZY)
         HE_EW_CASE(EW_SUB_THEN_MUL_SCALAR_MONT_2Q) HE_EW_CASE(EW_DIVROUND_COEFF) HE_EW_CASE(EW_SUBMUL2Q_THEN_ADD)
