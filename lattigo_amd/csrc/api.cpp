@@ -166,7 +166,7 @@ struct Coalescer {
     // deferred mode: [8] us the dispatcher paused because it was four batches ahead of the device, [9] us it waited for callers
     // while the device had two or more batches queued (free), [10] us it waited for callers with the device running dry, [11] batches
     // [12] (HERING_QUEUE_TIMING=1 only) device microseconds between the first and the last launch of the batches, as the stream ran them
-    uint64_t dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::atomic<uint64_t> dbg[16] = {};  // (the dispatcher adds to them outside the queue's lock)
     uint64_t op_launches[32] = {0}, op_calls[32] = {0};  // per operation (CoOp): batches launched, requests served (he_debug_queue_op_stats)
     std::deque<hipEvent_t> inflight_begin;  // HERING_QUEUE_TIMING=1: the event recorded before each batch of `inflight`
     // ---- deferred submission (he_ctx_set_deferred): a call files its request and RETURNS; a dispatcher thread of the context
