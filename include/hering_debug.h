@@ -47,7 +47,8 @@ int he_ctx_coalescing_stats(he_handle ctx, uint64_t out[4]);  /* the same counte
  * out[7] = allocations the context's buffer cache could not serve (hipMalloc calls); deferred submission (he_ctx_set_deferred):
  * out[8] = microseconds the dispatcher paused because it was four batches ahead of the device, out[9] / out[10] = microseconds it
  * waited for callers while the device had at least two batches queued (free) / while the device was running dry, out[11] = batches;
- * out[12] (HERING_QUEUE_TIMING=1 only) = device microseconds spent inside the dispatcher's batches; out[13..15] reserved */
+ * out[12] (HERING_QUEUE_TIMING=1 only) = device microseconds spent inside the dispatcher's batches; out[13] / out[14] = entry
+ * tables filled by a launch / reused from one of the context's table slots (same offsets as a recent batch); out[15] reserved */
 int he_debug_queue_counters(he_handle ctx, uint64_t out[16]);
 /* per operation of the queue (the CoOp numbering of csrc/api.cpp): out[2 i] = batches launched, out[2 i + 1] = requests served */
 int he_debug_queue_op_stats(he_handle ctx, uint64_t out[64]);

@@ -151,8 +151,15 @@ struct Coalescer {
     // read without the lock by every single-ciphertext call that asks "is the queue on?": atomic.  0 / 1 = off.
     std::atomic<int> max_batch{0};
     int window_us = 0;
-    size_t *d_tab = nullptr;  // [rows][B] entry offsets; one table is enough (stream order, see launch_tab_fill)
-    size_t tab_words = 0;     // capacity of d_tab: a batch whose table does not fit is served one by one
+    // entry tables: kTabSlots slots of [rows][B] word offsets in one allocation.  A batch whose offsets equal those of a slot
+    // (callers that loop over the same polynomials: the same table every round) reuses it without a fill launch; otherwise the
+    // least recently used slot is refilled -- in stream order, after the launches that read its old contents.
+    static constexpr int kTabSlots = 16;
+    size_t *d_tab = nullptr;
+    size_t tab_words = 0;     // capacity of ONE slot: a batch whose table does not fit is served one by one
+    struct TabSlot { std::vector<size_t> vals; uint64_t used = 0; };
+    TabSlot tab_slot[kTabSlots];
+    uint64_t tab_clock = 0, tab_hits = 0, tab_fills = 0;  // (under the context's lock, like the launches)
     std::deque<hipEvent_t> inflight;  // one event per launched batch, oldest first
     std::vector<hipEvent_t> free_events;
     uint64_t n_calls = 0, n_launches = 0, n_max = 0, n_fallback = 0;  // he_ctx_coalescing_stats
@@ -795,13 +802,27 @@ int co_run(Ctx &ctx, Coalescer &c, const std::vector<CoReq *> &batch, hipEvent_t
         std::vector<View> v(ns);
         for (size_t s = 0; s < ns; s++) {
             uint64_t *base = r0.ops[s].p;
-            if (!base) { v[s] = View{nullptr, 0}; continue; }
+            if (!base) continue;
             int e = 0;
             for (const CoReq *r : batch)
                 for (int i = 0; i < r->nb; i++, e++) vals[s * B + e] = (size_t)(r->ops[s].p + (size_t)i * r->ops[s].bstride - base);
-            v[s] = View{base, 0, c.d_tab + s * B};
         }
-        hipError_t e = launch_tab_fill(c.d_tab, vals.data(), (int)vals.size(), ctx.stream);
+        // a slot that already holds these offsets, or the least recently used one
+        int slot = -1, lru = 0;
+        for (int i = 0; i < Coalescer::kTabSlots; i++) {
+            if (c.tab_slot[i].vals == vals) { slot = i; break; }
+            if (c.tab_slot[i].used < c.tab_slot[lru].used) lru = i;
+        }
+        hipError_t e = hipSuccess;
+        if (slot < 0) {
+            slot = lru;
+            e = launch_tab_fill(c.d_tab + (size_t)slot * c.tab_words, vals.data(), (int)vals.size(), ctx.stream);
+            if (e == hipSuccess) { c.tab_slot[slot].vals = vals; c.tab_fills++; }
+            else c.tab_slot[slot].vals.clear();
+        } else c.tab_hits++;
+        c.tab_slot[slot].used = ++c.tab_clock;
+        size_t *tab = c.d_tab + (size_t)slot * c.tab_words;
+        for (size_t s = 0; s < ns; s++) v[s] = r0.ops[s].p ? View{r0.ops[s].p, 0, tab + s * B} : View{nullptr, 0};
         if (e != hipSuccess) rc = fail(HE_EDEVICE, "launch_tab_fill: %s", hipGetErrorString(e));
         else rc = r0.run(v.data(), B);
         const std::string msg = rc ? g_err : std::string();
@@ -2612,8 +2633,9 @@ static int ctx_set_coalescing(const std::shared_ptr<Ctx> &c, int max_batch, int 
         HIP_TRY(hipStreamSynchronize(c->stream));  // launches that read the old table
         if (co.d_tab) HIP_TRY(hipFree(co.d_tab));
         co.d_tab = nullptr; co.tab_words = 0;
-        HIP_TRY(hipMalloc((void **)&co.d_tab, words * sizeof(size_t)));
+        HIP_TRY(hipMalloc((void **)&co.d_tab, words * sizeof(size_t) * Coalescer::kTabSlots));
         co.tab_words = words;
+        for (auto &sl : co.tab_slot) { sl.vals.clear(); sl.used = 0; }
     }
     co.max_batch = max_batch;
     co.window_us = window_us;
@@ -2676,6 +2698,7 @@ int he_debug_queue_counters(he_handle h, uint64_t out[16]) {
     std::lock_guard<std::mutex> lk(c->co->mu);
     for (int i = 0; i < 16; i++) out[i] = c->co->dbg[i];
     out[7] = c->pool_misses.load(std::memory_order_relaxed);
+    out[13] = c->co->tab_fills; out[14] = c->co->tab_hits;  // (entry tables filled / reused; written under the context's lock: a glance)
     return HE_OK;
 }
 int he_ctx_coalescing_stats(he_handle h, uint64_t out[4]) {

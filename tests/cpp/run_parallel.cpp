@@ -127,10 +127,10 @@ int main(int argc, char **argv) {
             uint64_t dbg[16] = {0};
             he_debug_queue_counters(ctx.h(), dbg);
             std::fprintf(stderr, "queue counters: everyone %llu timeout %llu full %llu | gather %llu us launch %llu us | ahead-cap %llu us, "
-                                 "waiting (device busy) %llu us, waiting (device dry) %llu us, batches %llu | wall %.0f us\n",
+                                 "waiting (device busy) %llu us, waiting (device dry) %llu us, batches %llu | tables filled %llu reused %llu | wall %.0f us\n",
                          (unsigned long long)dbg[0], (unsigned long long)dbg[1], (unsigned long long)dbg[2], (unsigned long long)dbg[3],
                          (unsigned long long)dbg[4], (unsigned long long)dbg[8], (unsigned long long)dbg[9], (unsigned long long)dbg[10],
-                         (unsigned long long)dbg[11], dt * 1e6);
+                         (unsigned long long)dbg[11], (unsigned long long)dbg[13], (unsigned long long)dbg[14], dt * 1e6);
         }
         // parity of what was timed: EVERY caller's last result against the oracle, on the host's threads
         lo_ring *oQ = lo_ring_new(N, q.data(), nq), *oP = lo_ring_new(N, p.data(), np);
