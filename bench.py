@@ -27,6 +27,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -697,6 +698,111 @@ def _program_calls(program):
         yield fn
 
 
+def gpu_clock(device_id=0):
+    """Current shader / memory clock of the GPU (MHz) and its power draw (W) from the driver's sysfs tables of THE device this rank
+    runs on (found through its PCI bus id: the node's other GPUs are listed in sysfs too): pp_dpm_sclk / pp_dpm_mclk, the line
+    marked '*' is the level in use.  Read before, during and after the timed region so that box-to-box and power-management
+    effects (quiet data clocks ~15 % higher) can be told from kernel changes.  None where the files are absent."""
+    import glob
+    import lattigo_amd as la
+    if device_id not in _CLOCK_DIR:
+        d = None
+        bus = la.device_pci_bus_id(device_id)
+        if bus and os.path.exists(f"/sys/bus/pci/devices/{bus}/pp_dpm_sclk"):
+            d = f"/sys/bus/pci/devices/{bus}"
+        _CLOCK_DIR[device_id] = (d, bus)
+    d, bus = _CLOCK_DIR[device_id]
+    if d is None:
+        return None
+    out = {}
+    for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+        try:
+            levels = [ln for ln in open(os.path.join(d, name)).read().splitlines() if ln.strip()]
+            cur = [ln for ln in levels if ln.rstrip().endswith("*")] or levels[-1:]
+            out[key] = float(re.search(r"(\d+(?:\.\d+)?)\s*[Mm][Hh]z", cur[0]).group(1))
+        except (OSError, AttributeError, IndexError, ValueError):
+            out[key] = None
+    for key, pat, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6), ("temp_c", "temp1_input", 1e-3)):
+        try:
+            if key not in out:
+                out[key] = float(open(glob.glob(os.path.join(d, "hwmon", "hwmon*", pat))[0]).read()) * scale
+        except (OSError, IndexError, ValueError):
+            pass
+    out["pci_bus_id"] = bus
+    return out
+
+
+_CLOCK_DIR = {}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1) and hand over -- so that --gpus means N however the script is invoked.  A node with
+    fewer than N GPUs is refused (exit 2) unless HERING_FORCE_DEVICE (test hook: ranks share one GPU) is set."""
+    import socket
+    import lattigo_amd as la
+    have = la.device_count()
+    if have < args.gpus and "HERING_FORCE_DEVICE" not in os.environ:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} asked, this node has {have} GPU(s); no line printed\n")
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f"bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks ({' '.join(cmd[1:8])} ...)\n")
+    sys.stderr.flush()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
+# the other BASELINE configurations in the default line (`other_configs`): (workload, steps, warmup); c5's step is a whole
+# bootstrap trace of 16 ciphertexts (~0.18 s), so three timed steps keep the default run within minutes
+OTHER_CONFIGS = (("c2", 10, 2), ("c4", 10, 2), ("c5", 3, 1))
+
+
+def other_configs(args):
+    """BASELINE configs 2, 4 and 5 measured by the SAME script in child processes (one after the other, after the headline's own
+    context is gone): every entry of their timed batch verified against the oracle / the committed digest, their dominant kernel
+    timed by HIP events in that run.  Returns {workload: summary}; a child that fails is reported as {"error": ...} and makes the
+    run exit non-zero."""
+    import subprocess
+    out = {}
+    for wl, steps, warmup in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", wl, "--steps", str(steps), "--warmup", str(warmup),
+               "--no-b1", "--no-concurrent", "--no-ntt", "--no-cpu-baseline", "--no-other-configs"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.other_timeout)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if not lines:
+                out[wl] = {"error": f"exit {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+                continue
+            j = json.loads(lines[-1])
+        except Exception as e:  # noqa: BLE001 -- timeout, unparsable line
+            out[wl] = {"error": str(e)[-400:]}
+            continue
+        rf = j.get("roofline") or {}
+        valu = rf.get("valu") or {}
+        out[wl] = {
+            "metric": j["metric"], "value": j["value"], "unit": j["unit"], "steps": j["steps"], "warmup": j["warmup"],
+            "ms_per_step": j["ms_per_step"], "batch": j["config"].get("batch_per_gpu"), "workload": j["config"]["workload"],
+            "verified": j.get("verified"), "verified_detail": j.get("verified_detail"), "exit_code": r.returncode,
+            "roofline": {"kernel": rf.get("kernel"), "bound": rf.get("bound"), "achieved": rf.get("achieved"), "peak": rf.get("peak"),
+                         "unit": rf.get("unit"), "frac": rf.get("frac"), "avg_launch_ms": rf.get("avg_launch_ms"),
+                         "launches": rf.get("launches"), "alg_bytes_per_launch": rf.get("alg_bytes_per_launch"),
+                         "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
+                         "whole_op_frac": (rf.get("whole_op") or {}).get("frac"),
+                         "kernel_ms_per_step": dict(list((rf.get("kernel_ms_per_step") or {}).items())[:8])},
+            "valu": {"frac": valu.get("frac"), "instr_frac": (valu.get("instr") or {}).get("frac"),
+                     "modmul_equiv_per_op": valu.get("modmul_equiv_per_op"), "ideal_us_per_op": valu.get("ideal_us_per_op"),
+                     "achieved_us_per_op": valu.get("achieved_us_per_op")},
+            "gpu_clock": j.get("gpu_clock"), "accounting_problems": j.get("accounting_problems"),
+            "wall_s": time.perf_counter() - t0,
+        }
+    return out
+
+
 # default batches from sweeps on MI355X (round 3): c2 128 / 256 / 512 / 1024 / 2048: 204k / 223k / 243k / 257k / 263k (a logN = 14, 8-limb
 # ciphertext is small: the launches need the larger batch to fill the chip); c3 64 / 128 / 192 / 256 / 512: 33.9k / 36.6k / 37.5k /
 # 37.8k / 38.0k on one box (the persistent NTT+MAC kernel's tail shrinks with more items per workgroup; flat beyond 256);
@@ -757,7 +863,20 @@ def main():
                     help="N > 1: fail (exit 5) unless every rank runs on its own GPU, the RCCL communicator reaches all N ranks and every "
                          "rank's evaluation key equals rank 0's after the replication")
     ap.add_argument("--microbench", action="store_true", help="also report the modular-multiply probe")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default workload, one GPU: do not measure BASELINE configs 2, 4 and 5 into the line's `other_configs`")
+    ap.add_argument("--other-timeout", type=int, default=420, help="seconds a child run of `other_configs` may take")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and env_world == 0:
+        self_launch(args)  # does not return
+    if env_world not in (0, args.gpus):
+        # a line whose n_gpus differs from what was asked is never printed
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; no line printed\n")
+        sys.exit(2)
 
     from lattigo_amd.dist import ControlPlane
     cp = ControlPlane()  # gloo control plane only (barrier + MAX of the elapsed time); no data-path collective
@@ -792,13 +911,17 @@ def main():
     barrier()
     ctx.alg_bytes(reset=True)
     ctx.alg_valu(reset=True)
+    clock = {"before": gpu_clock(dev)}
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
         step()
+    clock["under_load"] = gpu_clock(dev)  # the steps are enqueued, the device is still running them (a sysfs read: microseconds)
     ev_ms = ctx.timer_stop()
     barrier()
     elapsed_rank = time.perf_counter() - t0
+    clock["after"] = gpu_clock(dev)
+    clock["source"] = "amdgpu sysfs of this rank's device: pp_dpm_sclk / pp_dpm_mclk (level in use), hwmon power / temperature"
     elapsed = cp.max_over_ranks(elapsed_rank)
     elapsed_min = -cp.max_over_ranks(-elapsed_rank)
     alg_trace = ctx.alg_bytes(reset=True)  # SURVEY 8(d) per-primitive bytes of the timed steps (key per entry, key per call)
@@ -847,6 +970,7 @@ def main():
     if args.no_kernel_timing:
         print(json.dumps({"metric": W["metric"], "value": value, "unit": W["unit"], "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "verified": verified, "roofline": None,
+                          "gpu_clock": clock,
                           "config": dict(W["config"])}), flush=True)
         cp.close()
         return
@@ -981,6 +1105,7 @@ def main():
         "config": cfg, "verified": verified, "verified_detail": vmsg,
         "hip_event_ms_per_step": ev_ms / args.steps,
         "rank_ms_per_step": {"min": elapsed_min / args.steps * 1e3, "max": elapsed / args.steps * 1e3},
+        "gpu_clock": clock,
         "ranks_seen": ranks_seen, "replicate_keys": args.replicate_keys,
         "multi_gpu_selftest": (None if world == 1 else ("ok" if not n_bad else f"FAILED on {int(n_bad)} rank(s): {multi_gpu_problems}")),
         "roofline": roofline,
@@ -1086,6 +1211,23 @@ def main():
             line["cpu_baseline"] = W["cpu"]()
         except Exception as e:  # the oracle is optional test infrastructure
             line["cpu_baseline"] = {"error": str(e)}
+    if world == 1 and args.workload == "c3" and not args.batch and not args.no_other_configs:
+        # the other BASELINE configurations, driver-visible: child runs of this script (their own context; this one's polynomials
+        # and keys are released first)
+        del W, step
+        import gc
+        gc.collect()
+        line["other_configs"] = other_configs(args)
+        if line.get("ntt"):
+            line["other_configs"]["ntt"] = {k: {kk: v[kk] for kk in ("batch", "limb_ntt_per_s", "limb_intt_per_s", "ms", "alg_GBs", "frac_of_hbm_peak")}
+                                            for k, v in line["ntt"].items()}
+        for wl, r in line["other_configs"].items():
+            if wl == "ntt":
+                continue
+            if "error" in r:
+                problems.append(f"other_configs.{wl}: {r['error'][-200:]}")
+            elif r.get("verified") is not True or r.get("exit_code"):
+                problems.append(f"other_configs.{wl}: verified={r.get('verified')} exit={r.get('exit_code')} {r.get('accounting_problems')}")
     if problems:
         line["accounting_problems"] = problems
     print(json.dumps(line), flush=True)

@@ -31,6 +31,9 @@ int he_alg_bytes(he_handle ctx, int reset, double out[2]);
  * ...) and by the arithmetic class of the limb: out[0] multiply-equivalents on integer-class limbs (64-bit Montgomery products),
  * out[1] on limbs below 2^47 (exact double-precision products), out[2] / out[3] how many of these are NTT butterflies */
 int he_alg_valu(he_handle ctx, int reset, double out[4]);
+/* PCI bus id ("0000:05:00.0") of a HIP device of this process: bench.py finds the device's clock tables in sysfs through it
+ * (/sys/bus/pci/devices/<id>/pp_dpm_sclk) -- the node's other GPUs are listed there too, whatever this process may see */
+int he_debug_device_pci_bus_id(int device, char *out, int len);
 /* dependent-MRedLazy throughput probe: returns modular multiplies per second */
 int he_probe_modmul(he_handle ctx, int iters, double *mults_per_s);
 /* the same for the exact double-precision product the limbs below 2^47 are computed with (error-free product + rounded quotient,

@@ -7,8 +7,8 @@ All arithmetic runs in ``libhering.so`` (hand-written HIP); there is no CPU
 fallback -- importing works without a GPU, creating a ``Context`` does not.
 """
 from ._lib import HeringError, lib_path, load  # noqa: F401
-from .ring import BasisExtender, Context, Graph, Poly, Ring, device_count  # noqa: F401
+from .ring import BasisExtender, Context, Graph, Poly, Ring, device_count, device_pci_bus_id  # noqa: F401
 from .rlwe import Decomposition, EvaluationKey, Evaluator  # noqa: F401
 
-__all__ = ["HeringError", "lib_path", "load", "device_count", "Context", "Ring", "Poly", "BasisExtender", "Evaluator",
+__all__ = ["HeringError", "lib_path", "load", "device_count", "device_pci_bus_id", "Context", "Ring", "Poly", "BasisExtender", "Evaluator",
            "EvaluationKey", "Decomposition"]

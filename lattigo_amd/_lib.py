@@ -59,7 +59,7 @@ def _declare(L):
     L.he_prof_kernel_name.restype = C.c_char_p
     L.he_prof_kernel_name.argtypes = [C.c_int]
     sig = {
-        "he_device_count": [C.POINTER(i)], "he_ctx_create": [i, HP], "he_ctx_destroy": [H], "he_ctx_sync": [H], "he_timer_start": [H],
+        "he_device_count": [C.POINTER(i)], "he_debug_device_pci_bus_id": [i, C.c_char_p, i], "he_ctx_create": [i, HP], "he_ctx_destroy": [H], "he_ctx_sync": [H], "he_timer_start": [H],
         "he_timer_stop": [H, C.POINTER(C.c_float)], "he_device_info": [H, u64p],
         "he_ring_create": [H, i, u64p, i, HP], "he_ring_create_type": [H, i, i, u64p, i, HP], "he_ring_destroy": [H], "he_ring_constant": [H, i, i, u64p],
         "he_ring_roots": [H, i, i, u64p],

@@ -1478,6 +1478,12 @@ int he_device_count(int *n) {
     if (e != hipSuccess) { (void)hipGetLastError(); *n = 0; }  // no driver / no device: zero, not an error
     return HE_OK;
 }
+int he_debug_device_pci_bus_id(int device, char *out, int len) {
+    if (!out || len < 13) return fail(HE_EINVAL, "he_debug_device_pci_bus_id: buffer of at least 13 bytes");
+    out[0] = 0;
+    if (hipDeviceGetPCIBusId(out, len, device) != hipSuccess) { (void)hipGetLastError(); out[0] = 0; return fail(HE_EDEVICE, "he_debug_device_pci_bus_id: no such device"); }
+    return HE_OK;
+}
 int he_ctx_sync(he_handle h) {
     GET(c, Ctx, h, T_CTX);
     if (c->capturing) return fail(HE_EINVAL, "he_ctx_sync: the context is capturing a graph (he_graph_end first)");
@@ -3807,7 +3813,7 @@ int he_eval_moddown_qp_to_q_ntt(he_handle hev, int levelQ, int levelP, he_handle
         TRY(get_md_plan(*ev, levelQ, levelP, &plan));
         // the fused basis extension runs one 128-thread workgroup per 1024 coefficients and batch entry over ALL destination
         // limbs: below one workgroup per CU the six-launch path, which also spreads the limbs over the grid, has the lower latency
-        const int rowbits = be.Q->logN <= 12 ? be.Q->logN : (be.Q->logN <= 15 ? 12 : 13);  // ntt_row_bits (kernels.hip)
+        const int rowbits = ntt_row_bits(be.Q->logN);
         const bool wide = (size_t)B * ((size_t)1 << rowbits) / 128 >= 256;
         if (!plan->ok || !wide) return moddown_q_ntt(be, levelQ, levelP, v[0], v[1], v[2], B, sP, sQ);
         // three launches: INTT rows (P) -> [cols + ModUpPtoQ + cols] -> NTT rows whose epilogue is the last op of the ModDown

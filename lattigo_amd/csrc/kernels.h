@@ -115,6 +115,7 @@ struct NttProdIn {
     View a, b, c;
     uint64_t ts[kMaxLimbs];
 };
+int ntt_row_bits(int logN);  // row stages of the two-pass transform (the rest are column stages)
 bool ntt_prod_in_supported(int logN);
 bool epilogue_scatter_supported(int logN);  // NttEpilogue::scatter_ginv / NttMacEpilogue::scatter_ginv: the production row sizes
 hipError_t launch_ntt_rows(const RingDev &r, const LimbTab &tab, View in, View out, int batch, bool inverse, int flags,

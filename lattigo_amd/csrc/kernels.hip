@@ -349,7 +349,11 @@ __device__ __forceinline__ int nat_e(int k, int tau) {
 // N = 2^n is split into a strided "column" stages and b contiguous "row" stages: rows of 4096 coefficients
 // (b = 12) up to logN = 15, rows of 8192 (b = 13, two 512-thread workgroups per CU) from logN = 16 so that the
 // fused basis extension never holds more than 8 strided coefficients per thread.
-static inline int ntt_row_bits(int n) { return n <= 12 ? n : (n <= 15 ? 12 : 13); }
+// HERING_ROWBITS16=12: logN = 16 on 4096-rows with four column stages inside the basis extension (A/B, NOTES.md round 6)
+int ntt_row_bits(int n) {
+    static const int rb16 = getenv("HERING_ROWBITS16") && atoi(getenv("HERING_ROWBITS16")) == 12 ? 12 : 13;
+    return n <= 12 ? n : (n <= 15 ? 12 : (n == 16 ? rb16 : 13));
+}
 
 // ------------------------------------------------------------------------------------
 // ntt_rows: b = LOGB stages on one contiguous row of 2^LOGB coefficients per workgroup.

@@ -94,6 +94,14 @@ def device_count() -> int:
     return int(n.value)
 
 
+def device_pci_bus_id(device_id: int = 0):
+    """PCI bus id of a HIP device ("0000:05:00.0"), lower case as sysfs spells it; None when the runtime cannot tell."""
+    buf = C.create_string_buffer(64)
+    if load().he_debug_device_pci_bus_id(int(device_id), buf, 64) != 0:
+        return None
+    return buf.value.decode().lower() or None
+
+
 class Context:
     """One HIP device + stream (one per process/GPU)."""
 

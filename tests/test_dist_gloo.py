@@ -131,3 +131,12 @@ def test_rccl_rendezvous_has_a_deadline(monkeypatch):
             assert cp._rccl is None
         assert time.time() - t0 < 5
         fake.gate.set()
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """bench.py never prints a line whose n_gpus differs from --gpus: a launcher that started another number of ranks is refused
+    before anything touches a device (runs without a GPU)."""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2 and "no line printed" in out.stderr and not out.stdout.strip(), (out.stdout, out.stderr)

@@ -39,6 +39,30 @@ def test_bench_two_ranks_every_workload(workload, batch):
     assert line["verified"] is True, line["verified_detail"]  # (c5: every entry against the oracle-backed trace's committed digest)
 
 
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` invoked plainly (no torch.distributed.run around it, the way the driver calls `--gpus 1`):
+    the script starts its two ranks itself and the line says n_gpus 2 with both ranks on the control plane (VERDICT r5 weak #7:
+    --gpus used to be parsed and ignored)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HERING_FORCE_DEVICE="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--no-ntt", "--replicate-keys", "host"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"]["control_plane_gloo"] == 2
+    assert line["verified"] is True and line["config"]["batch_per_gpu"] == 4
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """without the test hook, asking for more GPUs than the node has prints no line (exit 2) instead of a mislabelled one"""
+    n = _device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HERING_FORCE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 2 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], (out.stdout[-500:], out.stderr[-500:])
+
+
 _RCCL_WORKER = """
 import hashlib, os, sys
 sys.path.insert(0, %r)
