@@ -92,7 +92,7 @@ enum CoOp {
     CO_MUL_RELIN = 0, CO_GADGET_PRODUCT, CO_RELINEARIZE, CO_AUTOMORPHISM,
     CO_NTT, CO_EW, CO_EW_DOUBLE, CO_SHIFT, CO_RESCALE, CO_GATHER, CO_AUTO_COEFF, CO_MODUP, CO_MODDOWN_BE,
     CO_DECOMPOSE_SPLIT, CO_DECOMPOSE_NTT, CO_GP_LAZY, CO_GP_HOISTED_LAZY, CO_GP_HOISTED, CO_MODDOWN, CO_EVAL_MODDOWN,
-    CO_AUTO_HOISTED, CO_AUTO_HOISTED_LAZY, CO_CENTERED_LIFT, CO_DECOMP_FILL, CO_LINTRANS, CO_MUL, CO_COPY, CO_ZERO
+    CO_AUTO_HOISTED, CO_AUTO_HOISTED_LAZY, CO_CENTERED_LIFT, CO_DECOMP_FILL, CO_LINTRANS, CO_MUL, CO_COPY, CO_ZERO, CO_GIANT_STEP
 };
 struct CoReq {
     // ---- key: requests are batched together only when all of this matches
@@ -1638,9 +1638,16 @@ static int poly_alloc(he_handle hring, int n_limbs, int batch, bool zero, he_han
         return fail(HE_ENOMEM, "he_poly_alloc: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
     Ctx &cx = *r->ctx;
-    if (zero && !poison && n_limbs <= kMaxLimbs && batch < cx.co->max_batch.load(std::memory_order_relaxed) && !cx.capturing) {
-        // queue on: the zero fills of concurrent callers' fresh polynomials are one launch over an entry table like any other
-        // request (16 callers replaying a bootstrap issued 44 memsets each per bootstrap, every one under the context's lock)
+    // Deferred submission: the fill must be ON THE STREAM when this call returns -- a handle may be handed to another thread (or a
+    // goroutine may migrate between NewPoly and Upload), and a direct launch of that thread (upload, batched call) only waits for
+    // ITS OWN pending requests: a fill still sitting in the allocating thread's queue would land on top of the other thread's data
+    // (ADVICE r5).  So with a dispatcher the fill is a stream-ordered memset right here (NoFlush: a buffer fresh from the cache is
+    // addressed by no pending request); measured equal on the c5 replay (85.4 bootstraps/s either way, NOTES.md round 5).
+    const bool deferred = cx.co->depth.load(std::memory_order_relaxed) > 0;
+    if (zero && !poison && !deferred && n_limbs <= kMaxLimbs && batch < cx.co->max_batch.load(std::memory_order_relaxed) && !cx.capturing) {
+        // queue on (default mode: a call returns once its batch is enqueued): the zero fills of concurrent callers' fresh polynomials
+        // are one launch over an entry table like any other request (16 callers replaying a bootstrap issued 44 memsets each per
+        // bootstrap, every one under the context's lock)
         const std::shared_ptr<Ctx> ctx = r->ctx;
         const int N = r->N;
         CoReq q;
@@ -2333,7 +2340,9 @@ static int gather_api(he_handle hring, int level, he_handle hin, he_handle hidx,
     CoReq q;
     // (the index table is identified by its Galois element, not by its handle: callers that each built their own table of the same
     // automorphism share a batch -- entry 0's table serves them all)
-    q.op = CO_GATHER; q.obj = r.get(); q.par[0] = level; q.par[1] = add; q.par[2] = (int64_t)ix->gal;
+    // ... and by the cached table it points at: handles built on rings of another type (standard / conjugate-invariant, another
+    // NthRoot) with the same N and Galois element hold a different permutation and must not share entry 0's table
+    q.op = CO_GATHER; q.obj = r.get(); q.par[0] = level; q.par[1] = add; q.par[2] = (int64_t)ix->gal; q.par[3] = (int64_t)(uintptr_t)ix->d;
     q.ops = {pin->view(), pout->view()};
     q.keep = {r, pin, pout, ix};
     q.run = [r, ix, level, add](const View *v, int B) -> int {
@@ -2920,7 +2929,7 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, View dec, size_t dec_ds, con
     const View decv = dec;
     if (scatter && scatter->ginv) {  // (add_s arrives by Q limb: compact it to the launch limbs)
         KsScatter sc = *scatter;
-        for (int i = 0; i < n; i++) sc.add_s[i] = a.out_view[i] == 0 ? scatter->add_s[a.out_limb[i]] : 0;
+        for (int i = 0; i < n; i++) sc.add_s[i] = (a.out_view[i] == 0 && !scatter->plain) ? scatter->add_s[a.out_limb[i]] : 0;
         HIP_TRY(launch_ks_inner(be.qp, a, decv, own ? *own : decv, keyp, o0Q, o0P, o1Q, o1P, batch, be.ctx->stream, &sc));
         return HE_OK;
     }
@@ -3284,7 +3293,7 @@ static bool f64_raw_ok(const BasisExtender &be, int levelQ, int levelP, int nsrc
 // the caller guarantees that no P limb is of the double-precision class
 int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_t dec_bs, size_t dec_ds, const Evk &k, View cx,
                int own_alpha, View o0Q, View o0P, View o1Q, View o1P, int batch, bool q_out_f64 = false, bool own_reduce = true,
-               bool dec_f64 = false, const NttMacEpilogue *epi = nullptr, hipStream_t on = nullptr) {
+               bool dec_f64 = false, const NttMacEpilogue *epi = nullptr, hipStream_t on = nullptr, const KsScatter *giant = nullptr) {
     BasisExtender &be = *ev.be;
     const hipStream_t st = on ? on : be.ctx->stream;
     const int LQ = be.LQ, N = be.Q->N;
@@ -3319,8 +3328,9 @@ int ks_mac_f64(Evaluator &ev, int levelQ, int levelP, const uint64_t *dec, size_
         HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, st, &e));
         return HE_OK;
     }
+    if (giant && q_out_f64) return fail(HE_EINVAL, "ks_mac_f64: giant-step stores with double-format accumulators");
     if (!q_out_f64) {
-        HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, st));
+        HIP_TRY(launch_ntt_mac_f64(be.qp, a, decv, cx, k.keyd, o0Q, o0P, o1Q, o1P, batch, st, nullptr, giant));
         return HE_OK;
     }
     // double-format Q accumulators: the Q limbs and the P limbs go to separate launches (different store code)
@@ -3360,8 +3370,10 @@ struct MacDefer {
     size_t bs = 0, ds = 0;
     bool raw = false, own_reduce = true;
 };
+// giant (optional; the caller checked giant_step_fusable()): the accumulators leave through KsScatter's giant-step stores
 int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Evk &k, View o0Q, View o0P, View o1Q, View o1P,
-                             bool cx_canonical = false, bool *acc_q_f64 = nullptr, MacDefer *defer = nullptr, const TensorIn *tin = nullptr) {
+                             bool cx_canonical = false, bool *acc_q_f64 = nullptr, MacDefer *defer = nullptr, const TensorIn *tin = nullptr,
+                             const KsScatter *giant = nullptr) {
     const bool want_f64 = acc_q_f64 && *acc_q_f64;
     if (acc_q_f64) *acc_q_f64 = false;
     BasisExtender &be = *ev.be;
@@ -3392,6 +3404,7 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
             HIP_TRY(launch_tensor(be.qp, tt, tsv, tin->a0, tin->a1, tin->b0, tin->b1, View{nullptr, 0}, View{nullptr, 0}, cx, B, be.ctx->stream));
     }
     if (k.pw2) {  // base-2 gadget: bit windows of every Q-limb, NTT'd into every limb (evaluator_gadget_product.go:203-338)
+        if (giant) return fail(HE_EINVAL, "gadget product: giant-step stores with a base-2 gadget");
         hipStream_t st = be.ctx->stream;
         HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT));
         MaskSpreadArgs m{};
@@ -3444,7 +3457,8 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
                 return ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1);
             }
             TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, View{dec, bs}, B, 1, raw));
-            TRY(ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1));
+            TRY(ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 1, 0, -1, giant));
+            if (giant) return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, false, !cx_canonical, raw, nullptr, nullptr, giant);
             if (defer && defer->want) {
                 defer->deferred = true; defer->dec = dec; defer->bs = bs; defer->ds = ds; defer->raw = raw; defer->own_reduce = !cx_canonical;
                 return HE_OK;
@@ -3453,8 +3467,9 @@ int gadget_product_lazy_core(Evaluator &ev, int levelQ, View cx, int B, const Ev
             return ks_mac_f64(ev, levelQ, levelP, dec, bs, ds, k, cx, levelP + 1, o0Q, o0P, o1Q, o1P, B, want_f64, !cx_canonical, raw);
         }
         TRY(decompose_fused(ev, *plan, levelQ, levelP, levelP + 1, inv, View{dec, bs}, B));
-        return ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1);
+        return ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B, &cx, levelP + 1, 0, 0, -1, giant);
     }
+    if (giant) return fail(HE_EINVAL, "gadget product: giant-step stores need the fused decomposition");
     HIP_TRY(be_ntt(be, ident_tab(levelQ + 1), cx, inv, B, true, NTT_REDUCE_INPUT));
     TRY(decompose_ntt_into(ev, levelQ, levelP, levelP + 1, cx, inv, View{dec, bs}, ds, B));
     return ks_inner(ev, levelQ, levelP, View{dec, bs}, ds, k, o0Q, o0P, o1Q, o1P, B);
@@ -4111,6 +4126,87 @@ int he_automorphism_hoisted_lazy(he_handle hev, int levelQ, he_handle hin0, he_h
     return co_dispatch(*be.ctx, B, q);
 }
 
+// The giant step of MultiplyByDiagMatrixBSGS (circuits/common/lintrans/lintrans_evaluator.go:397-441) as one call:
+//   (c0, c1) = GadgetProductLazy(levelQ, cx, key);  c0 = ringQP.Add(c0, add);  out_k (+)= AutomorphismNTTWithIndex(c_k)
+// (accumulate: ...ThenAddLazy).  On standard rings with the fused decomposition the key inner products store through the
+// automorphism themselves (KsScatter giant step: no intermediate ciphertext, no Add and gather passes); otherwise the same
+// launches as the separate calls.  Bit-identical to the separate calls either way.
+int he_lintrans_giant_step(he_handle hev, int levelQ, he_handle hcx, he_handle hk, uint64_t gal, he_handle haddQ, he_handle haddP,
+                           he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, int accumulate) {
+    const char *who = "he_lintrans_giant_step";
+    GET(ev, Evaluator, hev, T_EVAL);
+    GET(cx, Poly, hcx, T_POLY);
+    GET(k, Evk, hk, T_EVK);
+    GET(addQ, Poly, haddQ, T_POLY);
+    BasisExtender &be = *ev->be;
+    TRY(check_key(*ev, *k, levelQ, who));
+    TRY(check_be_poly(*cx, be, levelQ + 1, who));
+    TRY(check_be_poly(*addQ, be, levelQ + 1, who));
+    const int levelP = k->nPk - 1, B = cx->batch;
+    if (levelP < 0) return fail(HE_EINVAL, "%s: the key has no special primes", who);
+    if (!(gal & 1)) return fail(HE_EINVAL, "%s: Galois element must be odd", who);
+    GET(addP, Poly, haddP, T_POLY);
+    TRY(check_be_poly(*addP, be, levelP + 1, who));
+    if (addQ->batch != B || addP->batch != B) return fail(HE_EINVAL, "%s: batch mismatch", who);
+    QPOut o;
+    TRY(get_qp_out(c0Q, c0P, c1Q, c1P, be, levelQ, levelP, B, o, who));
+    for (const Poly *out : {o.q0.get(), o.p0.get(), o.q1.get(), o.p1.get()})
+        if (out->d == cx->d || out->d == addQ->d || out->d == addP->d) return fail(HE_EINVAL, "%s: an output aliases an input", who);
+    CoReq q;
+    q.op = CO_GIANT_STEP; q.obj = ev.get(); q.key = k.get(); q.par[0] = levelQ; q.par[1] = (int64_t)gal; q.par[2] = accumulate ? 1 : 0;
+    q.ops = {cx->view(), addQ->view(), addP->view(), o.q0->view(), o.p0->view(), o.q1->view(), o.p1->view()};
+    q.keep = {ev, k, cx, addQ, addP, o.q0, o.p0, o.q1, o.p1};
+    q.run = [ev, k, levelQ, levelP, gal, accumulate](const View *v, int B) -> int {
+        BasisExtender &be = *ev->be;
+        const int N = be.Q->N;
+        const bool acc = accumulate != 0;
+        // SURVEY 8(d) accounting of the calls this one stands for: GadgetProductLazy + Add on QP + two automorphisms on QP
+        be.ctx->acct(levelQ + 1 + 2.0 * (levelQ + levelP + 2) + 3.0 * (levelQ + levelP + 2) + 2.0 * (acc ? 3.0 : 2.0) * (levelQ + levelP + 2),
+                     key_limbs(*k, levelQ), B, N);
+        { Valu V(be.Q->logN); valu_keyswitch(V, be, levelQ, levelP, base_rns_size(levelQ, levelP), true, true); V.into(*be.ctx, B); }
+        const size_t sQw = (size_t)(levelQ + 1) * N, sPw = (size_t)(levelP + 1) * N;
+        TRY(be.ctx->arena_reserve(ks_scratch_words(be, levelQ, levelP, B, true, k.get()) + 2 * B * (sQw + sPw) + 64));
+        const FusedPlan *plan = nullptr;
+        if (!k->pw2) TRY(get_dec_plan(*ev, levelQ, levelP, levelP + 1, &plan));
+        static const bool no_scatter = env_flag("HERING_NO_AUTO_SCATTER") || env_flag("HERING_NO_GIANT_FUSION");
+        const bool fuse = !no_scatter && be.type == 0 && plan && plan->ok && (!k->keyd || ntt_mac_giant_supported(be.Q->logN));
+        if (fuse) {
+            KsScatter ks;
+            const uint64_t mask = (2ull << be.Q->logN) - 1;
+            uint64_t x = gal & mask;
+            for (int i = 0; i < 6; i++) x = (x * (2 - gal * x)) & mask;  // Newton: g^-1 mod 2N (g odd)
+            ks.ginv = (uint32_t)x;
+            ks.plain = 1; ks.add0 = v[1]; ks.add0P = v[2]; ks.accumulate = acc ? 1 : 0;
+            for (int i = 0; i < kMaxLimbs; i++) ks.add_s[i] = 0;
+            return gadget_product_lazy_core(*ev, levelQ, v[0], B, *k, v[3], v[4], v[5], v[6], false, nullptr, nullptr, nullptr, &ks);
+        }
+        // the separate calls' launches
+        View t0Q{be.ctx->arena_take(B * sQw), sQw}, t1Q{be.ctx->arena_take(B * sQw), sQw};
+        View t0P{be.ctx->arena_take(B * sPw), sPw}, t1P{be.ctx->arena_take(B * sPw), sPw};
+        TRY(gadget_product_lazy_core(*ev, levelQ, v[0], B, *k, t0Q, t0P, t1Q, t1P));
+        const uint32_t *index = nullptr;
+        TRY(cached_auto_index(*ev, gal, &index));
+        hipStream_t st = be.ctx->stream;
+        const LimbTab tq = ident_tab(levelQ + 1), tp = ident_tab(levelP + 1, 0, 0, be.LQ);
+        HIP_TRY(launch_ew(be.qp, tq, EW_ADD, t0Q, v[1], t0Q, B, nullptr, nullptr, st));
+        HIP_TRY(launch_ew(be.qp, tp, EW_ADD, t0P, v[2], t0P, B, nullptr, nullptr, st));
+        HIP_TRY(launch_gather(be.qp, tq, t0Q, index, v[3], B, acc, st));
+        HIP_TRY(launch_gather(be.qp, tp, t0P, index, v[4], B, acc, st));
+        HIP_TRY(launch_gather(be.qp, tq, t1Q, index, v[5], B, acc, st));
+        HIP_TRY(launch_gather(be.qp, tp, t1P, index, v[6], B, acc, st));
+        return HE_OK;
+    };
+    q.tables_ok = [ev, k, levelQ](bool *ok) -> int {
+        *ok = false;
+        if (k->pw2 || k->nPk <= 0) return HE_OK;
+        const FusedPlan *plan = nullptr;
+        TRY(get_dec_plan(*ev, levelQ, k->nPk - 1, k->nPk, &plan));
+        *ok = plan->ok;
+        return HE_OK;
+    };
+    return co_dispatch(*be.ctx, B, q);
+}
+
 // centred lifts / hoisting-buffer fill of bootstrapping.Evaluator.ModUp (see hering.h)
 int he_centered_lift(he_handle hev, int strict, he_handle hsrc, int first_q, int levelQ, he_handle hdq, int levelP, he_handle hdp) {
     GET(ev, Evaluator, hev, T_EVAL);
@@ -4225,6 +4321,7 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
             q.keep.push_back(ixo);
         }
         q.blob.push_back(idx_gal[i]);  // (the rotation of the term is part of the key -- by Galois element, see gather_api)
+        q.blob.push_back((uint64_t)(uintptr_t)idx[i]);  // ... and by the cached table (another ring type: another permutation)
         View vt = tq->view();
         if (tq->batch == 1) vt.bstride = 0;  // one plaintext diagonal for the whole batch
         q.ops.push_back(vt); q.ops.push_back(c0q->view()); q.ops.push_back(c1q->view());
@@ -4269,7 +4366,7 @@ int he_lintrans_mul_sum(he_handle hev, int levelQ, int levelP, int n, const he_h
             per += 2.0;
             if (t[0].bstride || tabs) per += 1.0; else shared += 1.0;
         }
-        if (tabs) {
+        if (tabs && n > 0) {  // (n == 0: the request has four operands only)
             // rows 4 + 6 i + {0, 1, 2} are the Q part's (pt, c0, c1) of term i, + {3, 4, 5} the P part's: DiagMacArgs::term_tab wants
             // [3 i + j][B] -- a table with a stride of six rows per term, so the Q launch starts at row 4, the P launch at row 7,
             // and both skip the other part's three rows (term_tab_rows = 6)
@@ -4414,6 +4511,9 @@ int he_bgv_mul_relin(he_handle ev, int level, uint64_t t, he_handle a0, he_handl
 // ---------------------------------------------------------------------------------------
 int he_graph_begin(he_handle hctx) {
     GET(c, Ctx, hctx, T_CTX);
+    // deferred submission: everything ANY thread filed before the capture is launched first -- the dispatcher would otherwise keep
+    // launching other threads' earlier requests onto the capturing stream, recording them into the graph instead of running them
+    if (c->co->depth.load(std::memory_order_relaxed) > 0) TRY(co_flush_filed(*c));
     Scope sc(c.get());
     if (c->capturing) return fail(HE_EINVAL, "he_graph_begin: the context is already capturing");
     if (prof_active(c->stream)) return fail(HE_EINVAL, "he_graph_begin: kernel profiling is active on this context (he_prof_end first)");

@@ -280,10 +280,18 @@ struct KsArgs {
 // Optional (AutomorphismHoistedLazy as ONE launch, core/rlwe/evaluator_automorphism.go:104-165): the accumulators are stored
 // through the NTT-domain automorphism whose inverse Galois element is ginv (see NttEpilogue::scatter_ginv), and component 0 of
 // the Q limbs is first increased by MRed(add0, add_s[launch limb]) -- the ctIn[0] * P term -- read at the source position.
+// Round 6 -- the giant step of a baby-step giant-step linear transformation (circuits/common/lintrans/lintrans_evaluator.go:
+// 397-441: GadgetProductLazy, ringQP.Add of the inner loop's component-0 sum, AutomorphismNTTWithIndex[ThenAddLazy] of both
+// components into the outer accumulators) as the producers' own stores: `plain` -- the addend (add0 on the Q limbs, add0P on
+// the P limbs) is added as it is, CRed(acc + add); `accumulate` -- the destination word is increased (no reduction, as
+// ...ThenAddLazy) instead of overwritten.  launch_ntt_mac_f64 takes the same description for the double-precision limbs.
 struct KsScatter {
     uint32_t ginv = 0;
     View add0{nullptr, 0};
     uint64_t add_s[kMaxLimbs];
+    int plain = 0;
+    View add0P{nullptr, 0};
+    int accumulate = 0;
 };
 hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own, const uint64_t *key, View out0Q,
                            View out0P, View out1Q, View out1P, int batch, hipStream_t s, const KsScatter *sc = nullptr);
@@ -340,8 +348,12 @@ struct NttMacEpilogue {
     uint32_t scatter_ginv = 0;  // as NttEpilogue::scatter_ginv
 };
 bool ntt_mac_epilogue_supported(int logN);
+struct KsScatter;
+// giant (optional, without an epilogue, production row sizes): the accumulators leave through KsScatter's giant-step stores
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
-                              View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi = nullptr);
+                              View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi = nullptr,
+                              const KsScatter *giant = nullptr);
+bool ntt_mac_giant_supported(int logN);
 // keyd[i] = (double)IMForm(key[i]) for the limbs of class 2 (plain residues < 2^47), 0 elsewhere
 hipError_t launch_key_to_f64(const RingDev &r, const uint64_t *key, double *keyd, int nblocks, const uint8_t *limb_mod_host,
                              int nlimbs, hipStream_t s);

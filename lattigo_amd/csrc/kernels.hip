@@ -1297,6 +1297,28 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 2
 // Bit-identical to the plain kernel (same arithmetic on the same operands).
 // ------------------------------------------------------------------------------------
 
+// HE_MAC_R2 (round 6): the key inner product runs in the register order the LAST round of the row transform leaves (thread tau
+// holds the sixteen consecutive coefficients 16 tau .. 16 tau + 15) instead of the coalesced order k T + tau: a transformed digit
+// no longer stores its result back to the tile, waits for the workgroup and reads it again (one LDS exchange and one barrier of
+// three fewer per digit).  The double-precision key copy is laid out to match (key_to_f64_kernel: position k T + t of a row
+// holds coefficient 16 t + k, so the key rows are still read coalesced); the digit's own limb -- NTT-domain words in natural
+// order -- takes one exchange through the tile; the accumulators take the exchange back where they leave the kernel (the
+// ModDown epilogue subtracts first and transposes the difference: the same count as before).  0: round 3-5's order (A/B builds).
+#ifndef HE_MAC_R2
+#define HE_MAC_R2 1
+#endif
+#ifndef HE_MAC_K1_EARLY
+#define HE_MAC_K1_EARLY 0
+#endif
+#ifndef HE_MAC_EPI_PREFETCH
+#define HE_MAC_EPI_PREFETCH 1
+#endif
+// the tile positions of a thread's sixteen coefficients in that order (thread-private: no other thread touches them)
+template <int LOGB>
+__device__ __forceinline__ void mac_final_xfer(double (&x)[16], double *lds, int tau, bool store) {
+    if constexpr (LOGB % 4 == 0) rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, LOGB - 4, 0, store);
+    else rows_lds_xfer_f64<LOGB, LOGB % 4>(x, lds, tau, LOGB - LOGB % 4, 0, store);
+}
 typedef __attribute__((address_space(3))) void *he_lds_ptr;
 __device__ __forceinline__ unsigned lds_byte_addr(const void *p) { return (unsigned)(uintptr_t)(he_lds_ptr)p; }
 // one LDS-DMA instruction: lane i's 16 bytes at gsrc land at LDS byte lds_dst + 16 i (lds_dst wave-uniform).  hipcc does not
@@ -1321,6 +1343,9 @@ struct MacEpiK {
     unsigned etab_rows;
     unsigned sc_ginv;  // stores scattered by the automorphism of inverse Galois element sc_ginv (auto_dest); 0: none
     int sc_logN;
+    // without the epilogue (EPI = false, SCAT = true): the giant step of a linear transformation (KsScatter): component 0 takes
+    // the addend w0 (Q limbs) / w1 (P limbs) when has_w0, both accumulators go through auto_dest, gs_accum: the stores add
+    int gs_accum;
 };
 enum { ME_OUT0 = 0, ME_OUT1, ME_W0, ME_W1, ME_TA0, ME_TA1, ME_TB0, ME_TB1 };
 __device__ __forceinline__ size_t meoff(const MacEpiK &e, int which, size_t bs, size_t z, unsigned nbatch) {
@@ -1436,7 +1461,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
         // forward row transform of x (element k T + tau in, the same order out), with the prefetch of `nsrc` and -- digits only --
         // the two key rows issued where they hide best
         auto transform = [&](int nk, auto read_back, double (&x)[16], unsigned tau, unsigned lane, const uint64_t *nsrc, const double *k0p,
-                             const double *k1p, double (&kk0)[16], double (&kk1)[16]) {
+                             const double *k1p, double (&kk0)[16], double (&kk1)[16], int early = 0) {
             // read_back = false: the result stays in the tile (element e at lds_phys(e)) for the caller to pick up
             // nk (block-uniform): rows of sixteen words fetched on the way -- 2 (k0p and k1p), 1 (k0p), 0
             // round-2 twiddles first, then the DMA: ordinary loads issued after it could only return after it
@@ -1473,14 +1498,33 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #pragma unroll
                 for (int k = 0; k < 16; k++) kk0[k] = k0p[(unsigned)(k * T)];
             }
-            __builtin_amdgcn_sched_barrier(0);
-            rows_round16_f64<false>(x, t2, q, qi);
-            __builtin_amdgcn_sched_barrier(0);
-            if (nk >= 2) {
+            // HE_MAC_K1_EARLY: nothing stands between round 2 and the products any more (HE_MAC_R2), so the second key row is
+            // requested before the round as well where the registers allow it (4096-rows: 214 -> 2xx registers)
+            constexpr bool k1_early = HE_MAC_R2 && HE_MAC_K1_EARLY && LOGB == 12;
+            // early (the epilogue's transforms, HE_MAC_EPI_PREFETCH): both rows before the round -- held across the whole transform
+            // they cost 176 spilled registers
+            if ((k1_early || early != 0) && nk >= 2) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
             }
             __builtin_amdgcn_sched_barrier(0);
+            rows_round16_f64<false>(x, t2, q, qi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(k1_early || early != 0) && nk >= 2) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#if HE_MAC_R2
+            // the result stays in the registers, in the last round's order (coefficients 16 tau .. 16 tau + 15)
+            if constexpr (GREM > 0) {
+                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, true);
+                rows_sync(LOGB - 12);
+                rows_lds_xfer_f64<LOGB, GREM>(x, lds, tau, 12, 0, false);
+                rows_round_f64<GREM, false>(x, cur.tw, cur.rowtw, 12, 0, tau, 0, q, qi);
+            }
+            (void)read_back;
+#else
             rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 8, LOGB - 12, true);
             if constexpr (GREM > 0) {
                 rows_sync(LOGB - 12);
@@ -1493,6 +1537,7 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #pragma unroll
                 for (int k = 0; k < 16; k++) x[k] = lds[lds_phys(k * T + tau)];
             }
+#endif
         };
         // the prefetch buffer's next content after source `d` of the current item (block-uniform): the item's next source, or the
         // next item's first digit (then `w`, `more` describe that item)
@@ -1543,6 +1588,13 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #pragma unroll
                 for (int k = 0; k < 16; k++) kk1[k] = k1p[(unsigned)(k * T)];
                 __builtin_amdgcn_sched_barrier(0);
+#if HE_MAC_R2
+                // natural order -> the accumulators' order, through the tile (the key rows are in flight meanwhile)
+                __syncthreads();  // every wave is done with the tile (the previous digit's / item's last cross-wave read)
+                rows_lds_xfer_f64<LOGB, 4>(x, lds, tau, 0, LOGB - 4, true);  // element k T + tau
+                __syncthreads();
+                mac_final_xfer<LOGB>(x, lds, tau, false);
+#endif
             }
             MAC_STAMP2(1 + d * 12 + 8);
 #pragma unroll
@@ -1554,8 +1606,8 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
         }
         if constexpr (EPI) {
             // the two extension rows, through the same prefetch chain as two more digits
-#pragma unroll 1
-            for (int c = 0; c < 2; c++) {
+            auto ext_pass = [&](auto cc) __attribute__((always_inline)) {
+                const int c = cc;
                 unsigned tau_d = threadIdx.x;
                 asm volatile("" : "+v"(tau_d));
                 const unsigned tau = tau_d, lane = tau & 63u;
@@ -1581,20 +1633,51 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 const uint64_t *mcw = reinterpret_cast<const uint64_t *>(A.mc + cur.mi);
                 const uint64_t qu = ldc(mcw, 0);
                 const bool tensor = AA.e.tensor != 0, addw = !tensor && (second ? AA.e.has_w1 : AA.e.has_w0) != 0;
-                double kd0[16], kd1[16];  // (unused: no key rows on the way)
+                double kd0[16], kd1[16];  // the key rows' registers: free in these transforms (no key rows on the way)
                 MAC_STAMP2(48 + c * 4 + 1);
-                transform(0, std::true_type{}, x, tau, lane, nsrc, nullptr, nullptr, kd0, kd1);
+                // HE_MAC_EPI_PREFETCH (4096-rows): the operands the epilogue needs from memory -- a0, b0 (component 0) / a0, b1
+                // (component 1) of the tensor term, or the addend row -- are requested at the head of the transform into those
+                // registers, before its last round -- the place the key rows of a digit are requested (tools/mac_timeline.py,
+                // round 6: the epilogue phases were 10.6 k and 17.1 k cycles per item for ~2.6 k and ~3.5 k cycles of arithmetic:
+                // they waited for these loads)
+                constexpr bool prefetch = HE_MAC_R2 && HE_MAC_EPI_PREFETCH && LOGB == 12;  // tensor + addend modes
+                constexpr bool prefetch_w = false;  // the addend row alone at 8192-rows: measured equal to slightly slower (c4 2.35 -> 2.37-2.39 ms)
+                const uint64_t *pa0 = nullptr, *pa1 = nullptr, *pb0 = nullptr, *pb1 = nullptr, *wp = nullptr;
+                if (tensor) {
+                    pa0 = AA.e.ta0 + meoff(AA.e, ME_TA0, AA.e.ta0_bs, cur.bz, AA.nbatch) + off; pa1 = AA.e.ta1 + meoff(AA.e, ME_TA1, AA.e.ta1_bs, cur.bz, AA.nbatch) + off;
+                    pb0 = AA.e.tb0 + meoff(AA.e, ME_TB0, AA.e.tb0_bs, cur.bz, AA.nbatch) + off; pb1 = AA.e.tb1 + meoff(AA.e, ME_TB1, AA.e.tb1_bs, cur.bz, AA.nbatch) + off;
+                } else if (addw) {
+                    wp = (second ? AA.e.w1 + meoff(AA.e, ME_W1, AA.e.w1_bs, cur.bz, AA.nbatch) : AA.e.w0 + meoff(AA.e, ME_W0, AA.e.w0_bs, cur.bz, AA.nbatch)) + off;
+                }
+                constexpr int NB = LOGB == 12 ? 8 : 4;  // coefficients per batch (eight spill six registers in the 8192-row kernel).  Each batch waits ~2 000 cycles for its operands (tools/mac_timeline.py);
+                                       // the next batch in flight as well measured equal (a batch's arithmetic covers a quarter of
+                                       // that), and the registers that could hold a whole row early are what the transform runs on
+                uint64_t A0[NB], A1[NB], A2[NB], A3[NB];
+                if constexpr (prefetch) {
+                    const double *e0 = reinterpret_cast<const double *>(tensor ? pa0 : wp);
+                    const double *e1 = reinterpret_cast<const double *>(second ? pb1 : pb0);
+                    transform(tensor ? 2 : (addw ? 1 : 0), std::true_type{}, x, tau, lane, nsrc, e0, e1, kd0, kd1, 1);
+                } else if constexpr (prefetch_w) {
+                    transform(addw ? 1 : 0, std::true_type{}, x, tau, lane, nsrc, reinterpret_cast<const double *>(wp), nullptr, kd0, kd1, 1);
+                } else {
+                    transform(0, std::true_type{}, x, tau, lane, nsrc, nullptr, nullptr, kd0, kd1);
+                }
+#if HE_MAC_R2
+                // x - acc in the accumulators' order, then the transpose to the coalesced order of the operands and the stores
+                // (the tile positions written are the thread's own: no barrier before the stores)
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] -= reduce_f64(acc0[k], q, qi);  // (|y| < q: x - y stays an exact integer below 2^53)
+                mac_final_xfer<LOGB>(x, lds, tau, true);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = lds[lds_phys(k * T + tau)];
+#endif
                 MAC_STAMP2(48 + c * 4 + 2);
                 if (tensor) {
                     const double tsp = AA.e.tsp[cur.l];
-                    const uint64_t *pa0 = AA.e.ta0 + meoff(AA.e, ME_TA0, AA.e.ta0_bs, cur.bz, AA.nbatch) + off, *pa1 = AA.e.ta1 + meoff(AA.e, ME_TA1, AA.e.ta1_bs, cur.bz, AA.nbatch) + off;
-                    const uint64_t *pb0 = AA.e.tb0 + meoff(AA.e, ME_TB0, AA.e.tb0_bs, cur.bz, AA.nbatch) + off, *pb1 = AA.e.tb1 + meoff(AA.e, ME_TB1, AA.e.tb1_bs, cur.bz, AA.nbatch) + off;
                     const uint64_t twoq_u = qu << 1, brc0 = ldc(mcw, 2);
                     // caller words may be any 64-bit representative (as MRed accepts them); every pipeline of this library hands over
                     // words below 2q, which convert as they are -- the Barrett reduction runs only for a wave that met a larger one
-                    constexpr int NB = LOGB == 12 ? 8 : 4;  // coefficients per batch (eight spill six registers in the 8192-row kernel).  Each batch waits ~2 000 cycles for its operands (tools/mac_timeline.py);
-                                           // the next batch in flight as well measured equal (a batch's arithmetic covers a quarter of
-                                           // that), and the registers that could hold a whole row early are what the transform runs on
                     auto cvtb = [&](uint64_t (&w)[NB], double (&dd)[NB]) {
                         bool big = false;
 #pragma unroll
@@ -1606,7 +1689,6 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #pragma unroll
                         for (int k = 0; k < NB; k++) dd[k] = u52_to_f64(w[k]);
                     };
-                    uint64_t A0[NB], A1[NB], A2[NB], A3[NB];
                     auto issue = [&](auto hc, uint64_t (&r0)[NB], uint64_t (&r1)[NB], uint64_t (&r2)[NB], uint64_t (&r3)[NB]) {
                         constexpr int h = decltype(hc)::value;
 #pragma unroll
@@ -1632,14 +1714,40 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
 #pragma unroll
                         for (int k = 0; k < NB; k++) {
                             const int i = NB * h + k;
+#if HE_MAC_R2
+                            const double tt = modmul_f64(wv[k], tsp, q, qi) + modmul_f64(x[i], sp, q, qi);
+#else
                             const double yi = reduce_f64(acc0[i], q, qi);  // (|y| < q: x - y stays an exact integer below 2^53, as with the separate epilogue)
                             const double tt = modmul_f64(wv[k], tsp, q, qi) + modmul_f64(x[i] - yi, sp, q, qi);
+#endif
                             stnt(&op[(unsigned)(i * T)], canon_f64(tt, q, qi));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     };
 #define HE_H(n) std::integral_constant<int, n>{}
-                    if (NB == 8 && !second) {
+                    if constexpr (prefetch) {
+                        // kd0 = a0, kd1 = b0 (component 0) / b1 (component 1), all sixteen coefficients, requested a transform ago
+                        if (second) {  // the other two rows (b0, a1), all sixteen coefficients in one request: the accumulators are dead by now.
+                                       // (Requested right after the transform instead, a transpose earlier: 2.37 -> 2.41 ms.)
+#pragma unroll
+                            for (int k = 0; k < NB; k++) {
+                                const unsigned e = (unsigned)(k * T), e2 = (unsigned)((NB + k) * T);
+                                A1[k] = pb0[e]; A2[k] = pa1[e]; A0[k] = pb0[e2]; A3[k] = pa1[e2];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        auto half = [&](auto hc, uint64_t (&vb0)[NB], uint64_t (&va1)[NB]) {
+                            constexpr int h = decltype(hc)::value;
+                            uint64_t w0[NB], w1[NB];
+#pragma unroll
+                            for (int k = 0; k < NB; k++) { w0[k] = (uint64_t)__double_as_longlong(kd0[NB * h + k]); w1[k] = (uint64_t)__double_as_longlong(kd1[NB * h + k]); }
+                            // finish() forms u v (component 0) or u v2 + u2 v (component 1) from (r0, r1, r2, r3) = (u, v, u2, v2)
+                            if (!second) finish(hc, w0, w1, w0, w1);
+                            else finish(hc, w0, vb0, va1, w1);
+                        };
+                        half(HE_H(0), A1, A2);
+                        half(HE_H(1), A0, A3);
+                    } else if (NB == 8 && !second) {
                         // component 0 has two operand rows, not four: all sixteen coefficients' words in ONE request (the second
                         // eight in the registers component 1 uses for a1, b1)
 #pragma unroll
@@ -1660,13 +1768,21 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                     }
 #undef HE_H
                 } else if (addw) {
-                    const uint64_t *wp = (second ? AA.e.w1 + meoff(AA.e, ME_W1, AA.e.w1_bs, cur.bz, AA.nbatch) : AA.e.w0 + meoff(AA.e, ME_W0, AA.e.w0_bs, cur.bz, AA.nbatch)) + off;
                     uint64_t wv[16];
+                    if constexpr (prefetch || prefetch_w) {
 #pragma unroll
-                    for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[(unsigned)(k * T)]);
+                        for (int k = 0; k < 16; k++) wv[k] = (uint64_t)__double_as_longlong(kd0[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) wv[k] = ldnt(&wp[(unsigned)(k * T)]);
+                    }
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
+#if HE_MAC_R2
+                        const uint64_t v = canon_f64(modmul_f64(x[k], sp, q, qi), q, qi);
+#else
                         const uint64_t v = canon_f64(modmul_f64(x[k] - reduce_f64(acc0[k], q, qi), sp, q, qi), q, qi);
+#endif
                         uint64_t *dp = &op[(unsigned)(k * T)];
                         if constexpr (SCAT) dp = op - (cur.rowoff + tau) + auto_dest((unsigned)(cur.rowoff + tau) + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
                         stnt(dp, cred(wv[k] + v, qu));
@@ -1676,7 +1792,11 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                     for (int k = 0; k < 16; k++) {
                         uint64_t *dp = &op[(unsigned)(k * T)];
                         if constexpr (SCAT) dp = op - (cur.rowoff + tau) + auto_dest((unsigned)(cur.rowoff + tau) + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
+#if HE_MAC_R2
+                        stnt(dp, canon_f64(modmul_f64(x[k], sp, q, qi), q, qi));
+#else
                         stnt(dp, canon_f64(modmul_f64(x[k] - reduce_f64(acc0[k], q, qi), sp, q, qi), q, qi));
+#endif
                     }
                 }
                 MAC_STAMP2(48 + c * 4 + 3);
@@ -1684,6 +1804,15 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 // arrays inside the pass would put both in scratch memory)
 #pragma unroll
                 for (int k = 0; k < 16; k++) acc0[k] = acc1[k];
+            };
+            if constexpr (HE_MAC_R2 && HE_MAC_EPI_PREFETCH && LOGB == 12) {
+                // two copies of the pass: the second accumulator's registers are free in the second one (as ONE loop body the
+                // prefetched operand rows cost 180 spilled registers)
+                ext_pass(std::integral_constant<int, 0>{});
+                ext_pass(std::integral_constant<int, 1>{});
+            } else {
+#pragma unroll 1
+                for (int c = 0; c < 2; c++) ext_pass(c);
             }
         }
         const int ol = cur.out_limb;
@@ -1692,8 +1821,60 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
             o0 = (cur.isP ? A.o0P + voff(A.oP0_tab, A.oP0_bs, cur.bz) : A.o0Q + voff(A.oQ0_tab, A.oQ0_bs, cur.bz)) + (size_t)ol * A.N + cur.rowoff + tau;
             o1 = (cur.isP ? A.o1P + voff(A.oP1_tab, A.oP1_bs, cur.bz) : A.o1Q + voff(A.oQ1_tab, A.oQ1_bs, cur.bz)) + (size_t)ol * A.N + cur.rowoff + tau;
         }
+#if HE_MAC_R2
+        if constexpr (!EPI) {
+            // the accumulators leave in the coalesced order: one exchange each (the tile positions a thread writes are its own, and
+            // the other waves' last tile accesses were to theirs: no barrier before the first store)
+            auto to_natural = [&](double (&a)[16]) {
+                mac_final_xfer<LOGB>(a, lds, tau, true);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 16; k++) a[k] = lds[lds_phys(k * T + tau)];
+            };
+            to_natural(acc0);
+            __syncthreads();  // every wave has read acc0 before acc1 lands on it
+            to_natural(acc1);
+        }
+#endif
         if constexpr (EPI) {
             (void)o0; (void)o1; (void)ol;  // the epilogue wrote the final outputs
+        } else if constexpr (SCAT) {
+            // giant step (KsScatter::plain / accumulate): out_c[auto_dest(e)] (+)= CRed(acc_c[e] [+ add[e]])
+            const uint64_t qu = ldc(reinterpret_cast<const uint64_t *>(A.mc + cur.mi), 0);
+            const size_t src = cur.rowoff + tau;
+            const uint64_t *ap = nullptr;
+            if (AA.e.has_w0) ap = (cur.isP ? AA.e.w1 + meoff(AA.e, ME_W1, AA.e.w1_bs, cur.bz, AA.nbatch) : AA.e.w0 + meoff(AA.e, ME_W0, AA.e.w0_bs, cur.bz, AA.nbatch)) + (size_t)ol * A.N + src;
+            uint64_t *b0p = o0 - src, *b1p = o1 - src;  // limb bases
+            uint64_t av[16];
+            if (ap) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) av[k] = ldnt(&ap[(unsigned)(k * T)]);
+            }
+            if (AA.e.gs_accum) {
+                uint64_t p0[16], p1[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const unsigned d = auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
+                    p0[k] = b0p[d]; p1[k] = b1p[d];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const unsigned d = auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
+                    uint64_t v0 = canon_f64(acc0[k], q, qi);
+                    if (ap) v0 = cred(v0 + av[k], qu);
+                    stnt(&b0p[d], p0[k] + v0);
+                    stnt(&b1p[d], p1[k] + canon_f64(acc1[k], q, qi));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const unsigned d = auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
+                    uint64_t v0 = canon_f64(acc0[k], q, qi);
+                    if (ap) v0 = cred(v0 + av[k], qu);
+                    stnt(&b0p[d], v0);
+                    stnt(&b1p[d], canon_f64(acc1[k], q, qi));
+                }
+            }
         } else if constexpr (QF64) {  // the f64 ModDown epilogue reads these as doubles
             double *d0 = reinterpret_cast<double *>(o0), *d1 = reinterpret_cast<double *>(o1);
 #pragma unroll
@@ -1738,10 +1919,16 @@ bool ntt_mac_epilogue_supported(int logN) {
     const int b = ntt_row_bits(logN);
     return b == 12 || b == 13;
 }
+bool ntt_mac_giant_supported(int logN) {
+    const int b = ntt_row_bits(logN);
+    return HE_MAC_R2 && (b == 12 || b == 13);
+}
 hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, View own, const double *keyd, View out0Q,
-                              View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi) {
+                              View out0P, View out1Q, View out1P, int batch, hipStream_t s, const NttMacEpilogue *epi,
+                              const KsScatter *giant) {
     if (a.nlimbs <= 0 || batch <= 0) return hipSuccess;
     if (!r.twd_fwd || !keyd) return hipErrorInvalidValue;
+    if (giant && (epi || a.q_out_f64 || !giant->ginv || !ntt_mac_giant_supported(r.logN))) return hipErrorInvalidValue;
     if (dec.tab || (epi && epi->ext.tab) || (a.q_out_f64 && !no_tab({out0Q, out1Q}))) return hipErrorInvalidValue;
     const int b = ntt_row_bits(r.logN), aa = r.logN - b;
     if (epi && !ntt_mac_epilogue_supported(r.logN)) return hipErrorInvalidValue;
@@ -1755,8 +1942,8 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
     double mac_bytes = ((double)a.beta * batch + 2.0 * a.beta + 2.0 * batch) * a.nlimbs * (double)r.N * 8.0;
     // with the epilogue: + the two extension rows, + the addends (w0 / w1) or the four inputs of the product, per entry and limb
     if (epi) mac_bytes += (2.0 + (epi->tensor ? 4.0 : (epi->has_w0 ? 1.0 : 0.0) + (epi->has_w1 ? 1.0 : 0.0))) * batch * a.nlimbs * (double)r.N * 8.0;
-    static const bool plain_only = env_flag("HERING_MAC_PLAIN");
-    if (epi || b == 13 || (b == 12 && !plain_only)) {  // (the plain kernel has no 8192-row instantiation: it would spill)
+    static const bool plain_only = env_flag("HERING_MAC_PLAIN") && !HE_MAC_R2;  // (the plain kernel reads the key rows in natural order)
+    if (epi || giant || b == 13 || (b == 12 && !plain_only)) {  // (the plain kernel has no 8192-row instantiation: it would spill)
         NttMacDmaArgs D;
         D.k = A;
         D.e = MacEpiK{};
@@ -1785,6 +1972,27 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
             }
             for (int i = 0; i < a.nlimbs; i++) { D.e.sp[i] = epi->sp[i]; D.e.tsp[i] = epi->tsp[i]; }
         }
+        if (giant) {
+            D.e.sc_ginv = giant->ginv; D.e.sc_logN = r.logN;
+            D.e.has_w0 = giant->add0.p ? 1 : 0;
+            D.e.w0 = giant->add0.p; D.e.w0_bs = giant->add0.bstride; D.e.w1 = giant->add0P.p; D.e.w1_bs = giant->add0P.bstride;
+            D.e.gs_accum = giant->accumulate ? 1 : 0;
+            // entry tables of the addend: rows of the request's table, like the epilogue's operands
+            const View *vs[2] = {&giant->add0, &giant->add0P};
+            const size_t *base = nullptr;
+            for (const View *v : vs) if (v->tab && (!base || v->tab < base)) base = v->tab;
+            D.e.etab = base;
+            D.e.etab_rows = 0xFFFFFFFFu;
+            for (int i = 0; i < 2 && base; i++) {
+                if (!vs[i]->tab) continue;
+                const size_t d = (size_t)(vs[i]->tab - base);
+                if (d % (size_t)batch != 0 || d / (size_t)batch >= 15) return hipErrorInvalidValue;
+                const int which = i == 0 ? ME_W0 : ME_W1;
+                D.e.etab_rows = (D.e.etab_rows & ~(0xFu << (4 * which))) | ((unsigned)(d / (size_t)batch) << (4 * which));
+            }
+            // + the addend row and, accumulating, the two destination rows read
+            mac_bytes += ((giant->add0.p ? 1.0 : 0.0) + (giant->accumulate ? 2.0 : 0.0)) * batch * a.nlimbs * (double)r.N * 8.0;
+        }
         D.nbatch = (unsigned)batch;
         D.nitems = (unsigned)batch * (unsigned)a.nlimbs * (1u << aa);
         for (int i = 0; i < a.nlimbs; i++)
@@ -1805,6 +2013,9 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
         } else if (epi) {
             if (b == 12) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false, true>), dim3(G), dim3(256), 0, s, D);
             else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, false, true>), dim3(G), dim3(512), 0, s, D);
+        } else if (giant) {
+            if (b == 12) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false, false, true>), dim3(G), dim3(256), 0, s, D);
+            else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, false, false, true>), dim3(G), dim3(512), 0, s, D);
         } else if (b == 12) {
             if (a.q_out_f64) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, true>), dim3(G), dim3(256), 0, s, D);
             else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false>), dim3(G), dim3(256), 0, s, D);
@@ -1844,20 +2055,33 @@ struct KeyF64Args {
     double *keyd;
     const ModConst *mc;
     int N, nlimbs;
+    int rowbits;  // > 0: rows of 2^rowbits coefficients are stored in the NTT + MAC kernel's accumulator order (HE_MAC_R2)
     uint8_t mod[kMaxLimbs];
 };
 __global__ void __launch_bounds__(256) key_to_f64_kernel(KeyF64Args A) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= A.N) return;
     const int l = blockIdx.y;
-    const size_t off = ((size_t)blockIdx.z * A.nlimbs + l) * A.N + x;
+    const size_t base = ((size_t)blockIdx.z * A.nlimbs + l) * A.N;
     const ModConst m = A.mc[A.mod[l]];
-    A.keyd[off] = (m.q >> kF64Bits) == 0 ? (double)imform(A.key[off], m.q, m.qinv) : 0.0;
+    // coefficient e = 16 t + k of a row goes to position k T + t (T = row / 16 threads): thread t of the kernel reads its k-th key
+    // word at k T + t -- coalesced -- and finds the coefficient its k-th register holds after the last round of the transform
+    size_t dst = (size_t)x;
+    if (A.rowbits > 0) {
+        const unsigned e = (unsigned)x & ((1u << A.rowbits) - 1u), T = 1u << (A.rowbits - 4);
+        dst = (size_t)((unsigned)x - e) + (e & 15u) * T + (e >> 4);
+    }
+    A.keyd[base + dst] = (m.q >> kF64Bits) == 0 ? (double)imform(A.key[base + x], m.q, m.qinv) : 0.0;
 }
 hipError_t launch_key_to_f64(const RingDev &r, const uint64_t *key, double *keyd, int nblocks, const uint8_t *limb_mod_host,
                              int nlimbs, hipStream_t s) {
     KeyF64Args A{};
     A.key = key; A.keyd = keyd; A.mc = r.mc; A.N = r.N; A.nlimbs = nlimbs;
+#if HE_MAC_R2
+    A.rowbits = ntt_row_bits(r.logN) >= 12 ? ntt_row_bits(r.logN) : 0;  // the persistent kernel's rows (launch_ntt_mac_f64)
+#else
+    A.rowbits = 0;
+#endif
     for (int i = 0; i < nlimbs; i++) A.mod[i] = limb_mod_host[i];
     dim3 grid((unsigned)((r.N + 255) / 256), nlimbs, nblocks), block(256);
     hipLaunchKernelGGL(key_to_f64_kernel, grid, block, 0, s, A);
@@ -3404,6 +3628,11 @@ struct KsKArgs {
     const uint64_t *add0;
     size_t add0_bs;
     uint64_t add_s[kMaxLimbs];
+    // the giant step of a linear transformation (KsScatter::plain / accumulate): plain addend on Q and P limbs, stores that add
+    int add_plain, accum;
+    const uint64_t *add0P;
+    size_t add0P_bs;
+    const size_t *add0P_tab;
 };
 
 template <int BB, bool SCAT = false>
@@ -3433,12 +3662,25 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
     auto is_own = [&](int d) -> bool {
         return A.k.own_alpha > 0 && A.k.out_view[l] == 0 && ql >= d * A.k.own_alpha && ql < (d + 1) * A.k.own_alpha;
     };
-    [[maybe_unused]] uint64_t addv[BB];
+    [[maybe_unused]] uint64_t addv[BB], prev0[BB], prev1[BB];
     if constexpr (SCAT) {
-        if (A.add0 && A.k.out_view[l] == 0) {  // block-uniform; in flight over the whole digit loop
+        const bool onP = A.k.out_view[l] != 0;
+        if (A.add0 && (!onP || A.add_plain)) {  // block-uniform; in flight over the whole digit loop
+            const uint64_t *ap = onP ? A.add0P : A.add0;
 #pragma unroll
-            for (int b = 0; b < BB; b++)
-                addv[b] = ldnt(&A.add0[voff(A.add0_tab, A.add0_bs, (size_t)(b0 + b < A.batch ? b0 + b : b0)) + (size_t)A.k.out_limb[l] * A.N + x]);
+            for (int b = 0; b < BB; b++) {
+                const size_t bb = (size_t)(b0 + b < A.batch ? b0 + b : b0);
+                addv[b] = ldnt(&ap[(onP ? voff(A.add0P_tab, A.add0P_bs, bb) : voff(A.add0_tab, A.add0_bs, bb)) + (size_t)A.k.out_limb[l] * A.N + x]);
+            }
+        }
+        if (A.accum) {  // the words the stores will increase, requested now
+            const size_t pos = (size_t)A.k.out_limb[l] * A.N + auto_dest((unsigned)x, A.sc_ginv, A.sc_logN);
+#pragma unroll
+            for (int b = 0; b < BB; b++) {
+                const size_t bb = (size_t)(b0 + b < A.batch ? b0 + b : b0);
+                prev0[b] = (onP ? A.o0P + voff(A.oP0_tab, A.oP0_bs, bb) : A.o0Q + voff(A.oQ0_tab, A.oQ0_bs, bb))[pos];
+                prev1[b] = (onP ? A.o1P + voff(A.oP1_tab, A.oP1_bs, bb) : A.o1Q + voff(A.oQ1_tab, A.oQ1_bs, bb))[pos];
+            }
         }
     }
     uint64_t cn[BB], kn0, kn1;
@@ -3481,12 +3723,16 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(KsKArgs A) {
             uint64_t *o0 = isP ? A.o0P + voff(A.oP0_tab, A.oP0_bs, (size_t)(b0 + b)) : A.o0Q + voff(A.oQ0_tab, A.oQ0_bs, (size_t)(b0 + b));
             uint64_t *o1 = isP ? A.o1P + voff(A.oP1_tab, A.oP1_bs, (size_t)(b0 + b)) : A.o1Q + voff(A.oQ1_tab, A.oQ1_bs, (size_t)(b0 + b));
             size_t pos = (size_t)x;
+            uint64_t s0 = r0, s1 = r1;
             if constexpr (SCAT) {
-                if (A.add0 && !isP) r0 = cred(r0 + mred(addv[b], A.add_s[l], q, m.qinv), q);
+                if (A.add0 && A.add_plain) r0 = cred(r0 + addv[b], q);  // ringQP.Add of canonical words
+                else if (A.add0 && !isP) r0 = cred(r0 + mred(addv[b], A.add_s[l], q, m.qinv), q);
                 pos = auto_dest((unsigned)x, A.sc_ginv, A.sc_logN);
+                s0 = r0;
+                if (A.accum) { s0 = prev0[b] + r0; s1 = prev1[b] + r1; }  // AutomorphismNTTWithIndexThenAddLazy: no reduction
             }
-            stnt(&o0[(size_t)ol * A.N + pos], r0);
-            stnt(&o1[(size_t)ol * A.N + pos], r1);
+            stnt(&o0[(size_t)ol * A.N + pos], s0);
+            stnt(&o1[(size_t)ol * A.N + pos], s1);
         }
     }
 }
@@ -3502,6 +3748,7 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own
     A.dec_tab = dec.tab; A.oQ0_tab = out0Q.tab; A.oP0_tab = out0P.tab; A.oQ1_tab = out1Q.tab; A.oP1_tab = out1P.tab; A.add0_tab = nullptr;
     A.mc = r.mc; A.N = r.N; A.batch = batch; A.k = a;
     A.sc_ginv = 0; A.sc_logN = r.logN; A.add0 = nullptr; A.add0_bs = 0;
+    A.add_plain = 0; A.accum = 0; A.add0P = nullptr; A.add0P_bs = 0; A.add0P_tab = nullptr;
     const int bb = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1);
     dim3 grid((unsigned)((r.N + 255) / 256), a.nlimbs, (batch + bb - 1) / bb), block(256);
     // beta digits in, two key rows per digit shared by the batch, two accumulators out
@@ -3511,8 +3758,12 @@ hipError_t launch_ks_inner(const RingDev &r, const KsArgs &a, View dec, View own
         int nadd = 0;
         if (sc->add0.p) {
             A.add0 = sc->add0.p; A.add0_bs = sc->add0.bstride; A.add0_tab = sc->add0.tab;
-            for (int i = 0; i < a.nlimbs; i++) { A.add_s[i] = sc->add_s[i]; nadd += a.out_view[i] == 0; }
+            A.add_plain = sc->plain ? 1 : 0;
+            A.add0P = sc->add0P.p; A.add0P_bs = sc->add0P.bstride; A.add0P_tab = sc->add0P.tab;
+            for (int i = 0; i < a.nlimbs; i++) { A.add_s[i] = sc->add_s[i]; nadd += a.out_view[i] == 0 || sc->plain; }
         }
+        A.accum = sc->accumulate ? 1 : 0;
+        if (A.accum) nadd += 2 * a.nlimbs;  // the two destination rows are read as well
         ProfScope ps(K_KS_INNER, s, ks_bytes + (double)nadd * batch * (double)r.N * 8.0);
         if (bb == 4) hipLaunchKernelGGL((ks_inner_kernel<4, true>), grid, block, 0, s, A);
         else if (bb == 2) hipLaunchKernelGGL((ks_inner_kernel<2, true>), grid, block, 0, s, A);
