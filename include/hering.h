@@ -260,7 +260,7 @@ int he_evaluator_destroy(he_handle eval);
  * extender's ModUp / ModDown, all seven rlwe.EvaluatorProvider methods (core/rlwe/rlwe.go:10-18: he_decompose_ntt,
  * he_gadget_product[_lazy / _hoisted / _hoisted_lazy], he_moddown, he_eval_moddown_qp_to_q_ntt, he_relinearize,
  * he_automorphism_ct / _hoisted / _hoisted_lazy), he_ckks_mul_relin / he_bgv_mul_relin with or without a key, he_centered_lift,
- * he_decomp_fill and he_lintrans_mul_sum -- on the context of `eval` are filed in that context's submission queue; requests of the
+ * he_decomp_fill, he_lintrans_mul_sum and he_lintrans_giant_step -- on the context of `eval` are filed in that context's submission queue; requests of the
  * same (operation, object, scalar arguments, key, aliasing pattern of the operands) waiting at the same time -- from any number of
  * OS threads -- are executed as ONE batched launch that addresses each caller's own polynomials and hoisting buffers through a
  * device table of entry offsets (no staging copies), and every call returns once its batch is enqueued on the context's stream
@@ -425,6 +425,18 @@ int he_lintrans_mul_sum(he_handle eval, int levelQ, int levelP, int n, const he_
                         const he_handle *ct0Q, const he_handle *ct0P, const he_handle *ct1Q, const he_handle *ct1P,
                         const he_handle *index, int accumulate, he_handle out0Q, he_handle out0P, he_handle out1Q,
                         he_handle out1P);
+/* The giant step of lintrans.Evaluator.MultiplyByDiagMatrixBSGS (circuits/common/lintrans/lintrans_evaluator.go:397-441) as ONE
+ * call -- the calls the reference makes after the inner loop of giant step j != 0, in its order:
+ *   GadgetProductLazy(levelQ, cx, key, cQP)                                      (:412, core/rlwe/evaluator_gadget_product.go:45)
+ *   ringQP.Add(cQP[0], (addQ, addP), cQP[0])                                     (:413)
+ *   ringQP.AutomorphismNTTWithIndex(cQP[k], index_gal, out_k)                    (:419-420; accumulate == 0)
+ *   ringQP.AutomorphismNTTWithIndexThenAddLazy(cQP[k], index_gal, out_k)         (:422-423; accumulate != 0: out_k += ..., no reduction)
+ * with cx = the (ModDown'ed) inner sum of component 1, (addQ, addP) the inner sum of component 0 on Q and P, gal the Galois element
+ * of the giant step's rotation, key its Galois key, out_k = (ckQ, ckP) the outer accumulators.  Word for word what the separate
+ * calls produce; the intermediate ciphertext cQP is never materialised where the key inner products can store through the
+ * automorphism themselves (standard rings, RNS gadgets).  The outputs must not alias the inputs. */
+int he_lintrans_giant_step(he_handle eval, int levelQ, he_handle cx, he_handle key, uint64_t gal, he_handle addQ, he_handle addP,
+                           he_handle c0Q, he_handle c0P, he_handle c1Q, he_handle c1P, int accumulate);
 
 #ifdef __cplusplus
 }

@@ -543,6 +543,15 @@ public:
                                   any_index ? ix.data() : nullptr, accumulate ? 1 : 0, out[0].Q.h(), out[0].P.h(), out[1].Q.h(), out[1].P.h()));
     }
 
+    // the giant step of lintrans.Evaluator.MultiplyByDiagMatrixBSGS (lintrans_evaluator.go:397-441) as one call: GadgetProductLazy(cx)
+    // -> cQP; cQP[0] += add; out[k] (+)= AutomorphismNTTWithIndex[ThenAddLazy](cQP[k]) -- the key inner products store through
+    // the automorphism themselves (he_lintrans_giant_step)
+    void LinTransGiantStep(int levelQ, const Poly &cx, const EvaluationKey &galoisKey, uint64_t galEl, const PolyQP &add, bool accumulate,
+                           std::array<PolyQP, 2> &out) const {
+        check(he_lintrans_giant_step(h(), levelQ, cx.h(), galoisKey.h(), galEl, add.Q.h(), add.P.h(), out[0].Q.h(), out[0].P.h(), out[1].Q.h(),
+                                     out[1].P.h(), accumulate ? 1 : 0));
+    }
+
     // ---- rlwe.Evaluator ----
     void ModDown(int levelQ, int levelP, const std::array<PolyQP, 2> &ctQP, Ciphertext &ct) const {
         check(he_moddown(h(), levelQ, levelP, ctQP[0].Q.h(), ctQP[0].P.h(), ctQP[1].Q.h(), ctQP[1].P.h(), ct.Value.at(0).h(), ct.Value.at(1).h()));

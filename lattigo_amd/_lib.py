@@ -116,6 +116,7 @@ def _declare(L):
         "he_centered_lift": [H, i, H, i, i, H, i, H],
         "he_decomp_fill": [H, i, i, H, H],
         "he_lintrans_mul_sum": [H, i, i, i, HP, HP, HP, HP, HP, HP, HP, i, H, H, H, H],
+        "he_lintrans_giant_step": [H, i, H, H, C.c_uint64, H, H, H, H, H, H, i],
         "he_ckks_mul_relin": [H, i, H, H, H, H, H, H, H, H],
         "he_bgv_mul_relin": [H, i, C.c_uint64, H, H, H, H, H, H, H, H],
         "he_probe_modmul": [H, i, C.POINTER(C.c_double)], "he_probe_modmul_f64": [H, i, C.POINTER(C.c_double)],
@@ -175,6 +176,7 @@ _TRACE_FNS = {
     "he_relinearize": (41, "hihhhhhh"), "he_automorphism_ct": (42, "hihhihhh"), "he_automorphism_hoisted": (43, "hihhihhh"),
     "he_automorphism_hoisted_lazy": (44, "hihhihhhhh"), "he_centered_lift": (45, "hihiihih"), "he_decomp_fill": (46, "hiihh"),
     "he_lintrans_mul_sum": (47, "hiiiHHHHHHHihhhh"), "he_ckks_mul_relin": (48, "hihhhhhhhh"), "he_bgv_mul_relin": (49, "hiihhhhhhhh"),
+    "he_lintrans_giant_step": (50, "hihhihhhhhhi"),
 }
 # length of the arrays of a call: (function, argument index) -> index of the argument holding it (+1 for "level" arguments)
 _TRACE_LEN = {("he_mul_rns_scalar_montgomery", 3): (1, 1), ("he_add_scalar_bigint", 3): (4, 0), ("he_sub_scalar_bigint", 3): (4, 0),

@@ -1817,9 +1817,34 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
         }
         const int ol = cur.out_limb;
         uint64_t *o0 = nullptr, *o1 = nullptr;
+        // an opaque copy of the thread index for the item's tail, as in the digits: with the kernel-scope one the tile addresses
+        // of the exchanges below are hoisted out of the persistent loop -- and spilled (the giant-step variant: 54-89 registers,
+        // every reload followed by a vmcnt(0))
+        unsigned tau_t = threadIdx.x;
+        asm volatile("" : "+v"(tau_t));
+        const unsigned tau = tau_t;
         if constexpr (!EPI) {
             o0 = (cur.isP ? A.o0P + voff(A.oP0_tab, A.oP0_bs, cur.bz) : A.o0Q + voff(A.oQ0_tab, A.oQ0_bs, cur.bz)) + (size_t)ol * A.N + cur.rowoff + tau;
             o1 = (cur.isP ? A.o1P + voff(A.oP1_tab, A.oP1_bs, cur.bz) : A.o1Q + voff(A.oQ1_tab, A.oQ1_bs, cur.bz)) + (size_t)ol * A.N + cur.rowoff + tau;
+        }
+        // giant step (KsScatter::plain / accumulate): the addend row and the two destination rows are requested BEFORE the
+        // accumulators' exchanges (requested after them the launch was 29 % slower: 16.4 -> 21.1 ms per c5 step)
+        [[maybe_unused]] uint64_t gs_av[16], gs_p0[16], gs_p1[16];
+        [[maybe_unused]] const uint64_t *gs_ap = nullptr;
+        if constexpr (!EPI && SCAT) {
+            __builtin_amdgcn_sched_barrier(0);  // (not above the last digit's products: the key rows' registers are free only now)
+            const size_t src = cur.rowoff + tau;
+            if (AA.e.has_w0) gs_ap = (cur.isP ? AA.e.w1 + meoff(AA.e, ME_W1, AA.e.w1_bs, cur.bz, AA.nbatch) : AA.e.w0 + meoff(AA.e, ME_W0, AA.e.w0_bs, cur.bz, AA.nbatch)) + (size_t)ol * A.N + src;
+            if (gs_ap) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) gs_av[k] = ldnt(&gs_ap[(unsigned)(k * T)]);
+            }
+            if (AA.e.gs_accum) {
+                const uint64_t *b0p = o0 - src;  // limb base
+#pragma unroll
+                for (int k = 0; k < 16; k++) gs_p0[k] = b0p[auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #if HE_MAC_R2
         if constexpr (!EPI) {
@@ -1832,6 +1857,27 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 for (int k = 0; k < 16; k++) a[k] = lds[lds_phys(k * T + tau)];
             };
             to_natural(acc0);
+            if constexpr (SCAT) {
+                // giant step: component 0 leaves now (its operands were requested before the exchange), component 1's destination
+                // row is requested meanwhile -- all three rows in flight at once cost the 8192-row kernel 89 spilled registers
+                const uint64_t qu = ldc(reinterpret_cast<const uint64_t *>(A.mc + cur.mi), 0);
+                const size_t src = cur.rowoff + tau;
+                uint64_t *b0p = o0 - src;
+                const uint64_t *b1p = o1 - src;
+                const bool accum = AA.e.gs_accum != 0;
+                if (accum) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) gs_p1[k] = b1p[auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    uint64_t v0 = canon_f64(acc0[k], q, qi);
+                    if (gs_ap) v0 = cred(v0 + gs_av[k], qu);   // ringQP.Add of canonical words
+                    if (accum) v0 += gs_p0[k];                   // ...ThenAddLazy: no reduction
+                    stnt(&b0p[auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN)], v0);
+                }
+            }
             __syncthreads();  // every wave has read acc0 before acc1 lands on it
             to_natural(acc1);
         }
@@ -1839,41 +1885,15 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
         if constexpr (EPI) {
             (void)o0; (void)o1; (void)ol;  // the epilogue wrote the final outputs
         } else if constexpr (SCAT) {
-            // giant step (KsScatter::plain / accumulate): out_c[auto_dest(e)] (+)= CRed(acc_c[e] [+ add[e]])
-            const uint64_t qu = ldc(reinterpret_cast<const uint64_t *>(A.mc + cur.mi), 0);
+            // giant step (KsScatter::plain / accumulate): out_c[auto_dest(e)] (+)= CRed(acc_c[e] [+ add[e]]); component 0 left above
             const size_t src = cur.rowoff + tau;
-            const uint64_t *ap = nullptr;
-            if (AA.e.has_w0) ap = (cur.isP ? AA.e.w1 + meoff(AA.e, ME_W1, AA.e.w1_bs, cur.bz, AA.nbatch) : AA.e.w0 + meoff(AA.e, ME_W0, AA.e.w0_bs, cur.bz, AA.nbatch)) + (size_t)ol * A.N + src;
-            uint64_t *b0p = o0 - src, *b1p = o1 - src;  // limb bases
-            uint64_t av[16];
-            if (ap) {
+            uint64_t *b1p = o1 - src;
+            const bool accum = AA.e.gs_accum != 0;
 #pragma unroll
-                for (int k = 0; k < 16; k++) av[k] = ldnt(&ap[(unsigned)(k * T)]);
-            }
-            if (AA.e.gs_accum) {
-                uint64_t p0[16], p1[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const unsigned d = auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
-                    p0[k] = b0p[d]; p1[k] = b1p[d];
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const unsigned d = auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
-                    uint64_t v0 = canon_f64(acc0[k], q, qi);
-                    if (ap) v0 = cred(v0 + av[k], qu);
-                    stnt(&b0p[d], p0[k] + v0);
-                    stnt(&b1p[d], p1[k] + canon_f64(acc1[k], q, qi));
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const unsigned d = auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN);
-                    uint64_t v0 = canon_f64(acc0[k], q, qi);
-                    if (ap) v0 = cred(v0 + av[k], qu);
-                    stnt(&b0p[d], v0);
-                    stnt(&b1p[d], canon_f64(acc1[k], q, qi));
-                }
+            for (int k = 0; k < 16; k++) {
+                uint64_t v1 = canon_f64(acc1[k], q, qi);
+                if (accum) v1 += gs_p1[k];
+                stnt(&b1p[auto_dest((unsigned)src + (unsigned)(k * T), AA.e.sc_ginv, AA.e.sc_logN)], v1);
             }
         } else if constexpr (QF64) {  // the f64 ModDown epilogue reads these as doubles
             double *d0 = reinterpret_cast<double *>(o0), *d1 = reinterpret_cast<double *>(o1);

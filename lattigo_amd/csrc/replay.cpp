@@ -33,7 +33,7 @@ enum Fn : uint64_t {
     F_MUL_BIGINT_THEN_ADD, F_DOUBLE_RNS, F_SHIFT, F_MONOMIAL, F_MUL_BY_VECTOR, F_DIV, F_RESCALE_POLYS, F_INDEX_CREATE, F_INDEX_DESTROY,
     F_AUTO_INDEX, F_AUTO_INDEX_ADD, F_AUTO_COEFF, F_MODUP_QP, F_MODUP_PQ, F_MODDOWN_BE, F_EVAL_MODDOWN, F_DECOMP_CREATE, F_DECOMP_DESTROY,
     F_DECOMPOSE_NTT, F_GP_LAZY, F_GP_HOISTED_LAZY, F_MODDOWN, F_GP, F_GP_HOISTED, F_RELIN, F_AUTO_CT, F_AUTO_HOISTED, F_AUTO_HOISTED_LAZY,
-    F_CENTERED_LIFT, F_DECOMP_FILL, F_LINTRANS, F_CKKS_MUL, F_BGV_MUL, F_COUNT
+    F_CENTERED_LIFT, F_DECOMP_FILL, F_LINTRANS, F_CKKS_MUL, F_BGV_MUL, F_GIANT_STEP, F_COUNT
 };
 struct Arg {
     uint64_t kind = 0, val = 0;
@@ -152,6 +152,7 @@ int run_call(const Call &c, std::unordered_map<uint64_t, uint64_t> &map, std::ve
                                                     (int)I(11), H(12), H(13), H(14), H(15));
         case F_CKKS_MUL: return he_ckks_mul_relin(H(0), (int)I(1), H(2), H(3), H(4), H(5), H(6), H(7), H(8), H(9));
         case F_BGV_MUL: return he_bgv_mul_relin(H(0), (int)I(1), I(2), H(3), H(4), H(5), H(6), H(7), H(8), H(9), H(10));
+        case F_GIANT_STEP: return he_lintrans_giant_step(H(0), (int)I(1), H(2), H(3), I(4), H(5), H(6), H(7), H(8), H(9), H(10), (int)I(11));
         default: return HE_EINVAL;
     }
 }

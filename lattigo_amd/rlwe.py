@@ -256,6 +256,13 @@ class Evaluator:
         check(load().he_automorphism_hoisted_lazy(self.h, levelQ, ctIn[0].h, c1DecompQP.h, galEl, gk.h,
                                                   q0.h, p0.h, q1.h, p1.h))
 
+    # the giant step of lintrans.Evaluator.MultiplyByDiagMatrixBSGS (circuits/common/lintrans/lintrans_evaluator.go:397-441):
+    # GadgetProductLazy(cx) -> cQP; cQP[0] += addQP; outQP[k] (+)= phi_galEl(cQP[k]) -- he_lintrans_giant_step
+    def LinTransGiantStep(self, levelQ, cx: Poly, gk: EvaluationKey, galEl: int, addQP, outQP, accumulate: bool):
+        (q0, p0), (q1, p1) = outQP
+        check(load().he_lintrans_giant_step(self.h, levelQ, cx.h, gk.h, galEl, addQP[0].h, addQP[1].h, q0.h, p0.h, q1.h, p1.h,
+                                            1 if accumulate else 0))
+
     # schemes/ckks Evaluator.Mul / MulRelin (schemes/ckks/evaluator.go:613,742 -> mulRelin :764)
     def CKKSMulRelin(self, level, op0, op1, rlk: EvaluationKey | None, opOut):
         o2 = opOut[2].h if rlk is None else 0

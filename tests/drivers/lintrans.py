@@ -6,6 +6,8 @@ job, circuits/common/lintrans/lintrans.go:205) stays on the host: a ``LinearTran
 diagonals as QP polynomials in the NTT + Montgomery domain."""
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 
 from lattigo_amd._lib import H, check, load
@@ -81,6 +83,9 @@ class LinTransEvaluator:
         self.be = BasisExtender(self.ringQ, self.ringP)
         self.nth_root = self.ringQ.NthRoot()
         self._index = {}
+        # the giant step of the BSGS product through he_lintrans_giant_step (one call) or through the reference's own sequence of
+        # calls (HERING_DRIVER_NO_GIANT=1, and the parity test of the two)
+        self.fuse_giant = os.environ.get("HERING_DRIVER_NO_GIANT", "0") in ("", "0")
 
     def GaloisElement(self, k: int) -> int:
         return GaloisElement(self.nth_root, k)
@@ -222,17 +227,22 @@ class LinTransEvaluator:
                 evk = self.gks.GetGaloisKey(galEl)
                 if evk.LevelP() != levelP:
                     raise ValueError(f"LinearTransformation.LevelP = {levelP} != GaloiKey[{galEl}].LevelP() = {evk.LevelP()}")
-                rotIndex = self.AutomorphismIndex(galEl)
-                self.eval.GadgetProductLazy(levelQ, tmp1QP[0], evk, cQP)
-                rQ.Add(cQP[0][0], tmp0QP[0], cQP[0][0])
-                rP.Add(cQP[0][1], tmp0QP[1], cQP[0][1])
-                for src, dst in ((cQP[0], c0OutQP), (cQP[1], c1OutQP)):
-                    if cnt0 == 0:
-                        rQ.AutomorphismNTTWithIndex(src[0], rotIndex, dst[0])
-                        rP.AutomorphismNTTWithIndex(src[1], rotIndex, dst[1])
-                    else:
-                        rQ.AutomorphismNTTWithIndexThenAddLazy(src[0], rotIndex, dst[0])
-                        rP.AutomorphismNTTWithIndexThenAddLazy(src[1], rotIndex, dst[1])
+                if self.fuse_giant:
+                    # :412-423 as one native call (he_lintrans_giant_step): the key inner products store c0 + tmp0 and c1 through
+                    # the rotation into the outer accumulators; cQP is not materialised
+                    self.eval.LinTransGiantStep(levelQ, tmp1QP[0], evk, galEl, tmp0QP, (c0OutQP, c1OutQP), cnt0 != 0)
+                else:
+                    rotIndex = self.AutomorphismIndex(galEl)
+                    self.eval.GadgetProductLazy(levelQ, tmp1QP[0], evk, cQP)
+                    rQ.Add(cQP[0][0], tmp0QP[0], cQP[0][0])
+                    rP.Add(cQP[0][1], tmp0QP[1], cQP[0][1])
+                    for src, dst in ((cQP[0], c0OutQP), (cQP[1], c1OutQP)):
+                        if cnt0 == 0:
+                            rQ.AutomorphismNTTWithIndex(src[0], rotIndex, dst[0])
+                            rP.AutomorphismNTTWithIndex(src[1], rotIndex, dst[1])
+                        else:
+                            rQ.AutomorphismNTTWithIndexThenAddLazy(src[0], rotIndex, dst[0])
+                            rP.AutomorphismNTTWithIndexThenAddLazy(src[1], rotIndex, dst[1])
             else:
                 for src, dst in ((tmp0QP, c0OutQP), (tmp1QP, c1OutQP)):
                     if cnt0 == 0:

@@ -399,6 +399,11 @@ def _program(pr, ctx, gev, be, keys, nq, np_, seed, N):
                                          arr(lambda t_: t_[2][1].h), arr(lambda t_: t_[3].h if t_[3] is not None else 0), accumulate,
                                          out[0][0].h, out[0][1].h, out[1][0].h, out[1][1].h))
     res += [out[0][0], out[0][1], out[1][0], out[1][1]]
+    # the giant step of the BSGS product (he_lintrans_giant_step): overwriting, then accumulating onto the same outer accumulators
+    og = qp()
+    gev.LinTransGiantStep(lvQ, a, gk, gal, out[0], og, False)
+    gev.LinTransGiantStep(lvQ, b, gk, gal, out[1], og, True)
+    res += [og[0][0], og[0][1], og[1][0], og[1][1]]
     lq, lp_ = newq(), newp()
     check(load().he_centered_lift(gev.h, 1, a.h, 0, lvQ, lq.h, lvP, lp_.h)); res += [lq, lp_]
     dec2 = la.Decomposition(gev); keep.append(dec2)

@@ -1058,3 +1058,50 @@ def test_random_calls_with_the_queue_on(ctx, deferred):
         assert ctx.CoalescingStats()["calls"] - s0["calls"] > 50  # the batch-1 draws did go through the queue
     finally:
         ctx.SetCoalescing(0, 0)
+
+
+@pytest.mark.parametrize("logN,logq,logp,B", [(13, [55, 45, 45, 60, 45, 45], [55, 45], 3),    # 4096-rows; a double-precision special prime too
+                                               (16, [60, 45, 45, 45, 58], [61, 61], 2),       # 8192-rows
+                                               (15, [55, 55, 56], [55], 1),                    # integer-class limbs only (no NTT + MAC launch)
+                                               (11, [55, 45, 45], [55, 45], 2)])               # below the persistent kernel: the separate launches
+def test_lintrans_giant_step(ctx, logN, logq, logp, B):
+    """he_lintrans_giant_step (circuits/common/lintrans/lintrans_evaluator.go:397-441): GadgetProductLazy + ringQP.Add of the
+    inner sum + AutomorphismNTTWithIndex[ThenAddLazy] into the outer accumulators as one call whose key inner products store
+    through the automorphism -- against the oracle's separate calls, word for word, overwriting and accumulating (the
+    accumulator's previous words are arbitrary 64-bit values: ...ThenAddLazy does not reduce), full level and one below."""
+    q, p = O.GenModuli(logN + 1, logq, logp)
+    pr = Pair(ctx, logN, len(q), len(p), qmods=q, pmods=p)
+    N = pr.N
+    rng = rng_for(6100 + logN)
+    oev, gev = O.Evaluator(pr.oQ, pr.oP), la.Evaluator(pr.gQ, pr.gP)
+    nq, np_ = len(q), len(p)
+    beta = (nq + np_ - 1) // np_
+    kq = np.stack([np.stack([uniform_poly(rng, q, N) for _ in range(2)]) for _ in range(beta)])
+    kp = np.stack([np.stack([uniform_poly(rng, p, N) for _ in range(2)]) for _ in range(beta)])
+    okey, gkey = O.EvaluationKey(kq, kp), gev.NewEvaluationKey(kq, kp)
+    for levelQ in (nq - 1, nq - 2):
+        Qm = q[: levelQ + 1]
+        for galel, acc in ((5, False), (pow(5, 77, 2 * N), True), (2 * N - 1, True)):
+            cx = np.stack([uniform_poly(rng, Qm, N) for _ in range(B)])
+            aq = np.stack([uniform_poly(rng, Qm, N) for _ in range(B)])
+            ap = np.stack([uniform_poly(rng, p, N) for _ in range(B)])
+            prev = [[rng.integers(0, 1 << 63, size=(B, n, N), dtype=np.uint64) * np.uint64(2) + np.uint64(1) for n in (levelQ + 1, np_)]
+                    for _ in range(2)]
+            outs = [(la.Poly(pr.gQ, levelQ + 1, B).upload(prev[k][0]), la.Poly(pr.gP, np_, B).upload(prev[k][1])) for k in range(2)]
+            gev.LinTransGiantStep(levelQ, la.Poly(pr.gQ, levelQ + 1, B).upload(cx), gkey, galel,
+                                  (la.Poly(pr.gQ, levelQ + 1, B).upload(aq), la.Poly(pr.gP, np_, B).upload(ap)), outs, acc)
+            idx = pr.oQ.AutomorphismNTTIndex(galel)
+            for b in range(B):
+                wQ, wP = oev.GadgetProductLazy(levelQ, cx[b], okey)
+                for k in range(2):
+                    for part, (w, add, ring_, mods) in enumerate(((wQ[k], aq[b], pr.oQ, Qm), (wP[k], ap[b], pr.oP, p))):
+                        v = w.copy()
+                        if k == 0:  # ringQP.Add of canonical words: one conditional subtraction
+                            for i, m in enumerate(mods):
+                                s = v[i] + add[i]
+                                v[i] = np.where(s >= np.uint64(m), s - np.uint64(m), s)
+                        want = v[:, idx]
+                        if acc:
+                            want = prev[k][part][b] + want  # uint64 wrap-around, no reduction
+                        got = outs[k][part].download()[b] if B > 1 else outs[k][part].download().reshape(want.shape)
+                        assert np.array_equal(got, want), (logN, levelQ, galel, acc, b, k, part)
