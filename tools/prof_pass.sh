@@ -3,5 +3,5 @@
 R=$GRAFT_REPO_ROOT; TAG=$1; CTRS=$2; shift 2
 cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_$TAG
-timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -o b -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-ntt --no-concurrent "$@" > $R/gpurun_out/pmc_$TAG.log 2>&1
+timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -o b -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-ntt --no-concurrent --no-other-configs "$@" > $R/gpurun_out/pmc_$TAG.log 2>&1
 ls $R/gpurun_out/pmc_$TAG | head -3

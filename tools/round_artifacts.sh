@@ -2,7 +2,7 @@
 #   bash tools/round_artifacts.sh          -> bench line, rocprofv3 kernel stats of the same command, PMC traffic (c2, c3, c4, c5) + SQ passes
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_* $R/gpurun_out/prof_final
-BARGS="--no-cpu-baseline --no-verify --no-ntt --no-b1 --no-concurrent"
+BARGS="--no-cpu-baseline --no-verify --no-ntt --no-b1 --no-concurrent --no-other-configs"
 # PMC traffic: separate FETCH_SIZE / WRITE_SIZE passes (kernel trace only, as the guide prescribes); steps of bench.py's step() per
 # run = warmup + steps (no HIP-event leg under the profiler)
 for W in c2 c3 c4 c5; do
@@ -24,7 +24,7 @@ for W in c2 c4 c5; do
 done
 cd $R; timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 400 gpurun_out/bench_final.json
 rm -f gpurun_out/bench_configs.jsonl gpurun_out/bench_configs.err
-for w in c2 c4 c5; do S=10; [ $w = c5 ] && S=5; timeout 900 python bench.py --workload $w --steps $S --no-ntt >> gpurun_out/bench_configs.jsonl 2>> gpurun_out/bench_configs.err; done
+for w in c2 c4 c5; do S=10; [ $w = c5 ] && S=5; timeout 900 python bench.py --workload $w --steps $S --no-ntt --no-other-configs >> gpurun_out/bench_configs.jsonl 2>> gpurun_out/bench_configs.err; done
 timeout 300 python tools/bench_configs.py >> gpurun_out/bench_configs.jsonl 2>> gpurun_out/bench_configs.err
 timeout 200 python tools/ntt_prof.py >> gpurun_out/bench_configs.jsonl 2>> gpurun_out/bench_configs.err
 # machine probes behind DESIGN.md's ceilings: instruction issue rates and what HBM gives a streaming kernel by read : write mix
