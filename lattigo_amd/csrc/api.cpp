@@ -2937,41 +2937,6 @@ int ks_inner(Evaluator &ev, int levelQ, int levelP, View dec, size_t dec_ds, con
     return HE_OK;
 }
 
-// HE_MODUP_UNIFY (kernels.h ModUpDesc::bin_c): the binade in which the double-precision destinations of a descriptor can sum all
-// their products exactly.  Products: a split source (modulus of 2^51 and above) contributes y_lo T and y_hi T' with y_lo < 2^29,
-// y_hi < 2^(bits - 29); an unsplit one y T with y < q_i; T, T' < p for the largest destination modulus below 2^47.  The binade
-// constant is the first power of two above the largest possible sum; every fma drops a part below half an ulp of the running sum
-// (2^(e - 53)), recovered exactly in a second accumulator that joins the result unreduced: it must stay negligible (2^40 per
-// coefficient at most -- modup_f64_raw_ok counts 2^41 per source).
-void set_binade(const BasisExtender &be, ModUpDesc &D) {
-    static const bool off = env_flag("HERING_NO_MODUP_UNIFY");
-    D.bin_c = 0.0;
-    if (off || D.single || D.nsrc <= 0) return;
-    uint64_t pmax = 0;
-    for (int j = 0; j < D.ndst; j++) {
-        const uint64_t p = be.modulus(D.dst_mod[j]);
-        if ((p >> 47) == 0) pmax = std::max(pmax, p);
-    }
-    if (pmax == 0) return;
-    long double S = 0.0L;
-    int pieces = 0;
-    for (int i = 0; i < D.nsrc; i++) {
-        const uint64_t q = be.modulus(D.src_mod[i]);
-        if (D.src_split[i]) {
-            S += ((long double)(1ull << kYSplitBits) + (long double)((q >> kYSplitBits) + 1)) * (long double)pmax;
-            pieces += 2;
-        } else {
-            S += (long double)q * (long double)pmax;
-            pieces += 1;
-        }
-    }
-    int e = 0;
-    while (ldexpl(1.0L, e) <= S) e++;  // S < 2^e
-    // |dropped part| <= 2^(e - 53) per product
-    if (ldexpl((long double)pieces, e - 53) > 0x1p40L || e > 900) return;
-    D.bin_c = ldexp(1.0, e);
-}
-
 // ---- fused pipeline plans ------------------------------------------------------------------
 // which destinations of a descriptor take the lean integer path of modup_fused_kernel (see there): moduli below 2^58 that are
 // not on the double-precision path, column sums that cannot overflow, and a sum that one Montgomery reduction brings below 2p
@@ -3067,7 +3032,6 @@ int get_dec_plan(Evaluator &ev, int levelQ, int levelP, int nbPi, const FusedPla
         }
         D.ndst = n;
         mark_fast_destinations(be, D, basis);
-        set_binade(be, D);
         descs.push_back(D);
     }
     FusedPlan plan;
@@ -3107,7 +3071,6 @@ int get_md_plan(Evaluator &ev, int levelQ, int levelP, const FusedPlan **out) {
         }
         D.ndst = levelQ + 1;
         mark_fast_destinations(be, D, basis);
-        set_binade(be, D);
         TRY(upload_plan(ev, std::vector<ModUpDesc>{D}, plan));
     }
     auto ins = ev.md_plans.emplace(key, plan);

@@ -230,10 +230,6 @@ struct ModUpDesc {
     // (p - dst_half) 2^60 mod p}
     const uint64_t *t60;
     uint8_t dst_fast[kMaxLimbs];
-    // round 6 (HE_MODUP_UNIFY): != 0: the double-precision destinations sum ALL their products -- the split sources' pieces and the
-    // unsplit residues alike -- exactly in the binade [bin_c, 2 bin_c) and reduce once (the host chose bin_c above the largest
-    // possible sum and checked that the parts dropped below its ulp stay negligible); 0: the unsplit terms take modmul_f64 each
-    double bin_c;
     uint8_t src_split[8];
     uint64_t src_half[8];
     uint8_t src_limb[8], src_mod[8];

@@ -3019,9 +3019,6 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
 #ifndef HE_MODUP_YD
 #define HE_MODUP_YD 1
 #endif
-#ifndef HE_MODUP_UNIFY
-#define HE_MODUP_UNIFY 1
-#endif
     constexpr bool YD = DSTF64 && HE_MODUP_YD && NSRC <= 3 && LOGA <= 3 && KREG == 0;
     double ydreg[YD ? R : 1][YD ? NSRC : 1];
     double vi[R];
@@ -3200,47 +3197,6 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                 const double hd = (double)U64(D.dst_half[j]);
 #pragma unroll
                 for (int r = 0; r < R; r++) o[r] = __fma_rn(vd[r], vt1, -hd);
-                bool unified = false;
-#if HE_MODUP_MAGIC && HE_MODUP_UNIFY
-                // ModUpDesc::bin_c != 0: every product of the row -- the split sources' pieces and the unsplit residues alike -- joins
-                // ONE exact sum in the binade the host chose, and the sum is reduced once: four operations per product and six per
-                // coefficient, against seven per unsplit product (and a second reduction for the pieces) before
-                const double Cb = __longlong_as_double((long long)U64((uint64_t)__double_as_longlong(D.bin_c)));
-                if (Cb != 0.0) {
-                    unified = true;
-                    constexpr uint32_t ML = (1u << kYSplitBits) - 1u;
-                    double Tl[NSRC], Th[NSRC];
-#pragma unroll
-                    for (int i = 0; i < NSRC; i++) { Tl[i] = ldcd(Tr, 2 * i); Th[i] = ldcd(Tr, 2 * i + 1); }
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        double H = Cb, L = 0.0;
-#pragma unroll
-                        for (int i = 0; i < NSRC; i++) {
-                            if ((splitmask >> i) & 1) {
-                                const uint64_t yy = ytake(r, i);
-                                const double a0 = (double)((uint32_t)yy & ML), a1 = (double)(uint32_t)(yy >> kYSplitBits);
-                                double Hn = __fma_rn(a0, Tl[i], H);
-                                L += __fma_rn(a0, Tl[i], -(Hn - H));
-                                H = Hn;
-                                Hn = __fma_rn(a1, Th[i], H);
-                                L += __fma_rn(a1, Th[i], -(Hn - H));
-                                H = Hn;
-                            } else {
-                                double a;
-                                if constexpr (YD) a = ydreg[r][i];
-                                else a = u52_to_f64(ytake(r, i));
-                                const double Hn = __fma_rn(a, Tl[i], H);
-                                L += __fma_rn(a, Tl[i], -(Hn - H));
-                                H = Hn;
-                            }
-                        }
-                        const double Hs = H - Cb;
-                        o[r] += __fma_rn(-rint(Hs * pid), pd, Hs) + L;
-                    }
-                }
-#endif
-                if (!unified) {
 #if HE_MODUP_MAGIC
                 // Residues that do not fit a double (source modulus of 2^51 and above: the special primes in ModDown, q0 in the
                 // decomposition) are split y = yh 2^29 + yl and their 2 x (split sources) products with {T, T 2^29 mod p} are
@@ -3313,7 +3269,6 @@ __global__ void __launch_bounds__(128, HE_MODUP_WAVES) modup_fused_kernel(ModUpF
                         for (int r = 0; r < R; r++) o[r] += modmul_f64(u52_to_f64(ytake(r, i)), Tl, pd, pid);
                     }
                 }  // |o| < (2 + 5*NSRC) p + NSRC 2^32 (the split sources' low parts L are added unreduced; modup_f64_raw_ok counts them)
-                }  // (!unified)
             }
             if constexpr (LOGA > 0) {
                 const double *tw = A.twd_fwd + (size_t)mi * A.N;
@@ -3565,8 +3520,7 @@ bool modup_f64_raw_ok(int logN, int nsrc, uint64_t max_small_modulus) {
     // |o| < (2 + 5 nsrc) p + nsrc 2^32 after the matrix-vector sum (the second term: the exact low parts L of the split residues'
     // running sum, two per split source and below 2^31 each, join o unreduced -- HE_MODUP_MAGIC), + 2p per forward stage (column
     // and row): everything must stay below 2^53
-    // (HE_MODUP_UNIFY: the one-binade sum leaves at most 2^40 per coefficient unreduced -- api.cpp set_binade -- counted as 2^41 per source)
-    const long double bound = (long double)(2 + 5 * nsrc + 2 * logN) * (long double)max_small_modulus + (long double)nsrc * 0x1p41L;
+    const long double bound = (long double)(2 + 5 * nsrc + 2 * logN) * (long double)max_small_modulus + (long double)nsrc * 0x1p32L;
     return bound < 0x1p53L;
 }
 hipError_t launch_modup_fused(const RingDev &r, const ModUpDesc *descs_dev, int ndesc, int nsrc, int dst_classes, View src,
