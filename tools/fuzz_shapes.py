@@ -29,7 +29,7 @@ def api_case(ctx, rng):
     """One call of the scheme-level entry points with everything drawn at random: operation, level (below the ring's and the key's
     top), a key that stops below the ring's top level, batch size, and which outputs alias which inputs (the in-place forms the
     reference allows: MulRelin(ct0, ct1, ct0 / ct1), squaring, Relinearize and Rotate in place).  Every entry against the oracle."""
-    logN = int(rng.choice([11, 12, 13, 13, 14, 15]))
+    logN = int(rng.choice([11, 12, 13, 13, 14, 15, 16]))
     nq, np_ = int(rng.integers(2, 9)), int(rng.integers(1, 5))
     logq = [int(rng.choice([50, 55, 58, 60]))] + [int(rng.choice(QBITS)) for _ in range(nq - 1)]
     logp = [int(rng.choice(PBITS)) for _ in range(np_)]
@@ -39,7 +39,7 @@ def api_case(ctx, rng):
     nqk = int(rng.integers(1, nq + 1))                       # the key's Q limbs
     level = int(rng.integers(0, nqk))
     B = int(rng.choice([1, 1, 2, 3, 5]))
-    op = str(rng.choice(["bgv", "ckks", "relin", "rotate", "gadget"]))
+    op = str(rng.choice(["bgv", "ckks", "relin", "rotate", "gadget", "giant", "giant"]))
     alias = int(rng.integers(0, 4))
     seed = int(rng.integers(1, 1 << 30))
     tag = f"api op={op} logN={logN} logq={logq} logp={logp} nqk={nqk} level={level} B={B} alias={alias} seed={seed}"
@@ -78,6 +78,35 @@ def api_case(ctx, rng):
         out = d if alias & 1 else fresh()
         gev.Automorphism(level, d, gal, gk, out)
         want = [oev.Automorphism(h[b], gal, ok) for b in range(B)]
+    elif op == "giant":
+        # he_lintrans_giant_step (round 6): GadgetProductLazy + ringQP.Add + AutomorphismNTTWithIndex[ThenAddLazy] as one call, against
+        # the oracle's separate calls; the accumulators start from arbitrary 64-bit words when accumulating
+        h = draw(2)                                       # [:, 0] = cx, [:, 1] = the Q part of the addend
+        hp = np.stack([uniform_poly(r, p, N) for _ in range(B)])
+        acc = bool(alias & 1)
+        gal = int(rng.choice([pow(5, int(rng.integers(1, N // 2)), 2 * N), 2 * N - 1]))
+        prevQ = [r.integers(0, 1 << 63, size=(B, nl, N), dtype=np.uint64) * np.uint64(2) + np.uint64(alias) for _ in range(2)]
+        prevP = [r.integers(0, 1 << 63, size=(B, np_, N), dtype=np.uint64) * np.uint64(2) + np.uint64(1) for _ in range(2)]
+        outs = [(la.Poly(pr.gQ, nl, B).upload(prevQ[k]), la.Poly(pr.gP, np_, B).upload(prevP[k])) for k in range(2)]
+        gev.LinTransGiantStep(level, la.Poly(pr.gQ, nl, B).upload(np.ascontiguousarray(h[:, 0])), gk, gal,
+                              (la.Poly(pr.gQ, nl, B).upload(np.ascontiguousarray(h[:, 1])), la.Poly(pr.gP, np_, B).upload(hp)), outs, acc)
+        idx = pr.oQ.AutomorphismNTTIndex(gal)
+        for b in range(B):
+            wQ, wP = oev.GadgetProductLazy(level, h[b, 0], ok)
+            for k in range(2):
+                for part, (w, add, mods, prev) in enumerate(((wQ[k], h[b, 1], Qm, prevQ[k][b]), (wP[k], hp[b], p, prevP[k][b]))):
+                    v = np.array(w, dtype=np.uint64, copy=True)
+                    if k == 0:
+                        for i, m in enumerate(mods):
+                            sm = v[i] + add[i]
+                            v[i] = np.where(sm >= np.uint64(m), sm - np.uint64(m), sm)
+                    wantv = v[:, idx]
+                    if acc:
+                        wantv = prev + wantv
+                    gotv = outs[k][part].download().reshape(B, len(mods), N)[b]
+                    if not np.array_equal(gotv, wantv):
+                        raise AssertionError(f"{tag}: entry {b} component {k} part {part}")
+        return tag
     else:
         h = draw(1)
         d = up(h, 1)
