@@ -806,8 +806,10 @@ def other_configs(args):
 # default batches from sweeps on MI355X (round 3): c2 128 / 256 / 512 / 1024 / 2048: 204k / 223k / 243k / 257k / 263k (a logN = 14, 8-limb
 # ciphertext is small: the launches need the larger batch to fill the chip); c3 64 / 128 / 192 / 256 / 512: 33.9k / 36.6k / 37.5k /
 # 37.8k / 38.0k on one box (the persistent NTT+MAC kernel's tail shrinks with more items per workgroup; flat beyond 256);
-# c4 16 / 32 / 64 / 128: 8.6k / 9.2k / 9.6k / 9.8k; c5 8 / 16 / 32: 73 / 84 / 85
-WORKLOADS = {"c2": (setup_c2, 1024), "c3": (setup_c3, 256), "c4": (setup_c4, 64), "c5": (setup_c5, 16)}
+# c4 16 / 32 / 64 / 128: 8.6k / 9.2k / 9.6k / 9.8k (round 6: 64 / 128: 11.8k / 12.0k); c5 8 / 16 / 32: 73 / 84 / 85 (round 6, one box:
+# 16 / 24 / 32 / 48: 94.3 / 99.6 / 100.2 / 102.1 bootstraps/s -- a bootstrap's launches at its low levels are small: the default is 32 since
+# round 6, rounds 1-5 reported batch 16)
+WORKLOADS = {"c2": (setup_c2, 1024), "c3": (setup_c3, 256), "c4": (setup_c4, 128), "c5": (setup_c5, 32)}
 
 
 def ntt_rates(la, ctx):
