@@ -645,12 +645,18 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1, 4
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int e = nat_e<T>(k, tau);  // the wave's own 1024 coefficients: the first exchange stays inside the wave
-            uint64_t v = ldnt(&src[e]);
-            if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, q, mc.brc0);
-            lds[lds_phys(e)] = v;
+        for (int k = 0; k < 16; k++) x[k] = ldnt(&src[nat_e<T>(k, tau)]);  // the wave's own 1024 coefficients: the first exchange stays inside the wave
+        if (A.flags & NTT_REDUCE_INPUT) {  // (only for a wave that met a word of 2q or more: see ntt_rows_f64_kernel)
+            bool big = false;
+#pragma unroll
+            for (int k = 0; k < 16; k++) big = big || x[k] >= twoq;
+            if (__any(big)) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = bred_add_lazy(x[k], q, mc.brc0);
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[lds_phys(nat_e<T>(k, tau))] = x[k];
         rows_sync(0);
         if constexpr (GREM > 0) {
             constexpr int s0 = 4 * NR4;
@@ -1065,13 +1071,21 @@ __global__ void __launch_bounds__((1 << LOGB) / 16 > 0 ? (1 << LOGB) / 16 : 1) n
                 }
             }
         } else {
+        // caller-supplied words (any uint64): the Barrett reduction -- a dozen integer instructions per word -- runs only for a wave
+        // that actually met a word of 2q or more (every pipeline of this library, and a caller that keeps its polynomials reduced,
+        // hands over words below 2q, which convert as they are); the canonical result does not depend on the representative
+        if (A.flags & NTT_REDUCE_INPUT) {
+            const uint64_t twoq_u = mc.q << 1;
+            bool big = false;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int e = nat_e<T>(k, tau);
-            uint64_t v = nx[k];
-            if (A.flags & NTT_REDUCE_INPUT) v = bred_add_lazy(v, mc.q, mc.brc0);
-            lds[lds_phys(e)] = u52_to_f64(v);
+            for (int k = 0; k < 16; k++) big = big || nx[k] >= twoq_u;
+            if (__any(big)) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) nx[k] = bred_add_lazy(nx[k], mc.q, mc.brc0);
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[lds_phys(nat_e<T>(k, tau))] = u52_to_f64(nx[k]);
         }
         if constexpr (PIPE) if (bzi + 1 < b1) {
             const uint64_t *srcn = A.in + voff(A.in_tab, A.in_bs, bzi + 1) + in_off;
