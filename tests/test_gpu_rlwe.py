@@ -1019,7 +1019,7 @@ def test_random_scheme_level_calls(ctx):
     seen = set()
     for _ in range(150):
         seen.add(fz.api_case(ctx, rng).split()[1])
-    assert seen == {"op=bgv", "op=ckks", "op=relin", "op=rotate", "op=gadget"}
+    assert seen == {"op=bgv", "op=ckks", "op=relin", "op=rotate", "op=gadget", "op=giant"}  # (giant: he_lintrans_giant_step, round 6)
     # the ring-level generator of the same tool (every coefficient-wise formula, transforms, rescales, automorphisms; logN 4..16, level
     # below the top, batch, in place): 400 draws (71 681 on the GPU by the tool itself)
     ops = set()
