@@ -617,6 +617,52 @@ func (e *Evaluator) AutomorphismHoistedLazy(levelQ int, ctIn *rlwe.Ciphertext, c
 	})
 }
 
+// LinTransGiantStep is NOT a method of rlwe.EvaluatorProvider: it replaces lines 412-423 of
+// lintrans.Evaluator.MultiplyByDiagMatrixBSGS (circuits/common/lintrans/lintrans_evaluator.go) -- GadgetProductLazy(levelQ, cx, gk, cQP);
+// ringQP.Add(cQP.Value[0], add, cQP.Value[0]); ringQP.AutomorphismNTTWithIndex[ThenAddLazy](cQP.Value[k], index, outQP[k]) -- by one
+// native call whose key inner products store through the automorphism into the outer accumulators (he_lintrans_giant_step; word for
+// word what the separate calls produce).  A maintainer who wants it patches that loop body to
+//
+//	if dev, ok := eval.EvaluatorProvider.(*hering.Evaluator); ok {
+//		err = dev.LinTransGiantStep(levelQ, tmp1QP.Q, galEl, tmp0QP, c0OutQP, c1OutQP, cnt0 != 0)
+//	} else { ... the reference's own calls ... }
+//
+// Staleness: as AutomorphismHoistedLazy (inputs from their device twins, outputs on the device only).
+func (e *Evaluator) LinTransGiantStep(levelQ int, cx ring.Poly, galEl uint64, add, out0, out1 ringqp.Poly, accumulate bool) (err error) {
+	gk, err := e.CheckAndGetGaloisKey(galEl)
+	if err != nil {
+		return fmt.Errorf("cannot apply LinTransGiantStep: %w", err)
+	}
+	k, err := e.evk(&gk.GadgetCiphertext)
+	if err != nil {
+		return err
+	}
+	in, err := e.twin(e.RingQ, cx, true)
+	if err != nil {
+		return err
+	}
+	aq, ap, err := e.qp(add, gk.LevelP(), true)
+	if err != nil {
+		return err
+	}
+	// (accumulating: the accumulators' current words are inputs too)
+	q0, p0, err := e.qp(out0, gk.LevelP(), accumulate)
+	if err != nil {
+		return err
+	}
+	q1, p1, err := e.qp(out1, gk.LevelP(), accumulate)
+	if err != nil {
+		return err
+	}
+	acc := C.int(0)
+	if accumulate {
+		acc = 1
+	}
+	return lockedCall(func() C.int {
+		return C.he_lintrans_giant_step(e.h, C.int(levelQ), in.h, k.h, C.uint64_t(galEl), aq.h, h(ap), q0.h, h(p0), q1.h, h(p1), acc)
+	})
+}
+
 // ModDownQPtoQNTT: ring/basis_extension.go:235 through the evaluator's fused three-launch pipeline.
 // Staleness: inputs are read from their device twins (uploaded on first sight only -- call Upload after a host-side change);
 // outputs are written on the device only (Download / Sync before reading them on the host).
