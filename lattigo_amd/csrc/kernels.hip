@@ -1387,7 +1387,9 @@ struct NttMacDmaArgs {
 // accumulators' P parts arrive through the same prefetch chain as two more "digits", are transformed like them, and
 // out_c = [w_c +] (NTT(ext_c) - acc_c) s is formed against the accumulator still in registers -- the Q accumulators are never
 // written, and the separate forward-row + epilogue launch (HBM-bound, next to this latency-bound kernel) is gone.
-template <int LOGB, bool QF64, bool EPI = false, bool SCAT = false>
+// TEN (with EPI): the epilogue forms the tensor term (NttMacEpilogue::tensor) -- its own instantiation since round 6: with both
+// epilogue forms in one kernel the 4096-row variant was 75 KiB of code for a 64 KiB instruction cache shared by two CUs
+template <int LOGB, bool QF64, bool EPI = false, bool SCAT = false, bool TEN = false>
 __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(NttMacDmaArgs AA) {
     static_assert(LOGB == 12 || LOGB == 13, "production row sizes only");
     constexpr int N2 = 1 << LOGB;
@@ -1646,7 +1648,10 @@ __global__ void __launch_bounds__((1 << LOGB) / 16, 2) ntt_mac_f64_dma_kernel(Nt
                 const double sp = AA.e.sp[cur.l];
                 const uint64_t *mcw = reinterpret_cast<const uint64_t *>(A.mc + cur.mi);
                 const uint64_t qu = ldc(mcw, 0);
-                const bool tensor = AA.e.tensor != 0, addw = !tensor && (second ? AA.e.has_w1 : AA.e.has_w0) != 0;
+                // (4096-rows: compile-time; the 8192-row kernel keeps both forms behind a run-time flag -- split the same way its
+                // Rotate variant measured 2 % slower, 4.35 -> 4.46 ms per c4 step of 128, with 40 KiB of code instead of 57)
+                const bool tensor = LOGB == 12 ? TEN : AA.e.tensor != 0;
+                const bool addw = !tensor && (second ? AA.e.has_w1 : AA.e.has_w0) != 0;
                 double kd0[16], kd1[16];  // the key rows' registers: free in these transforms (no key rows on the way)
                 MAC_STAMP2(48 + c * 4 + 1);
                 // HE_MAC_EPI_PREFETCH (4096-rows): the operands the epilogue needs from memory -- a0, b0 (component 0) / a0, b1
@@ -2044,6 +2049,8 @@ hipError_t launch_ntt_mac_f64(const RingDev &r, const NttMacArgs &a, View dec, V
         if (epi && D.e.sc_ginv) {
             if (b == 12) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false, true, true>), dim3(G), dim3(256), 0, s, D);
             else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, false, true, true>), dim3(G), dim3(512), 0, s, D);
+        } else if (epi && D.e.tensor && b == 12) {
+            hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false, true, false, true>), dim3(G), dim3(256), 0, s, D);
         } else if (epi) {
             if (b == 12) hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<12, false, true>), dim3(G), dim3(256), 0, s, D);
             else hipLaunchKernelGGL((ntt_mac_f64_dma_kernel<13, false, true>), dim3(G), dim3(512), 0, s, D);
