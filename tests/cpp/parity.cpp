@@ -242,6 +242,33 @@ static void test_rlwe(const hering::Context &ctx, int logN) {
     eval.AutomorphismHoisted(level, cin, dec, galEl, evk, rot2);
     REQUIRE(rot2.Value[0].Download() == rot.Value[0].Download() && rot2.Value[1].Download() == rot.Value[1].Download());
 
+    // the giant step of lintrans.Evaluator.MultiplyByDiagMatrixBSGS (lintrans_evaluator.go:397-441) as one call against the reference's
+    // own sequence of calls through this header: GadgetProductLazy, ringQP.Add, AutomorphismNTTWithIndex, then ...ThenAddLazy
+    {
+        const uint64_t gs = 5;  // the generator: a rotation by one slot
+        const u64v addq = uniform(rng, q, N, B), addp = uniform(rng, p, N, B);
+        hering::PolyQP add{upload(ringQ, addq, B), upload(ringP, addp, B)};
+        std::array<hering::PolyQP, 2> fused{{{ringQ.NewPoly(B), ringP.NewPoly(B)}, {ringQ.NewPoly(B), ringP.NewPoly(B)}}};
+        std::array<hering::PolyQP, 2> sep{{{ringQ.NewPoly(B), ringP.NewPoly(B)}, {ringQ.NewPoly(B), ringP.NewPoly(B)}}};
+        const hering::AutomorphismIndex ixq = ringQ.AutomorphismNTTIndex(gs);
+        for (int round = 0; round < 2; round++) {  // overwrite, then accumulate onto the result
+            eval.LinTransGiantStep(level, pcx, evk, gs, add, round != 0, fused);
+            eval.GadgetProductLazy(level, pcx, evk, qp);
+            ringQ.Add(qp[0].Q, add.Q, qp[0].Q);
+            ringP.Add(qp[0].P, add.P, qp[0].P);
+            for (int k = 0; k < 2; k++) {
+                if (round == 0) {
+                    ringQ.AutomorphismNTTWithIndex(qp[k].Q, ixq, sep[k].Q);
+                    ringP.AutomorphismNTTWithIndex(qp[k].P, ixq, sep[k].P);
+                } else {
+                    ringQ.AutomorphismNTTWithIndexThenAddLazy(qp[k].Q, ixq, sep[k].Q);
+                    ringP.AutomorphismNTTWithIndexThenAddLazy(qp[k].P, ixq, sep[k].P);
+                }
+                REQUIRE(fused[k].Q.Download() == sep[k].Q.Download() && fused[k].P.Download() == sep[k].P.Download());
+            }
+        }
+    }
+
     // BGV MulRelin (tensorStandard + Relinearize) and the degree-2 product followed by Relinearize; then Rescale
     const uint64_t T = 65537;
     const u64v cts1 = uniform(rng, q, N, 2);  // one ciphertext: [2][limbs][N]
