@@ -1488,8 +1488,11 @@ int he_ctx_sync(he_handle h) {
     GET(c, Ctx, h, T_CTX);
     if (c->capturing) return fail(HE_EINVAL, "he_ctx_sync: the context is capturing a graph (he_graph_end first)");
     // deferred submission: everything filed before this call is launched first; a launch that failed after its call had returned
-    // is reported here
-    if (c->co->depth.load(std::memory_order_relaxed) > 0) TRY(co_flush_filed(*c));
+    // is reported here -- AFTER the stream has been drained (the caller that is told about a failure must not find the
+    // device still running the requests that preceded it)
+    int filed_rc = HE_OK;
+    std::string filed_msg;
+    if (c->co->depth.load(std::memory_order_relaxed) > 0 && (filed_rc = co_flush_filed(*c)) != HE_OK) filed_msg = he_last_error();
     // Many threads may wait on one context at once (the callers of a coalescing evaluator): ONE of them drains the stream, the
     // others sleep until a drain that STARTED after their call began has finished -- everything a caller enqueued before calling
     // is covered by such a drain -- instead of every thread spinning on the stream.
@@ -1523,6 +1526,7 @@ int he_ctx_sync(he_handle h) {
         c->sync_cv.notify_all();
         if (e != hipSuccess) return fail(HE_EDEVICE, "he_ctx_sync: %s", hipGetErrorString(e));
     }
+    if (filed_rc != HE_OK) return fail(filed_rc, "%s", filed_msg.c_str());
     return HE_OK;
 }
 int he_timer_start(he_handle h) {
